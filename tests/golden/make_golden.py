@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/* from the REAL reference (oracle/_ref, built from
+/root/reference by oracle/Makefile).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+What is written (all data, no reference source):
+
+  cx.ref.fa.gz / cx.qry.fa.gz   the "complex" synthetic pair (gsalign_amd.synth.make_complex(2024))
+  cx.{bwt,sa,pac,ann,amb}.gz    index files produced by the reference's bwt_index
+  cx.maf.gz / cx.vcf.gz         output of the unmodified reference CLI, -t 1, defaults
+  cx_sen.maf.gz / cx_sen.vcf.gz same with -sen
+  cx_stages.npz                 SeedVec / groups / AlnBlockVec after each of the 8 stages
+                                (driven through oracle/ref_glue.cpp), defaults
+  cx_sen_stages.npz             same with -sen, stages 1..8
+  ksw2_pairs.npz                2000+ (ref_frag, qry_frag) -> (aln1, aln2) from the reference's ksw2_alignment
+  gapsim.npz                    CalGapSimilarity known answers on the cx pair
+  small.*                       a 60 kb two-contig pair with its own index, MAF, VCF (quick CLI test)
+"""
+import gzip
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from gsalign_amd import synth                     # noqa: E402
+from oracle import oracle_py as op                # noqa: E402
+
+
+def gz(src, dst):
+    with open(src, "rb") as a, gzip.GzipFile(dst, "wb", mtime=0) as b:
+        shutil.copyfileobj(a, b)
+
+
+def main():
+    op.build(ref=True)
+    assert op.have_ref(), "oracle/_ref missing: needs /root/reference"
+    tmp = tempfile.mkdtemp(prefix="gsa_golden_")
+
+    # ---- cx ----
+    refs, qrys = synth.make_complex(2024)
+    synth.write_fasta(f"{tmp}/cx.ref.fa", refs); synth.write_fasta(f"{tmp}/cx.qry.fa", qrys)
+    op.ref_build_index(f"{tmp}/cx.ref.fa", f"{tmp}/cx")
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        gz(f"{tmp}/cx.{ext}", f"{HERE}/cx.{ext}.gz")
+    gz(f"{tmp}/cx.ref.fa", f"{HERE}/cx.ref.fa.gz"); gz(f"{tmp}/cx.qry.fa", f"{HERE}/cx.qry.fa.gz")
+    # the CLI is run with -i cx so that "##reference=cx" is stable
+    cwd = os.getcwd(); os.chdir(tmp)
+    op.ref_run_cli("cx", "cx.qry.fa", "cxout"); gz("cxout.maf", f"{HERE}/cx.maf.gz"); gz("cxout.vcf", f"{HERE}/cx.vcf.gz")
+    op.ref_run_cli("cx", "cx.qry.fa", "cxsen", ["-sen"]); gz("cxsen.maf", f"{HERE}/cx_sen.maf.gz"); gz("cxsen.vcf", f"{HERE}/cx_sen.vcf.gz")
+    os.chdir(cwd)
+    op.ref_dump_subprocess(f"{tmp}/cx", f"{tmp}/cx.qry.fa", f"{HERE}/cx_stages.npz", {})
+    op.ref_dump_subprocess(f"{tmp}/cx", f"{tmp}/cx.qry.fa", f"{HERE}/cx_sen_stages.npz", dict(sen=1, clr=50))
+
+    # ---- small pair ----
+    r2, q2 = synth.make_pair(60000, 2, 0.03, seed=5)
+    q2[1] = (q2[1][0], synth.revcomp(q2[1][1]))
+    synth.write_fasta(f"{tmp}/small.ref.fa", r2); synth.write_fasta(f"{tmp}/small.qry.fa", q2)
+    op.ref_build_index(f"{tmp}/small.ref.fa", f"{tmp}/small")
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        gz(f"{tmp}/small.{ext}", f"{HERE}/small.{ext}.gz")
+    gz(f"{tmp}/small.ref.fa", f"{HERE}/small.ref.fa.gz"); gz(f"{tmp}/small.qry.fa", f"{HERE}/small.qry.fa.gz")
+    os.chdir(tmp)
+    op.ref_run_cli("small", "small.qry.fa", "smallout"); gz("smallout.maf", f"{HERE}/small.maf.gz"); gz("smallout.vcf", f"{HERE}/small.vcf.gz")
+    os.chdir(cwd)
+
+    # ---- function-level known answers (one process: one index) ----
+    import subprocess
+    subprocess.run([sys.executable, os.path.abspath(__file__), "--func", tmp], check=True)
+    shutil.rmtree(tmp)
+    print("golden fixtures written to", HERE)
+
+
+def func_vectors(tmp):
+    rng = np.random.default_rng(99)
+    ref = op.RefLib(f"{tmp}/cx")
+    # ksw2 pairs: related pairs at several divergences, unrelated pairs, N's, lower case, length-1 sides, long ones
+    s1s, s2s, a1s, a2s = [], [], [], []
+
+    def add(a, b):
+        o1, o2 = ref.ksw2(a.tobytes(), b.tobytes())
+        s1s.append(a.tobytes()); s2s.append(b.tobytes()); a1s.append(o1); a2s.append(o2)
+
+    for i in range(2100):
+        ln = int(rng.integers(1, 260)) if i < 2000 else int(rng.integers(300, 1500))
+        a = synth.random_genome(ln, rng)
+        mode = i % 7
+        if mode == 0:
+            b = synth.random_genome(int(rng.integers(1, 260)), rng)
+        else:
+            b = synth.mutate(a, [0.02, 0.05, 0.1, 0.2, 0.3, 0.5][mode - 1], rng)
+            if b.size == 0:
+                b = synth.random_genome(1, rng)
+        if i % 11 == 0:
+            b[rng.integers(0, b.size, size=max(1, b.size // 20))] = ord("N")
+        if i % 13 == 0:
+            b = np.frombuffer(b.tobytes().lower(), dtype=np.uint8).copy()
+        if i % 17 == 0:
+            a = a.copy(); a[rng.integers(0, a.size)] = ord("N")
+        add(a, b)
+    for a, b in ((b"ACGTACGTTTGACCA", b"ACGTACGTGACCA"), (b"AAAAACCCCC", b"AAAAAGCCCCC"), (b"A", b"ACGT"), (b"ACGT", b"TTTT"),
+                 (b"A", b"A"), (b"A", b"C"), (b"ACGT", b"A"), (b"N", b"ACGTN")):
+        add(np.frombuffer(a, dtype=np.uint8), np.frombuffer(b, dtype=np.uint8))
+    big = synth.random_genome(3000, rng)
+    add(big, synth.mutate(big, 0.15, rng)); add(synth.random_genome(1, rng), big[:2500]); add(big[:2500], synth.random_genome(1, rng))
+
+    def pack(lst):
+        off = np.cumsum([0] + [len(x) for x in lst]).astype(np.int64)
+        return np.frombuffer(b"".join(lst), dtype=np.uint8), off
+    d = {}
+    for nm, lst in (("s1", s1s), ("s2", s2s), ("a1", a1s), ("a2", a2s)):
+        d[nm], d[nm + "_off"] = pack(lst)
+    np.savez_compressed(f"{HERE}/ksw2_pairs.npz", **d)
+
+    # gap similarity: windows from q7_gaps (contig 6) and q2_lower (contig 1) against the cx reference
+    qrys = synth.read_fasta(f"{tmp}/cx.qry.fa")
+    G = ref.lib.gsref_genome_size()
+    rows = []
+    for ci in (6, 1, 0):
+        seq = qrys[ci][1]
+        ref.set_query(seq, qrys[ci][0])
+        ref.run_to(3)
+        blk = ref.blocks()
+        off = 0
+        for nb in blk["b_nfrag"]:
+            qp = blk["f_qpos"][off:off + nb]; ql = blk["f_qlen"][off:off + nb]; rp = blk["f_rpos"][off:off + nb]; rl = blk["f_rlen"][off:off + nb]
+            for i in range(nb - 1):
+                q1, q2_, r1, r2_ = int(qp[i] + ql[i]), int(qp[i + 1]), int(rp[i] + rl[i]), int(rp[i + 1])
+                if q2_ - q1 > 100 or r2_ - r1 > 100:
+                    if q2_ >= q1 and r2_ >= r1 and q2_ - q1 <= 6000 and r2_ - r1 <= 6000:
+                        rows.append((ci, q1, q2_, r1, r2_, ref.gap_similarity(q1, q2_, r1, r2_)))
+            off += nb
+        # random windows, same diagonal and off diagonal
+        for _ in range(150):
+            ql_ = int(rng.integers(5, 3000)); q1 = int(rng.integers(0, seq.size - ql_))
+            r1 = int(rng.integers(0, 2 * G - 6000)); rl_ = ql_ if rng.random() < 0.5 else int(rng.integers(5, 3000))
+            rows.append((ci, q1, q1 + ql_, r1, r1 + rl_, ref.gap_similarity(q1, q1 + ql_, r1, r1 + rl_)))
+    np.savez_compressed(f"{HERE}/gapsim.npz", rows=np.asarray(rows, dtype=np.int64))
+    print("ksw2 pairs:", len(s1s), " gapsim rows:", len(rows), " true:", sum(r[5] for r in rows))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--func":
+        func_vectors(sys.argv[2])
+    else:
+        main()
