@@ -1,0 +1,251 @@
+"""ctypes binding of libgsa_hip.so (include/gsa_hip.h) for tests and bench.py.
+
+This is plumbing only: it fills `gsa_index_view` from numpy arrays and calls the
+C ABI.  There is no CPU path: if the library or a GPU is missing, loading /
+`Aligner()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libgsa_hip.so")
+
+EXPORTS = [
+    "gsa_default_params", "gsa_create", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig",
+    "gsa_set_query", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
+    "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling",
+]
+
+
+class IndexView(C.Structure):
+    _fields_ = [("primary", C.c_uint64), ("L2", C.c_uint64 * 5), ("bwt", C.POINTER(C.c_uint32)), ("bwt_words", C.c_uint64),
+                ("sa", C.POINTER(C.c_uint64)), ("n_sa", C.c_uint64), ("ref", C.c_char_p), ("G", C.c_int64),
+                ("chr_len", C.POINTER(C.c_int32)), ("n_chr", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("min_seed_len", C.c_int32), ("max_indel", C.c_int32), ("min_block_score", C.c_int32), ("min_aln_len", C.c_int32),
+                ("min_identity", C.c_int32), ("sensitive", C.c_int32), ("one_on_one", C.c_int32)]
+
+
+class Seed(C.Structure):
+    _fields_ = [("qpos", C.c_int32), ("len", C.c_int32), ("rpos", C.c_int64)]
+
+
+class Frag(C.Structure):
+    _fields_ = [("bseed", C.c_int32), ("qpos", C.c_int32), ("qlen", C.c_int32), ("rlen", C.c_int32), ("rpos", C.c_int64),
+                ("aln_off", C.c_int64), ("aln_len", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Block(C.Structure):
+    _fields_ = [("score", C.c_int32), ("aln_len", C.c_int32), ("bdup", C.c_int32), ("n_frag", C.c_int32), ("frag_off", C.c_int64),
+                ("bdir", C.c_int32), ("gpos", C.c_int32), ("chr", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("n_frags", C.c_int64), ("n_aln", C.c_int64), ("blocks", C.POINTER(Block)),
+                ("frags", C.POINTER(Frag)), ("aln1", C.POINTER(C.c_char)), ("aln2", C.POINTER(C.c_char))]
+
+
+FRAG_DT = np.dtype([("bseed", "<i4"), ("qpos", "<i4"), ("qlen", "<i4"), ("rlen", "<i4"), ("rpos", "<i8"), ("aln_off", "<i8"), ("aln_len", "<i4"), ("_pad", "<i4")])
+BLOCK_DT = np.dtype([("score", "<i4"), ("aln_len", "<i4"), ("bdup", "<i4"), ("n_frag", "<i4"), ("frag_off", "<i8"), ("bdir", "<i4"), ("gpos", "<i4"), ("chr", "<i4"), ("_pad", "<i4")])
+SEED_DT = np.dtype([("qpos", "<i4"), ("len", "<i4"), ("rpos", "<i8")])
+
+
+def build_library() -> None:
+    """hipcc cross-compiles for gfx950 without a GPU (seconds per file once warm)."""
+    subprocess.run(["make", "-C", os.path.join(HERE, "csrc"), "-j8", "lib"], check=True, stdout=subprocess.DEVNULL)
+
+
+def load_library() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    lib.gsa_create.argtypes = [C.c_int, C.POINTER(IndexView), C.POINTER(Params), C.POINTER(C.c_void_p)]
+    lib.gsa_last_error.restype = C.c_char_p
+    lib.gsa_last_error.argtypes = [C.c_void_p]
+    lib.gsa_seed_count.restype = C.c_int64
+    for name in ("gsa_destroy", "gsa_set_params", "gsa_align_contig", "gsa_set_query", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds",
+                 "gsa_group_count", "gsa_get_groups", "gsa_get_blocks", "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch",
+                 "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling"):
+        fn = getattr(lib, name)
+        if fn.argtypes is None:
+            fn.argtypes = None
+    return lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class GsaError(RuntimeError):
+    pass
+
+
+class Aligner:
+    """One gsa_ctx on one GPU."""
+
+    def __init__(self, idx, device: int = 0, **params):
+        self.lib = load_library()
+        self.idx = idx
+        self._ref = np.ascontiguousarray(idx.ref)
+        v = IndexView()
+        v.primary = int(idx.hdr[0])
+        v.L2[0] = 0
+        for i in range(1, 5):
+            v.L2[i] = int(idx.hdr[i])
+        v.bwt = _p(idx.bwt, C.c_uint32); v.bwt_words = idx.bwt.size
+        v.sa = _p(idx.sa, C.c_uint64); v.n_sa = idx.sa.size
+        v.ref = self._ref.ctypes.data_as(C.c_char_p); v.G = idx.G
+        v.chr_len = _p(idx.chr_len, C.c_int32); v.n_chr = len(idx.chr_len)
+        self.ctx = C.c_void_p()
+        p = self._params(**params)
+        rc = self.lib.gsa_create(device, C.byref(v), C.byref(p), C.byref(self.ctx))
+        if rc != 0:
+            raise GsaError(f"gsa_create -> {rc}: {self.lib.gsa_last_error(None).decode()}")
+
+    def _params(self, slen=15, ind=25, clr=200, alen=200, idy=70, sen=0, one=0) -> Params:
+        return Params(slen, ind, clr, alen, idy, sen, one)
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise GsaError(f"libgsa_hip error {rc}: {self.lib.gsa_last_error(self.ctx).decode()}")
+
+    def set_params(self, **params):
+        p = self._params(**params)
+        self._ck(self.lib.gsa_set_params(self.ctx, C.byref(p)))
+
+    def set_profiling(self, on: bool):
+        self._ck(self.lib.gsa_set_profiling(self.ctx, 1 if on else 0))
+
+    def set_query(self, seq: np.ndarray):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        self._q = seq
+        self._ck(self.lib.gsa_set_query(self.ctx, seq.ctypes.data_as(C.c_char_p), C.c_int32(seq.size)))
+
+    def run_to(self, stage: int):
+        self._ck(self.lib.gsa_run_to(self.ctx, stage))
+
+    def align_contig(self, seq: np.ndarray) -> dict:
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        self._q = seq
+        res = Result()
+        self._ck(self.lib.gsa_align_contig(self.ctx, seq.ctypes.data_as(C.c_char_p), C.c_int32(seq.size), C.byref(res)))
+        return self._result(res)
+
+    def seeds(self):
+        n = self.lib.gsa_seed_count(self.ctx)
+        out = np.zeros(n, dtype=SEED_DT)
+        if n:
+            self._ck(self.lib.gsa_get_seeds(self.ctx, out.ctypes.data_as(C.c_void_p)))
+        return out["qpos"].copy(), out["len"].copy(), out["rpos"].copy()
+
+    def groups(self):
+        n = self.lib.gsa_group_count(self.ctx)
+        b = np.zeros(n, np.int32); e = np.zeros(n, np.int32)
+        if n:
+            self._ck(self.lib.gsa_get_groups(self.ctx, _p(b, C.c_int32), _p(e, C.c_int32)))
+        return b, e
+
+    def _result(self, res: Result) -> dict:
+        nb, nf, na = res.n_blocks, res.n_frags, res.n_aln
+        blocks = np.ctypeslib.as_array(C.cast(res.blocks, C.POINTER(C.c_uint8)), shape=(nb * BLOCK_DT.itemsize,)).view(BLOCK_DT).copy() if nb else np.zeros(0, BLOCK_DT)
+        frags = np.ctypeslib.as_array(C.cast(res.frags, C.POINTER(C.c_uint8)), shape=(nf * FRAG_DT.itemsize,)).view(FRAG_DT).copy() if nf else np.zeros(0, FRAG_DT)
+        a1 = np.ctypeslib.as_array(C.cast(res.aln1, C.POINTER(C.c_uint8)), shape=(na,)).copy() if na else np.zeros(0, np.uint8)
+        a2 = np.ctypeslib.as_array(C.cast(res.aln2, C.POINTER(C.c_uint8)), shape=(na,)).copy() if na else np.zeros(0, np.uint8)
+        return dict(blocks=blocks, frags=frags, aln1=a1, aln2=a2)
+
+    def blocks(self) -> dict:
+        res = Result()
+        self._ck(self.lib.gsa_get_blocks(self.ctx, C.byref(res)))
+        return self._result(res)
+
+    def blocks_as_dump(self, with_aln: bool = False) -> dict:
+        """Same keys/shapes as oracle_py._StageReader.blocks(): records gathered in block order."""
+        r = self.blocks()
+        B, F = r["blocks"], r["frags"]
+        idx = np.concatenate([np.arange(o, o + n) for o, n in zip(B["frag_off"], B["n_frag"])]) if B.size else np.zeros(0, np.int64)
+        Fo = F[idx] if idx.size else np.zeros(0, FRAG_DT)
+        out = {"b_score": B["score"].copy(), "b_aln_len": B["aln_len"].copy(), "b_bdup": B["bdup"].copy(), "b_nfrag": B["n_frag"].copy(),
+               "b_bdir": B["bdir"].copy(), "b_gpos": B["gpos"].copy(), "b_chr": B["chr"].copy(),
+               "f_bseed": Fo["bseed"].copy(), "f_qpos": Fo["qpos"].copy(), "f_qlen": Fo["qlen"].copy(), "f_rlen": Fo["rlen"].copy(),
+               "f_alnlen": Fo["aln_len"].copy(), "f_rpos": Fo["rpos"].copy()}
+        if with_aln:
+            segs1 = [r["aln1"][o:o + n] for o, n in zip(Fo["aln_off"], Fo["aln_len"]) if n]
+            segs2 = [r["aln2"][o:o + n] for o, n in zip(Fo["aln_off"], Fo["aln_len"]) if n]
+            out["aln1"] = np.concatenate(segs1) if segs1 else np.zeros(0, np.uint8)
+            out["aln2"] = np.concatenate(segs2) if segs2 else np.zeros(0, np.uint8)
+        return out
+
+    def dump_stages(self, upto: int = 8) -> dict:
+        d = {}
+        for st in range(1, upto + 1):
+            self.run_to(st)
+            if st == 1:
+                q, l, r = self.seeds(); b, e = self.groups()
+                d.update(s1_qpos=q, s1_qlen=l, s1_rpos=r, s1_gbeg=b, s1_gend=e)
+            else:
+                for k, v in self.blocks_as_dump(with_aln=(st == 8)).items():
+                    d[f"s{st}_{k}"] = v
+        return d
+
+    def counters(self) -> np.ndarray:
+        c = np.zeros(8, np.uint64)
+        self._ck(self.lib.gsa_get_counters(self.ctx, _p(c, C.c_uint64)))
+        return c
+
+    def timings(self) -> np.ndarray:
+        t = np.zeros(8, np.float32)
+        self._ck(self.lib.gsa_get_timings(self.ctx, _p(t, C.c_float)))
+        return t
+
+    # ---- leaf operators ----
+    def bwt_search_batch(self, start, stop):
+        start = np.ascontiguousarray(start, np.int32); stop = np.ascontiguousarray(stop, np.int32)
+        n = start.size
+        ln = np.zeros(n, np.int32); fr = np.zeros(n, np.int32); loc = np.zeros(n * 100, np.int64)
+        self._ck(self.lib.gsa_bwt_search_batch(self.ctx, C.c_int32(n), _p(start, C.c_int32), _p(stop, C.c_int32), _p(ln, C.c_int32), _p(fr, C.c_int32), _p(loc, C.c_int64)))
+        return ln, fr, loc.reshape(n, 100)
+
+    def ksw2_batch(self, s1_list, s2_list):
+        """list of bytes pairs -> list of forward op strings (bytes)."""
+        n = len(s1_list)
+        l1 = np.array([len(x) for x in s1_list], np.int32); l2 = np.array([len(x) for x in s2_list], np.int32)
+        o1 = np.concatenate([[0], np.cumsum(l1[:-1], dtype=np.int64)]).astype(np.int64) if n else np.zeros(0, np.int64)
+        o2 = np.concatenate([[0], np.cumsum(l2[:-1], dtype=np.int64)]).astype(np.int64) if n else np.zeros(0, np.int64)
+        mn = (l1 + l2).astype(np.int64)
+        oo = np.concatenate([[0], np.cumsum(mn[:-1])]).astype(np.int64) if n else np.zeros(0, np.int64)
+        p1 = b"".join(s1_list) + b"\0"; p2 = b"".join(s2_list) + b"\0"
+        ops = np.zeros(int(mn.sum()) + 1, np.uint8); ol = np.zeros(n, np.int32)
+        self._ck(self.lib.gsa_ksw2_batch(self.ctx, C.c_int32(n), p1, _p(o1, C.c_int64), _p(l1, C.c_int32), p2, _p(o2, C.c_int64), _p(l2, C.c_int32),
+                                         ops.ctypes.data_as(C.c_char_p), _p(oo, C.c_int64), _p(ol, C.c_int32)))
+        return [ops[oo[i]:oo[i] + ol[i]].tobytes() for i in range(n)]
+
+    def gap_similarity_batch(self, q1, q2, r1, r2):
+        q1 = np.ascontiguousarray(q1, np.int32); q2 = np.ascontiguousarray(q2, np.int32)
+        r1 = np.ascontiguousarray(r1, np.int64); r2 = np.ascontiguousarray(r2, np.int64)
+        res = np.zeros(q1.size, np.int32)
+        self._ck(self.lib.gsa_gap_similarity_batch(self.ctx, C.c_int32(q1.size), _p(q1, C.c_int32), _p(q2, C.c_int32), _p(r1, C.c_int64), _p(r2, C.c_int64), _p(res, C.c_int32)))
+        return res
+
+    def close(self):
+        if self.ctx:
+            self.lib.gsa_destroy(self.ctx); self.ctx = C.c_void_p()
+
+
+def apply_ops(s1: bytes, s2: bytes, ops: bytes):
+    """Forward M/D/I string -> the two gapped strings (what ksw2_alignment leaves in s1/s2)."""
+    a, b, i, j = bytearray(), bytearray(), 0, 0
+    for o in ops:
+        if o == 0x44:      # 'D': gap in s1
+            a.append(0x2D); b.append(s2[j]); j += 1
+        elif o == 0x49:    # 'I': gap in s2
+            a.append(s1[i]); b.append(0x2D); i += 1
+        else:
+            a.append(s1[i]); b.append(s2[j]); i += 1; j += 1
+    return bytes(a), bytes(b)

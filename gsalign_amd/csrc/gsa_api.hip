@@ -1,0 +1,202 @@
+// gsalign_amd/csrc/gsa_api.hip -- C-ABI entry points of libgsa_hip.so (include/gsa_hip.h):
+// context life cycle, query upload, the eight-stage driver and the getters.
+// Host-side block-list bookkeeping (what the reference does on AlnBlockVec with
+// std::sort) lives in gsa_blocks.cpp.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include "gsa_ctx.h"
+
+static std::string g_create_error;
+
+int gsa_fail(gsa_ctx *ctx, int code, const std::string &msg)
+{
+	if (ctx) ctx->err = msg; else g_create_error = msg;
+	return code;
+}
+
+int host_stage4_5_6(gsa_ctx *c, int stage);    // gsa_blocks.cpp
+int host_stage8_finish(gsa_ctx *c);            // gsa_blocks.cpp
+int build_block_view(gsa_ctx *c);              // gsa_blocks.cpp
+
+extern "C" {
+
+void gsa_default_params(gsa_params *p)
+{
+	// main.cpp:202-214
+	p->min_seed_len = 15; p->max_indel = 25; p->min_block_score = 200; p->min_aln_len = 200; p->min_identity = 70;
+	p->sensitive = 0; p->one_on_one = 0;
+}
+
+const char *gsa_last_error(gsa_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int gsa_set_params(gsa_ctx *c, const gsa_params *p)
+{
+	if (!c || !p) return GSA_ERR_ARG;
+	if (p->min_seed_len < 1 || p->max_indel < 0) return gsa_fail(c, GSA_ERR_ARG, "bad parameter");
+	c->prm.MinSeedLength = p->sensitive ? 10 : p->min_seed_len;         // main.cpp:323
+	c->prm.MaxIndelSize = p->max_indel; c->prm.MinAlnBlockScore = p->min_block_score; c->prm.MinAlnLength = p->min_aln_len;
+	c->prm.MinSeqIdy = p->min_identity; c->prm.bSensitive = p->sensitive ? 1 : 0; c->prm.OneOnOne = p->one_on_one ? 1 : 0;
+	c->stage = 0;
+	return GSA_OK;
+}
+
+int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa_ctx **out)
+{
+	if (!idx || !out || !idx->bwt || !idx->sa || !idx->ref || !idx->chr_len || idx->n_chr <= 0 || idx->G <= 0) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create: bad index view");
+	if (idx->L2[4] != (uint64_t)(2 * idx->G)) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create: L2[4] != 2G");
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gsa_fail(nullptr, GSA_ERR_HIP, "no HIP device available (libgsa_hip.so has no CPU path)");
+	if (device < 0 || device >= ndev) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create: bad device ordinal");
+	gsa_ctx *c = new gsa_ctx();
+	c->device = device;
+	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
+#define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gsa_fail(nullptr, GSA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); gsa_destroy(c); return GSA_ERR_HIP; } } while (0)
+	CK(hipSetDevice(device));
+	CK(hipStreamCreate(&c->stream));
+	for (int i = 0; i < 16; i++) CK(hipEventCreate(&c->ev[i]));
+	const size_t bwt_bytes = ((idx->bwt_words + 15) / 16) * 64;          // whole 64-byte blocks
+	CK(hipMalloc(&c->d_bwt.p, bwt_bytes + 64)); c->d_bwt.cap = bwt_bytes + 64;
+	CK(hipMemset(c->d_bwt.p, 0, bwt_bytes + 64));
+	CK(hipMemcpy(c->d_bwt.p, idx->bwt, idx->bwt_words * 4, hipMemcpyHostToDevice));
+	CK(hipMalloc(&c->d_sa.p, idx->n_sa * 8)); c->d_sa.cap = idx->n_sa * 8;
+	CK(hipMemcpy(c->d_sa.p, idx->sa, idx->n_sa * 8, hipMemcpyHostToDevice));
+	CK(hipMalloc(&c->d_ref.p, (size_t)2 * idx->G + 64)); c->d_ref.cap = (size_t)2 * idx->G + 64;
+	CK(hipMemcpy(c->d_ref.p, idx->ref, (size_t)2 * idx->G, hipMemcpyHostToDevice));
+	// ChrLocMap (bwt_index.cpp:240-253) as a sorted table of last coordinates
+	c->G = idx->G;
+	{
+		i64 tot = 0; std::vector<std::pair<i64, i32> > ends;
+		for (int i = 0; i < idx->n_chr; i++) {
+			c->h_chr_len.push_back(idx->chr_len[i]); c->h_chr_fwd.push_back(tot); tot += idx->chr_len[i];
+			ends.push_back(std::make_pair(c->h_chr_fwd[i] + idx->chr_len[i] - 1, i));
+			ends.push_back(std::make_pair(2 * idx->G - tot + idx->chr_len[i] - 1, i));
+		}
+		if (tot != idx->G) { gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create: sum(chr_len) != G"); gsa_destroy(c); return GSA_ERR_ARG; }
+		std::sort(ends.begin(), ends.end());
+		for (size_t i = 0; i < ends.size(); i++) { c->h_chr_end.push_back(ends[i].first); c->h_chr_of_end.push_back(ends[i].second); }
+	}
+	CK(hipMalloc(&c->d_chr_end.p, c->h_chr_end.size() * 8)); CK(hipMemcpy(c->d_chr_end.p, c->h_chr_end.data(), c->h_chr_end.size() * 8, hipMemcpyHostToDevice));
+	CK(hipMalloc(&c->d_chr_of_end.p, c->h_chr_of_end.size() * 4)); CK(hipMemcpy(c->d_chr_of_end.p, c->h_chr_of_end.data(), c->h_chr_of_end.size() * 4, hipMemcpyHostToDevice));
+	CK(hipMalloc(&c->d_cnt.p, 16 * sizeof(u64))); c->d_cnt.cap = 16 * sizeof(u64);
+	CK(hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(u64)));
+#undef CK
+	c->di.primary = idx->primary; for (int i = 0; i < 5; i++) c->di.L2[i] = idx->L2[i]; c->di.L2[0] = 0;
+	c->di.seq_len = idx->L2[4];
+	c->di.bwt = c->d_bwt.as<uint4>(); c->di.sa = c->d_sa.as<u64>(); c->di.ref = c->d_ref.as<uint8_t>(); c->di.G = idx->G;
+	c->di.chr_end = c->d_chr_end.as<i64>(); c->di.chr_of_end = c->d_chr_of_end.as<i32>(); c->di.n_ends = (i32)c->h_chr_end.size();
+	gsa_params dp; gsa_default_params(&dp);
+	int rc = gsa_set_params(c, prm ? prm : &dp);
+	if (rc) { g_create_error = c->err; gsa_destroy(c); return rc; }
+	*out = c;
+	return GSA_OK;
+}
+
+void gsa_destroy(gsa_ctx *c)
+{
+	if (!c) return;
+	hipSetDevice(c->device);
+	if (c->stream) hipStreamSynchronize(c->stream);
+	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->d_query, &c->tmp, &c->d_cnt,
+		&c->d_hit_row, &c->d_hit_qpos, &c->d_hit_len, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
+		&c->d_flag, &c->d_scan, &c->g_beg, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
+		&c->a_next, &c->a_brk, &c->a_aurank, &c->a_aulist, &c->a_runinfo, &c->w_best, &c->w_sum, &c->w_n, &c->d_flag2, &c->d_scan2, &c->d_i64a,
+		&c->b_q, &c->b_len, &c->b_r, &c->b_gb, &c->b_ge, &c->c_q, &c->c_len, &c->c_r, &c->c_gb, &c->c_ge, &c->c_bid, &c->blk_beg, &c->blk_end, &c->blk_score,
+		&c->r_q, &c->r_len, &c->r_r, &c->r_bid, &c->r_tmp_q, &c->r_tmp_len, &c->r_tmp_r, &c->r_tmp_bid, &c->r_cut4, &c->r_cut5, &c->r_simjob, &c->r_simres, &c->d_leaf,
+		&c->fb_seedbase, &c->fb_sbeg, &c->fb_fragbase, &c->f_rec, &c->f_type, &c->f_mism, &c->f_alnlen, &c->f_job, &c->f_score,
+		&c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_aln1, &c->d_aln2, &c->d_alnoff, &c->bl_alnlen, &c->bl_score };
+	for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
+	if (c->h_cnt) hipHostFree(c->h_cnt);
+	for (int i = 0; i < 16; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+	if (c->stream) hipStreamDestroy(c->stream);
+	delete c;
+}
+
+int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->profiling = enable != 0; return GSA_OK; }
+
+int gsa_set_query(gsa_ctx *c, const char *query, int32_t qlen)
+{
+	if (!c || !query || qlen < 0) return GSA_ERR_ARG;
+	GSA_CHECK(c, hipSetDevice(c->device));
+	if (!dev_ensure<uint8_t>(c, c->d_query, (size_t)qlen + 64)) return GSA_ERR_NOMEM;
+	GSA_CHECK(c, hipMemcpyAsync(c->d_query.p, query, (size_t)qlen, hipMemcpyHostToDevice, c->stream));
+	c->h_query.assign(query, (size_t)qlen);
+	c->qlen = qlen; c->stage = 0;
+	c->qbits = ceil_log2_u64((u64)qlen + 1); if (c->qbits < 1) c->qbits = 1;
+	c->pdbits = ceil_log2_u64((u64)(2 * c->G) + (u64)qlen + 2);
+	if (c->qbits + c->pdbits > 64) return gsa_fail(c, GSA_ERR_LIMIT, "contig too long for the 64-bit seed key");
+	c->n_seeds = 0; c->n_groups = 0; c->n_blocks2 = 0; c->blocks.clear(); c->frags_stage = 0; c->have_host_seeds = false;
+	memset(c->counters, 0, sizeof(c->counters)); memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
+	return GSA_OK;
+}
+
+int gsa_run_to(gsa_ctx *c, int stage)
+{
+	if (!c || stage < 0 || stage > 8) return GSA_ERR_ARG;
+	GSA_CHECK(c, hipSetDevice(c->device));
+	int rc = GSA_OK;
+	while (c->stage < stage && rc == GSA_OK) {
+		const int next = c->stage + 1;
+		switch (next) {
+		case 1: rc = stage1_seed(c); break;
+		case 2: rc = stage2_chain(c); break;
+		case 3: rc = stage345_refine(c); break;                       // device part of S3..S5, host list = S3 state
+		case 4: case 5: case 6: rc = host_stage4_5_6(c, next); break;
+		case 7: rc = stage7_fill(c); break;
+		case 8: rc = stage78_extend(c); if (rc == GSA_OK) rc = host_stage8_finish(c); break;
+		}
+		if (rc == GSA_OK) { c->stage = next; c->frags_stage = (next == 8) ? 8 : 0; }
+	}
+	return rc;
+}
+
+int gsa_align_contig(gsa_ctx *c, const char *query, int32_t qlen, gsa_result *out)
+{
+	if (!c || !out) return GSA_ERR_ARG;
+	int rc = gsa_set_query(c, query, qlen); if (rc) return rc;
+	rc = gsa_run_to(c, 8); if (rc) return rc;
+	return gsa_get_blocks(c, out);
+}
+
+int64_t gsa_seed_count(gsa_ctx *c) { return c ? c->n_seeds : 0; }
+
+int gsa_get_seeds(gsa_ctx *c, gsa_seed *out)
+{
+	if (!c || (!out && c->n_seeds)) return GSA_ERR_ARG;
+	if (c->stage < 1) return gsa_fail(c, GSA_ERR_STATE, "run stage 1 first");
+	const size_t n = (size_t)c->n_seeds; if (!n) return GSA_OK;
+	std::vector<i32> q(n), l(n); std::vector<i64> r(n);
+	GSA_CHECK(c, hipMemcpy(q.data(), c->s_q.p, n * 4, hipMemcpyDeviceToHost));
+	GSA_CHECK(c, hipMemcpy(l.data(), c->s_len.p, n * 4, hipMemcpyDeviceToHost));
+	GSA_CHECK(c, hipMemcpy(r.data(), c->s_r.p, n * 8, hipMemcpyDeviceToHost));
+	for (size_t i = 0; i < n; i++) { out[i].qpos = q[i]; out[i].len = l[i]; out[i].rpos = r[i]; }
+	return GSA_OK;
+}
+
+int gsa_group_count(gsa_ctx *c) { return c ? c->n_groups : 0; }
+
+int gsa_get_groups(gsa_ctx *c, int32_t *beg, int32_t *end)
+{
+	if (!c) return GSA_ERR_ARG;
+	if (c->stage < 1) return gsa_fail(c, GSA_ERR_STATE, "run stage 1 first");
+	const size_t ng = (size_t)c->n_groups; if (!ng) return GSA_OK;
+	std::vector<i32> gb(ng + 1);
+	GSA_CHECK(c, hipMemcpy(gb.data(), c->g_beg.p, (ng + 1) * 4, hipMemcpyDeviceToHost));
+	for (size_t i = 0; i < ng; i++) { beg[i] = gb[i]; end[i] = gb[i + 1]; }
+	return GSA_OK;
+}
+
+int gsa_get_blocks(gsa_ctx *c, gsa_result *out)
+{
+	if (!c || !out) return GSA_ERR_ARG;
+	if (c->stage < 2) return gsa_fail(c, GSA_ERR_STATE, "run stage 2 first");
+	if (c->frags_stage != c->stage) { int rc = build_block_view(c); if (rc) return rc; }
+	out->n_blocks = (int32_t)c->h_blocks.size(); out->n_frags = (int64_t)c->h_frags.size(); out->n_aln = (int64_t)c->h_aln1.size();
+	out->blocks = c->h_blocks.data(); out->frags = c->h_frags.data(); out->aln1 = c->h_aln1.data(); out->aln2 = c->h_aln2.data();
+	return GSA_OK;
+}
+
+int gsa_get_counters(gsa_ctx *c, uint64_t counters[8]) { if (!c) return GSA_ERR_ARG; memcpy(counters, c->counters, sizeof(c->counters)); return GSA_OK; }
+int gsa_get_timings(gsa_ctx *c, float ms[8]) { if (!c) return GSA_ERR_ARG; memcpy(ms, c->kernel_ms, sizeof(c->kernel_ms)); return GSA_OK; }
+
+} // extern "C"

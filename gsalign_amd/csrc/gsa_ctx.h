@@ -1,0 +1,118 @@
+// gsalign_amd/csrc/gsa_ctx.h -- the context behind the opaque gsa_ctx handle.
+#ifndef GSA_CTX_H
+#define GSA_CTX_H
+#include "gsa_internal.h"
+
+// A leaf = a maximal run of seeds of one S2 block that neither S4 (large gaps)
+// nor S5 (reference chromosome ends) cuts.  Host-side block bookkeeping works on
+// ranges of leaves.
+struct Leaf {
+	i32 beg, end;        // seed range in the refined seed arrays
+	i32 sumlen;          // sum of (trimmed) seed lengths
+	i32 q_first, q_last_end;
+	i64 r_first, r_last_end;
+	i32 blk;             // S2 block this leaf belongs to
+	i32 cut4, cut5;      // how this leaf starts: S4 cut / S5 cut (0/0 = block start)
+};
+
+struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf range
+	i32 leaf_beg, leaf_end;
+	i32 score;
+	i32 bdup;
+	// filled at stage 8
+	i32 aln_len, bdir, gpos, chr;
+};
+
+struct gsa_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	std::string err;
+	Params prm;
+	DevIndex di;
+	bool profiling = false;
+	hipEvent_t ev[16];
+	float kernel_ms[8];
+	u64 counters[8];
+
+	// index (device)
+	DevBuf d_bwt, d_sa, d_ref, d_chr_end, d_chr_of_end;
+	std::vector<i64> h_chr_end, h_chr_fwd; std::vector<i32> h_chr_of_end, h_chr_len;
+	i64 G = 0;
+
+	// query
+	DevBuf d_query; i32 qlen = 0; int stage = 0;
+	std::string h_query;
+	int qbits = 1, pdbits = 1;
+
+	// scratch for rocPRIM
+	DevBuf tmp;
+	// device counters block (u64[16]) + pinned host mirror
+	DevBuf d_cnt; u64 *h_cnt = nullptr;
+
+	// ---- stage 1 ----
+	DevBuf d_hit_row, d_hit_qpos, d_hit_len;       // pending hits from the search kernel
+	DevBuf d_key_a, d_key_b, d_val_a, d_val_b;     // sort ping-pong
+	i64 n_seeds = 0;
+	DevBuf s_q, s_len, s_r, s_gid;                 // seeds in (PosDiff,qPos) order + group id
+	DevBuf d_flag, d_scan;                         // generic i32 flag / scan arrays (n+1)
+	i32 n_groups = 0;
+	DevBuf g_beg;                                  // group start indices (n_groups+1)
+
+	// ---- stage 2 ---- (arrays over seeds of active groups, (group,qPos,rPos) order)
+	i64 n_a = 0;
+	DevBuf a_q, a_len, a_r, a_gb, a_ge;            // + group begin/end index per seed
+	DevBuf a_uniq, a_cu, a_alive, a_ws, a_wid;
+	DevBuf a_next, a_brk, a_aurank, a_aulist, a_runinfo;
+	DevBuf w_best, w_sum, w_n;
+	DevBuf d_flag2, d_scan2, d_i64a;
+	i64 n_b = 0, n_c = 0;
+	DevBuf b_q, b_len, b_r, b_gb, b_ge;            // after compaction #1
+	DevBuf c_q, c_len, c_r, c_gb, c_ge;            // after compaction #2
+	DevBuf c_bid;                                  // S2 block id per seed (-1 = none)
+	i32 n_blocks2 = 0;
+	DevBuf blk_beg, blk_end, blk_score;            // S2 blocks kept by AddAlnBlock
+	std::vector<i32> h_blk_beg, h_blk_end, h_blk_score;
+
+	// ---- stages 3-5 ---- refined seed arrays (after RemoveOverlaps)
+	i64 n_r = 0;
+	DevBuf r_q, r_len, r_r, r_bid, r_tmp_q, r_tmp_len, r_tmp_r, r_tmp_bid;
+	DevBuf r_cut4, r_cut5, r_simjob, r_simres;
+	DevBuf d_leaf; std::vector<Leaf> h_leaf;
+	std::vector<HostBlock> blocks;                 // current AlnBlockVec
+	std::vector<i32> h_r_q, h_r_len; std::vector<i64> h_r_r;    // host copies of refined seeds (for getters / emit)
+	bool have_host_seeds = false;
+
+	// ---- stages 7-8 ----
+	i64 n_frags = 0, n_aln = 0;
+	DevBuf fb_seedbase, fb_sbeg, fb_fragbase;      // per final block
+	DevBuf f_rec;                                  // gsa_frag records
+	DevBuf f_type, f_mism, f_alnlen, f_job, f_score;
+	DevBuf j_frag, j_opsoff, j_nops, d_ops, j_cells;
+	DevBuf d_aln1, d_aln2, d_alnoff;
+	DevBuf bl_alnlen, bl_score;
+	std::vector<gsa_frag> h_frags; std::vector<gsa_block> h_blocks; std::vector<char> h_aln1, h_aln2;
+	int frags_stage = 0;                           // stage for which h_frags/h_blocks were built
+};
+
+template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n)
+{
+	size_t bytes = (n ? n : 1) * sizeof(T);
+	if (bytes <= b.cap) return (T *)b.p;
+	if (b.p) { hipStreamSynchronize(c->stream); hipFree(b.p); b.p = nullptr; b.cap = 0; }
+	size_t want = bytes + bytes / 4 + 256;
+	if (hipMalloc(&b.p, want) != hipSuccess) { gsa_fail(c, GSA_ERR_NOMEM, "hipMalloc"); return nullptr; }
+	b.cap = want;
+	return (T *)b.p;
+}
+
+// stage drivers (one per translation unit)
+int stage1_seed(gsa_ctx *c);          // k_seed.hip
+int stage2_chain(gsa_ctx *c);         // k_chain.hip
+int stage345_refine(gsa_ctx *c);      // k_refine.hip  (device part of S3, S4, S5 + leaf table)
+int stage7_fill(gsa_ctx *c);          // k_extend.hip  (S6: gap records of the final block list)
+int stage78_extend(gsa_ctx *c);       // k_extend.hip  (S7: classification, DP, gapped strings, block sums)
+int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res);   // k_gapsim.hip
+int run_ksw2_jobs(gsa_ctx *c, i32 n, const uint8_t *pool1, const i64 *off1, const i32 *len1,
+                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len);   // k_extend.hip
+
+#endif

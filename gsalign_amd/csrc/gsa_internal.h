@@ -1,0 +1,63 @@
+// gsalign_amd/csrc/gsa_internal.h -- shared between the translation units of
+// libgsa_hip.so.  Device-side index view, the context, small helpers.
+#ifndef GSA_INTERNAL_H
+#define GSA_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/gsa_hip.h"
+
+typedef uint64_t u64;
+typedef int64_t i64;
+typedef uint32_t u32;
+typedef int32_t i32;
+
+// hard constants of the reference
+#define GSA_CHUNK 10000          // SeedExplorationChunk, GSAlign.cpp:5
+#define GSA_MAX_SEED_FREQ 100    // MaxSeedFreq, bwt_search.cpp:3
+#define GSA_MAX_SEED_GAP 5000    // MaxSeedGap, structure.h:23
+#define GSA_GAP_CHECK 300        // ProcessCandidateAlignment.cpp:131
+#define GSA_MAX_MISMATCH 5       // ProcessCandidateAlignment.cpp:327
+#define GSA_WIN_SEEDS 30         // GSAlign.cpp:331
+#define GSA_WIN_SPAN 3000        // GSAlign.cpp:331
+
+// ---- device view of the FM-index (a1) --------------------------------------
+// bwt: 64-byte blocks; block b covers BWT rows 128b..128b+127.  Words 0-7 = four
+// u64 running counts (A,C,G,T before the block); words 8-15 = 128 symbols, 2 bit
+// each, MSB first inside each u32.
+struct DevIndex {
+	u64 primary, L2[5], seq_len;
+	const uint4 *bwt;       // 4 x uint4 per block
+	const u64 *sa;          // sa[i] = SA of row 32 i ; sa[0] = -1
+	const uint8_t *ref;     // 2G ASCII
+	i64 G;
+	const i64 *chr_end;     // 2*n_chr sorted last coordinates (ChrLocMap keys)
+	const i32 *chr_of_end;  // chromosome index per entry (ChrLocMap values)
+	i32 n_ends;
+};
+
+struct DevBuf {
+	void *p = nullptr; size_t cap = 0;
+	template <class T> T *as() const { return (T *)p; }
+};
+
+struct Params {
+	i32 MinSeedLength, MaxIndelSize, MinAlnBlockScore, MinAlnLength, MinSeqIdy;
+	i32 bSensitive, OneOnOne;
+};
+
+#define GSA_CHECK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return gsa_fail((ctx), GSA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+int gsa_fail(gsa_ctx *ctx, int code, const std::string &msg);
+
+// ---- rocPRIM-backed primitives (gsa_prim.hip) --------------------------------
+// All asynchronous on `stream`; `tmp` is a reusable scratch buffer that grows.
+int prim_sort_pairs_u64_u32(gsa_ctx *, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n, int begin_bit, int end_bit);
+int prim_exscan_i32(gsa_ctx *, const i32 *in, i32 *out, size_t n);        // out[i] = sum in[0..i)
+int prim_exscan_i32_i64(gsa_ctx *, const i32 *in, i64 *out, size_t n);
+
+static inline int ceil_log2_u64(u64 v) { int b = 0; while ((1ull << b) < v && b < 63) b++; return b; }
+static inline unsigned grid_for(size_t n, unsigned block) { size_t g = (n + block - 1) / block; return (unsigned)(g ? g : 1); }
+
+#endif

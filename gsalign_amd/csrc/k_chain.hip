@@ -1,0 +1,414 @@
+// gsalign_amd/csrc/k_chain.hip -- stage 2: seed-group analysis / chaining (a7).
+//
+// Replaces GenerateAlignmentBlocks -> SeedGroupAnalysis -> {RemoveOutlierSeeds,
+// RefinePDFmap, FindNeighboringPosDiffAvg, RemoveRedundantSeeds, AddAlnBlock}
+// (reference src/GSAlign.cpp:29-49,145-153,178-225,245-391).
+//
+// The reference walks each seed group sequentially.  Here every step is a
+// data-parallel pass over ALL seeds of ALL groups at once (one lane per seed,
+// group boundaries carried per seed), because one group -- the main diagonal --
+// usually holds most of a contig's seeds:
+//   sort (group,qPos,rPos) -> unique flags -> outlier windows (the greedy window
+//   segmentation becomes a "next window start" function + chain walk) -> per-
+//   window PosDiff histogram via one radix sort + run lengths -> multi-hit
+//   resolution from ranked alive-unique neighbours -> compaction -> noise stencil
+//   -> compaction -> block cuts -> AddAlnBlock filter.
+// Exactness notes: integer means truncate toward zero,
+// PosDiff>>4 is an arithmetic shift, the modal bucket is the first maximum in
+// ascending key order, bucket counts are read after zeroing.
+#include "gsa_ctx.h"
+
+#define TPB 256
+#define GID(n) i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (n)) return
+
+__device__ __forceinline__ i64 d_llabs(i64 v) { return v < 0 ? -v : v; }
+
+// ---- A. active groups -> (group,qPos,rPos) order ------------------------------
+__global__ void k_group_count(i32 ng, const i32 *__restrict__ g_beg, const i64 *__restrict__ ps, i32 min_score, i32 *gcount)
+{
+	i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (g > ng) return;
+	if (g == ng) { gcount[g] = 0; return; }
+	i64 sc = ps[g_beg[g + 1]] - ps[g_beg[g]];
+	gcount[g] = sc >= min_score ? g_beg[g + 1] - g_beg[g] : 0;       // GSAlign.cpp:387
+}
+
+__global__ void k_active_keys(i64 n, const i32 *__restrict__ s_q, const i32 *__restrict__ s_gid, const i32 *__restrict__ g_beg,
+                              const i32 *__restrict__ abeg, int qbits, u64 *key, u32 *val)
+{
+	GID(n);
+	const i32 g = s_gid[i];
+	if (abeg[g + 1] == abeg[g]) return;
+	const i32 p = abeg[g] + (i32)(i - g_beg[g]);
+	key[p] = ((u64)(u32)g << qbits) | (u32)s_q[i];
+	val[p] = (u32)i;
+}
+
+__global__ void k_gather_active(i64 na, const u32 *__restrict__ perm, const i32 *__restrict__ s_q, const i32 *__restrict__ s_len, const i64 *__restrict__ s_r,
+                                const i32 *__restrict__ s_gid, const i32 *__restrict__ abeg, i32 *a_q, i32 *a_len, i64 *a_r, i32 *a_gb, i32 *a_ge)
+{
+	GID(na);
+	const u32 s = perm[i];
+	a_q[i] = s_q[s]; a_len[i] = s_len[s]; a_r[i] = s_r[s];
+	const i32 g = s_gid[s];
+	a_gb[i] = abeg[g]; a_ge[i] = abeg[g + 1];
+}
+
+// ---- B. unique flags, break flags ---------------------------------------------
+// uniq: no other seed of the group shares qPos (GSAlign.cpp:316-325)
+// brk : unique and PosDiff differs from the previous seed (the only places where
+//       an outlier window may close, :328-331)
+__global__ void k_uniq_brk(i64 na, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge,
+                           i32 *uniq, i32 *brk, i32 *alive)
+{
+	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > na) return;
+	if (i == na) { uniq[i] = 0; brk[i] = 0; return; }
+	const i32 gb = a_gb[i], ge = a_ge[i], q = a_q[i];
+	const bool u = !(i > gb && a_q[i - 1] == q) && !(i + 1 < ge && a_q[i + 1] == q);
+	uniq[i] = u ? 1 : 0;
+	brk[i] = (u && i > gb && (a_r[i] - q) != (a_r[i - 1] - a_q[i - 1])) ? 1 : 0;
+	alive[i] = 1;
+}
+
+__global__ void k_scatter_idx(i64 n, const i32 *__restrict__ flag, const i32 *__restrict__ ex, i32 *list)
+{
+	GID(n);
+	if (flag[i]) list[ex[i]] = (i32)i;
+}
+
+// next window start for every candidate start (group head or brk position)
+__global__ void k_next_window(i64 na, const i32 *__restrict__ a_q, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge,
+                              const i32 *__restrict__ uniq, const i32 *__restrict__ cuEx, const i32 *__restrict__ brk, const i32 *__restrict__ brkEx,
+                              const i32 *__restrict__ blist, i32 *next)
+{
+	GID(na);
+	const i32 gb = a_gb[i], ge = a_ge[i];
+	if (!(i == gb || brk[i])) { next[i] = -1; return; }
+	// n counts unique seeds: from the group head inclusive for the first window, after a restart exclusive
+	const i32 base = (i == gb) ? cuEx[gb] : cuEx[i] + uniq[i];
+	// first j in (i, ge) with cuIncl[j] - base >= 30   (cuIncl[j] = cuEx[j+1])
+	i32 lo = (i32)i + 1, hi = ge;
+	while (lo < hi) { i32 mid = (lo + hi) >> 1; if (cuEx[mid + 1] - base >= GSA_WIN_SEEDS) hi = mid; else lo = mid + 1; }
+	const i32 j1 = lo;
+	lo = (i32)i + 1; hi = ge;
+	const i32 qi = a_q[i];
+	while (lo < hi) { i32 mid = (lo + hi) >> 1; if (a_q[mid] - qi > GSA_WIN_SPAN) hi = mid; else lo = mid + 1; }
+	const i32 j0 = j1 > lo ? j1 : lo;
+	i32 nx = ge;
+	if (j0 < ge) { const i32 nB = brkEx[na]; const i32 k = brkEx[j0]; if (k < nB) { const i32 cand = blist[k]; if (cand < ge) nx = cand; } }
+	next[i] = nx;
+}
+
+// greedy window segmentation: one lane per group follows next[] from the group head
+__global__ void k_walk_windows(i64 na, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge, const i32 *__restrict__ next, i32 *ws)
+{
+	GID(na);
+	if (a_gb[i] != i) return;
+	const i32 ge = a_ge[i];
+	i32 p = (i32)i;
+	while (p < ge) { ws[p] = 1; p = next[p]; }
+}
+
+// ---- C. outliers: per-window histogram of PosDiff>>4 over unique seeds -----------
+__global__ void k_outlier_keys(i64 na, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const i32 *__restrict__ uniq,
+                               const i32 *__restrict__ ws, const i32 *__restrict__ wsEx, u64 *key, u32 *val)
+{
+	GID(na);
+	const i32 w = wsEx[i] + ws[i] - 1;
+	const i64 pd = a_r[i] - a_q[i];
+	const u32 b = (u32)(i32)(pd >> 4) ^ 0x80000000u;
+	key[i] = uniq[i] ? (((u64)(u32)w << 32) | b) : ~0ull;       // non-unique seeds sort to the end
+	val[i] = (u32)i;
+}
+
+__global__ void k_run_heads(i64 na, const u64 *__restrict__ key, i32 *head)
+{
+	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > na) return;
+	if (i == na) { head[i] = 0; return; }
+	head[i] = (key[i] != ~0ull && (i == 0 || key[i] != key[i - 1])) ? 1 : 0;
+}
+
+// run r = [rs[r], rs[r+1]) ; the last run ends at nU (number of unique seeds)
+__global__ void k_window_mode(i64 na, const i32 *__restrict__ headEx, const i32 *__restrict__ rs, const u64 *__restrict__ key, const i32 *__restrict__ cuEx,
+                              unsigned long long *wbest)
+{
+	GID(na);
+	const i32 nRuns = headEx[na];
+	if (i >= nRuns) return;
+	const i32 nU = cuEx[na];
+	const i32 b = rs[i], e = (i + 1 < nRuns) ? rs[i + 1] : nU;
+	const u64 k = key[b];
+	const u32 w = (u32)(k >> 32);
+	// first maximum in ascending key order (RefinePDFmap, GSAlign.cpp:251)
+	atomicMax(&wbest[w], ((unsigned long long)(u32)(e - b) << 32) | (0xFFFFFFFFu - (u32)k));
+}
+
+__global__ void k_window_avg(i64 na, const u64 *__restrict__ key, const u32 *__restrict__ val, const i32 *__restrict__ cuEx,
+                             const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const unsigned long long *__restrict__ wbest,
+                             unsigned long long *wsum, i32 *wn)
+{
+	GID(na);
+	if (i >= cuEx[na]) return;
+	const u64 k = key[i]; const u32 w = (u32)(k >> 32);
+	const i32 kk = (i32)((u32)k ^ 0x80000000u), mode = (i32)((0xFFFFFFFFu - (u32)wbest[w]) ^ 0x80000000u);
+	i64 dk = (i64)kk - mode; if (dk < 0) dk = -dk;
+	if (dk < 3) {                                                    // surviving bucket (:256)
+		const u32 s = val[i];
+		atomicAdd(&wsum[w], (unsigned long long)(a_r[s] - a_q[s]));
+		atomicAdd(&wn[w], 1);
+	}
+}
+
+__global__ void k_outlier_kill(i64 na, const u64 *__restrict__ key, const u32 *__restrict__ val, const i32 *__restrict__ cuEx,
+                               const i32 *__restrict__ head, const i32 *__restrict__ headEx, const i32 *__restrict__ rs,
+                               const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const unsigned long long *__restrict__ wbest,
+                               const unsigned long long *__restrict__ wsum, const i32 *__restrict__ wn, i64 G, i32 max_indel, i32 *alive)
+{
+	GID(na);
+	const i32 nU = cuEx[na];
+	if (i >= nU) return;
+	const u64 k = key[i]; const u32 w = (u32)(k >> 32);
+	const i32 kk = (i32)((u32)k ^ 0x80000000u), mode = (i32)((0xFFFFFFFFu - (u32)wbest[w]) ^ 0x80000000u);
+	i64 dk = (i64)kk - mode; if (dk < 0) dk = -dk;
+	const i32 nRuns = headEx[na];
+	const i32 r = headEx[i] + head[i] - 1;
+	const i32 rl = ((r + 1 < nRuns) ? rs[r + 1] : nU) - rs[r];
+	const i32 cnt = dk < 3 ? rl : 0;                                 // counts are read after zeroing (App. B #23)
+	const i64 avg = wn[w] > 0 ? (i64)wsum[w] / wn[w] : G;            // C division: truncation toward zero
+	const u32 s = val[i];
+	const i64 pd = a_r[s] - a_q[s];
+	if (d_llabs(avg - pd) > max_indel && cnt < 3) alive[s] = 0;      // GSAlign.cpp:290, Min_PD_Freq = 3
+}
+
+// ---- D. multi-hit query positions (GSAlign.cpp:178-225,341-350) -------------------
+__global__ void k_au_flags(i64 na, const i32 *__restrict__ uniq, const i32 *__restrict__ alive, i32 *au)
+{
+	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > na) return;
+	au[i] = (i < na && uniq[i] && alive[i]) ? 1 : 0;
+}
+
+__global__ void k_multihit(i64 na, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge,
+                           const i32 *__restrict__ auEx, const i32 *__restrict__ aulist, i64 G, i32 max_indel, i32 *alive)
+{
+	GID(na);
+	const i32 gb = a_gb[i], ge = a_ge[i], q = a_q[i];
+	if (!(i + 1 < ge && a_q[i + 1] == q) || (i > gb && a_q[i - 1] == q)) return;   // not the head of a multi-hit run
+	i32 j = (i32)i + 1; while (j < ge && a_q[j] == q) j++;
+	i64 s1 = 0, s2 = 0; i32 n1 = 0, n2 = 0;
+	for (i32 k = auEx[i] - 1; k >= auEx[gb] && n1 < 5; k--) { const i32 s = aulist[k]; s1 += a_r[s] - a_q[s]; n1++; }
+	for (i32 k = auEx[j]; k < auEx[ge] && n2 < 5; k++) { const i32 s = aulist[k]; s2 += a_r[s] - a_q[s]; n2++; }
+	const i64 avg = (n1 > 0 || n2 > 0) ? (s1 + s2) / (n1 + n2) : (a_r[i] - q);
+	i32 idx = -1; i64 md = G;
+	for (i32 k = (i32)i; k < j; k++) { const i64 d = d_llabs((a_r[k] - q) - avg); if (d < max_indel && d < md) { md = d; idx = k; } }
+	for (i32 k = (i32)i; k < j; k++) if (k != idx) alive[k] = 0;
+}
+
+// ---- E. compaction, noise stencil, block cuts -----------------------------------
+__global__ void k_flag_tail(i64 n, i32 *flag) { if (blockIdx.x == 0 && threadIdx.x == 0) flag[n] = 0; }
+
+__global__ void k_compact(i64 n, const i32 *__restrict__ keep, const i32 *__restrict__ ex, const i32 *__restrict__ q, const i32 *__restrict__ len,
+                          const i64 *__restrict__ r, const i32 *__restrict__ gb, const i32 *__restrict__ ge, i32 *oq, i32 *olen, i64 *orr, i32 *ogb, i32 *oge)
+{
+	GID(n);
+	if (!keep[i]) return;
+	const i32 p = ex[i];
+	oq[p] = q[i]; olen[p] = len[i]; orr[p] = r[i]; ogb[p] = ex[gb[i]]; oge[p] = ex[ge[i]];
+}
+
+// 3-point noise filter (GSAlign.cpp:355-362): pure stencil on PosDiff
+__global__ void k_noise(const i32 *__restrict__ nptr, const i32 *__restrict__ q, const i64 *__restrict__ r, const i32 *__restrict__ gb, const i32 *__restrict__ ge, i32 *keep)
+{
+	const i64 n = *nptr;
+	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > n) return;
+	if (i == n) { keep[i] = 0; return; }
+	i32 k = 1;
+	if (i > gb[i] && i + 1 < ge[i]) {
+		const i64 pd = r[i] - q[i], p0 = r[i - 1] - q[i - 1], p1 = r[i + 1] - q[i + 1];
+		if (d_llabs(pd - p0) > 5 && d_llabs(pd - p1) > 5) k = 0;
+	}
+	keep[i] = k;
+}
+
+__global__ void k_compact_n(const i32 *__restrict__ nptr, const i32 *__restrict__ keep, const i32 *__restrict__ ex, const i32 *__restrict__ q, const i32 *__restrict__ len,
+                            const i64 *__restrict__ r, const i32 *__restrict__ gb, const i32 *__restrict__ ge, i32 *oq, i32 *olen, i64 *orr, i32 *ogb, i32 *oge)
+{
+	const i64 n = *nptr;
+	GID(n);
+	if (!keep[i]) return;
+	const i32 p = ex[i];
+	oq[p] = q[i]; olen[p] = len[i]; orr[p] = r[i]; ogb[p] = ex[gb[i]]; oge[p] = ex[ge[i]];
+}
+
+// block heads (GSAlign.cpp:364-374): group head, query gap > MaxSeedGap, or diagonal jump > 100
+__global__ void k_block_heads(const i32 *__restrict__ nptr, const i32 *__restrict__ q, const i32 *__restrict__ len, const i64 *__restrict__ r,
+                              const i32 *__restrict__ gb, i32 *head)
+{
+	const i64 n = *nptr;
+	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > n) return;
+	if (i == n) { head[i] = 0; return; }
+	i32 h = 1;
+	if (i > gb[i]) {
+		const i64 pd = r[i] - q[i], p0 = r[i - 1] - q[i - 1];
+		h = (q[i] - q[i - 1] - len[i - 1] > GSA_MAX_SEED_GAP || d_llabs(p0 - pd) > 100) ? 1 : 0;
+	}
+	head[i] = h;
+}
+
+// AddAlnBlock filter (GSAlign.cpp:29-49); bstart[] lists block heads, nAll = headEx[n]
+__global__ void k_block_filter(const i32 *__restrict__ nptr, const i32 *__restrict__ headEx, const i32 *__restrict__ bstart, const i32 *__restrict__ q,
+                               const i32 *__restrict__ len, const i64 *__restrict__ ps, Params prm, i32 *bkeep, i32 *bscore)
+{
+	const i64 n = *nptr;
+	i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (b > n) return;
+	const i32 nAll = headEx[n];
+	if (b >= nAll) { bkeep[b] = 0; return; }
+	const i32 s = bstart[b], e = (b + 1 < nAll) ? bstart[b + 1] : (i32)n;
+	const i32 score = (i32)(ps[e] - ps[s]);
+	const i32 region = q[e - 1] + len[e - 1] - q[s];
+	const bool drop = score < prm.MinAlnBlockScore || region < prm.MinAlnLength || (score < 1000 && (double)score < region * 0.05);
+	bkeep[b] = drop ? 0 : 1; bscore[b] = score;
+}
+
+__global__ void k_block_emit(const i32 *__restrict__ nptr, const i32 *__restrict__ headEx, const i32 *__restrict__ bstart, const i32 *__restrict__ bkeep,
+                             const i32 *__restrict__ bkeepEx, const i32 *__restrict__ bscore, i32 *blk_beg, i32 *blk_end, i32 *blk_score)
+{
+	const i64 n = *nptr;
+	GID(n);
+	const i32 nAll = headEx[n];
+	if (i >= nAll || !bkeep[i]) return;
+	const i32 p = bkeepEx[i];
+	blk_beg[p] = bstart[i]; blk_end[p] = (i + 1 < nAll) ? bstart[i + 1] : (i32)n; blk_score[p] = bscore[i];
+}
+
+__global__ void k_seed_block_id(const i32 *__restrict__ nptr, const i32 *__restrict__ head, const i32 *__restrict__ headEx, const i32 *__restrict__ bkeep,
+                                const i32 *__restrict__ bkeepEx, i32 *bid)
+{
+	const i64 n = *nptr;
+	GID(n);
+	const i32 b = headEx[i] + head[i] - 1;
+	bid[i] = bkeep[b] ? bkeepEx[b] : -1;
+}
+
+#define LAUNCH(k, n, ...) hipLaunchKernelGGL(k, dim3(grid_for((size_t)(n), TPB)), dim3(TPB), 0, st, __VA_ARGS__)
+#define ENS(T, buf, n) do { if (!dev_ensure<T>(c, c->buf, (size_t)(n))) return GSA_ERR_NOMEM; } while (0)
+#define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+int stage2_chain(gsa_ctx *c)
+{
+	hipStream_t st = c->stream;
+	c->n_blocks2 = 0; c->n_c = 0; c->n_a = 0; c->blocks.clear();
+	c->h_blk_beg.clear(); c->h_blk_end.clear(); c->h_blk_score.clear();
+	const i64 n = c->n_seeds; const i32 ng = c->n_groups;
+	if (n == 0 || ng == 0) return GSA_OK;
+	if (c->profiling) hipEventRecord(c->ev[4], st);
+	// A. group scores, active groups
+	ENS(i64, d_i64a, n + 1); ENS(i32, d_flag2, n + 2); ENS(i32, d_scan2, n + 2);
+	// s_len has n entries; scan n+1 with a zero tail staged in d_flag
+	GSA_CHECK(c, hipMemcpyAsync(c->d_flag.p, c->s_len.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+	LAUNCH(k_flag_tail, 1, n, c->d_flag.as<i32>());
+	RC(prim_exscan_i32_i64(c, c->d_flag.as<i32>(), c->d_i64a.as<i64>(), (size_t)n + 1));
+	i32 *gcount = c->d_flag2.as<i32>(), *abeg = c->d_scan2.as<i32>();
+	LAUNCH(k_group_count, ng + 1, ng, c->g_beg.as<i32>(), c->d_i64a.as<i64>(), c->prm.MinAlnBlockScore, gcount);
+	RC(prim_exscan_i32(c, gcount, abeg, (size_t)ng + 1));
+	i32 na32 = 0;
+	GSA_CHECK(c, hipMemcpyAsync(&na32, abeg + ng, 4, hipMemcpyDeviceToHost, st));
+	GSA_CHECK(c, hipStreamSynchronize(st));
+	const i64 na = na32; c->n_a = na;
+	if (na == 0) return GSA_OK;
+	ENS(u64, d_key_a, n); ENS(u64, d_key_b, n); ENS(u32, d_val_a, n); ENS(u32, d_val_b, n);
+	LAUNCH(k_active_keys, n, n, c->s_q.as<i32>(), c->s_gid.as<i32>(), c->g_beg.as<i32>(), abeg, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>());
+	const int gbits = ceil_log2_u64((u64)ng + 1);
+	RC(prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + gbits));
+	ENS(i32, a_q, na); ENS(i32, a_len, na); ENS(i64, a_r, na); ENS(i32, a_gb, na); ENS(i32, a_ge, na);
+	LAUNCH(k_gather_active, na, na, c->d_val_b.as<u32>(), c->s_q.as<i32>(), c->s_len.as<i32>(), c->s_r.as<i64>(), c->s_gid.as<i32>(), abeg,
+	       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>());
+	// B. unique / break flags, window chain
+	ENS(i32, a_uniq, na + 1); ENS(i32, a_cu, na + 1); ENS(i32, a_alive, na + 1); ENS(i32, a_brk, na + 1); ENS(i32, a_aurank, na + 1);
+	ENS(i32, a_aulist, na + 1); ENS(i32, a_next, na + 1); ENS(i32, a_ws, na + 1); ENS(i32, a_wid, na + 1); ENS(i32, a_runinfo, na + 1);
+	i32 *uniq = c->a_uniq.as<i32>(), *cuEx = c->a_cu.as<i32>(), *alive = c->a_alive.as<i32>(), *brk = c->a_brk.as<i32>();
+	i32 *brkEx = c->a_aurank.as<i32>(), *blist = c->a_aulist.as<i32>(), *next = c->a_next.as<i32>(), *ws = c->a_ws.as<i32>(), *wsEx = c->a_wid.as<i32>();
+	LAUNCH(k_uniq_brk, na + 1, na, c->a_q.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, brk, alive);
+	RC(prim_exscan_i32(c, uniq, cuEx, (size_t)na + 1));
+	RC(prim_exscan_i32(c, brk, brkEx, (size_t)na + 1));
+	LAUNCH(k_scatter_idx, na, na, brk, brkEx, blist);
+	LAUNCH(k_next_window, na, na, c->a_q.as<i32>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, cuEx, brk, brkEx, blist, next);
+	GSA_CHECK(c, hipMemsetAsync(ws, 0, ((size_t)na + 1) * 4, st));
+	LAUNCH(k_walk_windows, na, na, c->a_gb.as<i32>(), c->a_ge.as<i32>(), next, ws);
+	RC(prim_exscan_i32(c, ws, wsEx, (size_t)na + 1));
+	// C. outliers
+	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);
+	GSA_CHECK(c, hipMemsetAsync(c->w_best.p, 0, ((size_t)na + 1) * 8, st));
+	GSA_CHECK(c, hipMemsetAsync(c->w_sum.p, 0, ((size_t)na + 1) * 8, st));
+	GSA_CHECK(c, hipMemsetAsync(c->w_n.p, 0, ((size_t)na + 1) * 4, st));
+	LAUNCH(k_outlier_keys, na, na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, wsEx, c->d_key_a.as<u64>(), c->d_val_a.as<u32>());
+	RC(prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, 64));
+	i32 *head = c->d_flag.as<i32>(), *headEx = c->d_scan.as<i32>(), *rs = c->a_runinfo.as<i32>();
+	LAUNCH(k_run_heads, na + 1, na, c->d_key_b.as<u64>(), head);
+	RC(prim_exscan_i32(c, head, headEx, (size_t)na + 1));
+	LAUNCH(k_scatter_idx, na, na, head, headEx, rs);
+	LAUNCH(k_window_mode, na, na, headEx, rs, c->d_key_b.as<u64>(), cuEx, c->w_best.as<unsigned long long>());
+	LAUNCH(k_window_avg, na, na, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), cuEx, c->a_q.as<i32>(), c->a_r.as<i64>(), c->w_best.as<unsigned long long>(),
+	       c->w_sum.as<unsigned long long>(), c->w_n.as<i32>());
+	LAUNCH(k_outlier_kill, na, na, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), cuEx, head, headEx, rs, c->a_q.as<i32>(), c->a_r.as<i64>(),
+	       c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->G, c->prm.MaxIndelSize, alive);
+	// D. multi-hit positions
+	i32 *au = c->d_flag.as<i32>(), *auEx = c->a_aurank.as<i32>(), *aulist = c->a_aulist.as<i32>();
+	LAUNCH(k_au_flags, na + 1, na, uniq, alive, au);
+	RC(prim_exscan_i32(c, au, auEx, (size_t)na + 1));
+	LAUNCH(k_scatter_idx, na, na, au, auEx, aulist);
+	LAUNCH(k_multihit, na, na, c->a_q.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), auEx, aulist, c->G, c->prm.MaxIndelSize, alive);
+	// E. compaction #1
+	LAUNCH(k_flag_tail, 1, na, alive);
+	i32 *ex = c->d_scan.as<i32>();
+	RC(prim_exscan_i32(c, alive, ex, (size_t)na + 1));
+	ENS(i32, b_q, na); ENS(i32, b_len, na); ENS(i64, b_r, na); ENS(i32, b_gb, na); ENS(i32, b_ge, na);
+	LAUNCH(k_compact, na, na, alive, ex, c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(),
+	       c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(), c->b_ge.as<i32>());
+	// n_b lives on the device at ex[na]; keep a private copy because `ex` is reused
+	i32 *d_counts = c->w_n.as<i32>();          // [0] = n_b, [1] = n_c   (w_n is free again)
+	GSA_CHECK(c, hipMemcpyAsync(d_counts, ex + na, 4, hipMemcpyDeviceToDevice, st));
+	// noise stencil + compaction #2
+	i32 *keep = c->d_flag.as<i32>(), *keepEx = c->d_scan2.as<i32>();
+	GSA_CHECK(c, hipMemsetAsync(keep, 0, ((size_t)na + 1) * 4, st));
+	LAUNCH(k_noise, na + 1, d_counts, c->b_q.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(), c->b_ge.as<i32>(), keep);
+	RC(prim_exscan_i32(c, keep, keepEx, (size_t)na + 1));
+	ENS(i32, c_q, na); ENS(i32, c_len, na + 1); ENS(i64, c_r, na); ENS(i32, c_gb, na); ENS(i32, c_ge, na); ENS(i32, c_bid, na);
+	GSA_CHECK(c, hipMemsetAsync(c->c_len.p, 0, ((size_t)na + 1) * 4, st));
+	LAUNCH(k_compact_n, na, d_counts, keep, keepEx, c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(), c->b_ge.as<i32>(),
+	       c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), c->c_ge.as<i32>());
+	GSA_CHECK(c, hipMemcpyAsync(d_counts + 1, keepEx + na, 4, hipMemcpyDeviceToDevice, st));
+	// block cuts + AddAlnBlock
+	i32 *bhead = c->a_uniq.as<i32>(), *bheadEx = c->a_cu.as<i32>(), *bstart = c->a_brk.as<i32>();
+	GSA_CHECK(c, hipMemsetAsync(bhead, 0, ((size_t)na + 1) * 4, st));
+	LAUNCH(k_block_heads, na + 1, d_counts + 1, c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), bhead);
+	RC(prim_exscan_i32(c, bhead, bheadEx, (size_t)na + 1));
+	LAUNCH(k_scatter_idx, na, na, bhead, bheadEx, bstart);
+	RC(prim_exscan_i32_i64(c, c->c_len.as<i32>(), c->d_i64a.as<i64>(), (size_t)na + 1));
+	i32 *bkeep = c->a_ws.as<i32>(), *bkeepEx = c->a_wid.as<i32>(), *bscore = c->a_next.as<i32>();
+	GSA_CHECK(c, hipMemsetAsync(bkeep, 0, ((size_t)na + 1) * 4, st));
+	LAUNCH(k_block_filter, na + 1, d_counts + 1, bheadEx, bstart, c->c_q.as<i32>(), c->c_len.as<i32>(), c->d_i64a.as<i64>(), c->prm, bkeep, bscore);
+	RC(prim_exscan_i32(c, bkeep, bkeepEx, (size_t)na + 1));
+	ENS(i32, blk_beg, na + 1); ENS(i32, blk_end, na + 1); ENS(i32, blk_score, na + 1);
+	LAUNCH(k_block_emit, na, d_counts + 1, bheadEx, bstart, bkeep, bkeepEx, bscore, c->blk_beg.as<i32>(), c->blk_end.as<i32>(), c->blk_score.as<i32>());
+	LAUNCH(k_seed_block_id, na, d_counts + 1, bhead, bheadEx, bkeep, bkeepEx, c->c_bid.as<i32>());
+	i32 h_counts[2] = {0, 0}, nblk = 0;
+	GSA_CHECK(c, hipMemcpyAsync(h_counts, d_counts, 8, hipMemcpyDeviceToHost, st));
+	GSA_CHECK(c, hipMemcpyAsync(&nblk, bkeepEx + na, 4, hipMemcpyDeviceToHost, st));
+	if (c->profiling) hipEventRecord(c->ev[5], st);
+	GSA_CHECK(c, hipStreamSynchronize(st));
+	c->n_b = h_counts[0]; c->n_c = h_counts[1]; c->n_blocks2 = nblk;
+	if (nblk > 0) {
+		c->h_blk_beg.resize(nblk); c->h_blk_end.resize(nblk); c->h_blk_score.resize(nblk);
+		GSA_CHECK(c, hipMemcpy(c->h_blk_beg.data(), c->blk_beg.p, (size_t)nblk * 4, hipMemcpyDeviceToHost));
+		GSA_CHECK(c, hipMemcpy(c->h_blk_end.data(), c->blk_end.p, (size_t)nblk * 4, hipMemcpyDeviceToHost));
+		GSA_CHECK(c, hipMemcpy(c->h_blk_score.data(), c->blk_score.p, (size_t)nblk * 4, hipMemcpyDeviceToHost));
+	}
+	if (c->profiling) { float ms; hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); c->kernel_ms[3] = ms; }
+	return GSA_OK;
+}

@@ -1,0 +1,120 @@
+// gsalign_amd/csrc/k_gapsim.hip -- gap similarity test (a9).
+//
+// Replaces CalGapSimilarity / CreateKmerVecFromReadSeq / CreateKmerID
+// (reference src/KmerAnalysis.cpp:10-17,32-76,78-121).  One wavefront per gap:
+//   * flanks on one diagonal: count positions with equal codes (or an N on
+//     either side); similar if count >= q_len*0.5;
+//   * otherwise (both windows <= 5000): multiset intersection of the 5-mer ids of
+//     the two windows, similar if |intersection| > (q_len+r_len)*0.1.
+// The sorted-vector set_intersection of the reference equals sum(min(h1,h2))
+// over two histograms, which live in LDS.  The reference's id arithmetic is kept
+// bit-exact, including what a code 4 (n, IUPAC) does to the rolling id and the
+// literal-'N' rescan quirk, which is replayed sequentially
+// by one lane because it is a state machine.
+#include "gsa_ctx.h"
+#include "gsa_fm.h"
+
+#define KBINS 1376          // max id: 4*(256+64+16+4+1) = 1364
+
+__device__ __forceinline__ u32 kmer_id_direct(const uint8_t *s, int pos)       // CreateKmerID, no masking
+{
+	u32 id = 0;
+	for (int i = pos; i < pos + 5; i++) id = (id << 2) + gsa_nt4(s[i]);
+	return id;
+}
+
+// one window -> histogram (all 64 lanes call)
+__device__ void kmer_hist(const uint8_t *__restrict__ s, int len, u32 *hist, int lane)
+{
+	// does the window contain a literal 'N'?
+	int hasN = 0;
+	for (int p = lane; p < len; p += 64) hasN |= (s[p] == 'N');
+	hasN = __any(hasN);
+	if (!hasN) {
+		// wid_0 = direct id; wid_p (p>=1) = ((wid_{p-1} & 0xFF) << 2) + v[p+4], which depends on v[p..p+4] only
+		for (int p = lane; p + 5 <= len; p += 64) {
+			u32 id;
+			if (p == 0) id = kmer_id_direct(s, 0);
+			else {
+				u32 t = 0;
+				for (int i = 0; i < 4; i++) t = (t << 2) + gsa_nt4(s[p + i]);
+				id = ((t & 0xFF) << 2) + gsa_nt4(s[p + 4]);
+			}
+			atomicAdd(&hist[id], 1u);
+		}
+	} else if (lane == 0) {
+		u32 wid, count = 0, head = 0, tail = 0;
+		while (count < 5 && tail < (u32)len) { if (s[tail++] != 'N') count++; else count = 0; }
+		if (count == 5) {
+			wid = kmer_id_direct(s, (short)head); hist[wid]++;
+			for (head += 1; tail < (u32)len; head++, tail++) {
+				if (s[tail] != 'N') { wid = ((wid & 0xFF) << 2) + gsa_nt4(s[tail]); hist[wid]++; }
+				else {
+					count = 0; tail++;
+					while (count < 5 && tail < (u32)len) { if (s[tail++] != 'N') count++; else count = 0; }
+					if (count == 5) { wid = kmer_id_direct(s, (short)head); hist[wid]++; }
+					else break;
+				}
+			}
+		}
+	}
+}
+
+__global__ void __launch_bounds__(64) k_gapsim(DevIndex di, const uint8_t *__restrict__ query, i32 n, const i32 *__restrict__ q1a, const i32 *__restrict__ q2a,
+                                                const i64 *__restrict__ r1a, const i64 *__restrict__ r2a, i32 *res)
+{
+	__shared__ u32 h1[KBINS], h2[KBINS];
+	const int job = blockIdx.x, lane = threadIdx.x;
+	if (job >= n) return;
+	const i32 q1 = q1a[job], q2 = q2a[job]; const i64 r1 = r1a[job], r2 = r2a[job];
+	const int q_len = q2 - q1, r_len = (int)(r2 - r1);
+	bool sim = false;
+	if (r1 - q1 == r2 - q2) {
+		int idy = 0;
+		for (int p = lane; p < q_len; p += 64) {
+			const int a = gsa_nt4(di.ref[r1 + p]), b = gsa_nt4(query[q1 + p]);
+			idy += (a == b || a == 4 || b == 4);
+		}
+		for (int o = 32; o; o >>= 1) idy += __shfl_xor(idy, o);
+		if ((double)idy >= q_len * 0.5) sim = true;
+	}
+	if (!sim && q_len <= GSA_MAX_SEED_GAP && r_len <= GSA_MAX_SEED_GAP) {
+		for (int b = lane; b < KBINS; b += 64) { h1[b] = 0; h2[b] = 0; }
+		__syncthreads();
+		kmer_hist(query + q1, q_len, h1, lane);
+		kmer_hist(di.ref + r1, r_len, h2, lane);
+		__syncthreads();
+		int common = 0;
+		for (int b = lane; b < KBINS; b += 64) common += (int)(h1[b] < h2[b] ? h1[b] : h2[b]);
+		for (int o = 32; o; o >>= 1) common += __shfl_xor(common, o);
+		if ((double)common > (q_len + r_len) * 0.1) sim = true;
+	}
+	if (lane == 0) res[job] = sim ? 1 : 0;
+}
+
+int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res)
+{
+	if (n <= 0) return GSA_OK;
+	hipLaunchKernelGGL(k_gapsim, dim3(n), dim3(64), 0, c->stream, c->di, c->d_query.as<uint8_t>(), n, d_q1, d_q2, d_r1, d_r2, d_res);
+	GSA_CHECK(c, hipGetLastError());
+	return GSA_OK;
+}
+
+extern "C" int gsa_gap_similarity_batch(gsa_ctx *c, int32_t n, const int32_t *q1, const int32_t *q2, const int64_t *r1, const int64_t *r2, int32_t *similar)
+{
+	if (!c || n < 0) return GSA_ERR_ARG;
+	if (c->qlen <= 0) return gsa_fail(c, GSA_ERR_STATE, "gsa_set_query first");
+	if (n == 0) return GSA_OK;
+	for (int i = 0; i < n; i++)
+		if (q1[i] < 0 || q2[i] < q1[i] || q2[i] > c->qlen || r1[i] < 0 || r2[i] < r1[i] || r2[i] > 2 * c->G) return gsa_fail(c, GSA_ERR_ARG, "gap window out of range");
+	hipStream_t st = c->stream;
+	i32 *dq1, *dq2, *dres; i64 *dr1, *dr2;
+	GSA_CHECK(c, hipMalloc(&dq1, n * 4)); GSA_CHECK(c, hipMalloc(&dq2, n * 4)); GSA_CHECK(c, hipMalloc(&dres, n * 4));
+	GSA_CHECK(c, hipMalloc(&dr1, n * 8)); GSA_CHECK(c, hipMalloc(&dr2, n * 8));
+	GSA_CHECK(c, hipMemcpyAsync(dq1, q1, n * 4, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(dq2, q2, n * 4, hipMemcpyHostToDevice, st));
+	GSA_CHECK(c, hipMemcpyAsync(dr1, r1, n * 8, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(dr2, r2, n * 8, hipMemcpyHostToDevice, st));
+	int rc = run_gapsim_jobs(c, n, dq1, dq2, dr1, dr2, dres);
+	if (rc == GSA_OK) { GSA_CHECK(c, hipMemcpyAsync(similar, dres, n * 4, hipMemcpyDeviceToHost, st)); GSA_CHECK(c, hipStreamSynchronize(st)); }
+	hipFree(dq1); hipFree(dq2); hipFree(dres); hipFree(dr1); hipFree(dr2);
+	return rc;
+}

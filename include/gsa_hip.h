@@ -1,0 +1,170 @@
+/* include/gsa_hip.h -- C ABI of libgsa_hip.so, the MI355X (gfx950) hot path of a
+ * GSAlign-compatible whole-genome aligner.
+ *
+ * The reference (hsinnan75/GSAlign v1.0.22) has no plugin / FFI interface; its
+ * hot path is the set of functions GenomeComparison() launches per query contig
+ * (reference src/GSAlign.cpp:483-540) and they communicate through globals.
+ * This header is the seam a maintainer would bind instead (SURVEY.md section
+ * 8(b)); every entry point cites the reference code it replaces.  Plain C:
+ * pointers and sizes only, no C++/torch types.  One gsa_ctx per GPU; a context
+ * is not thread-safe; calls are synchronous for the caller.
+ *
+ * All results are bit-identical to the reference's: seeds, blocks, gap records,
+ * op strings, scores.
+ */
+#ifndef GSA_HIP_H
+#define GSA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gsa_ctx gsa_ctx;
+
+/* error codes (negative); gsa_last_error() has the text */
+enum {
+	GSA_OK = 0,
+	GSA_ERR_ARG = -1,      /* bad argument                      */
+	GSA_ERR_HIP = -2,      /* a HIP runtime call failed         */
+	GSA_ERR_NOMEM = -3,    /* device or host allocation failed  */
+	GSA_ERR_STATE = -4,    /* call order violated               */
+	GSA_ERR_LIMIT = -5     /* an internal capacity was exceeded */
+};
+
+/* The in-memory index the reference keeps in Refbwt / RefSequence / ChromosomeVec
+ * (structure.h:28-38,141-155; filled by bwa_idx_load + RestoreReferenceInfo,
+ * bwt_index.cpp:147-264).  Host pointers; gsa_create copies them to the device
+ * and does not keep them. */
+typedef struct {
+	uint64_t primary;          /* bwt_t::primary                                        */
+	uint64_t L2[5];            /* bwt_t::L2, L2[0] = 0, L2[4] = seq_len = 2G            */
+	const uint32_t *bwt;       /* bwt_t::bwt: interleaved Occ checkpoints + 2-bit BWT   */
+	uint64_t bwt_words;        /* bwt_t::bwt_size                                       */
+	const uint64_t *sa;        /* bwt_t::sa, sa[0] = (uint64_t)-1, sa_intv = 32         */
+	uint64_t n_sa;             /* bwt_t::n_sa                                           */
+	const char *ref;           /* RefSequence: 2G ASCII bytes, forward + reverse compl. */
+	int64_t G;                 /* GenomeSize (forward length)                           */
+	const int32_t *chr_len;    /* ChromosomeVec[i].len                                  */
+	int32_t n_chr;             /* iChromsomeNum                                         */
+} gsa_index_view;
+
+/* The tunables the reference parses into globals (main.cpp:202-214,236-299,323). */
+typedef struct {
+	int32_t min_seed_len;      /* -slen  MinSeedLength     [15]; forced to 10 by -sen  */
+	int32_t max_indel;         /* -ind   MaxIndelSize      [25]                        */
+	int32_t min_block_score;   /* -clr   MinAlnBlockScore  [200] (50 with -sen)        */
+	int32_t min_aln_len;       /* -alen  MinAlnLength      [200]                       */
+	int32_t min_identity;      /* -idy   MinSeqIdy         [70]                        */
+	int32_t sensitive;         /* -sen   bSensitive        [0]                         */
+	int32_t one_on_one;        /* -one   OneOnOneMode      [0]                         */
+} gsa_params;
+void gsa_default_params(gsa_params *p);
+
+/* ---- records ------------------------------------------------------------ */
+/* one located exact match; the reference's FragPair_t with bSeed = true
+ * (structure.h:103-113), order = CompByPosDiff (ProcessCandidateAlignment.cpp:3-7) */
+typedef struct { int32_t qpos; int32_t len; int64_t rpos; } gsa_seed;
+
+/* FragPair_t of a finished block.  aln_off/aln_len address the two gapped
+ * strings of a non-seed pair inside gsa_result::aln1 / aln2. */
+typedef struct {
+	int32_t bseed, qpos, qlen, rlen;
+	int64_t rpos;
+	int64_t aln_off;
+	int32_t aln_len;
+	int32_t _pad;
+} gsa_frag;
+
+/* AlnBlock_t (structure.h:115-122) after the identity filter (GSAlign.cpp:529-540) */
+typedef struct {
+	int32_t score, aln_len, bdup, n_frag;
+	int64_t frag_off;          /* first gsa_frag of this block           */
+	int32_t bdir, gpos, chr;   /* Coordinate_t from GenCoordinateInfo    */
+	int32_t _pad;
+} gsa_block;
+
+/* everything GenomeComparison() leaves in AlnBlockVec for one query contig,
+ * in the reference's order (RemoveBadAlnBlocks, GSAlign.cpp:540).  Memory is
+ * owned by the context and valid until the next gsa_align_contig/gsa_destroy. */
+typedef struct {
+	int32_t n_blocks;
+	int64_t n_frags;
+	int64_t n_aln;
+	const gsa_block *blocks;
+	const gsa_frag *frags;
+	const char *aln1, *aln2;   /* reference-side / query-side gapped strings */
+} gsa_result;
+
+/* ---- life cycle --------------------------------------------------------- */
+int  gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa_ctx **out);
+void gsa_destroy(gsa_ctx *ctx);
+int  gsa_set_params(gsa_ctx *ctx, const gsa_params *prm);
+const char *gsa_last_error(gsa_ctx *ctx);   /* ctx may be NULL: error of the last failed gsa_create */
+
+/* ---- the drop-in call ----------------------------------------------------
+ * Replaces the body of the per-contig loop of GenomeComparison()
+ * (GSAlign.cpp:483-540): S1 IdentifyLocalMEM ... S7 GenerateFragAlignment,
+ * identity filter, GenCoordinateInfo, final RemoveBadAlnBlocks.
+ * query = raw contig bytes exactly as loaded from FASTA (any case, IUPAC ok). */
+int gsa_align_contig(gsa_ctx *ctx, const char *query, int32_t qlen, gsa_result *out);
+
+/* ---- stage-level entry points (what the parity tests drive) --------------
+ * gsa_set_query uploads a contig; gsa_run_to(stage) advances the same
+ * eight-stage sequence the oracle uses:
+ *  1 IdentifyLocalMEM + SeedGrouping            GSAlign.cpp:51-107,126-143,492-495
+ *  2 GenerateAlignmentBlocks                    GSAlign.cpp:305-391,497
+ *  3 CheckAlnBlockOverlaps                      ProcessCandidateAlignment.cpp:189-239
+ *  4 CheckAlnBlockLargeGaps + RemoveBadAlnBlocks  :120-156,72-79 ; KmerAnalysis.cpp:78-121
+ *  5 CheckAlnBlockSpanMultiSeqs + RemoveBadAlnBlocks  :81-118
+ *  6 EstChromosomeSimilarity + RemoveRedundantAlnBlocks(1),(2)   GSAlign.cpp:393-471
+ *  7 FillAlnBlockGaps                           ProcessCandidateAlignment.cpp:241-276
+ *  8 GenerateFragAlignment + identity filter    ProcessCandidateAlignment.cpp:290-351, GSAlign.cpp:523-540
+ */
+int gsa_set_query(gsa_ctx *ctx, const char *query, int32_t qlen);
+int gsa_run_to(gsa_ctx *ctx, int stage);
+
+/* stage 1 outputs: SeedVec in final order, and the SeedGrouping ranges */
+int64_t gsa_seed_count(gsa_ctx *ctx);
+int  gsa_get_seeds(gsa_ctx *ctx, gsa_seed *out);                   /* out[gsa_seed_count] */
+int  gsa_group_count(gsa_ctx *ctx);
+int  gsa_get_groups(gsa_ctx *ctx, int32_t *beg, int32_t *end);
+/* stage >= 2 outputs: the current AlnBlockVec */
+int  gsa_get_blocks(gsa_ctx *ctx, gsa_result *out);
+
+/* ---- leaf operators ------------------------------------------------------ */
+/* BWT_Search (bwt_search.cpp:141-185) for a batch of (start, stop) windows of
+ * the current query: out_len[i] = match length, out_freq[i] = accepted hit
+ * count (0 if rejected), out_loc[100*i ..] = located positions. */
+int gsa_bwt_search_batch(gsa_ctx *ctx, int32_t n, const int32_t *start, const int32_t *stop,
+                         int32_t *out_len, int32_t *out_freq, int64_t *out_loc);
+
+/* ksw2_alignment (ksw2_alignment.cpp:251-273) for a batch of fragment pairs:
+ * s1 = reference-side fragment (length m), s2 = query-side fragment (length n),
+ * given as offsets into two byte pools.  ops receives, per pair, the forward
+ * M/D/I string ('D' = gap in s1, 'I' = gap in s2) at ops_off[i]; ops_len[i]
+ * <= m+n.  Caller sizes ops as sum(m+n). */
+int gsa_ksw2_batch(gsa_ctx *ctx, int32_t n_pairs,
+                   const char *pool1, const int64_t *off1, const int32_t *len1,
+                   const char *pool2, const int64_t *off2, const int32_t *len2,
+                   char *ops, const int64_t *ops_off, int32_t *ops_len);
+
+/* CalGapSimilarity (KmerAnalysis.cpp:78-121) on the current query, batch */
+int gsa_gap_similarity_batch(gsa_ctx *ctx, int32_t n, const int32_t *q1, const int32_t *q2,
+                             const int64_t *r1, const int64_t *r2, int32_t *similar);
+
+/* ---- measurement ---------------------------------------------------------
+ * Event counters and HIP-event timings of the last gsa_align_contig /
+ * gsa_run_to sequence.  counters: [0] Occ blocks read by seed extension,
+ * [1] LF steps, [2] located hits, [3] seeds, [4] DP cells, [5] DP jobs,
+ * [6] sum(m+n) over DP jobs, [7] reserved.  kernel_ms: per-kernel-family device
+ * time measured with hipEvents on the library's stream:
+ * [0] seed search [1] locate [2] sorts [3] chaining (S2) [4] refinement (S3-S6)
+ * [5] DP + string materialisation [6] total device time [7] host list logic. */
+int gsa_get_counters(gsa_ctx *ctx, uint64_t counters[8]);
+int gsa_get_timings(gsa_ctx *ctx, float kernel_ms[8]);
+int gsa_set_profiling(gsa_ctx *ctx, int enable);   /* per-stage hipEvent timing on/off (default off) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

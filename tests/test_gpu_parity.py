@@ -1,0 +1,113 @@
+"""Parity of the HIP path (through the C ABI) with the oracle, on a real MI355X.
+
+Bar: bit-exact -- every seed, group, block, gap record, score and gapped string."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_stage_equal
+from gsalign_amd import capi, indexio, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(cx_index):
+    a = capi.Aligner(cx_index)
+    yield a
+    a.close()
+
+
+@pytest.fixture(scope="module")
+def ora(oracle_built, cx_index):
+    o = oracle_built.Oracle(cx_index)
+    yield o
+    o.close()
+
+
+def test_bwt_search_leaf_operator(gpu, ora, cx_queries):
+    rng = np.random.default_rng(1)
+    for ci in (0, 1, 4):
+        seq = cx_queries[ci][1]
+        gpu.set_query(seq); ora.set_query(seq)
+        starts = rng.integers(0, seq.size - 1, size=400).astype(np.int32)
+        starts = np.array([s for s in starts if seq[s] in b"ACGTacgt"], np.int32)
+        stops = np.minimum((starts // 10000 + 1) * 10000, seq.size).astype(np.int32)
+        ln, fr, loc = gpu.bwt_search_batch(starts, stops)
+        for i, (s, e) in enumerate(zip(starts, stops)):
+            olen, olocs = ora.bwt_search(int(s), int(e))
+            assert ln[i] == olen and fr[i] == olocs.size and np.array_equal(loc[i, :fr[i]], olocs), (ci, s, e)
+
+
+def test_ksw2_leaf_operator_golden(gpu):
+    d = np.load(os.path.join(GOLDEN, "ksw2_pairs.npz"))
+    n = d["s1_off"].size - 1
+    s1 = [d["s1"][d["s1_off"][i]:d["s1_off"][i + 1]].tobytes() for i in range(n)]
+    s2 = [d["s2"][d["s2_off"][i]:d["s2_off"][i + 1]].tobytes() for i in range(n)]
+    ops = gpu.ksw2_batch(s1, s2)
+    for i in range(n):
+        a1 = d["a1"][d["a1_off"][i]:d["a1_off"][i + 1]].tobytes(); a2 = d["a2"][d["a2_off"][i]:d["a2_off"][i + 1]].tobytes()
+        assert capi.apply_ops(s1[i], s2[i], ops[i]) == (a1, a2), f"pair {i} m={len(s1[i])} n={len(s2[i])}"
+
+
+def test_gap_similarity_leaf_operator_golden(gpu, cx_queries):
+    rows = np.load(os.path.join(GOLDEN, "gapsim.npz"))["rows"]
+    for ci in np.unique(rows[:, 0]):
+        sel = rows[rows[:, 0] == ci]
+        gpu.set_query(cx_queries[int(ci)][1])
+        got = gpu.gap_similarity_batch(sel[:, 1], sel[:, 2], sel[:, 3], sel[:, 4])
+        assert np.array_equal(got, sel[:, 5].astype(np.int32)), np.flatnonzero(got != sel[:, 5])[:10]
+
+
+@pytest.mark.parametrize("golden,params", [("cx_stages.npz", {}), ("cx_sen_stages.npz", dict(sen=1, clr=50))])
+def test_stages_vs_golden(gpu, cx_queries, golden, params):
+    want = np.load(os.path.join(GOLDEN, golden))
+    gpu.set_params(**params)
+    for ci, (name, seq) in enumerate(cx_queries):
+        gpu.set_query(seq)
+        assert_stage_equal(gpu.dump_stages(8), want, prefix=f"c{ci}_")
+    gpu.set_params()
+
+
+@pytest.mark.parametrize("seed,params", [(41, {}), (42, dict(sen=1, clr=50)), (43, dict(one=1, ind=40, clr=300, alen=1000)), (44, dict(idy=95, slen=12))])
+def test_stages_vs_oracle_fresh_inputs(oracle_built, tmp_path, seed, params):
+    # a fresh complex pair; index built by the reference's bwt_index when oracle/_ref travelled, else skip
+    if not oracle_built.have_ref():
+        pytest.skip("oracle/_ref not present")
+    refs, qrys = synth.make_complex(seed)
+    rf, px = str(tmp_path / "r.fa"), str(tmp_path / "r")
+    synth.write_fasta(rf, refs); oracle_built.ref_build_index(rf, px)
+    idx = indexio.load_index(px)
+    o = oracle_built.Oracle(idx, params); g = capi.Aligner(idx, **params)
+    for name, seq in qrys:
+        o.set_query(seq); g.set_query(seq)
+        want = o.dump_stages(8)
+        assert_stage_equal(g.dump_stages(8), want)
+    o.close(); g.close()
+
+
+def test_align_contig_drop_in(gpu, ora, cx_queries):
+    for name, seq in cx_queries[:5]:
+        ora.set_query(seq); ora.run_to(8)
+        want = ora.blocks(with_aln=True)
+        r = gpu.align_contig(seq)
+        got = gpu.blocks_as_dump(with_aln=True)
+        for k, v in want.items():
+            assert np.array_equal(got[k], v), (name, k)
+        c = gpu.counters(); oc = ora.counters()
+        assert c[2] == oc[2] and c[3] == oc[3] and c[0] == oc[0] and c[1] == oc[1], (c, oc)
+
+
+def test_midsize_pair_2pct(oracle_built, tmp_path):
+    if not oracle_built.have_ref():
+        pytest.skip("oracle/_ref not present")
+    refs, qrys = synth.make_pair(1000000, 2, 0.02, seed=9)
+    rf, px = str(tmp_path / "r.fa"), str(tmp_path / "r")
+    synth.write_fasta(rf, refs); oracle_built.ref_build_index(rf, px)
+    idx = indexio.load_index(px)
+    o = oracle_built.Oracle(idx); g = capi.Aligner(idx)
+    for name, seq in qrys:
+        o.set_query(seq); g.set_query(seq)
+        assert_stage_equal(g.dump_stages(8), o.dump_stages(8))
+    o.close(); g.close()
