@@ -160,6 +160,19 @@ class Aligner:
         a2 = np.ctypeslib.as_array(C.cast(res.aln2, C.POINTER(C.c_uint8)), shape=(na,)).copy() if na else np.zeros(0, np.uint8)
         return dict(blocks=blocks, frags=frags, aln1=a1, aln2=a2)
 
+    def raw_result(self) -> Result:
+        """The gsa_result view (pointers into library-owned memory, no copies)."""
+        res = Result()
+        self._ck(self.lib.gsa_get_blocks(self.ctx, C.byref(res)))
+        return res
+
+    def block_records(self) -> np.ndarray:
+        """uint8 [n_blocks, 40]: the finished gsa_block records (copied; small)."""
+        res = self.raw_result()
+        if not res.n_blocks:
+            return np.zeros((0, 40), np.uint8)
+        return np.ctypeslib.as_array(C.cast(res.blocks, C.POINTER(C.c_uint8)), shape=(res.n_blocks * 40,)).reshape(-1, 40).copy()
+
     def blocks(self) -> dict:
         res = Result()
         self._ck(self.lib.gsa_get_blocks(self.ctx, C.byref(res)))

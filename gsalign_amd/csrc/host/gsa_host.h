@@ -1,0 +1,65 @@
+// gsalign_amd/csrc/host/gsa_host.h -- CPU-side parts of the aligner that
+// north_star keeps on the host: index build/load, query FASTA loading, MAF / ALN
+// / VCF emission.  Plain C++ (g++), no HIP.  Built twice: into the CLI
+// (GSAlign_hip) and into libgsa_host.so, whose C entry points let the CPU tests
+// drive the emitters and the index builder without a GPU.
+#ifndef GSA_HOST_H
+#define GSA_HOST_H
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include "gsa_hip.h"
+
+struct HostIndex {
+	uint64_t primary = 0, L2[5] = {0, 0, 0, 0, 0};
+	std::vector<uint32_t> bwt;
+	std::vector<uint64_t> sa;
+	int64_t G = 0;
+	std::vector<std::string> chr_name;
+	std::vector<int32_t> chr_len;
+	std::vector<int64_t> chr_fwd, chr_rev;        // FowardLocation / ReverseLocation (bwt_index.cpp:247-248)
+	std::vector<int64_t> end_key; std::vector<int32_t> end_chr;   // ChrLocMap as sorted arrays
+	std::string ref;                              // RefSequence: 2G ASCII
+
+	void fill_view(gsa_index_view *v) const;
+	// GenCoordinateInfo (tools.cpp:120-140)
+	void coordinate(int64_t rpos, int *bdir, int *chr, int *gpos) const;
+};
+
+struct QueryContig { std::string name, seq; };
+
+// index files (reference src/bwt_index.cpp:25-264, src/GetData.cpp:8-24)
+bool gsah_index_files_exist(const std::string &prefix);
+bool gsah_load_index(const std::string &prefix, HostIndex &idx, std::string &err);
+// bwa_idx_build (reference src/BWT_Index/bwtindex.c:77-149): byte-identical .bwt .sa .pac .ann .amb
+bool gsah_build_index(const std::string &fasta, const std::string &prefix, std::string &err);
+// LoadQueryFile / TrimChromosomeName / CheckQuerySeq (reference src/main.cpp:35-114)
+bool gsah_load_query(const std::string &path, std::vector<QueryContig> &out, std::string &err);
+
+// one finished contig, as delivered by gsa_align_contig
+struct ContigResult {
+	std::vector<gsa_block> blocks;
+	std::vector<gsa_frag> frags;
+	std::string aln1, aln2;
+	void assign(const gsa_result &r);
+};
+
+struct Variant { int pos, chr_idx, query_idx, type; std::string ref_frag, alt_frag; };   // structure.h:124-132
+
+struct Emitter {
+	const HostIndex *idx = nullptr;
+	bool allow_dup = true;                 // !-unique
+	std::vector<Variant> vars;             // VarVec
+	int n_snv = 0, n_ins = 0, n_del = 0;
+	// OutputMAF (tools.cpp:149-220).  first = (QueryChrIdx == 0).  May shorten the last record of a block (iExtension).
+	void maf(FILE *fp, bool first, const QueryContig &q, ContigResult &r) const;
+	// OutputAlignment (tools.cpp:222-286)
+	void aln(FILE *fp, const QueryContig &q, ContigResult &r) const;
+	// VariantIdentification (SeqVariant.cpp:12-119)
+	void variants(int query_idx, const QueryContig &q, const ContigResult &r);
+	// OutputSequenceVariants (SeqVariant.cpp:121-143)
+	void vcf(FILE *fp, const std::string &reference_label);
+};
+
+#endif

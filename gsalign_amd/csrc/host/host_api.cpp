@@ -1,0 +1,44 @@
+// gsalign_amd/csrc/host/host_api.cpp -- C entry points of libgsa_host.so, so that
+// the CPU test-suite can drive the host-side components (index builder, loader,
+// emitters) without a GPU.  The CLI uses the C++ interface directly.
+#include <cstring>
+#include "gsa_host.h"
+
+extern "C" {
+
+// returns 0 on success; err (>= 256 bytes) receives the message otherwise
+int gsah_c_build_index(const char *fasta, const char *prefix, char *err)
+{
+	std::string e;
+	if (gsah_build_index(fasta, prefix, e)) return 0;
+	if (err) { strncpy(err, e.c_str(), 255); err[255] = 0; }
+	return -1;
+}
+
+// Emit MAF + VCF for a whole query FASTA given, per contig, a finished gsa_result.
+// get_result(user, contig_index, seq, len, &result) is called once per contig, in order.
+typedef int (*gsah_result_cb)(void *user, int contig, const char *seq, int len, gsa_result *out);
+
+int gsah_c_emit(const char *index_prefix, const char *query_fa, const char *maf_path, const char *vcf_path, const char *reference_label,
+                int allow_dup, gsah_result_cb cb, void *user, char *err)
+{
+	std::string e; HostIndex idx; std::vector<QueryContig> qs;
+	if (!gsah_load_index(index_prefix, idx, e) || !gsah_load_query(query_fa, qs, e)) { if (err) { strncpy(err, e.c_str(), 255); err[255] = 0; } return -1; }
+	Emitter em; em.idx = &idx; em.allow_dup = allow_dup != 0;
+	for (size_t ci = 0; ci < qs.size(); ci++) {
+		gsa_result res; memset(&res, 0, sizeof(res));
+		if (cb(user, (int)ci, qs[ci].seq.data(), (int)qs[ci].seq.size(), &res) != 0) { if (err) strcpy(err, "result callback failed"); return -2; }
+		if (res.n_blocks == 0) continue;                         // GSAlign.cpp:541
+		ContigResult cr; cr.assign(res);
+		FILE *fp = fopen(maf_path, ci == 0 ? "w" : "a");         // tools.cpp:158-163
+		if (!fp) { if (err) strcpy(err, "cannot open MAF output"); return -3; }
+		em.maf(fp, ci == 0, qs[ci], cr); fclose(fp);
+		em.variants((int)ci, qs[ci], cr);
+	}
+	FILE *fp = fopen(vcf_path, "w");
+	if (!fp) { if (err) strcpy(err, "cannot open VCF output"); return -3; }
+	em.vcf(fp, reference_label); fclose(fp);
+	return 0;
+}
+
+} // extern "C"

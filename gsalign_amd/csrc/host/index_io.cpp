@@ -1,0 +1,299 @@
+// gsalign_amd/csrc/host/index_io.cpp -- BWA-style index files: loader and builder.
+//
+// Loader  : reference src/bwt_index.cpp:25-264 (bwa_idx_load, RestoreReferenceInfo),
+//           src/GetData.cpp:8-24 (CheckBWAIndexFiles).
+// Builder : reference src/BWT_Index/bwtindex.c:77-149 (bwa_idx_build),
+//           bntseq.c:59-88,110-211 (pack FASTA, N -> lrand48()&3 with seed 11,
+//           .ann/.amb text), bwt.c:101-123 (sampled SA).
+// The reference grows the BWT incrementally (BWT-SW, bwt_gen.c); the files it
+// produces are mathematically determined by the FASTA, so this
+// builder sorts all suffixes with a linear-time SA-IS and derives BWT, Occ and
+// the SA samples from that -- the output is byte-identical.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <zlib.h>
+#include "gsa_host.h"
+
+namespace {
+
+inline int nt4(unsigned char c)
+{
+	switch (c | 0x20) { case 'a': return 0; case 'c': return 1; case 'g': return 2; case 't': return 3; default: return 4; }
+}
+
+bool read_file(const std::string &path, std::vector<uint8_t> &out)
+{
+	FILE *fp = fopen(path.c_str(), "rb");
+	if (!fp) return false;
+	fseek(fp, 0, SEEK_END); long n = ftell(fp); fseek(fp, 0, SEEK_SET);
+	out.resize((size_t)n);
+	size_t got = n ? fread(out.data(), 1, (size_t)n, fp) : 0;
+	fclose(fp);
+	return got == (size_t)n;
+}
+
+// ---- SA-IS (Nong, Zhang, Chan): suffix array of T[0..n), T[n-1] = unique smallest ----
+template <class Ch>
+void induce(const Ch *T, int32_t *SA, int32_t n, int32_t K, const std::vector<bool> &isS, std::vector<int32_t> &bkt, const std::vector<int32_t> &cnt)
+{
+	int32_t sum = 0;
+	for (int32_t c = 0; c < K; c++) { bkt[c] = sum; sum += cnt[c]; }                 // bucket starts
+	for (int32_t i = 0; i < n; i++) { int32_t j = SA[i] - 1; if (SA[i] > 0 && !isS[j]) SA[bkt[T[j]]++] = j; }
+	sum = 0;
+	for (int32_t c = 0; c < K; c++) { sum += cnt[c]; bkt[c] = sum; }                 // bucket ends
+	for (int32_t i = n - 1; i >= 0; i--) { int32_t j = SA[i] - 1; if (SA[i] > 0 && isS[j]) SA[--bkt[T[j]]] = j; }
+}
+
+template <class Ch>
+void sais(const Ch *T, int32_t *SA, int32_t n, int32_t K)
+{
+	if (n == 1) { SA[0] = 0; return; }
+	std::vector<bool> isS(n);
+	isS[n - 1] = true;
+	for (int32_t i = n - 2; i >= 0; i--) isS[i] = T[i] < T[i + 1] || (T[i] == T[i + 1] && isS[i + 1]);
+	auto isLMS = [&](int32_t i) { return i > 0 && isS[i] && !isS[i - 1]; };
+	std::vector<int32_t> cnt(K, 0), bkt(K);
+	for (int32_t i = 0; i < n; i++) cnt[T[i]]++;
+	auto ends = [&]() { int32_t s = 0; for (int32_t c = 0; c < K; c++) { s += cnt[c]; bkt[c] = s; } };
+	// 1. sort LMS substrings
+	std::fill(SA, SA + n, -1);
+	ends();
+	for (int32_t i = 1; i < n; i++) if (isLMS(i)) SA[--bkt[T[i]]] = i;
+	induce(T, SA, n, K, isS, bkt, cnt);
+	int32_t n1 = 0;
+	for (int32_t i = 0; i < n; i++) if (isLMS(SA[i])) SA[n1++] = SA[i];
+	std::fill(SA + n1, SA + n, -1);
+	int32_t name = 0, prev = -1;
+	for (int32_t i = 0; i < n1; i++) {
+		int32_t pos = SA[i]; bool diff = false;
+		if (prev < 0) diff = true;
+		else for (int32_t d = 0;; d++) {
+			if (pos + d >= n || prev + d >= n || T[pos + d] != T[prev + d] || isS[pos + d] != isS[prev + d]) { diff = true; break; }
+			if (d > 0 && (isLMS(pos + d) || isLMS(prev + d))) { diff = !(isLMS(pos + d) && isLMS(prev + d)); break; }
+		}
+		if (diff) { name++; prev = pos; }
+		SA[n1 + (pos >> 1)] = name - 1;
+	}
+	for (int32_t i = n - 1, j = n - 1; i >= n1; i--) if (SA[i] >= 0) SA[j--] = SA[i];
+	int32_t *s1 = SA + n - n1, *SA1 = SA;
+	// 2. order of the LMS suffixes
+	if (name < n1) sais<int32_t>(s1, SA1, n1, name);
+	else for (int32_t i = 0; i < n1; i++) SA1[s1[i]] = i;
+	// 3. induce everything from the sorted LMS suffixes
+	for (int32_t i = 1, j = 0; i < n; i++) if (isLMS(i)) s1[j++] = i;
+	for (int32_t i = 0; i < n1; i++) SA1[i] = s1[SA1[i]];
+	std::fill(SA + n1, SA + n, -1);
+	ends();
+	for (int32_t i = n1 - 1; i >= 0; i--) { int32_t j = SA[i]; SA[i] = -1; SA[--bkt[T[j]]] = j; }
+	induce(T, SA, n, K, isS, bkt, cnt);
+}
+
+struct FaRec { std::string name, comment, seq; };
+
+// kseq-style FASTA parsing (BWT_Index/kseq.h:176-215): name up to the first white space,
+// the rest of the header line is the comment; plain or gzip'd input.
+bool read_fasta_gz(const std::string &path, std::vector<FaRec> &recs)
+{
+	gzFile fp = gzopen(path.c_str(), "r");
+	if (!fp) return false;
+	std::string data; char buf[1 << 16]; int n;
+	while ((n = gzread(fp, buf, sizeof(buf))) > 0) data.append(buf, (size_t)n);
+	gzclose(fp);
+	size_t p = 0, N = data.size();
+	while (p < N && data[p] != '>' && data[p] != '@') p++;
+	while (p < N) {
+		p++;                                   // skip '>'
+		FaRec r;
+		size_t e = p; while (e < N && !isspace((unsigned char)data[e])) e++;
+		r.name = data.substr(p, e - p);
+		if (e < N && data[e] != '\n') { size_t le = data.find('\n', e + 1); if (le == std::string::npos) le = N; r.comment = data.substr(e + 1, le - e - 1); e = le; }
+		while (!r.comment.empty() && r.comment.back() == '\r') r.comment.pop_back();
+		p = e < N ? e + 1 : N;
+		while (p < N && data[p] != '>') {
+			size_t le = data.find('\n', p); if (le == std::string::npos) le = N;
+			size_t ce = le; while (ce > p && data[ce - 1] == '\r') ce--;
+			r.seq.append(data, p, ce - p);
+			p = le < N ? le + 1 : N;
+		}
+		recs.push_back(r);
+	}
+	return true;
+}
+
+void fput(FILE *fp, const void *p, size_t n) { if (n) fwrite(p, 1, n, fp); }
+
+} // namespace
+
+void HostIndex::fill_view(gsa_index_view *v) const
+{
+	v->primary = primary; for (int i = 0; i < 5; i++) v->L2[i] = L2[i];
+	v->bwt = bwt.data(); v->bwt_words = bwt.size(); v->sa = sa.data(); v->n_sa = sa.size();
+	v->ref = ref.data(); v->G = G; v->chr_len = chr_len.data(); v->n_chr = (int32_t)chr_len.size();
+}
+
+void HostIndex::coordinate(int64_t rpos, int *bdir, int *chr, int *gpos) const
+{
+	size_t k = std::lower_bound(end_key.begin(), end_key.end(), rpos) - end_key.begin();
+	*chr = end_chr[k];
+	if (rpos < G) { *bdir = 1; *gpos = (int)(rpos + 1 - chr_fwd[*chr]); }
+	else { *bdir = 0; *gpos = (int)(end_key[k] - rpos + 1); }
+}
+
+bool gsah_index_files_exist(const std::string &prefix)
+{
+	for (const char *ext : { ".ann", ".amb", ".pac" }) { FILE *fp = fopen((prefix + ext).c_str(), "r"); if (!fp) return false; fclose(fp); }
+	return true;
+}
+
+bool gsah_load_index(const std::string &prefix, HostIndex &idx, std::string &err)
+{
+	std::vector<uint8_t> raw;
+	if (!read_file(prefix + ".bwt", raw) || raw.size() < 40) { err = "cannot read " + prefix + ".bwt"; return false; }
+	memcpy(&idx.primary, raw.data(), 8); idx.L2[0] = 0; memcpy(&idx.L2[1], raw.data() + 8, 32);
+	idx.bwt.resize((raw.size() - 40) / 4); memcpy(idx.bwt.data(), raw.data() + 40, idx.bwt.size() * 4);
+	const uint64_t seq_len = idx.L2[4];
+	if (!read_file(prefix + ".sa", raw) || raw.size() < 56) { err = "cannot read " + prefix + ".sa"; return false; }
+	uint64_t sa_intv; memcpy(&sa_intv, raw.data() + 40, 8);
+	if ((sa_intv & 0xffffffffu) != 32) { err = "unexpected SA interval"; return false; }
+	const uint64_t n_sa = (seq_len + 32) / 32;
+	if (raw.size() < 56 + (n_sa - 1) * 8) { err = prefix + ".sa is truncated"; return false; }
+	idx.sa.resize(n_sa); idx.sa[0] = (uint64_t)-1; memcpy(idx.sa.data() + 1, raw.data() + 56, (n_sa - 1) * 8);
+	FILE *fp = fopen((prefix + ".ann").c_str(), "r");
+	if (!fp) { err = "cannot read " + prefix + ".ann"; return false; }
+	long long G; int n_seqs; unsigned seed;
+	if (fscanf(fp, "%lld%d%u", &G, &n_seqs, &seed) != 3) { fclose(fp); err = "bad .ann"; return false; }
+	idx.G = G; idx.chr_name.clear(); idx.chr_len.clear();
+	char str[10240];
+	for (int i = 0; i < n_seqs; i++) {
+		unsigned gi; long long off; int len, nambs, ch;
+		if (fscanf(fp, "%u%10239s", &gi, str) != 2) { fclose(fp); err = "bad .ann"; return false; }
+		idx.chr_name.push_back(str);
+		while ((ch = fgetc(fp)) != '\n' && ch != EOF);
+		if (fscanf(fp, "%lld%d%d", &off, &len, &nambs) != 3) { fclose(fp); err = "bad .ann"; return false; }
+		idx.chr_len.push_back(len);
+	}
+	fclose(fp);
+	if (seq_len != (uint64_t)(2 * idx.G)) { err = "index is not forward+reverse"; return false; }
+	if (!read_file(prefix + ".pac", raw) || (int64_t)raw.size() < idx.G / 4 + (idx.G % 4 ? 1 : 0)) { err = "cannot read " + prefix + ".pac"; return false; }
+	// RestoreReferenceInfo (bwt_index.cpp:229-264)
+	idx.ref.resize((size_t)(2 * idx.G));
+	const int64_t G2 = 2 * idx.G;
+	for (int64_t f = 0; f < idx.G; f++) {
+		const int b = raw[f >> 2] >> ((~f & 3) << 1) & 3;
+		idx.ref[f] = "ACGT"[b]; idx.ref[G2 - 1 - f] = "TGCA"[b];
+	}
+	idx.chr_fwd.clear(); idx.chr_rev.clear(); idx.end_key.clear(); idx.end_chr.clear();
+	int64_t tot = 0; std::vector<std::pair<int64_t, int32_t> > ends;
+	for (int i = 0; i < n_seqs; i++) {
+		idx.chr_fwd.push_back(tot); tot += idx.chr_len[i]; idx.chr_rev.push_back(G2 - tot);
+		ends.push_back(std::make_pair(idx.chr_fwd[i] + idx.chr_len[i] - 1, i)); ends.push_back(std::make_pair(idx.chr_rev[i] + idx.chr_len[i] - 1, i));
+	}
+	std::sort(ends.begin(), ends.end());
+	for (size_t i = 0; i < ends.size(); i++) { idx.end_key.push_back(ends[i].first); idx.end_chr.push_back(ends[i].second); }
+	return true;
+}
+
+bool gsah_build_index(const std::string &fasta, const std::string &prefix, std::string &err)
+{
+	std::vector<FaRec> recs;
+	if (!read_fasta_gz(fasta, recs) || recs.empty()) { err = "cannot read FASTA " + fasta; return false; }
+	// ---- pack: bns_fasta2bntseq / add1 (bntseq.c:110-211) ----
+	struct Hole { int64_t off; int32_t len; char amb; };
+	std::vector<Hole> holes; std::vector<int64_t> offs; std::vector<int32_t> nambs;
+	std::vector<uint8_t> codes;
+	srand48(11);
+	for (size_t s = 0; s < recs.size(); s++) {
+		offs.push_back((int64_t)codes.size()); nambs.push_back(0);
+		int lasts = 0;
+		for (size_t i = 0; i < recs[s].seq.size(); i++) {
+			const unsigned char ch = (unsigned char)recs[s].seq[i];
+			int c = nt4(ch);
+			if (c >= 4) {
+				if (lasts == ch) holes.back().len++;
+				else { Hole h = { offs[s] + (int64_t)i, 1, (char)ch }; holes.push_back(h); nambs[s]++; }
+				c = (int)(lrand48() & 3);
+			}
+			lasts = ch;
+			codes.push_back((uint8_t)c);
+		}
+	}
+	const int64_t G = (int64_t)codes.size();
+	if (G <= 0) { err = "empty reference"; return false; }
+	if (2 * G + 1 >= (1ll << 31)) { err = "reference too long for the 32-bit suffix sorter (> 1 Gbp)"; return false; }
+	// .pac (forward only; bntseq.c:192-201)
+	{
+		std::vector<uint8_t> pac((size_t)((G >> 2) + ((G & 3) ? 1 : 0)), 0);
+		for (int64_t l = 0; l < G; l++) pac[l >> 2] |= codes[l] << ((~l & 3) << 1);
+		FILE *fp = fopen((prefix + ".pac").c_str(), "wb"); if (!fp) { err = "cannot write " + prefix + ".pac"; return false; }
+		fput(fp, pac.data(), pac.size());
+		uint8_t ct = 0; if (G % 4 == 0) fput(fp, &ct, 1);
+		ct = (uint8_t)(G % 4); fput(fp, &ct, 1);
+		fclose(fp);
+	}
+	// .ann / .amb (bns_dump, bntseq.c:59-88)
+	{
+		FILE *fp = fopen((prefix + ".ann").c_str(), "w"); if (!fp) { err = "cannot write .ann"; return false; }
+		fprintf(fp, "%lld %d %u\n", (long long)G, (int)recs.size(), 11u);
+		for (size_t s = 0; s < recs.size(); s++) {
+			const std::string anno = recs[s].comment.empty() ? "(null)" : recs[s].comment;
+			fprintf(fp, "%d %s", 0, recs[s].name.c_str());
+			if (!anno.empty()) fprintf(fp, " %s\n", anno.c_str()); else fprintf(fp, "\n");
+			fprintf(fp, "%lld %d %d\n", (long long)offs[s], (int)recs[s].seq.size(), nambs[s]);
+		}
+		fclose(fp);
+		fp = fopen((prefix + ".amb").c_str(), "w"); if (!fp) { err = "cannot write .amb"; return false; }
+		fprintf(fp, "%lld %d %u\n", (long long)G, (int)recs.size(), (unsigned)holes.size());
+		for (size_t h = 0; h < holes.size(); h++) fprintf(fp, "%lld %d %c\n", (long long)holes[h].off, holes[h].len, holes[h].amb);
+		fclose(fp);
+	}
+	// ---- text = forward + reverse complement, then '$' ----
+	const int64_t S = 2 * G; const int32_t n = (int32_t)(S + 1);
+	std::vector<uint8_t> T((size_t)n);
+	for (int64_t i = 0; i < G; i++) { T[i] = codes[i] + 1; T[S - 1 - i] = (3 - codes[i]) + 1; }
+	T[S] = 0;
+	std::vector<int32_t> SA((size_t)n);
+	sais<uint8_t>(T.data(), SA.data(), n, 5);
+	// ---- BWT without '$', primary, L2 ----
+	uint64_t primary = 0, L2[5] = {0, 0, 0, 0, 0};
+	std::vector<uint32_t> packed((size_t)((S + 15) / 16), 0);
+	{
+		int64_t k = 0;
+		for (int32_t i = 0; i < n; i++) {
+			if (SA[i] == 0) { primary = (uint64_t)i; continue; }
+			const uint32_t c = T[SA[i] - 1] - 1;
+			packed[k >> 4] |= c << ((~k & 15) << 1);
+			k++;
+		}
+		for (int64_t i = 0; i < S; i++) L2[T[i]]++;            // T[i] in 1..4 -> L2[1..4] counts
+		for (int c = 1; c < 5; c++) L2[c] += L2[c - 1];
+	}
+	// ---- interleave Occ every 128 (bwt_bwtupdate_core, bwtindex.c:53-75) ----
+	const uint64_t n_occ = (uint64_t)(S + 127) / 128 + 1;
+	std::vector<uint32_t> bwt(packed.size() + n_occ * 8, 0);
+	{
+		uint64_t c[4] = {0, 0, 0, 0}; size_t k = 0;
+		for (int64_t i = 0; i < S; i++) {
+			if (i % 128 == 0) { memcpy(&bwt[k], c, 32); k += 8; }
+			if (i % 16 == 0) bwt[k++] = packed[i >> 4];
+			c[packed[i >> 4] >> ((~i & 15) << 1) & 3]++;
+		}
+		memcpy(&bwt[k], c, 32); k += 8;
+		if (k != bwt.size()) { err = "internal: inconsistent bwt size"; return false; }
+	}
+	{
+		FILE *fp = fopen((prefix + ".bwt").c_str(), "wb"); if (!fp) { err = "cannot write .bwt"; return false; }
+		fput(fp, &primary, 8); fput(fp, &L2[1], 32); fput(fp, bwt.data(), bwt.size() * 4);
+		fclose(fp);
+	}
+	// ---- SA sampled every 32 rows (bwt_cal_sa + bwt_dump_sa, bwt.c:101-123,185-196) ----
+	{
+		const uint64_t n_sa = (uint64_t)(S + 32) / 32, intv = 32, seq_len = (uint64_t)S;
+		std::vector<uint64_t> sa(n_sa);
+		for (uint64_t i = 1; i < n_sa; i++) sa[i] = (uint64_t)SA[32 * i];
+		FILE *fp = fopen((prefix + ".sa").c_str(), "wb"); if (!fp) { err = "cannot write .sa"; return false; }
+		fput(fp, &primary, 8); fput(fp, &L2[1], 32); fput(fp, &intv, 8); fput(fp, &seq_len, 8); fput(fp, sa.data() + 1, (n_sa - 1) * 8);
+		fclose(fp);
+	}
+	return true;
+}

@@ -1,0 +1,129 @@
+// gsalign_amd/csrc/host/main.cpp -- GSAlign_hip: command-line front end with the
+// reference's surface (reference src/main.cpp:14-334): same flags, same defaults
+// (the CODE's defaults: -clr 200, -alen 200), same output files, with the per-contig
+// hot path handed to libgsa_hip.so (gsa_align_contig) instead of GenomeComparison's
+// pthread stages.  Extra flag: -gpu N (device ordinal).
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include "gsa_host.h"
+
+static void usage(const char *prog, int t, const gsa_params &p, int fmt)
+{
+	fprintf(stderr, "\nGenAlign v%s\n", "1.0.22");
+	fprintf(stderr, "Usage: %s [-i IndexFile Prefix / -r Reference file] -q QueryFile[Fasta]\n\n", prog);
+	fprintf(stderr, "Options: -t     INT     number of threads [%d] (accepted for compatibility; the hot path runs on the GPU)\n", t);
+	fprintf(stderr, "         -o     STR     Set the prefix of the output files [output]\n");
+	fprintf(stderr, "         -fmt   INT     Set the output format 1:maf, 2:aln [%d]\n", fmt);
+	fprintf(stderr, "         -idy   INT     Set the minimal sequence identity (0-100) of a local alignment [%d]\n", p.min_identity);
+	fprintf(stderr, "         -slen  INT     Set the minimal seed length [%d]\n", p.min_seed_len);
+	fprintf(stderr, "         -alen  INT     Set the minimal alignment length [%d]\n", p.min_aln_len);
+	fprintf(stderr, "         -ind   INT     Set the maximal indel size [%d]\n", p.max_indel);
+	fprintf(stderr, "         -clr   INT     Set the minimal cluster size [%d]\n", p.min_block_score);
+	fprintf(stderr, "         -unique        Output unique alignment only [false]\n");
+	fprintf(stderr, "         -sen           Sensitive mode [False]\n");
+	fprintf(stderr, "         -one           set one on one aligment mode[false]\n");
+	fprintf(stderr, "         -no_vcf        do not write the VCF file\n");
+	fprintf(stderr, "         -gpu   INT     GPU ordinal [0]\n\n");
+}
+
+static bool check_prefix(const char *p)                     // CheckOutputPrefix (main.cpp:116-138)
+{
+	if (strcmp(p, "/dev/null") == 0) return true;
+	for (size_t i = 0; i < strlen(p); i++) {
+		const int c = (unsigned char)p[i];
+		if (!isprint(c) || (c >= 32 && c <= 44) || (c >= 58 && c <= 64) || (c >= 123 && c <= 127)) { fprintf(stderr, "FatalError: Please specify a valid prefix name\n"); return false; }
+	}
+	return true;
+}
+
+static bool first_char_is_header(const char *path)          // CheckInputFile (main.cpp:49-64)
+{
+	FILE *fp = fopen(path, "r"); if (!fp) return false;
+	int c = fgetc(fp); fclose(fp);
+	return c == '>';
+}
+
+int main(int argc, char *argv[])
+{
+	gsa_params prm; gsa_default_params(&prm);
+	int threads = 8, fmt = 1, gpu = 0; bool vcf = true, allow_dup = true;
+	const char *index_prefix = NULL, *ref_fa = NULL, *query_fa = NULL, *out_prefix = NULL;
+	if (argc == 1 || strcmp(argv[1], "-h") == 0) { usage(argv[0], threads, prm, fmt); return 0; }
+	if (strcmp(argv[1], "index") == 0) {
+		if (argc == 4) { std::string e; if (!gsah_build_index(argv[2], argv[3], e)) { fprintf(stderr, "%s\n", e.c_str()); return 1; } }
+		else fprintf(stderr, "usage: %s index ref.fa prefix\n", argv[0]);
+		return 0;
+	}
+	for (int i = 1; i < argc; i++) {
+		const std::string a = argv[i];
+		if (a == "-i") index_prefix = argv[++i];
+		else if (a == "-r" && i + 1 < argc) ref_fa = argv[++i];
+		else if (a == "-q" && i + 1 < argc) query_fa = argv[++i];
+		else if (a == "-t" && i + 1 < argc) { if ((threads = atoi(argv[++i])) < 0) { fprintf(stderr, "Warning! Thread number should be greater than 0!\n"); threads = 16; } }
+		else if (a == "-slen" && i + 1 < argc) { prm.min_seed_len = atoi(argv[++i]); if (prm.min_seed_len < 10 || prm.min_seed_len > 30) { fprintf(stderr, "Warning! minimal seed length is between 10~20!\n"); return 0; } }
+		else if (a == "-ind" && i + 1 < argc) { prm.max_indel = atoi(argv[++i]); if (prm.max_indel < 10 || prm.max_indel > 100) { fprintf(stderr, "Warning! maximal indel size is between 10~100!\n"); return 0; } }
+		else if (a == "-sen" || a == "-sensitive") { prm.sensitive = 1; prm.min_aln_len = 200; prm.min_block_score = 50; }
+		else if (a == "-unique") allow_dup = false;
+		else if (a == "-no_vcf") vcf = false;
+		else if (a == "-one") prm.one_on_one = 1;
+		else if (a == "-idy" && i + 1 < argc) prm.min_identity = atoi(argv[++i]);
+		else if (a == "-alen" && i + 1 < argc) prm.min_aln_len = atoi(argv[++i]);
+		else if (a == "-clr" && i + 1 < argc) prm.min_block_score = atoi(argv[++i]);
+		else if (a == "-fmt" && i + 1 < argc) fmt = atoi(argv[++i]);
+		else if (a == "-o") out_prefix = argv[++i];
+		else if (a == "-gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
+		else if (a == "-dp" || a == "-d" || a == "-debug") { /* dot-plots / debug output: not supported, ignored */ }
+		else if ((a == "-gp" || a == "-obr") && i + 1 < argc) ++i;
+		else fprintf(stderr, "Warning! Unknow parameter: %s\n", argv[i]);
+	}
+	if ((index_prefix == NULL && ref_fa == NULL) || query_fa == NULL) { usage(argv[0], threads, prm, fmt); return 0; }
+	if (out_prefix == NULL) out_prefix = "output"; else if (!check_prefix(out_prefix)) return 0;
+
+	const time_t t0 = time(NULL);
+	fprintf(stderr, "Step1. Load the two genome sequences...\n");
+	std::string err; std::vector<QueryContig> qs;
+	if (!first_char_is_header(query_fa) || !gsah_load_query(query_fa, qs, err)) { fprintf(stderr, "Please check the query file: %s\n", query_fa); return 0; }
+	fprintf(stderr, "\tLoad the query sequences (%d %s)\n", (int)qs.size(), qs.size() > 1 ? "chromosomes" : "chromosome");
+	HostIndex idx; std::string prefix;
+	if (index_prefix != NULL && gsah_index_files_exist(index_prefix)) prefix = index_prefix;
+	else if (ref_fa != NULL && first_char_is_header(ref_fa)) {
+		prefix = ref_fa; size_t p = prefix.find_last_of('.'); if (p != std::string::npos && p > 0) prefix.resize(p);
+		if (!gsah_build_index(ref_fa, prefix, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+	} else { fprintf(stderr, "Please specify a valid reference genome\n"); return 0; }
+	if (!gsah_load_index(prefix, idx, err)) { fprintf(stderr, "\n\nError! Please check your input! (%s)\n", err.c_str()); return 1; }
+	fprintf(stderr, "\tLoad the reference sequences (%d %s)\n", (int)idx.chr_len.size(), idx.chr_len.size() > 1 ? "chromosomes" : "chromosome");
+
+	gsa_index_view view; idx.fill_view(&view);
+	gsa_ctx *ctx = NULL;
+	if (gsa_create(gpu, &view, &prm, &ctx) != GSA_OK) { fprintf(stderr, "GPU initialisation failed: %s\n", gsa_last_error(NULL)); return 2; }
+
+	const std::string maf = std::string(out_prefix) + ".maf", aln = std::string(out_prefix) + ".aln", vcfn = std::string(out_prefix) + ".vcf";
+	Emitter em; em.idx = &idx; em.allow_dup = allow_dup;
+	long long n_aln = 0, tot_len = 0, tot_match = 0, n_dup = 0;
+	fprintf(stderr, "Step2. Sequence analysis for all query chromosomes\n");
+	for (size_t ci = 0; ci < qs.size(); ci++) {
+		fprintf(stderr, "\tProcess query chromsomoe: %s...\n", qs[ci].name.c_str());
+		gsa_result res;
+		if (gsa_align_contig(ctx, qs[ci].seq.data(), (int32_t)qs[ci].seq.size(), &res) != GSA_OK) { fprintf(stderr, "GPU error: %s\n", gsa_last_error(ctx)); gsa_destroy(ctx); return 2; }
+		if (res.n_blocks == 0) continue;
+		ContigResult cr; cr.assign(res);
+		long long len = 0, score = 0;
+		for (size_t b = 0; b < cr.blocks.size(); b++) { len += cr.blocks[b].aln_len; score += cr.blocks[b].score; if (cr.blocks[b].bdup) n_dup++; }
+		n_aln += (long long)cr.blocks.size(); tot_len += len; tot_match += score;
+		fprintf(stderr, "\t\tProduce %d local alignments (length = %lld), ANI=%.2f%%\n", (int)cr.blocks.size(), len, 100 * (1.0 * score / len));
+		if (fmt == 1) { FILE *fp = fopen(maf.c_str(), ci == 0 ? "w" : "a"); if (fp) { em.maf(fp, ci == 0, qs[ci], cr); fclose(fp); } }
+		if (fmt == 2) { FILE *fp = fopen(aln.c_str(), ci == 0 ? "w" : "a"); if (fp) { em.aln(fp, qs[ci], cr); fclose(fp); } }
+		if (vcf) em.variants((int)ci, qs[ci], cr);
+	}
+	if (n_aln > 0) fprintf(stderr, "\tAlignment#=%d (total alignment length=%lld) ANI=%.2f%%, unique alignment#=%d\n", (int)n_aln, tot_len, 100 * (1.0 * tot_match / tot_len), (int)(n_aln - n_dup));
+	fprintf(stderr, "\tIt took %lld seconds for genome sequence alignment.\n", (long long)(time(NULL) - t0));
+	if (vcf) {
+		fprintf(stderr, "\nGSAlign identifies %d SNVs, %d insertions, and %d deletions [%s].\n\n", em.n_snv, em.n_ins, em.n_del, vcfn.c_str());
+		FILE *fp = fopen(vcfn.c_str(), "w");
+		if (fp) { em.vcf(fp, index_prefix != NULL ? index_prefix : ref_fa); fclose(fp); }
+	}
+	gsa_destroy(ctx);
+	return 0;
+}

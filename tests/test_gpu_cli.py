@@ -1,0 +1,39 @@
+"""End-to-end on the GPU box: the GSAlign_hip CLI (host C++ + libgsa_hip.so) must
+write MAF and VCF files byte-identical to the reference's on the golden inputs,
+and identical to the live reference binary (oracle/_ref) on a fresh input."""
+import os
+import subprocess
+
+import pytest
+
+from gsalign_amd import hostlib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def run_cli(cwd, *args):
+    subprocess.run([hostlib.CLI_PATH, *args], cwd=cwd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+@pytest.mark.parametrize("name,extra,maf,vcf", [("cx", [], "cx.maf", "cx.vcf"), ("cx", ["-sen"], "cx_sen.maf", "cx_sen.vcf"), ("small", [], "small.maf", "small.vcf")])
+def test_cli_golden(golden_dir, tmp_path, name, extra, maf, vcf):
+    run_cli(golden_dir, "-i", name, "-q", f"{name}.qry.fa", "-o", str(tmp_path / "out"), "-t", "1", *extra)
+    assert open(tmp_path / "out.maf", "rb").read() == open(os.path.join(golden_dir, maf), "rb").read()
+    assert open(tmp_path / "out.vcf", "rb").read() == open(os.path.join(golden_dir, vcf), "rb").read()
+
+
+def test_cli_builds_its_own_index_and_matches_live_reference(oracle_built, tmp_path):
+    if not oracle_built.have_ref():
+        pytest.skip("oracle/_ref not present")
+    refs, qrys = synth.make_pair(400000, 3, 0.03, seed=77)
+    qrys[2] = (qrys[2][0], synth.revcomp(qrys[2][1]))
+    d = str(tmp_path)
+    synth.write_fasta(os.path.join(d, "r.fa"), refs); synth.write_fasta(os.path.join(d, "q.fa"), qrys)
+    run_cli(d, "-r", "r.fa", "-q", "q.fa", "-o", "mine")                 # builds r.{bwt,sa,pac,ann,amb} itself
+    os.makedirs(os.path.join(d, "refidx"))
+    oracle_built.ref_build_index(os.path.join(d, "r.fa"), os.path.join(d, "refidx", "r"))
+    for ext in ("bwt", "sa", "pac", "ann", "amb"):
+        assert open(os.path.join(d, f"r.{ext}"), "rb").read() == open(os.path.join(d, "refidx", f"r.{ext}"), "rb").read(), ext
+    subprocess.run([oracle_built.REF_GSALIGN, "-r", "r.fa", "-q", "q.fa", "-o", "theirs", "-t", "1"], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert open(os.path.join(d, "mine.maf"), "rb").read() == open(os.path.join(d, "theirs.maf"), "rb").read()
+    assert open(os.path.join(d, "mine.vcf"), "rb").read() == open(os.path.join(d, "theirs.vcf"), "rb").read()
