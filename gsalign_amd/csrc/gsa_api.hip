@@ -54,6 +54,7 @@ int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gsa_fail(nullptr, GSA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); gsa_destroy(c); return GSA_ERR_HIP; } } while (0)
 	CK(hipSetDevice(device));
 	CK(hipStreamCreate(&c->stream));
+	CK(hipStreamCreate(&c->stream_aux[0])); CK(hipStreamCreate(&c->stream_aux[1]));
 	for (int i = 0; i < 16; i++) CK(hipEventCreate(&c->ev[i]));
 	const size_t bwt_bytes = ((idx->bwt_words + 15) / 16) * 64;          // whole 64-byte blocks
 	CK(hipMalloc(&c->d_bwt.p, bwt_bytes + 64)); c->d_bwt.cap = bwt_bytes + 64;
@@ -85,6 +86,8 @@ int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa
 	c->di.seq_len = idx->L2[4];
 	c->di.bwt = c->d_bwt.as<uint4>(); c->di.sa = c->d_sa.as<u64>(); c->di.ref = c->d_ref.as<uint8_t>(); c->di.G = idx->G;
 	c->di.chr_end = c->d_chr_end.as<i64>(); c->di.chr_of_end = c->d_chr_of_end.as<i32>(); c->di.n_ends = (i32)c->h_chr_end.size();
+	c->di.sa32 = nullptr; c->di.sa64 = nullptr; c->di.kmer = nullptr; c->di.kmer_k = 0;
+	if (int rcd = build_dense_sa(c, idx->n_sa)) { g_create_error = c->err; gsa_destroy(c); return rcd; }
 	gsa_params dp; gsa_default_params(&dp);
 	int rc = gsa_set_params(c, prm ? prm : &dp);
 	if (rc) { g_create_error = c->err; gsa_destroy(c); return rc; }
@@ -98,7 +101,7 @@ void gsa_destroy(gsa_ctx *c)
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
 	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->d_query, &c->tmp, &c->d_cnt,
-		&c->d_hit_row, &c->d_hit_qpos, &c->d_hit_len, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
+		&c->d_sa_dense, &c->d_kmer, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
 		&c->d_flag, &c->d_scan, &c->g_beg, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
 		&c->a_next, &c->a_brk, &c->a_aurank, &c->a_aulist, &c->a_runinfo, &c->w_best, &c->w_sum, &c->w_n, &c->d_flag2, &c->d_scan2, &c->d_i64a,
 		&c->b_q, &c->b_len, &c->b_r, &c->b_gb, &c->b_ge, &c->c_q, &c->c_len, &c->c_r, &c->c_gb, &c->c_ge, &c->c_bid, &c->blk_beg, &c->blk_end, &c->blk_score,
@@ -108,11 +111,12 @@ void gsa_destroy(gsa_ctx *c)
 	for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
 	for (int i = 0; i < 16; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+	for (int i = 0; i < 2; i++) if (c->stream_aux[i]) hipStreamDestroy(c->stream_aux[i]);
 	if (c->stream) hipStreamDestroy(c->stream);
 	delete c;
 }
 
-int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->profiling = enable != 0; return GSA_OK; }
+int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->profiling = (enable & 1) != 0; c->count_blocks = (enable & 2) != 0; return GSA_OK; }
 
 int gsa_set_query(gsa_ctx *c, const char *query, int32_t qlen)
 {
@@ -197,6 +201,6 @@ int gsa_get_blocks(gsa_ctx *c, gsa_result *out)
 }
 
 int gsa_get_counters(gsa_ctx *c, uint64_t counters[8]) { if (!c) return GSA_ERR_ARG; memcpy(counters, c->counters, sizeof(c->counters)); return GSA_OK; }
-int gsa_get_timings(gsa_ctx *c, float ms[8]) { if (!c) return GSA_ERR_ARG; memcpy(ms, c->kernel_ms, sizeof(c->kernel_ms)); return GSA_OK; }
+int gsa_get_timings(gsa_ctx *c, float ms[8]) { if (!c) return GSA_ERR_ARG; memcpy(ms, c->kernel_ms, sizeof(c->kernel_ms)); if (getenv("GSA_DEBUG")) fprintf(stderr, "[gsa] seed rounds max %llu, wave iters sum %llu max %llu\n", (unsigned long long)c->dbg[0], (unsigned long long)c->dbg[1], (unsigned long long)c->dbg[2]); return GSA_OK; }
 
 } // extern "C"

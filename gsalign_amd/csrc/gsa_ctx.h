@@ -26,10 +26,13 @@ struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf ra
 struct gsa_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t stream_aux[2] = {nullptr, nullptr};   // the DP size classes run concurrently
 	std::string err;
 	Params prm;
 	DevIndex di;
 	bool profiling = false;
+	bool count_blocks = false;                     // run the accounting build of the seed kernel (exact algorithmic Occ-block count)
+	u64 dbg[4] = {0, 0, 0, 0};
 	hipEvent_t ev[16];
 	float kernel_ms[8];
 	u64 counters[8];
@@ -50,7 +53,9 @@ struct gsa_ctx {
 	DevBuf d_cnt; u64 *h_cnt = nullptr;
 
 	// ---- stage 1 ----
-	DevBuf d_hit_row, d_hit_qpos, d_hit_len;       // pending hits from the search kernel
+	DevBuf d_kmer;                                 // top-of-tree jump table
+	DevBuf d_sa_dense;                             // one SA entry per BWT row (built at gsa_create)
+	DevBuf d_cand_s, d_cand_len, d_cand_x0, d_cand_freq, d_onpath;   // memoised matches of the search kernel + on-path bits
 	DevBuf d_key_a, d_key_b, d_val_a, d_val_b;     // sort ping-pong
 	i64 n_seeds = 0;
 	DevBuf s_q, s_len, s_r, s_gid;                 // seeds in (PosDiff,qPos) order + group id
@@ -106,6 +111,7 @@ template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 }
 
 // stage drivers (one per translation unit)
+int build_dense_sa(gsa_ctx *c, u64 n_sa);   // k_seed.hip
 int stage1_seed(gsa_ctx *c);          // k_seed.hip
 int stage2_chain(gsa_ctx *c);         // k_chain.hip
 int stage345_refine(gsa_ctx *c);      // k_refine.hip  (device part of S3, S4, S5 + leaf table)

@@ -7,6 +7,8 @@
 // One Occ query = one 64-byte block (4 x global_load_dwordx4 issued together),
 // then three 64-bit popcounts per 32 symbols instead of the reference's byte
 // table; the count is a pure function of (block, row) so results are identical.
+// Everything is written with selects instead of runtime-indexed arrays so that
+// nothing spills to scratch.
 #ifndef GSA_FM_H
 #define GSA_FM_H
 #include "gsa_internal.h"
@@ -19,7 +21,7 @@ __device__ __forceinline__ int gsa_nt4(uint8_t c)
 
 struct FmBlock { uint4 c0, c1, w0, w1; };
 
-__device__ __forceinline__ FmBlock fm_load(const uint4 *bwt, u64 blk)
+__device__ __forceinline__ FmBlock fm_load(const uint4 *__restrict__ bwt, u64 blk)
 {
 	const uint4 *p = bwt + (blk << 2);
 	FmBlock b; b.c0 = p[0]; b.c1 = p[1]; b.w0 = p[2]; b.w1 = p[3];
@@ -30,87 +32,154 @@ __device__ __forceinline__ FmBlock fm_load(const uint4 *bwt, u64 blk)
 __device__ __forceinline__ void fm_count(const FmBlock &b, int n, u32 &c1, u32 &c2, u32 &c3)
 {
 	const u64 M = 0x5555555555555555ull;
-	u64 W[4] = { ((u64)b.w0.x << 32) | b.w0.y, ((u64)b.w0.z << 32) | b.w0.w, ((u64)b.w1.x << 32) | b.w1.y, ((u64)b.w1.z << 32) | b.w1.w };
 	c1 = c2 = c3 = 0;
-#pragma unroll
-	for (int j = 0; j < 4; j++) {
-		int nj = n - 32 * j; nj = nj < 0 ? 0 : (nj > 32 ? 32 : nj);
-		u64 m = nj == 0 ? 0ull : (M & ~((nj == 32) ? 0ull : ((1ull << (64 - 2 * nj)) - 1)));
-		u64 lo = W[j] & M, hi = (W[j] >> 1) & M;
-		c3 += __popcll(hi & lo & m);
-		c2 += __popcll(hi & ~lo & m);
-		c1 += __popcll(~hi & lo & m);
-	}
+#define GSA_CNT(J, HI, LO) { int nj = n - 32 * (J); nj = nj < 0 ? 0 : (nj > 32 ? 32 : nj); \
+		const u64 W = ((u64)(HI) << 32) | (LO); \
+		const u64 m = nj == 0 ? 0ull : (M & ~((nj == 32) ? 0ull : ((1ull << (64 - 2 * nj)) - 1))); \
+		const u64 lo = W & M, hi = (W >> 1) & M; \
+		c3 += __popcll(hi & lo & m); c2 += __popcll(hi & ~lo & m); c1 += __popcll(~hi & lo & m); }
+	GSA_CNT(0, b.w0.x, b.w0.y) GSA_CNT(1, b.w0.z, b.w0.w) GSA_CNT(2, b.w1.x, b.w1.y) GSA_CNT(3, b.w1.z, b.w1.w)
+#undef GSA_CNT
 }
 
-// Occ(c, k) for all four c at the rows inside one loaded block
-__device__ __forceinline__ void fm_occ4_in(const FmBlock &b, int n, u64 cnt[4])
+struct Occ4 { u64 a, c, g, t; };
+
+__device__ __forceinline__ u64 occ_sel(const Occ4 &o, int i) { return i == 0 ? o.a : (i == 1 ? o.c : (i == 2 ? o.g : o.t)); }
+
+// Occ(c, k) for all four c at a row inside one loaded block (n = symbols up to the row, inclusive)
+__device__ __forceinline__ Occ4 fm_occ4_in(const FmBlock &b, int n)
 {
 	u32 c1, c2, c3; fm_count(b, n, c1, c2, c3);
-	cnt[0] = (((u64)b.c0.y << 32) | b.c0.x) + (u32)(n - c1 - c2 - c3);
-	cnt[1] = (((u64)b.c0.w << 32) | b.c0.z) + c1;
-	cnt[2] = (((u64)b.c1.y << 32) | b.c1.x) + c2;
-	cnt[3] = (((u64)b.c1.w << 32) | b.c1.z) + c3;
+	Occ4 o;
+	o.a = (((u64)b.c0.y << 32) | b.c0.x) + (u32)(n - c1 - c2 - c3);
+	o.c = (((u64)b.c0.w << 32) | b.c0.z) + c1;
+	o.g = (((u64)b.c1.y << 32) | b.c1.x) + c2;
+	o.t = (((u64)b.c1.w << 32) | b.c1.z) + c3;
+	return o;
 }
 
-// bwt_2occ4(k, l): returns the number of 64-byte blocks touched
-__device__ __forceinline__ int fm_2occ4(const DevIndex &di, u64 k, u64 l, u64 ck[4], u64 cl[4])
+// bwt_2occ4(k, l): returns the number of 64-byte blocks the reference touches.
+// Branch-free on the memory side: both blocks are requested back to back (the second
+// request is an L1 hit when the rows share a block) and waited for once.
+__device__ __forceinline__ int fm_2occ4(const DevIndex &di, u64 k, u64 l, Occ4 &ck, Occ4 &cl)
 {
 	const bool kn = (k == (u64)-1), ln = (l == (u64)-1);
-	u64 kk = k - (k >= di.primary), ll = l - (l >= di.primary);
-	int touched = 0;
-	if (!kn && !ln && (kk >> 7) == (ll >> 7)) {
-		FmBlock b = fm_load(di.bwt, kk >> 7);
-		fm_occ4_in(b, (int)(kk & 127) + 1, ck);
-		fm_occ4_in(b, (int)(ll & 127) + 1, cl);
-		return 1;
-	}
-	FmBlock bk, bl;
-	if (!kn) bk = fm_load(di.bwt, kk >> 7);
-	if (!ln) bl = fm_load(di.bwt, ll >> 7);
-	if (kn) { ck[0] = ck[1] = ck[2] = ck[3] = 0; } else { fm_occ4_in(bk, (int)(kk & 127) + 1, ck); touched++; }
-	if (ln) { cl[0] = cl[1] = cl[2] = cl[3] = 0; } else { fm_occ4_in(bl, (int)(ll & 127) + 1, cl); touched++; }
-	return touched;
+	const u64 kk = kn ? 0 : k - (k >= di.primary), ll = ln ? 0 : l - (l >= di.primary);
+	const FmBlock bk = fm_load(di.bwt, kk >> 7);
+	const FmBlock bl = fm_load(di.bwt, ll >> 7);
+	const Occ4 z = {0, 0, 0, 0};
+	ck = fm_occ4_in(bk, (int)(kk & 127) + 1);
+	cl = fm_occ4_in(bl, (int)(ll & 127) + 1);
+	if (kn) ck = z;
+	if (ln) cl = z;
+	if (!kn && !ln && (kk >> 7) == (ll >> 7)) return 1;
+	return (kn ? 0 : 1) + (ln ? 0 : 1);
 }
 
 struct FmIntv { u64 x0, x1, x2; };
 
+__device__ __forceinline__ u64 l2_sel(const DevIndex &di, int i) { return i == 0 ? di.L2[0] : (i == 1 ? di.L2[1] : (i == 2 ? di.L2[2] : (i == 3 ? di.L2[3] : di.L2[4]))); }
+
 __device__ __forceinline__ FmIntv fm_init(const DevIndex &di, int p)
 {
-	FmIntv v; v.x0 = di.L2[p] + 1; v.x1 = di.L2[3 - p] + 1; v.x2 = di.L2[p + 1] - di.L2[p];
+	FmIntv v; v.x0 = l2_sel(di, p) + 1; v.x1 = l2_sel(di, 3 - p) + 1; v.x2 = l2_sel(di, p + 1) - l2_sel(di, p);
 	return v;
 }
 
 // one forward extension by base nt (0..3); returns false if the interval dies
 __device__ __forceinline__ bool fm_extend(const DevIndex &di, FmIntv &ik, int nt, u32 &blocks)
 {
-	u64 tk[4], tl[4];
+	Occ4 tk, tl;
 	blocks += fm_2occ4(di, ik.x1 - 1, ik.x1 - 1 + ik.x2, tk, tl);
-	u64 o2[4];
-#pragma unroll
-	for (int i = 0; i < 4; i++) o2[i] = tl[i] - tk[i];
+	const u64 o2a = tl.a - tk.a, o2c = tl.c - tk.c, o2g = tl.g - tk.g, o2t = tl.t - tk.t;
 	const int i = 3 - nt;
-	if (o2[i] == 0) return false;
+	const u64 o2i = i == 0 ? o2a : (i == 1 ? o2c : (i == 2 ? o2g : o2t));
+	if (o2i == 0) return false;
 	u64 o0 = ik.x0 + ((ik.x1 <= di.primary && ik.x1 + ik.x2 - 1 >= di.primary) ? 1 : 0);   // ok[3].x0
 	// ok[2].x0 = ok[3].x0 + ok[3].x2, ok[1].x0 = ..., ok[0].x0 = ...
-	if (i < 3) o0 += o2[3];
-	if (i < 2) o0 += o2[2];
-	if (i < 1) o0 += o2[1];
-	ik.x0 = o0; ik.x1 = di.L2[i] + 1 + tk[i]; ik.x2 = o2[i];
+	if (i < 3) o0 += o2t;
+	if (i < 2) o0 += o2g;
+	if (i < 1) o0 += o2c;
+	ik.x0 = o0; ik.x1 = l2_sel(di, i) + 1 + occ_sel(tk, i); ik.x2 = o2i;
 	return true;
 }
 
-// BWT_Search without the locate step: maximal forward match from `start`, capped at `stop`
+// the same step on two blocks that are already in registers (kk, ll = primary-corrected rows)
+__device__ __forceinline__ bool fm_extend_loaded(const DevIndex &di, FmIntv &ik, int nt, const FmBlock &bk, const FmBlock &bl, u64 kk, u64 ll, bool kn, bool ln, u32 &blocks)
+{
+	const Occ4 z = {0, 0, 0, 0};
+	Occ4 tk = fm_occ4_in(bk, (int)(kk & 127) + 1), tl = fm_occ4_in(bl, (int)(ll & 127) + 1);
+	if (kn) tk = z;
+	if (ln) tl = z;
+	blocks += (!kn && !ln && (kk >> 7) == (ll >> 7)) ? 1 : ((kn ? 0 : 1) + (ln ? 0 : 1));
+	const u64 o2a = tl.a - tk.a, o2c = tl.c - tk.c, o2g = tl.g - tk.g, o2t = tl.t - tk.t;
+	const int i = 3 - nt;
+	const u64 o2i = i == 0 ? o2a : (i == 1 ? o2c : (i == 2 ? o2g : o2t));
+	if (o2i == 0) return false;
+	u64 o0 = ik.x0 + ((ik.x1 <= di.primary && ik.x1 + ik.x2 - 1 >= di.primary) ? 1 : 0);
+	if (i < 3) o0 += o2t;
+	if (i < 2) o0 += o2g;
+	if (i < 1) o0 += o2c;
+	ik.x0 = o0; ik.x1 = l2_sel(di, i) + 1 + occ_sel(tk, i); ik.x2 = o2i;
+	return true;
+}
+
+// BWT_Search without the locate step: maximal forward match from `start`, capped at
+// `stop`.  codes[] holds nt4 codes (0..4), e.g. a query window staged in LDS.
+__device__ __forceinline__ int fm_search_codes(const DevIndex &di, const uint8_t *codes, int start, int stop, FmIntv &ik, u32 &blocks)
+{
+	ik = fm_init(di, codes[start]);
+	int pos;
+	for (pos = start + 1; pos < stop; pos++) {
+		const int nt = codes[pos];
+		if (nt > 3) break;
+		if (!fm_extend(di, ik, nt, blocks)) break;
+	}
+	return pos - start;
+}
+
+// same on raw ASCII
 __device__ __forceinline__ int fm_search(const DevIndex &di, const uint8_t *q, int start, int stop, FmIntv &ik, u32 &blocks)
 {
 	ik = fm_init(di, gsa_nt4(q[start]));
 	int pos;
 	for (pos = start + 1; pos < stop; pos++) {
-		int nt = gsa_nt4(q[pos]);
+		const int nt = gsa_nt4(q[pos]);
 		if (nt > 3) break;
 		if (!fm_extend(di, ik, nt, blocks)) break;
 	}
 	return pos - start;
+}
+
+// Direct text comparison for a UNIQUE interval (x2 == 1).  Returns how many of the next
+// (at most 16) positions satisfy pos+t < clen, tp+t < tend, codes[pos+t] <= 3 and
+// ref[tp+t] == "ACGT"[codes[pos+t]], counted from t = 0 up to the first failure.
+// Equivalent to that many successful bwt_2occ4 extension steps: with one occurrence
+// left, a forward extension succeeds iff the text continues with the query base, and it
+// leaves x0 (the row of the only suffix) and x2 = 1 unchanged.  ref is RefSequence
+// (upper-case ACGT, bwt_index.cpp:199-209), allocated with 64 bytes of slack.
+// The three aligned 8-byte words covering [tp, tp+16) are passed in (a = word at tp & ~7).
+__device__ __forceinline__ int text_match16w(u64 a, u64 b, u64 c, i64 tp, i64 tend, const uint8_t *codes, int pos, int clen)
+{
+	int avail = clen - pos;
+	if (tend - tp < (i64)avail) avail = (int)(tend - tp);
+	if (avail > 16) avail = 16;
+	if (avail <= 0) return 0;
+	const int sh = (int)(tp & 7) * 8;
+	const u64 lo = sh ? (a >> sh) | (b << (64 - sh)) : a;
+	const u64 hi = sh ? (b >> sh) | (c << (64 - sh)) : b;
+	u64 elo = 0, ehi = 0;
+#pragma unroll
+	for (int t = 0; t < 8; t++) {
+		const int p0 = pos + t < clen ? pos + t : clen - 1, p1 = pos + 8 + t < clen ? pos + 8 + t : clen - 1;
+		const u32 c0 = codes[p0], c1 = codes[p1];
+		elo |= (u64)(c0 <= 3 ? (0x54474341u >> (8 * c0)) & 0xFFu : 0xFFu) << (8 * t);
+		ehi |= (u64)(c1 <= 3 ? (0x54474341u >> (8 * c1)) & 0xFFu : 0xFFu) << (8 * t);
+	}
+	u64 x = lo ^ elo;
+	int n = x ? (__ffsll((unsigned long long)x) - 1) >> 3 : 8;
+	if (n == 8) { x = hi ^ ehi; n = 8 + (x ? (__ffsll((unsigned long long)x) - 1) >> 3 : 8); }
+	return n < avail ? n : avail;
 }
 
 // bwt_invPsi: one LF step.  Symbol fetch uses k-(k>primary), Occ uses k-(k>=primary);
@@ -118,23 +187,31 @@ __device__ __forceinline__ int fm_search(const DevIndex &di, const uint8_t *q, i
 __device__ __forceinline__ u64 fm_lf(const DevIndex &di, u64 k)
 {
 	if (k == di.primary) return 0;
-	u64 x = k - (k > di.primary);
-	FmBlock b = fm_load(di.bwt, x >> 7);
-	int s = (int)(x & 127);
-	u32 w = s < 64 ? (s < 32 ? (s < 16 ? b.w0.x : b.w0.y) : (s < 48 ? b.w0.z : b.w0.w))
-	               : (s < 96 ? (s < 80 ? b.w1.x : b.w1.y) : (s < 112 ? b.w1.z : b.w1.w));
-	int sym = (w >> ((~s & 15) << 1)) & 3;
-	u64 cnt[4]; fm_occ4_in(b, s + 1, cnt);
-	return di.L2[sym] + cnt[sym];
+	const u64 x = k - (k > di.primary);
+	const FmBlock b = fm_load(di.bwt, x >> 7);
+	const int s = (int)(x & 127);
+	const u32 w = s < 64 ? (s < 32 ? (s < 16 ? b.w0.x : b.w0.y) : (s < 48 ? b.w0.z : b.w0.w))
+	                     : (s < 96 ? (s < 80 ? b.w1.x : b.w1.y) : (s < 112 ? b.w1.z : b.w1.w));
+	const int sym = (w >> ((~s & 15) << 1)) & 3;
+	const Occ4 o = fm_occ4_in(b, s + 1);
+	return l2_sel(di, sym) + occ_sel(o, sym);
 }
 
-// bwt_sa: locate row k (sa_intv = 32, sampled by row)
-__device__ __forceinline__ u64 fm_locate(const DevIndex &di, u64 k, u32 &steps)
+// bwt_sa by walking (sa_intv = 32, sampled by row) -- used to densify the SA at
+// index upload and by the leaf operator
+__device__ __forceinline__ u64 fm_locate_walk(const DevIndex &di, u64 k, u32 &steps)
 {
 	u64 s = 0;
 	while (k & 31) { ++s; k = fm_lf(di, k); }
 	steps += (u32)s;
 	return s + di.sa[k >> 5];
+}
+
+// bwt_sa through the dense SA built at gsa_create (one 4- or 8-byte read)
+__device__ __forceinline__ u64 fm_locate(const DevIndex &di, u64 k)
+{
+	if (k == 0) return (u64)-1;                      // sa[0] = -1 sentinel (bwt_index.cpp:40)
+	return di.sa32 ? (u64)di.sa32[k] : di.sa64[k];
 }
 
 #endif

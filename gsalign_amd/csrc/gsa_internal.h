@@ -29,12 +29,16 @@ typedef int32_t i32;
 struct DevIndex {
 	u64 primary, L2[5], seq_len;
 	const uint4 *bwt;       // 4 x uint4 per block
-	const u64 *sa;          // sa[i] = SA of row 32 i ; sa[0] = -1
+	const u64 *sa;          // sa[i] = SA of row 32 i ; sa[0] = -1   (the on-disk sampling)
+	const u32 *sa32;        // dense SA, one entry per row, built on the device at gsa_create
+	const u64 *sa64;        //   (32-bit entries when 2G < 2^32, else 64-bit); row 0 is the -1 sentinel
 	const uint8_t *ref;     // 2G ASCII
 	i64 G;
 	const i64 *chr_end;     // 2*n_chr sorted last coordinates (ChrLocMap keys)
 	const i32 *chr_of_end;  // chromosome index per entry (ChrLocMap values)
 	i32 n_ends;
+	const u64 *kmer;        // k-mer -> (x0,x1,x2,0) after the first kmer_k bases, x2 = 0: absent (built at gsa_create)
+	i32 kmer_k;
 };
 
 struct DevBuf {

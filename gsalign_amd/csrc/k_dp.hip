@@ -1,78 +1,227 @@
 // gsalign_amd/csrc/k_dp.hip -- batched gap-closing DP (a13) and the public leaf
-// operator gsa_ksw2_batch.  Device code is in gsa_dp.h.
+// operator gsa_ksw2_batch.  Cell recurrence and traceback automaton: gsa_dp.h.
+//
+// Two kernels, chosen per job by size (jobs are launched largest first):
+//  * k_dp_small  n <= 64 and m+n-1 <= 128 (the bulk of the jobs: median 11 x 11).
+//    One wavefront per alignment, lane t owns target column t.  The (u,v,x,y) state
+//    lives in REGISTERS; the left neighbour and the reference base travel one lane
+//    up per anti-diagonal with DPP wave shifts (systolic array); direction bytes
+//    and the traceback stay in LDS.  No barrier, no global traffic but the result.
+//  * k_dp_wg<T>  everything else (up to 5000 x 5000): one T-thread workgroup per
+//    alignment, state in LDS (x and v ping-pong so one barrier per anti-diagonal
+//    suffices), direction bytes to HBM diagonal-major (coalesced), traceback by
+//    one lane on 64x64 tiles staged through LDS.
+#include <algorithm>
 #include "gsa_ctx.h"
 #include "gsa_dp.h"
 
-__global__ void k_dp_cells(i32 n, const i32 *__restrict__ len1, const i32 *__restrict__ len2, i32 *cells)
-{
-	i32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i <= n) cells[i] = i < n ? len1[i] * len2[i] : 0;
-}
+#define SMALL_ROWS 128
+#define SMALL_WAVES 4
 
-// one wavefront (= one 64-thread workgroup) per alignment
-__global__ void __launch_bounds__(64) k_dp_wave(i32 first, i32 n_jobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1, const i32 *__restrict__ len1,
-                                                 const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2, const i32 *__restrict__ len2,
-                                                 uint8_t *dir, const i64 *__restrict__ diroff, i64 dirbase, uint8_t *rev, uint8_t *ops, const i64 *__restrict__ ops_off,
-                                                 i32 *ops_len, int npad)
+__global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const i32 *__restrict__ order, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
+                                                                const i32 *__restrict__ len1, const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2,
+                                                                const i32 *__restrict__ len2, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len)
 {
-	extern __shared__ __attribute__((aligned(16))) int8_t lds[];
-	const i32 job = first + blockIdx.x;
-	if (job >= first + n_jobs) return;
+	__shared__ uint8_t s_dir[SMALL_WAVES][SMALL_ROWS * 64];
+	__shared__ uint8_t s_rev[SMALL_WAVES][SMALL_ROWS + 64];
+	__shared__ int s_n[SMALL_WAVES];
+	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const i32 slot = blockIdx.x * SMALL_WAVES + w;
+	if (slot >= n_jobs) return;
+	const i32 job = order[slot];
 	const int m = len1[job], n = len2[job];
 	const uint8_t *s1 = pool1 + off1[job], *s2 = pool2 + off2[job];
-	uint8_t *d = dir + (diroff[job] - dirbase);
-	uint8_t *rv = rev + ops_off[job], *op = ops + ops_off[job];
-	const int lane = threadIdx.x;
-	if (m <= 0 || n <= 0) { if (lane == 0) ops_len[job] = 0; return; }
-	dp_fill(s1, m, s2, n, lds, npad, d);
-	__syncthreads();
-	__shared__ int s_nops;
-	if (lane == 0) s_nops = dp_backtrack(d, m, n, rv);
-	__syncthreads();
-	const int nops = s_nops;
-	for (int p = lane; p < nops; p += 64) op[p] = rv[nops - 1 - p];
+	uint8_t *dir = s_dir[w], *rev = s_rev[w];
+	const int cq = lane < n ? gsa_nt4(s2[lane]) : 4;
+	// reference base for lane t at diagonal r is s1[r - t]: it enters at lane 0 and moves one lane up per diagonal
+	const int c1a = lane < m ? gsa_nt4(s1[lane]) : 4, c1b = lane + 64 < m ? gsa_nt4(s1[lane + 64]) : 4;
+	int u = lane ? 2 : 0, v = 0, x = 0, y = 0, wref = 4;
+	const int nr = m + n - 1;
+	for (int r = 0; r < nr; r++) {
+		const int inb = r < m ? (r < 64 ? __shfl(c1a, r) : __shfl(c1b, r - 64)) : 4;      // s1[r] broadcast
+		wref = wave_shr1(wref, inb);
+		const int xt1 = wave_shr1(x, 0), vt1 = wave_shr1(v, r ? 2 : 0);                     // (r-1,t-1); boundary for t = 0 (:157-164)
+		const int jj = r - lane;
+		if (lane < n && jj >= 0 && jj < m) {
+			int un, vn, xn, yn;
+			const int d = dp_cell(xt1, vt1, u, y, cq, wref, un, vn, xn, yn);
+			u = un; v = vn; x = xn; y = yn;
+			dir[r * 64 + lane] = (uint8_t)d;
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	if (lane == 0) {
+		int i = n - 1, j = m - 1, state = 0, k = 0;
+		while (i >= 0 && j >= 0) rev[k++] = (uint8_t)dp_bt_step(dir[(i + j) * 64 + i], state, i, j);
+		for (; i >= 0; --i) rev[k++] = 'D';
+		for (; j >= 0; --j) rev[k++] = 'I';
+		s_n[w] = k;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	const int nops = s_n[w];
+	uint8_t *op = ops + ops_off[job];
+	for (int p = lane; p < nops; p += 64) op[p] = rev[nops - 1 - p];
 	if (lane == 0) ops_len[job] = nops;
 }
 
-// All pointers are device pointers.  Jobs are processed in batches so that the
+template <int T>
+__global__ void __launch_bounds__(T) k_dp_wg(i32 n_jobs, const i32 *__restrict__ order, const i64 *__restrict__ diroff, const uint8_t *__restrict__ pool1,
+                                              const i64 *__restrict__ off1, const i32 *__restrict__ len1, const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2,
+                                              const i32 *__restrict__ len2, uint8_t *dirbase, uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, int npad)
+{
+	extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+	__shared__ uint8_t tile[64][64];
+	__shared__ int s_i, s_j, s_state, s_k;
+	if ((i32)blockIdx.x >= n_jobs) return;
+	const i32 job = order[blockIdx.x];
+	const int m = len1[job], n = len2[job], tid = threadIdx.x;
+	const uint8_t *s1 = pool1 + off1[job], *s2 = pool2 + off2[job];
+	uint8_t *dir = dirbase + diroff[blockIdx.x];
+	uint8_t *rev = revbase + ops_off[job], *op = ops + ops_off[job];
+	if (m <= 0 || n <= 0) { if (tid == 0) ops_len[job] = 0; return; }
+	int8_t *U = lds, *Y = lds + npad, *X0 = lds + 2 * npad, *X1 = lds + 3 * npad, *V0 = lds + 4 * npad, *V1 = lds + 5 * npad;
+	for (int t = tid; t < n; t += T) { U[t] = t ? 2 : 0; Y[t] = 0; X0[t] = 0; X1[t] = 0; V0[t] = 0; V1[t] = 0; }   // (r-1, t=r) boundary: u = q, y = 0 (:165)
+	__syncthreads();
+	const int nr = m + n - 1;
+	i64 off = 0;
+	for (int r = 0; r < nr; r++) {
+		const int st = r - m + 1 > 0 ? r - m + 1 : 0, en = r < n - 1 ? r : n - 1;
+		const int8_t *Xp = (r & 1) ? X1 : X0, *Vp = (r & 1) ? V1 : V0;
+		int8_t *Xn = (r & 1) ? X0 : X1, *Vn = (r & 1) ? V0 : V1;
+		for (int t = st + tid; t <= en; t += T) {
+			int xt1, vt1;
+			if (t > 0) { xt1 = Xp[t - 1]; vt1 = Vp[t - 1]; } else { xt1 = 0; vt1 = r ? 2 : 0; }
+			int un, vn, xn, yn;
+			const int d = dp_cell(xt1, vt1, U[t], Y[t], gsa_nt4(s2[t]), gsa_nt4(s1[r - t]), un, vn, xn, yn);
+			U[t] = (int8_t)un; Y[t] = (int8_t)yn; Xn[t] = (int8_t)xn; Vn[t] = (int8_t)vn;
+			dir[off + (t - st)] = (uint8_t)d;
+		}
+		off += en - st + 1;
+		__syncthreads();
+	}
+	// ---- traceback on 64 x 64 tiles: rows = diagonals R..R-63, columns = targets T0..T0-63 ----
+	if (tid == 0) { s_i = n - 1; s_j = m - 1; s_state = 0; s_k = 0; }
+	__threadfence_block();
+	__syncthreads();
+	while (s_i >= 0 && s_j >= 0) {
+		const int R = s_i + s_j, T0 = s_i;
+		for (int e = tid; e < 64 * 64; e += T) {
+			const int rr = e >> 6, cc = e & 63;
+			const int r = R - rr, t = T0 - cc;
+			uint8_t val = 0;
+			if (r >= 0 && t >= 0) {
+				const int st = r - m + 1 > 0 ? r - m + 1 : 0, en = r < n - 1 ? r : n - 1;
+				if (t >= st && t <= en) val = dir[dp_rowoff(r, m, n) + (t - st)];
+			}
+			tile[rr][cc] = val;
+		}
+		__syncthreads();
+		if (tid == 0) {
+			int i = s_i, j = s_j, state = s_state, k = s_k;
+			while (i >= 0 && j >= 0) {
+				const int rr = R - (i + j), cc = T0 - i;
+				if (rr > 63 || cc > 63) break;
+				rev[k++] = (uint8_t)dp_bt_step(tile[rr][cc], state, i, j);
+			}
+			s_i = i; s_j = j; s_state = state; s_k = k;
+		}
+		__syncthreads();
+	}
+	if (tid == 0) {
+		int i = s_i, j = s_j, k = s_k;
+		for (; i >= 0; --i) rev[k++] = 'D';
+		for (; j >= 0; --j) rev[k++] = 'I';
+		s_k = k; ops_len[job] = k;
+	}
+	__threadfence_block();
+	__syncthreads();
+	const int nops = s_k;
+	for (int p = tid; p < nops; p += T) op[p] = rev[nops - 1 - p];
+}
+
+// All pointers are device pointers.  Large jobs are processed in batches so that the
 // direction bytes of one batch fit the budget.
 int run_ksw2_jobs(gsa_ctx *c, i32 n, const uint8_t *pool1, const i64 *off1, const i32 *len1,
                   const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len)
 {
 	if (n <= 0) return GSA_OK;
 	hipStream_t st = c->stream;
-	i32 *cells = dev_ensure<i32>(c, c->d_flag2, (size_t)n + 1);
-	i64 *coff = dev_ensure<i64>(c, c->j_cells, (size_t)n + 1);
-	if (!cells || !coff) return GSA_ERR_NOMEM;
-	hipLaunchKernelGGL(k_dp_cells, dim3(grid_for(n + 1, 256)), dim3(256), 0, st, n, len1, len2, cells);
-	int rc = prim_exscan_i32_i64(c, cells, coff, (size_t)n + 1); if (rc) return rc;
-	std::vector<i64> h_coff((size_t)n + 1); std::vector<i32> h_len2((size_t)n); std::vector<i64> h_ooff((size_t)n); std::vector<i32> h_len1((size_t)n);
-	GSA_CHECK(c, hipMemcpyAsync(h_coff.data(), coff, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, st));
+	std::vector<i32> h_len1((size_t)n), h_len2((size_t)n); std::vector<i64> h_ooff((size_t)n);
 	GSA_CHECK(c, hipMemcpyAsync(h_len2.data(), len2, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipMemcpyAsync(h_len1.data(), len1, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipMemcpyAsync(h_ooff.data(), ops_off, (size_t)n * 8, hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipStreamSynchronize(st));
+	std::vector<i32> small, mid, big;
 	i64 ops_total = 0;
-	for (i32 i = 0; i < n; i++) { i64 e = h_ooff[i] + h_len1[i] + h_len2[i]; if (e > ops_total) ops_total = e; }
-	uint8_t *rev = dev_ensure<uint8_t>(c, c->d_i64a, (size_t)ops_total + 64);
-	if (!rev) return GSA_ERR_NOMEM;
-	const i64 budget = 6ll << 30;      // direction bytes per batch
-	c->counters[4] += (u64)h_coff[n]; c->counters[5] += (u64)n;
-	for (i32 i = 0; i < n; i++) c->counters[6] += (u64)h_len1[i] + (u64)h_len2[i];
-	i32 first = 0;
-	while (first < n) {
-		i32 last = first; int nmax = 0;
-		while (last < n && (last == first || h_coff[last + 1] - h_coff[first] <= budget)) { if (h_len2[last] > nmax) nmax = h_len2[last]; last++; }
-		const i64 bytes = h_coff[last] - h_coff[first];
-		uint8_t *dir = dev_ensure<uint8_t>(c, c->d_scan2, (size_t)bytes + 64);
-		if (!dir) return GSA_ERR_NOMEM;
-		const int npad = (nmax + 63) & ~63;
-		if ((size_t)npad * 4 > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP fragment longer than 38400 bases");
-		hipLaunchKernelGGL(k_dp_wave, dim3(last - first), dim3(64), (size_t)npad * 4, st, first, last - first, pool1, off1, len1, pool2, off2, len2,
-		                   dir, coff, h_coff[first], rev, ops, ops_off, ops_len, npad);
-		first = last;
+	for (i32 i = 0; i < n; i++) {
+		const i64 m = h_len1[i], nn = h_len2[i];
+		c->counters[4] += (u64)(m * nn); c->counters[6] += (u64)(m + nn);
+		if (h_ooff[i] + m + nn > ops_total) ops_total = h_ooff[i] + m + nn;
+		if (m <= 0 || nn <= 0) mid.push_back(i);
+		else if (nn <= 64 && m + nn - 1 <= SMALL_ROWS) small.push_back(i);
+		else if (nn > 512) big.push_back(i);
+		else mid.push_back(i);
 	}
-	GSA_CHECK(c, hipGetLastError());
+	c->counters[5] += (u64)n;
+	auto by_cells = [&](i32 a, i32 b) { const i64 ca = (i64)h_len1[a] * h_len2[a], cb = (i64)h_len1[b] * h_len2[b]; return ca != cb ? ca > cb : a < b; };
+	std::sort(small.begin(), small.end(), by_cells); std::sort(mid.begin(), mid.end(), by_cells); std::sort(big.begin(), big.end(), by_cells);
+	// big first (longest critical path), then mid, then the many small ones fill the machine around them
+	i32 *d_order = dev_ensure<i32>(c, c->d_flag2, (size_t)n + 1);
+	uint8_t *rev = dev_ensure<uint8_t>(c, c->d_i64a, (size_t)ops_total + 64);
+	if (!d_order || !rev) return GSA_ERR_NOMEM;
+	std::vector<i32> order; order.reserve((size_t)n);
+	order.insert(order.end(), big.begin(), big.end()); order.insert(order.end(), mid.begin(), mid.end()); order.insert(order.end(), small.begin(), small.end());
+	GSA_CHECK(c, hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+	// One direction buffer for both workgroup classes (offsets continue), so the three kernels can run
+	// CONCURRENTLY on three streams: the few huge jobs set the critical path, everything else fills
+	// the machine around them.  If the direction bytes exceed the budget the classes are batched.
+	const i64 budget = 12ll << 30;
+	std::vector<i32> wg_jobs(big); wg_jobs.insert(wg_jobs.end(), mid.begin(), mid.end());
+	std::vector<i64> h_diroff(wg_jobs.size() + 1, 0);
+	hipEvent_t ev_fork = c->ev[10], ev_j1 = c->ev[11], ev_j2 = c->ev[12];
+	size_t first = 0;
+	bool small_done = small.empty();
+	while (first < wg_jobs.size() || !small_done) {
+		size_t last = first; i64 bytes = 0; int nmax_big = 1, nmax_mid = 1; size_t nbig = 0;
+		while (last < wg_jobs.size()) {
+			const i32 jb = wg_jobs[last]; const i64 cells = (i64)h_len1[jb] * h_len2[jb];
+			if (last > first && bytes + cells > budget) break;
+			h_diroff[last] = bytes; bytes += cells;
+			if (last < big.size()) { nbig++; if (h_len2[jb] > nmax_big) nmax_big = h_len2[jb]; } else if (h_len2[jb] > nmax_mid) nmax_mid = h_len2[jb];
+			last++;
+		}
+		uint8_t *dir = dev_ensure<uint8_t>(c, c->d_scan2, (size_t)bytes + 64);
+		i64 *d_diroff = dev_ensure<i64>(c, c->j_cells, wg_jobs.size() + 1);
+		if (!dir || !d_diroff) return GSA_ERR_NOMEM;
+		if (last > first) GSA_CHECK(c, hipMemcpyAsync(d_diroff + first, h_diroff.data() + first, (last - first) * 8, hipMemcpyHostToDevice, st));
+		const int npad_big = (nmax_big + 63) & ~63, npad_mid = (nmax_mid + 63) & ~63;
+		if ((size_t)npad_big * 6 > 140 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP fragment longer than 23800 bases");
+		GSA_CHECK(c, hipEventRecord(ev_fork, st));
+		const size_t nmid = (last - first) - nbig;
+		if (nbig) hipLaunchKernelGGL(k_dp_wg<1024>, dim3((unsigned)nbig), dim3(1024), (size_t)npad_big * 6, st, (i32)nbig, d_order + first, d_diroff + first, pool1, off1, len1, pool2, off2, len2, dir, rev, ops, ops_off, ops_len, npad_big);
+		if (nmid) {
+			GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[0], ev_fork, 0));
+			hipLaunchKernelGGL(k_dp_wg<256>, dim3((unsigned)nmid), dim3(256), (size_t)npad_mid * 6, c->stream_aux[0], (i32)nmid, d_order + first + nbig, d_diroff + first + nbig, pool1, off1, len1, pool2, off2, len2, dir, rev, ops, ops_off, ops_len, npad_mid);
+			GSA_CHECK(c, hipEventRecord(ev_j1, c->stream_aux[0]));
+			GSA_CHECK(c, hipStreamWaitEvent(st, ev_j1, 0));
+		}
+		if (!small_done) {
+			const unsigned nb = (unsigned)((small.size() + SMALL_WAVES - 1) / SMALL_WAVES);
+			GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], ev_fork, 0));
+			hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, c->stream_aux[1], (i32)small.size(), d_order + wg_jobs.size(), pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len);
+			GSA_CHECK(c, hipEventRecord(ev_j2, c->stream_aux[1]));
+			GSA_CHECK(c, hipStreamWaitEvent(st, ev_j2, 0));
+			small_done = true;
+		}
+		GSA_CHECK(c, hipGetLastError());
+		first = last;
+		if (first < wg_jobs.size()) GSA_CHECK(c, hipStreamSynchronize(st));       // the direction buffer is reused by the next batch
+	}
+	GSA_CHECK(c, hipStreamSynchronize(st));       // staging vectors (order, diroff) go out of scope
 	return GSA_OK;
 }
 

@@ -6,56 +6,178 @@
 #include "gsa_ctx.h"
 #include "gsa_fm.h"
 
-enum { CNT_OCCBLK = 0, CNT_LF = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 4, CNT_DPJOBS = 5, CNT_DPMN = 6, CNT_MEMS = 8, CNT_OVERFLOW = 9 };
+enum { CNT_OCCBLK = 0, CNT_LF = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 4, CNT_DPJOBS = 5, CNT_DPMN = 6, CNT_CAND = 8, CNT_OVERFLOW = 9, CNT_OCCBLK_ALL = 10 };
+
+#define SEED_WG 256
+enum { M_DONE = 0, M_FM = 1, M_TEXT = 2, M_KMER = 3, M_LOC = 4 };
+#define PATH_WORDS 320          // 10240 on-path bits per chunk
 
 // ---------------------------------------------------------------------------
 // Seed exploration.  Work unit = one 10 000-bp chunk (absolute position, App. B
-// #1).  The walk inside a chunk is a chain: next start = start+len+1 after a hit
-// (start+5 with -sen), start+1 after a miss, so one lane owns one chunk.
-// Every accepted match appends its freq BWT rows to the pending-hit list.
+// #1).  Inside a chunk the reference walks a CHAIN: next start = start+len+1
+// after an accepted match (start+5 with -sen), start+1 otherwise, so the walk is
+// sequential -- but "next start" is a pure function of the start position, i.e.
+// the chunk is a functional graph whose paths merge (two walks that are inside
+// the same exact match end at the same mismatch).  One 256-lane workgroup owns a
+// chunk: lane j speculatively walks the sub-range [jS, (j+1)S) from its left
+// edge, memoising next(s) per position in LDS; then lanes re-enter their
+// sub-range at the previous lane's exit and follow the memo (a re-walk costs new
+// searches only until it merges with what is already memoised) until no exit
+// moves.  The result is exactly the reference's chain; the on-path bit per
+// position selects which memoised matches become seeds.
+// The chunk's query codes, the memo and the on-path bits live in LDS.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_seed_chunks(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm,
-                                                     u64 *cnt, u64 *hit_row, i32 *hit_qpos, i32 *hit_len, u64 hit_cap)
+template <bool COUNT>
+__global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
+                                                      i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *onpath)
 {
-	const i64 chunk = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	i64 s0 = chunk * GSA_CHUNK;
-	if (s0 >= qlen) return;
-	int start = (int)s0, stop = (int)(s0 + GSA_CHUNK < qlen ? s0 + GSA_CHUNK : qlen);
-	u32 blocks = 0;
-	while (start < stop) {
-		if (gsa_nt4(q[start]) > 3) { start++; continue; }
-		FmIntv ik;
-		int len = fm_search(di, q, start, stop, ik, blocks);
-		if (len >= prm.MinSeedLength && ik.x2 <= GSA_MAX_SEED_FREQ) {
-			u32 f = (u32)ik.x2;
-			u64 off = atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)f);
-			if (off + f <= hit_cap) {
-				for (u32 i = 0; i < f; i++) { hit_row[off + i] = ik.x0 + i; hit_qpos[off + i] = start; hit_len[off + i] = len; }
-			} else cnt[CNT_OVERFLOW] = 1;
-			start += prm.bSensitive ? 5 : len + 1;
-		} else start++;
+	__shared__ uint8_t codes[GSA_CHUNK];
+	__shared__ uint16_t memo[GSA_CHUNK];      // next(s)-s, 0 = unknown
+	__shared__ uint16_t mblk[COUNT ? GSA_CHUNK : 1];   // Occ blocks the search from s read (accounting build only)
+	__shared__ u32 bits[PATH_WORDS];
+	__shared__ i32 exits[SEED_WG + 1];
+	__shared__ int changed;
+	const int chunk = blockIdx.x, j = threadIdx.x;
+	const i64 c0 = (i64)chunk * GSA_CHUNK;
+	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
+	for (int p = j; p < clen; p += SEED_WG) { codes[p] = (uint8_t)gsa_nt4(q[c0 + p]); memo[p] = 0; }
+	for (int p = j; p < PATH_WORDS; p += SEED_WG) bits[p] = 0;
+	const int S = (clen + SEED_WG - 1) / SEED_WG;
+	const int bend = (j + 1) * S < clen ? (j + 1) * S : clen;
+	int entry = j * S < clen ? j * S : clen, exit_ = entry;
+	bool dirty = true;
+	u32 all_blocks = 0, rounds = 0, iters = 0;
+	const long long tA = clock64();
+	__syncthreads();
+	const long long tB = clock64(); long long tC = 0;
+	for (;;) {
+		// One flat loop per wave.  Every iteration each lane has exactly ONE memory request pending
+		// (two Occ blocks / 24 bytes of reference text / a k-mer table entry / an SA entry); all lanes
+		// issue their requests together, wait once, then consume by mode -- so lanes that are in
+		// different searches, or in different phases of a search, never serialise on each other's
+		// memory latency.
+		int s = entry, pos = 0, mode = M_DONE; u32 kid = 0;
+		FmIntv ik = {0, 0, 0}; u32 blk = 0; i64 tp = 0;
+#define START_NEXT() do { \
+			while (s < bend) { const int m_ = memo[s]; if (m_) { s += m_; continue; } \
+				if (codes[s] > 3) { memo[s] = 1; if (COUNT) mblk[s] = 0; s += 1; continue; } break; } \
+			if (s >= bend) { mode = M_DONE; exit_ = s; } \
+			else { \
+				ik = fm_init(di, codes[s]); pos = s + 1; blk = 0; mode = M_FM; \
+				if (!COUNT && di.kmer_k > 1 && s + di.kmer_k <= clen) { \
+					u32 id_ = 0; bool ok_ = true; \
+					for (int t_ = 0; t_ < di.kmer_k; t_++) { const u32 cd_ = codes[s + t_]; ok_ = ok_ && cd_ <= 3; id_ = (id_ << 2) | (cd_ & 3); } \
+					if (ok_) { kid = id_; mode = M_KMER; } \
+				} \
+			} } while (0)
+		if (dirty) START_NEXT();
+		while (!__all(mode == M_DONE)) {
+			iters++;
+			// ---- request phase (convergent) ----
+			u64 kk = 0, ll = 0; bool kn = true, ln = true;
+			if (mode == M_FM) {
+				const u64 k = ik.x1 - 1, l = ik.x1 - 1 + ik.x2;
+				kn = (k == (u64)-1); ln = (l == (u64)-1);
+				kk = kn ? 0 : k - (k >= di.primary); ll = ln ? 0 : l - (l >= di.primary);
+			}
+			const FmBlock bk = fm_load(di.bwt, kk >> 7), bl = fm_load(di.bwt, ll >> 7);
+			const u64 *pt = (const u64 *)(di.ref + (mode == M_TEXT ? (tp & ~7ll) : 0));
+			const u64 t0 = pt[0], t1 = pt[1], t2 = pt[2];
+			const ulonglong2 *pe = (const ulonglong2 *)((di.kmer ? di.kmer : (const u64 *)di.bwt) + (mode == M_KMER ? ((size_t)kid << 2) : 0));
+			const ulonglong2 e0 = pe[0], e1 = pe[1];
+			const u64 sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
+			// ---- consume phase ----
+			bool ended = false;
+			if (mode == M_KMER) {
+				if (e1.x != 0) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; mode = ik.x2 == 1 ? M_LOC : M_FM; }
+				else mode = M_FM;                       // k-mer absent: the match is shorter than k, walk it base by base
+			} else if (mode == M_LOC) {
+				tp = (i64)sav + (pos - s); mode = M_TEXT;
+			} else if (mode == M_TEXT) {
+				const int got = text_match16w(t0, t1, t2, tp, (i64)di.seq_len, codes, pos, clen);
+				pos += got; tp += got;
+				ended = got < 16;
+			} else if (mode == M_FM) {
+				ended = true;
+				if (pos < clen) {
+					const int nt = codes[pos];
+					if (nt <= 3 && fm_extend_loaded(di, ik, nt, bk, bl, kk, ll, kn, ln, blk)) {
+						pos++; ended = false;
+						if (!COUNT && ik.x2 == 1) mode = M_LOC;
+					}
+				}
+			}
+			if (ended) {
+				const int len = pos - s;
+				int d = 1;
+				if (len >= prm.MinSeedLength && ik.x2 <= GSA_MAX_SEED_FREQ) {
+					const u32 slot = (u32)atomicAdd((unsigned long long *)&cnt[CNT_CAND], 1ull);
+					if (slot < cand_cap) { cand_s[slot] = (i32)(c0 + s); cand_len[slot] = len; cand_x0[slot] = ik.x0; cand_freq[slot] = (i32)ik.x2; }
+					else cnt[CNT_OVERFLOW] = 1;
+					d = prm.bSensitive ? 5 : len + 1;
+				}
+				memo[s] = (uint16_t)d; if (COUNT) mblk[s] = (uint16_t)blk;
+				all_blocks += blk;
+				s += d;
+				START_NEXT();
+			}
+		}
+#undef START_NEXT
+		rounds++;
+		if (rounds == 1) tC = clock64();
+		exits[j + 1] = exit_;
+		if (j == 0) { exits[0] = 0; changed = 0; }
+		__syncthreads();
+		const int ne = exits[j];
+		dirty = (ne != entry);
+		if (dirty) { entry = ne; exit_ = ne; changed = 1; }
+		__syncthreads();
+		const int again = changed;
+		__syncthreads();
+		if (!again) break;
 	}
-	atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK], (unsigned long long)blocks);
+	// mark the true path and count the Occ blocks the reference's walk reads
+	u32 alg_blocks = 0;
+	for (int s = entry; s < bend;) { atomicOr(&bits[s >> 5], 1u << (s & 31)); if (COUNT) alg_blocks += mblk[s]; s += memo[s]; }
+	for (int o = 32; o; o >>= 1) { alg_blocks += __shfl_down(alg_blocks, o); all_blocks += __shfl_down(all_blocks, o); }
+	if ((j & 63) == 0) {
+		if (alg_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK], (unsigned long long)alg_blocks);
+		if (all_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK_ALL], (unsigned long long)all_blocks);
+		atomicAdd((unsigned long long *)&cnt[12], (unsigned long long)iters);
+		atomicMax((unsigned long long *)&cnt[13], (unsigned long long)iters);
+	}
+	const long long tD = clock64();
+	if (j == 0) atomicMax((unsigned long long *)&cnt[11], (unsigned long long)rounds);
+	if ((j & 63) == 0) { atomicMax((unsigned long long *)&cnt[14], (unsigned long long)(tB - tA)); atomicMax((unsigned long long *)&cnt[15], (unsigned long long)(tC - tB)); atomicAdd((unsigned long long *)&cnt[3], (unsigned long long)(tC - tB)); atomicMax((unsigned long long *)&cnt[1], (unsigned long long)(tD - tC)); }
+	__syncthreads();
+	for (int p = j; p < PATH_WORDS; p += SEED_WG) onpath[(size_t)chunk * PATH_WORDS + p] = bits[p];
 }
 
 // ---------------------------------------------------------------------------
-// Locate: one lane per pending hit, ~31 dependent LF steps each (a3).  Emits the
-// 64-bit sort key ((PosDiff + qlen) << qbits) | qPos and the seed length.
+// Candidate -> seeds: keep the matches whose start lies on the true chain, locate
+// every hit through the dense SA (a3: one read instead of ~31 dependent LF steps)
+// and emit the 64-bit sort key ((PosDiff + qlen) << qbits) | qPos with the length.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_locate(DevIndex di, i64 n, const u64 *__restrict__ hit_row, const i32 *__restrict__ hit_qpos,
-                                                 const i32 *__restrict__ hit_len, i32 qlen, int qbits, u64 *key, u32 *val, u64 *cnt)
+__global__ void __launch_bounds__(256) k_seed_select(DevIndex di, const u64 *cnt_in, u32 cand_cap, const i32 *__restrict__ cand_s, const i32 *__restrict__ cand_len,
+                                                      const u64 *__restrict__ cand_x0, const i32 *__restrict__ cand_freq, const u32 *__restrict__ onpath,
+                                                      i32 qlen, int qbits, u64 *key, u32 *val, u64 hit_cap, u64 *cnt)
 {
-	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	u32 steps = 0;
-	if (i < n) {
-		u64 r = fm_locate(di, hit_row[i], steps);
-		i64 pd = (i64)r - hit_qpos[i] + qlen;
-		key[i] = ((u64)pd << qbits) | (u32)hit_qpos[i];
-		val[i] = (u32)hit_len[i];
+	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+	u64 nc = cnt_in[CNT_CAND]; if (nc > cand_cap) nc = cand_cap;
+	if (i >= nc) return;
+	const i32 s = cand_s[i];
+	const i32 chunk = s / GSA_CHUNK, p = s - chunk * GSA_CHUNK;
+	if (!((onpath[(size_t)chunk * PATH_WORDS + (p >> 5)] >> (p & 31)) & 1u)) return;
+	const u32 f = (u32)cand_freq[i];
+	const u64 off = atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)f);
+	if (off + f > hit_cap) { cnt[CNT_OVERFLOW] = 2; return; }
+	const u64 x0 = cand_x0[i]; const u32 len = (u32)cand_len[i];
+	for (u32 h = 0; h < f; h++) {
+		const u64 r = fm_locate(di, x0 + h);
+		const i64 pd = (i64)r - s + qlen;
+		key[off + h] = ((u64)pd << qbits) | (u32)s;
+		val[off + h] = len;
 	}
-	// one atomic per wave
-	for (int o = 32; o; o >>= 1) steps += __shfl_down(steps, o);
-	if ((threadIdx.x & 63) == 0 && steps) atomicAdd((unsigned long long *)&cnt[CNT_LF], (unsigned long long)steps);
 }
 
 // sorted keys -> SoA seeds + "new group starts here" flag (SeedGrouping, a6)
@@ -84,39 +206,116 @@ __global__ void k_group_ids(i64 n, const i32 *__restrict__ flag, const i32 *__re
 	if (flag[i]) g_beg[g] = (i32)i;
 }
 
+// ---------------------------------------------------------------------------
+// Dense SA (index upload time).  The on-disk SA keeps every 32nd ROW; a walk from
+// sampled row k (SA = p) visits rows with SA p-1, p-2, ... and stops at the next
+// sampled row, so the walks started at all sampled rows together touch every row
+// exactly once: 2G LF steps in total, one lane per sampled row.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_densify_sa(DevIndex di, u64 n_sa, u32 *d32, u64 *d64)
+{
+	const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_sa) return;
+	u64 k = i << 5;
+	u64 p = i == 0 ? di.seq_len : di.sa[i];
+	if (d32) d32[k] = (u32)(i == 0 ? 0xFFFFFFFFu : p); else d64[k] = i == 0 ? (u64)-1 : p;
+	for (;;) {
+		k = fm_lf(di, k); p -= 1;
+		if ((k & 31) == 0) break;
+		if (d32) d32[k] = (u32)p; else d64[k] = p;
+	}
+}
+
+// k-mer jump table: entry id = the interval BWT_Search holds after matching the k bases of id
+// (first base in the top bits); x2 = 0 when the walk dies earlier (then the stepwise walk is used).
+__global__ void __launch_bounds__(256) k_build_kmer(DevIndex di, int k, u64 *tab)
+{
+	const u32 id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= (1u << (2 * k))) return;
+	FmIntv ik = fm_init(di, (int)((id >> (2 * (k - 1))) & 3));
+	u32 blk = 0; bool alive = true;
+	for (int t = 1; t < k && alive; t++) alive = fm_extend(di, ik, (int)((id >> (2 * (k - 1 - t))) & 3), blk);
+	u64 *e = tab + ((size_t)id << 2);
+	e[0] = ik.x0; e[1] = ik.x1; e[2] = alive ? ik.x2 : 0; e[3] = 0;
+}
+
+int build_dense_sa(gsa_ctx *c, u64 n_sa)
+{
+	{
+		// k = floor(log4(2G)) - 1, capped: about 1/4 of the k-mers absent at most, table <= 512 MiB
+		int k = 0; while ((1ull << (2 * (k + 1))) <= c->di.seq_len) k++;
+		k -= 1; if (k > 12) k = 12;
+		if (k >= 2) {
+			const size_t n = (size_t)1 << (2 * k);
+			if (!dev_ensure<u64>(c, c->d_kmer, n * 4)) return GSA_ERR_NOMEM;
+			hipLaunchKernelGGL(k_build_kmer, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->di, k, c->d_kmer.as<u64>());
+			GSA_CHECK(c, hipGetLastError());
+			GSA_CHECK(c, hipStreamSynchronize(c->stream));
+			c->di.kmer = c->d_kmer.as<u64>(); c->di.kmer_k = k;
+		}
+	}
+	const u64 rows = c->di.seq_len + 1;
+	const bool use32 = c->di.seq_len < 0xFFFFFFF0ull;
+	if (use32) { if (!dev_ensure<u32>(c, c->d_sa_dense, rows + 32)) return GSA_ERR_NOMEM; c->di.sa32 = c->d_sa_dense.as<u32>(); c->di.sa64 = nullptr; }
+	else { if (!dev_ensure<u64>(c, c->d_sa_dense, rows + 32)) return GSA_ERR_NOMEM; c->di.sa64 = c->d_sa_dense.as<u64>(); c->di.sa32 = nullptr; }
+	hipLaunchKernelGGL(k_densify_sa, dim3(grid_for(n_sa, 256)), dim3(256), 0, c->stream, c->di, n_sa, (u32 *)c->di.sa32, (u64 *)c->di.sa64);
+	GSA_CHECK(c, hipGetLastError());
+	GSA_CHECK(c, hipStreamSynchronize(c->stream));
+	return GSA_OK;
+}
+
 int stage1_seed(gsa_ctx *c)
 {
 	const i32 qlen = c->qlen;
 	hipStream_t st = c->stream;
-	GSA_CHECK(c, hipMemsetAsync(c->d_cnt.p, 0, 16 * sizeof(u64), st));
 	c->n_seeds = 0; c->n_groups = 0;
 	if (qlen <= 0) return GSA_OK;
 	const i64 n_chunks = ((i64)qlen + GSA_CHUNK - 1) / GSA_CHUNK;
-	// pending-hit capacity: grows and retries on overflow
-	size_t cap = c->d_hit_row.cap / sizeof(u64);
-	if (cap < (size_t)qlen / 16 + 4096) cap = (size_t)qlen / 16 + 4096;
+	size_t ccap = c->d_cand_s.cap / sizeof(i32);
+	if (ccap < (size_t)qlen / 8 + 4096) ccap = (size_t)qlen / 8 + 4096;
+	size_t hcap = c->d_key_a.cap / sizeof(u64);
+	if (hcap < (size_t)qlen / 16 + 4096) hcap = (size_t)qlen / 16 + 4096;
+	if (!dev_ensure<u32>(c, c->d_onpath, (size_t)n_chunks * PATH_WORDS)) return GSA_ERR_NOMEM;
 	i64 n_hits = 0;
-	for (int attempt = 0; attempt < 8; attempt++) {
-		if (!dev_ensure<u64>(c, c->d_hit_row, cap) || !dev_ensure<i32>(c, c->d_hit_qpos, cap) || !dev_ensure<i32>(c, c->d_hit_len, cap)) return GSA_ERR_NOMEM;
-		GSA_CHECK(c, hipMemsetAsync(c->d_cnt.p, 0, 16 * sizeof(u64), st));
-		if (c->profiling) hipEventRecord(c->ev[0], st);
-		hipLaunchKernelGGL(k_seed_chunks, dim3(grid_for(n_chunks, 64)), dim3(64), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm,
-		                   c->d_cnt.as<u64>(), c->d_hit_row.as<u64>(), c->d_hit_qpos.as<i32>(), c->d_hit_len.as<i32>(), (u64)cap);
-		if (c->profiling) hipEventRecord(c->ev[1], st);
-		GSA_CHECK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt.p, 16 * sizeof(u64), hipMemcpyDeviceToHost, st));
+	bool need_search = true;
+	for (int attempt = 0;; attempt++) {
+		if (attempt == 8) return gsa_fail(c, GSA_ERR_LIMIT, "seed buffers keep overflowing");
+		if (!dev_ensure<i32>(c, c->d_cand_s, ccap) || !dev_ensure<i32>(c, c->d_cand_len, ccap) || !dev_ensure<u64>(c, c->d_cand_x0, ccap) || !dev_ensure<i32>(c, c->d_cand_freq, ccap)) return GSA_ERR_NOMEM;
+		if (!dev_ensure<u64>(c, c->d_key_a, hcap) || !dev_ensure<u32>(c, c->d_val_a, hcap)) return GSA_ERR_NOMEM;
+		u64 *cnt = c->d_cnt.as<u64>();
+		if (need_search) {
+			GSA_CHECK(c, hipMemsetAsync(cnt, 0, 16 * sizeof(u64), st));
+			if (c->profiling) hipEventRecord(c->ev[0], st);
+			if (c->count_blocks)
+				hipLaunchKernelGGL(k_seed_wg<true>, dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
+				                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_onpath.as<u32>());
+			else
+				hipLaunchKernelGGL(k_seed_wg<false>, dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
+				                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_onpath.as<u32>());
+			if (c->profiling) hipEventRecord(c->ev[1], st);
+		} else {
+			GSA_CHECK(c, hipMemsetAsync(cnt + CNT_HITS, 0, sizeof(u64), st));
+			GSA_CHECK(c, hipMemsetAsync(cnt + CNT_OVERFLOW, 0, sizeof(u64), st));
+		}
+		hipLaunchKernelGGL(k_seed_select, dim3(grid_for(ccap, 256)), dim3(256), 0, st, c->di, cnt, (u32)ccap, c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
+		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), qlen, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), (u64)hcap, cnt);
+		if (c->profiling) hipEventRecord(c->ev[2], st);
+		GSA_CHECK(c, hipMemcpyAsync(c->h_cnt, cnt, 16 * sizeof(u64), hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipStreamSynchronize(st));
 		n_hits = (i64)c->h_cnt[CNT_HITS];
-		if (!c->h_cnt[CNT_OVERFLOW]) break;
-		cap = (size_t)n_hits + (size_t)n_hits / 8 + 4096;
-		if (attempt == 7) return gsa_fail(c, GSA_ERR_LIMIT, "pending-hit buffer overflow");
+		if (c->h_cnt[CNT_CAND] > ccap) { ccap = (size_t)c->h_cnt[CNT_CAND] + (size_t)c->h_cnt[CNT_CAND] / 8 + 4096; need_search = true; continue; }
+		if (c->h_cnt[CNT_OVERFLOW] == 2 || (size_t)n_hits > hcap) { hcap = (size_t)n_hits + (size_t)n_hits / 8 + 4096; need_search = false; continue; }
+		break;
 	}
+	c->counters[0] = c->h_cnt[CNT_OCCBLK]; c->counters[1] = 0; c->counters[2] = (u64)n_hits; c->counters[3] = (u64)n_hits; c->counters[7] = c->h_cnt[CNT_OCCBLK_ALL];
+	c->dbg[0] = c->h_cnt[11]; c->dbg[1] = c->h_cnt[12]; c->dbg[2] = c->h_cnt[13];
+	if (getenv("GSA_DEBUG")) fprintf(stderr, "[gsa] clk init max %llu, round1 max %llu avg %llu, later rounds max %llu\n", (unsigned long long)c->h_cnt[14], (unsigned long long)c->h_cnt[15], (unsigned long long)(c->h_cnt[3] / ((u64)n_chunks * 4)), (unsigned long long)c->h_cnt[1]);
 	c->n_seeds = n_hits;
+	if (c->profiling) { float ms; hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms; hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->kernel_ms[1] = ms; }
 	if (n_hits == 0) return GSA_OK;
 	if (n_hits >= (1ll << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");
 	const size_t n = (size_t)n_hits;
-	if (!dev_ensure<u64>(c, c->d_key_a, n) || !dev_ensure<u64>(c, c->d_key_b, n) || !dev_ensure<u32>(c, c->d_val_a, n) || !dev_ensure<u32>(c, c->d_val_b, n)) return GSA_ERR_NOMEM;
-	hipLaunchKernelGGL(k_locate, dim3(grid_for(n, 256)), dim3(256), 0, st, c->di, (i64)n, c->d_hit_row.as<u64>(), c->d_hit_qpos.as<i32>(), c->d_hit_len.as<i32>(),
-	                   qlen, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->d_cnt.as<u64>());
+	if (!dev_ensure<u64>(c, c->d_key_b, hcap) || !dev_ensure<u32>(c, c->d_val_b, hcap)) return GSA_ERR_NOMEM;
 	if (c->profiling) hipEventRecord(c->ev[2], st);
 	int rc = prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), n, 0, c->qbits + c->pdbits);
 	if (rc) return rc;
@@ -130,16 +329,9 @@ int stage1_seed(gsa_ctx *c)
 	if (c->profiling) hipEventRecord(c->ev[3], st);
 	i32 ng = 0;
 	GSA_CHECK(c, hipMemcpyAsync(&ng, c->d_scan.as<i32>() + n, sizeof(i32), hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipMemcpyAsync(c->h_cnt, c->d_cnt.p, 16 * sizeof(u64), hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipStreamSynchronize(st));
 	c->n_groups = ng;
-	c->counters[0] = c->h_cnt[CNT_OCCBLK]; c->counters[1] = c->h_cnt[CNT_LF]; c->counters[2] = (u64)n_hits; c->counters[3] = (u64)n_hits;
-	if (c->profiling) {
-		float ms;
-		hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms;
-		hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->kernel_ms[1] = ms;
-		hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->kernel_ms[2] = ms;
-	}
+	if (c->profiling) { float ms; hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->kernel_ms[2] = ms; }
 	return GSA_OK;
 }
 
@@ -157,7 +349,8 @@ __global__ void k_search_batch(DevIndex di, const uint8_t *__restrict__ q, Param
 	int f = 0;
 	if (len >= prm.MinSeedLength && ik.x2 <= GSA_MAX_SEED_FREQ) {
 		f = (int)ik.x2;
-		for (int h = 0; h < f; h++) out_loc[(i64)i * GSA_MAX_SEED_FREQ + h] = (i64)fm_locate(di, ik.x0 + h, steps);
+		// even hits: the reference's LF walk on the sampled SA; odd hits: the dense SA (both must agree with bwt_sa)
+		for (int h = 0; h < f; h++) out_loc[(i64)i * GSA_MAX_SEED_FREQ + h] = (h & 1) ? (i64)fm_locate(di, ik.x0 + h) : (i64)fm_locate_walk(di, ik.x0 + h, steps);
 	}
 	out_freq[i] = f;
 }

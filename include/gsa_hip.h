@@ -156,13 +156,17 @@ int gsa_gap_similarity_batch(gsa_ctx *ctx, int32_t n, const int32_t *q1, const i
  * Event counters and HIP-event timings of the last gsa_align_contig /
  * gsa_run_to sequence.  counters: [0] Occ blocks read by seed extension,
  * [1] LF steps, [2] located hits, [3] seeds, [4] DP cells, [5] DP jobs,
- * [6] sum(m+n) over DP jobs, [7] reserved.  kernel_ms: per-kernel-family device
+ * [6] sum(m+n) over DP jobs, [7] Occ blocks actually read incl. speculative walks
+ * ([0] counts what the reference's walk reads = the algorithmic figure).  kernel_ms: per-kernel-family device
  * time measured with hipEvents on the library's stream:
  * [0] seed search [1] locate [2] sorts [3] chaining (S2) [4] refinement (S3-S6)
  * [5] DP + string materialisation [6] total device time [7] host list logic. */
 int gsa_get_counters(gsa_ctx *ctx, uint64_t counters[8]);
 int gsa_get_timings(gsa_ctx *ctx, float kernel_ms[8]);
-int gsa_set_profiling(gsa_ctx *ctx, int enable);   /* per-stage hipEvent timing on/off (default off) */
+/* flags: bit 0 = per-stage hipEvent timing; bit 1 = run the ACCOUNTING build of the seed kernel,
+ * which also records, per search, how many Occ blocks the reference's walk reads, so that counters[0]
+ * is exact (same seeds either way; the default build leaves counters[0] = 0). */
+int gsa_set_profiling(gsa_ctx *ctx, int flags);
 
 #ifdef __cplusplus
 }
