@@ -110,6 +110,7 @@ void gsa_destroy(gsa_ctx *c)
 		&c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_aln1, &c->d_aln2, &c->d_alnoff, &c->bl_alnlen, &c->bl_score };
 	for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
+	for (DevBuf *b : { &c->p_frags, &c->p_aln1, &c->p_aln2 }) if (b->p) hipHostFree(b->p);
 	for (int i = 0; i < 16; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 2; i++) if (c->stream_aux[i]) hipStreamDestroy(c->stream_aux[i]);
 	if (c->stream) hipStreamDestroy(c->stream);
@@ -195,8 +196,14 @@ int gsa_get_blocks(gsa_ctx *c, gsa_result *out)
 	if (!c || !out) return GSA_ERR_ARG;
 	if (c->stage < 2) return gsa_fail(c, GSA_ERR_STATE, "run stage 2 first");
 	if (c->frags_stage != c->stage) { int rc = build_block_view(c); if (rc) return rc; }
-	out->n_blocks = (int32_t)c->h_blocks.size(); out->n_frags = (int64_t)c->h_frags.size(); out->n_aln = (int64_t)c->h_aln1.size();
-	out->blocks = c->h_blocks.data(); out->frags = c->h_frags.data(); out->aln1 = c->h_aln1.data(); out->aln2 = c->h_aln2.data();
+	out->n_blocks = (int32_t)c->h_blocks.size(); out->blocks = c->h_blocks.data();
+	if (c->result_pinned && c->stage == 8) {
+		out->n_frags = c->n_frags; out->n_aln = c->n_aln;
+		out->frags = c->p_frags.as<gsa_frag>(); out->aln1 = c->p_aln1.as<char>(); out->aln2 = c->p_aln2.as<char>();
+	} else {
+		out->n_frags = (int64_t)c->h_frags.size(); out->n_aln = (int64_t)c->h_aln1.size();
+		out->frags = c->h_frags.data(); out->aln1 = c->h_aln1.data(); out->aln2 = c->h_aln2.data();
+	}
 	return GSA_OK;
 }
 

@@ -138,7 +138,7 @@ int host_stage4_5_6(gsa_ctx *c, int stage)
 int host_stage8_finish(gsa_ctx *c)
 {
 	const size_t nfb = c->blocks.size();
-	c->h_blocks.clear(); c->h_frags.clear(); c->h_aln1.clear(); c->h_aln2.clear();
+	c->h_blocks.clear(); c->h_frags.clear(); c->h_aln1.clear(); c->h_aln2.clear(); c->result_pinned = false;
 	if (nfb == 0) return GSA_OK;
 	std::vector<i32> bl_len(nfb), bl_score(nfb), fragbase(nfb);
 	GSA_CHECK(c, hipMemcpy(bl_len.data(), c->bl_alnlen.p, nfb * 4, hipMemcpyDeviceToHost));
@@ -178,12 +178,14 @@ int host_stage8_finish(gsa_ctx *c)
 	}
 	c->kernel_ms[7] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	// records + gapped strings to the host
-	c->h_frags.resize((size_t)c->n_frags); c->h_aln1.resize((size_t)c->n_aln); c->h_aln2.resize((size_t)c->n_aln);
-	if (c->n_frags) GSA_CHECK(c, hipMemcpy(c->h_frags.data(), c->f_rec.p, (size_t)c->n_frags * sizeof(gsa_frag), hipMemcpyDeviceToHost));
+	if (!pin_ensure<gsa_frag>(c, c->p_frags, (size_t)c->n_frags) || !pin_ensure<char>(c, c->p_aln1, (size_t)c->n_aln) || !pin_ensure<char>(c, c->p_aln2, (size_t)c->n_aln)) return GSA_ERR_NOMEM;
+	if (c->n_frags) GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, (size_t)c->n_frags * sizeof(gsa_frag), hipMemcpyDeviceToHost, c->stream));
 	if (c->n_aln) {
-		GSA_CHECK(c, hipMemcpy(c->h_aln1.data(), c->d_aln1.p, (size_t)c->n_aln, hipMemcpyDeviceToHost));
-		GSA_CHECK(c, hipMemcpy(c->h_aln2.data(), c->d_aln2.p, (size_t)c->n_aln, hipMemcpyDeviceToHost));
+		GSA_CHECK(c, hipMemcpyAsync(c->p_aln1.p, c->d_aln1.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, c->stream));
+		GSA_CHECK(c, hipMemcpyAsync(c->p_aln2.p, c->d_aln2.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, c->stream));
 	}
+	GSA_CHECK(c, hipStreamSynchronize(c->stream));
+	c->result_pinned = true;
 	c->frags_stage = 8;
 	return GSA_OK;
 }
@@ -191,7 +193,7 @@ int host_stage8_finish(gsa_ctx *c)
 // materialise the current AlnBlockVec for the getters (stages 2..7; stage 8 is built above)
 int build_block_view(gsa_ctx *c)
 {
-	c->h_blocks.clear(); c->h_frags.clear(); c->h_aln1.clear(); c->h_aln2.clear();
+	c->h_blocks.clear(); c->h_frags.clear(); c->h_aln1.clear(); c->h_aln2.clear(); c->result_pinned = false;
 	if (c->stage == 8) { c->frags_stage = 8; return GSA_OK; }     // nothing survived
 	if (c->stage == 2) {
 		const size_t nc = (size_t)c->n_c;

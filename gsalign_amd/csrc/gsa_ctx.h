@@ -97,6 +97,8 @@ struct gsa_ctx {
 	DevBuf bl_alnlen, bl_score;
 	std::vector<gsa_frag> h_frags; std::vector<gsa_block> h_blocks; std::vector<char> h_aln1, h_aln2;
 	int frags_stage = 0;                           // stage for which h_frags/h_blocks were built
+	// stage-8 results land in pinned host memory (one async D2H each, no pageable staging)
+	DevBuf p_frags, p_aln1, p_aln2; bool result_pinned = false;
 };
 
 template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n)
@@ -106,6 +108,17 @@ template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 	if (b.p) { hipStreamSynchronize(c->stream); hipFree(b.p); b.p = nullptr; b.cap = 0; }
 	size_t want = bytes + bytes / 4 + 256;
 	if (hipMalloc(&b.p, want) != hipSuccess) { gsa_fail(c, GSA_ERR_NOMEM, "hipMalloc"); return nullptr; }
+	b.cap = want;
+	return (T *)b.p;
+}
+
+template <class T> static inline T *pin_ensure(gsa_ctx *c, DevBuf &b, size_t n)
+{
+	size_t bytes = (n ? n : 1) * sizeof(T);
+	if (bytes <= b.cap) return (T *)b.p;
+	if (b.p) { hipStreamSynchronize(c->stream); hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+	size_t want = bytes + bytes / 4 + 4096;
+	if (hipHostMalloc(&b.p, want) != hipSuccess) { gsa_fail(c, GSA_ERR_NOMEM, "hipHostMalloc"); return nullptr; }
 	b.cap = want;
 	return (T *)b.p;
 }

@@ -68,37 +68,59 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 	if (lane == 0) ops_len[job] = nops;
 }
 
-template <int T>
+template <int T, int KMAX>
 __global__ void __launch_bounds__(T) k_dp_wg(i32 n_jobs, const i32 *__restrict__ order, const i64 *__restrict__ diroff, const uint8_t *__restrict__ pool1,
                                               const i64 *__restrict__ off1, const i32 *__restrict__ len1, const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2,
-                                              const i32 *__restrict__ len2, uint8_t *dirbase, uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, int npad)
+                                              const i32 *__restrict__ len2, uint8_t *dirbase, uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, int mpad)
 {
-	extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+	extern __shared__ __attribute__((aligned(16))) int8_t lds[];        // the reference fragment as nt4 codes
 	__shared__ uint8_t tile[64][64];
+	__shared__ int xchg[2][T / 64][KMAX];                               // (x | v << 8) of each wave's last lane, per column set, ping-pong by diagonal parity
 	__shared__ int s_i, s_j, s_state, s_k;
 	if ((i32)blockIdx.x >= n_jobs) return;
 	const i32 job = order[blockIdx.x];
-	const int m = len1[job], n = len2[job], tid = threadIdx.x;
+	const int m = len1[job], n = len2[job], tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const uint8_t *s1 = pool1 + off1[job], *s2 = pool2 + off2[job];
 	uint8_t *dir = dirbase + diroff[blockIdx.x];
 	uint8_t *rev = revbase + ops_off[job], *op = ops + ops_off[job];
 	if (m <= 0 || n <= 0) { if (tid == 0) ops_len[job] = 0; return; }
-	int8_t *U = lds, *Y = lds + npad, *X0 = lds + 2 * npad, *X1 = lds + 3 * npad, *V0 = lds + 4 * npad, *V1 = lds + 5 * npad;
-	for (int t = tid; t < n; t += T) { U[t] = t ? 2 : 0; Y[t] = 0; X0[t] = 0; X1[t] = 0; V0[t] = 0; V1[t] = 0; }   // (r-1, t=r) boundary: u = q, y = 0 (:165)
+	// Thread tid owns target columns t = tid + k*T: their (u,v,x,y) state stays in registers for the
+	// whole fill; the left neighbour's (x,v) of the previous diagonal arrives by a DPP wave shift, and
+	// only the lane at a wave boundary goes through LDS.  One barrier per anti-diagonal.
+	int8_t *C1 = lds;
+	for (int t = tid; t < m; t += T) C1[t] = (int8_t)gsa_nt4(s1[t]);
+	int u[KMAX], y[KMAX], x[KMAX], v[KMAX], cq[KMAX];
+#pragma unroll
+	for (int k = 0; k < KMAX; k++) { const int t = tid + k * T; u[k] = t ? 2 : 0; y[k] = 0; x[k] = 0; v[k] = 0; cq[k] = t < n ? gsa_nt4(s2[t]) : 4; }
+	if (lane == 63) {
+#pragma unroll
+		for (int k = 0; k < KMAX; k++) { xchg[0][w][k] = 0; xchg[1][w][k] = 0; }
+	}
 	__syncthreads();
 	const int nr = m + n - 1;
 	i64 off = 0;
 	for (int r = 0; r < nr; r++) {
 		const int st = r - m + 1 > 0 ? r - m + 1 : 0, en = r < n - 1 ? r : n - 1;
-		const int8_t *Xp = (r & 1) ? X1 : X0, *Vp = (r & 1) ? V1 : V0;
-		int8_t *Xn = (r & 1) ? X0 : X1, *Vn = (r & 1) ? V0 : V1;
-		for (int t = st + tid; t <= en; t += T) {
-			int xt1, vt1;
-			if (t > 0) { xt1 = Xp[t - 1]; vt1 = Vp[t - 1]; } else { xt1 = 0; vt1 = r ? 2 : 0; }
-			int un, vn, xn, yn;
-			const int d = dp_cell(xt1, vt1, U[t], Y[t], gsa_nt4(s2[t]), gsa_nt4(s1[r - t]), un, vn, xn, yn);
-			U[t] = (int8_t)un; Y[t] = (int8_t)yn; Xn[t] = (int8_t)xn; Vn[t] = (int8_t)vn;
-			dir[off + (t - st)] = (uint8_t)d;
+		const int par = r & 1;
+#pragma unroll
+		for (int k = 0; k < KMAX; k++) {
+			const int t = tid + k * T;
+			if (k * T > en) break;                                       // uniform: no column of this set is on the diagonal yet / any more
+			// (x,v) of column t-1 on diagonal r-1
+			int fill;
+			if (w > 0) fill = xchg[par][w - 1][k];
+			else if (k > 0) fill = xchg[par][T / 64 - 1][k - 1];
+			else fill = (r ? 2 : 0) << 8;                                // t = 0 boundary: x1 = 0, v1 = q (:157-164)
+			const int packed = wave_shr1(x[k] | (v[k] << 8), fill);
+			const int xt1 = packed & 0xff, vt1 = packed >> 8;
+			const int jj = r - t;
+			if (t < n && jj >= 0 && jj < m) {
+				int un, vn, xn, yn;
+				const int d = dp_cell(xt1, vt1, u[k], y[k], cq[k], C1[jj], un, vn, xn, yn);
+				u[k] = un; v[k] = vn; x[k] = xn; y[k] = yn;
+				dir[off + (t - st)] = (uint8_t)d;
+			}
+			if (lane == 63) xchg[par ^ 1][w][k] = x[k] | (v[k] << 8);
 		}
 		off += en - st + 1;
 		__syncthreads();
@@ -186,26 +208,28 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n, const uint8_t *pool1, const i64 *off1, cons
 	size_t first = 0;
 	bool small_done = small.empty();
 	while (first < wg_jobs.size() || !small_done) {
-		size_t last = first; i64 bytes = 0; int nmax_big = 1, nmax_mid = 1; size_t nbig = 0;
+		size_t last = first; i64 bytes = 0; int nmax_big = 1, nmax_mid = 1, mmax_big = 1, mmax_mid = 1; size_t nbig = 0;
 		while (last < wg_jobs.size()) {
 			const i32 jb = wg_jobs[last]; const i64 cells = (i64)h_len1[jb] * h_len2[jb];
 			if (last > first && bytes + cells > budget) break;
 			h_diroff[last] = bytes; bytes += cells;
-			if (last < big.size()) { nbig++; if (h_len2[jb] > nmax_big) nmax_big = h_len2[jb]; } else if (h_len2[jb] > nmax_mid) nmax_mid = h_len2[jb];
+			if (last < big.size()) { nbig++; if (h_len2[jb] > nmax_big) nmax_big = h_len2[jb]; if (h_len1[jb] > mmax_big) mmax_big = h_len1[jb]; }
+			else { if (h_len2[jb] > nmax_mid) nmax_mid = h_len2[jb]; if (h_len1[jb] > mmax_mid) mmax_mid = h_len1[jb]; }
 			last++;
 		}
 		uint8_t *dir = dev_ensure<uint8_t>(c, c->d_scan2, (size_t)bytes + 64);
 		i64 *d_diroff = dev_ensure<i64>(c, c->j_cells, wg_jobs.size() + 1);
 		if (!dir || !d_diroff) return GSA_ERR_NOMEM;
 		if (last > first) GSA_CHECK(c, hipMemcpyAsync(d_diroff + first, h_diroff.data() + first, (last - first) * 8, hipMemcpyHostToDevice, st));
-		const int npad_big = (nmax_big + 63) & ~63, npad_mid = (nmax_mid + 63) & ~63;
-		if ((size_t)npad_big * 6 > 140 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP fragment longer than 23800 bases");
+		const int npad_big = (nmax_big + 63) & ~63, npad_mid = (nmax_mid + 63) & ~63, mpad_big = (mmax_big + 63) & ~63, mpad_mid = (mmax_mid + 63) & ~63;
+		if (nmax_big > 5 * 1024 || mpad_big > 140 * 1024 || mpad_mid > 140 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP fragment too long (query side > 5120 or reference side > 143360 bases)");
+		(void)npad_big; (void)npad_mid;
 		GSA_CHECK(c, hipEventRecord(ev_fork, st));
 		const size_t nmid = (last - first) - nbig;
-		if (nbig) hipLaunchKernelGGL(k_dp_wg<1024>, dim3((unsigned)nbig), dim3(1024), (size_t)npad_big * 6, st, (i32)nbig, d_order + first, d_diroff + first, pool1, off1, len1, pool2, off2, len2, dir, rev, ops, ops_off, ops_len, npad_big);
+		if (nbig) hipLaunchKernelGGL((k_dp_wg<1024, 5>), dim3((unsigned)nbig), dim3(1024), (size_t)mpad_big, st, (i32)nbig, d_order + first, d_diroff + first, pool1, off1, len1, pool2, off2, len2, dir, rev, ops, ops_off, ops_len, mpad_big);
 		if (nmid) {
 			GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[0], ev_fork, 0));
-			hipLaunchKernelGGL(k_dp_wg<256>, dim3((unsigned)nmid), dim3(256), (size_t)npad_mid * 6, c->stream_aux[0], (i32)nmid, d_order + first + nbig, d_diroff + first + nbig, pool1, off1, len1, pool2, off2, len2, dir, rev, ops, ops_off, ops_len, npad_mid);
+			hipLaunchKernelGGL((k_dp_wg<256, 2>), dim3((unsigned)nmid), dim3(256), (size_t)mpad_mid, c->stream_aux[0], (i32)nmid, d_order + first + nbig, d_diroff + first + nbig, pool1, off1, len1, pool2, off2, len2, dir, rev, ops, ops_off, ops_len, mpad_mid);
 			GSA_CHECK(c, hipEventRecord(ev_j1, c->stream_aux[0]));
 			GSA_CHECK(c, hipStreamWaitEvent(st, ev_j1, 0));
 		}
