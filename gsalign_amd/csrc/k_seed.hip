@@ -29,8 +29,9 @@ enum { M_DONE = 0, M_FM = 1, M_TEXT = 2, M_KMER = 3, M_LOC = 4 };
 // ---------------------------------------------------------------------------
 template <bool COUNT>
 __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
-                                                      i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *onpath)
+                                                      i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath)
 {
+	__shared__ u32 s_ncand;
 	__shared__ uint8_t codes[GSA_CHUNK];
 	__shared__ uint16_t memo[GSA_CHUNK];      // next(s)-s, 0 = unknown
 	__shared__ uint16_t mblk[COUNT ? GSA_CHUNK : 1];   // Occ blocks the search from s read (accounting build only)
@@ -42,6 +43,8 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
 	for (int p = j; p < clen; p += SEED_WG) { codes[p] = (uint8_t)gsa_nt4(q[c0 + p]); memo[p] = 0; }
 	for (int p = j; p < PATH_WORDS; p += SEED_WG) bits[p] = 0;
+	if (j == 0) s_ncand = 0;
+	const size_t cbase = (size_t)chunk * cand_cap;      // this chunk's private candidate segment
 	const int S = (clen + SEED_WG - 1) / SEED_WG;
 	const int bend = (j + 1) * S < clen ? (j + 1) * S : clen;
 	int entry = j * S < clen ? j * S : clen, exit_ = entry;
@@ -111,8 +114,8 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 				const int len = pos - s;
 				int d = 1;
 				if (len >= prm.MinSeedLength && ik.x2 <= GSA_MAX_SEED_FREQ) {
-					const u32 slot = (u32)atomicAdd((unsigned long long *)&cnt[CNT_CAND], 1ull);
-					if (slot < cand_cap) { cand_s[slot] = (i32)(c0 + s); cand_len[slot] = len; cand_x0[slot] = ik.x0; cand_freq[slot] = (i32)ik.x2; }
+					const u32 slot = atomicAdd(&s_ncand, 1u);                 // LDS counter: no global round trip in the loop
+					if (slot < cand_cap) { cand_s[cbase + slot] = (i32)(c0 + s); cand_len[cbase + slot] = len; cand_x0[cbase + slot] = ik.x0; cand_freq[cbase + slot] = (i32)ik.x2; }
 					else cnt[CNT_OVERFLOW] = 1;
 					d = prm.bSensitive ? 5 : len + 1;
 				}
@@ -151,6 +154,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	if ((j & 63) == 0) { atomicMax((unsigned long long *)&cnt[14], (unsigned long long)(tB - tA)); atomicMax((unsigned long long *)&cnt[15], (unsigned long long)(tC - tB)); atomicAdd((unsigned long long *)&cnt[3], (unsigned long long)(tC - tB)); atomicMax((unsigned long long *)&cnt[1], (unsigned long long)(tD - tC)); }
 	__syncthreads();
 	for (int p = j; p < PATH_WORDS; p += SEED_WG) onpath[(size_t)chunk * PATH_WORDS + p] = bits[p];
+	if (j == 0) { cand_cnt[chunk] = s_ncand < cand_cap ? s_ncand : cand_cap; atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand); }
 }
 
 // ---------------------------------------------------------------------------
@@ -158,25 +162,26 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 // every hit through the dense SA (a3: one read instead of ~31 dependent LF steps)
 // and emit the 64-bit sort key ((PosDiff + qlen) << qbits) | qPos with the length.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_seed_select(DevIndex di, const u64 *cnt_in, u32 cand_cap, const i32 *__restrict__ cand_s, const i32 *__restrict__ cand_len,
+__global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, const u32 *__restrict__ cand_cnt, const i32 *__restrict__ cand_s, const i32 *__restrict__ cand_len,
                                                       const u64 *__restrict__ cand_x0, const i32 *__restrict__ cand_freq, const u32 *__restrict__ onpath,
                                                       i32 qlen, int qbits, u64 *key, u32 *val, u64 hit_cap, u64 *cnt)
 {
-	const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-	u64 nc = cnt_in[CNT_CAND]; if (nc > cand_cap) nc = cand_cap;
-	if (i >= nc) return;
-	const i32 s = cand_s[i];
-	const i32 chunk = s / GSA_CHUNK, p = s - chunk * GSA_CHUNK;
-	if (!((onpath[(size_t)chunk * PATH_WORDS + (p >> 5)] >> (p & 31)) & 1u)) return;
-	const u32 f = (u32)cand_freq[i];
-	const u64 off = atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)f);
-	if (off + f > hit_cap) { cnt[CNT_OVERFLOW] = 2; return; }
-	const u64 x0 = cand_x0[i]; const u32 len = (u32)cand_len[i];
-	for (u32 h = 0; h < f; h++) {
-		const u64 r = fm_locate(di, x0 + h);
-		const i64 pd = (i64)r - s + qlen;
-		key[off + h] = ((u64)pd << qbits) | (u32)s;
-		val[off + h] = len;
+	const u32 chunk = blockIdx.x, nc = cand_cnt[chunk];
+	const size_t cbase = (size_t)chunk * cand_cap;
+	for (u32 i = threadIdx.x; i < nc; i += blockDim.x) {
+		const i32 s = cand_s[cbase + i];
+		const i32 p = s - (i32)chunk * GSA_CHUNK;
+		if (!((onpath[(size_t)chunk * PATH_WORDS + (p >> 5)] >> (p & 31)) & 1u)) continue;
+		const u32 f = (u32)cand_freq[cbase + i];
+		const u64 off = atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)f);
+		if (off + f > hit_cap) { cnt[CNT_OVERFLOW] = 2; continue; }
+		const u64 x0 = cand_x0[cbase + i]; const u32 len = (u32)cand_len[cbase + i];
+		for (u32 h = 0; h < f; h++) {
+			const u64 r = fm_locate(di, x0 + h);
+			const i64 pd = (i64)r - s + qlen;
+			key[off + h] = ((u64)pd << qbits) | (u32)s;
+			val[off + h] = len;
+		}
 	}
 }
 
@@ -271,8 +276,7 @@ int stage1_seed(gsa_ctx *c)
 	c->n_seeds = 0; c->n_groups = 0;
 	if (qlen <= 0) return GSA_OK;
 	const i64 n_chunks = ((i64)qlen + GSA_CHUNK - 1) / GSA_CHUNK;
-	size_t ccap = c->d_cand_s.cap / sizeof(i32);
-	if (ccap < (size_t)qlen / 8 + 4096) ccap = (size_t)qlen / 8 + 4096;
+	size_t ccap = c->cand_cap_per_chunk;                // candidate slots per chunk (grows on overflow)
 	size_t hcap = c->d_key_a.cap / sizeof(u64);
 	if (hcap < (size_t)qlen / 16 + 4096) hcap = (size_t)qlen / 16 + 4096;
 	if (!dev_ensure<u32>(c, c->d_onpath, (size_t)n_chunks * PATH_WORDS)) return GSA_ERR_NOMEM;
@@ -280,7 +284,8 @@ int stage1_seed(gsa_ctx *c)
 	bool need_search = true;
 	for (int attempt = 0;; attempt++) {
 		if (attempt == 8) return gsa_fail(c, GSA_ERR_LIMIT, "seed buffers keep overflowing");
-		if (!dev_ensure<i32>(c, c->d_cand_s, ccap) || !dev_ensure<i32>(c, c->d_cand_len, ccap) || !dev_ensure<u64>(c, c->d_cand_x0, ccap) || !dev_ensure<i32>(c, c->d_cand_freq, ccap)) return GSA_ERR_NOMEM;
+		const size_t ctot = ccap * (size_t)n_chunks;
+		if (!dev_ensure<i32>(c, c->d_cand_s, ctot) || !dev_ensure<i32>(c, c->d_cand_len, ctot) || !dev_ensure<u64>(c, c->d_cand_x0, ctot) || !dev_ensure<i32>(c, c->d_cand_freq, ctot) || !dev_ensure<u32>(c, c->d_cand_cnt, (size_t)n_chunks)) return GSA_ERR_NOMEM;
 		if (!dev_ensure<u64>(c, c->d_key_a, hcap) || !dev_ensure<u32>(c, c->d_val_a, hcap)) return GSA_ERR_NOMEM;
 		u64 *cnt = c->d_cnt.as<u64>();
 		if (need_search) {
@@ -288,22 +293,22 @@ int stage1_seed(gsa_ctx *c)
 			if (c->profiling) hipEventRecord(c->ev[0], st);
 			if (c->count_blocks)
 				hipLaunchKernelGGL(k_seed_wg<true>, dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
-				                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_onpath.as<u32>());
+				                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>());
 			else
 				hipLaunchKernelGGL(k_seed_wg<false>, dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
-				                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_onpath.as<u32>());
+				                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>());
 			if (c->profiling) hipEventRecord(c->ev[1], st);
 		} else {
 			GSA_CHECK(c, hipMemsetAsync(cnt + CNT_HITS, 0, sizeof(u64), st));
 			GSA_CHECK(c, hipMemsetAsync(cnt + CNT_OVERFLOW, 0, sizeof(u64), st));
 		}
-		hipLaunchKernelGGL(k_seed_select, dim3(grid_for(ccap, 256)), dim3(256), 0, st, c->di, cnt, (u32)ccap, c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
+		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), 0, st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
 		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), qlen, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), (u64)hcap, cnt);
 		if (c->profiling) hipEventRecord(c->ev[2], st);
 		GSA_CHECK(c, hipMemcpyAsync(c->h_cnt, cnt, 16 * sizeof(u64), hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipStreamSynchronize(st));
 		n_hits = (i64)c->h_cnt[CNT_HITS];
-		if (c->h_cnt[CNT_CAND] > ccap) { ccap = (size_t)c->h_cnt[CNT_CAND] + (size_t)c->h_cnt[CNT_CAND] / 8 + 4096; need_search = true; continue; }
+		if (c->h_cnt[CNT_CAND] > ccap) { ccap = (size_t)c->h_cnt[CNT_CAND] + 256; c->cand_cap_per_chunk = ccap; need_search = true; continue; }
 		if (c->h_cnt[CNT_OVERFLOW] == 2 || (size_t)n_hits > hcap) { hcap = (size_t)n_hits + (size_t)n_hits / 8 + 4096; need_search = false; continue; }
 		break;
 	}
