@@ -53,6 +53,7 @@ struct gsa_ctx {
 	DevBuf d_cnt; u64 *h_cnt = nullptr;
 
 	// ---- stage 1 ----
+	DevBuf d_ref2;                                 // 2-bit packed reference text
 	DevBuf d_kmer;                                 // top-of-tree jump table
 	DevBuf d_sa_dense;                             // one SA entry per BWT row (built at gsa_create)
 	DevBuf d_cand_s, d_cand_len, d_cand_x0, d_cand_freq, d_onpath, d_cand_cnt;

@@ -33,6 +33,7 @@ struct DevIndex {
 	const u32 *sa32;        // dense SA, one entry per row, built on the device at gsa_create
 	const u64 *sa64;        //   (32-bit entries when 2G < 2^32, else 64-bit); row 0 is the -1 sentinel
 	const uint8_t *ref;     // 2G ASCII
+	const u32 *ref2;        // the same text 2-bit packed, 16 bases per word, LSB first (built at gsa_create)
 	i64 G;
 	const i64 *chr_end;     // 2*n_chr sorted last coordinates (ChrLocMap keys)
 	const i32 *chr_of_end;  // chromosome index per entry (ChrLocMap values)

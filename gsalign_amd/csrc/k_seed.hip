@@ -9,8 +9,41 @@
 enum { CNT_OCCBLK = 0, CNT_LF = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 4, CNT_DPJOBS = 5, CNT_DPMN = 6, CNT_CAND = 8, CNT_OVERFLOW = 9, CNT_OCCBLK_ALL = 10 };
 
 #define SEED_WG 256
-enum { M_DONE = 0, M_FM = 1, M_TEXT = 2, M_KMER = 3, M_LOC = 4 };
+#define NSUB 1024               // speculative sub-ranges per chunk (work items of the workgroup)
 #define PATH_WORDS 320          // 10240 on-path bits per chunk
+#define QP_WORDS (GSA_CHUNK / 16 + 4)
+#define QN_WORDS (GSA_CHUNK / 32 + 4)
+enum { M_DONE = 0, M_FM = 1, M_TEXT = 2, M_KMER = 3, M_LOC = 4, M_ADV = 5 };
+
+// ---- 2-bit packed sequences: base p sits at bits (2*(p&15)) of word p>>4 (LSB first) ----
+__device__ __forceinline__ int q_code(const u32 *qp, int p) { return (qp[p >> 4] >> ((p & 15) << 1)) & 3; }
+__device__ __forceinline__ int q_isn(const u32 *qn, int p) { return (qn[p >> 5] >> (p & 31)) & 1; }
+__device__ __forceinline__ u64 funnel64(u32 w0, u32 w1, u32 w2, int sh)      // 64 bits starting sh (even, < 32) bits into w0
+{
+	const u64 lo = (u64)w0 | ((u64)w1 << 32);
+	return sh ? (lo >> sh) | ((u64)w2 << (64 - sh)) : lo;
+}
+__device__ __forceinline__ u64 q_bits64(const u32 *qp, int p) { const int w = p >> 4; return funnel64(qp[w], qp[w + 1], qp[w + 2], (p & 15) << 1); }
+__device__ __forceinline__ u32 q_nbits32(const u32 *qn, int p) { const int w = p >> 5; return (u32)((((u64)qn[w + 1] << 32) | qn[w]) >> (p & 31)); }
+
+// Unique interval (x2 == 1): how many of the next (at most 32) query bases continue the only
+// occurrence, i.e. pos+t < clen, tp+t < tend, query base t unambiguous and equal to text base t.
+// Equivalent to that many successful bwt_2occ4 steps, which leave x0 and x2 = 1 unchanged
+// (see DESIGN.md section 4).  r0..r2 = packed reference words starting at word tp>>4.
+__device__ __forceinline__ int text_match32(u32 r0, u32 r1, u32 r2, i64 tp, i64 tend, const u32 *qp, const u32 *qn, int pos, int clen)
+{
+	int avail = clen - pos;
+	if (tend - tp < (i64)avail) avail = (int)(tend - tp);
+	if (avail > 32) avail = 32;
+	if (avail <= 0) return 0;
+	const u64 d = funnel64(r0, r1, r2, (int)(tp & 15) << 1) ^ q_bits64(qp, pos);
+	const u64 dm = (d | (d >> 1)) & 0x5555555555555555ull;
+	const u32 nm = q_nbits32(qn, pos);
+	int n = dm ? (__ffsll((unsigned long long)dm) - 1) >> 1 : 32;
+	const int fn = nm ? __ffs((int)nm) - 1 : 32;
+	n = n < fn ? n : fn;
+	return n < avail ? n : avail;
+}
 
 // ---------------------------------------------------------------------------
 // Seed exploration.  Work unit = one 10 000-bp chunk (absolute position, App. B
@@ -19,61 +52,68 @@ enum { M_DONE = 0, M_FM = 1, M_TEXT = 2, M_KMER = 3, M_LOC = 4 };
 // sequential -- but "next start" is a pure function of the start position, i.e.
 // the chunk is a functional graph whose paths merge (two walks that are inside
 // the same exact match end at the same mismatch).  One 256-lane workgroup owns a
-// chunk: lane j speculatively walks the sub-range [jS, (j+1)S) from its left
-// edge, memoising next(s) per position in LDS; then lanes re-enter their
-// sub-range at the previous lane's exit and follow the memo (a re-walk costs new
-// searches only until it merges with what is already memoised) until no exit
-// moves.  The result is exactly the reference's chain; the on-path bit per
-// position selects which memoised matches become seeds.
-// The chunk's query codes, the memo and the on-path bits live in LDS.
+// chunk and cuts it into NSUB sub-ranges.  Round 1: lanes pull sub-ranges from an
+// LDS queue and walk each one speculatively from its left edge, memoising next(s)
+// per position.  Later rounds: a sub-range whose true entry (= the previous
+// sub-range's exit) differs from where it was entered is re-walked along the memo
+// (new searches only until it merges) until no exit moves.  The result is exactly
+// the reference's chain; the on-path bit per position selects which memoised
+// matches become seeds.  Query (2-bit packed + N bitmap), memo, exits and on-path
+// bits live in LDS.
 // ---------------------------------------------------------------------------
 template <bool COUNT>
 __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath)
 {
-	__shared__ u32 s_ncand;
-	__shared__ uint8_t codes[GSA_CHUNK];
+	__shared__ u32 s_ncand, s_queue;
+	__shared__ int changed;
+	__shared__ u32 qp[QP_WORDS], qn[QN_WORDS];
 	__shared__ uint16_t memo[GSA_CHUNK];      // next(s)-s, 0 = unknown
 	__shared__ uint16_t mblk[COUNT ? GSA_CHUNK : 1];   // Occ blocks the search from s read (accounting build only)
 	__shared__ u32 bits[PATH_WORDS];
-	__shared__ i32 exits[SEED_WG + 1];
-	__shared__ int changed;
+	__shared__ uint16_t entry_of[NSUB], exit_of[NSUB];
 	const int chunk = blockIdx.x, j = threadIdx.x;
 	const i64 c0 = (i64)chunk * GSA_CHUNK;
 	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
-	for (int p = j; p < clen; p += SEED_WG) { codes[p] = (uint8_t)gsa_nt4(q[c0 + p]); memo[p] = 0; }
+	// stage the chunk: 32 bases per lane per pass -> two code words + one N word (16-byte global loads)
+	for (int g = j; g < QN_WORDS; g += SEED_WG) {
+		u32 w0 = 0, w1 = 0, wn = 0;
+		const int p0 = g << 5;
+		if (p0 < clen) {
+			const uint8_t *src = q + c0 + p0;
+			uint8_t b[32];
+			if (p0 + 32 <= clen) { *(uint4 *)&b[0] = *(const uint4 *)src; *(uint4 *)&b[16] = *(const uint4 *)(src + 16); }
+			else { for (int t = 0; t < 32; t++) b[t] = p0 + t < clen ? src[t] : (uint8_t)'N'; }
+#pragma unroll
+			for (int t = 0; t < 32; t++) {
+				const u32 cd = (u32)gsa_nt4(b[t]);
+				if (t < 16) w0 |= (cd & 3) << (2 * t); else w1 |= (cd & 3) << (2 * (t - 16));
+				wn |= (cd > 3 ? 1u : 0u) << t;
+			}
+		}
+		if (2 * g < QP_WORDS) qp[2 * g] = w0;
+		if (2 * g + 1 < QP_WORDS) qp[2 * g + 1] = w1;
+		qn[g] = wn;
+	}
+	for (int p = j; p < clen; p += SEED_WG) memo[p] = 0;
 	for (int p = j; p < PATH_WORDS; p += SEED_WG) bits[p] = 0;
-	if (j == 0) s_ncand = 0;
+	if (j == 0) { s_ncand = 0; s_queue = 0; }
 	const size_t cbase = (size_t)chunk * cand_cap;      // this chunk's private candidate segment
-	const int S = (clen + SEED_WG - 1) / SEED_WG;
-	const int bend = (j + 1) * S < clen ? (j + 1) * S : clen;
-	int entry = j * S < clen ? j * S : clen, exit_ = entry;
-	bool dirty = true;
+	const int S = (clen + NSUB - 1) / NSUB;             // sub-range length (>= 1)
+	const int nitems = (clen + S - 1) / S;
+	for (int it = j; it < nitems; it += SEED_WG) entry_of[it] = (uint16_t)(it * S);
 	u32 all_blocks = 0, rounds = 0, iters = 0;
-	const long long tA = clock64();
+	u32 dirty = 0;                                      // rounds >= 2: bit k = my k-th static item (j + k*SEED_WG) must be re-walked
 	__syncthreads();
-	const long long tB = clock64(); long long tC = 0;
 	for (;;) {
 		// One flat loop per wave.  Every iteration each lane has exactly ONE memory request pending
-		// (two Occ blocks / 24 bytes of reference text / a k-mer table entry / an SA entry); all lanes
-		// issue their requests together, wait once, then consume by mode -- so lanes that are in
+		// (two Occ blocks / 12 bytes of packed reference text / a k-mer table entry / an SA entry); all
+		// lanes issue their requests together, wait once, then consume by mode -- so lanes that are in
 		// different searches, or in different phases of a search, never serialise on each other's
 		// memory latency.
-		int s = entry, pos = 0, mode = M_DONE; u32 kid = 0;
+		int item = -1, s = 0, bend = 0, pos = 0, mode = M_ADV; u32 kid = 0;
 		FmIntv ik = {0, 0, 0}; u32 blk = 0; i64 tp = 0;
-#define START_NEXT() do { \
-			while (s < bend) { const int m_ = memo[s]; if (m_) { s += m_; continue; } \
-				if (codes[s] > 3) { memo[s] = 1; if (COUNT) mblk[s] = 0; s += 1; continue; } break; } \
-			if (s >= bend) { mode = M_DONE; exit_ = s; } \
-			else { \
-				ik = fm_init(di, codes[s]); pos = s + 1; blk = 0; mode = M_FM; \
-				if (!COUNT && di.kmer_k > 1 && s + di.kmer_k <= clen) { \
-					u32 id_ = 0; bool ok_ = true; \
-					for (int t_ = 0; t_ < di.kmer_k; t_++) { const u32 cd_ = codes[s + t_]; ok_ = ok_ && cd_ <= 3; id_ = (id_ << 2) | (cd_ & 3); } \
-					if (ok_) { kid = id_; mode = M_KMER; } \
-				} \
-			} } while (0)
-		if (dirty) START_NEXT();
+		bool need_item = true;
 		while (!__all(mode == M_DONE)) {
 			iters++;
 			// ---- request phase (convergent) ----
@@ -84,31 +124,28 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 				kk = kn ? 0 : k - (k >= di.primary); ll = ln ? 0 : l - (l >= di.primary);
 			}
 			const FmBlock bk = fm_load(di.bwt, kk >> 7), bl = fm_load(di.bwt, ll >> 7);
-			const u64 *pt = (const u64 *)(di.ref + (mode == M_TEXT ? (tp & ~7ll) : 0));
-			const u64 t0 = pt[0], t1 = pt[1], t2 = pt[2];
+			const u32 *pt = di.ref2 + (mode == M_TEXT ? (tp >> 4) : 0);
+			const u32 r0 = pt[0], r1 = pt[1], r2 = pt[2];
 			const ulonglong2 *pe = (const ulonglong2 *)((di.kmer ? di.kmer : (const u64 *)di.bwt) + (mode == M_KMER ? ((size_t)kid << 2) : 0));
 			const ulonglong2 e0 = pe[0], e1 = pe[1];
 			const u64 sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
-			// ---- consume phase ----
+			// ---- consume phase: straight-line, one predicated block per mode ----
 			bool ended = false;
 			if (mode == M_KMER) {
-				if (e1.x != 0) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; mode = ik.x2 == 1 ? M_LOC : M_FM; }
-				else mode = M_FM;                       // k-mer absent: the match is shorter than k, walk it base by base
+				const bool hit = e1.x != 0;             // absent k-mer: the match is shorter than k, walk it base by base
+				if (hit) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; }
+				mode = (hit && ik.x2 == 1) ? M_LOC : M_FM;
 			} else if (mode == M_LOC) {
 				tp = (i64)sav + (pos - s); mode = M_TEXT;
 			} else if (mode == M_TEXT) {
-				const int got = text_match16w(t0, t1, t2, tp, (i64)di.seq_len, codes, pos, clen);
+				const int got = text_match32(r0, r1, r2, tp, (i64)di.seq_len, qp, qn, pos, clen);
 				pos += got; tp += got;
-				ended = got < 16;
+				ended = got < 32;
 			} else if (mode == M_FM) {
-				ended = true;
-				if (pos < clen) {
-					const int nt = codes[pos];
-					if (nt <= 3 && fm_extend_loaded(di, ik, nt, bk, bl, kk, ll, kn, ln, blk)) {
-						pos++; ended = false;
-						if (!COUNT && ik.x2 == 1) mode = M_LOC;
-					}
-				}
+				const bool can = pos < clen && !q_isn(qn, pos < clen ? pos : 0);
+				const bool ok = can && fm_extend_loaded(di, ik, q_code(qp, pos < clen ? pos : 0), bk, bl, kk, ll, kn, ln, blk);
+				ended = !ok;
+				if (ok) { pos++; if (!COUNT && ik.x2 == 1) mode = M_LOC; }
 			}
 			if (ended) {
 				const int len = pos - s;
@@ -121,19 +158,47 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 				}
 				memo[s] = (uint16_t)d; if (COUNT) mblk[s] = (uint16_t)blk;
 				all_blocks += blk;
-				s += d;
-				START_NEXT();
+				s += d; mode = M_ADV;
+			}
+			// ---- advance: ONE step per iteration (no inner loop): take an item / hop over a memoised or
+			// ambiguous position / open the next search ----
+			if (mode == M_ADV) {
+				if (need_item) {
+					if (rounds == 0) { const u32 it_ = atomicAdd(&s_queue, 1u); item = it_ < (u32)nitems ? (int)it_ : -1; }
+					else if (dirty) { const int k_ = __ffs((int)dirty) - 1; dirty &= dirty - 1; item = j + k_ * SEED_WG; }
+					else item = -1;
+					need_item = false;
+					if (item < 0) mode = M_DONE;
+					else { s = entry_of[item]; bend = (item + 1) * S < clen ? (item + 1) * S : clen; }
+				}
+				if (mode == M_ADV) {
+					if (s >= bend) { exit_of[item] = (uint16_t)s; need_item = true; }
+					else {
+						const int m_ = memo[s];
+						if (m_) s += m_;
+						else if (q_isn(qn, s)) { memo[s] = 1; if (COUNT) mblk[s] = 0; s += 1; }
+						else {
+							ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
+							if (!COUNT && di.kmer_k > 1 && s + di.kmer_k <= clen && (q_nbits32(qn, s) & ((1u << di.kmer_k) - 1)) == 0) {
+								kid = (u32)q_bits64(qp, s) & ((1u << (2 * di.kmer_k)) - 1); mode = M_KMER;
+							}
+						}
+					}
+				}
 			}
 		}
-#undef START_NEXT
 		rounds++;
-		if (rounds == 1) tC = clock64();
-		exits[j + 1] = exit_;
-		if (j == 0) { exits[0] = 0; changed = 0; }
+		if (j == 0) changed = 0;
 		__syncthreads();
-		const int ne = exits[j];
-		dirty = (ne != entry);
-		if (dirty) { entry = ne; exit_ = ne; changed = 1; }
+		// true entry of every sub-range = exit of the one before it
+		dirty = 0;
+		for (int k = 0, it = j; it < nitems; k++, it += SEED_WG) {
+			const int ne = it ? exit_of[it - 1] : 0;
+			if (ne != entry_of[it]) dirty |= 1u << k;
+		}
+		__syncthreads();
+		for (int k = 0, it = j; it < nitems; k++, it += SEED_WG)
+			if (dirty & (1u << k)) { entry_of[it] = it ? exit_of[it - 1] : 0; changed = 1; }
 		__syncthreads();
 		const int again = changed;
 		__syncthreads();
@@ -141,7 +206,10 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	}
 	// mark the true path and count the Occ blocks the reference's walk reads
 	u32 alg_blocks = 0;
-	for (int s = entry; s < bend;) { atomicOr(&bits[s >> 5], 1u << (s & 31)); if (COUNT) alg_blocks += mblk[s]; s += memo[s]; }
+	for (int it = j; it < nitems; it += SEED_WG) {
+		const int bend = (it + 1) * S < clen ? (it + 1) * S : clen;
+		for (int s = entry_of[it]; s < bend;) { atomicOr(&bits[s >> 5], 1u << (s & 31)); if (COUNT) alg_blocks += mblk[s]; s += memo[s]; }
+	}
 	for (int o = 32; o; o >>= 1) { alg_blocks += __shfl_down(alg_blocks, o); all_blocks += __shfl_down(all_blocks, o); }
 	if ((j & 63) == 0) {
 		if (alg_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK], (unsigned long long)alg_blocks);
@@ -149,9 +217,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		atomicAdd((unsigned long long *)&cnt[12], (unsigned long long)iters);
 		atomicMax((unsigned long long *)&cnt[13], (unsigned long long)iters);
 	}
-	const long long tD = clock64();
 	if (j == 0) atomicMax((unsigned long long *)&cnt[11], (unsigned long long)rounds);
-	if ((j & 63) == 0) { atomicMax((unsigned long long *)&cnt[14], (unsigned long long)(tB - tA)); atomicMax((unsigned long long *)&cnt[15], (unsigned long long)(tC - tB)); atomicAdd((unsigned long long *)&cnt[3], (unsigned long long)(tC - tB)); atomicMax((unsigned long long *)&cnt[1], (unsigned long long)(tD - tC)); }
 	__syncthreads();
 	for (int p = j; p < PATH_WORDS; p += SEED_WG) onpath[(size_t)chunk * PATH_WORDS + p] = bits[p];
 	if (j == 0) { cand_cnt[chunk] = s_ncand < cand_cap ? s_ncand : cand_cap; atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand); }
@@ -237,15 +303,32 @@ __global__ void __launch_bounds__(256) k_build_kmer(DevIndex di, int k, u64 *tab
 {
 	const u32 id = blockIdx.x * blockDim.x + threadIdx.x;
 	if (id >= (1u << (2 * k))) return;
-	FmIntv ik = fm_init(di, (int)((id >> (2 * (k - 1))) & 3));
+	FmIntv ik = fm_init(di, (int)(id & 3));                  // base t of the k-mer = bits 2t..2t+1 (same packing as the query in LDS)
 	u32 blk = 0; bool alive = true;
-	for (int t = 1; t < k && alive; t++) alive = fm_extend(di, ik, (int)((id >> (2 * (k - 1 - t))) & 3), blk);
+	for (int t = 1; t < k && alive; t++) alive = fm_extend(di, ik, (int)((id >> (2 * t)) & 3), blk);
 	u64 *e = tab + ((size_t)id << 2);
 	e[0] = ik.x0; e[1] = ik.x1; e[2] = alive ? ik.x2 : 0; e[3] = 0;
 }
 
+// 2-bit packed copy of RefSequence (16 bases per word, LSB first) for the unique-interval text comparison
+__global__ void __launch_bounds__(256) k_pack_ref(const uint8_t *__restrict__ ref, u64 n, u32 *out, u64 words)
+{
+	const u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= words) return;
+	u32 v = 0;
+	for (int t = 0; t < 16; t++) { const u64 p = w * 16 + t; if (p < n) v |= ((u32)gsa_nt4(ref[p]) & 3) << (2 * t); }
+	out[w] = v;
+}
+
 int build_dense_sa(gsa_ctx *c, u64 n_sa)
 {
+	{
+		const u64 words = c->di.seq_len / 16 + 4;
+		if (!dev_ensure<u32>(c, c->d_ref2, words)) return GSA_ERR_NOMEM;
+		hipLaunchKernelGGL(k_pack_ref, dim3(grid_for(words, 256)), dim3(256), 0, c->stream, c->di.ref, c->di.seq_len, c->d_ref2.as<u32>(), words);
+		GSA_CHECK(c, hipGetLastError());
+		c->di.ref2 = c->d_ref2.as<u32>();
+	}
 	{
 		// k = floor(log4(2G)) - 1, capped: about 1/4 of the k-mers absent at most, table <= 512 MiB
 		int k = 0; while ((1ull << (2 * (k + 1))) <= c->di.seq_len) k++;
@@ -314,7 +397,6 @@ int stage1_seed(gsa_ctx *c)
 	}
 	c->counters[0] = c->h_cnt[CNT_OCCBLK]; c->counters[1] = 0; c->counters[2] = (u64)n_hits; c->counters[3] = (u64)n_hits; c->counters[7] = c->h_cnt[CNT_OCCBLK_ALL];
 	c->dbg[0] = c->h_cnt[11]; c->dbg[1] = c->h_cnt[12]; c->dbg[2] = c->h_cnt[13];
-	if (getenv("GSA_DEBUG")) fprintf(stderr, "[gsa] clk init max %llu, round1 max %llu avg %llu, later rounds max %llu\n", (unsigned long long)c->h_cnt[14], (unsigned long long)c->h_cnt[15], (unsigned long long)(c->h_cnt[3] / ((u64)n_chunks * 4)), (unsigned long long)c->h_cnt[1]);
 	c->n_seeds = n_hits;
 	if (c->profiling) { float ms; hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms; hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->kernel_ms[1] = ms; }
 	if (n_hits == 0) return GSA_OK;
