@@ -95,6 +95,7 @@ struct gsa_ctx {
 	DevBuf f_rec;                                  // gsa_frag records
 	DevBuf f_type, f_mism, f_alnlen, f_job, f_score;
 	DevBuf j_frag, j_opsoff, j_nops, d_ops, j_cells;
+	DevBuf d_dp_bnd, d_dp_ctr, d_dp_jobs;          // striped DP: boundary granules, tickets, job descriptors
 	DevBuf d_aln1, d_aln2, d_alnoff;
 	DevBuf bl_alnlen, bl_score;
 	std::vector<gsa_frag> h_frags; std::vector<gsa_block> h_blocks; std::vector<char> h_aln1, h_aln2;

@@ -1,16 +1,15 @@
 // gsalign_amd/csrc/k_dp.hip -- batched gap-closing DP (a13) and the public leaf
 // operator gsa_ksw2_batch.  Cell recurrence and traceback automaton: gsa_dp.h.
 //
-// Two kernels, chosen per job by size (jobs are launched largest first):
+// Two kernels, chosen per job by size (jobs are launched largest first, the two kernels run concurrently):
 //  * k_dp_small  n <= 64 and m+n-1 <= 128 (the bulk of the jobs: median 11 x 11).
 //    One wavefront per alignment, lane t owns target column t.  The (u,v,x,y) state
 //    lives in REGISTERS; the left neighbour and the reference base travel one lane
 //    up per anti-diagonal with DPP wave shifts (systolic array); direction bytes
 //    and the traceback stay in LDS.  No barrier, no global traffic but the result.
-//  * k_dp_wg<T>  everything else (up to 5000 x 5000): one T-thread workgroup per
-//    alignment, state in LDS (x and v ping-pong so one barrier per anti-diagonal
-//    suffices), direction bytes to HBM diagonal-major (coalesced), traceback by
-//    one lane on 64x64 tiles staged through LDS.
+//  * k_dp_stripe  everything else (up to 5000 x 5000): the target columns are cut
+//    into 64-wide stripes, one wavefront per stripe on its own CU, boundary columns
+//    handed over through HBM; see the comment at the kernel.
 #include <algorithm>
 #include "gsa_ctx.h"
 #include "gsa_dp.h"
@@ -68,105 +67,138 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 	if (lane == 0) ops_len[job] = nops;
 }
 
-template <int T, int KMAX>
-__global__ void __launch_bounds__(T) k_dp_wg(i32 n_jobs, const i32 *__restrict__ order, const i64 *__restrict__ diroff, const uint8_t *__restrict__ pool1,
-                                              const i64 *__restrict__ off1, const i32 *__restrict__ len1, const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2,
-                                              const i32 *__restrict__ len2, uint8_t *dirbase, uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, int mpad)
+// ---------------------------------------------------------------------------
+// k_dp_stripe: every alignment that does not fit the small kernel.  The n target
+// columns are cut into stripes of 64; ONE WAVEFRONT PER STRIPE, on whatever CU the
+// dispatcher picks, so a 1.5k x 1.5k problem runs on ~25 CUs instead of one.
+// Stripe p sweeps its own anti-diagonals (local diagonal rl: lane l handles row
+// rl - l), state in registers, left neighbour by a DPP wave shift.  The only
+// inter-stripe dependency is the (x,v) pair of stripe p-1's last column per row;
+// it is handed over through HBM as self-validating 4-byte granules {tag,x|v<<8}
+// written and read with agent-scope relaxed atomics (write-through / L1-bypassing,
+// so no fence and no separate flag; granules are zeroed before the launch).
+// Stripe p trails stripe p-1 by 64..96 diagonals and fetches 32 rows of boundary at
+// a time.  Direction bytes go to HBM diagonal-major.  The stripe that finishes last
+// (agent-scope release/acquire around a ticket counter) runs the traceback: 64x64
+// tiles held in REGISTERS (lane = tile row), walked with scalar state + v_readlane,
+// i.e. without a memory round trip per step.
+// Forward progress: stripe p only waits for stripe p-1, which has a lower
+// workgroup index and was therefore dispatched earlier; spins are bounded.
+// ---------------------------------------------------------------------------
+struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; };
+
+__device__ __forceinline__ u32 sel16(const u32 (&w)[16], int q)
 {
-	extern __shared__ __attribute__((aligned(16))) int8_t lds[];        // the reference fragment as nt4 codes
-	__shared__ uint8_t tile[64][64];
-	__shared__ int xchg[2][T / 64][KMAX];                               // (x | v << 8) of each wave's last lane, per column set, ping-pong by diagonal parity
-	__shared__ int s_i, s_j, s_state, s_k;
-	if ((i32)blockIdx.x >= n_jobs) return;
-	const i32 job = order[blockIdx.x];
-	const int m = len1[job], n = len2[job], tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-	const uint8_t *s1 = pool1 + off1[job], *s2 = pool2 + off2[job];
-	uint8_t *dir = dirbase + diroff[blockIdx.x];
-	uint8_t *rev = revbase + ops_off[job], *op = ops + ops_off[job];
-	if (m <= 0 || n <= 0) { if (tid == 0) ops_len[job] = 0; return; }
-	// Thread tid owns target columns t = tid + k*T: their (u,v,x,y) state stays in registers for the
-	// whole fill; the left neighbour's (x,v) of the previous diagonal arrives by a DPP wave shift, and
-	// only the lane at a wave boundary goes through LDS.  One barrier per anti-diagonal.
-	int8_t *C1 = lds;
-	for (int t = tid; t < m; t += T) C1[t] = (int8_t)gsa_nt4(s1[t]);
-	int u[KMAX], y[KMAX], x[KMAX], v[KMAX], cq[KMAX];
-#pragma unroll
-	for (int k = 0; k < KMAX; k++) { const int t = tid + k * T; u[k] = t ? 2 : 0; y[k] = 0; x[k] = 0; v[k] = 0; cq[k] = t < n ? gsa_nt4(s2[t]) : 4; }
-	if (lane == 63) {
-#pragma unroll
-		for (int k = 0; k < KMAX; k++) { xchg[0][w][k] = 0; xchg[1][w][k] = 0; }
+	switch (q) {
+	case 0: return w[0]; case 1: return w[1]; case 2: return w[2]; case 3: return w[3]; case 4: return w[4]; case 5: return w[5]; case 6: return w[6]; case 7: return w[7];
+	case 8: return w[8]; case 9: return w[9]; case 10: return w[10]; case 11: return w[11]; case 12: return w[12]; case 13: return w[13]; case 14: return w[14]; default: return w[15];
 	}
-	__syncthreads();
-	const int nr = m + n - 1;
-	i64 off = 0;
-	for (int r = 0; r < nr; r++) {
-		const int st = r - m + 1 > 0 ? r - m + 1 : 0, en = r < n - 1 ? r : n - 1;
-		const int par = r & 1;
-#pragma unroll
-		for (int k = 0; k < KMAX; k++) {
-			const int t = tid + k * T;
-			if (k * T > en) break;                                       // uniform: no column of this set is on the diagonal yet / any more
-			// (x,v) of column t-1 on diagonal r-1
-			int fill;
-			if (w > 0) fill = xchg[par][w - 1][k];
-			else if (k > 0) fill = xchg[par][T / 64 - 1][k - 1];
-			else fill = (r ? 2 : 0) << 8;                                // t = 0 boundary: x1 = 0, v1 = q (:157-164)
-			const int packed = wave_shr1(x[k] | (v[k] << 8), fill);
-			const int xt1 = packed & 0xff, vt1 = packed >> 8;
-			const int jj = r - t;
-			if (t < n && jj >= 0 && jj < m) {
-				int un, vn, xn, yn;
-				const int d = dp_cell(xt1, vt1, u[k], y[k], cq[k], C1[jj], un, vn, xn, yn);
-				u[k] = un; v[k] = vn; x[k] = xn; y[k] = yn;
-				dir[off + (t - st)] = (uint8_t)d;
-			}
-			if (lane == 63) xchg[par ^ 1][w][k] = x[k] | (v[k] << 8);
-		}
-		off += en - st + 1;
-		__syncthreads();
-	}
-	// ---- traceback on 64 x 64 tiles: rows = diagonals R..R-63, columns = targets T0..T0-63 ----
-	if (tid == 0) { s_i = n - 1; s_j = m - 1; s_state = 0; s_k = 0; }
-	__threadfence_block();
-	__syncthreads();
-	while (s_i >= 0 && s_j >= 0) {
-		const int R = s_i + s_j, T0 = s_i;
-		for (int e = tid; e < 64 * 64; e += T) {
-			const int rr = e >> 6, cc = e & 63;
-			const int r = R - rr, t = T0 - cc;
-			uint8_t val = 0;
-			if (r >= 0 && t >= 0) {
-				const int st = r - m + 1 > 0 ? r - m + 1 : 0, en = r < n - 1 ? r : n - 1;
-				if (t >= st && t <= en) val = dir[dp_rowoff(r, m, n) + (t - st)];
-			}
-			tile[rr][cc] = val;
-		}
-		__syncthreads();
-		if (tid == 0) {
-			int i = s_i, j = s_j, state = s_state, k = s_k;
-			while (i >= 0 && j >= 0) {
-				const int rr = R - (i + j), cc = T0 - i;
-				if (rr > 63 || cc > 63) break;
-				rev[k++] = (uint8_t)dp_bt_step(tile[rr][cc], state, i, j);
-			}
-			s_i = i; s_j = j; s_state = state; s_k = k;
-		}
-		__syncthreads();
-	}
-	if (tid == 0) {
-		int i = s_i, j = s_j, k = s_k;
-		for (; i >= 0; --i) rev[k++] = 'D';
-		for (; j >= 0; --j) rev[k++] = 'I';
-		s_k = k; ops_len[job] = k;
-	}
-	__threadfence_block();
-	__syncthreads();
-	const int nops = s_k;
-	for (int p = tid; p < nops; p += T) op[p] = rev[nops - 1 - p];
 }
 
-// All pointers are device pointers.  Large jobs are processed in batches so that the
-// direction bytes of one batch fit the budget.
+__global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__restrict__ sjobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
+                                                   const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2, uint8_t *dirbase, u32 *bndbase, u32 *ctr,
+                                                   uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len)
+{
+	extern __shared__ __attribute__((aligned(16))) int8_t C1[];        // the reference fragment as nt4 codes
+	// which job / stripe am I (uniform)
+	int lo = 0, hi = nsj;
+	while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sjobs[mid].first_block <= (i32)blockIdx.x) lo = mid; else hi = mid; }
+	const StripeJob sj = sjobs[lo];
+	const int p = (int)blockIdx.x - sj.first_block, m = sj.m, n = sj.n, P = sj.P, lane = threadIdx.x;
+	const uint8_t *s1 = pool1 + off1[sj.job], *s2 = pool2 + off2[sj.job];
+	uint8_t *dir = dirbase + sj.diroff;
+	u32 *bnd_in = bndbase + sj.bndoff + (size_t)(p - 1) * m, *bnd_out = bndbase + sj.bndoff + (size_t)p * m;
+	u32 *err = ctr;                                                     // ctr[0]: spin-bound error flag
+	for (int t = lane; t < m; t += 64) C1[t] = (int8_t)gsa_nt4(s1[t]);
+	const int t = p * 64 + lane;
+	const int Wp = n - p * 64 < 64 ? n - p * 64 : 64;
+	const int cq = t < n ? gsa_nt4(s2[t]) : 4;
+	int u = t ? 2 : 0, y = 0, x = 0, v = 0;
+	u32 bin = 0;
+	__syncthreads();
+	const int nl = m + Wp - 1;
+	i64 off = dp_rowoff((i64)p * 64, m, n);
+	for (int rl = 0; rl < nl; rl++) {
+		const int r = rl + p * 64;
+		const int st = r - m + 1 > 0 ? r - m + 1 : 0, en = r < n - 1 ? r : n - 1;
+		if (p > 0 && (rl & 31) == 0 && rl < m) {
+			// boundary rows rl .. rl+31 from stripe p-1: spin until every granule carries its tag
+			const int row = rl + (lane & 31);
+			const bool need = lane < 32 && row < m;
+			u32 g = 0; u32 spins = 0;
+			for (;;) {
+				if (need) g = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (__all(!need || (g >> 16) != 0)) break;
+				if (++spins > (1u << 20) || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+				__builtin_amdgcn_s_sleep(2);
+			}
+			bin = g & 0xffffu;
+		}
+		const int fill = p > 0 ? __builtin_amdgcn_readlane((int)bin, rl & 31) : ((r ? 2 : 0) << 8);     // t = 0 boundary: x1 = 0, v1 = q (:157-164)
+		const int packed = wave_shr1(x | (v << 8), fill);
+		const int jj = rl - lane;
+		if (lane < Wp && jj >= 0 && jj < m) {
+			int un, vn, xn, yn;
+			const int d = dp_cell(packed & 0xff, packed >> 8, u, y, cq, C1[jj], un, vn, xn, yn);
+			u = un; v = vn; x = xn; y = yn;
+			dir[off + (t - st)] = (uint8_t)d;
+			if (lane == Wp - 1 && p < P - 1) __hip_atomic_store(&bnd_out[jj], (1u << 16) | (u32)(xn | (vn << 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		off += en - st + 1;
+	}
+	// ---- ticket: the last stripe to finish does the traceback ----
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	u32 ticket = 0;
+	if (lane == 0) ticket = __hip_atomic_fetch_add(&ctr[sj.ctr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	ticket = (u32)__builtin_amdgcn_readfirstlane((int)ticket);
+	if ((int)ticket != P - 1) return;
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	uint8_t *rev = revbase + ops_off[sj.job], *op = ops + ops_off[sj.job];
+	int i = n - 1, j = m - 1, state = 0, k = 0;
+	while (i >= 0 && j >= 0) {
+		const int R = i + j, T0 = i;
+		u32 w[16];
+#pragma unroll
+		for (int q2 = 0; q2 < 16; q2++) w[q2] = 0;
+		{
+			const int rr_r = R - lane;                                   // my tile row = diagonal rr_r, bytes = columns T0-63 .. T0
+			const int st = rr_r - m + 1 > 0 ? rr_r - m + 1 : 0, en = rr_r < n - 1 ? rr_r : n - 1;
+			if (rr_r >= 0 && st <= T0 && en >= T0 - 63) {
+				const uint8_t *pa = dir + dp_rowoff(rr_r, m, n) + (T0 - 63 - st);
+				const int sh = (int)((size_t)pa & 3);
+				const u32 *al = (const u32 *)(pa - sh);
+				u32 a[17];
+#pragma unroll
+				for (int q2 = 0; q2 < 17; q2++) a[q2] = al[q2];
+#pragma unroll
+				for (int q2 = 0; q2 < 16; q2++) w[q2] = sh == 0 ? a[q2] : (sh == 1 ? __builtin_amdgcn_alignbyte(a[q2 + 1], a[q2], 1) : (sh == 2 ? __builtin_amdgcn_alignbyte(a[q2 + 1], a[q2], 2) : __builtin_amdgcn_alignbyte(a[q2 + 1], a[q2], 3)));
+			}
+		}
+		for (;;) {
+			const int rr = R - (i + j), bidx = i - (T0 - 63);
+			if (i < 0 || j < 0 || rr > 63 || bidx < 0) break;
+			const u32 mine = sel16(w, bidx >> 2);
+			const u32 word = (u32)__builtin_amdgcn_readlane((int)mine, rr);
+			const int opc = dp_bt_step((word >> ((bidx & 3) << 3)) & 0xffu, state, i, j);
+			if (lane == 0) rev[k] = (uint8_t)opc;
+			k++;
+		}
+	}
+	if (lane == 0) {
+		for (; i >= 0; --i) rev[k++] = 'D';
+		for (; j >= 0; --j) rev[k++] = 'I';
+		ops_len[sj.job] = k;
+	}
+	k = __builtin_amdgcn_readfirstlane(k);
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	for (int q2 = lane; q2 < k; q2 += 64) op[q2] = rev[k - 1 - q2];
+}
+
+// All pointers are device pointers.  Jobs that do not fit the small kernel are processed in
+// batches so that the direction bytes of one batch fit the budget.
 int run_ksw2_jobs(gsa_ctx *c, i32 n, const uint8_t *pool1, const i64 *off1, const i32 *len1,
                   const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len)
 {
@@ -177,75 +209,70 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n, const uint8_t *pool1, const i64 *off1, cons
 	GSA_CHECK(c, hipMemcpyAsync(h_len1.data(), len1, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipMemcpyAsync(h_ooff.data(), ops_off, (size_t)n * 8, hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipStreamSynchronize(st));
-	std::vector<i32> small, mid, big;
-	i64 ops_total = 0;
+	std::vector<i32> small, large, empty;
+	i64 ops_total = 0; int mmax = 1;
 	for (i32 i = 0; i < n; i++) {
 		const i64 m = h_len1[i], nn = h_len2[i];
 		c->counters[4] += (u64)(m * nn); c->counters[6] += (u64)(m + nn);
 		if (h_ooff[i] + m + nn > ops_total) ops_total = h_ooff[i] + m + nn;
-		if (m <= 0 || nn <= 0) mid.push_back(i);
+		if (m <= 0 || nn <= 0) empty.push_back(i);
 		else if (nn <= 64 && m + nn - 1 <= SMALL_ROWS) small.push_back(i);
-		else if (nn > 512) big.push_back(i);
-		else mid.push_back(i);
+		else { large.push_back(i); if (m > mmax) mmax = (int)m; }
 	}
 	c->counters[5] += (u64)n;
+	if (!empty.empty()) return gsa_fail(c, GSA_ERR_ARG, "DP job with an empty side");
 	auto by_cells = [&](i32 a, i32 b) { const i64 ca = (i64)h_len1[a] * h_len2[a], cb = (i64)h_len1[b] * h_len2[b]; return ca != cb ? ca > cb : a < b; };
-	std::sort(small.begin(), small.end(), by_cells); std::sort(mid.begin(), mid.end(), by_cells); std::sort(big.begin(), big.end(), by_cells);
-	// big first (longest critical path), then mid, then the many small ones fill the machine around them
+	std::sort(small.begin(), small.end(), by_cells); std::sort(large.begin(), large.end(), by_cells);
+	const int mpad = (mmax + 63) & ~63;
+	if (mpad > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 153600 bases");
 	i32 *d_order = dev_ensure<i32>(c, c->d_flag2, (size_t)n + 1);
 	uint8_t *rev = dev_ensure<uint8_t>(c, c->d_i64a, (size_t)ops_total + 64);
 	if (!d_order || !rev) return GSA_ERR_NOMEM;
-	std::vector<i32> order; order.reserve((size_t)n);
-	order.insert(order.end(), big.begin(), big.end()); order.insert(order.end(), mid.begin(), mid.end()); order.insert(order.end(), small.begin(), small.end());
-	GSA_CHECK(c, hipMemcpyAsync(d_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
-	// One direction buffer for both workgroup classes (offsets continue), so the three kernels can run
-	// CONCURRENTLY on three streams: the few huge jobs set the critical path, everything else fills
-	// the machine around them.  If the direction bytes exceed the budget the classes are batched.
-	const i64 budget = 12ll << 30;
-	std::vector<i32> wg_jobs(big); wg_jobs.insert(wg_jobs.end(), mid.begin(), mid.end());
-	std::vector<i64> h_diroff(wg_jobs.size() + 1, 0);
-	hipEvent_t ev_fork = c->ev[10], ev_j1 = c->ev[11], ev_j2 = c->ev[12];
-	size_t first = 0;
-	bool small_done = small.empty();
-	while (first < wg_jobs.size() || !small_done) {
-		size_t last = first; i64 bytes = 0; int nmax_big = 1, nmax_mid = 1, mmax_big = 1, mmax_mid = 1; size_t nbig = 0;
-		while (last < wg_jobs.size()) {
-			const i32 jb = wg_jobs[last]; const i64 cells = (i64)h_len1[jb] * h_len2[jb];
-			if (last > first && bytes + cells > budget) break;
-			h_diroff[last] = bytes; bytes += cells;
-			if (last < big.size()) { nbig++; if (h_len2[jb] > nmax_big) nmax_big = h_len2[jb]; if (h_len1[jb] > mmax_big) mmax_big = h_len1[jb]; }
-			else { if (h_len2[jb] > nmax_mid) nmax_mid = h_len2[jb]; if (h_len1[jb] > mmax_mid) mmax_mid = h_len1[jb]; }
-			last++;
-		}
-		uint8_t *dir = dev_ensure<uint8_t>(c, c->d_scan2, (size_t)bytes + 64);
-		i64 *d_diroff = dev_ensure<i64>(c, c->j_cells, wg_jobs.size() + 1);
-		if (!dir || !d_diroff) return GSA_ERR_NOMEM;
-		if (last > first) GSA_CHECK(c, hipMemcpyAsync(d_diroff + first, h_diroff.data() + first, (last - first) * 8, hipMemcpyHostToDevice, st));
-		const int npad_big = (nmax_big + 63) & ~63, npad_mid = (nmax_mid + 63) & ~63, mpad_big = (mmax_big + 63) & ~63, mpad_mid = (mmax_mid + 63) & ~63;
-		if (nmax_big > 5 * 1024 || mpad_big > 140 * 1024 || mpad_mid > 140 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP fragment too long (query side > 5120 or reference side > 143360 bases)");
-		(void)npad_big; (void)npad_mid;
+	hipEvent_t ev_fork = c->ev[10], ev_j2 = c->ev[12];
+	// the many small jobs run on a second stream, concurrently with the striped ones
+	if (!small.empty()) {
+		GSA_CHECK(c, hipMemcpyAsync(d_order, small.data(), small.size() * 4, hipMemcpyHostToDevice, st));
 		GSA_CHECK(c, hipEventRecord(ev_fork, st));
-		const size_t nmid = (last - first) - nbig;
-		if (nbig) hipLaunchKernelGGL((k_dp_wg<1024, 5>), dim3((unsigned)nbig), dim3(1024), (size_t)mpad_big, st, (i32)nbig, d_order + first, d_diroff + first, pool1, off1, len1, pool2, off2, len2, dir, rev, ops, ops_off, ops_len, mpad_big);
-		if (nmid) {
-			GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[0], ev_fork, 0));
-			hipLaunchKernelGGL((k_dp_wg<256, 2>), dim3((unsigned)nmid), dim3(256), (size_t)mpad_mid, c->stream_aux[0], (i32)nmid, d_order + first + nbig, d_diroff + first + nbig, pool1, off1, len1, pool2, off2, len2, dir, rev, ops, ops_off, ops_len, mpad_mid);
-			GSA_CHECK(c, hipEventRecord(ev_j1, c->stream_aux[0]));
-			GSA_CHECK(c, hipStreamWaitEvent(st, ev_j1, 0));
-		}
-		if (!small_done) {
-			const unsigned nb = (unsigned)((small.size() + SMALL_WAVES - 1) / SMALL_WAVES);
-			GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], ev_fork, 0));
-			hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, c->stream_aux[1], (i32)small.size(), d_order + wg_jobs.size(), pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len);
-			GSA_CHECK(c, hipEventRecord(ev_j2, c->stream_aux[1]));
-			GSA_CHECK(c, hipStreamWaitEvent(st, ev_j2, 0));
-			small_done = true;
-		}
+		GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], ev_fork, 0));
+		const unsigned nb = (unsigned)((small.size() + SMALL_WAVES - 1) / SMALL_WAVES);
+		hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, c->stream_aux[1], (i32)small.size(), d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len);
 		GSA_CHECK(c, hipGetLastError());
-		first = last;
-		if (first < wg_jobs.size()) GSA_CHECK(c, hipStreamSynchronize(st));       // the direction buffer is reused by the next batch
+		GSA_CHECK(c, hipEventRecord(ev_j2, c->stream_aux[1]));
 	}
-	GSA_CHECK(c, hipStreamSynchronize(st));       // staging vectors (order, diroff) go out of scope
+	const i64 budget = 12ll << 30;
+	std::vector<StripeJob> sj;
+	size_t first = 0;
+	while (first < large.size()) {
+		sj.clear();
+		i64 dbytes = 128, bwords = 0; i32 nctr = 1, nblocks = 0;
+		size_t last = first;
+		while (last < large.size()) {
+			const i32 jb = large[last]; const i64 m = h_len1[jb], nn = h_len2[jb], cells = m * nn;
+			if (last > first && dbytes + cells > budget) break;
+			StripeJob s; s.job = jb; s.m = (i32)m; s.n = (i32)nn; s.P = (i32)((nn + 63) / 64);
+			s.diroff = dbytes; dbytes += cells + 128;
+			s.bndoff = bwords; bwords += (i64)(s.P - 1) * m;
+			s.ctr = nctr++; s.first_block = nblocks; nblocks += s.P;
+			sj.push_back(s); last++;
+		}
+		uint8_t *dir = dev_ensure<uint8_t>(c, c->d_scan2, (size_t)dbytes + 512);
+		u32 *bnd = dev_ensure<u32>(c, c->d_dp_bnd, (size_t)bwords + 64);
+		u32 *ctr = dev_ensure<u32>(c, c->d_dp_ctr, (size_t)nctr + 64);
+		StripeJob *d_sj = dev_ensure<StripeJob>(c, c->d_dp_jobs, sj.size() + 1);
+		if (!dir || !bnd || !ctr || !d_sj) return GSA_ERR_NOMEM;
+		GSA_CHECK(c, hipMemsetAsync(bnd, 0, ((size_t)bwords + 64) * 4, st));
+		GSA_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nctr + 64) * 4, st));
+		GSA_CHECK(c, hipMemcpyAsync(d_sj, sj.data(), sj.size() * sizeof(StripeJob), hipMemcpyHostToDevice, st));
+		hipLaunchKernelGGL(k_dp_stripe, dim3((unsigned)nblocks), dim3(64), (size_t)mpad, st, (i32)sj.size(), d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len);
+		GSA_CHECK(c, hipGetLastError());
+		u32 h_err = 0;
+		GSA_CHECK(c, hipMemcpyAsync(&h_err, ctr, 4, hipMemcpyDeviceToHost, st));
+		GSA_CHECK(c, hipStreamSynchronize(st));       // also: the staging vector and the direction buffer are reused by the next batch
+		if (h_err) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
+		first = last;
+	}
+	if (!small.empty()) GSA_CHECK(c, hipStreamWaitEvent(st, ev_j2, 0));
+	GSA_CHECK(c, hipStreamSynchronize(st));
 	return GSA_OK;
 }
 
