@@ -53,7 +53,16 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	if (lane == 0) {
 		int i = n - 1, j = m - 1, state = 0, k = 0;
-		while (i >= 0 && j >= 0) rev[k++] = (uint8_t)dp_bt_step(dir[(i + j) * 64 + i], state, i, j);
+		while (i >= 0 && j >= 0) {
+			const u32 tmp = dir[(i + j) * 64 + i];
+			int ns = state;                                                 // ksw_backtrack automaton (:38-52), branch-free
+			if (ns != 0 && !((tmp >> (ns + 2)) & 1)) ns = 0;
+			if (ns == 0) ns = (int)(tmp & 7);
+			state = ns;
+			const int isM = ns == 0 ? 1 : 0, isD = (ns == 1 || ns == 3) ? 1 : 0;
+			rev[k++] = (uint8_t)(isM ? 'M' : (isD ? 'D' : 'I'));
+			i -= isM | isD; j -= isM | (1 - isD);
+		}
 		for (; i >= 0; --i) rev[k++] = 'D';
 		for (; j >= 0; --j) rev[k++] = 'I';
 		s_n[w] = k;
@@ -157,6 +166,7 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 	uint8_t *rev = revbase + ops_off[sj.job], *op = ops + ops_off[sj.job];
 	int i = n - 1, j = m - 1, state = 0, k = 0;
 	while (i >= 0 && j >= 0) {
+		i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
 		const int R = i + j, T0 = i;
 		u32 w[16];
 #pragma unroll
@@ -176,11 +186,23 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 			}
 		}
 		for (;;) {
+			// the walker state is wave-uniform: pin it to scalar registers so that the tile-word select and
+			// the automaton run on the scalar unit (v_readlane instead of a memory round trip per step)
+			i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
+			state = __builtin_amdgcn_readfirstlane(state); k = __builtin_amdgcn_readfirstlane(k);
 			const int rr = R - (i + j), bidx = i - (T0 - 63);
 			if (i < 0 || j < 0 || rr > 63 || bidx < 0) break;
 			const u32 mine = sel16(w, bidx >> 2);
 			const u32 word = (u32)__builtin_amdgcn_readlane((int)mine, rr);
-			const int opc = dp_bt_step((word >> ((bidx & 3) << 3)) & 0xffu, state, i, j);
+			// the automaton of ksw_backtrack (:38-52), branch-free on scalar values
+			const u32 tmp = (word >> ((bidx & 3) << 3)) & 0xffu;
+			int ns = state;
+			if (ns != 0 && !((tmp >> (ns + 2)) & 1)) ns = 0;
+			if (ns == 0) ns = (int)(tmp & 7);
+			state = ns;
+			const int isM = ns == 0 ? 1 : 0, isD = (ns == 1 || ns == 3) ? 1 : 0;
+			const int opc = isM ? 'M' : (isD ? 'D' : 'I');
+			i -= isM | isD; j -= isM | (1 - isD);
 			if (lane == 0) rev[k] = (uint8_t)opc;
 			k++;
 		}
