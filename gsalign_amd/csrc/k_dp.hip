@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 // it is handed over through HBM as self-validating 4-byte granules {tag,x|v<<8}
 // written and read with agent-scope relaxed atomics (write-through / L1-bypassing,
 // so no fence and no separate flag; granules are zeroed before the launch).
-// Stripe p trails stripe p-1 by 64..96 diagonals and fetches 32 rows of boundary at
+// Stripe p trails stripe p-1 by 64..80 diagonals and fetches 16 rows of boundary at
 // a time.  Direction bytes go to HBM diagonal-major.  The stripe that finishes last
 // (agent-scope release/acquire around a ticket counter) runs the traceback: 64x64
 // tiles held in REGISTERS (lane = tile row), walked with scalar state + v_readlane,
@@ -126,14 +126,18 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 	u32 bin = 0;
 	__syncthreads();
 	const int nl = m + Wp - 1;
+	int cref = lane == 0 ? C1[0] : 4;                   // reference code of my row on the current diagonal, fetched one diagonal ahead
 	i64 off = dp_rowoff((i64)p * 64, m, n);
 	for (int rl = 0; rl < nl; rl++) {
 		const int r = rl + p * 64;
 		const int st = r - m + 1 > 0 ? r - m + 1 : 0, en = r < n - 1 ? r : n - 1;
-		if (p > 0 && (rl & 31) == 0 && rl < m) {
-			// boundary rows rl .. rl+31 from stripe p-1: spin until every granule carries its tag
-			const int row = rl + (lane & 31);
-			const bool need = lane < 32 && row < m;
+		// prefetch the reference code of the NEXT diagonal (row jj+1) so the LDS latency is off the recurrence chain
+		const int jn = rl + 1 - lane;
+		const int cnext = (jn >= 0 && jn < m) ? C1[jn] : 4;
+		if (p > 0 && (rl & 15) == 0 && rl < m) {
+			// boundary rows rl .. rl+15 from stripe p-1: spin until every granule carries its tag
+			const int row = rl + (lane & 15);
+			const bool need = lane < 16 && row < m;
 			u32 g = 0; u32 spins = 0;
 			for (;;) {
 				if (need) g = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -143,17 +147,18 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 			}
 			bin = g & 0xffffu;
 		}
-		const int fill = p > 0 ? __builtin_amdgcn_readlane((int)bin, rl & 31) : ((r ? 2 : 0) << 8);     // t = 0 boundary: x1 = 0, v1 = q (:157-164)
+		const int fill = p > 0 ? __builtin_amdgcn_readlane((int)bin, rl & 15) : ((r ? 2 : 0) << 8);     // t = 0 boundary: x1 = 0, v1 = q (:157-164)
 		const int packed = wave_shr1(x | (v << 8), fill);
 		const int jj = rl - lane;
 		if (lane < Wp && jj >= 0 && jj < m) {
 			int un, vn, xn, yn;
-			const int d = dp_cell(packed & 0xff, packed >> 8, u, y, cq, C1[jj], un, vn, xn, yn);
+			const int d = dp_cell(packed & 0xff, packed >> 8, u, y, cq, cref, un, vn, xn, yn);
 			u = un; v = vn; x = xn; y = yn;
 			dir[off + (t - st)] = (uint8_t)d;
 			if (lane == Wp - 1 && p < P - 1) __hip_atomic_store(&bnd_out[jj], (1u << 16) | (u32)(xn | (vn << 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		off += en - st + 1;
+		cref = cnext;
 	}
 	// ---- ticket: the last stripe to finish does the traceback ----
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
