@@ -135,6 +135,6 @@ int stage7_fill(gsa_ctx *c);          // k_extend.hip  (S6: gap records of the f
 int stage78_extend(gsa_ctx *c);       // k_extend.hip  (S7: classification, DP, gapped strings, block sums)
 int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res);   // k_gapsim.hip
 int run_ksw2_jobs(gsa_ctx *c, i32 n, const uint8_t *pool1, const i64 *off1, const i32 *len1,
-                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len);   // k_extend.hip
+                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total);   // k_dp.hip
 
 #endif

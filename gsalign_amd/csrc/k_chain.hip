@@ -100,14 +100,59 @@ __global__ void k_next_window(i64 na, const i32 *__restrict__ a_q, const i32 *__
 	next[i] = nx;
 }
 
-// greedy window segmentation: one lane per group follows next[] from the group head
-__global__ void k_walk_windows(i64 na, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge, const i32 *__restrict__ next, i32 *ws)
+// Greedy window segmentation.  chain(p) = next[p] runs through every window start of every group
+// (next[] returns the group end = the next group's head when a group has no further window), so
+// the starts are ONE chain over the whole array -- sequential, but like the seed chunks it is a
+// functional graph whose paths merge (window ends snap to the sparse "break" positions).  One
+// 1024-lane workgroup cuts the array into tiles, walks every tile speculatively from its first
+// candidate, then re-enters each tile at the previous tile's exit until no exit moves, and only
+// then marks the starts.  Exactly the reference's segmentation (GSAlign.cpp:326-338).
+#define WALK_T 1024
+#define WALK_MAXTILES 8192
+__global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__restrict__ a_gb, const i32 *__restrict__ brk, const i32 *__restrict__ next, i32 *ws)
 {
-	GID(na);
-	if (a_gb[i] != i) return;
-	const i32 ge = a_ge[i];
-	i32 p = (i32)i;
-	while (p < ge) { ws[p] = 1; p = next[p]; }
+	__shared__ i32 entry[WALK_MAXTILES], exit_[WALK_MAXTILES];
+	__shared__ int changed;
+	const int tid = threadIdx.x;
+	i64 ts = 256; while ((na + ts - 1) / ts > WALK_MAXTILES) ts <<= 1;
+	const int nt = (int)((na + ts - 1) / ts);
+	for (int t = tid; t < nt; t += WALK_T) {
+		const i64 b = (i64)t * ts, e = b + ts < na ? b + ts : na;
+		i64 p = b;
+		if (t > 0) while (p < e && !(a_gb[p] == p || brk[p])) p++;      // first candidate start in the tile (tile 0 starts at the true head 0)
+		entry[t] = (i32)p; exit_[t] = -1;                                // exit -1 = "must be (re)walked"
+	}
+	__syncthreads();
+	for (;;) {
+		for (int t = tid; t < nt; t += WALK_T) {
+			if (exit_[t] >= 0) continue;                                   // entry unchanged since the last walk
+			const i64 e = (i64)(t + 1) * ts < na ? (i64)(t + 1) * ts : na;
+			i64 p = entry[t];
+			// a speculative entry may sit on a non-candidate (next = -1): slide to the next candidate; positions
+			// on the true chain are always candidates, so this never changes a true path
+			while (p < e) { const i32 nx = next[p]; p = nx >= 0 ? nx : p + 1; }
+			exit_[t] = (i32)p;
+		}
+		if (tid == 0) changed = 0;
+		__syncthreads();
+		// true entry of a tile = exit of the tile before it (entry[] is private to the owning lane)
+		bool moved[WALK_MAXTILES / WALK_T];
+		for (int t = tid, k = 0; t < nt; t += WALK_T, k++) {
+			moved[k] = false;
+			if (t == 0) continue;
+			const i32 ne = exit_[t - 1];
+			if (ne != entry[t]) { entry[t] = ne; moved[k] = true; changed = 1; }
+		}
+		__syncthreads();
+		const int again = changed;
+		for (int t = tid, k = 0; t < nt; t += WALK_T, k++) if (moved[k]) exit_[t] = -1;
+		__syncthreads();
+		if (!again) break;
+	}
+	for (int t = tid; t < nt; t += WALK_T) {
+		const i64 e = (i64)(t + 1) * ts < na ? (i64)(t + 1) * ts : na;
+		for (i64 p = entry[t]; p < e; p = next[p]) ws[p] = 1;
+	}
 }
 
 // ---- C. outliers: per-window histogram of PosDiff>>4 over unique seeds -----------
@@ -339,7 +384,7 @@ int stage2_chain(gsa_ctx *c)
 	LAUNCH(k_scatter_idx, na, na, brk, brkEx, blist);
 	LAUNCH(k_next_window, na, na, c->a_q.as<i32>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, cuEx, brk, brkEx, blist, next);
 	GSA_CHECK(c, hipMemsetAsync(ws, 0, ((size_t)na + 1) * 4, st));
-	LAUNCH(k_walk_windows, na, na, c->a_gb.as<i32>(), c->a_ge.as<i32>(), next, ws);
+	hipLaunchKernelGGL(k_walk_windows, dim3(1), dim3(WALK_T), 0, st, na, c->a_gb.as<i32>(), brk, next, ws);
 	RC(prim_exscan_i32(c, ws, wsEx, (size_t)na + 1));
 	// C. outliers
 	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);

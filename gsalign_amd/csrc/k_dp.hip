@@ -227,21 +227,19 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 // All pointers are device pointers.  Jobs that do not fit the small kernel are processed in
 // batches so that the direction bytes of one batch fit the budget.
 int run_ksw2_jobs(gsa_ctx *c, i32 n, const uint8_t *pool1, const i64 *off1, const i32 *len1,
-                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len)
+                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total)
 {
 	if (n <= 0) return GSA_OK;
 	hipStream_t st = c->stream;
-	std::vector<i32> h_len1((size_t)n), h_len2((size_t)n); std::vector<i64> h_ooff((size_t)n);
+	std::vector<i32> h_len1((size_t)n), h_len2((size_t)n);
 	GSA_CHECK(c, hipMemcpyAsync(h_len2.data(), len2, (size_t)n * 4, hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipMemcpyAsync(h_len1.data(), len1, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipMemcpyAsync(h_ooff.data(), ops_off, (size_t)n * 8, hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipStreamSynchronize(st));
 	std::vector<i32> small, large, empty;
-	i64 ops_total = 0; int mmax = 1;
+	int mmax = 1;
 	for (i32 i = 0; i < n; i++) {
 		const i64 m = h_len1[i], nn = h_len2[i];
 		c->counters[4] += (u64)(m * nn); c->counters[6] += (u64)(m + nn);
-		if (h_ooff[i] + m + nn > ops_total) ops_total = h_ooff[i] + m + nn;
 		if (m <= 0 || nn <= 0) empty.push_back(i);
 		else if (nn <= 64 && m + nn - 1 <= SMALL_ROWS) small.push_back(i);
 		else { large.push_back(i); if (m > mmax) mmax = (int)m; }
@@ -249,7 +247,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n, const uint8_t *pool1, const i64 *off1, cons
 	c->counters[5] += (u64)n;
 	if (!empty.empty()) return gsa_fail(c, GSA_ERR_ARG, "DP job with an empty side");
 	auto by_cells = [&](i32 a, i32 b) { const i64 ca = (i64)h_len1[a] * h_len2[a], cb = (i64)h_len1[b] * h_len2[b]; return ca != cb ? ca > cb : a < b; };
-	std::sort(small.begin(), small.end(), by_cells); std::sort(large.begin(), large.end(), by_cells);
+	std::sort(large.begin(), large.end(), by_cells);     // largest first: they are the critical path (the small ones need no order)
 	const int mpad = (mmax + 63) & ~63;
 	if (mpad > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 153600 bases");
 	i32 *d_order = dev_ensure<i32>(c, c->d_flag2, (size_t)n + 1);
@@ -325,7 +323,7 @@ extern "C" int gsa_ksw2_batch(gsa_ctx *c, int32_t n_pairs, const char *pool1, co
 	GSA_CHECK(c, hipMemcpyAsync(d_o1, off1, n * 8, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(d_o2, off2, n * 8, hipMemcpyHostToDevice, st));
 	GSA_CHECK(c, hipMemcpyAsync(d_oo, ops_off, n * 8, hipMemcpyHostToDevice, st));
 	GSA_CHECK(c, hipMemcpyAsync(d_l1, len1, n * 4, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(d_l2, len2, n * 4, hipMemcpyHostToDevice, st));
-	int rc = run_ksw2_jobs(c, n_pairs, d_p1, d_o1, d_l1, d_p2, d_o2, d_l2, d_ops, d_oo, d_ol);
+	int rc = run_ksw2_jobs(c, n_pairs, d_p1, d_o1, d_l1, d_p2, d_o2, d_l2, d_ops, d_oo, d_ol, po);
 	if (rc == GSA_OK) {
 		GSA_CHECK(c, hipMemcpyAsync(ops, d_ops, po, hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipMemcpyAsync(ops_len, d_ol, n * 4, hipMemcpyDeviceToHost, st));

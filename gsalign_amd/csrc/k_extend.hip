@@ -212,7 +212,7 @@ int stage78_extend(gsa_ctx *c)
 		GSA_CHECK(c, hipMemcpyAsync(&ops_total, c->j_opsoff.as<i64>() + nj, 8, hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipStreamSynchronize(st));
 		ENS(uint8_t, d_ops, ops_total + 64);
-		RC(run_ksw2_jobs(c, nj, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>()));
+		RC(run_ksw2_jobs(c, nj, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), ops_total));
 	}
 	// gapped-string offsets
 	ENS(i64, d_alnoff, nf + 2);
