@@ -63,9 +63,9 @@ __device__ __forceinline__ int text_match32(u32 r0, u32 r1, u32 r2, i64 tp, i64 
 // ---------------------------------------------------------------------------
 template <bool COUNT>
 __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
-                                                      i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath)
+                                                      i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits)
 {
-	__shared__ u32 s_ncand, s_queue;
+	__shared__ u32 s_ncand, s_queue, s_hits;
 	__shared__ int changed;
 	__shared__ u32 qp[QP_WORDS], qn[QN_WORDS];
 	__shared__ uint16_t memo[GSA_CHUNK];      // next(s)-s, 0 = unknown
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	}
 	for (int p = j; p < clen; p += SEED_WG) memo[p] = 0;
 	for (int p = j; p < PATH_WORDS; p += SEED_WG) bits[p] = 0;
-	if (j == 0) { s_ncand = 0; s_queue = 0; }
+	if (j == 0) { s_ncand = 0; s_queue = 0; s_hits = 0; }
 	const size_t cbase = (size_t)chunk * cand_cap;      // this chunk's private candidate segment
 	const int S = (clen + NSUB - 1) / NSUB;             // sub-range length (>= 1)
 	const int nitems = (clen + S - 1) / S;
@@ -220,7 +220,16 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	if (j == 0) atomicMax((unsigned long long *)&cnt[11], (unsigned long long)rounds);
 	__syncthreads();
 	for (int p = j; p < PATH_WORDS; p += SEED_WG) onpath[(size_t)chunk * PATH_WORDS + p] = bits[p];
-	if (j == 0) { cand_cnt[chunk] = s_ncand < cand_cap ? s_ncand : cand_cap; atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand); }
+	// how many located hits will this chunk contribute (so that the select kernel needs no global atomic)
+	{
+		const u32 nc = s_ncand < cand_cap ? s_ncand : cand_cap;
+		u32 h = 0;
+		for (u32 i = j; i < nc; i += SEED_WG) { const i32 p = cand_s[cbase + i] - (i32)c0; if ((bits[p >> 5] >> (p & 31)) & 1u) h += (u32)cand_freq[cbase + i]; }
+		for (int o = 32; o; o >>= 1) h += __shfl_down(h, o);
+		if ((j & 63) == 0 && h) atomicAdd(&s_hits, h);
+		__syncthreads();
+		if (j == 0) { cand_cnt[chunk] = nc; chunk_hits[chunk] = (i32)s_hits; atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand); }
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -230,17 +239,20 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, const u32 *__restrict__ cand_cnt, const i32 *__restrict__ cand_s, const i32 *__restrict__ cand_len,
                                                       const u64 *__restrict__ cand_x0, const i32 *__restrict__ cand_freq, const u32 *__restrict__ onpath,
-                                                      i32 qlen, int qbits, u64 *key, u32 *val, u64 hit_cap, u64 *cnt)
+                                                      const i32 *__restrict__ hit_base, i32 qlen, int qbits, u64 *key, u32 *val)
 {
+	__shared__ u32 s_off;
 	const u32 chunk = blockIdx.x, nc = cand_cnt[chunk];
 	const size_t cbase = (size_t)chunk * cand_cap;
+	if (threadIdx.x == 0) s_off = 0;
+	__syncthreads();
+	const u64 base = (u64)hit_base[chunk];
 	for (u32 i = threadIdx.x; i < nc; i += blockDim.x) {
 		const i32 s = cand_s[cbase + i];
 		const i32 p = s - (i32)chunk * GSA_CHUNK;
 		if (!((onpath[(size_t)chunk * PATH_WORDS + (p >> 5)] >> (p & 31)) & 1u)) continue;
 		const u32 f = (u32)cand_freq[cbase + i];
-		const u64 off = atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)f);
-		if (off + f > hit_cap) { cnt[CNT_OVERFLOW] = 2; continue; }
+		const u64 off = base + atomicAdd(&s_off, f);
 		const u64 x0 = cand_x0[cbase + i]; const u32 len = (u32)cand_len[cbase + i];
 		for (u32 h = 0; h < f; h++) {
 			const u64 r = fm_locate(di, x0 + h);
@@ -360,50 +372,47 @@ int stage1_seed(gsa_ctx *c)
 	if (qlen <= 0) return GSA_OK;
 	const i64 n_chunks = ((i64)qlen + GSA_CHUNK - 1) / GSA_CHUNK;
 	size_t ccap = c->cand_cap_per_chunk;                // candidate slots per chunk (grows on overflow)
-	size_t hcap = c->d_key_a.cap / sizeof(u64);
-	if (hcap < (size_t)qlen / 16 + 4096) hcap = (size_t)qlen / 16 + 4096;
-	if (!dev_ensure<u32>(c, c->d_onpath, (size_t)n_chunks * PATH_WORDS)) return GSA_ERR_NOMEM;
+	if (!dev_ensure<u32>(c, c->d_onpath, (size_t)n_chunks * PATH_WORDS) || !dev_ensure<i32>(c, c->d_chunk_hits, (size_t)n_chunks + 1) || !dev_ensure<i32>(c, c->d_chunk_base, (size_t)n_chunks + 1)) return GSA_ERR_NOMEM;
 	i64 n_hits = 0;
-	bool need_search = true;
+	u64 *cnt = c->d_cnt.as<u64>();
 	for (int attempt = 0;; attempt++) {
 		if (attempt == 8) return gsa_fail(c, GSA_ERR_LIMIT, "seed buffers keep overflowing");
 		const size_t ctot = ccap * (size_t)n_chunks;
 		if (!dev_ensure<i32>(c, c->d_cand_s, ctot) || !dev_ensure<i32>(c, c->d_cand_len, ctot) || !dev_ensure<u64>(c, c->d_cand_x0, ctot) || !dev_ensure<i32>(c, c->d_cand_freq, ctot) || !dev_ensure<u32>(c, c->d_cand_cnt, (size_t)n_chunks)) return GSA_ERR_NOMEM;
-		if (!dev_ensure<u64>(c, c->d_key_a, hcap) || !dev_ensure<u32>(c, c->d_val_a, hcap)) return GSA_ERR_NOMEM;
-		u64 *cnt = c->d_cnt.as<u64>();
-		if (need_search) {
-			GSA_CHECK(c, hipMemsetAsync(cnt, 0, 16 * sizeof(u64), st));
-			if (c->profiling) hipEventRecord(c->ev[0], st);
-			if (c->count_blocks)
-				hipLaunchKernelGGL(k_seed_wg<true>, dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
-				                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>());
-			else
-				hipLaunchKernelGGL(k_seed_wg<false>, dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
-				                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>());
-			if (c->profiling) hipEventRecord(c->ev[1], st);
-		} else {
-			GSA_CHECK(c, hipMemsetAsync(cnt + CNT_HITS, 0, sizeof(u64), st));
-			GSA_CHECK(c, hipMemsetAsync(cnt + CNT_OVERFLOW, 0, sizeof(u64), st));
-		}
-		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), 0, st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
-		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), qlen, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), (u64)hcap, cnt);
-		if (c->profiling) hipEventRecord(c->ev[2], st);
+		GSA_CHECK(c, hipMemsetAsync(cnt, 0, 16 * sizeof(u64), st));
+		GSA_CHECK(c, hipMemsetAsync(c->d_chunk_hits.as<i32>() + n_chunks, 0, sizeof(i32), st));
+		if (c->profiling) hipEventRecord(c->ev[0], st);
+		if (c->count_blocks)
+			hipLaunchKernelGGL(k_seed_wg<true>, dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
+			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>());
+		else
+			hipLaunchKernelGGL(k_seed_wg<false>, dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
+			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>());
+		if (c->profiling) hipEventRecord(c->ev[1], st);
+		int rcs = prim_exscan_i32(c, c->d_chunk_hits.as<i32>(), c->d_chunk_base.as<i32>(), (size_t)n_chunks + 1);
+		if (rcs) return rcs;
+		i32 tot = 0;
 		GSA_CHECK(c, hipMemcpyAsync(c->h_cnt, cnt, 16 * sizeof(u64), hipMemcpyDeviceToHost, st));
+		GSA_CHECK(c, hipMemcpyAsync(&tot, c->d_chunk_base.as<i32>() + n_chunks, sizeof(i32), hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipStreamSynchronize(st));
-		n_hits = (i64)c->h_cnt[CNT_HITS];
-		if (c->h_cnt[CNT_CAND] > ccap) { ccap = (size_t)c->h_cnt[CNT_CAND] + 256; c->cand_cap_per_chunk = ccap; need_search = true; continue; }
-		if (c->h_cnt[CNT_OVERFLOW] == 2 || (size_t)n_hits > hcap) { hcap = (size_t)n_hits + (size_t)n_hits / 8 + 4096; need_search = false; continue; }
+		if (c->h_cnt[CNT_CAND] > ccap) { ccap = (size_t)c->h_cnt[CNT_CAND] + 256; c->cand_cap_per_chunk = ccap; continue; }
+		n_hits = tot;
 		break;
 	}
+	const size_t hcap = (size_t)n_hits + 64;
+	if (n_hits > 0) {
+		if (!dev_ensure<u64>(c, c->d_key_a, hcap) || !dev_ensure<u32>(c, c->d_val_a, hcap)) return GSA_ERR_NOMEM;
+		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), 0, st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
+		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), qlen, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>());
+	}
+	if (c->profiling) hipEventRecord(c->ev[2], st);
 	c->counters[0] = c->h_cnt[CNT_OCCBLK]; c->counters[1] = 0; c->counters[2] = (u64)n_hits; c->counters[3] = (u64)n_hits; c->counters[7] = c->h_cnt[CNT_OCCBLK_ALL];
 	c->dbg[0] = c->h_cnt[11]; c->dbg[1] = c->h_cnt[12]; c->dbg[2] = c->h_cnt[13];
 	c->n_seeds = n_hits;
-	if (c->profiling) { float ms; hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms; hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->kernel_ms[1] = ms; }
-	if (n_hits == 0) return GSA_OK;
+	if (n_hits == 0) { if (c->profiling) { GSA_CHECK(c, hipStreamSynchronize(st)); float ms; hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms; } return GSA_OK; }
 	if (n_hits >= (1ll << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");
 	const size_t n = (size_t)n_hits;
 	if (!dev_ensure<u64>(c, c->d_key_b, hcap) || !dev_ensure<u32>(c, c->d_val_b, hcap)) return GSA_ERR_NOMEM;
-	if (c->profiling) hipEventRecord(c->ev[2], st);
 	int rc = prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), n, 0, c->qbits + c->pdbits);
 	if (rc) return rc;
 	if (!dev_ensure<i32>(c, c->s_q, n) || !dev_ensure<i32>(c, c->s_len, n) || !dev_ensure<i64>(c, c->s_r, n) || !dev_ensure<i32>(c, c->s_gid, n) ||
@@ -418,7 +427,7 @@ int stage1_seed(gsa_ctx *c)
 	GSA_CHECK(c, hipMemcpyAsync(&ng, c->d_scan.as<i32>() + n, sizeof(i32), hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipStreamSynchronize(st));
 	c->n_groups = ng;
-	if (c->profiling) { float ms; hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->kernel_ms[2] = ms; }
+	if (c->profiling) { float ms; hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms; hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->kernel_ms[1] = ms; hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->kernel_ms[2] = ms; }
 	return GSA_OK;
 }
 
