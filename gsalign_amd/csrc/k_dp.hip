@@ -123,39 +123,44 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 	const int Wp = n - p * 64 < 64 ? n - p * 64 : 64;
 	const int cq = t < n ? gsa_nt4(s2[t]) : 4;
 	int u = t ? 2 : 0, y = 0, x = 0, v = 0;
-	u32 bin = 0;
+	u32 bin = 0, gnext = 0;
 	__syncthreads();
 	const int nl = m + Wp - 1;
 	int cref = lane == 0 ? C1[0] : 4;                   // reference code of my row on the current diagonal, fetched one diagonal ahead
 	i64 off = dp_rowoff((i64)p * 64, m, n);
+	// boundary granules are fetched ONE BLOCK AHEAD (16 rows per block) so their L2 latency overlaps the block before
+	if (p > 0) { const int row = lane & 15; if (lane < 16 && row < m) gnext = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	const bool mycol = lane < Wp;
+	const bool publish = lane == Wp - 1 && p < P - 1;
 	for (int rl = 0; rl < nl; rl++) {
 		const int r = rl + p * 64;
 		const int st = r - m + 1 > 0 ? r - m + 1 : 0, en = r < n - 1 ? r : n - 1;
 		// prefetch the reference code of the NEXT diagonal (row jj+1) so the LDS latency is off the recurrence chain
 		const int jn = rl + 1 - lane;
-		const int cnext = (jn >= 0 && jn < m) ? C1[jn] : 4;
+		const int cnext = ((unsigned)jn < (unsigned)m) ? C1[jn] : 4;
 		if (p > 0 && (rl & 15) == 0 && rl < m) {
 			// boundary rows rl .. rl+15 from stripe p-1: spin until every granule carries its tag
 			const int row = rl + (lane & 15);
 			const bool need = lane < 16 && row < m;
-			u32 g = 0; u32 spins = 0;
-			for (;;) {
-				if (need) g = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (__all(!need || (g >> 16) != 0)) break;
+			u32 g = gnext; u32 spins = 0;
+			while (!__all(!need || (g >> 16) != 0)) {
 				if (++spins > (1u << 20) || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-				__builtin_amdgcn_s_sleep(2);
+				__builtin_amdgcn_s_sleep(1);
+				if (need) g = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			bin = g & 0xffffu;
+			const int rown = row + 16;
+			gnext = (lane < 16 && rown < m) ? __hip_atomic_load(&bnd_in[rown], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 		}
 		const int fill = p > 0 ? __builtin_amdgcn_readlane((int)bin, rl & 15) : ((r ? 2 : 0) << 8);     // t = 0 boundary: x1 = 0, v1 = q (:157-164)
 		const int packed = wave_shr1(x | (v << 8), fill);
 		const int jj = rl - lane;
-		if (lane < Wp && jj >= 0 && jj < m) {
+		if (mycol && (unsigned)jj < (unsigned)m) {
 			int un, vn, xn, yn;
 			const int d = dp_cell(packed & 0xff, packed >> 8, u, y, cq, cref, un, vn, xn, yn);
 			u = un; v = vn; x = xn; y = yn;
 			dir[off + (t - st)] = (uint8_t)d;
-			if (lane == Wp - 1 && p < P - 1) __hip_atomic_store(&bnd_out[jj], (1u << 16) | (u32)(xn | (vn << 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (publish) __hip_atomic_store(&bnd_out[jj], (1u << 16) | (u32)(xn | (vn << 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		off += en - st + 1;
 		cref = cnext;
