@@ -119,3 +119,28 @@ def test_midsize_pair_2pct(oracle_built, tmp_path):
         o.set_query(seq); g.set_query(seq)
         assert_stage_equal(g.dump_stages(8), o.dump_stages(8))
     o.close(); g.close()
+
+
+@pytest.mark.parametrize("total,ncontig,div,seed,params", [
+    (1500000, 1, 0.001, 3, {}),                       # 0.1 %: few seeds, multi-kb DP problems (striped kernel, traceback tiles)
+    (2000000, 3, 0.01, 12, {}),                       # 1 %
+    (600000, 2, 0.02, 13, dict(sen=1, clr=50)),       # -sen: 5-bp stride, many tiny groups, candidate-buffer growth
+    (800000, 2, 0.08, 14, dict(slen=12, idy=60)),     # high divergence, short seeds
+])
+def test_scaled_pairs_vs_oracle(oracle_built, tmp_path, total, ncontig, div, seed, params):
+    """Larger synthetic pairs than the committed fixtures; index from OUR builder, result vs the oracle."""
+    from gsalign_amd import hostlib
+    refs, qrys = synth.make_pair(total, ncontig, div, seed=seed)
+    if ncontig > 1:
+        qrys[-1] = (qrys[-1][0], synth.revcomp(qrys[-1][1]))
+    rf, px = str(tmp_path / "r.fa"), str(tmp_path / "r")
+    synth.write_fasta(rf, refs); hostlib.build_index(rf, px)
+    idx = indexio.load_index(px)
+    o = oracle_built.Oracle(idx, params); g = capi.Aligner(idx, **params)
+    for name, seq in qrys:
+        o.set_query(seq); o.run_to(8); want = o.blocks(with_aln=True)
+        g.align_contig(seq); got = g.blocks_as_dump(with_aln=True)
+        for k, v in want.items():
+            assert np.array_equal(got[k], v), (name, k)
+        assert want["b_score"].size > 0
+    o.close(); g.close()
