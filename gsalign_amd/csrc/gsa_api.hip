@@ -53,6 +53,8 @@ int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gsa_fail(nullptr, GSA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); gsa_destroy(c); return GSA_ERR_HIP; } } while (0)
 	CK(hipSetDevice(device));
+	(void)hipSetDeviceFlags(hipDeviceScheduleSpin);      // host waits spin instead of sleeping: the pipeline has ~20 short count read-backs per contig
+	(void)hipGetLastError();
 	CK(hipStreamCreate(&c->stream));
 	CK(hipStreamCreate(&c->stream_aux[0])); CK(hipStreamCreate(&c->stream_aux[1]));
 	for (int i = 0; i < 16; i++) CK(hipEventCreate(&c->ev[i]));
