@@ -19,6 +19,20 @@ int host_stage4_5_6(gsa_ctx *c, int stage);    // gsa_blocks.cpp
 int host_stage8_finish(gsa_ctx *c);            // gsa_blocks.cpp
 int build_block_view(gsa_ctx *c);              // gsa_blocks.cpp
 
+void collect_events(gsa_ctx *c)
+{
+	if (!c->profiling) { c->ev_pending = 0; return; }
+	float ms;
+	if (c->ev_pending & 1) {
+		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->kernel_ms[0] = ms;
+		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->kernel_ms[1] = ms;
+		if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) c->kernel_ms[2] = ms;
+	}
+	if (c->ev_pending & 2) { if (hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) c->kernel_ms[3] = ms; }
+	c->ev_pending = 0;
+	(void)hipGetLastError();
+}
+
 extern "C" {
 
 void gsa_default_params(gsa_params *p)
@@ -83,6 +97,9 @@ int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa
 	CK(hipMalloc(&c->d_chr_of_end.p, c->h_chr_of_end.size() * 4)); CK(hipMemcpy(c->d_chr_of_end.p, c->h_chr_of_end.data(), c->h_chr_of_end.size() * 4, hipMemcpyHostToDevice));
 	CK(hipMalloc(&c->d_cnt.p, 16 * sizeof(u64))); c->d_cnt.cap = 16 * sizeof(u64);
 	CK(hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(u64)));
+	CK(hipMalloc(&c->d_mail.p, MAIL_N * sizeof(i32))); c->d_mail.cap = MAIL_N * sizeof(i32);
+	CK(hipMemset(c->d_mail.p, 0, MAIL_N * sizeof(i32)));
+	CK(hipHostMalloc((void **)&c->h_mail, MAIL_N * sizeof(i32)));
 #undef CK
 	c->di.primary = idx->primary; for (int i = 0; i < 5; i++) c->di.L2[i] = idx->L2[i]; c->di.L2[0] = 0;
 	c->di.seq_len = idx->L2[4];
@@ -102,7 +119,7 @@ void gsa_destroy(gsa_ctx *c)
 	if (!c) return;
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
-	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->d_query, &c->tmp, &c->d_cnt,
+	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->d_query, &c->tmp, &c->d_cnt, &c->d_mail,
 		&c->d_sa_dense, &c->d_kmer, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
 		&c->d_flag, &c->d_scan, &c->g_beg, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
 		&c->a_next, &c->a_brk, &c->a_aurank, &c->a_aulist, &c->a_runinfo, &c->w_best, &c->w_sum, &c->w_n, &c->d_flag2, &c->d_scan2, &c->d_i64a,
@@ -112,7 +129,8 @@ void gsa_destroy(gsa_ctx *c)
 		&c->d_dp_bnd, &c->d_dp_ctr, &c->d_dp_jobs, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_aln1, &c->d_aln2, &c->d_alnoff, &c->bl_alnlen, &c->bl_score };
 	for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
-	for (DevBuf *b : { &c->p_frags, &c->p_aln1, &c->p_aln2 }) if (b->p) hipHostFree(b->p);
+	if (c->h_mail) hipHostFree(c->h_mail);
+	for (DevBuf *b : { &c->p_frags, &c->p_aln1, &c->p_aln2, &c->p_leaf, &c->p_blk }) if (b->p) hipHostFree(b->p);
 	for (int i = 0; i < 16; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 2; i++) if (c->stream_aux[i]) hipStreamDestroy(c->stream_aux[i]);
 	if (c->stream) hipStreamDestroy(c->stream);
@@ -132,7 +150,7 @@ int gsa_set_query(gsa_ctx *c, const char *query, int32_t qlen)
 	c->qbits = ceil_log2_u64((u64)qlen + 1); if (c->qbits < 1) c->qbits = 1;
 	c->pdbits = ceil_log2_u64((u64)(2 * c->G) + (u64)qlen + 2);
 	if (c->qbits + c->pdbits > 64) return gsa_fail(c, GSA_ERR_LIMIT, "contig too long for the 64-bit seed key");
-	c->n_seeds = 0; c->n_groups = 0; c->n_blocks2 = 0; c->blocks.clear(); c->frags_stage = 0; c->have_host_seeds = false;
+	c->n_seeds = 0; c->n_groups = 0; c->n_blocks2 = 0; c->blocks.clear(); c->frags_stage = 0; c->have_host_seeds = false; c->ev_pending = 0; c->s2_host = false;
 	memset(c->counters, 0, sizeof(c->counters)); memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
 	return GSA_OK;
 }
@@ -154,6 +172,8 @@ int gsa_run_to(gsa_ctx *c, int stage)
 		}
 		if (rc == GSA_OK) { c->stage = next; c->frags_stage = (next == 8) ? 8 : 0; }
 	}
+	// stages 1-2 leave work in flight (no count read-backs); the call returns with the stream idle
+	if (rc == GSA_OK) { GSA_CHECK(c, hipStreamSynchronize(c->stream)); collect_events(c); }
 	return rc;
 }
 
@@ -180,13 +200,22 @@ int gsa_get_seeds(gsa_ctx *c, gsa_seed *out)
 	return GSA_OK;
 }
 
-int gsa_group_count(gsa_ctx *c) { return c ? c->n_groups : 0; }
+int gsa_group_count(gsa_ctx *c)
+{
+	if (!c) return 0;
+	if (c->n_groups < 0) {      // stage 1 leaves the count on the device
+		i32 ng = 0;
+		if (hipMemcpy(&ng, c->d_mail.as<i32>() + M_NG, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+		c->n_groups = ng;
+	}
+	return c->n_groups;
+}
 
 int gsa_get_groups(gsa_ctx *c, int32_t *beg, int32_t *end)
 {
 	if (!c) return GSA_ERR_ARG;
 	if (c->stage < 1) return gsa_fail(c, GSA_ERR_STATE, "run stage 1 first");
-	const size_t ng = (size_t)c->n_groups; if (!ng) return GSA_OK;
+	const size_t ng = (size_t)gsa_group_count(c); if (!ng) return GSA_OK;
 	std::vector<i32> gb(ng + 1);
 	GSA_CHECK(c, hipMemcpy(gb.data(), c->g_beg.p, (ng + 1) * 4, hipMemcpyDeviceToHost));
 	for (size_t i = 0; i < ng; i++) { beg[i] = gb[i]; end[i] = gb[i + 1]; }

@@ -140,10 +140,19 @@ int host_stage8_finish(gsa_ctx *c)
 	const size_t nfb = c->blocks.size();
 	c->h_blocks.clear(); c->h_frags.clear(); c->h_aln1.clear(); c->h_aln2.clear(); c->result_pinned = false;
 	if (nfb == 0) return GSA_OK;
-	std::vector<i32> bl_len(nfb), bl_score(nfb), fragbase(nfb);
-	GSA_CHECK(c, hipMemcpy(bl_len.data(), c->bl_alnlen.p, nfb * 4, hipMemcpyDeviceToHost));
-	GSA_CHECK(c, hipMemcpy(bl_score.data(), c->bl_score.p, nfb * 4, hipMemcpyDeviceToHost));
-	GSA_CHECK(c, hipMemcpy(fragbase.data(), c->fb_fragbase.p, nfb * 4, hipMemcpyDeviceToHost));
+	// everything the host needs comes back in one go: per-block sums, records, gapped strings
+	if (!pin_ensure<i32>(c, c->p_blk, 3 * nfb)) return GSA_ERR_NOMEM;
+	if (!pin_ensure<gsa_frag>(c, c->p_frags, (size_t)c->n_frags) || !pin_ensure<char>(c, c->p_aln1, (size_t)c->n_aln) || !pin_ensure<char>(c, c->p_aln2, (size_t)c->n_aln)) return GSA_ERR_NOMEM;
+	i32 *bl_len = c->p_blk.as<i32>(), *bl_score = bl_len + nfb, *fragbase = bl_score + nfb;
+	GSA_CHECK(c, hipMemcpyAsync(bl_len, c->bl_alnlen.p, nfb * 4, hipMemcpyDeviceToHost, c->stream));
+	GSA_CHECK(c, hipMemcpyAsync(bl_score, c->bl_score.p, nfb * 4, hipMemcpyDeviceToHost, c->stream));
+	GSA_CHECK(c, hipMemcpyAsync(fragbase, c->fb_fragbase.p, nfb * 4, hipMemcpyDeviceToHost, c->stream));
+	if (c->n_frags) GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, (size_t)c->n_frags * sizeof(gsa_frag), hipMemcpyDeviceToHost, c->stream));
+	if (c->n_aln) {
+		GSA_CHECK(c, hipMemcpyAsync(c->p_aln1.p, c->d_aln1.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, c->stream));
+		GSA_CHECK(c, hipMemcpyAsync(c->p_aln2.p, c->d_aln2.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, c->stream));
+	}
+	GSA_CHECK(c, hipStreamSynchronize(c->stream));
 	auto t0 = std::chrono::steady_clock::now();
 	std::vector<HostBlock> &B = c->blocks;
 	// keep (frag_off, n_frag) beside each block while the list is re-sorted
@@ -177,14 +186,6 @@ int host_stage8_finish(gsa_ctx *c)
 		o.bdir = B[k].bdir; o.gpos = B[k].gpos; o.chr = B[k].chr; o._pad = 0;
 	}
 	c->kernel_ms[7] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-	// records + gapped strings to the host
-	if (!pin_ensure<gsa_frag>(c, c->p_frags, (size_t)c->n_frags) || !pin_ensure<char>(c, c->p_aln1, (size_t)c->n_aln) || !pin_ensure<char>(c, c->p_aln2, (size_t)c->n_aln)) return GSA_ERR_NOMEM;
-	if (c->n_frags) GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, (size_t)c->n_frags * sizeof(gsa_frag), hipMemcpyDeviceToHost, c->stream));
-	if (c->n_aln) {
-		GSA_CHECK(c, hipMemcpyAsync(c->p_aln1.p, c->d_aln1.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, c->stream));
-		GSA_CHECK(c, hipMemcpyAsync(c->p_aln2.p, c->d_aln2.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, c->stream));
-	}
-	GSA_CHECK(c, hipStreamSynchronize(c->stream));
 	c->result_pinned = true;
 	c->frags_stage = 8;
 	return GSA_OK;
@@ -196,6 +197,7 @@ int build_block_view(gsa_ctx *c)
 	c->h_blocks.clear(); c->h_frags.clear(); c->h_aln1.clear(); c->h_aln2.clear(); c->result_pinned = false;
 	if (c->stage == 8) { c->frags_stage = 8; return GSA_OK; }     // nothing survived
 	if (c->stage == 2) {
+		if (int rc = stage2_fetch_host(c)) return rc;
 		const size_t nc = (size_t)c->n_c;
 		std::vector<i32> q(nc), l(nc); std::vector<i64> r(nc);
 		if (nc) {

@@ -13,7 +13,13 @@ struct Leaf {
 	i64 r_first, r_last_end;
 	i32 blk;             // S2 block this leaf belongs to
 	i32 cut4, cut5;      // how this leaf starts: S4 cut / S5 cut (0/0 = block start)
+	i32 blk_score;       // AddAlnBlock score of that S2 block
 };
+
+// Device "mailbox" (i32[MAIL_N]) of the counts the stages produce; the host reads the whole
+// box in ONE pinned copy where it needs them instead of one read-back per count.
+enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_ANY = 8, MAIL_N = 64 };
+#define LEAF_CHUNK 1024      // leaves copied together with the mailbox (more -> a second copy)
 
 struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf range
 	i32 leaf_beg, leaf_end;
@@ -51,6 +57,10 @@ struct gsa_ctx {
 	DevBuf tmp;
 	// device counters block (u64[16]) + pinned host mirror
 	DevBuf d_cnt; u64 *h_cnt = nullptr;
+	DevBuf d_mail; i32 *h_mail = nullptr;          // count mailbox + pinned mirror
+	DevBuf p_leaf;                                 // pinned landing zone for the leaf table
+	int ev_pending = 0;                            // bit0: stage-1 events, bit1: stage-2 events not yet read
+	bool s2_host = false;                          // n_b/n_c/n_blocks2/h_blk_* fetched for the stage-2 view
 
 	// ---- stage 1 ----
 	DevBuf d_ref2;                                 // 2-bit packed reference text
@@ -102,7 +112,7 @@ struct gsa_ctx {
 	std::vector<gsa_frag> h_frags; std::vector<gsa_block> h_blocks; std::vector<char> h_aln1, h_aln2;
 	int frags_stage = 0;                           // stage for which h_frags/h_blocks were built
 	// stage-8 results land in pinned host memory (one async D2H each, no pageable staging)
-	DevBuf p_frags, p_aln1, p_aln2; bool result_pinned = false;
+	DevBuf p_frags, p_aln1, p_aln2, p_blk; bool result_pinned = false;
 };
 
 template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n)
@@ -131,6 +141,8 @@ template <class T> static inline T *pin_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 int build_dense_sa(gsa_ctx *c, u64 n_sa);   // k_seed.hip
 int stage1_seed(gsa_ctx *c);          // k_seed.hip
 int stage2_chain(gsa_ctx *c);         // k_chain.hip
+int stage2_fetch_host(gsa_ctx *c);    // k_chain.hip  (counts + S2 block table for the stage-2 view)
+void collect_events(gsa_ctx *c);      // gsa_api.hip  (deferred hipEventElapsedTime of stages 1-2)
 int stage345_refine(gsa_ctx *c);      // k_refine.hip  (device part of S3, S4, S5 + leaf table)
 int stage7_fill(gsa_ctx *c);          // k_extend.hip  (S6: gap records of the final block list)
 int stage78_extend(gsa_ctx *c);       // k_extend.hip  (S7: classification, DP, gapped strings, block sums)

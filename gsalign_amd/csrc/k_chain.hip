@@ -23,35 +23,26 @@
 
 __device__ __forceinline__ i64 d_llabs(i64 v) { return v < 0 ? -v : v; }
 
-// ---- A. active groups -> (group,qPos,rPos) order ------------------------------
-__global__ void k_group_count(i32 ng, const i32 *__restrict__ g_beg, const i64 *__restrict__ ps, i32 min_score, i32 *gcount)
-{
-	i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (g > ng) return;
-	if (g == ng) { gcount[g] = 0; return; }
-	i64 sc = ps[g_beg[g + 1]] - ps[g_beg[g]];
-	gcount[g] = sc >= min_score ? g_beg[g + 1] - g_beg[g] : 0;       // GSAlign.cpp:387
-}
-
-__global__ void k_active_keys(i64 n, const i32 *__restrict__ s_q, const i32 *__restrict__ s_gid, const i32 *__restrict__ g_beg,
-                              const i32 *__restrict__ abeg, int qbits, u64 *key, u32 *val)
+// ---- A. (group,qPos,rPos) order ---------------------------------------------------
+// The reference skips groups whose total seed length is below MinAlnBlockScore
+// (GSAlign.cpp:387).  Any block cut from such a group scores below the same threshold
+// and AddAlnBlock drops it (:145-153), so analysing ALL groups gives the same block
+// list; that keeps the seed count a host-known launch bound (no read-back here).
+__global__ void k_group_keys(i64 n, const i32 *__restrict__ s_q, const i32 *__restrict__ s_gid, int qbits, u64 *key, u32 *val)
 {
 	GID(n);
-	const i32 g = s_gid[i];
-	if (abeg[g + 1] == abeg[g]) return;
-	const i32 p = abeg[g] + (i32)(i - g_beg[g]);
-	key[p] = ((u64)(u32)g << qbits) | (u32)s_q[i];
-	val[p] = (u32)i;
+	key[i] = ((u64)(u32)s_gid[i] << qbits) | (u32)s_q[i];
+	val[i] = (u32)i;
 }
 
 __global__ void k_gather_active(i64 na, const u32 *__restrict__ perm, const i32 *__restrict__ s_q, const i32 *__restrict__ s_len, const i64 *__restrict__ s_r,
-                                const i32 *__restrict__ s_gid, const i32 *__restrict__ abeg, i32 *a_q, i32 *a_len, i64 *a_r, i32 *a_gb, i32 *a_ge)
+                                const i32 *__restrict__ s_gid, const i32 *__restrict__ g_beg, i32 *a_q, i32 *a_len, i64 *a_r, i32 *a_gb, i32 *a_ge)
 {
 	GID(na);
 	const u32 s = perm[i];
 	a_q[i] = s_q[s]; a_len[i] = s_len[s]; a_r[i] = s_r[s];
 	const i32 g = s_gid[s];
-	a_gb[i] = abeg[g]; a_ge[i] = abeg[g + 1];
+	a_gb[i] = g_beg[g]; a_ge[i] = g_beg[g + 1];
 }
 
 // ---- B. unique flags, break flags ---------------------------------------------
@@ -347,31 +338,21 @@ __global__ void k_seed_block_id(const i32 *__restrict__ nptr, const i32 *__restr
 int stage2_chain(gsa_ctx *c)
 {
 	hipStream_t st = c->stream;
-	c->n_blocks2 = 0; c->n_c = 0; c->n_a = 0; c->blocks.clear();
+	c->n_blocks2 = 0; c->n_c = 0; c->n_b = 0; c->n_a = 0; c->blocks.clear(); c->s2_host = true;
 	c->h_blk_beg.clear(); c->h_blk_end.clear(); c->h_blk_score.clear();
-	const i64 n = c->n_seeds; const i32 ng = c->n_groups;
-	if (n == 0 || ng == 0) return GSA_OK;
+	const i64 n = c->n_seeds;
+	if (n == 0) return GSA_OK;
+	c->s2_host = false;
 	if (c->profiling) hipEventRecord(c->ev[4], st);
-	// A. group scores, active groups
-	ENS(i64, d_i64a, n + 1); ENS(i32, d_flag2, n + 2); ENS(i32, d_scan2, n + 2);
-	// s_len has n entries; scan n+1 with a zero tail staged in d_flag
-	GSA_CHECK(c, hipMemcpyAsync(c->d_flag.p, c->s_len.p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
-	LAUNCH(k_flag_tail, 1, n, c->d_flag.as<i32>());
-	RC(prim_exscan_i32_i64(c, c->d_flag.as<i32>(), c->d_i64a.as<i64>(), (size_t)n + 1));
-	i32 *gcount = c->d_flag2.as<i32>(), *abeg = c->d_scan2.as<i32>();
-	LAUNCH(k_group_count, ng + 1, ng, c->g_beg.as<i32>(), c->d_i64a.as<i64>(), c->prm.MinAlnBlockScore, gcount);
-	RC(prim_exscan_i32(c, gcount, abeg, (size_t)ng + 1));
-	i32 na32 = 0;
-	GSA_CHECK(c, hipMemcpyAsync(&na32, abeg + ng, 4, hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipStreamSynchronize(st));
-	const i64 na = na32; c->n_a = na;
-	if (na == 0) return GSA_OK;
+	// A. all seeds in (group, qPos, rPos) order
+	const i64 na = n; c->n_a = na;
+	ENS(i64, d_i64a, n + 2); ENS(i32, d_flag2, n + 2); ENS(i32, d_scan2, n + 2);
 	ENS(u64, d_key_a, n); ENS(u64, d_key_b, n); ENS(u32, d_val_a, n); ENS(u32, d_val_b, n);
-	LAUNCH(k_active_keys, n, n, c->s_q.as<i32>(), c->s_gid.as<i32>(), c->g_beg.as<i32>(), abeg, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>());
-	const int gbits = ceil_log2_u64((u64)ng + 1);
+	LAUNCH(k_group_keys, n, n, c->s_q.as<i32>(), c->s_gid.as<i32>(), c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>());
+	const int gbits = ceil_log2_u64((u64)n + 1);
 	RC(prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + gbits));
 	ENS(i32, a_q, na); ENS(i32, a_len, na); ENS(i64, a_r, na); ENS(i32, a_gb, na); ENS(i32, a_ge, na);
-	LAUNCH(k_gather_active, na, na, c->d_val_b.as<u32>(), c->s_q.as<i32>(), c->s_len.as<i32>(), c->s_r.as<i64>(), c->s_gid.as<i32>(), abeg,
+	LAUNCH(k_gather_active, na, na, c->d_val_b.as<u32>(), c->s_q.as<i32>(), c->s_len.as<i32>(), c->s_r.as<i64>(), c->s_gid.as<i32>(), c->g_beg.as<i32>(),
 	       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>());
 	// B. unique / break flags, window chain
 	ENS(i32, a_uniq, na + 1); ENS(i32, a_cu, na + 1); ENS(i32, a_alive, na + 1); ENS(i32, a_brk, na + 1); ENS(i32, a_aurank, na + 1);
@@ -416,7 +397,7 @@ int stage2_chain(gsa_ctx *c)
 	LAUNCH(k_compact, na, na, alive, ex, c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(),
 	       c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(), c->b_ge.as<i32>());
 	// n_b lives on the device at ex[na]; keep a private copy because `ex` is reused
-	i32 *d_counts = c->w_n.as<i32>();          // [0] = n_b, [1] = n_c   (w_n is free again)
+	i32 *d_counts = c->d_mail.as<i32>() + M_NB;   // mailbox: [M_NB] = n_b, [M_NC] = n_c
 	GSA_CHECK(c, hipMemcpyAsync(d_counts, ex + na, 4, hipMemcpyDeviceToDevice, st));
 	// noise stencil + compaction #2
 	i32 *keep = c->d_flag.as<i32>(), *keepEx = c->d_scan2.as<i32>();
@@ -442,18 +423,25 @@ int stage2_chain(gsa_ctx *c)
 	ENS(i32, blk_beg, na + 1); ENS(i32, blk_end, na + 1); ENS(i32, blk_score, na + 1);
 	LAUNCH(k_block_emit, na, d_counts + 1, bheadEx, bstart, bkeep, bkeepEx, bscore, c->blk_beg.as<i32>(), c->blk_end.as<i32>(), c->blk_score.as<i32>());
 	LAUNCH(k_seed_block_id, na, d_counts + 1, bhead, bheadEx, bkeep, bkeepEx, c->c_bid.as<i32>());
-	i32 h_counts[2] = {0, 0}, nblk = 0;
-	GSA_CHECK(c, hipMemcpyAsync(h_counts, d_counts, 8, hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipMemcpyAsync(&nblk, bkeepEx + na, 4, hipMemcpyDeviceToHost, st));
-	if (c->profiling) hipEventRecord(c->ev[5], st);
-	GSA_CHECK(c, hipStreamSynchronize(st));
-	c->n_b = h_counts[0]; c->n_c = h_counts[1]; c->n_blocks2 = nblk;
+	GSA_CHECK(c, hipMemcpyAsync(c->d_mail.as<i32>() + M_NBLK, bkeepEx + na, 4, hipMemcpyDeviceToDevice, st));
+	if (c->profiling) { hipEventRecord(c->ev[5], st); c->ev_pending |= 2; }
+	return GSA_OK;      // counts stay in the mailbox; stage 3 reads them with its own first read-back
+}
+
+// Host copies of the stage-2 counts and block table (stage views, tests).
+int stage2_fetch_host(gsa_ctx *c)
+{
+	if (c->s2_host) return GSA_OK;
+	GSA_CHECK(c, hipStreamSynchronize(c->stream));
+	GSA_CHECK(c, hipMemcpy(c->h_mail, c->d_mail.p, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost));
+	c->n_b = c->h_mail[M_NB]; c->n_c = c->h_mail[M_NC]; c->n_blocks2 = c->h_mail[M_NBLK];
+	const i32 nblk = c->n_blocks2;
+	c->h_blk_beg.resize(nblk); c->h_blk_end.resize(nblk); c->h_blk_score.resize(nblk);
 	if (nblk > 0) {
-		c->h_blk_beg.resize(nblk); c->h_blk_end.resize(nblk); c->h_blk_score.resize(nblk);
 		GSA_CHECK(c, hipMemcpy(c->h_blk_beg.data(), c->blk_beg.p, (size_t)nblk * 4, hipMemcpyDeviceToHost));
 		GSA_CHECK(c, hipMemcpy(c->h_blk_end.data(), c->blk_end.p, (size_t)nblk * 4, hipMemcpyDeviceToHost));
 		GSA_CHECK(c, hipMemcpy(c->h_blk_score.data(), c->blk_score.p, (size_t)nblk * 4, hipMemcpyDeviceToHost));
 	}
-	if (c->profiling) { float ms; hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); c->kernel_ms[3] = ms; }
+	c->s2_host = true;
 	return GSA_OK;
 }

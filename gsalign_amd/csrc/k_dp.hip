@@ -87,60 +87,66 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 // written and read with agent-scope relaxed atomics (write-through / L1-bypassing,
 // so no fence and no separate flag; granules are zeroed before the launch).
 // Stripe p trails stripe p-1 by 64..80 diagonals and fetches 16 rows of boundary at
-// a time.  Direction bytes go to HBM diagonal-major.  The stripe that finishes last
-// (agent-scope release/acquire around a ticket counter) runs the traceback: 64x64
-// tiles held in REGISTERS (lane = tile row), walked with scalar state + v_readlane,
-// i.e. without a memory round trip per step.
+// a time.
+// Direction bytes go to HBM STRIPE-LOCAL: stripe p owns (m+63) rows of 64 bytes,
+// row = local diagonal, byte = lane -- one coalesced 64-byte store per step with a
+// scalar base, and every traceback tile is one contiguous block.
+// The stripe that finishes last (agent-scope release/acquire around a ticket
+// counter) runs the traceback.  It keeps a DP_TILE_ROWS x 64 tile of the current
+// stripe in LDS and walks it RUN BY RUN: the lanes look ahead along the three
+// possible directions (21 cells each) in one LDS read, a ballot gives the length
+// of the run the automaton of ksw_backtrack would take step by step, and the run
+// is emitted at once.
 // Forward progress: stripe p only waits for stripe p-1, which has a lower
 // workgroup index and was therefore dispatched earlier; spins are bounded.
 // ---------------------------------------------------------------------------
 struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; };
-
-__device__ __forceinline__ u32 sel16(const u32 (&w)[16], int q)
-{
-	switch (q) {
-	case 0: return w[0]; case 1: return w[1]; case 2: return w[2]; case 3: return w[3]; case 4: return w[4]; case 5: return w[5]; case 6: return w[6]; case 7: return w[7];
-	case 8: return w[8]; case 9: return w[9]; case 10: return w[10]; case 11: return w[11]; case 12: return w[12]; case 13: return w[13]; case 14: return w[14]; default: return w[15];
-	}
-}
+#define DP_TILE_ROWS 128
+#define DP_LOOK 21
 
 __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__restrict__ sjobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
                                                    const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2, uint8_t *dirbase, u32 *bndbase, u32 *ctr,
                                                    uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len)
 {
 	extern __shared__ __attribute__((aligned(16))) int8_t C1[];        // the reference fragment as nt4 codes
+	__shared__ __attribute__((aligned(16))) uint8_t tile[DP_TILE_ROWS * 64];
 	// which job / stripe am I (uniform)
 	int lo = 0, hi = nsj;
 	while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sjobs[mid].first_block <= (i32)blockIdx.x) lo = mid; else hi = mid; }
 	const StripeJob sj = sjobs[lo];
 	const int p = (int)blockIdx.x - sj.first_block, m = sj.m, n = sj.n, P = sj.P, lane = threadIdx.x;
 	const uint8_t *s1 = pool1 + off1[sj.job], *s2 = pool2 + off2[sj.job];
+	const size_t pitch = (size_t)(m + 63) * 64;                         // direction bytes of one stripe
+	const int mpad64 = (m + 64 + 63) & ~63;                             // C1 is readable one 64-row block past the end
 	uint8_t *dir = dirbase + sj.diroff;
 	u32 *bnd_in = bndbase + sj.bndoff + (size_t)(p - 1) * m, *bnd_out = bndbase + sj.bndoff + (size_t)p * m;
 	u32 *err = ctr;                                                     // ctr[0]: spin-bound error flag
-	for (int t = lane; t < m; t += 64) C1[t] = (int8_t)gsa_nt4(s1[t]);
+	for (int t = lane; t < m; t += 64) C1[t] = (int8_t)(gsa_nt4(s1[t]) << 2);      // pre-multiplied: bit offset into the score table
+	for (int t = m + lane; t < mpad64; t += 64) C1[t] = 16;
 	const int t = p * 64 + lane;
 	const int Wp = n - p * 64 < 64 ? n - p * 64 : 64;
 	const int cq = t < n ? gsa_nt4(s2[t]) : 4;
+	// z = score + q + e as a 4-bit table over the reference code (ksw2_alignment.cpp:74-95: match 1, mismatch -1, N 0)
+	u32 tbl = 0;
+#pragma unroll
+	for (int cc = 0; cc < 5; cc++) tbl |= (u32)((cq == 4 || cc == 4) ? 6 : (cq == cc ? 7 : 5)) << (4 * cc);
 	int u = t ? 2 : 0, y = 0, x = 0, v = 0;
 	u32 bin = 0, gnext = 0;
 	__syncthreads();
 	const int nl = m + Wp - 1;
-	int cref = lane == 0 ? C1[0] : 4;                   // reference code of my row on the current diagonal, fetched one diagonal ahead
-	i64 off = dp_rowoff((i64)p * 64, m, n);
+	int wref = 16;                                      // 4 * reference code of my row on the current diagonal (travels one lane up per diagonal)
+	int creg = 16;                                      // lane q: 4 * code of reference row (rl & ~63) + q
+	uint8_t *dirp = dir + (size_t)p * pitch;
 	// boundary granules are fetched ONE BLOCK AHEAD (16 rows per block) so their L2 latency overlaps the block before
 	if (p > 0) { const int row = lane & 15; if (lane < 16 && row < m) gnext = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-	const bool mycol = lane < Wp;
+	const int jjoff = lane < Wp ? lane : 0x40000000;    // lanes beyond the stripe never become valid
 	const bool publish = lane == Wp - 1 && p < P - 1;
-	for (int rl = 0; rl < nl; rl++) {
-		const int r = rl + p * 64;
-		const int st = r - m + 1 > 0 ? r - m + 1 : 0, en = r < n - 1 ? r : n - 1;
-		// prefetch the reference code of the NEXT diagonal (row jj+1) so the LDS latency is off the recurrence chain
-		const int jn = rl + 1 - lane;
-		const int cnext = ((unsigned)jn < (unsigned)m) ? C1[jn] : 4;
-		if (p > 0 && (rl & 15) == 0 && rl < m) {
-			// boundary rows rl .. rl+15 from stripe p-1: spin until every granule carries its tag
-			const int row = rl + (lane & 15);
+	for (int rl0 = 0; rl0 < nl; rl0 += 16) {
+		if ((rl0 & 63) == 0) creg = C1[rl0 + lane];
+		if (p == 0) bin = (rl0 == 0 && lane == 0) ? 0u : 0x200u;      // t = 0 boundary: x1 = 0, v1 = q, except for the very first cell (:157-164)
+		else if (rl0 < m) {
+			// boundary rows rl0 .. rl0+15 from stripe p-1: spin until every granule carries its tag
+			const int row = rl0 + (lane & 15);
 			const bool need = lane < 16 && row < m;
 			u32 g = gnext; u32 spins = 0;
 			while (!__all(!need || (g >> 16) != 0)) {
@@ -152,18 +158,32 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 			const int rown = row + 16;
 			gnext = (lane < 16 && rown < m) ? __hip_atomic_load(&bnd_in[rown], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 		}
-		const int fill = p > 0 ? __builtin_amdgcn_readlane((int)bin, rl & 15) : ((r ? 2 : 0) << 8);     // t = 0 boundary: x1 = 0, v1 = q (:157-164)
-		const int packed = wave_shr1(x | (v << 8), fill);
-		const int jj = rl - lane;
-		if (mycol && (unsigned)jj < (unsigned)m) {
-			int un, vn, xn, yn;
-			const int d = dp_cell(packed & 0xff, packed >> 8, u, y, cq, cref, un, vn, xn, yn);
-			u = un; v = vn; x = xn; y = yn;
-			dir[off + (t - st)] = (uint8_t)d;
-			if (publish) __hip_atomic_store(&bnd_out[jj], (1u << 16) | (u32)(xn | (vn << 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const int cbase = rl0 & 63;
+		uint8_t *rowp = dirp + ((size_t)rl0 << 6);
+#pragma unroll
+		for (int k2 = 0; k2 < 16; k2++) {
+			const int rl = rl0 + k2;
+			if (rl >= nl) break;
+			wref = wave_shr1(wref, __builtin_amdgcn_readlane(creg, cbase + k2));
+			const int packed = wave_shr1(x | (v << 8), __builtin_amdgcn_readlane((int)bin, k2));
+			const int jj = rl - jjoff;
+			if ((unsigned)jj < (unsigned)m) {
+				const int x1 = packed & 0xff, v1 = packed >> 8;
+				int z = (int)__builtin_amdgcn_ubfe(tbl, (u32)wref, 4u);
+				int a = x1 + v1, b = y + u;
+				int d = a > z ? 1 : 0; z = z > a ? z : a;
+				if (b > z) d = 2;
+				z = z > b ? z : b;
+				z = z < 7 ? z : 7;
+				const int un = z - v1, vn = z - u;
+				z -= 2; a -= z; b -= z;
+				if (a > 0) d |= 0x08; else a = 0;
+				if (b > 0) d |= 0x10; else b = 0;
+				u = un; v = vn; x = a; y = b;
+				rowp[(k2 << 6) + lane] = (uint8_t)d;
+				if (publish) __hip_atomic_store(&bnd_out[jj], (1u << 16) | (u32)(a | (vn << 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
 		}
-		off += en - st + 1;
-		cref = cnext;
 	}
 	// ---- ticket: the last stripe to finish does the traceback ----
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -175,46 +195,50 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	uint8_t *rev = revbase + ops_off[sj.job], *op = ops + ops_off[sj.job];
 	int i = n - 1, j = m - 1, state = 0, k = 0;
+	// lane l looks at the cell e = l % 21 steps ahead along direction g = l / 21 (0: M, 1: D, 2: I)
+	const int g = lane / DP_LOOK, e = lane - g * DP_LOOK;
+	const int dlc = g == 2 ? 0 : -e, drl = g == 0 ? -2 * e : -e;
 	while (i >= 0 && j >= 0) {
 		i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
-		const int R = i + j, T0 = i;
-		u32 w[16];
-#pragma unroll
-		for (int q2 = 0; q2 < 16; q2++) w[q2] = 0;
+		// tile: stripe sp, local diagonals rl_lo .. rl_hi
+		const int sp = i >> 6, rl_hi = j + (i & 63);
+		const int rl_lo = rl_hi - (DP_TILE_ROWS - 1) > 0 ? rl_hi - (DP_TILE_ROWS - 1) : 0;
 		{
-			const int rr_r = R - lane;                                   // my tile row = diagonal rr_r, bytes = columns T0-63 .. T0
-			const int st = rr_r - m + 1 > 0 ? rr_r - m + 1 : 0, en = rr_r < n - 1 ? rr_r : n - 1;
-			if (rr_r >= 0 && st <= T0 && en >= T0 - 63) {
-				const uint8_t *pa = dir + dp_rowoff(rr_r, m, n) + (T0 - 63 - st);
-				const int sh = (int)((size_t)pa & 3);
-				const u32 *al = (const u32 *)(pa - sh);
-				u32 a[17];
+			const uint4 *src = (const uint4 *)(dir + (size_t)sp * pitch + ((size_t)rl_lo << 6));
+			const int nvec = (rl_hi - rl_lo + 1) * 4;
+			uint4 *dst = (uint4 *)tile;
 #pragma unroll
-				for (int q2 = 0; q2 < 17; q2++) a[q2] = al[q2];
-#pragma unroll
-				for (int q2 = 0; q2 < 16; q2++) w[q2] = sh == 0 ? a[q2] : (sh == 1 ? __builtin_amdgcn_alignbyte(a[q2 + 1], a[q2], 1) : (sh == 2 ? __builtin_amdgcn_alignbyte(a[q2 + 1], a[q2], 2) : __builtin_amdgcn_alignbyte(a[q2 + 1], a[q2], 3)));
-			}
+			for (int q2 = 0; q2 < DP_TILE_ROWS * 4 / 64; q2++) { const int id = q2 * 64 + lane; if (id < nvec) dst[id] = src[id]; }
 		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 		for (;;) {
-			// the walker state is wave-uniform: pin it to scalar registers so that the tile-word select and
-			// the automaton run on the scalar unit (v_readlane instead of a memory round trip per step)
+			// the walker state is wave-uniform: pin it to scalar registers
 			i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
 			state = __builtin_amdgcn_readfirstlane(state); k = __builtin_amdgcn_readfirstlane(k);
-			const int rr = R - (i + j), bidx = i - (T0 - 63);
-			if (i < 0 || j < 0 || rr > 63 || bidx < 0) break;
-			const u32 mine = sel16(w, bidx >> 2);
-			const u32 word = (u32)__builtin_amdgcn_readlane((int)mine, rr);
-			// the automaton of ksw_backtrack (:38-52), branch-free on scalar values
-			const u32 tmp = (word >> ((bidx & 3) << 3)) & 0xffu;
-			int ns = state;
-			if (ns != 0 && !((tmp >> (ns + 2)) & 1)) ns = 0;
-			if (ns == 0) ns = (int)(tmp & 7);
-			state = ns;
-			const int isM = ns == 0 ? 1 : 0, isD = (ns == 1 || ns == 3) ? 1 : 0;
-			const int opc = isM ? 'M' : (isD ? 'D' : 'I');
-			i -= isM | isD; j -= isM | (1 - isD);
-			if (lane == 0) rev[k] = (uint8_t)opc;
-			k++;
+			if (i < 0 || j < 0) break;
+			const int lc = i - (sp << 6), rl = j + lc;
+			if (lc < 0 || rl < rl_lo) break;                       // left the tile: reload
+			const int lc2 = lc + dlc, rl2 = rl + drl;
+			const bool valid = lane < 3 * DP_LOOK && lc2 >= 0 && rl2 >= rl_lo && rl2 - lc2 >= 0;
+			const u32 tmp = valid ? tile[((rl2 - rl_lo) << 6) + lc2] : 0xffu;
+			const u32 cur = (u32)__builtin_amdgcn_readfirstlane((int)tmp);
+			// the automaton of ksw_backtrack (:38-52) for the current cell ...
+			int S = state;
+			if (S != 0 && !((cur >> (S + 2)) & 1)) S = 0;
+			if (S == 0) S = (int)(cur & 7);
+			const int isM = S == 0 ? 1 : 0, isD = (S == 1 || S == 3) ? 1 : 0;
+			const int gS = isM ? 0 : (isD ? 1 : 2);
+			// ... and for the cells behind it while they keep the same state
+			const bool cont = valid && g == gS && (isM ? (tmp & 7) == 0 : (((tmp >> (S + 2)) & 1) != 0 || (int)(tmp & 7) == S));
+			const unsigned long long bal = __ballot(cont) >> (gS * DP_LOOK + 1);
+			int run = __builtin_ctzll(~bal);
+			run = run < DP_LOOK - 1 ? run : DP_LOOK - 1;
+			const int L = 1 + run;
+			if (lane < L) rev[k + lane] = (uint8_t)(isM ? 'M' : (isD ? 'D' : 'I'));
+			k += L; state = S;
+			i -= (isM | isD) ? L : 0; j -= (isM | (1 - isD)) ? L : 0;
 		}
 	}
 	if (lane == 0) {
@@ -253,7 +277,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n, const uint8_t *pool1, const i64 *off1, cons
 	if (!empty.empty()) return gsa_fail(c, GSA_ERR_ARG, "DP job with an empty side");
 	auto by_cells = [&](i32 a, i32 b) { const i64 ca = (i64)h_len1[a] * h_len2[a], cb = (i64)h_len1[b] * h_len2[b]; return ca != cb ? ca > cb : a < b; };
 	std::sort(large.begin(), large.end(), by_cells);     // largest first: they are the critical path (the small ones need no order)
-	const int mpad = (mmax + 63) & ~63;
+	const int mpad = (mmax + 64 + 63) & ~63;
 	if (mpad > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 153600 bases");
 	i32 *d_order = dev_ensure<i32>(c, c->d_flag2, (size_t)n + 1);
 	uint8_t *rev = dev_ensure<uint8_t>(c, c->d_i64a, (size_t)ops_total + 64);
@@ -277,7 +301,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n, const uint8_t *pool1, const i64 *off1, cons
 		i64 dbytes = 128, bwords = 0; i32 nctr = 1, nblocks = 0;
 		size_t last = first;
 		while (last < large.size()) {
-			const i32 jb = large[last]; const i64 m = h_len1[jb], nn = h_len2[jb], cells = m * nn;
+			const i32 jb = large[last]; const i64 m = h_len1[jb], nn = h_len2[jb], cells = ((nn + 63) / 64) * (m + 63) * 64;   // stripe-local direction bytes
 			if (last > first && dbytes + cells > budget) break;
 			StripeJob s; s.job = jb; s.m = (i32)m; s.n = (i32)nn; s.P = (i32)((nn + 63) / 64);
 			s.diroff = dbytes; dbytes += cells + 128;

@@ -19,28 +19,31 @@
 #define ENS(T, buf, n) do { if (!dev_ensure<T>(c, c->buf, (size_t)(n))) return GSA_ERR_NOMEM; } while (0)
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
-__global__ void k_inblock_flag(i64 n, const i32 *__restrict__ bid, i32 *flag)
+// `ub` is the host-known upper bound (the seed count); the live count sits in the mailbox.
+__global__ void k_inblock_flag(i64 ub, const i32 *__restrict__ d_n, const i32 *__restrict__ bid, i32 *flag)
 {
 	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > n) return;
-	flag[i] = (i < n && bid[i] >= 0) ? 1 : 0;
+	if (i > ub) return;
+	flag[i] = (i < *d_n && bid[i] >= 0) ? 1 : 0;
 }
 
 __global__ void k_take(i64 n, const i32 *__restrict__ keep, const i32 *__restrict__ ex, const i32 *__restrict__ q, const i32 *__restrict__ len,
-                       const i64 *__restrict__ r, const i32 *__restrict__ bid, i32 *oq, i32 *olen, i64 *orr, i32 *obid)
+                       const i64 *__restrict__ r, const i32 *__restrict__ bid, i32 *oq, i32 *olen, i64 *orr, i32 *obid, i32 *d_nout)
 {
 	GID(n);
+	if (i == 0) *d_nout = ex[n];
 	if (!keep[i]) return;
 	const i32 p = ex[i];
 	oq[p] = q[i]; olen[p] = len[i]; orr[p] = r[i]; obid[p] = bid[i];
 }
 
 // one RemoveOverlaps pass (ProcessCandidateAlignment.cpp:197-226)
-__global__ void k_overlap_pass(i64 n, const i32 *__restrict__ q, i32 *len, const i64 *__restrict__ r, const i32 *__restrict__ bid, i32 *keep, i32 *anykill)
+__global__ void k_overlap_pass(i64 ub, const i32 *__restrict__ d_n, const i32 *__restrict__ q, i32 *len, const i64 *__restrict__ r, const i32 *__restrict__ bid, i32 *keep, i32 *anykill)
 {
 	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > n) return;
-	if (i == n) { keep[i] = 0; return; }
+	if (i > ub) return;
+	const i64 n = *d_n;
+	if (i >= n) { keep[i] = 0; return; }
 	i32 k = 1;
 	if (i + 1 < n && bid[i + 1] == bid[i]) {
 		const i64 ri = r[i], rj = r[i + 1]; const i32 qi = q[i], qj = q[i + 1];
@@ -58,11 +61,12 @@ __global__ void k_overlap_pass(i64 n, const i32 *__restrict__ q, i32 *len, const
 }
 
 // S4 (CheckGapsBetweenSeeds, :120-156): cut4[i] = 1 cut before i; job[i] = needs CalGapSimilarity
-__global__ void k_gap_cuts(i64 n, const i32 *__restrict__ q, const i32 *__restrict__ len, const i64 *__restrict__ r, const i32 *__restrict__ bid,
+__global__ void k_gap_cuts(i64 ub, const i32 *__restrict__ d_n, const i32 *__restrict__ q, const i32 *__restrict__ len, const i64 *__restrict__ r, const i32 *__restrict__ bid,
                            i32 *cut4, i32 *job)
 {
 	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > n) return;
+	if (i > ub) return;
+	const i64 n = *d_n;
 	i32 cut = 0, jb = 0;
 	if (i < n && i > 0 && bid[i - 1] == bid[i]) {
 		const i32 qGap = q[i] - q[i - 1] - len[i - 1];
@@ -112,16 +116,17 @@ __global__ void k_chr_cuts(i64 n, DevIndex di, const i64 *__restrict__ r, const 
 
 __global__ void k_leaf_emit(i64 n, const i32 *__restrict__ head, const i32 *__restrict__ headEx, const i32 *__restrict__ lstart, const i32 *__restrict__ q,
                             const i32 *__restrict__ len, const i64 *__restrict__ r, const i32 *__restrict__ bid, const i32 *__restrict__ cut4,
-                            const i32 *__restrict__ cut5, const i64 *__restrict__ ps, Leaf *leaf)
+                            const i32 *__restrict__ cut5, const i64 *__restrict__ ps, const i32 *__restrict__ blk_score, Leaf *leaf, i32 *d_nl)
 {
 	GID(n);
 	const i32 nl = headEx[n];
+	if (i == 0) *d_nl = nl;
 	if (i >= nl) return;
 	const i32 s = lstart[i], e = (i + 1 < nl) ? lstart[i + 1] : (i32)n;
 	Leaf L;
 	L.beg = s; L.end = e; L.sumlen = (i32)(ps[e] - ps[s]);
 	L.q_first = q[s]; L.q_last_end = q[e - 1] + len[e - 1]; L.r_first = r[s]; L.r_last_end = r[e - 1] + len[e - 1];
-	L.blk = bid[s]; L.cut4 = cut4[s]; L.cut5 = cut5[s];
+	L.blk = bid[s]; L.cut4 = cut4[s]; L.cut5 = cut5[s]; L.blk_score = blk_score[L.blk];
 	leaf[i] = L;
 }
 
@@ -135,48 +140,49 @@ int stage345_refine(gsa_ctx *c)
 {
 	hipStream_t st = c->stream;
 	c->n_r = 0; c->h_leaf.clear(); c->blocks.clear(); c->have_host_seeds = false;
-	const i64 nc = c->n_c;
-	if (c->n_blocks2 == 0 || nc == 0) return GSA_OK;
+	const i64 ub = c->n_seeds;                    // every count below is <= the seed count
+	if (ub == 0) { c->n_blocks2 = 0; c->n_c = 0; c->n_b = 0; return GSA_OK; }
 	if (c->profiling) hipEventRecord(c->ev[6], st);
+	i32 *mail = c->d_mail.as<i32>();
 	// seeds that belong to a kept S2 block
-	ENS(i32, d_flag, nc + 1); ENS(i32, d_scan, nc + 1);
+	ENS(i32, d_flag, ub + 1); ENS(i32, d_scan, ub + 1);
 	i32 *flag = c->d_flag.as<i32>(), *ex = c->d_scan.as<i32>();
-	LAUNCH(k_inblock_flag, nc + 1, nc, c->c_bid.as<i32>(), flag);
-	RC(prim_exscan_i32(c, flag, ex, (size_t)nc + 1));
-	i32 nr32 = 0;
-	GSA_CHECK(c, hipMemcpyAsync(&nr32, ex + nc, 4, hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipStreamSynchronize(st));
-	i64 nr = nr32;
-	ENS(i32, r_q, nr + 1); ENS(i32, r_len, nr + 1); ENS(i64, r_r, nr + 1); ENS(i32, r_bid, nr + 1);
-	ENS(i32, r_tmp_q, nr + 1); ENS(i32, r_tmp_len, nr + 1); ENS(i64, r_tmp_r, nr + 1); ENS(i32, r_tmp_bid, nr + 1);
-	LAUNCH(k_take, nc, nc, flag, ex, c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_bid.as<i32>(),
-	       c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>());
-	// S3: passes until nothing dies
-	i32 *anykill = c->d_cnt.as<i32>() + 24;      // u64[12] of the counter block
-	for (int pass = 0; pass < 1000; pass++) {
-		GSA_CHECK(c, hipMemsetAsync(anykill, 0, 4, st));
-		LAUNCH(k_overlap_pass, nr + 1, nr, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), flag, anykill);
-		i32 h_any = 0;
-		GSA_CHECK(c, hipMemcpyAsync(&h_any, anykill, 4, hipMemcpyDeviceToHost, st));
-		GSA_CHECK(c, hipStreamSynchronize(st));
-		if (!h_any) break;
-		RC(prim_exscan_i32(c, flag, ex, (size_t)nr + 1));
-		LAUNCH(k_take, nr, nr, flag, ex, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(),
-		       c->r_tmp_q.as<i32>(), c->r_tmp_len.as<i32>(), c->r_tmp_r.as<i64>(), c->r_tmp_bid.as<i32>());
-		GSA_CHECK(c, hipMemcpyAsync(&nr32, ex + nr, 4, hipMemcpyDeviceToHost, st));
-		GSA_CHECK(c, hipStreamSynchronize(st));
-		nr = nr32;
-		std::swap(c->r_q, c->r_tmp_q); std::swap(c->r_len, c->r_tmp_len); std::swap(c->r_r, c->r_tmp_r); std::swap(c->r_bid, c->r_tmp_bid);
-	}
-	c->n_r = nr;
-	// S4 cuts
-	ENS(i32, r_cut4, nr + 1); ENS(i32, r_cut5, nr + 1); ENS(i32, r_simjob, nr + 1); ENS(i32, r_simres, nr + 1);
+	ENS(i32, r_q, ub + 1); ENS(i32, r_len, ub + 1); ENS(i64, r_r, ub + 1); ENS(i32, r_bid, ub + 1);
+	ENS(i32, r_tmp_q, ub + 1); ENS(i32, r_tmp_len, ub + 1); ENS(i64, r_tmp_r, ub + 1); ENS(i32, r_tmp_bid, ub + 1);
+	ENS(i32, r_cut4, ub + 1); ENS(i32, r_cut5, ub + 1); ENS(i32, r_simjob, ub + 1); ENS(i32, r_simres, ub + 1);
 	i32 *cut4 = c->r_cut4.as<i32>(), *cut5 = c->r_cut5.as<i32>(), *job = c->r_simjob.as<i32>();
-	LAUNCH(k_gap_cuts, nr + 1, nr, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, job);
-	RC(prim_exscan_i32(c, job, ex, (size_t)nr + 1));
-	i32 nj = 0;
-	GSA_CHECK(c, hipMemcpyAsync(&nj, ex + nr, 4, hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipStreamSynchronize(st));
+	LAUNCH(k_inblock_flag, ub + 1, ub, mail + M_NC, c->c_bid.as<i32>(), flag);
+	RC(prim_exscan_i32(c, flag, ex, (size_t)ub + 1));
+	LAUNCH(k_take, ub, ub, flag, ex, c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_bid.as<i32>(),
+	       c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), mail + M_NR);
+	// S3: passes until nothing dies.  A pass that kills nothing followed by its compaction is the
+	// identity, so the passes are issued two at a time with the S4 gap scan behind them and the
+	// host looks at the kill flags once per batch.
+	GSA_CHECK(c, hipMemsetAsync(mail + M_ANY, 0, 32 * sizeof(i32), st));
+	int round = 0;
+	for (;;) {
+		for (int k = 0; k < 2; k++, round++) {
+			LAUNCH(k_overlap_pass, ub + 1, ub, mail + M_NR, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), flag, mail + M_ANY + (round & 31));
+			RC(prim_exscan_i32(c, flag, ex, (size_t)ub + 1));
+			LAUNCH(k_take, ub, ub, flag, ex, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(),
+			       c->r_tmp_q.as<i32>(), c->r_tmp_len.as<i32>(), c->r_tmp_r.as<i64>(), c->r_tmp_bid.as<i32>(), mail + M_NR);
+			std::swap(c->r_q, c->r_tmp_q); std::swap(c->r_len, c->r_tmp_len); std::swap(c->r_r, c->r_tmp_r); std::swap(c->r_bid, c->r_tmp_bid);
+		}
+		// S4 cuts (speculative: valid if the last pass killed nothing)
+		LAUNCH(k_gap_cuts, ub + 1, ub, mail + M_NR, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, job);
+		RC(prim_exscan_i32(c, job, ex, (size_t)ub + 1));
+		GSA_CHECK(c, hipMemcpyAsync(mail + M_NJ, ex + ub, 4, hipMemcpyDeviceToDevice, st));
+		GSA_CHECK(c, hipMemcpyAsync(c->h_mail, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
+		GSA_CHECK(c, hipStreamSynchronize(st));
+		if (!c->h_mail[M_ANY + ((round - 1) & 31)]) break;
+		if (round >= 2000) return gsa_fail(c, GSA_ERR_STATE, "internal: RemoveOverlaps does not converge");
+		if ((round & 31) == 0) GSA_CHECK(c, hipMemsetAsync(mail + M_ANY, 0, 32 * sizeof(i32), st));
+	}
+	collect_events(c);
+	c->n_b = c->h_mail[M_NB]; c->n_c = c->h_mail[M_NC]; c->n_blocks2 = c->h_mail[M_NBLK];
+	const i64 nr = c->h_mail[M_NR]; const i32 nj = c->h_mail[M_NJ];
+	c->n_r = nr;
+	if (c->n_blocks2 == 0 || nr == 0) { c->n_r = 0; return GSA_OK; }
 	if (nj > 0) {
 		// job arrays carved from the (free) stage-2 scratch
 		ENS(i32, a_uniq, nj); ENS(i32, a_cu, nj); ENS(i64, w_best, nj); ENS(i64, w_sum, nj); ENS(i32, a_brk, nj);
@@ -194,15 +200,23 @@ int stage345_refine(gsa_ctx *c)
 	// prefix sums of the trimmed lengths (zero tail)
 	GSA_CHECK(c, hipMemsetAsync(c->r_len.as<i32>() + nr, 0, 4, st));
 	RC(prim_exscan_i32_i64(c, c->r_len.as<i32>(), c->d_i64a.as<i64>(), (size_t)nr + 1));
-	i32 nl = 0;
-	GSA_CHECK(c, hipMemcpyAsync(&nl, ex + nr, 4, hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipStreamSynchronize(st));
-	ENS(Leaf, d_leaf, nl + 1);
-	LAUNCH(k_leaf_emit, nr, nr, flag, ex, lstart, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, cut5, c->d_i64a.as<i64>(), c->d_leaf.as<Leaf>());
-	c->h_leaf.resize(nl);
-	GSA_CHECK(c, hipMemcpyAsync(c->h_leaf.data(), c->d_leaf.p, (size_t)nl * sizeof(Leaf), hipMemcpyDeviceToHost, st));
+	ENS(Leaf, d_leaf, nr + 1);
+	LAUNCH(k_leaf_emit, nr, nr, flag, ex, lstart, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, cut5, c->d_i64a.as<i64>(),
+	       c->blk_score.as<i32>(), c->d_leaf.as<Leaf>(), mail + M_NL);
+	// the leaf count and the first LEAF_CHUNK leaves come back together
+	const size_t first = (size_t)std::min<i64>(nr, LEAF_CHUNK);
+	if (!pin_ensure<Leaf>(c, c->p_leaf, (size_t)LEAF_CHUNK)) return GSA_ERR_NOMEM;
+	GSA_CHECK(c, hipMemcpyAsync(c->h_mail + M_NL, mail + M_NL, sizeof(i32), hipMemcpyDeviceToHost, st));
+	GSA_CHECK(c, hipMemcpyAsync(c->p_leaf.p, c->d_leaf.p, first * sizeof(Leaf), hipMemcpyDeviceToHost, st));
 	if (c->profiling) hipEventRecord(c->ev[7], st);
 	GSA_CHECK(c, hipStreamSynchronize(st));
+	const i32 nl = c->h_mail[M_NL];
+	if ((size_t)nl > first) {
+		if (!pin_ensure<Leaf>(c, c->p_leaf, (size_t)nl)) return GSA_ERR_NOMEM;
+		GSA_CHECK(c, hipMemcpyAsync(c->p_leaf.p, c->d_leaf.p, (size_t)nl * sizeof(Leaf), hipMemcpyDeviceToHost, st));
+		GSA_CHECK(c, hipStreamSynchronize(st));
+	}
+	c->h_leaf.assign(c->p_leaf.as<Leaf>(), c->p_leaf.as<Leaf>() + nl);
 	if (c->profiling) { float ms; hipEventElapsedTime(&ms, c->ev[6], c->ev[7]); c->kernel_ms[4] = ms; }
 	// host list after S3 = the S2 blocks, in S2 order, with their S2 scores
 	c->blocks.resize(c->n_blocks2);
@@ -212,8 +226,9 @@ int stage345_refine(gsa_ctx *c)
 			HostBlock &hb = c->blocks[b];
 			hb.leaf_beg = (i32)l;
 			while (l < c->h_leaf.size() && c->h_leaf[l].blk == b) l++;
-			hb.leaf_end = (i32)l; hb.score = c->h_blk_score[b]; hb.bdup = 0; hb.aln_len = 0; hb.bdir = 0; hb.gpos = 0; hb.chr = 0;
+			hb.leaf_end = (i32)l; hb.bdup = 0; hb.aln_len = 0; hb.bdir = 0; hb.gpos = 0; hb.chr = 0;
 			if (hb.leaf_end == hb.leaf_beg) return gsa_fail(c, GSA_ERR_STATE, "internal: S2 block without seeds after S3");
+			hb.score = c->h_leaf[hb.leaf_beg].blk_score;
 		}
 	}
 	return GSA_OK;

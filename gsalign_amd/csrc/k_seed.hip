@@ -391,10 +391,10 @@ int stage1_seed(gsa_ctx *c)
 		if (c->profiling) hipEventRecord(c->ev[1], st);
 		int rcs = prim_exscan_i32(c, c->d_chunk_hits.as<i32>(), c->d_chunk_base.as<i32>(), (size_t)n_chunks + 1);
 		if (rcs) return rcs;
-		i32 tot = 0;
 		GSA_CHECK(c, hipMemcpyAsync(c->h_cnt, cnt, 16 * sizeof(u64), hipMemcpyDeviceToHost, st));
-		GSA_CHECK(c, hipMemcpyAsync(&tot, c->d_chunk_base.as<i32>() + n_chunks, sizeof(i32), hipMemcpyDeviceToHost, st));
+		GSA_CHECK(c, hipMemcpyAsync(c->h_mail, c->d_chunk_base.as<i32>() + n_chunks, sizeof(i32), hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipStreamSynchronize(st));
+		const i32 tot = c->h_mail[0];
 		if (c->h_cnt[CNT_CAND] > ccap) { ccap = (size_t)c->h_cnt[CNT_CAND] + 256; c->cand_cap_per_chunk = ccap; continue; }
 		n_hits = tot;
 		break;
@@ -423,11 +423,10 @@ int stage1_seed(gsa_ctx *c)
 	if (rc) return rc;
 	hipLaunchKernelGGL(k_group_ids, dim3(grid_for(n + 1, 256)), dim3(256), 0, st, (i64)n, c->d_flag.as<i32>(), c->d_scan.as<i32>(), c->s_gid.as<i32>(), c->g_beg.as<i32>());
 	if (c->profiling) hipEventRecord(c->ev[3], st);
-	i32 ng = 0;
-	GSA_CHECK(c, hipMemcpyAsync(&ng, c->d_scan.as<i32>() + n, sizeof(i32), hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipStreamSynchronize(st));
-	c->n_groups = ng;
-	if (c->profiling) { float ms; hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms; hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->kernel_ms[1] = ms; hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->kernel_ms[2] = ms; }
+	// the group count stays on the device (mailbox); nothing downstream needs it on the host
+	GSA_CHECK(c, hipMemcpyAsync(c->d_mail.as<i32>() + M_NG, c->d_scan.as<i32>() + n, sizeof(i32), hipMemcpyDeviceToDevice, st));
+	c->n_groups = -1;
+	c->ev_pending |= 1;
 	return GSA_OK;
 }
 
