@@ -86,8 +86,8 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 // it is handed over through HBM as self-validating 4-byte granules {tag,x|v<<8}
 // written and read with agent-scope relaxed atomics (write-through / L1-bypassing,
 // so no fence and no separate flag; granules are zeroed before the launch).
-// Stripe p trails stripe p-1 by 64..80 diagonals and fetches 16 rows of boundary at
-// a time.
+// The boundary column travels down a second DPP chain and is published 8 rows at a
+// time (one 32-byte store); stripe p fetches 8 rows per poll, one block ahead.
 // Direction bytes go to HBM STRIPE-LOCAL: stripe p owns (m+63) rows of 64 bytes,
 // row = local diagonal, byte = lane -- one coalesced 64-byte store per step with a
 // scalar base, and every traceback tile is one contiguous block.
@@ -102,6 +102,15 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 // ---------------------------------------------------------------------------
 struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; };
 #define DP_TILE_ROWS 128
+#ifndef DP_G
+#define DP_G 8               // boundary rows per hand-off block (4, 8 or 16)
+#endif
+// -DGSA_DP_TIMING: in-kernel phase timers for tools/dp_probe.py (single-job launches only)
+#ifdef GSA_DP_TIMING
+#define DPT(...) __VA_ARGS__
+#else
+#define DPT(...)
+#endif
 #define DP_LOOK 21
 
 __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__restrict__ sjobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
@@ -130,61 +139,96 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 	u32 tbl = 0;
 #pragma unroll
 	for (int cc = 0; cc < 5; cc++) tbl |= (u32)((cq == 4 || cc == 4) ? 6 : (cq == cc ? 7 : 5)) << (4 * cc);
-	int u = t ? 2 : 0, y = 0, x = 0, v = 0;
+	int u = t ? 2 : 0, y = 0;
 	u32 bin = 0, gnext = 0;
 	__syncthreads();
 	const int nl = m + Wp - 1;
+	DPT(const unsigned long long T0c = wall_clock64();)
 	int wref = 16;                                      // 4 * reference code of my row on the current diagonal (travels one lane up per diagonal)
 	int creg = 16;                                      // lane q: 4 * code of reference row (rl & ~63) + q
 	uint8_t *dirp = dir + (size_t)p * pitch;
-	// boundary granules are fetched ONE BLOCK AHEAD (16 rows per block) so their L2 latency overlaps the block before
-	if (p > 0) { const int row = lane & 15; if (lane < 16 && row < m) gnext = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	// boundary granules are fetched ONE BLOCK AHEAD (8 rows per block) so their L2 latency overlaps the block before
+	if (p > 0) { const int row = (lane & (DP_G - 1)) < m ? (lane & (DP_G - 1)) : m - 1; gnext = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	asm volatile("" :: "v"(gnext));                      // the first prefetch is complete before the loop: inside it, waits then only count stores issued after a prefetch
 	const int jjoff = lane < Wp ? lane : 0x40000000;    // lanes beyond the stripe never become valid
-	const bool publish = lane == Wp - 1 && p < P - 1;
-	for (int rl0 = 0; rl0 < nl; rl0 += 16) {
-		if ((rl0 & 63) == 0) creg = C1[rl0 + lane];
-		if (p == 0) bin = (rl0 == 0 && lane == 0) ? 0u : 0x200u;      // t = 0 boundary: x1 = 0, v1 = q, except for the very first cell (:157-164)
-		else if (rl0 < m) {
-			// boundary rows rl0 .. rl0+15 from stripe p-1: spin until every granule carries its tag
-			const int row = rl0 + (lane & 15);
-			const bool need = lane < 16 && row < m;
-			u32 g = gnext; u32 spins = 0;
-			while (!__all(!need || (g >> 16) != 0)) {
-				if (++spins > (1u << 20) || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-				__builtin_amdgcn_s_sleep(1);
-				if (need) g = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			bin = g & 0xffffu;
-			const int rown = row + 16;
-			gnext = (lane < 16 && rown < m) ? __hip_atomic_load(&bnd_in[rown], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-		}
-		const int cbase = rl0 & 63;
-		uint8_t *rowp = dirp + ((size_t)rl0 << 6);
-#pragma unroll
-		for (int k2 = 0; k2 < 16; k2++) {
-			const int rl = rl0 + k2;
-			if (rl >= nl) break;
-			wref = wave_shr1(wref, __builtin_amdgcn_readlane(creg, cbase + k2));
-			const int packed = wave_shr1(x | (v << 8), __builtin_amdgcn_readlane((int)bin, k2));
-			const int jj = rl - jjoff;
-			if ((unsigned)jj < (unsigned)m) {
-				const int x1 = packed & 0xff, v1 = packed >> 8;
-				int z = (int)__builtin_amdgcn_ubfe(tbl, (u32)wref, 4u);
-				int a = x1 + v1, b = y + u;
-				int d = a > z ? 1 : 0; z = z > a ? z : a;
-				if (b > z) d = 2;
-				z = z > b ? z : b;
-				z = z < 7 ? z : 7;
-				const int un = z - v1, vn = z - u;
-				z -= 2; a -= z; b -= z;
-				if (a > 0) d |= 0x08; else a = 0;
-				if (b > 0) d |= 0x10; else b = 0;
-				u = un; v = vn; x = a; y = b;
-				rowp[(k2 << 6) + lane] = (uint8_t)d;
-				if (publish) __hip_atomic_store(&bnd_out[jj], (1u << 16) | (u32)(a | (vn << 8)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-		}
+	const bool pub_stripe = p < P - 1;                  // (then Wp == 64 and lane 63 owns the boundary column)
+	int dlast = 0;
+	int pk = 0;                                         // x | v << 8 of my column after the current diagonal
+	int hist = 0;                                       // lane 63 - q: pk of lane 63 q diagonals ago (boundary rows travel one lane down per diagonal)
+	// one anti-diagonal; K2 is the position inside the 16-row block (a literal in the unrolled body)
+#define DP_STEP(K2, FIRST)                                                                                           \
+	{                                                                                                           \
+		const int rl_ = rl0 + (K2);                                                                             \
+		if (((K2) & (DP_G - 1)) == 0) {                                                                                  \
+			if (FIRST) bin = (rl_ == 0 && lane == 0) ? 0u : 0x200u;    /* t = 0 boundary: x1 = 0, v1 = q, except for the very first cell (:157-164) */ \
+			else if (rl_ < m) {                                                                                 \
+				/* boundary rows rl_ .. rl_+DP_G-1 from stripe p-1: spin until every granule carries its tag */       \
+				const int row = rl_ + (lane & (DP_G - 1));                                                               \
+				const bool need = lane < DP_G && row < m;                                                          \
+				u32 g = gnext;                                                                                  \
+				if (!__all(!need || (g >> 16) != 0)) {      /* (first look outside the loop: its wait only covers the prefetch) */ \
+					u32 spins = 0;                                                                              \
+					do {                                                                                        \
+						if (++spins > (1u << 20) || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; } \
+						__builtin_amdgcn_s_sleep(1);                                                            \
+						if (need) g = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+					} while (!__all(!need || (g >> 16) != 0));                                                  \
+				}                                                                                               \
+				bin = g & 0xffffu;                                                                              \
+				/* every lane loads (clamped row): an unconditional load lands in gnext without a copy that would wait for it */ \
+				const int rown = row + DP_G < m ? row + DP_G : m - 1;                                           \
+				gnext = __hip_atomic_load(&bnd_in[rown], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           \
+			}                                                                                                   \
+		}                                                                                                       \
+		wref = wave_shr1(wref, __builtin_amdgcn_readlane(creg, cbase + (K2)));                                  \
+		const int packed = wave_shr1(pk, __builtin_amdgcn_readlane((int)bin, (K2) & (DP_G - 1)));                            \
+		const int jj = rl_ - jjoff;                                                                             \
+		if ((unsigned)jj < (unsigned)m) {                                                                       \
+			const int x1 = packed & 0xff, v1 = packed >> 8;                                                     \
+			int z = (int)__builtin_amdgcn_ubfe(tbl, (u32)wref, 4u);                                             \
+			int a = x1 + v1, b = y + u;                                                                         \
+			int d = a > z ? 1 : 0; z = z > a ? z : a;                                                           \
+			if (b > z) d = 2;                                                                                   \
+			z = z > b ? z : b;                                                                                  \
+			z = z < 7 ? z : 7;                                                                                  \
+			const int un = z - v1, vn = z - u;                                                                  \
+			z -= 2; a -= z; b -= z;                                                                             \
+			if (a > 0) d |= 0x08; else a = 0;                                                                   \
+			if (b > 0) d |= 0x10; else b = 0;                                                                   \
+			u = un; y = b; pk = a | (vn << 8); dlast = d;                                                       \
+		}                                                                                                       \
+		/* stored by every lane (slots of cells outside the matrix are never read): a straight-line store    \
+		   keeps the vmcnt bookkeeping exact, so waiting for a boundary prefetch does not drain the stores */ \
+		rowp[((K2) << 6) + lane] = (uint8_t)dlast;                                                              \
+		hist = __builtin_amdgcn_update_dpp(pk, hist, 0x130, 0xf, 0xf, false);      /* wave_shl:1, lane 63 takes pk */ \
+		if (((K2) & (DP_G - 1)) == DP_G - 2 && pub_stripe && rl_ >= 62 + DP_G) {                                                       \
+			/* rows rl_-62-DP_G .. rl_-63 of the boundary column are complete: one store of DP_G tagged granules */ \
+			const int row = rl_ - 126 + lane;                                                                   \
+			if (lane >= 64 - DP_G && row < m) __hip_atomic_store(&bnd_out[row], (1u << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+		}                                                                                                       \
 	}
+	// (two copies of the loop: stripe 0 has no boundary loads in flight, and keeping it apart keeps its waits off the stores)
+#define DP_LOOP(FIRST)                                                                                          \
+	for (int rl0 = 0; rl0 < nl; rl0 += 16) {                                                                    \
+		if ((rl0 & 63) == 0) creg = C1[rl0 + lane];                                                             \
+		const int cbase = rl0 & 63;                                                                             \
+		uint8_t *rowp = dirp + ((size_t)rl0 << 6);                                                              \
+		if (rl0 + 16 <= nl) {                                                                                   \
+			DP_STEP(0, FIRST) DP_STEP(1, FIRST) DP_STEP(2, FIRST) DP_STEP(3, FIRST) DP_STEP(4, FIRST) DP_STEP(5, FIRST) DP_STEP(6, FIRST) DP_STEP(7, FIRST) \
+			DP_STEP(8, FIRST) DP_STEP(9, FIRST) DP_STEP(10, FIRST) DP_STEP(11, FIRST) DP_STEP(12, FIRST) DP_STEP(13, FIRST) DP_STEP(14, FIRST) DP_STEP(15, FIRST) \
+		} else {                                                                                                \
+			for (int k2 = 0; rl0 + k2 < nl; k2++) DP_STEP(k2, FIRST)                                            \
+		}                                                                                                       \
+	}
+	if (p == 0) { DP_LOOP(1) } else { DP_LOOP(0) }
+#undef DP_LOOP
+#undef DP_STEP
+	if (pub_stripe) {
+		// the last (partial) block of boundary rows: lane 63 - q holds row m-1-q
+		const int row = m - 64 + lane;
+		if (lane >= 64 - DP_G && row >= 0) __hip_atomic_store(&bnd_out[row], (1u << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	DPT(if (p == 0 && lane == 0) ctr[sj.ctr + 40] = (u32)(wall_clock64() - T0c); if (p == P - 1 && lane == 0) ctr[sj.ctr + 41] = (u32)(wall_clock64() - T0c);)
 	// ---- ticket: the last stripe to finish does the traceback ----
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -192,6 +236,7 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 	if (lane == 0) ticket = __hip_atomic_fetch_add(&ctr[sj.ctr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	ticket = (u32)__builtin_amdgcn_readfirstlane((int)ticket);
 	if ((int)ticket != P - 1) return;
+	DPT(const unsigned long long T1c = wall_clock64(); int ntile = 0, nrun = 0;)
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	uint8_t *rev = revbase + ops_off[sj.job], *op = ops + ops_off[sj.job];
 	int i = n - 1, j = m - 1, state = 0, k = 0;
@@ -201,6 +246,7 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 	while (i >= 0 && j >= 0) {
 		i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
 		// tile: stripe sp, local diagonals rl_lo .. rl_hi
+		DPT(ntile++;)
 		const int sp = i >> 6, rl_hi = j + (i & 63);
 		const int rl_lo = rl_hi - (DP_TILE_ROWS - 1) > 0 ? rl_hi - (DP_TILE_ROWS - 1) : 0;
 		{
@@ -237,10 +283,11 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 			run = run < DP_LOOK - 1 ? run : DP_LOOK - 1;
 			const int L = 1 + run;
 			if (lane < L) rev[k + lane] = (uint8_t)(isM ? 'M' : (isD ? 'D' : 'I'));
-			k += L; state = S;
+			k += L; state = S; DPT(nrun++;)
 			i -= (isM | isD) ? L : 0; j -= (isM | (1 - isD)) ? L : 0;
 		}
 	}
+	DPT(if (lane == 0) { ctr[sj.ctr + 42] = (u32)(wall_clock64() - T1c); ctr[sj.ctr + 43] = ntile; ctr[sj.ctr + 44] = nrun; ctr[sj.ctr + 45] = (u32)(wall_clock64() - T0c); })
 	if (lane == 0) {
 		for (; i >= 0; --i) rev[k++] = 'D';
 		for (; j >= 0; --j) rev[k++] = 'I';
@@ -321,6 +368,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n, const uint8_t *pool1, const i64 *off1, cons
 		GSA_CHECK(c, hipGetLastError());
 		u32 h_err = 0;
 		GSA_CHECK(c, hipMemcpyAsync(&h_err, ctr, 4, hipMemcpyDeviceToHost, st));
+		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (sj.size() == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })
 		GSA_CHECK(c, hipStreamSynchronize(st));       // also: the staging vector and the direction buffer are reused by the next batch
 		if (h_err) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
 		first = last;
