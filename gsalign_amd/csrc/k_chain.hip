@@ -68,14 +68,30 @@ __global__ void k_scatter_idx(i64 n, const i32 *__restrict__ flag, const i32 *__
 	if (flag[i]) list[ex[i]] = (i32)i;
 }
 
-// next window start for every candidate start (group head or brk position)
+// Window starts.  Every group head is one; further starts only exist in groups with at least
+// GSA_WIN_SEEDS unique seeds (a window needs that many to close, GSAlign.cpp:326-338).  Candidates =
+// heads and break positions of those "big" groups; ws[] starts out as the head flags.
+__global__ void k_cand_flags(i64 na, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge, const i32 *__restrict__ cuEx, const i32 *__restrict__ brk,
+                             i32 *candf, i32 *ws)
+{
+	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i > na) return;
+	if (i == na) { candf[i] = 0; ws[i] = 0; return; }
+	const i32 gb = a_gb[i], ge = a_ge[i];
+	const bool head = i == gb;
+	ws[i] = head ? 1 : 0;
+	candf[i] = (cuEx[ge] - cuEx[gb] >= GSA_WIN_SEEDS && (head || brk[i])) ? 1 : 0;
+}
+
+// next window start for every candidate; a group without a further window hands over to the first
+// candidate behind it (the head of the next big group) or to na
 __global__ void k_next_window(i64 na, const i32 *__restrict__ a_q, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge,
                               const i32 *__restrict__ uniq, const i32 *__restrict__ cuEx, const i32 *__restrict__ brk, const i32 *__restrict__ brkEx,
-                              const i32 *__restrict__ blist, i32 *next)
+                              const i32 *__restrict__ blist, const i32 *__restrict__ candf, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, i32 *next)
 {
 	GID(na);
+	if (!candf[i]) { next[i] = -1; return; }
 	const i32 gb = a_gb[i], ge = a_ge[i];
-	if (!(i == gb || brk[i])) { next[i] = -1; return; }
 	// n counts unique seeds: from the group head inclusive for the first window, after a restart exclusive
 	const i32 base = (i == gb) ? cuEx[gb] : cuEx[i] + uniq[i];
 	// first j in (i, ge) with cuIncl[j] - base >= 30   (cuIncl[j] = cuEx[j+1])
@@ -88,30 +104,29 @@ __global__ void k_next_window(i64 na, const i32 *__restrict__ a_q, const i32 *__
 	const i32 j0 = j1 > lo ? j1 : lo;
 	i32 nx = ge;
 	if (j0 < ge) { const i32 nB = brkEx[na]; const i32 k = brkEx[j0]; if (k < nB) { const i32 cand = blist[k]; if (cand < ge) nx = cand; } }
+	if (nx == ge) { const i32 k = candEx[ge]; nx = k < candEx[na] ? clist[k] : (i32)na; }
 	next[i] = nx;
 }
 
-// Greedy window segmentation.  chain(p) = next[p] runs through every window start of every group
-// (next[] returns the group end = the next group's head when a group has no further window), so
-// the starts are ONE chain over the whole array -- sequential, but like the seed chunks it is a
-// functional graph whose paths merge (window ends snap to the sparse "break" positions).  One
-// 1024-lane workgroup cuts the array into tiles, walks every tile speculatively from its first
-// candidate, then re-enters each tile at the previous tile's exit until no exit moves, and only
-// then marks the starts.  Exactly the reference's segmentation (GSAlign.cpp:326-338).
+// Greedy window segmentation.  chain(p) = next[p] runs through every candidate that is a window
+// start, across all big groups: ONE chain over the whole array -- sequential, but like the seed
+// chunks it is a functional graph whose paths merge (window ends snap to the sparse "break"
+// positions).  One 1024-lane workgroup cuts the array into tiles, walks every tile speculatively
+// from its first candidate, then re-enters each tile at the previous tile's exit until no exit
+// moves, and only then marks the starts.  Exactly the reference's segmentation (GSAlign.cpp:326-338).
 #define WALK_T 1024
 #define WALK_MAXTILES 8192
-__global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__restrict__ a_gb, const i32 *__restrict__ brk, const i32 *__restrict__ next, i32 *ws)
+__global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, const i32 *__restrict__ next, i32 *ws)
 {
 	__shared__ i32 entry[WALK_MAXTILES], exit_[WALK_MAXTILES];
 	__shared__ int changed;
 	const int tid = threadIdx.x;
 	i64 ts = 256; while ((na + ts - 1) / ts > WALK_MAXTILES) ts <<= 1;
 	const int nt = (int)((na + ts - 1) / ts);
+	const i32 nC = candEx[na];
 	for (int t = tid; t < nt; t += WALK_T) {
-		const i64 b = (i64)t * ts, e = b + ts < na ? b + ts : na;
-		i64 p = b;
-		if (t > 0) while (p < e && !(a_gb[p] == p || brk[p])) p++;      // first candidate start in the tile (tile 0 starts at the true head 0)
-		entry[t] = (i32)p; exit_[t] = -1;                                // exit -1 = "must be (re)walked"
+		const i32 k = candEx[(i64)t * ts];                               // first candidate at or behind the tile start
+		entry[t] = k < nC ? clist[k] : (i32)na; exit_[t] = -1;           // exit -1 = "must be (re)walked"
 	}
 	__syncthreads();
 	for (;;) {
@@ -119,9 +134,7 @@ __global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__re
 			if (exit_[t] >= 0) continue;                                   // entry unchanged since the last walk
 			const i64 e = (i64)(t + 1) * ts < na ? (i64)(t + 1) * ts : na;
 			i64 p = entry[t];
-			// a speculative entry may sit on a non-candidate (next = -1): slide to the next candidate; positions
-			// on the true chain are always candidates, so this never changes a true path
-			while (p < e) { const i32 nx = next[p]; p = nx >= 0 ? nx : p + 1; }
+			while (p < e) { const i32 nx = next[p]; p = nx >= 0 ? nx : p + 1; }      // (entries and chain positions are candidates: nx >= 0)
 			exit_[t] = (i32)p;
 		}
 		if (tid == 0) changed = 0;
@@ -363,9 +376,12 @@ int stage2_chain(gsa_ctx *c)
 	RC(prim_exscan_i32(c, uniq, cuEx, (size_t)na + 1));
 	RC(prim_exscan_i32(c, brk, brkEx, (size_t)na + 1));
 	LAUNCH(k_scatter_idx, na, na, brk, brkEx, blist);
-	LAUNCH(k_next_window, na, na, c->a_q.as<i32>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, cuEx, brk, brkEx, blist, next);
-	GSA_CHECK(c, hipMemsetAsync(ws, 0, ((size_t)na + 1) * 4, st));
-	hipLaunchKernelGGL(k_walk_windows, dim3(1), dim3(WALK_T), 0, st, na, c->a_gb.as<i32>(), brk, next, ws);
+	i32 *candf = c->d_flag.as<i32>(), *candEx = c->d_scan.as<i32>(), *clist = c->a_runinfo.as<i32>();
+	LAUNCH(k_cand_flags, na + 1, na, c->a_gb.as<i32>(), c->a_ge.as<i32>(), cuEx, brk, candf, ws);
+	RC(prim_exscan_i32(c, candf, candEx, (size_t)na + 1));
+	LAUNCH(k_scatter_idx, na, na, candf, candEx, clist);
+	LAUNCH(k_next_window, na, na, c->a_q.as<i32>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, cuEx, brk, brkEx, blist, candf, candEx, clist, next);
+	hipLaunchKernelGGL(k_walk_windows, dim3(1), dim3(WALK_T), 0, st, na, candEx, clist, next, ws);
 	RC(prim_exscan_i32(c, ws, wsEx, (size_t)na + 1));
 	// C. outliers
 	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);
