@@ -52,7 +52,7 @@ int gsa_set_params(gsa_ctx *c, const gsa_params *p)
 	c->prm.MaxIndelSize = p->max_indel; c->prm.MinAlnBlockScore = p->min_block_score; c->prm.MinAlnLength = p->min_aln_len;
 	c->prm.MinSeqIdy = p->min_identity; c->prm.bSensitive = p->sensitive ? 1 : 0; c->prm.OneOnOne = p->one_on_one ? 1 : 0;
 	c->stage = 0;
-	return GSA_OK;
+	return build_presence(c);
 }
 
 int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa_ctx **out)
@@ -105,7 +105,7 @@ int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa
 	c->di.seq_len = idx->L2[4];
 	c->di.bwt = c->d_bwt.as<uint4>(); c->di.sa = c->d_sa.as<u64>(); c->di.ref = c->d_ref.as<uint8_t>(); c->di.G = idx->G;
 	c->di.chr_end = c->d_chr_end.as<i64>(); c->di.chr_of_end = c->d_chr_of_end.as<i32>(); c->di.n_ends = (i32)c->h_chr_end.size();
-	c->di.sa32 = nullptr; c->di.sa64 = nullptr; c->di.kmer = nullptr; c->di.kmer_k = 0; c->di.ref2 = nullptr;
+	c->di.sa32 = nullptr; c->di.sa64 = nullptr; c->di.kmer = nullptr; c->di.kmer_k = 0; c->di.ref2 = nullptr; c->di.pres = nullptr; c->di.pres_k = 0;
 	if (int rcd = build_dense_sa(c, idx->n_sa)) { g_create_error = c->err; gsa_destroy(c); return rcd; }
 	gsa_params dp; gsa_default_params(&dp);
 	int rc = gsa_set_params(c, prm ? prm : &dp);
@@ -120,7 +120,7 @@ void gsa_destroy(gsa_ctx *c)
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
 	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->d_query, &c->tmp, &c->d_cnt, &c->d_mail,
-		&c->d_sa_dense, &c->d_kmer, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
+		&c->d_sa_dense, &c->d_kmer, &c->d_pres, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
 		&c->d_flag, &c->d_scan, &c->g_beg, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
 		&c->a_next, &c->a_brk, &c->a_aurank, &c->a_aulist, &c->a_runinfo, &c->w_best, &c->w_sum, &c->w_n, &c->d_flag2, &c->d_scan2, &c->d_i64a,
 		&c->b_q, &c->b_len, &c->b_r, &c->b_gb, &c->b_ge, &c->c_q, &c->c_len, &c->c_r, &c->c_gb, &c->c_ge, &c->c_bid, &c->blk_beg, &c->blk_end, &c->blk_score,
@@ -239,6 +239,6 @@ int gsa_get_blocks(gsa_ctx *c, gsa_result *out)
 }
 
 int gsa_get_counters(gsa_ctx *c, uint64_t counters[8]) { if (!c) return GSA_ERR_ARG; memcpy(counters, c->counters, sizeof(c->counters)); return GSA_OK; }
-int gsa_get_timings(gsa_ctx *c, float ms[8]) { if (!c) return GSA_ERR_ARG; memcpy(ms, c->kernel_ms, sizeof(c->kernel_ms)); if (getenv("GSA_DEBUG")) fprintf(stderr, "[gsa] seed rounds max %llu, wave iters sum %llu max %llu\n", (unsigned long long)c->dbg[0], (unsigned long long)c->dbg[1], (unsigned long long)c->dbg[2]); return GSA_OK; }
+int gsa_get_timings(gsa_ctx *c, float ms[8]) { if (!c) return GSA_ERR_ARG; memcpy(ms, c->kernel_ms, sizeof(c->kernel_ms)); if (getenv("GSA_DEBUG")) fprintf(stderr, "[gsa] seed rounds max %llu, wave iters sum %llu max %llu; slowest chunk: round 1 %.1f us, resolver %.1f us, up to the marks %.1f us\n", (unsigned long long)c->dbg[0], (unsigned long long)c->dbg[1], (unsigned long long)c->dbg[2], c->dbg[3] * 0.01, c->dbg[4] * 0.01, c->dbg[5] * 0.01); return GSA_OK; }
 
 } // extern "C"

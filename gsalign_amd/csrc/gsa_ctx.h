@@ -38,7 +38,7 @@ struct gsa_ctx {
 	DevIndex di;
 	bool profiling = false;
 	bool count_blocks = false;                     // run the accounting build of the seed kernel (exact algorithmic Occ-block count)
-	u64 dbg[4] = {0, 0, 0, 0};
+	u64 dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	hipEvent_t ev[16];
 	float kernel_ms[8];
 	u64 counters[8];
@@ -65,6 +65,7 @@ struct gsa_ctx {
 	// ---- stage 1 ----
 	DevBuf d_ref2;                                 // 2-bit packed reference text
 	DevBuf d_kmer;                                 // top-of-tree jump table
+	DevBuf d_pres;                                 // MinSeedLength-mer presence bitmap
 	DevBuf d_sa_dense;                             // one SA entry per BWT row (built at gsa_create)
 	DevBuf d_cand_s, d_cand_len, d_cand_x0, d_cand_freq, d_onpath, d_cand_cnt;
 	size_t cand_cap_per_chunk = 1536;
@@ -139,6 +140,7 @@ template <class T> static inline T *pin_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 
 // stage drivers (one per translation unit)
 int build_dense_sa(gsa_ctx *c, u64 n_sa);   // k_seed.hip
+int build_presence(gsa_ctx *c);             // k_seed.hip  (after MinSeedLength changed)
 int stage1_seed(gsa_ctx *c);          // k_seed.hip
 int stage2_chain(gsa_ctx *c);         // k_chain.hip
 int stage2_fetch_host(gsa_ctx *c);    // k_chain.hip  (counts + S2 block table for the stage-2 view)

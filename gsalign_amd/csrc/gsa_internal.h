@@ -40,6 +40,8 @@ struct DevIndex {
 	i32 n_ends;
 	const u64 *kmer;        // k-mer -> (x0,x1,x2,0) after the first kmer_k bases, x2 = 0: absent (built at gsa_create)
 	i32 kmer_k;
+	const u32 *pres;        // presence bitmap of all pres_k-mers of the text (pres_k = min(MinSeedLength, 16)); rebuilt by gsa_set_params
+	i32 pres_k;
 };
 
 struct DevBuf {

@@ -72,6 +72,9 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	__shared__ uint16_t mblk[COUNT ? GSA_CHUNK : 1];   // Occ blocks the search from s read (accounting build only)
 	__shared__ u32 bits[PATH_WORDS];
 	__shared__ uint16_t entry_of[NSUB], exit_of[NSUB];
+	__shared__ uint16_t pend_it[SEED_WG];                       // sub-ranges to walk for real in this pass
+	__shared__ uint16_t jmp[2][NSUB], walked_from[NSUB];        // pointer-jumping buffers; entry of the last real walk of a re-walked sub-range
+	__shared__ u32 rewalked[NSUB / 32], onchain[NSUB / 32], s_npend;
 	const int chunk = blockIdx.x, j = threadIdx.x;
 	const i64 c0 = (i64)chunk * GSA_CHUNK;
 	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
@@ -97,13 +100,16 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	}
 	for (int p = j; p < clen; p += SEED_WG) memo[p] = 0;
 	for (int p = j; p < PATH_WORDS; p += SEED_WG) bits[p] = 0;
-	if (j == 0) { s_ncand = 0; s_queue = 0; s_hits = 0; }
+	if (j == 0) { s_ncand = 0; s_queue = 0; s_hits = 0; s_npend = 0; }
+	if (j < NSUB / 32) rewalked[j] = 0;
 	const size_t cbase = (size_t)chunk * cand_cap;      // this chunk's private candidate segment
 	const int S = (clen + NSUB - 1) / NSUB;             // sub-range length (>= 1)
 	const int nitems = (clen + S - 1) / S;
 	for (int it = j; it < nitems; it += SEED_WG) entry_of[it] = (uint16_t)(it * S);
 	u32 all_blocks = 0, rounds = 0, iters = 0;
-	u32 dirty = 0;                                      // rounds >= 2: bit k = my k-th static item (j + k*SEED_WG) must be re-walked
+	unsigned long long t_begin = wall_clock64(), t_round0 = 0, t_resolve = 0, t_stage = 0;
+	u32 dirty = 0;                                      // rounds >= 2: this lane has one sub-range (fb_item) to walk for real
+	int fb_item = 0;
 	__syncthreads();
 	for (;;) {
 		// One flat loop per wave.  Every iteration each lane has exactly ONE memory request pending
@@ -111,7 +117,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		// lanes issue their requests together, wait once, then consume by mode -- so lanes that are in
 		// different searches, or in different phases of a search, never serialise on each other's
 		// memory latency.
-		int item = -1, s = 0, bend = 0, pos = 0, mode = M_ADV; u32 kid = 0;
+		int item = -1, s = 0, bend = 0, pos = 0, mode = M_ADV; u32 kid = 0, pid = 0;
 		FmIntv ik = {0, 0, 0}; u32 blk = 0; i64 tp = 0;
 		bool need_item = true;
 		while (!__all(mode == M_DONE)) {
@@ -128,13 +134,18 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 			const u32 r0 = pt[0], r1 = pt[1], r2 = pt[2];
 			const ulonglong2 *pe = (const ulonglong2 *)((di.kmer ? di.kmer : (const u64 *)di.bwt) + (mode == M_KMER ? ((size_t)kid << 2) : 0));
 			const ulonglong2 e0 = pe[0], e1 = pe[1];
+			const u32 pw = di.pres ? di.pres[mode == M_KMER ? (pid >> 5) : 0] : ~0u;
 			const u64 sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
 			// ---- consume phase: straight-line, one predicated block per mode ----
 			bool ended = false;
 			if (mode == M_KMER) {
-				const bool hit = e1.x != 0;             // absent k-mer: the match is shorter than k, walk it base by base
-				if (hit) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; }
-				mode = (hit && ik.x2 == 1) ? M_LOC : M_FM;
+				if (!((pw >> (pid & 31)) & 1u)) {       // the first MinSeedLength bases do not occur: no seed here, next start s+1
+					memo[s] = 1; s += 1; mode = M_ADV;
+				} else {
+					const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k, walk it base by base
+					if (hit) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; }
+					mode = (hit && ik.x2 == 1) ? M_LOC : M_FM;
+				}
 			} else if (mode == M_LOC) {
 				tp = (i64)sav + (pos - s); mode = M_TEXT;
 			} else if (mode == M_TEXT) {
@@ -162,45 +173,81 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 			}
 			// ---- advance: ONE step per iteration (no inner loop): take an item / hop over a memoised or
 			// ambiguous position / open the next search ----
-			if (mode == M_ADV) {
+			// (a few steps per iteration: hops over memoised / ambiguous positions cost no memory access)
+			for (int step = 0; step < 4 && mode == M_ADV; step++) {
 				if (need_item) {
 					if (rounds == 0) { const u32 it_ = atomicAdd(&s_queue, 1u); item = it_ < (u32)nitems ? (int)it_ : -1; }
-					else if (dirty) { const int k_ = __ffs((int)dirty) - 1; dirty &= dirty - 1; item = j + k_ * SEED_WG; }
+					else if (dirty) { dirty = 0; item = fb_item; }
 					else item = -1;
 					need_item = false;
-					if (item < 0) mode = M_DONE;
-					else { s = entry_of[item]; bend = (item + 1) * S < clen ? (item + 1) * S : clen; }
+					if (item < 0) { mode = M_DONE; break; }
+					s = entry_of[item]; bend = (item + 1) * S < clen ? (item + 1) * S : clen;
 				}
-				if (mode == M_ADV) {
-					if (s >= bend) { exit_of[item] = (uint16_t)s; need_item = true; }
-					else {
-						const int m_ = memo[s];
-						if (m_) s += m_;
-						else if (q_isn(qn, s)) { memo[s] = 1; if (COUNT) mblk[s] = 0; s += 1; }
-						else {
-							ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
-							if (!COUNT && di.kmer_k > 1 && s + di.kmer_k <= clen && (q_nbits32(qn, s) & ((1u << di.kmer_k) - 1)) == 0) {
-								kid = (u32)q_bits64(qp, s) & ((1u << (2 * di.kmer_k)) - 1); mode = M_KMER;
-							}
-						}
+				if (s >= bend) { exit_of[item] = (uint16_t)s; need_item = true; continue; }
+				const int m_ = memo[s];
+				if (m_) { s += m_; continue; }
+				const u32 nb = q_nbits32(qn, s);
+				const int L = prm.MinSeedLength < 32 ? prm.MinSeedLength : 32;
+				if (nb & 1u) { memo[s] = 1; if (COUNT) mblk[s] = 0; s += 1; }
+				else if (!COUNT && (s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0)) { memo[s] = 1; s += 1; }      // cannot reach MinSeedLength
+				else {
+					ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
+					if (!COUNT && di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
+						const u64 qb = q_bits64(qp, s);
+						kid = (u32)qb & ((1u << (2 * di.kmer_k)) - 1); mode = M_KMER;
+						pid = di.pres_k ? (u32)(qb & ((1ull << (2 * di.pres_k)) - 1)) : 0;
 					}
 				}
 			}
 		}
 		rounds++;
-		if (j == 0) changed = 0;
 		__syncthreads();
-		// true entry of every sub-range = exit of the one before it
-		dirty = 0;
-		for (int k = 0, it = j; it < nitems; k++, it += SEED_WG) {
-			const int ne = it ? exit_of[it - 1] : 0;
-			if (ne != entry_of[it]) dirty |= 1u << k;
+		if (rounds == 1) t_round0 = wall_clock64() - t_begin;
+		const unsigned long long t_r0 = wall_clock64();
+		// True entries.  A walk that enters sub-range `it` on a memoised position leaves it at exit_of[it]
+		// wherever it entered (all walks inside a sub-range merge), so at sub-range level the true chain is
+		// the orbit of 0 under it -> exit_of[it] / S: found by pointer jumping (log2 NSUB parallel rounds in
+		// LDS), the true entry of an on-chain sub-range being its predecessor's exit.  In round 1 only
+		// `it`'s own walk wrote memo[] inside `it`, so an entry e with memo[e] != 0 lies on that walk.  An
+		// entry the speculation never visited (a random >= MinSeedLength match made the speculative walk
+		// jump over it) needs a real walk: such sub-ranges are collected, ASSUMED to keep their exit, walked
+		// in parallel (one lane each) in another pass of the loop above, and the chain is resolved again.
+		for (int it = j; it < nitems; it += SEED_WG) { const int X = exit_of[it]; jmp[0][it] = (uint16_t)(X >= clen ? 0xffff : X / S); }
+		if (j < NSUB / 32) onchain[j] = j == 0 ? 1u : 0u;
+		if (j == 0) s_npend = 0;
+		__syncthreads();
+		int cur = 0;
+		for (int span = 1; span < nitems; span <<= 1) {
+			for (int it = j; it < nitems; it += SEED_WG) {
+				const int t = jmp[cur][it];
+				if (t != 0xffff) {
+					if ((onchain[it >> 5] >> (it & 31)) & 1u) atomicOr(&onchain[t >> 5], 1u << (t & 31));
+					jmp[cur ^ 1][it] = jmp[cur][t];
+				} else jmp[cur ^ 1][it] = 0xffff;
+			}
+			__syncthreads();
+			cur ^= 1;
+		}
+		for (int it = j; it < nitems; it += SEED_WG) entry_of[it] = (uint16_t)(it ? clen : 0);      // off-chain: nothing to mark
+		__syncthreads();
+		for (int it = j; it < nitems; it += SEED_WG)
+			if ((onchain[it >> 5] >> (it & 31)) & 1u) { const int X = exit_of[it]; if (X < clen) entry_of[X / S] = (uint16_t)X; }
+		__syncthreads();
+		for (int it = j; it < nitems; it += SEED_WG) {
+			if (!((onchain[it >> 5] >> (it & 31)) & 1u)) continue;
+			const int e = entry_of[it];
+			const bool known = ((rewalked[it >> 5] >> (it & 31)) & 1u) ? e == walked_from[it] : memo[e] != 0;
+			if (!known) {
+				const u32 idx = atomicAdd(&s_npend, 1u);
+				if (idx < SEED_WG) { pend_it[idx] = (uint16_t)it; walked_from[it] = (uint16_t)e; atomicOr(&rewalked[it >> 5], 1u << (it & 31)); }
+			}
 		}
 		__syncthreads();
-		for (int k = 0, it = j; it < nitems; k++, it += SEED_WG)
-			if (dirty & (1u << k)) { entry_of[it] = it ? exit_of[it - 1] : 0; changed = 1; }
+		if (j == 0) { if (s_npend > SEED_WG) s_npend = SEED_WG; changed = s_npend > 0 ? 1 : 0; }
 		__syncthreads();
+		t_resolve += wall_clock64() - t_r0;
 		const int again = changed;
+		if (again && j < (int)s_npend) { fb_item = pend_it[j]; dirty = 1; }
 		__syncthreads();
 		if (!again) break;
 	}
@@ -217,7 +264,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		atomicAdd((unsigned long long *)&cnt[12], (unsigned long long)iters);
 		atomicMax((unsigned long long *)&cnt[13], (unsigned long long)iters);
 	}
-	if (j == 0) atomicMax((unsigned long long *)&cnt[11], (unsigned long long)rounds);
+	if (j == 0) { atomicMax((unsigned long long *)&cnt[11], (unsigned long long)rounds); atomicMax((unsigned long long *)&cnt[14], t_round0); atomicMax((unsigned long long *)&cnt[15], t_resolve); atomicMax((unsigned long long *)&cnt[7], wall_clock64() - t_begin); }
 	__syncthreads();
 	for (int p = j; p < PATH_WORDS; p += SEED_WG) onpath[(size_t)chunk * PATH_WORDS + p] = bits[p];
 	// how many located hits will this chunk contribute (so that the select kernel needs no global atomic)
@@ -332,6 +379,35 @@ __global__ void __launch_bounds__(256) k_pack_ref(const uint8_t *__restrict__ re
 	out[w] = v;
 }
 
+// Presence bitmap: bit id is set iff the pres_k-mer id (same packing as the query in LDS) occurs in the
+// indexed text.  BWT_Search from s reaches MinSeedLength iff the first MinSeedLength bases occur, so an
+// absent pres_k-mer (pres_k <= MinSeedLength) settles a search that yields no seed with ONE read.
+__global__ void __launch_bounds__(256) k_build_pres(const u32 *__restrict__ ref2, u64 seq_len, int k, u32 *bm)
+{
+	const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p + (u64)k > seq_len) return;
+	const u64 w = p >> 4;
+	const u32 id = (u32)(funnel64(ref2[w], ref2[w + 1], ref2[w + 2], (int)(p & 15) << 1) & ((1ull << (2 * k)) - 1));
+	atomicOr(&bm[id >> 5], 1u << (id & 31));
+}
+
+int build_presence(gsa_ctx *c)
+{
+	if (!c->di.ref2) return GSA_OK;                       // (gsa_create sets the parameters after the index is up)
+	int k = c->prm.MinSeedLength < 16 ? c->prm.MinSeedLength : 16;
+	if (k == c->di.pres_k && c->di.pres) return GSA_OK;
+	c->di.pres = nullptr; c->di.pres_k = 0;
+	if (k < 8) return GSA_OK;                             // short seeds: nearly every k-mer present, nothing to gain
+	const size_t words = ((size_t)1 << (2 * k)) / 32;
+	if (!dev_ensure<u32>(c, c->d_pres, words)) return GSA_ERR_NOMEM;
+	GSA_CHECK(c, hipMemsetAsync(c->d_pres.p, 0, words * 4, c->stream));
+	hipLaunchKernelGGL(k_build_pres, dim3(grid_for(c->di.seq_len, 256)), dim3(256), 0, c->stream, c->di.ref2, c->di.seq_len, k, c->d_pres.as<u32>());
+	GSA_CHECK(c, hipGetLastError());
+	GSA_CHECK(c, hipStreamSynchronize(c->stream));
+	c->di.pres = c->d_pres.as<u32>(); c->di.pres_k = k;
+	return GSA_OK;
+}
+
 int build_dense_sa(gsa_ctx *c, u64 n_sa)
 {
 	{
@@ -407,7 +483,7 @@ int stage1_seed(gsa_ctx *c)
 	}
 	if (c->profiling) hipEventRecord(c->ev[2], st);
 	c->counters[0] = c->h_cnt[CNT_OCCBLK]; c->counters[1] = 0; c->counters[2] = (u64)n_hits; c->counters[3] = (u64)n_hits; c->counters[7] = c->h_cnt[CNT_OCCBLK_ALL];
-	c->dbg[0] = c->h_cnt[11]; c->dbg[1] = c->h_cnt[12]; c->dbg[2] = c->h_cnt[13];
+	c->dbg[0] = c->h_cnt[11]; c->dbg[1] = c->h_cnt[12]; c->dbg[2] = c->h_cnt[13]; c->dbg[3] = c->h_cnt[14]; c->dbg[4] = c->h_cnt[15]; c->dbg[5] = c->h_cnt[7];
 	c->n_seeds = n_hits;
 	if (n_hits == 0) { if (c->profiling) { GSA_CHECK(c, hipStreamSynchronize(st)); float ms; hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms; } return GSA_OK; }
 	if (n_hits >= (1ll << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");
