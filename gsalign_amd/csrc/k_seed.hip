@@ -144,7 +144,8 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 				} else {
 					const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k, walk it base by base
 					if (hit) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; }
-					mode = (hit && ik.x2 == 1) ? M_LOC : M_FM;
+					mode = M_FM;
+					if (hit && ik.x2 == 1) { tp = (i64)(e1.y - 1) + di.kmer_k; mode = M_TEXT; }      // unique: straight to the text comparison
 				}
 			} else if (mode == M_LOC) {
 				tp = (i64)sav + (pos - s); mode = M_TEXT;
@@ -357,7 +358,8 @@ __global__ void __launch_bounds__(256) k_densify_sa(DevIndex di, u64 n_sa, u32 *
 }
 
 // k-mer jump table: entry id = the interval BWT_Search holds after matching the k bases of id
-// (first base in the top bits); x2 = 0 when the walk dies earlier (then the stepwise walk is used).
+// (base t in bits 2t..2t+1); x2 = 0 when the walk dies earlier (then the stepwise walk is used).
+// Needs the dense SA (unique k-mers carry their text position).
 __global__ void __launch_bounds__(256) k_build_kmer(DevIndex di, int k, u64 *tab)
 {
 	const u32 id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,7 +368,8 @@ __global__ void __launch_bounds__(256) k_build_kmer(DevIndex di, int k, u64 *tab
 	u32 blk = 0; bool alive = true;
 	for (int t = 1; t < k && alive; t++) alive = fm_extend(di, ik, (int)((id >> (2 * t)) & 3), blk);
 	u64 *e = tab + ((size_t)id << 2);
-	e[0] = ik.x0; e[1] = ik.x1; e[2] = alive ? ik.x2 : 0; e[3] = 0;
+	e[0] = ik.x0; e[1] = ik.x1; e[2] = alive ? ik.x2 : 0;
+	e[3] = (alive && ik.x2 == 1) ? fm_locate(di, ik.x0) + 1 : 0;          // unique k-mer: where it is in the text (+1; saves the SA read)
 }
 
 // 2-bit packed copy of RefSequence (16 bases per word, LSB first) for the unique-interval text comparison
@@ -417,10 +420,18 @@ int build_dense_sa(gsa_ctx *c, u64 n_sa)
 		GSA_CHECK(c, hipGetLastError());
 		c->di.ref2 = c->d_ref2.as<u32>();
 	}
+	const u64 rows = c->di.seq_len + 1;
+	const bool use32 = c->di.seq_len < 0xFFFFFFF0ull;
+	if (use32) { if (!dev_ensure<u32>(c, c->d_sa_dense, rows + 32)) return GSA_ERR_NOMEM; c->di.sa32 = c->d_sa_dense.as<u32>(); c->di.sa64 = nullptr; }
+	else { if (!dev_ensure<u64>(c, c->d_sa_dense, rows + 32)) return GSA_ERR_NOMEM; c->di.sa64 = c->d_sa_dense.as<u64>(); c->di.sa32 = nullptr; }
+	hipLaunchKernelGGL(k_densify_sa, dim3(grid_for(n_sa, 256)), dim3(256), 0, c->stream, c->di, n_sa, (u32 *)c->di.sa32, (u64 *)c->di.sa64);
+	GSA_CHECK(c, hipGetLastError());
+	GSA_CHECK(c, hipStreamSynchronize(c->stream));
 	{
-		// k = floor(log4(2G)) - 1, capped: about 1/4 of the k-mers absent at most, table <= 512 MiB
-		int k = 0; while ((1ull << (2 * (k + 1))) <= c->di.seq_len) k++;
-		k -= 1; if (k > 12) k = 12;
+		// k = ceil(log4(2G)) + 1, capped at 14 (8 GiB of 288): most k-mers that occur are unique, so a search is
+		// table -> text comparison with no stepwise Occ walk in between
+		int k = 0; while ((1ull << (2 * k)) < c->di.seq_len) k++;
+		k += 1; if (k > 14) k = 14;
 		if (k >= 2) {
 			const size_t n = (size_t)1 << (2 * k);
 			if (!dev_ensure<u64>(c, c->d_kmer, n * 4)) return GSA_ERR_NOMEM;
@@ -430,13 +441,6 @@ int build_dense_sa(gsa_ctx *c, u64 n_sa)
 			c->di.kmer = c->d_kmer.as<u64>(); c->di.kmer_k = k;
 		}
 	}
-	const u64 rows = c->di.seq_len + 1;
-	const bool use32 = c->di.seq_len < 0xFFFFFFF0ull;
-	if (use32) { if (!dev_ensure<u32>(c, c->d_sa_dense, rows + 32)) return GSA_ERR_NOMEM; c->di.sa32 = c->d_sa_dense.as<u32>(); c->di.sa64 = nullptr; }
-	else { if (!dev_ensure<u64>(c, c->d_sa_dense, rows + 32)) return GSA_ERR_NOMEM; c->di.sa64 = c->d_sa_dense.as<u64>(); c->di.sa32 = nullptr; }
-	hipLaunchKernelGGL(k_densify_sa, dim3(grid_for(n_sa, 256)), dim3(256), 0, c->stream, c->di, n_sa, (u32 *)c->di.sa32, (u64 *)c->di.sa64);
-	GSA_CHECK(c, hipGetLastError());
-	GSA_CHECK(c, hipStreamSynchronize(c->stream));
 	return GSA_OK;
 }
 
