@@ -105,7 +105,7 @@ int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa
 	c->di.seq_len = idx->L2[4];
 	c->di.bwt = c->d_bwt.as<uint4>(); c->di.sa = c->d_sa.as<u64>(); c->di.ref = c->d_ref.as<uint8_t>(); c->di.G = idx->G;
 	c->di.chr_end = c->d_chr_end.as<i64>(); c->di.chr_of_end = c->d_chr_of_end.as<i32>(); c->di.n_ends = (i32)c->h_chr_end.size();
-	c->di.sa32 = nullptr; c->di.sa64 = nullptr; c->di.kmer = nullptr; c->di.kmer_k = 0; c->di.ref2 = nullptr; c->di.pres = nullptr; c->di.pres_k = 0;
+	c->di.sa32 = nullptr; c->di.sa64 = nullptr; c->di.kmer = nullptr; c->di.kmer_k = 0; c->di.kmer_e16 = 0; c->di.ref2 = nullptr; c->di.pres = nullptr; c->di.pres_k = 0;
 	if (int rcd = build_dense_sa(c, idx->n_sa)) { g_create_error = c->err; gsa_destroy(c); return rcd; }
 	gsa_params dp; gsa_default_params(&dp);
 	int rc = gsa_set_params(c, prm ? prm : &dp);

@@ -38,7 +38,9 @@ struct DevIndex {
 	const i64 *chr_end;     // 2*n_chr sorted last coordinates (ChrLocMap keys)
 	const i32 *chr_of_end;  // chromosome index per entry (ChrLocMap values)
 	i32 n_ends;
-	const u64 *kmer;        // k-mer -> (x0,x1,x2,0) after the first kmer_k bases, x2 = 0: absent (built at gsa_create)
+	const u64 *kmer;        // k-mer -> (x0,x1,x2,loc+1) after the first kmer_k bases, x2 = 0: absent (built at gsa_create);
+	                        // four u32 per entry when kmer_e16 (text < 2^32), else four u64
+	i32 kmer_e16;
 	i32 kmer_k;
 	const u32 *pres;        // presence bitmap of all pres_k-mers of the text (pres_k = min(MinSeedLength, 16)); rebuilt by gsa_set_params
 	i32 pres_k;

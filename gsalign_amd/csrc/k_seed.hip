@@ -61,7 +61,7 @@ __device__ __forceinline__ int text_match32(u32 r0, u32 r1, u32 r2, i64 tp, i64 
 // matches become seeds.  Query (2-bit packed + N bitmap), memo, exits and on-path
 // bits live in LDS.
 // ---------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool E16>
 __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits)
 {
@@ -130,10 +130,18 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 				kk = kn ? 0 : k - (k >= di.primary); ll = ln ? 0 : l - (l >= di.primary);
 			}
 			const FmBlock bk = fm_load(di.bwt, kk >> 7), bl = fm_load(di.bwt, ll >> 7);
-			const u32 *pt = di.ref2 + (mode == M_TEXT ? (tp >> 4) : 0);
-			const u32 r0 = pt[0], r1 = pt[1], r2 = pt[2];
-			const ulonglong2 *pe = (const ulonglong2 *)((di.kmer ? di.kmer : (const u64 *)di.bwt) + (mode == M_KMER ? ((size_t)kid << 2) : 0));
-			const ulonglong2 e0 = pe[0], e1 = pe[1];
+			struct __attribute__((packed, aligned(4))) W3 { u32 a, b, c; };
+			const W3 w3 = *(const W3 *)(di.ref2 + (mode == M_TEXT ? (tp >> 4) : 0));      // 12 bytes of packed text, one access
+			const u32 r0 = w3.a, r1 = w3.b, r2 = w3.c;
+			// one k-mer table entry: 16 bytes (one load) when the text is below 2^32, else 32
+			ulonglong2 e0 = {0, 0}, e1 = {0, 0};
+			if (E16) {
+				const uint4 e = ((const uint4 *)(di.kmer ? di.kmer : (const u64 *)di.bwt))[mode == M_KMER ? kid : 0];
+				e0.x = e.x; e0.y = e.y; e1.x = e.z; e1.y = e.w;
+			} else {
+				const ulonglong2 *pe = (const ulonglong2 *)((di.kmer ? di.kmer : (const u64 *)di.bwt) + (mode == M_KMER ? ((size_t)kid << 2) : 0));
+				e0 = pe[0]; e1 = pe[1];
+			}
 			const u32 pw = di.pres ? di.pres[mode == M_KMER ? (pid >> 5) : 0] : ~0u;
 			const u64 sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
 			// ---- consume phase: straight-line, one predicated block per mode ----
@@ -360,16 +368,17 @@ __global__ void __launch_bounds__(256) k_densify_sa(DevIndex di, u64 n_sa, u32 *
 // k-mer jump table: entry id = the interval BWT_Search holds after matching the k bases of id
 // (base t in bits 2t..2t+1); x2 = 0 when the walk dies earlier (then the stepwise walk is used).
 // Needs the dense SA (unique k-mers carry their text position).
-__global__ void __launch_bounds__(256) k_build_kmer(DevIndex di, int k, u64 *tab)
+__global__ void __launch_bounds__(256) k_build_kmer(DevIndex di, int k, u64 *tab, int e16)
 {
 	const u32 id = blockIdx.x * blockDim.x + threadIdx.x;
 	if (id >= (1u << (2 * k))) return;
 	FmIntv ik = fm_init(di, (int)(id & 3));                  // base t of the k-mer = bits 2t..2t+1 (same packing as the query in LDS)
 	u32 blk = 0; bool alive = true;
 	for (int t = 1; t < k && alive; t++) alive = fm_extend(di, ik, (int)((id >> (2 * t)) & 3), blk);
+	const u64 loc1 = (alive && ik.x2 == 1) ? fm_locate(di, ik.x0) + 1 : 0;      // unique k-mer: where it is in the text (+1; saves the SA read)
+	if (e16) { ((uint4 *)tab)[id] = make_uint4((u32)ik.x0, (u32)ik.x1, alive ? (u32)ik.x2 : 0u, (u32)loc1); return; }
 	u64 *e = tab + ((size_t)id << 2);
-	e[0] = ik.x0; e[1] = ik.x1; e[2] = alive ? ik.x2 : 0;
-	e[3] = (alive && ik.x2 == 1) ? fm_locate(di, ik.x0) + 1 : 0;          // unique k-mer: where it is in the text (+1; saves the SA read)
+	e[0] = ik.x0; e[1] = ik.x1; e[2] = alive ? ik.x2 : 0; e[3] = loc1;
 }
 
 // 2-bit packed copy of RefSequence (16 bases per word, LSB first) for the unique-interval text comparison
@@ -434,8 +443,10 @@ int build_dense_sa(gsa_ctx *c, u64 n_sa)
 		k += 1; if (k > 14) k = 14;
 		if (k >= 2) {
 			const size_t n = (size_t)1 << (2 * k);
-			if (!dev_ensure<u64>(c, c->d_kmer, n * 4)) return GSA_ERR_NOMEM;
-			hipLaunchKernelGGL(k_build_kmer, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->di, k, c->d_kmer.as<u64>());
+			const int e16 = c->di.seq_len < 0xFFFFFFF0ull ? 1 : 0;
+			if (!dev_ensure<u64>(c, c->d_kmer, e16 ? n * 2 : n * 4)) return GSA_ERR_NOMEM;
+			hipLaunchKernelGGL(k_build_kmer, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->di, k, c->d_kmer.as<u64>(), e16);
+			c->di.kmer_e16 = e16;
 			GSA_CHECK(c, hipGetLastError());
 			GSA_CHECK(c, hipStreamSynchronize(c->stream));
 			c->di.kmer = c->d_kmer.as<u64>(); c->di.kmer_k = k;
@@ -463,10 +474,12 @@ int stage1_seed(gsa_ctx *c)
 		GSA_CHECK(c, hipMemsetAsync(c->d_chunk_hits.as<i32>() + n_chunks, 0, sizeof(i32), st));
 		if (c->profiling) hipEventRecord(c->ev[0], st);
 		if (c->count_blocks)
-			hipLaunchKernelGGL(k_seed_wg<true>, dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
+			hipLaunchKernelGGL((k_seed_wg<true, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
 			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>());
 		else
-			hipLaunchKernelGGL(k_seed_wg<false>, dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
+			if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
+			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>());
+			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
 			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>());
 		if (c->profiling) hipEventRecord(c->ev[1], st);
 		int rcs = prim_exscan_i32(c, c->d_chunk_hits.as<i32>(), c->d_chunk_base.as<i32>(), (size_t)n_chunks + 1);
