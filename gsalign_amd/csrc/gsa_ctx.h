@@ -18,7 +18,7 @@ struct Leaf {
 
 // Device "mailbox" (i32[MAIL_N]) of the counts the stages produce; the host reads the whole
 // box in ONE pinned copy where it needs them instead of one read-back per count.
-enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_ANY = 8, MAIL_N = 64 };
+enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_TICKET = 48, M_NBRAW = 49, MAIL_N = 64 };
 #define LEAF_CHUNK 1024      // leaves copied together with the mailbox (more -> a second copy)
 
 struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf range
@@ -58,6 +58,7 @@ struct gsa_ctx {
 	// device counters block (u64[16]) + pinned host mirror
 	DevBuf d_cnt; u64 *h_cnt = nullptr;
 	DevBuf d_mail; i32 *h_mail = nullptr;          // count mailbox + pinned mirror
+	DevBuf d_lb_status[2]; u32 lb_epoch = 0, lb_base = 0;   // look-back scan state (gsa_scan.h); the ticket counter sits in the mailbox
 	DevBuf p_leaf;                                 // pinned landing zone for the leaf table
 	int ev_pending = 0;                            // bit0: stage-1 events, bit1: stage-2 events not yet read
 	bool s2_host = false;                          // n_b/n_c/n_blocks2/h_blk_* fetched for the stage-2 view

@@ -1,0 +1,147 @@
+// gsalign_amd/csrc/gsa_scan.h -- single-pass "flag -> exclusive scan -> emit" kernels.
+//
+// The chaining / refinement / extension stages are long chains of tiny data-parallel
+// passes (compute a flag per element, prefix-sum it, scatter by the result).  As
+// separate launches every link costs a dependent dispatch (4-5 us on MI355X, more
+// than its work at bacterial sizes), so each flag + scan + scatter triple is ONE
+// launch here: a decoupled look-back scan (Merrill & Garland) whose tile status words
+// travel through HBM as self-validating 64-bit words {epoch, flag, value} with
+// agent-scope relaxed atomics -- the same hand-off as the DP boundary granules: no
+// fence, no re-initialisation between launches (the epoch invalidates old words).
+// Tiles take their number from a ticket counter in dispatch order, so a tile only
+// ever waits for tiles that are already running.
+#ifndef GSA_SCAN_H
+#define GSA_SCAN_H
+#include "gsa_ctx.h"
+
+#define LB_TPB 256
+#define LB_ITEMS 4
+#define LB_TILE (LB_TPB * LB_ITEMS)
+
+struct LbArgs {
+	unsigned long long *status[2];   // tile status words, one array per scanned component
+	u32 *ticket;                     // never reset: tile = ticket - base
+	u32 base, epoch;
+	i32 *err;                        // set when a spin runs into its bound (a bug, not a state)
+};
+
+__device__ __forceinline__ unsigned long long lb_pack(u32 epoch, u32 flag, u32 val) { return ((unsigned long long)(epoch & 0x3fffffffu) << 34) | ((unsigned long long)flag << 32) | val; }
+
+// exclusive prefix of tile `tile` for one component; agg = the tile's total (same in all threads).
+// Must be called by every thread of the workgroup.
+__device__ __forceinline__ i32 lb_tile_prefix(const LbArgs &lb, int comp, int tile, i32 agg, i32 *s_bcast)
+{
+	unsigned long long *st = lb.status[comp];
+	const int tid = threadIdx.x, lane = tid & 63;
+	const u32 ep = lb.epoch & 0x3fffffffu;
+	if (tile == 0) {
+		if (tid == 0) { __hip_atomic_store(&st[0], lb_pack(ep, 2, (u32)agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_bcast[comp] = 0; }
+	} else if (tid < 64) {
+		if (lane == 0) __hip_atomic_store(&st[tile], lb_pack(ep, 1, (u32)agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		i32 excl = 0;
+		for (int base = tile - 1;; base -= 64) {
+			const int idx = base - lane;
+			unsigned long long w = lb_pack(ep, 2, 0);                    // tiles before tile 0: prefix 0
+			u32 spins = 0;
+			for (;;) {
+				if (idx >= 0) w = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (!__any((u32)(w >> 34) != ep || ((w >> 32) & 3) == 0)) break;
+				if (++spins > (1u << 22)) { if (lane == 0) *lb.err = 1; w = lb_pack(ep, 2, 0); break; }
+				__builtin_amdgcn_s_sleep(1);
+			}
+			const unsigned long long pm = __ballot(((w >> 32) & 3) == 2);
+			const int first = pm ? __ffsll((long long)pm) - 1 : 64;      // nearest predecessor that already knows its inclusive prefix
+			i32 v = lane <= first ? (i32)(u32)w : 0;
+			for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+			excl += v;
+			if (pm) break;
+		}
+		if (lane == 0) { __hip_atomic_store(&st[tile], lb_pack(ep, 2, (u32)(excl + agg)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_bcast[comp] = excl; }
+	}
+	__syncthreads();
+	return s_bcast[comp];
+}
+
+// Generic fused pass over i in [0, n):  v = op.value(i, k)  (NV components, k < NV),
+// ex = exclusive prefix sums, then op.emit(i, v, ex);  op.done(totals) once, by the thread
+// that owns the last element (or thread 0 of tile 0 when n == 0).
+template <int NV, class Op>
+__global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
+{
+	__shared__ i32 s_tile, s_bcast[2], s_wsum[2][LB_TPB / 64];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (tid == 0) s_tile = (i32)(atomicAdd(lb.ticket, 1u) - lb.base);
+	__syncthreads();
+	const int tile = s_tile;
+	const i64 i0 = (i64)tile * LB_TILE + (i64)tid * LB_ITEMS;
+	i32 v[NV][LB_ITEMS], tsum[NV];
+#pragma unroll
+	for (int c = 0; c < NV; c++) tsum[c] = 0;
+#pragma unroll
+	for (int k = 0; k < LB_ITEMS; k++) {
+		const i64 i = i0 + k;
+#pragma unroll
+		for (int c = 0; c < NV; c++) { v[c][k] = i < n ? op.value(i, c) : 0; tsum[c] += v[c][k]; }
+	}
+	// thread totals -> exclusive offsets inside the tile
+	i32 toff[NV], agg[NV];
+#pragma unroll
+	for (int c = 0; c < NV; c++) {
+		i32 inc = tsum[c];
+		for (int o = 1; o < 64; o <<= 1) { const i32 t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+		if (lane == 63) s_wsum[c][wv] = inc;
+		toff[c] = inc - tsum[c];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int c = 0; c < NV; c++) {
+		i32 wo = 0, tot = 0;
+#pragma unroll
+		for (int w = 0; w < LB_TPB / 64; w++) { const i32 s = s_wsum[c][w]; if (w < wv) wo += s; tot += s; }
+		toff[c] += wo; agg[c] = tot;
+	}
+	i32 pre[NV];
+#pragma unroll
+	for (int c = 0; c < NV; c++) pre[c] = lb_tile_prefix(lb, c, tile, agg[c], s_bcast);
+#pragma unroll
+	for (int c = 0; c < NV; c++) toff[c] += pre[c];
+	i32 vv[NV], ee[NV];
+#pragma unroll
+	for (int k = 0; k < LB_ITEMS; k++) {
+		const i64 i = i0 + k;
+#pragma unroll
+		for (int c = 0; c < NV; c++) { vv[c] = v[c][k]; ee[c] = toff[c]; toff[c] += v[c][k]; }
+		if (i < n) {
+			op.emit(i, vv, ee);
+			if (i == n - 1) { i32 tt[NV]; for (int c = 0; c < NV; c++) tt[c] = ee[c] + vv[c]; op.done(tt); }
+		}
+	}
+	if (n == 0 && tile == 0 && tid == 0) { i32 tt[NV]; for (int c = 0; c < NV; c++) tt[c] = 0; op.done(tt); }
+}
+
+// host side: one fused pass on the context's stream
+template <int NV, class Op>
+static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op)
+{
+	const size_t tiles = n > 0 ? (size_t)((n + LB_TILE - 1) / LB_TILE) : 1;
+	for (int k = 0; k < 2; k++) {
+		if (c->d_lb_status[k].cap < tiles * 8) {
+			if (!dev_ensure<unsigned long long>(c, c->d_lb_status[k], tiles + 1024)) return GSA_ERR_NOMEM;
+			GSA_CHECK(c, hipMemsetAsync(c->d_lb_status[k].p, 0, c->d_lb_status[k].cap, c->stream));       // fresh memory: no word may look current
+		}
+	}
+	c->lb_epoch++;
+	if ((c->lb_epoch & 0x3fffffffu) == 0) {      // epoch wrapped: forget every old word
+		for (int k = 0; k < 2; k++) GSA_CHECK(c, hipMemsetAsync(c->d_lb_status[k].p, 0, c->d_lb_status[k].cap, c->stream));
+		c->lb_epoch = 1;
+	}
+	LbArgs lb;
+	lb.status[0] = c->d_lb_status[0].as<unsigned long long>(); lb.status[1] = c->d_lb_status[1].as<unsigned long long>();
+	lb.ticket = c->d_mail.as<u32>() + M_TICKET; lb.base = c->lb_base; lb.epoch = c->lb_epoch; lb.err = c->d_mail.as<i32>() + M_LBERR;
+	hipLaunchKernelGGL((k_lb_pass<NV, Op>), dim3((unsigned)tiles), dim3(LB_TPB), 0, c->stream, n, op, lb);
+	GSA_CHECK(c, hipGetLastError());
+	c->lb_base += (u32)tiles;
+	return GSA_OK;
+}
+
+#endif

@@ -17,6 +17,7 @@
 // PosDiff>>4 is an arithmetic shift, the modal bucket is the first maximum in
 // ascending key order, bucket counts are read after zeroing.
 #include "gsa_ctx.h"
+#include "gsa_scan.h"
 
 #define TPB 256
 #define GID(n) i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (n)) return
@@ -45,43 +46,47 @@ __global__ void k_gather_active(i64 na, const u32 *__restrict__ perm, const i32 
 	a_gb[i] = g_beg[g]; a_ge[i] = g_beg[g + 1];
 }
 
-// ---- B. unique flags, break flags ---------------------------------------------
+// ---- B. unique flags, break flags, window-start candidates -------------------------
+// (each struct below is one fused pass: value -> exclusive scan -> emit, see gsa_scan.h)
 // uniq: no other seed of the group shares qPos (GSAlign.cpp:316-325)
 // brk : unique and PosDiff differs from the previous seed (the only places where
 //       an outlier window may close, :328-331)
-__global__ void k_uniq_brk(i64 na, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge,
-                           i32 *uniq, i32 *brk, i32 *alive)
-{
-	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > na) return;
-	if (i == na) { uniq[i] = 0; brk[i] = 0; return; }
-	const i32 gb = a_gb[i], ge = a_ge[i], q = a_q[i];
-	const bool u = !(i > gb && a_q[i - 1] == q) && !(i + 1 < ge && a_q[i + 1] == q);
-	uniq[i] = u ? 1 : 0;
-	brk[i] = (u && i > gb && (a_r[i] - q) != (a_r[i - 1] - a_q[i - 1])) ? 1 : 0;
-	alive[i] = 1;
-}
-
-__global__ void k_scatter_idx(i64 n, const i32 *__restrict__ flag, const i32 *__restrict__ ex, i32 *list)
-{
-	GID(n);
-	if (flag[i]) list[ex[i]] = (i32)i;
-}
+struct OpUniqBrk {
+	i64 na; const i32 *a_q; const i64 *a_r; const i32 *a_gb, *a_ge;
+	i32 *uniq, *brk, *alive, *cuEx, *brkEx, *blist;
+	__device__ i32 value(i64 i, int c) const
+	{
+		const i32 gb = a_gb[i], ge = a_ge[i], q = a_q[i];
+		const bool u = !(i > gb && a_q[i - 1] == q) && !(i + 1 < ge && a_q[i + 1] == q);
+		if (c == 0) return u ? 1 : 0;
+		return (u && i > gb && (a_r[i] - q) != (a_r[i - 1] - a_q[i - 1])) ? 1 : 0;
+	}
+	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	{
+		uniq[i] = v[0]; brk[i] = v[1]; alive[i] = 1; cuEx[i] = ex[0]; brkEx[i] = ex[1];
+		if (v[1]) blist[ex[1]] = (i32)i;
+	}
+	__device__ void done(const i32 *t) const { cuEx[na] = t[0]; brkEx[na] = t[1]; uniq[na] = 0; brk[na] = 0; }
+};
 
 // Window starts.  Every group head is one; further starts only exist in groups with at least
 // GSA_WIN_SEEDS unique seeds (a window needs that many to close, GSAlign.cpp:326-338).  Candidates =
 // heads and break positions of those "big" groups; ws[] starts out as the head flags.
-__global__ void k_cand_flags(i64 na, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge, const i32 *__restrict__ cuEx, const i32 *__restrict__ brk,
-                             i32 *candf, i32 *ws)
-{
-	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > na) return;
-	if (i == na) { candf[i] = 0; ws[i] = 0; return; }
-	const i32 gb = a_gb[i], ge = a_ge[i];
-	const bool head = i == gb;
-	ws[i] = head ? 1 : 0;
-	candf[i] = (cuEx[ge] - cuEx[gb] >= GSA_WIN_SEEDS && (head || brk[i])) ? 1 : 0;
-}
+struct OpCand {
+	i64 na; const i32 *a_gb, *a_ge, *cuEx, *brk;
+	i32 *candf, *candEx, *clist, *ws;
+	__device__ i32 value(i64 i, int) const
+	{
+		const i32 gb = a_gb[i], ge = a_ge[i];
+		return (cuEx[ge] - cuEx[gb] >= GSA_WIN_SEEDS && (i == gb || brk[i])) ? 1 : 0;
+	}
+	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	{
+		candf[i] = v[0]; candEx[i] = ex[0]; ws[i] = i == a_gb[i] ? 1 : 0;
+		if (v[0]) clist[ex[0]] = (i32)i;
+	}
+	__device__ void done(const i32 *t) const { candEx[na] = t[0]; candf[na] = 0; ws[na] = 0; }
+};
 
 // next window start for every candidate; a group without a further window hands over to the first
 // candidate behind it (the head of the next big group) or to na
@@ -160,24 +165,31 @@ __global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__re
 }
 
 // ---- C. outliers: per-window histogram of PosDiff>>4 over unique seeds -----------
-__global__ void k_outlier_keys(i64 na, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const i32 *__restrict__ uniq,
-                               const i32 *__restrict__ ws, const i32 *__restrict__ wsEx, u64 *key, u32 *val)
-{
-	GID(na);
-	const i32 w = wsEx[i] + ws[i] - 1;
-	const i64 pd = a_r[i] - a_q[i];
-	const u32 b = (u32)(i32)(pd >> 4) ^ 0x80000000u;
-	key[i] = uniq[i] ? (((u64)(u32)w << 32) | b) : ~0ull;       // non-unique seeds sort to the end
-	val[i] = (u32)i;
-}
+// window id per seed = (number of starts up to and including it) - 1; the same pass builds the
+// (window, bucket) sort keys and clears the per-window accumulators
+struct OpWindowKeys {
+	i64 na; const i32 *a_q; const i64 *a_r; const i32 *uniq, *ws;
+	i32 *wsEx; u64 *key; u32 *val; unsigned long long *wbest, *wsum; i32 *wn;
+	__device__ i32 value(i64 i, int) const { return ws[i]; }
+	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	{
+		wsEx[i] = ex[0];
+		const i32 w = ex[0] + v[0] - 1;
+		const i64 pd = a_r[i] - a_q[i];
+		const u32 b = (u32)(i32)(pd >> 4) ^ 0x80000000u;
+		key[i] = uniq[i] ? (((u64)(u32)w << 32) | b) : ~0ull;       // non-unique seeds sort to the end
+		val[i] = (u32)i;
+		wbest[i] = 0; wsum[i] = 0; wn[i] = 0;
+	}
+	__device__ void done(const i32 *t) const { wsEx[na] = t[0]; wbest[na] = 0; wsum[na] = 0; wn[na] = 0; }
+};
 
-__global__ void k_run_heads(i64 na, const u64 *__restrict__ key, i32 *head)
-{
-	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > na) return;
-	if (i == na) { head[i] = 0; return; }
-	head[i] = (key[i] != ~0ull && (i == 0 || key[i] != key[i - 1])) ? 1 : 0;
-}
+struct OpRunHeads {
+	i64 na; const u64 *key; i32 *head, *headEx, *rs;
+	__device__ i32 value(i64 i, int) const { return (key[i] != ~0ull && (i == 0 || key[i] != key[i - 1])) ? 1 : 0; }
+	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const { head[i] = v[0]; headEx[i] = ex[0]; if (v[0]) rs[ex[0]] = (i32)i; }
+	__device__ void done(const i32 *t) const { headEx[na] = t[0]; head[na] = 0; }
+};
 
 // run r = [rs[r], rs[r+1]) ; the last run ends at nU (number of unique seeds)
 __global__ void k_window_mode(i64 na, const i32 *__restrict__ headEx, const i32 *__restrict__ rs, const u64 *__restrict__ key, const i32 *__restrict__ cuEx,
@@ -232,12 +244,12 @@ __global__ void k_outlier_kill(i64 na, const u64 *__restrict__ key, const u32 *_
 }
 
 // ---- D. multi-hit query positions (GSAlign.cpp:178-225,341-350) -------------------
-__global__ void k_au_flags(i64 na, const i32 *__restrict__ uniq, const i32 *__restrict__ alive, i32 *au)
-{
-	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > na) return;
-	au[i] = (i < na && uniq[i] && alive[i]) ? 1 : 0;
-}
+struct OpAliveUnique {      // ranks of the alive unique seeds
+	i64 na; const i32 *uniq, *alive; i32 *auEx, *aulist;
+	__device__ i32 value(i64 i, int) const { return (uniq[i] && alive[i]) ? 1 : 0; }
+	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const { auEx[i] = ex[0]; if (v[0]) aulist[ex[0]] = (i32)i; }
+	__device__ void done(const i32 *t) const { auEx[na] = t[0]; }
+};
 
 __global__ void k_multihit(i64 na, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge,
                            const i32 *__restrict__ auEx, const i32 *__restrict__ aulist, i64 G, i32 max_indel, i32 *alive)
@@ -256,84 +268,82 @@ __global__ void k_multihit(i64 na, const i32 *__restrict__ a_q, const i64 *__res
 }
 
 // ---- E. compaction, noise stencil, block cuts -----------------------------------
-__global__ void k_flag_tail(i64 n, i32 *flag) { if (blockIdx.x == 0 && threadIdx.x == 0) flag[n] = 0; }
-
-__global__ void k_compact(i64 n, const i32 *__restrict__ keep, const i32 *__restrict__ ex, const i32 *__restrict__ q, const i32 *__restrict__ len,
-                          const i64 *__restrict__ r, const i32 *__restrict__ gb, const i32 *__restrict__ ge, i32 *oq, i32 *olen, i64 *orr, i32 *ogb, i32 *oge)
-{
-	GID(n);
-	if (!keep[i]) return;
-	const i32 p = ex[i];
-	oq[p] = q[i]; olen[p] = len[i]; orr[p] = r[i]; ogb[p] = ex[gb[i]]; oge[p] = ex[ge[i]];
-}
-
-// 3-point noise filter (GSAlign.cpp:355-362): pure stencil on PosDiff
-__global__ void k_noise(const i32 *__restrict__ nptr, const i32 *__restrict__ q, const i64 *__restrict__ r, const i32 *__restrict__ gb, const i32 *__restrict__ ge, i32 *keep)
-{
-	const i64 n = *nptr;
-	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > n) return;
-	if (i == n) { keep[i] = 0; return; }
-	i32 k = 1;
-	if (i > gb[i] && i + 1 < ge[i]) {
-		const i64 pd = r[i] - q[i], p0 = r[i - 1] - q[i - 1], p1 = r[i + 1] - q[i + 1];
-		if (d_llabs(pd - p0) > 5 && d_llabs(pd - p1) > 5) k = 0;
+// After the first compaction only "is my neighbour in my group" is ever asked, so the seeds
+// carry a group id (the group's old begin index) instead of group bounds.
+struct OpCompactAlive {
+	const i32 *alive, *a_q, *a_len; const i64 *a_r; const i32 *a_gb;
+	i32 *b_q, *b_len; i64 *b_r; i32 *b_g, *mail;
+	__device__ i32 value(i64 i, int) const { return alive[i] ? 1 : 0; }
+	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	{
+		if (!v[0]) return;
+		const i32 p = ex[0];
+		b_q[p] = a_q[i]; b_len[p] = a_len[i]; b_r[p] = a_r[i]; b_g[p] = a_gb[i];
 	}
-	keep[i] = k;
-}
+	__device__ void done(const i32 *t) const { mail[M_NB] = t[0]; }
+};
 
-__global__ void k_compact_n(const i32 *__restrict__ nptr, const i32 *__restrict__ keep, const i32 *__restrict__ ex, const i32 *__restrict__ q, const i32 *__restrict__ len,
-                            const i64 *__restrict__ r, const i32 *__restrict__ gb, const i32 *__restrict__ ge, i32 *oq, i32 *olen, i64 *orr, i32 *ogb, i32 *oge)
-{
-	const i64 n = *nptr;
-	GID(n);
-	if (!keep[i]) return;
-	const i32 p = ex[i];
-	oq[p] = q[i]; olen[p] = len[i]; orr[p] = r[i]; ogb[p] = ex[gb[i]]; oge[p] = ex[ge[i]];
-}
+// 3-point noise filter (GSAlign.cpp:355-362): pure stencil on PosDiff, then compaction #2
+struct OpNoise {
+	const i32 *b_q, *b_len; const i64 *b_r; const i32 *b_g;
+	i32 *c_q, *c_len; i64 *c_r; i32 *c_g, *mail;
+	__device__ i32 value(i64 i, int) const
+	{
+		const i64 nb = mail[M_NB];
+		if (i >= nb) return 0;
+		if (i > 0 && i + 1 < nb && b_g[i - 1] == b_g[i] && b_g[i + 1] == b_g[i]) {
+			const i64 pd = b_r[i] - b_q[i], p0 = b_r[i - 1] - b_q[i - 1], p1 = b_r[i + 1] - b_q[i + 1];
+			if (d_llabs(pd - p0) > 5 && d_llabs(pd - p1) > 5) return 0;
+		}
+		return 1;
+	}
+	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	{
+		if (!v[0]) return;
+		const i32 p = ex[0];
+		c_q[p] = b_q[i]; c_len[p] = b_len[i]; c_r[p] = b_r[i]; c_g[p] = b_g[i];
+	}
+	__device__ void done(const i32 *t) const { mail[M_NC] = t[0]; }
+};
 
 // block heads (GSAlign.cpp:364-374): group head, query gap > MaxSeedGap, or diagonal jump > 100
-__global__ void k_block_heads(const i32 *__restrict__ nptr, const i32 *__restrict__ q, const i32 *__restrict__ len, const i64 *__restrict__ r,
-                              const i32 *__restrict__ gb, i32 *head)
-{
-	const i64 n = *nptr;
-	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > n) return;
-	if (i == n) { head[i] = 0; return; }
-	i32 h = 1;
-	if (i > gb[i]) {
-		const i64 pd = r[i] - q[i], p0 = r[i - 1] - q[i - 1];
-		h = (q[i] - q[i - 1] - len[i - 1] > GSA_MAX_SEED_GAP || d_llabs(p0 - pd) > 100) ? 1 : 0;
+struct OpBlockHeads {
+	i64 na; const i32 *c_q, *c_len; const i64 *c_r; const i32 *c_g;
+	i32 *bhead, *bheadEx, *bstart, *mail;
+	__device__ i32 value(i64 i, int) const
+	{
+		if (i >= mail[M_NC]) return 0;
+		if (i == 0 || c_g[i - 1] != c_g[i]) return 1;
+		const i64 pd = c_r[i] - c_q[i], p0 = c_r[i - 1] - c_q[i - 1];
+		return (c_q[i] - c_q[i - 1] - c_len[i - 1] > GSA_MAX_SEED_GAP || d_llabs(p0 - pd) > 100) ? 1 : 0;
 	}
-	head[i] = h;
-}
+	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const { bhead[i] = v[0]; bheadEx[i] = ex[0]; if (v[0]) bstart[ex[0]] = (i32)i; }
+	__device__ void done(const i32 *t) const { bheadEx[na] = t[0]; bhead[na] = 0; mail[M_NBRAW] = t[0]; }
+};
 
-// AddAlnBlock filter (GSAlign.cpp:29-49); bstart[] lists block heads, nAll = headEx[n]
-__global__ void k_block_filter(const i32 *__restrict__ nptr, const i32 *__restrict__ headEx, const i32 *__restrict__ bstart, const i32 *__restrict__ q,
-                               const i32 *__restrict__ len, const i64 *__restrict__ ps, Params prm, i32 *bkeep, i32 *bscore)
-{
-	const i64 n = *nptr;
-	i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (b > n) return;
-	const i32 nAll = headEx[n];
-	if (b >= nAll) { bkeep[b] = 0; return; }
-	const i32 s = bstart[b], e = (b + 1 < nAll) ? bstart[b + 1] : (i32)n;
-	const i32 score = (i32)(ps[e] - ps[s]);
-	const i32 region = q[e - 1] + len[e - 1] - q[s];
-	const bool drop = score < prm.MinAlnBlockScore || region < prm.MinAlnLength || (score < 1000 && (double)score < region * 0.05);
-	bkeep[b] = drop ? 0 : 1; bscore[b] = score;
-}
-
-__global__ void k_block_emit(const i32 *__restrict__ nptr, const i32 *__restrict__ headEx, const i32 *__restrict__ bstart, const i32 *__restrict__ bkeep,
-                             const i32 *__restrict__ bkeepEx, const i32 *__restrict__ bscore, i32 *blk_beg, i32 *blk_end, i32 *blk_score)
-{
-	const i64 n = *nptr;
-	GID(n);
-	const i32 nAll = headEx[n];
-	if (i >= nAll || !bkeep[i]) return;
-	const i32 p = bkeepEx[i];
-	blk_beg[p] = bstart[i]; blk_end[p] = (i + 1 < nAll) ? bstart[i + 1] : (i32)n; blk_score[p] = bscore[i];
-}
+// AddAlnBlock filter (GSAlign.cpp:29-49) over the raw blocks + the table of the kept ones
+struct OpBlockFilter {
+	i64 na; const i32 *bstart, *c_q, *c_len; const i64 *ps; Params prm;
+	i32 *bkeep, *bkeepEx, *blk_beg, *blk_end, *blk_score, *mail;
+	__device__ void span(i64 b, i32 &s, i32 &e) const { const i32 nAll = mail[M_NBRAW]; s = bstart[b]; e = (b + 1 < nAll) ? bstart[b + 1] : mail[M_NC]; }
+	__device__ i32 value(i64 b, int) const
+	{
+		if (b >= mail[M_NBRAW]) return 0;
+		i32 s, e; span(b, s, e);
+		const i32 score = (i32)(ps[e] - ps[s]);
+		const i32 region = c_q[e - 1] + c_len[e - 1] - c_q[s];
+		const bool drop = score < prm.MinAlnBlockScore || region < prm.MinAlnLength || (score < 1000 && (double)score < region * 0.05);
+		return drop ? 0 : 1;
+	}
+	__device__ void emit(i64 b, const i32 *v, const i32 *ex) const
+	{
+		bkeep[b] = v[0]; bkeepEx[b] = ex[0];
+		if (!v[0]) return;
+		i32 s, e; span(b, s, e);
+		blk_beg[ex[0]] = s; blk_end[ex[0]] = e; blk_score[ex[0]] = (i32)(ps[e] - ps[s]);
+	}
+	__device__ void done(const i32 *t) const { mail[M_NBLK] = t[0]; }
+};
 
 __global__ void k_seed_block_id(const i32 *__restrict__ nptr, const i32 *__restrict__ head, const i32 *__restrict__ headEx, const i32 *__restrict__ bkeep,
                                 const i32 *__restrict__ bkeepEx, i32 *bid)
@@ -372,74 +382,44 @@ int stage2_chain(gsa_ctx *c)
 	ENS(i32, a_aulist, na + 1); ENS(i32, a_next, na + 1); ENS(i32, a_ws, na + 1); ENS(i32, a_wid, na + 1); ENS(i32, a_runinfo, na + 1);
 	i32 *uniq = c->a_uniq.as<i32>(), *cuEx = c->a_cu.as<i32>(), *alive = c->a_alive.as<i32>(), *brk = c->a_brk.as<i32>();
 	i32 *brkEx = c->a_aurank.as<i32>(), *blist = c->a_aulist.as<i32>(), *next = c->a_next.as<i32>(), *ws = c->a_ws.as<i32>(), *wsEx = c->a_wid.as<i32>();
-	LAUNCH(k_uniq_brk, na + 1, na, c->a_q.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, brk, alive);
-	RC(prim_exscan_i32(c, uniq, cuEx, (size_t)na + 1));
-	RC(prim_exscan_i32(c, brk, brkEx, (size_t)na + 1));
-	LAUNCH(k_scatter_idx, na, na, brk, brkEx, blist);
+	i32 *mail = c->d_mail.as<i32>();
+	{ OpUniqBrk op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, brk, alive, cuEx, brkEx, blist }; RC((lb_launch<2>(c, na, op))); }
 	i32 *candf = c->d_flag.as<i32>(), *candEx = c->d_scan.as<i32>(), *clist = c->a_runinfo.as<i32>();
-	LAUNCH(k_cand_flags, na + 1, na, c->a_gb.as<i32>(), c->a_ge.as<i32>(), cuEx, brk, candf, ws);
-	RC(prim_exscan_i32(c, candf, candEx, (size_t)na + 1));
-	LAUNCH(k_scatter_idx, na, na, candf, candEx, clist);
+	{ OpCand op = { na, c->a_gb.as<i32>(), c->a_ge.as<i32>(), cuEx, brk, candf, candEx, clist, ws }; RC((lb_launch<1>(c, na, op))); }
 	LAUNCH(k_next_window, na, na, c->a_q.as<i32>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, cuEx, brk, brkEx, blist, candf, candEx, clist, next);
 	hipLaunchKernelGGL(k_walk_windows, dim3(1), dim3(WALK_T), 0, st, na, candEx, clist, next, ws);
-	RC(prim_exscan_i32(c, ws, wsEx, (size_t)na + 1));
 	// C. outliers
 	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);
-	GSA_CHECK(c, hipMemsetAsync(c->w_best.p, 0, ((size_t)na + 1) * 8, st));
-	GSA_CHECK(c, hipMemsetAsync(c->w_sum.p, 0, ((size_t)na + 1) * 8, st));
-	GSA_CHECK(c, hipMemsetAsync(c->w_n.p, 0, ((size_t)na + 1) * 4, st));
-	LAUNCH(k_outlier_keys, na, na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, wsEx, c->d_key_a.as<u64>(), c->d_val_a.as<u32>());
+	{ OpWindowKeys op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, wsEx, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(),
+	                      c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>() }; RC((lb_launch<1>(c, na, op))); }
 	RC(prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, 64));
 	i32 *head = c->d_flag.as<i32>(), *headEx = c->d_scan.as<i32>(), *rs = c->a_runinfo.as<i32>();
-	LAUNCH(k_run_heads, na + 1, na, c->d_key_b.as<u64>(), head);
-	RC(prim_exscan_i32(c, head, headEx, (size_t)na + 1));
-	LAUNCH(k_scatter_idx, na, na, head, headEx, rs);
+	{ OpRunHeads op = { na, c->d_key_b.as<u64>(), head, headEx, rs }; RC((lb_launch<1>(c, na, op))); }
 	LAUNCH(k_window_mode, na, na, headEx, rs, c->d_key_b.as<u64>(), cuEx, c->w_best.as<unsigned long long>());
 	LAUNCH(k_window_avg, na, na, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), cuEx, c->a_q.as<i32>(), c->a_r.as<i64>(), c->w_best.as<unsigned long long>(),
 	       c->w_sum.as<unsigned long long>(), c->w_n.as<i32>());
 	LAUNCH(k_outlier_kill, na, na, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), cuEx, head, headEx, rs, c->a_q.as<i32>(), c->a_r.as<i64>(),
 	       c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->G, c->prm.MaxIndelSize, alive);
 	// D. multi-hit positions
-	i32 *au = c->d_flag.as<i32>(), *auEx = c->a_aurank.as<i32>(), *aulist = c->a_aulist.as<i32>();
-	LAUNCH(k_au_flags, na + 1, na, uniq, alive, au);
-	RC(prim_exscan_i32(c, au, auEx, (size_t)na + 1));
-	LAUNCH(k_scatter_idx, na, na, au, auEx, aulist);
+	i32 *auEx = c->a_aurank.as<i32>(), *aulist = c->a_aulist.as<i32>();
+	{ OpAliveUnique op = { na, uniq, alive, auEx, aulist }; RC((lb_launch<1>(c, na, op))); }
 	LAUNCH(k_multihit, na, na, c->a_q.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), auEx, aulist, c->G, c->prm.MaxIndelSize, alive);
-	// E. compaction #1
-	LAUNCH(k_flag_tail, 1, na, alive);
-	i32 *ex = c->d_scan.as<i32>();
-	RC(prim_exscan_i32(c, alive, ex, (size_t)na + 1));
-	ENS(i32, b_q, na); ENS(i32, b_len, na); ENS(i64, b_r, na); ENS(i32, b_gb, na); ENS(i32, b_ge, na);
-	LAUNCH(k_compact, na, na, alive, ex, c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(),
-	       c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(), c->b_ge.as<i32>());
-	// n_b lives on the device at ex[na]; keep a private copy because `ex` is reused
-	i32 *d_counts = c->d_mail.as<i32>() + M_NB;   // mailbox: [M_NB] = n_b, [M_NC] = n_c
-	GSA_CHECK(c, hipMemcpyAsync(d_counts, ex + na, 4, hipMemcpyDeviceToDevice, st));
-	// noise stencil + compaction #2
-	i32 *keep = c->d_flag.as<i32>(), *keepEx = c->d_scan2.as<i32>();
-	GSA_CHECK(c, hipMemsetAsync(keep, 0, ((size_t)na + 1) * 4, st));
-	LAUNCH(k_noise, na + 1, d_counts, c->b_q.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(), c->b_ge.as<i32>(), keep);
-	RC(prim_exscan_i32(c, keep, keepEx, (size_t)na + 1));
-	ENS(i32, c_q, na); ENS(i32, c_len, na + 1); ENS(i64, c_r, na); ENS(i32, c_gb, na); ENS(i32, c_ge, na); ENS(i32, c_bid, na);
-	GSA_CHECK(c, hipMemsetAsync(c->c_len.p, 0, ((size_t)na + 1) * 4, st));
-	LAUNCH(k_compact_n, na, d_counts, keep, keepEx, c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(), c->b_ge.as<i32>(),
-	       c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), c->c_ge.as<i32>());
-	GSA_CHECK(c, hipMemcpyAsync(d_counts + 1, keepEx + na, 4, hipMemcpyDeviceToDevice, st));
+	// E. compaction #1, noise stencil + compaction #2 (counts stay in the mailbox)
+	ENS(i32, b_q, na); ENS(i32, b_len, na); ENS(i64, b_r, na); ENS(i32, b_gb, na);
+	{ OpCompactAlive op = { alive, c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(),
+	                        c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(), mail }; RC((lb_launch<1>(c, na, op))); }
+	ENS(i32, c_q, na); ENS(i32, c_len, na + 1); ENS(i64, c_r, na); ENS(i32, c_gb, na); ENS(i32, c_bid, na);
+	{ OpNoise op = { c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(),
+	                 c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), mail }; RC((lb_launch<1>(c, na, op))); }
 	// block cuts + AddAlnBlock
 	i32 *bhead = c->a_uniq.as<i32>(), *bheadEx = c->a_cu.as<i32>(), *bstart = c->a_brk.as<i32>();
-	GSA_CHECK(c, hipMemsetAsync(bhead, 0, ((size_t)na + 1) * 4, st));
-	LAUNCH(k_block_heads, na + 1, d_counts + 1, c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), bhead);
-	RC(prim_exscan_i32(c, bhead, bheadEx, (size_t)na + 1));
-	LAUNCH(k_scatter_idx, na, na, bhead, bheadEx, bstart);
-	RC(prim_exscan_i32_i64(c, c->c_len.as<i32>(), c->d_i64a.as<i64>(), (size_t)na + 1));
-	i32 *bkeep = c->a_ws.as<i32>(), *bkeepEx = c->a_wid.as<i32>(), *bscore = c->a_next.as<i32>();
-	GSA_CHECK(c, hipMemsetAsync(bkeep, 0, ((size_t)na + 1) * 4, st));
-	LAUNCH(k_block_filter, na + 1, d_counts + 1, bheadEx, bstart, c->c_q.as<i32>(), c->c_len.as<i32>(), c->d_i64a.as<i64>(), c->prm, bkeep, bscore);
-	RC(prim_exscan_i32(c, bkeep, bkeepEx, (size_t)na + 1));
+	{ OpBlockHeads op = { na, c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), bhead, bheadEx, bstart, mail }; RC((lb_launch<1>(c, na, op))); }
+	RC(prim_exscan_i32_i64(c, c->c_len.as<i32>(), c->d_i64a.as<i64>(), (size_t)na + 1));      // (entries behind n_c are never looked at)
+	i32 *bkeep = c->a_ws.as<i32>(), *bkeepEx = c->a_wid.as<i32>();
 	ENS(i32, blk_beg, na + 1); ENS(i32, blk_end, na + 1); ENS(i32, blk_score, na + 1);
-	LAUNCH(k_block_emit, na, d_counts + 1, bheadEx, bstart, bkeep, bkeepEx, bscore, c->blk_beg.as<i32>(), c->blk_end.as<i32>(), c->blk_score.as<i32>());
-	LAUNCH(k_seed_block_id, na, d_counts + 1, bhead, bheadEx, bkeep, bkeepEx, c->c_bid.as<i32>());
-	GSA_CHECK(c, hipMemcpyAsync(c->d_mail.as<i32>() + M_NBLK, bkeepEx + na, 4, hipMemcpyDeviceToDevice, st));
+	{ OpBlockFilter op = { na, bstart, c->c_q.as<i32>(), c->c_len.as<i32>(), c->d_i64a.as<i64>(), c->prm, bkeep, bkeepEx,
+	                       c->blk_beg.as<i32>(), c->blk_end.as<i32>(), c->blk_score.as<i32>(), mail }; RC((lb_launch<1>(c, na, op))); }
+	LAUNCH(k_seed_block_id, na, mail + M_NC, bhead, bheadEx, bkeep, bkeepEx, c->c_bid.as<i32>());
 	if (c->profiling) { hipEventRecord(c->ev[5], st); c->ev_pending |= 2; }
 	return GSA_OK;      // counts stay in the mailbox; stage 3 reads them with its own first read-back
 }
