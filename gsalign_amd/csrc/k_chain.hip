@@ -307,23 +307,25 @@ struct OpNoise {
 };
 
 // block heads (GSAlign.cpp:364-374): group head, query gap > MaxSeedGap, or diagonal jump > 100
+// (second component: prefix sums of the seed lengths, 32-bit wrapping -- only differences over a block are used)
 struct OpBlockHeads {
 	i64 na; const i32 *c_q, *c_len; const i64 *c_r; const i32 *c_g;
-	i32 *bhead, *bheadEx, *bstart, *mail;
-	__device__ i32 value(i64 i, int) const
+	i32 *bhead, *bheadEx, *bstart; u32 *ps; i32 *mail;
+	__device__ i32 value(i64 i, int c) const
 	{
 		if (i >= mail[M_NC]) return 0;
+		if (c == 1) return c_len[i];
 		if (i == 0 || c_g[i - 1] != c_g[i]) return 1;
 		const i64 pd = c_r[i] - c_q[i], p0 = c_r[i - 1] - c_q[i - 1];
 		return (c_q[i] - c_q[i - 1] - c_len[i - 1] > GSA_MAX_SEED_GAP || d_llabs(p0 - pd) > 100) ? 1 : 0;
 	}
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const { bhead[i] = v[0]; bheadEx[i] = ex[0]; if (v[0]) bstart[ex[0]] = (i32)i; }
-	__device__ void done(const i32 *t) const { bheadEx[na] = t[0]; bhead[na] = 0; mail[M_NBRAW] = t[0]; }
+	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const { bhead[i] = v[0]; bheadEx[i] = ex[0]; ps[i] = (u32)ex[1]; if (v[0]) bstart[ex[0]] = (i32)i; }
+	__device__ void done(const i32 *t) const { bheadEx[na] = t[0]; bhead[na] = 0; ps[na] = (u32)t[1]; mail[M_NBRAW] = t[0]; }
 };
 
 // AddAlnBlock filter (GSAlign.cpp:29-49) over the raw blocks + the table of the kept ones
 struct OpBlockFilter {
-	i64 na; const i32 *bstart, *c_q, *c_len; const i64 *ps; Params prm;
+	i64 na; const i32 *bstart, *c_q, *c_len; const u32 *ps; Params prm;
 	i32 *bkeep, *bkeepEx, *blk_beg, *blk_end, *blk_score, *mail;
 	__device__ void span(i64 b, i32 &s, i32 &e) const { const i32 nAll = mail[M_NBRAW]; s = bstart[b]; e = (b + 1 < nAll) ? bstart[b + 1] : mail[M_NC]; }
 	__device__ i32 value(i64 b, int) const
@@ -413,11 +415,10 @@ int stage2_chain(gsa_ctx *c)
 	                 c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), mail }; RC((lb_launch<1>(c, na, op))); }
 	// block cuts + AddAlnBlock
 	i32 *bhead = c->a_uniq.as<i32>(), *bheadEx = c->a_cu.as<i32>(), *bstart = c->a_brk.as<i32>();
-	{ OpBlockHeads op = { na, c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), bhead, bheadEx, bstart, mail }; RC((lb_launch<1>(c, na, op))); }
-	RC(prim_exscan_i32_i64(c, c->c_len.as<i32>(), c->d_i64a.as<i64>(), (size_t)na + 1));      // (entries behind n_c are never looked at)
+	{ OpBlockHeads op = { na, c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), bhead, bheadEx, bstart, c->d_flag2.as<u32>(), mail }; RC((lb_launch<2>(c, na, op))); }
 	i32 *bkeep = c->a_ws.as<i32>(), *bkeepEx = c->a_wid.as<i32>();
 	ENS(i32, blk_beg, na + 1); ENS(i32, blk_end, na + 1); ENS(i32, blk_score, na + 1);
-	{ OpBlockFilter op = { na, bstart, c->c_q.as<i32>(), c->c_len.as<i32>(), c->d_i64a.as<i64>(), c->prm, bkeep, bkeepEx,
+	{ OpBlockFilter op = { na, bstart, c->c_q.as<i32>(), c->c_len.as<i32>(), c->d_flag2.as<u32>(), c->prm, bkeep, bkeepEx,
 	                       c->blk_beg.as<i32>(), c->blk_end.as<i32>(), c->blk_score.as<i32>(), mail }; RC((lb_launch<1>(c, na, op))); }
 	LAUNCH(k_seed_block_id, na, mail + M_NC, bhead, bheadEx, bkeep, bkeepEx, c->c_bid.as<i32>());
 	if (c->profiling) { hipEventRecord(c->ev[5], st); c->ev_pending |= 2; }

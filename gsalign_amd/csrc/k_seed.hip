@@ -5,6 +5,7 @@
 // (reference src/GSAlign.cpp:51-107,126-143; src/bwt_search.cpp:121-185).
 #include "gsa_ctx.h"
 #include "gsa_fm.h"
+#include "gsa_scan.h"
 
 enum { CNT_OCCBLK = 0, CNT_LF = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 4, CNT_DPJOBS = 5, CNT_DPMN = 6, CNT_CAND = 8, CNT_OVERFLOW = 9, CNT_OCCBLK_ALL = 10 };
 
@@ -319,31 +320,28 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 	}
 }
 
-// sorted keys -> SoA seeds + "new group starts here" flag (SeedGrouping, a6)
-__global__ void k_decode_seeds(i64 n, const u64 *__restrict__ key, const u32 *__restrict__ val, i32 qlen, int qbits, i32 max_indel,
-                               i32 *s_q, i32 *s_len, i64 *s_r, i32 *flag)
-{
-	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > n) return;
-	if (i == n) { flag[n] = 0; return; }
-	const u64 qmask = (1ull << qbits) - 1;
-	u64 k = key[i];
-	i32 qp = (i32)(k & qmask); i64 pd = (i64)(k >> qbits) - qlen;
-	s_q[i] = qp; s_len[i] = (i32)val[i]; s_r[i] = pd + qp;
-	i32 f = 1;
-	if (i > 0) { i64 pd0 = (i64)(key[i - 1] >> qbits) - qlen; f = (pd - pd0 > max_indel) ? 1 : 0; }
-	flag[i] = f;
-}
-
-__global__ void k_group_ids(i64 n, const i32 *__restrict__ flag, const i32 *__restrict__ ex, i32 *gid, i32 *g_beg)
-{
-	i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i > n) return;
-	if (i == n) { g_beg[ex[n]] = (i32)n; return; }
-	i32 g = ex[i] + flag[i] - 1;
-	gid[i] = g;
-	if (flag[i]) g_beg[g] = (i32)i;
-}
+// sorted keys -> SoA seeds + group ids (SeedGrouping, a6): one fused pass (gsa_scan.h); a new group
+// starts where PosDiff jumps by more than MaxIndelSize
+struct OpDecodeGroup {
+	i64 n; const u64 *key; const u32 *val; i32 qlen; int qbits; i32 max_indel;
+	i32 *s_q, *s_len; i64 *s_r; i32 *s_gid, *g_beg, *mail;
+	__device__ i32 value(i64 i, int) const
+	{
+		if (i == 0) return 1;
+		const i64 pd = (i64)(key[i] >> qbits) - qlen, pd0 = (i64)(key[i - 1] >> qbits) - qlen;
+		return (pd - pd0 > max_indel) ? 1 : 0;
+	}
+	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	{
+		const u64 k = key[i];
+		const i32 qp = (i32)(k & ((1ull << qbits) - 1)); const i64 pd = (i64)(k >> qbits) - qlen;
+		s_q[i] = qp; s_len[i] = (i32)val[i]; s_r[i] = pd + qp;
+		const i32 g = ex[0] + v[0] - 1;
+		s_gid[i] = g;
+		if (v[0]) g_beg[g] = (i32)i;
+	}
+	__device__ void done(const i32 *t) const { g_beg[t[0]] = (i32)n; mail[M_NG] = t[0]; }
+};
 
 // ---------------------------------------------------------------------------
 // Dense SA (index upload time).  The on-disk SA keeps every 32nd ROW; a walk from
@@ -510,14 +508,14 @@ int stage1_seed(gsa_ctx *c)
 	if (rc) return rc;
 	if (!dev_ensure<i32>(c, c->s_q, n) || !dev_ensure<i32>(c, c->s_len, n) || !dev_ensure<i64>(c, c->s_r, n) || !dev_ensure<i32>(c, c->s_gid, n) ||
 	    !dev_ensure<i32>(c, c->d_flag, n + 1) || !dev_ensure<i32>(c, c->d_scan, n + 1) || !dev_ensure<i32>(c, c->g_beg, n + 1)) return GSA_ERR_NOMEM;
-	hipLaunchKernelGGL(k_decode_seeds, dim3(grid_for(n + 1, 256)), dim3(256), 0, st, (i64)n, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), qlen, c->qbits, c->prm.MaxIndelSize,
-	                   c->s_q.as<i32>(), c->s_len.as<i32>(), c->s_r.as<i64>(), c->d_flag.as<i32>());
-	rc = prim_exscan_i32(c, c->d_flag.as<i32>(), c->d_scan.as<i32>(), n + 1);
-	if (rc) return rc;
-	hipLaunchKernelGGL(k_group_ids, dim3(grid_for(n + 1, 256)), dim3(256), 0, st, (i64)n, c->d_flag.as<i32>(), c->d_scan.as<i32>(), c->s_gid.as<i32>(), c->g_beg.as<i32>());
+	{
+		OpDecodeGroup op = { (i64)n, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), qlen, c->qbits, c->prm.MaxIndelSize,
+		                     c->s_q.as<i32>(), c->s_len.as<i32>(), c->s_r.as<i64>(), c->s_gid.as<i32>(), c->g_beg.as<i32>(), c->d_mail.as<i32>() };
+		rc = lb_launch<1>(c, (i64)n, op);
+		if (rc) return rc;
+	}
 	if (c->profiling) hipEventRecord(c->ev[3], st);
 	// the group count stays on the device (mailbox); nothing downstream needs it on the host
-	GSA_CHECK(c, hipMemcpyAsync(c->d_mail.as<i32>() + M_NG, c->d_scan.as<i32>() + n, sizeof(i32), hipMemcpyDeviceToDevice, st));
 	c->n_groups = -1;
 	c->ev_pending |= 1;
 	return GSA_OK;
