@@ -13,6 +13,7 @@
 #include <algorithm>
 #include "gsa_ctx.h"
 #include "gsa_dp.h"
+#include "gsa_scan.h"
 
 #define SMALL_ROWS 128
 #define SMALL_WAVES 4
@@ -300,81 +301,132 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 	for (int q2 = lane; q2 < k; q2 += 64) op[q2] = rev[k - 1 - q2];
 }
 
-// All pointers are device pointers.  Jobs that do not fit the small kernel are processed in
-// batches so that the direction bytes of one batch fit the budget.
-int run_ksw2_jobs(gsa_ctx *c, i32 n, const uint8_t *pool1, const i64 *off1, const i32 *len1,
+// Size classes on the device: one fused pass (gsa_scan.h) lists the jobs that need the striped kernel
+// as (job, m, n) triples and packs the others into the small kernel's order array.
+struct OpClassify {
+	const i32 *len1, *len2; i32 *order, *lg, *mail;
+	__device__ i32 value(i64 j, int) const
+	{
+		if (j >= mail[M_NJOB]) return 0;
+		const i32 m = len1[j], n = len2[j];
+		return (n <= 64 && m + n - 1 <= SMALL_ROWS) ? 0 : 1;
+	}
+	__device__ void emit(i64 j, const i32 *v, const i32 *ex) const
+	{
+		if (j >= mail[M_NJOB]) return;
+		const i32 m = len1[j], n = len2[j];
+		if (m <= 0 || n <= 0) mail[M_DPERR] = 2;
+		if (v[0]) { i32 *e = lg + 3 * (size_t)ex[0]; e[0] = (i32)j; e[1] = m; e[2] = n; }
+		else order[j - ex[0]] = (i32)j;
+	}
+	__device__ void done(const i32 *t) const { mail[M_NLARGE] = t[0]; }
+};
+
+// sum of m*n over the jobs (measurement only)
+__global__ void k_dp_cells(const i32 *__restrict__ mail, const i32 *__restrict__ len1, const i32 *__restrict__ len2, unsigned long long *out)
+{
+	const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	unsigned long long v = j < mail[M_NJOB] ? (unsigned long long)len1[j] * (unsigned long long)len2[j] : 0;
+	for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+	if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+#define LG_CHUNK 2048       // large-job triples copied together with the mailbox (more -> a second copy)
+
+// All pointers are device pointers; the job count sits in mail[M_NJOB] (<= n_ub).  Jobs that do not fit
+// the small kernel are processed in batches so that the direction bytes of one batch fit the budget.
+// Returns with the work enqueued: errors of the last batch land in the mailbox (M_DPERR, M_DPERR2).
+int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, const i32 *len1,
                   const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total)
 {
-	if (n <= 0) return GSA_OK;
+	if (n_ub <= 0) return GSA_OK;
 	hipStream_t st = c->stream;
-	std::vector<i32> h_len1((size_t)n), h_len2((size_t)n);
-	GSA_CHECK(c, hipMemcpyAsync(h_len2.data(), len2, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipMemcpyAsync(h_len1.data(), len1, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipStreamSynchronize(st));
-	std::vector<i32> small, large, empty;
-	int mmax = 1;
-	for (i32 i = 0; i < n; i++) {
-		const i64 m = h_len1[i], nn = h_len2[i];
-		c->counters[4] += (u64)(m * nn); c->counters[6] += (u64)(m + nn);
-		if (m <= 0 || nn <= 0) empty.push_back(i);
-		else if (nn <= 64 && m + nn - 1 <= SMALL_ROWS) small.push_back(i);
-		else { large.push_back(i); if (m > mmax) mmax = (int)m; }
+	i32 *mail = c->d_mail.as<i32>();
+	i32 *d_order = dev_ensure<i32>(c, c->d_flag2, (size_t)n_ub + 2);
+	i32 *d_lg = dev_ensure<i32>(c, c->d_dp_large, 3 * ((size_t)n_ub + 1));
+	uint8_t *rev = dev_ensure<uint8_t>(c, c->d_i64a, (size_t)ops_total + 64);
+	if (!d_order || !d_lg || !rev) return GSA_ERR_NOMEM;
+	if (!pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * LG_CHUNK)) return GSA_ERR_NOMEM;
+	GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR, 0, 3 * sizeof(i32), st));                    // M_DPERR, M_NLARGE, M_DPERR2
+	{ OpClassify op = { len1, len2, d_order, d_lg, mail }; int rc = lb_launch<1>(c, n_ub, op); if (rc) return rc; }
+	if (c->profiling) {
+		GSA_CHECK(c, hipMemsetAsync(mail + M_CELLS, 0, 8, st));
+		hipLaunchKernelGGL(k_dp_cells, dim3(grid_for((size_t)n_ub, 256)), dim3(256), 0, st, mail, len1, len2, (unsigned long long *)(mail + M_CELLS));
 	}
-	c->counters[5] += (u64)n;
-	if (!empty.empty()) return gsa_fail(c, GSA_ERR_ARG, "DP job with an empty side");
-	auto by_cells = [&](i32 a, i32 b) { const i64 ca = (i64)h_len1[a] * h_len2[a], cb = (i64)h_len1[b] * h_len2[b]; return ca != cb ? ca > cb : a < b; };
-	std::sort(large.begin(), large.end(), by_cells);     // largest first: they are the critical path (the small ones need no order)
+	i32 *h = c->p_dp.as<i32>();
+	const size_t first_lg = (size_t)std::min<i64>(n_ub, LG_CHUNK);
+	GSA_CHECK(c, hipMemcpyAsync(h, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
+	GSA_CHECK(c, hipMemcpyAsync(h + MAIL_N, d_lg, first_lg * 12, hipMemcpyDeviceToHost, st));
+	GSA_CHECK(c, hipStreamSynchronize(st));
+	if (h[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
+	if (h[M_DPERR]) return gsa_fail(c, GSA_ERR_ARG, "DP job with an empty side");
+	const i32 n = h[M_NJOB], nlarge = h[M_NLARGE], nsmall = n - nlarge;
+	if (n <= 0) return GSA_OK;
+	c->counters[5] += (u64)n; c->counters[6] += (u64)(u32)h[M_OPSTOT];
+	if (c->profiling) c->counters[4] += *(const unsigned long long *)(h + M_CELLS);
+	if ((size_t)nlarge > first_lg) {
+		if (!pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * (size_t)nlarge)) return GSA_ERR_NOMEM;
+		h = c->p_dp.as<i32>();
+		GSA_CHECK(c, hipMemcpyAsync(h + MAIL_N, d_lg, (size_t)nlarge * 12, hipMemcpyDeviceToHost, st));
+		GSA_CHECK(c, hipStreamSynchronize(st));
+	}
+	struct Lg { i32 job, m, n; };
+	std::vector<Lg> large((const Lg *)(h + MAIL_N), (const Lg *)(h + MAIL_N) + nlarge);
+	std::sort(large.begin(), large.end(), [](const Lg &a, const Lg &b) { const i64 ca = (i64)a.m * a.n, cb = (i64)b.m * b.n; return ca != cb ? ca > cb : a.job < b.job; });   // largest first: they are the critical path
+	int mmax = 1;
+	for (const Lg &g : large) if (g.m > mmax) mmax = g.m;
 	const int mpad = (mmax + 64 + 63) & ~63;
 	if (mpad > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 153600 bases");
-	i32 *d_order = dev_ensure<i32>(c, c->d_flag2, (size_t)n + 1);
-	uint8_t *rev = dev_ensure<uint8_t>(c, c->d_i64a, (size_t)ops_total + 64);
-	if (!d_order || !rev) return GSA_ERR_NOMEM;
 	hipEvent_t ev_fork = c->ev[10], ev_j2 = c->ev[12];
 	// the many small jobs run on a second stream, concurrently with the striped ones
-	if (!small.empty()) {
-		GSA_CHECK(c, hipMemcpyAsync(d_order, small.data(), small.size() * 4, hipMemcpyHostToDevice, st));
+	if (nsmall > 0) {
 		GSA_CHECK(c, hipEventRecord(ev_fork, st));
 		GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], ev_fork, 0));
-		const unsigned nb = (unsigned)((small.size() + SMALL_WAVES - 1) / SMALL_WAVES);
-		hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, c->stream_aux[1], (i32)small.size(), d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len);
+		const unsigned nb = (unsigned)((nsmall + SMALL_WAVES - 1) / SMALL_WAVES);
+		hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, c->stream_aux[1], nsmall, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len);
 		GSA_CHECK(c, hipGetLastError());
 		GSA_CHECK(c, hipEventRecord(ev_j2, c->stream_aux[1]));
 	}
 	const i64 budget = 12ll << 30;
-	std::vector<StripeJob> sj;
 	size_t first = 0;
 	while (first < large.size()) {
-		sj.clear();
+		// descriptors are staged in pinned memory: the upload is asynchronous
+		size_t cnt = 0;
+		{ size_t l = first; i64 db = 128; while (l < large.size()) { const i64 cells = (((i64)large[l].n + 63) / 64) * ((i64)large[l].m + 63) * 64; if (l > first && db + cells > budget) break; db += cells + 128; l++; } cnt = l - first; }
+		if (!pin_ensure<StripeJob>(c, c->p_sj, cnt + 1)) return GSA_ERR_NOMEM;
+		StripeJob *sj = c->p_sj.as<StripeJob>();
 		i64 dbytes = 128, bwords = 0; i32 nctr = 1, nblocks = 0;
-		size_t last = first;
-		while (last < large.size()) {
-			const i32 jb = large[last]; const i64 m = h_len1[jb], nn = h_len2[jb], cells = ((nn + 63) / 64) * (m + 63) * 64;   // stripe-local direction bytes
-			if (last > first && dbytes + cells > budget) break;
-			StripeJob s; s.job = jb; s.m = (i32)m; s.n = (i32)nn; s.P = (i32)((nn + 63) / 64);
+		for (size_t k = 0; k < cnt; k++) {
+			const Lg &g = large[first + k];
+			const i64 cells = (((i64)g.n + 63) / 64) * ((i64)g.m + 63) * 64;   // stripe-local direction bytes
+			StripeJob s; s.job = g.job; s.m = g.m; s.n = g.n; s.P = (g.n + 63) / 64;
 			s.diroff = dbytes; dbytes += cells + 128;
-			s.bndoff = bwords; bwords += (i64)(s.P - 1) * m;
+			s.bndoff = bwords; bwords += (i64)(s.P - 1) * g.m;
 			s.ctr = nctr++; s.first_block = nblocks; nblocks += s.P;
-			sj.push_back(s); last++;
+			sj[k] = s;
 		}
+		const size_t last = first + cnt;
 		uint8_t *dir = dev_ensure<uint8_t>(c, c->d_scan2, (size_t)dbytes + 512);
 		u32 *bnd = dev_ensure<u32>(c, c->d_dp_bnd, (size_t)bwords + 64);
 		u32 *ctr = dev_ensure<u32>(c, c->d_dp_ctr, (size_t)nctr + 64);
-		StripeJob *d_sj = dev_ensure<StripeJob>(c, c->d_dp_jobs, sj.size() + 1);
+		StripeJob *d_sj = dev_ensure<StripeJob>(c, c->d_dp_jobs, cnt + 1);
 		if (!dir || !bnd || !ctr || !d_sj) return GSA_ERR_NOMEM;
 		GSA_CHECK(c, hipMemsetAsync(bnd, 0, ((size_t)bwords + 64) * 4, st));
 		GSA_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nctr + 64) * 4, st));
-		GSA_CHECK(c, hipMemcpyAsync(d_sj, sj.data(), sj.size() * sizeof(StripeJob), hipMemcpyHostToDevice, st));
-		hipLaunchKernelGGL(k_dp_stripe, dim3((unsigned)nblocks), dim3(64), (size_t)mpad, st, (i32)sj.size(), d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len);
+		GSA_CHECK(c, hipMemcpyAsync(d_sj, sj, cnt * sizeof(StripeJob), hipMemcpyHostToDevice, st));
+		hipLaunchKernelGGL(k_dp_stripe, dim3((unsigned)nblocks), dim3(64), (size_t)mpad, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len);
 		GSA_CHECK(c, hipGetLastError());
-		u32 h_err = 0;
-		GSA_CHECK(c, hipMemcpyAsync(&h_err, ctr, 4, hipMemcpyDeviceToHost, st));
-		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (sj.size() == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })
-		GSA_CHECK(c, hipStreamSynchronize(st));       // also: the staging vector and the direction buffer are reused by the next batch
-		if (h_err) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
+		GSA_CHECK(c, hipMemcpyAsync(mail + M_DPERR2, ctr, 4, hipMemcpyDeviceToDevice, st));
+		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })
+		if (last < large.size()) {
+			// the staging buffer and the direction bytes are reused by the next batch
+			GSA_CHECK(c, hipMemcpyAsync(h, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
+			GSA_CHECK(c, hipStreamSynchronize(st));
+			if (h[M_DPERR2]) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
+		}
 		first = last;
 	}
-	if (!small.empty()) GSA_CHECK(c, hipStreamWaitEvent(st, ev_j2, 0));
-	GSA_CHECK(c, hipStreamSynchronize(st));
+	if (nsmall > 0) GSA_CHECK(c, hipStreamWaitEvent(st, ev_j2, 0));
 	return GSA_OK;
 }
 
@@ -400,11 +452,16 @@ extern "C" int gsa_ksw2_batch(gsa_ctx *c, int32_t n_pairs, const char *pool1, co
 	GSA_CHECK(c, hipMemcpyAsync(d_o1, off1, n * 8, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(d_o2, off2, n * 8, hipMemcpyHostToDevice, st));
 	GSA_CHECK(c, hipMemcpyAsync(d_oo, ops_off, n * 8, hipMemcpyHostToDevice, st));
 	GSA_CHECK(c, hipMemcpyAsync(d_l1, len1, n * 4, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(d_l2, len2, n * 4, hipMemcpyHostToDevice, st));
+	const i32 cnts[2] = { n_pairs, (i32)po };
+	GSA_CHECK(c, hipMemcpyAsync(c->d_mail.as<i32>() + M_NJOB, cnts, 8, hipMemcpyHostToDevice, st));      // M_NJOB, M_OPSTOT
 	int rc = run_ksw2_jobs(c, n_pairs, d_p1, d_o1, d_l1, d_p2, d_o2, d_l2, d_ops, d_oo, d_ol, po);
 	if (rc == GSA_OK) {
+		i32 err = 0;
 		GSA_CHECK(c, hipMemcpyAsync(ops, d_ops, po, hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipMemcpyAsync(ops_len, d_ol, n * 4, hipMemcpyDeviceToHost, st));
+		GSA_CHECK(c, hipMemcpyAsync(&err, c->d_mail.as<i32>() + M_DPERR2, 4, hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipStreamSynchronize(st));
+		if (err) rc = gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
 	}
 	hipFree(d_p1); hipFree(d_p2); hipFree(d_ops); hipFree(d_o1); hipFree(d_o2); hipFree(d_oo); hipFree(d_l1); hipFree(d_l2); hipFree(d_ol);
 	return rc;

@@ -1,7 +1,7 @@
 // gsalign_amd/csrc/k_gapsim.hip -- gap similarity test (a9).
 //
 // Replaces CalGapSimilarity / CreateKmerVecFromReadSeq / CreateKmerID
-// (reference src/KmerAnalysis.cpp:10-17,32-76,78-121).  One wavefront per gap:
+// (reference src/KmerAnalysis.cpp:10-17,32-76,78-121).  One 256-thread workgroup per gap:
 //   * flanks on one diagonal: count positions with equal codes (or an N on
 //     either side); similar if count >= q_len*0.5;
 //   * otherwise (both windows <= 5000): multiset intersection of the 5-mer ids of
@@ -15,6 +15,7 @@
 #include "gsa_fm.h"
 
 #define KBINS 1376          // max id: 4*(256+64+16+4+1) = 1364
+#define GS_T 256            // threads per gap (the longest window, 5000 bases, sets the kernel's duration)
 
 __device__ __forceinline__ u32 kmer_id_direct(const uint8_t *s, int pos)       // CreateKmerID, no masking
 {
@@ -23,16 +24,21 @@ __device__ __forceinline__ u32 kmer_id_direct(const uint8_t *s, int pos)       /
 	return id;
 }
 
-// one window -> histogram (all 64 lanes call)
-__device__ void kmer_hist(const uint8_t *__restrict__ s, int len, u32 *hist, int lane)
+// one window -> histogram (all GS_T threads call)
+__device__ void kmer_hist(const uint8_t *__restrict__ s, int len, u32 *hist, int lane, int *s_flag)
 {
 	// does the window contain a literal 'N'?
+	if (lane == 0) *s_flag = 0;
+	__syncthreads();
 	int hasN = 0;
-	for (int p = lane; p < len; p += 64) hasN |= (s[p] == 'N');
-	hasN = __any(hasN);
+	for (int p = lane; p < len; p += GS_T) hasN |= (s[p] == 'N');
+	if (hasN) *s_flag = 1;
+	__syncthreads();
+	hasN = *s_flag;
+	__syncthreads();
 	if (!hasN) {
 		// wid_0 = direct id; wid_p (p>=1) = ((wid_{p-1} & 0xFF) << 2) + v[p+4], which depends on v[p..p+4] only
-		for (int p = lane; p + 5 <= len; p += 64) {
+		for (int p = lane; p + 5 <= len; p += GS_T) {
 			u32 id;
 			if (p == 0) id = kmer_id_direct(s, 0);
 			else {
@@ -60,34 +66,44 @@ __device__ void kmer_hist(const uint8_t *__restrict__ s, int len, u32 *hist, int
 	}
 }
 
-__global__ void __launch_bounds__(64) k_gapsim(DevIndex di, const uint8_t *__restrict__ query, i32 n, const i32 *__restrict__ q1a, const i32 *__restrict__ q2a,
+__global__ void __launch_bounds__(GS_T) k_gapsim(DevIndex di, const uint8_t *__restrict__ query, i32 n, const i32 *__restrict__ q1a, const i32 *__restrict__ q2a,
                                                 const i64 *__restrict__ r1a, const i64 *__restrict__ r2a, i32 *res)
 {
 	__shared__ u32 h1[KBINS], h2[KBINS];
+	__shared__ int s_acc, s_flag;
 	const int job = blockIdx.x, lane = threadIdx.x;
 	if (job >= n) return;
 	const i32 q1 = q1a[job], q2 = q2a[job]; const i64 r1 = r1a[job], r2 = r2a[job];
 	const int q_len = q2 - q1, r_len = (int)(r2 - r1);
 	bool sim = false;
+	if (lane == 0) s_acc = 0;
+	__syncthreads();
 	if (r1 - q1 == r2 - q2) {
 		int idy = 0;
-		for (int p = lane; p < q_len; p += 64) {
+		for (int p = lane; p < q_len; p += GS_T) {
 			const int a = gsa_nt4(di.ref[r1 + p]), b = gsa_nt4(query[q1 + p]);
 			idy += (a == b || a == 4 || b == 4);
 		}
 		for (int o = 32; o; o >>= 1) idy += __shfl_xor(idy, o);
-		if ((double)idy >= q_len * 0.5) sim = true;
+		if ((lane & 63) == 0 && idy) atomicAdd(&s_acc, idy);
+		__syncthreads();
+		if ((double)s_acc >= q_len * 0.5) sim = true;
+		__syncthreads();
+		if (lane == 0) s_acc = 0;
+		__syncthreads();
 	}
 	if (!sim && q_len <= GSA_MAX_SEED_GAP && r_len <= GSA_MAX_SEED_GAP) {
-		for (int b = lane; b < KBINS; b += 64) { h1[b] = 0; h2[b] = 0; }
+		for (int b = lane; b < KBINS; b += GS_T) { h1[b] = 0; h2[b] = 0; }
 		__syncthreads();
-		kmer_hist(query + q1, q_len, h1, lane);
-		kmer_hist(di.ref + r1, r_len, h2, lane);
+		kmer_hist(query + q1, q_len, h1, lane, &s_flag);
+		kmer_hist(di.ref + r1, r_len, h2, lane, &s_flag);
 		__syncthreads();
 		int common = 0;
-		for (int b = lane; b < KBINS; b += 64) common += (int)(h1[b] < h2[b] ? h1[b] : h2[b]);
+		for (int b = lane; b < KBINS; b += GS_T) common += (int)(h1[b] < h2[b] ? h1[b] : h2[b]);
 		for (int o = 32; o; o >>= 1) common += __shfl_xor(common, o);
-		if ((double)common > (q_len + r_len) * 0.1) sim = true;
+		if ((lane & 63) == 0 && common) atomicAdd(&s_acc, common);
+		__syncthreads();
+		if ((double)s_acc > (q_len + r_len) * 0.1) sim = true;
 	}
 	if (lane == 0) res[job] = sim ? 1 : 0;
 }
@@ -95,7 +111,7 @@ __global__ void __launch_bounds__(64) k_gapsim(DevIndex di, const uint8_t *__res
 int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res)
 {
 	if (n <= 0) return GSA_OK;
-	hipLaunchKernelGGL(k_gapsim, dim3(n), dim3(64), 0, c->stream, c->di, c->d_query.as<uint8_t>(), n, d_q1, d_q2, d_r1, d_r2, d_res);
+	hipLaunchKernelGGL(k_gapsim, dim3(n), dim3(GS_T), 0, c->stream, c->di, c->d_query.as<uint8_t>(), n, d_q1, d_q2, d_r1, d_r2, d_res);
 	GSA_CHECK(c, hipGetLastError());
 	return GSA_OK;
 }
