@@ -15,8 +15,7 @@
 #include "gsa_ctx.h"
 
 #define LB_TPB 256
-#define LB_ITEMS 4
-#define LB_TILE (LB_TPB * LB_ITEMS)
+#define LB_ITEMS 4          // elements per thread (default; passes with heavy per-element work use 1)
 
 struct LbArgs {
 	unsigned long long *status[2];   // tile status words, one array per scanned component
@@ -65,20 +64,21 @@ __device__ __forceinline__ i32 lb_tile_prefix(const LbArgs &lb, int comp, int ti
 // Generic fused pass over i in [0, n):  v = op.value(i, k)  (NV components, k < NV),
 // ex = exclusive prefix sums, then op.emit(i, v, ex);  op.done(totals) once, by the thread
 // that owns the last element (or thread 0 of tile 0 when n == 0).
-template <int NV, class Op>
+template <int NV, class Op, int ITEMS>
 __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 {
+	constexpr int LB_TILE = LB_TPB * ITEMS;
 	__shared__ i32 s_tile, s_bcast[2], s_wsum[2][LB_TPB / 64];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	if (tid == 0) s_tile = (i32)(atomicAdd(lb.ticket, 1u) - lb.base);
 	__syncthreads();
 	const int tile = s_tile;
-	const i64 i0 = (i64)tile * LB_TILE + (i64)tid * LB_ITEMS;
-	i32 v[NV][LB_ITEMS], tsum[NV];
+	const i64 i0 = (i64)tile * LB_TILE + (i64)tid * ITEMS;
+	i32 v[NV][ITEMS], tsum[NV];
 #pragma unroll
 	for (int c = 0; c < NV; c++) tsum[c] = 0;
 #pragma unroll
-	for (int k = 0; k < LB_ITEMS; k++) {
+	for (int k = 0; k < ITEMS; k++) {
 		const i64 i = i0 + k;
 #pragma unroll
 		for (int c = 0; c < NV; c++) { v[c][k] = i < n ? op.value(i, c) : 0; tsum[c] += v[c][k]; }
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 	for (int c = 0; c < NV; c++) toff[c] += pre[c];
 	i32 vv[NV], ee[NV];
 #pragma unroll
-	for (int k = 0; k < LB_ITEMS; k++) {
+	for (int k = 0; k < ITEMS; k++) {
 		const i64 i = i0 + k;
 #pragma unroll
 		for (int c = 0; c < NV; c++) { vv[c] = v[c][k]; ee[c] = toff[c]; toff[c] += v[c][k]; }
@@ -120,9 +120,10 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 }
 
 // host side: one fused pass on the context's stream
-template <int NV, class Op>
+template <int NV, int ITEMS = LB_ITEMS, class Op>
 static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op)
 {
+	constexpr i64 LB_TILE = (i64)LB_TPB * ITEMS;
 	const size_t tiles = n > 0 ? (size_t)((n + LB_TILE - 1) / LB_TILE) : 1;
 	for (int k = 0; k < 2; k++) {
 		if (c->d_lb_status[k].cap < tiles * 8) {
@@ -138,7 +139,7 @@ static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op)
 	LbArgs lb;
 	lb.status[0] = c->d_lb_status[0].as<unsigned long long>(); lb.status[1] = c->d_lb_status[1].as<unsigned long long>();
 	lb.ticket = c->d_mail.as<u32>() + M_TICKET; lb.base = c->lb_base; lb.epoch = c->lb_epoch; lb.err = c->d_mail.as<i32>() + M_LBERR;
-	hipLaunchKernelGGL((k_lb_pass<NV, Op>), dim3((unsigned)tiles), dim3(LB_TPB), 0, c->stream, n, op, lb);
+	hipLaunchKernelGGL((k_lb_pass<NV, Op, ITEMS>), dim3((unsigned)tiles), dim3(LB_TPB), 0, c->stream, n, op, lb);
 	GSA_CHECK(c, hipGetLastError());
 	c->lb_base += (u32)tiles;
 	return GSA_OK;

@@ -116,44 +116,82 @@ struct OpRecSums {
 	__device__ void done(const i32 *t) const { ps_len[n] = (u32)t[0]; ps_score[n] = (u32)t[1]; }
 };
 
-// one wavefront per record: write aln1/aln2 and the record's (aln_len, score) contribution
-__global__ void __launch_bounds__(64) k_materialize(const i32 *__restrict__ nf_ptr, const i32 *__restrict__ ftype, const i32 *__restrict__ fmism, const i32 *__restrict__ fjob,
-                                                     const i32 *__restrict__ alen, const i64 *__restrict__ aoff, const uint8_t *__restrict__ ops,
-                                                     const i64 *__restrict__ opsoff, const uint8_t *__restrict__ query, const uint8_t *__restrict__ ref,
-                                                     gsa_frag *frag, uint8_t *aln1, uint8_t *aln2, i32 *c_len, i32 *c_score)
+// Gapped strings and the records' (aln_len, score) contributions.  256 records per workgroup: a thread
+// settles its own record when it is a seed or a short gap (the bulk: median gap 11 bases); longer gaps
+// are queued in LDS and written by whole wavefronts.
+#define MAT_SERIAL 32
+__global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_ptr, const i32 *__restrict__ ftype, const i32 *__restrict__ fmism, const i32 *__restrict__ fjob,
+                                                      const i32 *__restrict__ alen, const i64 *__restrict__ aoff, const uint8_t *__restrict__ ops,
+                                                      const i64 *__restrict__ opsoff, const uint8_t *__restrict__ query, const uint8_t *__restrict__ ref,
+                                                      gsa_frag *frag, uint8_t *aln1, uint8_t *aln2, i32 *c_len, i32 *c_score)
 {
-	const i64 i = blockIdx.x;
-	if (i >= nf_ptr[0]) return;
-	const int lane = threadIdx.x;
-	const i32 t = ftype[i];
-	const gsa_frag f = frag[i];
-	const i64 o = aoff[i]; const i32 L = alen[i];
-	if (t == FT_SEED) { if (lane == 0) { c_len[i] = f.qlen; c_score[i] = f.qlen; } return; }
-	const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos;
-	i32 score = 0;
-	if (t == FT_DEL) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = rs[p]; aln2[o + p] = '-'; } }
-	else if (t == FT_INS) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = '-'; aln2[o + p] = qs[p]; } }
-	else if (t == FT_EQ) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = rs[p]; aln2[o + p] = qs[p]; } score = f.qlen - fmism[i]; }
-	else {
-		// ops are forward M/D/I; 'D' puts '-' into aln1, 'I' into aln2 (ksw2_alignment.cpp:264-272)
-		const uint8_t *op = ops + opsoff[fjob[i]];
-		i32 i1 = 0, i2 = 0;                      // consumed bases of the reference / query fragment so far
-		for (i32 base = 0; base < L; base += 64) {
-			const i32 p = base + lane;
-			const uint8_t ch = p < L ? op[p] : 0;
-			const int c1 = (ch == 'M' || ch == 'I') ? 1 : 0, c2 = (ch == 'M' || ch == 'D') ? 1 : 0;
-			int s1 = c1, s2 = c2;                 // inclusive wave prefix sums
-			for (int d = 1; d < 64; d <<= 1) { int a = __shfl_up(s1, d), b = __shfl_up(s2, d); if (lane >= d) { s1 += a; s2 += b; } }
-			if (p < L) {
-				const uint8_t a1 = c1 ? rs[i1 + s1 - 1] : '-', a2 = c2 ? qs[i2 + s2 - 1] : '-';
-				aln1[o + p] = a1; aln2[o + p] = a2;
-				score += (gsa_nt4(a1) == gsa_nt4(a2));             // CountIdenticalPairs (:38-47)
+	__shared__ i32 s_list[256];
+	__shared__ int s_n;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const i64 nf = nf_ptr[0];
+	if (tid == 0) s_n = 0;
+	__syncthreads();
+	{
+		const i64 i = (i64)blockIdx.x * 256 + tid;
+		if (i < nf) {
+			const i32 t = ftype[i];
+			if (t == FT_SEED) { const i32 l = frag[i].qlen; c_len[i] = l; c_score[i] = l; }
+			else if (alen[i] > MAT_SERIAL) s_list[atomicAdd(&s_n, 1)] = tid;
+			else {
+				const gsa_frag f = frag[i];
+				const i64 o = aoff[i]; const i32 L = alen[i];
+				const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos;
+				i32 score = 0;
+				if (t == FT_DEL) { for (i32 p = 0; p < L; p++) { aln1[o + p] = rs[p]; aln2[o + p] = '-'; } }
+				else if (t == FT_INS) { for (i32 p = 0; p < L; p++) { aln1[o + p] = '-'; aln2[o + p] = qs[p]; } }
+				else if (t == FT_EQ) { for (i32 p = 0; p < L; p++) { aln1[o + p] = rs[p]; aln2[o + p] = qs[p]; } score = f.qlen - fmism[i]; }
+				else {
+					// ops are forward M/D/I; 'D' puts '-' into aln1, 'I' into aln2 (ksw2_alignment.cpp:264-272)
+					const uint8_t *op = ops + opsoff[fjob[i]];
+					i32 i1 = 0, i2 = 0;
+					for (i32 p = 0; p < L; p++) {
+						const uint8_t ch = op[p];
+						const uint8_t a1 = (ch == 'M' || ch == 'I') ? rs[i1++] : (uint8_t)'-', a2 = (ch == 'M' || ch == 'D') ? qs[i2++] : (uint8_t)'-';
+						aln1[o + p] = a1; aln2[o + p] = a2;
+						score += (gsa_nt4(a1) == gsa_nt4(a2));             // CountIdenticalPairs (:38-47)
+					}
+				}
+				c_len[i] = L; c_score[i] = score; frag[i].aln_off = o; frag[i].aln_len = L;
 			}
-			i1 += __shfl(s1, 63); i2 += __shfl(s2, 63);
 		}
-		for (int d = 32; d; d >>= 1) score += __shfl_xor(score, d);
 	}
-	if (lane == 0) { c_len[i] = L; c_score[i] = score; frag[i].aln_off = o; frag[i].aln_len = L; }
+	__syncthreads();
+	const int nlist = s_n;
+	for (int g = wv; g < nlist; g += 4) {
+		const i64 i = (i64)blockIdx.x * 256 + s_list[g];
+		const i32 t = ftype[i];
+		const gsa_frag f = frag[i];
+		const i64 o = aoff[i]; const i32 L = alen[i];
+		const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos;
+		i32 score = 0;
+		if (t == FT_DEL) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = rs[p]; aln2[o + p] = '-'; } }
+		else if (t == FT_INS) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = '-'; aln2[o + p] = qs[p]; } }
+		else if (t == FT_EQ) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = rs[p]; aln2[o + p] = qs[p]; } score = f.qlen - fmism[i]; }
+		else {
+			const uint8_t *op = ops + opsoff[fjob[i]];
+			i32 i1 = 0, i2 = 0;                      // consumed bases of the reference / query fragment so far
+			for (i32 base = 0; base < L; base += 64) {
+				const i32 p = base + lane;
+				const uint8_t ch = p < L ? op[p] : 0;
+				const int c1 = (ch == 'M' || ch == 'I') ? 1 : 0, c2 = (ch == 'M' || ch == 'D') ? 1 : 0;
+				int s1 = c1, s2 = c2;                 // inclusive wave prefix sums
+				for (int d = 1; d < 64; d <<= 1) { int a = __shfl_up(s1, d), b = __shfl_up(s2, d); if (lane >= d) { s1 += a; s2 += b; } }
+				if (p < L) {
+					const uint8_t a1 = c1 ? rs[i1 + s1 - 1] : '-', a2 = c2 ? qs[i2 + s2 - 1] : '-';
+					aln1[o + p] = a1; aln2[o + p] = a2;
+					score += (gsa_nt4(a1) == gsa_nt4(a2));
+				}
+				i1 += __shfl(s1, 63); i2 += __shfl(s2, 63);
+			}
+			for (int d = 32; d; d >>= 1) score += __shfl_xor(score, d);
+		}
+		if (lane == 0) { c_len[i] = L; c_score[i] = score; frag[i].aln_off = o; frag[i].aln_len = L; }
+	}
 }
 
 __global__ void k_block_sums(i32 nfb, const i32 *__restrict__ nf_ptr, const i32 *__restrict__ fragbase, const u32 *__restrict__ ps_len, const u32 *__restrict__ ps_score, i32 *bl_len, i32 *bl_score)
@@ -203,7 +241,7 @@ int stage7_fill(gsa_ctx *c)
 	ENS(gsa_frag, f_rec, nfu + 1); ENS(i32, f_type, nfu + 1); ENS(i32, f_mism, nfu + 1); ENS(i32, f_score, nfu + 1); ENS(i32, f_job, nfu + 1); ENS(i32, f_alnlen, nfu + 1);
 	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), c->fb_sbeg.as<i32>(), c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
 	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), c->fb_fragbase.as<i32>(), c->d_mail.as<i32>() };
-	RC((lb_launch<1>(c, ns, op)));
+	RC((lb_launch<1, 1>(c, ns, op)));      // (one slot per thread: the mismatch count of a gap is a serial loop)
 	c->n_frags = -1;
 	return GSA_OK;
 }
@@ -230,7 +268,7 @@ int stage78_extend(gsa_ctx *c)
 	ENS(uint8_t, d_aln1, c->span_ub + 64); ENS(uint8_t, d_aln2, c->span_ub + 64);
 	ENS(i32, d_flag, nfu + 2);
 	i32 *c_len = c->d_flag.as<i32>(), *c_score = c->f_score.as<i32>();
-	hipLaunchKernelGGL(k_materialize, dim3((unsigned)nfu), dim3(64), 0, st, mail + M_NF, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(), c->f_alnlen.as<i32>(),
+	hipLaunchKernelGGL(k_materialize, dim3((unsigned)((nfu + 255) / 256)), dim3(256), 0, st, mail + M_NF, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(), c->f_alnlen.as<i32>(),
 	                   c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
 	                   c->f_rec.as<gsa_frag>(), c->d_aln1.as<uint8_t>(), c->d_aln2.as<uint8_t>(), c_len, c_score);
 	// per-block sums via prefix sums
