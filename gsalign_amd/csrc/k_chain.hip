@@ -92,7 +92,7 @@ struct OpCand {
 // candidate behind it (the head of the next big group) or to na
 __global__ void k_next_window(i64 na, const i32 *__restrict__ a_q, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge,
                               const i32 *__restrict__ uniq, const i32 *__restrict__ cuEx, const i32 *__restrict__ brk, const i32 *__restrict__ brkEx,
-                              const i32 *__restrict__ blist, const i32 *__restrict__ candf, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, i32 *next)
+                              const i32 *__restrict__ blist, const i32 *__restrict__ candf, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, i32 *next, i32 *nextk)
 {
 	GID(na);
 	if (!candf[i]) { next[i] = -1; return; }
@@ -109,8 +109,9 @@ __global__ void k_next_window(i64 na, const i32 *__restrict__ a_q, const i32 *__
 	const i32 j0 = j1 > lo ? j1 : lo;
 	i32 nx = ge;
 	if (j0 < ge) { const i32 nB = brkEx[na]; const i32 k = brkEx[j0]; if (k < nB) { const i32 cand = blist[k]; if (cand < ge) nx = cand; } }
-	if (nx == ge) { const i32 k = candEx[ge]; nx = k < candEx[na] ? clist[k] : (i32)na; }
-	next[i] = nx;
+	i32 nk = candEx[nx];                                   // the same hop in candidate ranks (the walk's LDS form)
+	if (nx == ge) { nk = candEx[ge]; nx = nk < candEx[na] ? clist[nk] : (i32)na; }
+	next[i] = nx; nextk[candEx[i]] = nk;
 }
 
 // Greedy window segmentation.  chain(p) = next[p] runs through every candidate that is a window
@@ -121,14 +122,59 @@ __global__ void k_next_window(i64 na, const i32 *__restrict__ a_q, const i32 *__
 // moves, and only then marks the starts.  Exactly the reference's segmentation (GSAlign.cpp:326-338).
 #define WALK_T 1024
 #define WALK_MAXTILES 8192
-__global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, const i32 *__restrict__ next, i32 *ws)
+#define WALK_LDS_CAND 24576      // up to this many candidates the chain itself sits in LDS (16-bit hop lengths, with 2048 tiles)
+__global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, const i32 *__restrict__ next, const i32 *__restrict__ nextk, i32 *ws)
 {
-	__shared__ i32 entry[WALK_MAXTILES], exit_[WALK_MAXTILES];
+	__shared__ i32 buf[2 * WALK_MAXTILES];
 	__shared__ int changed;
 	const int tid = threadIdx.x;
+	const i32 nC = candEx[na];
+	if (nC <= WALK_LDS_CAND) {
+		// candidate space: nk[k] = rank of the next start after candidate k; a hop is one LDS read
+		uint16_t *nk = (uint16_t *)buf;                      // hop length; 0xffff = look it up in global memory
+		i32 *entry = buf + WALK_LDS_CAND / 2, *exit_ = entry + 2048;
+		i64 ts = 256; while ((na + ts - 1) / ts > 2048) ts <<= 1;
+		const int nt = (int)((na + ts - 1) / ts);
+		for (int k = tid; k < nC; k += WALK_T) { const i32 d = nextk[k] - k; nk[k] = (uint16_t)(d < 0xffff ? d : 0xffff); }
+#define WALK_HOP(k) { const i32 d_ = nk[k]; k = d_ != 0xffff ? k + d_ : nextk[k]; }
+		for (int t = tid; t < nt; t += WALK_T) { entry[t] = candEx[(i64)t * ts]; exit_[t] = -1; }
+		__syncthreads();
+		for (;;) {
+			for (int t = tid; t < nt; t += WALK_T) {
+				if (exit_[t] >= 0) continue;
+				const i64 pe = (i64)(t + 1) * ts < na ? (i64)(t + 1) * ts : na;
+				const i32 ke = candEx[pe];
+				i32 k = entry[t];
+				while (k < ke) WALK_HOP(k)
+				exit_[t] = k;
+			}
+			if (tid == 0) changed = 0;
+			__syncthreads();
+			bool moved[2];
+			for (int t = tid, q = 0; t < nt; t += WALK_T, q++) {
+				moved[q] = false;
+				if (t == 0) continue;
+				const i32 ne = exit_[t - 1];
+				if (ne != entry[t]) { entry[t] = ne; moved[q] = true; changed = 1; }
+			}
+			__syncthreads();
+			const int again = changed;
+			for (int t = tid, q = 0; t < nt; t += WALK_T, q++) if (moved[q]) exit_[t] = -1;
+			__syncthreads();
+			if (!again) break;
+		}
+		for (int t = tid; t < nt; t += WALK_T) {
+			const i64 pe = (i64)(t + 1) * ts < na ? (i64)(t + 1) * ts : na;
+			const i32 ke = candEx[pe];
+			for (i32 k = entry[t]; k < ke;) { ws[clist[k]] = 1; WALK_HOP(k) }
+		}
+#undef WALK_HOP
+		return;
+	}
+	// position space, the chain stays in global memory
+	i32 *entry = buf, *exit_ = buf + WALK_MAXTILES;
 	i64 ts = 256; while ((na + ts - 1) / ts > WALK_MAXTILES) ts <<= 1;
 	const int nt = (int)((na + ts - 1) / ts);
-	const i32 nC = candEx[na];
 	for (int t = tid; t < nt; t += WALK_T) {
 		const i32 k = candEx[(i64)t * ts];                               // first candidate at or behind the tile start
 		entry[t] = k < nC ? clist[k] : (i32)na; exit_[t] = -1;           // exit -1 = "must be (re)walked"
@@ -388,8 +434,9 @@ int stage2_chain(gsa_ctx *c)
 	{ OpUniqBrk op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, brk, alive, cuEx, brkEx, blist }; RC((lb_launch<2>(c, na, op))); }
 	i32 *candf = c->d_flag.as<i32>(), *candEx = c->d_scan.as<i32>(), *clist = c->a_runinfo.as<i32>();
 	{ OpCand op = { na, c->a_gb.as<i32>(), c->a_ge.as<i32>(), cuEx, brk, candf, candEx, clist, ws }; RC((lb_launch<1>(c, na, op))); }
-	LAUNCH(k_next_window, na, na, c->a_q.as<i32>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, cuEx, brk, brkEx, blist, candf, candEx, clist, next);
-	hipLaunchKernelGGL(k_walk_windows, dim3(1), dim3(WALK_T), 0, st, na, candEx, clist, next, ws);
+	LAUNCH(k_next_window, na, na, c->a_q.as<i32>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, cuEx, brk, brkEx, blist, candf, candEx, clist, next, c->d_flag2.as<i32>());
+	hipLaunchKernelGGL(k_walk_windows, dim3(1), dim3(WALK_T), 0, st, na, candEx, clist, next, c->d_flag2.as<i32>(), ws);
+	if (getenv("GSA_DEBUG_CHAIN")) { i32 nc_ = 0, nb_ = 0; hipStreamSynchronize(st); hipMemcpy(&nc_, candEx + na, 4, hipMemcpyDeviceToHost); hipMemcpy(&nb_, brkEx + na, 4, hipMemcpyDeviceToHost); fprintf(stderr, "[gsa] stage 2: %lld seeds, %d window-start candidates, %d breaks\n", (long long)na, nc_, nb_); }
 	// C. outliers
 	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);
 	{ OpWindowKeys op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, wsEx, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(),

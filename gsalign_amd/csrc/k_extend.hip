@@ -120,22 +120,24 @@ struct OpRecSums {
 // settles its own record when it is a seed or a short gap (the bulk: median gap 11 bases); longer gaps
 // are queued in LDS and written by whole wavefronts.
 #define MAT_SERIAL 32
+#define MAT_BLOCK 512         // DP records longer than this are written by the whole workgroup
 __global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_ptr, const i32 *__restrict__ ftype, const i32 *__restrict__ fmism, const i32 *__restrict__ fjob,
                                                       const i32 *__restrict__ alen, const i64 *__restrict__ aoff, const uint8_t *__restrict__ ops,
                                                       const i64 *__restrict__ opsoff, const uint8_t *__restrict__ query, const uint8_t *__restrict__ ref,
                                                       gsa_frag *frag, uint8_t *aln1, uint8_t *aln2, i32 *c_len, i32 *c_score)
 {
-	__shared__ i32 s_list[256];
-	__shared__ int s_n;
+	__shared__ i32 s_list[256], s_long[256];
+	__shared__ int s_n, s_nl, s_w1[4], s_w2[4], s_sc;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const i64 nf = nf_ptr[0];
-	if (tid == 0) s_n = 0;
+	if (tid == 0) { s_n = 0; s_nl = 0; }
 	__syncthreads();
 	{
 		const i64 i = (i64)blockIdx.x * 256 + tid;
 		if (i < nf) {
 			const i32 t = ftype[i];
 			if (t == FT_SEED) { const i32 l = frag[i].qlen; c_len[i] = l; c_score[i] = l; }
+			else if (alen[i] > MAT_BLOCK && t == FT_DP) s_long[atomicAdd(&s_nl, 1)] = tid;
 			else if (alen[i] > MAT_SERIAL) s_list[atomicAdd(&s_n, 1)] = tid;
 			else {
 				const gsa_frag f = frag[i];
@@ -191,6 +193,40 @@ __global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_
 			for (int d = 32; d; d >>= 1) score += __shfl_xor(score, d);
 		}
 		if (lane == 0) { c_len[i] = L; c_score[i] = score; frag[i].aln_off = o; frag[i].aln_len = L; }
+	}
+	// the few very long DP records: 256 positions per pass, prefix counts across the workgroup
+	const int nlong = s_nl;
+	for (int g = 0; g < nlong; g++) {
+		const i64 i = (i64)blockIdx.x * 256 + s_long[g];
+		const gsa_frag f = frag[i];
+		const i64 o = aoff[i]; const i32 L = alen[i];
+		const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos, *op = ops + opsoff[fjob[i]];
+		i32 i1 = 0, i2 = 0, score = 0;
+		if (tid == 0) s_sc = 0;
+		for (i32 base = 0; base < L; base += 256) {
+			const i32 p = base + tid;
+			const uint8_t ch = p < L ? op[p] : 0;
+			const int c1 = (ch == 'M' || ch == 'I') ? 1 : 0, c2 = (ch == 'M' || ch == 'D') ? 1 : 0;
+			int s1 = c1, s2 = c2;
+			for (int d = 1; d < 64; d <<= 1) { int a = __shfl_up(s1, d), b = __shfl_up(s2, d); if (lane >= d) { s1 += a; s2 += b; } }
+			__syncthreads();
+			if (lane == 63) { s_w1[wv] = s1; s_w2[wv] = s2; }
+			__syncthreads();
+			int w1 = 0, w2 = 0, t1 = 0, t2 = 0;
+			for (int w = 0; w < 4; w++) { if (w < wv) { w1 += s_w1[w]; w2 += s_w2[w]; } t1 += s_w1[w]; t2 += s_w2[w]; }
+			if (p < L) {
+				const uint8_t a1 = c1 ? rs[i1 + w1 + s1 - 1] : '-', a2 = c2 ? qs[i2 + w2 + s2 - 1] : '-';
+				aln1[o + p] = a1; aln2[o + p] = a2;
+				score += (gsa_nt4(a1) == gsa_nt4(a2));
+			}
+			i1 += t1; i2 += t2;
+		}
+		for (int d = 32; d; d >>= 1) score += __shfl_xor(score, d);
+		__syncthreads();
+		if (lane == 0 && score) atomicAdd(&s_sc, score);
+		__syncthreads();
+		if (tid == 0) { c_len[i] = L; c_score[i] = s_sc; frag[i].aln_off = o; frag[i].aln_len = L; }
+		__syncthreads();
 	}
 }
 
