@@ -140,25 +140,24 @@ int host_stage8_finish(gsa_ctx *c)
 	const size_t nfb = c->blocks.size();
 	c->h_blocks.clear(); c->h_frags.clear(); c->h_aln1.clear(); c->h_aln2.clear(); c->result_pinned = false;
 	if (nfb == 0) return GSA_OK;
-	// counts (mailbox) and per-block sums first, then records and gapped strings with their real sizes
-	if (!pin_ensure<i32>(c, c->p_blk, 3 * nfb + MAIL_N)) return GSA_ERR_NOMEM;
-	i32 *bl_len = c->p_blk.as<i32>(), *bl_score = bl_len + nfb, *fragbase = bl_score + nfb, *hm = fragbase + nfb;
-	GSA_CHECK(c, hipMemcpyAsync(bl_len, c->bl_alnlen.p, nfb * 4, hipMemcpyDeviceToHost, c->stream));
-	GSA_CHECK(c, hipMemcpyAsync(bl_score, c->bl_score.p, nfb * 4, hipMemcpyDeviceToHost, c->stream));
-	GSA_CHECK(c, hipMemcpyAsync(fragbase, c->fb_fragbase.p, nfb * 4, hipMemcpyDeviceToHost, c->stream));
-	GSA_CHECK(c, hipMemcpyAsync(hm, c->d_mail.p, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, c->stream));
+	// stage78_extend left everything in flight: per-block sums, records, patch list, string pools, mailbox
 	GSA_CHECK(c, hipStreamSynchronize(c->stream));
 	if (c->profiling) { float ms; if (hipEventElapsedTime(&ms, c->ev[8], c->ev[9]) == hipSuccess) c->kernel_ms[5] = ms; (void)hipGetLastError(); }
+	i32 *bl_len = c->p_blk.as<i32>(), *bl_score = bl_len + nfb, *fragbase = bl_score + nfb;
+	const i32 *hm = c->p_blk.as<i32>() + 3 * (nfb + 1);
 	if (hm[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	if (hm[M_DPERR2]) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
-	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN];
-	if (!pin_ensure<gsa_frag>(c, c->p_frags, (size_t)c->n_frags) || !pin_ensure<char>(c, c->p_aln1, (size_t)c->n_aln) || !pin_ensure<char>(c, c->p_aln2, (size_t)c->n_aln)) return GSA_ERR_NOMEM;
-	if (c->n_frags) GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, (size_t)c->n_frags * sizeof(gsa_frag), hipMemcpyDeviceToHost, c->stream));
-	if (c->n_aln) {
-		GSA_CHECK(c, hipMemcpyAsync(c->p_aln1.p, c->d_aln1.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, c->stream));
-		GSA_CHECK(c, hipMemcpyAsync(c->p_aln2.p, c->d_aln2.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, c->stream));
+	// the large DP jobs finished after the records left: their (aln_len, score) arrive as a patch list
+	{
+		gsa_frag *fr = c->p_frags.as<gsa_frag>();
+		const i32 *pt = c->p_patch.as<i32>();
+		for (i32 g = 0; g < c->n_large; g++) {
+			const i32 rec = pt[3 * g], L = pt[3 * g + 1], sc = pt[3 * g + 2];
+			fr[rec].aln_len = L;
+			const size_t k = (size_t)(std::upper_bound(fragbase, fragbase + nfb, rec) - fragbase) - 1;      // block of the record
+			bl_len[k] += L; bl_score[k] += sc;
+		}
 	}
-	// (the host list logic below runs while the records travel)
 	auto t0 = std::chrono::steady_clock::now();
 	std::vector<HostBlock> &B = c->blocks;
 	// keep (frag_off, n_frag) beside each block while the list is re-sorted
@@ -192,7 +191,6 @@ int host_stage8_finish(gsa_ctx *c)
 		o.bdir = B[k].bdir; o.gpos = B[k].gpos; o.chr = B[k].chr; o._pad = 0;
 	}
 	c->kernel_ms[7] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-	GSA_CHECK(c, hipStreamSynchronize(c->stream));
 	c->result_pinned = true;
 	c->frags_stage = 8;
 	return GSA_OK;

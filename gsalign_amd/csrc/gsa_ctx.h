@@ -104,6 +104,8 @@ struct gsa_ctx {
 
 	// ---- stages 7-8 ----
 	i64 n_frags = 0, n_aln = 0;                    // (n_frags < 0: still in the mailbox, see frags_count())
+	i32 n_large = 0;                               // large DP jobs of the current contig (their records are patched on the host)
+	DevBuf d_patch, p_patch;                       // (record, aln_len, score) of the large jobs: device / pinned
 	i64 nf_ub = 0, span_ub = 0;                    // host-known upper bounds: records, and bases in gaps (ops / gapped strings)
 	DevBuf fb_seedbase, fb_sbeg, fb_fragbase;      // per final block
 	DevBuf f_rec;                                  // gsa_frag records
@@ -153,7 +155,8 @@ int stage7_fill(gsa_ctx *c);          // k_extend.hip  (S6: gap records of the f
 i64 frags_count(gsa_ctx *c);          // k_extend.hip  (record count, fetched from the mailbox when still unknown)
 int stage78_extend(gsa_ctx *c);       // k_extend.hip  (S7: classification, DP, gapped strings, block sums)
 int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res);   // k_gapsim.hip
+struct Ksw2Launch { i32 n = 0, nsmall = 0, nlarge = 0; bool small_in_flight = false; };      // what run_ksw2_jobs left running
 int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, const i32 *len1,
-                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total);   // k_dp.hip
+                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total, Ksw2Launch *out);   // k_dp.hip
 
 #endif

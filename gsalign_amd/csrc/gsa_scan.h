@@ -121,25 +121,26 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 
 // host side: one fused pass on the context's stream
 template <int NV, int ITEMS = LB_ITEMS, class Op>
-static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op)
+static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op, hipStream_t stream = nullptr)
 {
+	if (!stream) stream = c->stream;      // (only one stream may run fused passes at a time: they share the status words)
 	constexpr i64 LB_TILE = (i64)LB_TPB * ITEMS;
 	const size_t tiles = n > 0 ? (size_t)((n + LB_TILE - 1) / LB_TILE) : 1;
 	for (int k = 0; k < 2; k++) {
 		if (c->d_lb_status[k].cap < tiles * 8) {
 			if (!dev_ensure<unsigned long long>(c, c->d_lb_status[k], tiles + 1024)) return GSA_ERR_NOMEM;
-			GSA_CHECK(c, hipMemsetAsync(c->d_lb_status[k].p, 0, c->d_lb_status[k].cap, c->stream));       // fresh memory: no word may look current
+			GSA_CHECK(c, hipMemsetAsync(c->d_lb_status[k].p, 0, c->d_lb_status[k].cap, stream));       // fresh memory: no word may look current
 		}
 	}
 	c->lb_epoch++;
 	if ((c->lb_epoch & 0x3fffffffu) == 0) {      // epoch wrapped: forget every old word
-		for (int k = 0; k < 2; k++) GSA_CHECK(c, hipMemsetAsync(c->d_lb_status[k].p, 0, c->d_lb_status[k].cap, c->stream));
+		for (int k = 0; k < 2; k++) GSA_CHECK(c, hipMemsetAsync(c->d_lb_status[k].p, 0, c->d_lb_status[k].cap, stream));
 		c->lb_epoch = 1;
 	}
 	LbArgs lb;
 	lb.status[0] = c->d_lb_status[0].as<unsigned long long>(); lb.status[1] = c->d_lb_status[1].as<unsigned long long>();
 	lb.ticket = c->d_mail.as<u32>() + M_TICKET; lb.base = c->lb_base; lb.epoch = c->lb_epoch; lb.err = c->d_mail.as<i32>() + M_LBERR;
-	hipLaunchKernelGGL((k_lb_pass<NV, Op, ITEMS>), dim3((unsigned)tiles), dim3(LB_TPB), 0, c->stream, n, op, lb);
+	hipLaunchKernelGGL((k_lb_pass<NV, Op, ITEMS>), dim3((unsigned)tiles), dim3(LB_TPB), 0, stream, n, op, lb);
 	GSA_CHECK(c, hipGetLastError());
 	c->lb_base += (u32)tiles;
 	return GSA_OK;

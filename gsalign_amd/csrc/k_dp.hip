@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 // Size classes on the device: one fused pass (gsa_scan.h) lists the jobs that need the striped kernel
 // as (job, m, n) triples and packs the others into the small kernel's order array.
 struct OpClassify {
-	const i32 *len1, *len2; i32 *order, *lg, *mail;
+	const i32 *len1, *len2; i32 *order, *lg, *jlarge, *mail;
 	__device__ i32 value(i64 j, int) const
 	{
 		if (j >= mail[M_NJOB]) return 0;
@@ -316,6 +316,7 @@ struct OpClassify {
 		if (j >= mail[M_NJOB]) return;
 		const i32 m = len1[j], n = len2[j];
 		if (m <= 0 || n <= 0) mail[M_DPERR] = 2;
+		jlarge[j] = v[0];
 		if (v[0]) { i32 *e = lg + 3 * (size_t)ex[0]; e[0] = (i32)j; e[1] = m; e[2] = n; }
 		else order[j - ex[0]] = (i32)j;
 	}
@@ -337,18 +338,20 @@ __global__ void k_dp_cells(const i32 *__restrict__ mail, const i32 *__restrict__
 // the small kernel are processed in batches so that the direction bytes of one batch fit the budget.
 // Returns with the work enqueued: errors of the last batch land in the mailbox (M_DPERR, M_DPERR2).
 int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, const i32 *len1,
-                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total)
+                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total, Ksw2Launch *out)
 {
+	*out = Ksw2Launch();
 	if (n_ub <= 0) return GSA_OK;
 	hipStream_t st = c->stream;
 	i32 *mail = c->d_mail.as<i32>();
 	i32 *d_order = dev_ensure<i32>(c, c->d_flag2, (size_t)n_ub + 2);
-	i32 *d_lg = dev_ensure<i32>(c, c->d_dp_large, 3 * ((size_t)n_ub + 1));
+	i32 *d_lg = dev_ensure<i32>(c, c->d_dp_large, 4 * ((size_t)n_ub + 1));      // (job, m, n) triples of the large jobs, then one flag per job
+	i32 *d_jlarge = d_lg ? d_lg + 3 * ((size_t)n_ub + 1) : nullptr;
 	uint8_t *rev = dev_ensure<uint8_t>(c, c->d_i64a, (size_t)ops_total + 64);
 	if (!d_order || !d_lg || !rev) return GSA_ERR_NOMEM;
 	if (!pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * LG_CHUNK)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR, 0, 3 * sizeof(i32), st));                    // M_DPERR, M_NLARGE, M_DPERR2
-	{ OpClassify op = { len1, len2, d_order, d_lg, mail }; int rc = lb_launch<1>(c, n_ub, op); if (rc) return rc; }
+	{ OpClassify op = { len1, len2, d_order, d_lg, d_jlarge, mail }; int rc = lb_launch<1>(c, n_ub, op); if (rc) return rc; }
 	if (c->profiling) {
 		GSA_CHECK(c, hipMemsetAsync(mail + M_CELLS, 0, 8, st));
 		hipLaunchKernelGGL(k_dp_cells, dim3(grid_for((size_t)n_ub, 256)), dim3(256), 0, st, mail, len1, len2, (unsigned long long *)(mail + M_CELLS));
@@ -361,6 +364,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	if (h[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	if (h[M_DPERR]) return gsa_fail(c, GSA_ERR_ARG, "DP job with an empty side");
 	const i32 n = h[M_NJOB], nlarge = h[M_NLARGE], nsmall = n - nlarge;
+	out->n = n; out->nsmall = nsmall; out->nlarge = nlarge;
 	if (n <= 0) return GSA_OK;
 	c->counters[5] += (u64)n; c->counters[6] += (u64)(u32)h[M_OPSTOT];
 	if (c->profiling) c->counters[4] += *(const unsigned long long *)(h + M_CELLS);
@@ -386,6 +390,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 		hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, c->stream_aux[1], nsmall, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len);
 		GSA_CHECK(c, hipGetLastError());
 		GSA_CHECK(c, hipEventRecord(ev_j2, c->stream_aux[1]));
+		out->small_in_flight = true;
 	}
 	const i64 budget = 12ll << 30;
 	size_t first = 0;
@@ -426,7 +431,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 		}
 		first = last;
 	}
-	if (nsmall > 0) GSA_CHECK(c, hipStreamWaitEvent(st, ev_j2, 0));
+	// (no join: the caller decides what else runs behind the small kernel on stream_aux[1]; event ev[12] marks its end)
 	return GSA_OK;
 }
 
@@ -454,7 +459,9 @@ extern "C" int gsa_ksw2_batch(gsa_ctx *c, int32_t n_pairs, const char *pool1, co
 	GSA_CHECK(c, hipMemcpyAsync(d_l1, len1, n * 4, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(d_l2, len2, n * 4, hipMemcpyHostToDevice, st));
 	const i32 cnts[2] = { n_pairs, (i32)po };
 	GSA_CHECK(c, hipMemcpyAsync(c->d_mail.as<i32>() + M_NJOB, cnts, 8, hipMemcpyHostToDevice, st));      // M_NJOB, M_OPSTOT
-	int rc = run_ksw2_jobs(c, n_pairs, d_p1, d_o1, d_l1, d_p2, d_o2, d_l2, d_ops, d_oo, d_ol, po);
+	Ksw2Launch kl;
+	int rc = run_ksw2_jobs(c, n_pairs, d_p1, d_o1, d_l1, d_p2, d_o2, d_l2, d_ops, d_oo, d_ol, po, &kl);
+	if (rc == GSA_OK && kl.small_in_flight) GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[12], 0));
 	if (rc == GSA_OK) {
 		i32 err = 0;
 		GSA_CHECK(c, hipMemcpyAsync(ops, d_ops, po, hipMemcpyDeviceToHost, st));

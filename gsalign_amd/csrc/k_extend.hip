@@ -91,9 +91,11 @@ struct OpDpJobs {
 	__device__ void done(const i32 *t) const { mail[M_NJOB] = t[0]; mail[M_OPSTOT] = t[1]; opsoff[t[0]] = t[1]; }
 };
 
-// lengths and offsets of the gapped strings
-struct OpAlnLen {
-	const i32 *ftype; const gsa_frag *frag; const i32 *fjob, *nops;
+// Offsets of the gapped strings.  Every gap gets the room it can need at most (a DP gap m+n, the others
+// their exact length), so the offsets do not depend on the DP results and everything that is not a
+// large DP job can be written while the striped kernel still runs.
+struct OpAlnOff {
+	const i32 *ftype; const gsa_frag *frag;
 	i32 *alen; i64 *aoff; i32 *mail;
 	__device__ i32 value(i64 i, int) const
 	{
@@ -101,10 +103,10 @@ struct OpAlnLen {
 		const i32 t = ftype[i];
 		if (t == FT_DEL) return frag[i].rlen;
 		if (t == FT_INS || t == FT_EQ) return frag[i].qlen;
-		if (t == FT_DP) return nops[fjob[i]];
+		if (t == FT_DP) return frag[i].rlen + frag[i].qlen;
 		return 0;
 	}
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const { alen[i] = v[0]; aoff[i] = ex[0]; }
+	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const { alen[i] = v[0]; aoff[i] = ex[0]; }      // (alen of a DP gap: replaced by the op count)
 	__device__ void done(const i32 *t) const { mail[M_NALN] = t[0]; }
 };
 
@@ -116,32 +118,73 @@ struct OpRecSums {
 	__device__ void done(const i32 *t) const { ps_len[n] = (u32)t[0]; ps_score[n] = (u32)t[1]; }
 };
 
+// one DP record written by a whole 256-thread workgroup: 256 positions per pass, prefix counts of the
+// consumed bases across the workgroup.  Returns the score (identical pairs) in every thread.
+__device__ i32 write_dp_record_wg(i64 i, i32 L, const i32 *__restrict__ fjob, const i64 *__restrict__ aoff, const uint8_t *__restrict__ ops, const i64 *__restrict__ opsoff,
+                                  const uint8_t *__restrict__ query, const uint8_t *__restrict__ ref, gsa_frag *frag, uint8_t *aln1, uint8_t *aln2,
+                                  int *s_w1, int *s_w2, int *s_sc)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const gsa_frag f = frag[i];
+	const i64 o = aoff[i];
+	const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos, *op = ops + opsoff[fjob[i]];
+	i32 i1 = 0, i2 = 0, score = 0;
+	if (tid == 0) *s_sc = 0;
+	for (i32 base = 0; base < L; base += 256) {
+		const i32 p = base + tid;
+		const uint8_t ch = p < L ? op[p] : 0;
+		const int c1 = (ch == 'M' || ch == 'I') ? 1 : 0, c2 = (ch == 'M' || ch == 'D') ? 1 : 0;
+		int s1 = c1, s2 = c2;
+		for (int d = 1; d < 64; d <<= 1) { int a = __shfl_up(s1, d), b = __shfl_up(s2, d); if (lane >= d) { s1 += a; s2 += b; } }
+		__syncthreads();
+		if (lane == 63) { s_w1[wv] = s1; s_w2[wv] = s2; }
+		__syncthreads();
+		int w1 = 0, w2 = 0, t1 = 0, t2 = 0;
+		for (int w = 0; w < 4; w++) { if (w < wv) { w1 += s_w1[w]; w2 += s_w2[w]; } t1 += s_w1[w]; t2 += s_w2[w]; }
+		if (p < L) {
+			// ops are forward M/D/I; 'D' puts '-' into aln1, 'I' into aln2 (ksw2_alignment.cpp:264-272)
+			const uint8_t a1 = c1 ? rs[i1 + w1 + s1 - 1] : '-', a2 = c2 ? qs[i2 + w2 + s2 - 1] : '-';
+			aln1[o + p] = a1; aln2[o + p] = a2;
+			score += (gsa_nt4(a1) == gsa_nt4(a2));             // CountIdenticalPairs (:38-47)
+		}
+		i1 += t1; i2 += t2;
+	}
+	for (int d = 32; d; d >>= 1) score += __shfl_xor(score, d);
+	__syncthreads();
+	if (lane == 0 && score) atomicAdd(s_sc, score);
+	__syncthreads();
+	const i32 total = *s_sc;
+	if (tid == 0) { frag[i].aln_off = o; frag[i].aln_len = L; }
+	__syncthreads();
+	return total;
+}
+
 // Gapped strings and the records' (aln_len, score) contributions.  256 records per workgroup: a thread
 // settles its own record when it is a seed or a short gap (the bulk: median gap 11 bases); longer gaps
 // are queued in LDS and written by whole wavefronts.
 #define MAT_SERIAL 32
-#define MAT_BLOCK 512         // DP records longer than this are written by the whole workgroup
 __global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_ptr, const i32 *__restrict__ ftype, const i32 *__restrict__ fmism, const i32 *__restrict__ fjob,
-                                                      const i32 *__restrict__ alen, const i64 *__restrict__ aoff, const uint8_t *__restrict__ ops,
+                                                      const i32 *__restrict__ jlarge, const i32 *__restrict__ nops, const i32 *__restrict__ alen, const i64 *__restrict__ aoff, const uint8_t *__restrict__ ops,
                                                       const i64 *__restrict__ opsoff, const uint8_t *__restrict__ query, const uint8_t *__restrict__ ref,
                                                       gsa_frag *frag, uint8_t *aln1, uint8_t *aln2, i32 *c_len, i32 *c_score)
 {
-	__shared__ i32 s_list[256], s_long[256];
-	__shared__ int s_n, s_nl, s_w1[4], s_w2[4], s_sc;
+	__shared__ i32 s_list[256];
+	__shared__ int s_n;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const i64 nf = nf_ptr[0];
-	if (tid == 0) { s_n = 0; s_nl = 0; }
+	if (tid == 0) s_n = 0;
 	__syncthreads();
 	{
 		const i64 i = (i64)blockIdx.x * 256 + tid;
 		if (i < nf) {
 			const i32 t = ftype[i];
+			const i32 Lr = t == FT_DP ? (jlarge[fjob[i]] ? -1 : nops[fjob[i]]) : alen[i];       // -1: a large DP job, written after the striped kernel
 			if (t == FT_SEED) { const i32 l = frag[i].qlen; c_len[i] = l; c_score[i] = l; }
-			else if (alen[i] > MAT_BLOCK && t == FT_DP) s_long[atomicAdd(&s_nl, 1)] = tid;
-			else if (alen[i] > MAT_SERIAL) s_list[atomicAdd(&s_n, 1)] = tid;
+			else if (Lr < 0) { c_len[i] = 0; c_score[i] = 0; frag[i].aln_off = aoff[i]; frag[i].aln_len = 0; }
+			else if (Lr > MAT_SERIAL) s_list[atomicAdd(&s_n, 1)] = tid;
 			else {
 				const gsa_frag f = frag[i];
-				const i64 o = aoff[i]; const i32 L = alen[i];
+				const i64 o = aoff[i]; const i32 L = Lr;
 				const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos;
 				i32 score = 0;
 				if (t == FT_DEL) { for (i32 p = 0; p < L; p++) { aln1[o + p] = rs[p]; aln2[o + p] = '-'; } }
@@ -168,7 +211,7 @@ __global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_
 		const i64 i = (i64)blockIdx.x * 256 + s_list[g];
 		const i32 t = ftype[i];
 		const gsa_frag f = frag[i];
-		const i64 o = aoff[i]; const i32 L = alen[i];
+		const i64 o = aoff[i]; const i32 L = t == FT_DP ? nops[fjob[i]] : alen[i];
 		const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos;
 		i32 score = 0;
 		if (t == FT_DEL) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = rs[p]; aln2[o + p] = '-'; } }
@@ -194,40 +237,22 @@ __global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_
 		}
 		if (lane == 0) { c_len[i] = L; c_score[i] = score; frag[i].aln_off = o; frag[i].aln_len = L; }
 	}
-	// the few very long DP records: 256 positions per pass, prefix counts across the workgroup
-	const int nlong = s_nl;
-	for (int g = 0; g < nlong; g++) {
-		const i64 i = (i64)blockIdx.x * 256 + s_long[g];
-		const gsa_frag f = frag[i];
-		const i64 o = aoff[i]; const i32 L = alen[i];
-		const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos, *op = ops + opsoff[fjob[i]];
-		i32 i1 = 0, i2 = 0, score = 0;
-		if (tid == 0) s_sc = 0;
-		for (i32 base = 0; base < L; base += 256) {
-			const i32 p = base + tid;
-			const uint8_t ch = p < L ? op[p] : 0;
-			const int c1 = (ch == 'M' || ch == 'I') ? 1 : 0, c2 = (ch == 'M' || ch == 'D') ? 1 : 0;
-			int s1 = c1, s2 = c2;
-			for (int d = 1; d < 64; d <<= 1) { int a = __shfl_up(s1, d), b = __shfl_up(s2, d); if (lane >= d) { s1 += a; s2 += b; } }
-			__syncthreads();
-			if (lane == 63) { s_w1[wv] = s1; s_w2[wv] = s2; }
-			__syncthreads();
-			int w1 = 0, w2 = 0, t1 = 0, t2 = 0;
-			for (int w = 0; w < 4; w++) { if (w < wv) { w1 += s_w1[w]; w2 += s_w2[w]; } t1 += s_w1[w]; t2 += s_w2[w]; }
-			if (p < L) {
-				const uint8_t a1 = c1 ? rs[i1 + w1 + s1 - 1] : '-', a2 = c2 ? qs[i2 + w2 + s2 - 1] : '-';
-				aln1[o + p] = a1; aln2[o + p] = a2;
-				score += (gsa_nt4(a1) == gsa_nt4(a2));
-			}
-			i1 += t1; i2 += t2;
-		}
-		for (int d = 32; d; d >>= 1) score += __shfl_xor(score, d);
-		__syncthreads();
-		if (lane == 0 && score) atomicAdd(&s_sc, score);
-		__syncthreads();
-		if (tid == 0) { c_len[i] = L; c_score[i] = s_sc; frag[i].aln_off = o; frag[i].aln_len = L; }
-		__syncthreads();
-	}
+}
+
+// The records of the large DP jobs, after the striped kernel: one workgroup per job; (record, aln_len,
+// score) go to a patch list the host applies to the records and block sums it already holds.
+__global__ void __launch_bounds__(256) k_materialize_large(i32 nlarge, const i32 *__restrict__ lg, const i32 *__restrict__ jfrag, const i32 *__restrict__ fjob, const i32 *__restrict__ nops,
+                                                            const i64 *__restrict__ aoff, const uint8_t *__restrict__ ops, const i64 *__restrict__ opsoff,
+                                                            const uint8_t *__restrict__ query, const uint8_t *__restrict__ ref, gsa_frag *frag, uint8_t *aln1, uint8_t *aln2, i32 *patch)
+{
+	__shared__ int s_w1[4], s_w2[4], s_sc;
+	const int g = blockIdx.x;
+	if (g >= nlarge) return;
+	const i32 job = lg[3 * g];
+	const i64 i = jfrag[job];
+	const i32 L = nops[job];
+	const i32 sc = write_dp_record_wg(i, L, fjob, aoff, ops, opsoff, query, ref, frag, aln1, aln2, s_w1, s_w2, &s_sc);
+	if (threadIdx.x == 0) { patch[3 * g] = (i32)i; patch[3 * g + 1] = L; patch[3 * g + 2] = sc; }
 }
 
 __global__ void k_block_sums(i32 nfb, const i32 *__restrict__ nf_ptr, const i32 *__restrict__ fragbase, const u32 *__restrict__ ps_len, const u32 *__restrict__ ps_score, i32 *bl_len, i32 *bl_score)
@@ -282,12 +307,16 @@ int stage7_fill(gsa_ctx *c)
 	return GSA_OK;
 }
 
-// stage 8: S7 on the records built by stage7_fill
+// stage 8: S7 on the records built by stage7_fill.  Stream plan: the striped DP kernel (the latency
+// floor of a contig) runs on the main stream; behind the small-job kernel on stream_aux[1] everything
+// that does not depend on a large job is finished and sent to the host meanwhile -- strings, record
+// sums, per-block sums, the records themselves.  After the striped kernel only the large jobs' strings,
+// a patch list and the string pools remain.
 int stage78_extend(gsa_ctx *c)
 {
-	hipStream_t st = c->stream;
+	hipStream_t st = c->stream, sx = c->stream_aux[1];
 	const i32 nfb = (i32)c->blocks.size(); const i64 nfu = c->nf_ub;
-	c->n_aln = 0;
+	c->n_aln = 0; c->n_large = 0;
 	if (nfb == 0 || nfu == 0) { c->n_frags = 0; return GSA_OK; }
 	if (c->profiling) hipEventRecord(c->ev[8], st);
 	i32 *mail = c->d_mail.as<i32>();
@@ -296,23 +325,50 @@ int stage78_extend(gsa_ctx *c)
 	ENS(i64, w_best, nju + 1); ENS(i64, w_sum, nju + 1); ENS(i32, a_uniq, nju + 1); ENS(i32, a_cu, nju + 1);
 	i64 *off1 = c->w_best.as<i64>(), *off2 = c->w_sum.as<i64>(); i32 *len1 = c->a_uniq.as<i32>(), *len2 = c->a_cu.as<i32>();
 	{ OpDpJobs op = { c->f_type.as<i32>(), c->f_rec.as<gsa_frag>(), c->j_frag.as<i32>(), off1, len1, off2, len2, c->j_opsoff.as<i64>(), c->f_job.as<i32>(), mail }; RC((lb_launch<2>(c, nfu, op))); }
-	ENS(uint8_t, d_ops, c->span_ub + 64);
-	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub));
-	// gapped strings
 	ENS(i64, d_alnoff, nfu + 2);
-	{ OpAlnLen op = { c->f_type.as<i32>(), c->f_rec.as<gsa_frag>(), c->f_job.as<i32>(), c->j_nops.as<i32>(), c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), mail }; RC((lb_launch<1>(c, nfu, op))); }
-	ENS(uint8_t, d_aln1, c->span_ub + 64); ENS(uint8_t, d_aln2, c->span_ub + 64);
-	ENS(i32, d_flag, nfu + 2);
+	{ OpAlnOff op = { c->f_type.as<i32>(), c->f_rec.as<gsa_frag>(), c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), mail }; RC((lb_launch<1>(c, nfu, op))); }
+	ENS(uint8_t, d_ops, c->span_ub + 64); ENS(uint8_t, d_aln1, c->span_ub + 64); ENS(uint8_t, d_aln2, c->span_ub + 64);
+	ENS(i32, d_flag, nfu + 2); ENS(u32, d_scan, nfu + 2); ENS(u32, d_flag2, nfu + 2); ENS(i32, bl_alnlen, nfb + 1); ENS(i32, bl_score, nfb + 1);
+	Ksw2Launch kl;
+	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub, &kl));
+	// (run_ksw2_jobs read the mailbox: the record count and the size of the string pools are known now)
+	const i32 *hm = c->p_dp.as<i32>();
+	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN]; c->n_large = kl.nlarge;
+	const size_t nfr = (size_t)c->n_frags;
+	if (!pin_ensure<gsa_frag>(c, c->p_frags, nfr) || !pin_ensure<char>(c, c->p_aln1, (size_t)c->n_aln) || !pin_ensure<char>(c, c->p_aln2, (size_t)c->n_aln) ||
+	    !pin_ensure<i32>(c, c->p_blk, (size_t)3 * (nfb + 1) + MAIL_N + 8) || !pin_ensure<i32>(c, c->p_patch, 3 * (size_t)kl.nlarge + 4)) return GSA_ERR_NOMEM;
+	// ---- behind the small jobs (stream_aux[1]; when there is no small job it starts at the fork) ----
+	if (!kl.small_in_flight) { GSA_CHECK(c, hipEventRecord(c->ev[10], st)); GSA_CHECK(c, hipStreamWaitEvent(sx, c->ev[10], 0)); }
+	const i32 *jlarge = c->d_dp_large.as<i32>() + 3 * ((size_t)nju + 1);
 	i32 *c_len = c->d_flag.as<i32>(), *c_score = c->f_score.as<i32>();
-	hipLaunchKernelGGL(k_materialize, dim3((unsigned)((nfu + 255) / 256)), dim3(256), 0, st, mail + M_NF, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(), c->f_alnlen.as<i32>(),
-	                   c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
+	hipLaunchKernelGGL(k_materialize, dim3((unsigned)((nfu + 255) / 256)), dim3(256), 0, sx, mail + M_NF, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(),
+	                   jlarge, c->j_nops.as<i32>(), c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
 	                   c->f_rec.as<gsa_frag>(), c->d_aln1.as<uint8_t>(), c->d_aln2.as<uint8_t>(), c_len, c_score);
-	// per-block sums via prefix sums
-	ENS(u32, d_scan, nfu + 2); ENS(u32, d_flag2, nfu + 2);
-	{ OpRecSums op = { nfu, c_len, c_score, c->d_scan.as<u32>(), c->d_flag2.as<u32>(), mail }; RC((lb_launch<2>(c, nfu, op))); }
-	ENS(i32, bl_alnlen, nfb + 1); ENS(i32, bl_score, nfb + 1);
-	LAUNCH(k_block_sums, nfb, nfb, mail + M_NF, c->fb_fragbase.as<i32>(), c->d_scan.as<u32>(), c->d_flag2.as<u32>(), c->bl_alnlen.as<i32>(), c->bl_score.as<i32>());
-	// the counts come back together with the per-block sums (host_stage8_finish)
+	// per-block sums via prefix sums (the large jobs' records count as zero here, the host adds them from the patch list)
+	u32 *ps_score = c->d_flag2.as<u32>();      // (the small kernel's order array is free again)
+	{ OpRecSums op = { nfu, c_len, c_score, c->d_scan.as<u32>(), ps_score, mail }; RC((lb_launch<2>(c, nfu, op, sx))); }
+	hipLaunchKernelGGL(k_block_sums, dim3(grid_for((size_t)nfb, TPB)), dim3(TPB), 0, sx, nfb, mail + M_NF, c->fb_fragbase.as<i32>(), c->d_scan.as<u32>(), ps_score, c->bl_alnlen.as<i32>(), c->bl_score.as<i32>());
+	i32 *h_len = c->p_blk.as<i32>(), *h_score = h_len + nfb, *h_fragbase = h_score + nfb;
+	GSA_CHECK(c, hipMemcpyAsync(h_len, c->bl_alnlen.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
+	GSA_CHECK(c, hipMemcpyAsync(h_score, c->bl_score.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
+	GSA_CHECK(c, hipMemcpyAsync(h_fragbase, c->fb_fragbase.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
+	if (nfr) GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, nfr * sizeof(gsa_frag), hipMemcpyDeviceToHost, sx));
+	GSA_CHECK(c, hipEventRecord(c->ev[13], sx));
+	// ---- behind the striped kernel (main stream) ----
+	if (kl.nlarge > 0) {
+		ENS(i32, d_patch, 3 * (size_t)kl.nlarge + 4);
+		hipLaunchKernelGGL(k_materialize_large, dim3((unsigned)kl.nlarge), dim3(256), 0, st, kl.nlarge, c->d_dp_large.as<i32>(), c->j_frag.as<i32>(), c->f_job.as<i32>(), c->j_nops.as<i32>(),
+		                   c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
+		                   c->f_rec.as<gsa_frag>(), c->d_aln1.as<uint8_t>(), c->d_aln2.as<uint8_t>(), c->d_patch.as<i32>());
+		GSA_CHECK(c, hipMemcpyAsync(c->p_patch.p, c->d_patch.p, 3 * (size_t)kl.nlarge * 4, hipMemcpyDeviceToHost, st));
+	}
+	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[13], 0));      // the other strings are written, the records are on the host
+	if (c->n_aln) {
+		GSA_CHECK(c, hipMemcpyAsync(c->p_aln1.p, c->d_aln1.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, st));
+		GSA_CHECK(c, hipMemcpyAsync(c->p_aln2.p, c->d_aln2.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, st));
+	}
+	GSA_CHECK(c, hipMemcpyAsync(c->p_blk.as<i32>() + 3 * (nfb + 1), mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
 	if (c->profiling) hipEventRecord(c->ev[9], st);
+	GSA_CHECK(c, hipGetLastError());
 	return GSA_OK;
 }
