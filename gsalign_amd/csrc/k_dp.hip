@@ -11,6 +11,7 @@
 //    into 64-wide stripes, one wavefront per stripe on its own CU, boundary columns
 //    handed over through HBM; see the comment at the kernel.
 #include <algorithm>
+#include <cstring>
 #include "gsa_ctx.h"
 #include "gsa_dp.h"
 #include "gsa_scan.h"
@@ -369,8 +370,9 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	c->counters[5] += (u64)n; c->counters[6] += (u64)(u32)h[M_OPSTOT];
 	if (c->profiling) c->counters[4] += *(const unsigned long long *)(h + M_CELLS);
 	if ((size_t)nlarge > first_lg) {
+		i32 keep[MAIL_N]; memcpy(keep, h, sizeof(keep));      // the mailbox copy must survive the reallocation (the caller reads it too)
 		if (!pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * (size_t)nlarge)) return GSA_ERR_NOMEM;
-		h = c->p_dp.as<i32>();
+		h = c->p_dp.as<i32>(); memcpy(h, keep, sizeof(keep));
 		GSA_CHECK(c, hipMemcpyAsync(h + MAIL_N, d_lg, (size_t)nlarge * 12, hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipStreamSynchronize(st));
 	}
