@@ -121,6 +121,7 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 {
 	extern __shared__ __attribute__((aligned(16))) int8_t C1[];        // the reference fragment as nt4 codes
 	__shared__ __attribute__((aligned(16))) uint8_t tile[DP_TILE_ROWS * 64];
+	__builtin_amdgcn_s_setprio(3);      // these waves are the contig's latency floor: they issue ahead of whatever else shares the SIMD
 	// which job / stripe am I (uniform)
 	int lo = 0, hi = nsj;
 	while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sjobs[mid].first_block <= (i32)blockIdx.x) lo = mid; else hi = mid; }
