@@ -147,6 +147,7 @@ int host_stage8_finish(gsa_ctx *c)
 	const i32 *hm = c->p_blk.as<i32>() + 3 * (nfb + 1);
 	if (hm[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	if (hm[M_DPERR2]) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
+	if (c->profiling) { const unsigned long long *cc = (const unsigned long long *)(hm + M_CELLS); c->counters[4] += cc[0]; c->counters[6] += cc[1]; }
 	// the large DP jobs finished after the records left: their (aln_len, score) arrive as a patch list
 	{
 		gsa_frag *fr = c->p_frags.as<gsa_frag>();

@@ -87,7 +87,8 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 // inter-stripe dependency is the (x,v) pair of stripe p-1's last column per row;
 // it is handed over through HBM as self-validating 4-byte granules {tag,x|v<<8}
 // written and read with agent-scope relaxed atomics (write-through / L1-bypassing,
-// so no fence and no separate flag; granules are zeroed before the launch).
+// so no fence and no separate flag; the tag is a 16-bit launch epoch, so the granules
+// need no clearing between launches).
 // The boundary column travels down a second DPP chain and is published 8 rows at a
 // time (one 32-byte store); stripe p fetches 8 rows per poll, one block ahead.
 // Direction bytes go to HBM STRIPE-LOCAL: stripe p owns (m+63) rows of 64 bytes,
@@ -117,7 +118,7 @@ struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; }
 
 __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__restrict__ sjobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
                                                    const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2, uint8_t *dirbase, u32 *bndbase, u32 *ctr,
-                                                   uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len)
+                                                   uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, u32 ep)
 {
 	extern __shared__ __attribute__((aligned(16))) int8_t C1[];        // the reference fragment as nt4 codes
 	__shared__ __attribute__((aligned(16))) uint8_t tile[DP_TILE_ROWS * 64];
@@ -169,13 +170,13 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 				const int row = rl_ + (lane & (DP_G - 1));                                                               \
 				const bool need = lane < DP_G && row < m;                                                          \
 				u32 g = gnext;                                                                                  \
-				if (!__all(!need || (g >> 16) != 0)) {      /* (first look outside the loop: its wait only covers the prefetch) */ \
+				if (!__all(!need || (g >> 16) == ep)) {      /* (first look outside the loop: its wait only covers the prefetch) */ \
 					u32 spins = 0;                                                                              \
 					do {                                                                                        \
 						if (++spins > (1u << 20) || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; } \
 						__builtin_amdgcn_s_sleep(1);                                                            \
 						if (need) g = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-					} while (!__all(!need || (g >> 16) != 0));                                                  \
+					} while (!__all(!need || (g >> 16) == ep));                                                  \
 				}                                                                                               \
 				bin = g & 0xffffu;                                                                              \
 				/* every lane loads (clamped row): an unconditional load lands in gnext without a copy that would wait for it */ \
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 		if (((K2) & (DP_G - 1)) == DP_G - 2 && pub_stripe && rl_ >= 62 + DP_G) {                                                       \
 			/* rows rl_-62-DP_G .. rl_-63 of the boundary column are complete: one store of DP_G tagged granules */ \
 			const int row = rl_ - 126 + lane;                                                                   \
-			if (lane >= 64 - DP_G && row < m) __hip_atomic_store(&bnd_out[row], (1u << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+			if (lane >= 64 - DP_G && row < m) __hip_atomic_store(&bnd_out[row], (ep << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
 		}                                                                                                       \
 	}
 	// (two copies of the loop: stripe 0 has no boundary loads in flight, and keeping it apart keeps its waits off the stores)
@@ -229,7 +230,7 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 	if (pub_stripe) {
 		// the last (partial) block of boundary rows: lane 63 - q holds row m-1-q
 		const int row = m - 64 + lane;
-		if (lane >= 64 - DP_G && row >= 0) __hip_atomic_store(&bnd_out[row], (1u << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (lane >= 64 - DP_G && row >= 0) __hip_atomic_store(&bnd_out[row], (ep << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	DPT(if (p == 0 && lane == 0) ctr[sj.ctr + 40] = (u32)(wall_clock64() - T0c); if (p == P - 1 && lane == 0) ctr[sj.ctr + 41] = (u32)(wall_clock64() - T0c);)
 	// ---- ticket: the last stripe to finish does the traceback ----
@@ -325,13 +326,19 @@ struct OpClassify {
 	__device__ void done(const i32 *t) const { mail[M_NLARGE] = t[0]; }
 };
 
-// sum of m*n over the jobs (measurement only)
+// sums of m*n and m+n over the jobs (measurement only)
 __global__ void k_dp_cells(const i32 *__restrict__ mail, const i32 *__restrict__ len1, const i32 *__restrict__ len2, unsigned long long *out)
 {
 	const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	unsigned long long v = j < mail[M_NJOB] ? (unsigned long long)len1[j] * (unsigned long long)len2[j] : 0;
-	for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-	if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+	const bool in = j < mail[M_NJOB];
+	unsigned long long v = in ? (unsigned long long)len1[j] * (unsigned long long)len2[j] : 0, w = in ? (unsigned long long)(len1[j] + len2[j]) : 0;
+	for (int o = 32; o; o >>= 1) { v += __shfl_xor(v, o); w += __shfl_xor(w, o); }
+	if ((threadIdx.x & 63) == 0 && v) { atomicAdd(out, v); atomicAdd(out + 1, w); }
+}
+
+void dp_count_cells(gsa_ctx *c, i32 n_ub, const i32 *len1, const i32 *len2, hipStream_t stream)
+{
+	hipLaunchKernelGGL(k_dp_cells, dim3(grid_for((size_t)n_ub, 256)), dim3(256), 0, stream, c->d_mail.as<i32>(), len1, len2, (unsigned long long *)(c->d_mail.as<i32>() + M_CELLS));
 }
 
 #define LG_CHUNK 2048       // large-job triples copied together with the mailbox (more -> a second copy)
@@ -352,12 +359,8 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	uint8_t *rev = dev_ensure<uint8_t>(c, c->d_i64a, (size_t)ops_total + 64);
 	if (!d_order || !d_lg || !rev) return GSA_ERR_NOMEM;
 	if (!pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * LG_CHUNK)) return GSA_ERR_NOMEM;
-	GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR, 0, 3 * sizeof(i32), st));                    // M_DPERR, M_NLARGE, M_DPERR2
+	GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR, 0, 7 * sizeof(i32), st));                    // M_DPERR, M_NLARGE, M_DPERR2, M_CELLS (2 x u64)
 	{ OpClassify op = { len1, len2, d_order, d_lg, d_jlarge, mail }; int rc = lb_launch<1>(c, n_ub, op); if (rc) return rc; }
-	if (c->profiling) {
-		GSA_CHECK(c, hipMemsetAsync(mail + M_CELLS, 0, 8, st));
-		hipLaunchKernelGGL(k_dp_cells, dim3(grid_for((size_t)n_ub, 256)), dim3(256), 0, st, mail, len1, len2, (unsigned long long *)(mail + M_CELLS));
-	}
 	i32 *h = c->p_dp.as<i32>();
 	const size_t first_lg = (size_t)std::min<i64>(n_ub, LG_CHUNK);
 	GSA_CHECK(c, hipMemcpyAsync(h, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
@@ -368,8 +371,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	const i32 n = h[M_NJOB], nlarge = h[M_NLARGE], nsmall = n - nlarge;
 	out->n = n; out->nsmall = nsmall; out->nlarge = nlarge;
 	if (n <= 0) return GSA_OK;
-	c->counters[5] += (u64)n; c->counters[6] += (u64)(u32)h[M_OPSTOT];
-	if (c->profiling) c->counters[4] += *(const unsigned long long *)(h + M_CELLS);
+	c->counters[5] += (u64)n;
 	if ((size_t)nlarge > first_lg) {
 		i32 keep[MAIL_N]; memcpy(keep, h, sizeof(keep));      // the mailbox copy must survive the reallocation (the caller reads it too)
 		if (!pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * (size_t)nlarge)) return GSA_ERR_NOMEM;
@@ -415,14 +417,17 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 		}
 		const size_t last = first + cnt;
 		uint8_t *dir = dev_ensure<uint8_t>(c, c->d_scan2, (size_t)dbytes + 512);
+		const size_t bnd_cap0 = c->d_dp_bnd.cap;
 		u32 *bnd = dev_ensure<u32>(c, c->d_dp_bnd, (size_t)bwords + 64);
 		u32 *ctr = dev_ensure<u32>(c, c->d_dp_ctr, (size_t)nctr + 64);
 		StripeJob *d_sj = dev_ensure<StripeJob>(c, c->d_dp_jobs, cnt + 1);
 		if (!dir || !bnd || !ctr || !d_sj) return GSA_ERR_NOMEM;
-		GSA_CHECK(c, hipMemsetAsync(bnd, 0, ((size_t)bwords + 64) * 4, st));
+		// boundary granules carry the launch epoch as their tag: cleared only when the buffer is new or the epoch wraps
+		c->dp_epoch = (c->dp_epoch + 1) & 0xffffu;
+		if (c->dp_epoch == 0 || c->d_dp_bnd.cap != bnd_cap0) { GSA_CHECK(c, hipMemsetAsync(bnd, 0, c->d_dp_bnd.cap, st)); if (c->dp_epoch == 0) c->dp_epoch = 1; }
 		GSA_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nctr + 64) * 4, st));
 		GSA_CHECK(c, hipMemcpyAsync(d_sj, sj, cnt * sizeof(StripeJob), hipMemcpyHostToDevice, st));
-		hipLaunchKernelGGL(k_dp_stripe, dim3((unsigned)nblocks), dim3(64), (size_t)mpad, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len);
+		hipLaunchKernelGGL(k_dp_stripe, dim3((unsigned)nblocks), dim3(64), (size_t)mpad, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch);
 		GSA_CHECK(c, hipGetLastError());
 		GSA_CHECK(c, hipMemcpyAsync(mail + M_DPERR2, ctr, 4, hipMemcpyDeviceToDevice, st));
 		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })

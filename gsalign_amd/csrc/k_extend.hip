@@ -71,43 +71,33 @@ struct OpSlots {
 	__device__ void done(const i32 *t) const { mail[M_NF] = t[0]; }
 };
 
-// DP job list: component 0 counts the jobs, component 1 sums m+n = the length of the op strings
+// DP job list and string offsets in one pass.  Component 0 counts the DP jobs.  Component 1 gives every
+// gap the room it can need AT MOST (a DP gap m+n, the others their exact length): the offsets of the
+// gapped strings, and of a DP job's op string, then do not depend on the DP results, and everything
+// that is not a large DP job can be written while the striped kernel still runs.
 struct OpDpJobs {
 	const i32 *ftype; const gsa_frag *frag;
-	i32 *jfrag; i64 *off1; i32 *len1; i64 *off2; i32 *len2; i64 *opsoff; i32 *fjob, *mail;
+	i32 *jfrag; i64 *off1; i32 *len1; i64 *off2; i32 *len2; i64 *opsoff; i32 *fjob, *alen; i64 *aoff; i32 *mail;
 	__device__ i32 value(i64 i, int c) const
-	{
-		if (i >= mail[M_NF] || ftype[i] != FT_DP) return 0;
-		return c == 0 ? 1 : frag[i].rlen + frag[i].qlen;
-	}
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
-	{
-		if (i >= mail[M_NF]) return;
-		if (!v[0]) { fjob[i] = -1; return; }
-		const i32 j = ex[0];
-		jfrag[j] = (i32)i; off1[j] = frag[i].rpos; len1[j] = frag[i].rlen; off2[j] = frag[i].qpos; len2[j] = frag[i].qlen; opsoff[j] = ex[1];
-		fjob[i] = j;
-	}
-	__device__ void done(const i32 *t) const { mail[M_NJOB] = t[0]; mail[M_OPSTOT] = t[1]; opsoff[t[0]] = t[1]; }
-};
-
-// Offsets of the gapped strings.  Every gap gets the room it can need at most (a DP gap m+n, the others
-// their exact length), so the offsets do not depend on the DP results and everything that is not a
-// large DP job can be written while the striped kernel still runs.
-struct OpAlnOff {
-	const i32 *ftype; const gsa_frag *frag;
-	i32 *alen; i64 *aoff; i32 *mail;
-	__device__ i32 value(i64 i, int) const
 	{
 		if (i >= mail[M_NF]) return 0;
 		const i32 t = ftype[i];
+		if (c == 0) return t == FT_DP ? 1 : 0;
 		if (t == FT_DEL) return frag[i].rlen;
 		if (t == FT_INS || t == FT_EQ) return frag[i].qlen;
 		if (t == FT_DP) return frag[i].rlen + frag[i].qlen;
 		return 0;
 	}
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const { alen[i] = v[0]; aoff[i] = ex[0]; }      // (alen of a DP gap: replaced by the op count)
-	__device__ void done(const i32 *t) const { mail[M_NALN] = t[0]; }
+	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	{
+		if (i >= mail[M_NF]) return;
+		alen[i] = v[1]; aoff[i] = ex[1];                      // (alen of a DP gap: replaced by the op count)
+		if (!v[0]) { fjob[i] = -1; return; }
+		const i32 j = ex[0];
+		jfrag[j] = (i32)i; off1[j] = frag[i].rpos; len1[j] = frag[i].rlen; off2[j] = frag[i].qpos; len2[j] = frag[i].qlen; opsoff[j] = ex[1];
+		fjob[i] = j;
+	}
+	__device__ void done(const i32 *t) const { mail[M_NJOB] = t[0]; mail[M_NALN] = t[1]; }
 };
 
 // prefix sums of the records' (aln_len, score) contributions, 32-bit wrapping (only differences over a block are used)
@@ -324,9 +314,9 @@ int stage78_extend(gsa_ctx *c)
 	ENS(i32, j_frag, nju + 1); ENS(i64, j_opsoff, nju + 2); ENS(i32, j_nops, nju + 1);
 	ENS(i64, w_best, nju + 1); ENS(i64, w_sum, nju + 1); ENS(i32, a_uniq, nju + 1); ENS(i32, a_cu, nju + 1);
 	i64 *off1 = c->w_best.as<i64>(), *off2 = c->w_sum.as<i64>(); i32 *len1 = c->a_uniq.as<i32>(), *len2 = c->a_cu.as<i32>();
-	{ OpDpJobs op = { c->f_type.as<i32>(), c->f_rec.as<gsa_frag>(), c->j_frag.as<i32>(), off1, len1, off2, len2, c->j_opsoff.as<i64>(), c->f_job.as<i32>(), mail }; RC((lb_launch<2>(c, nfu, op))); }
 	ENS(i64, d_alnoff, nfu + 2);
-	{ OpAlnOff op = { c->f_type.as<i32>(), c->f_rec.as<gsa_frag>(), c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), mail }; RC((lb_launch<1>(c, nfu, op))); }
+	{ OpDpJobs op = { c->f_type.as<i32>(), c->f_rec.as<gsa_frag>(), c->j_frag.as<i32>(), off1, len1, off2, len2, c->j_opsoff.as<i64>(), c->f_job.as<i32>(),
+	                  c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), mail }; RC((lb_launch<2>(c, nfu, op))); }
 	ENS(uint8_t, d_ops, c->span_ub + 64); ENS(uint8_t, d_aln1, c->span_ub + 64); ENS(uint8_t, d_aln2, c->span_ub + 64);
 	ENS(i32, d_flag, nfu + 2); ENS(u32, d_scan, nfu + 2); ENS(u32, d_flag2, nfu + 2); ENS(i32, bl_alnlen, nfb + 1); ENS(i32, bl_score, nfb + 1);
 	Ksw2Launch kl;
@@ -348,6 +338,7 @@ int stage78_extend(gsa_ctx *c)
 	u32 *ps_score = c->d_flag2.as<u32>();      // (the small kernel's order array is free again)
 	{ OpRecSums op = { nfu, c_len, c_score, c->d_scan.as<u32>(), ps_score, mail }; RC((lb_launch<2>(c, nfu, op, sx))); }
 	hipLaunchKernelGGL(k_block_sums, dim3(grid_for((size_t)nfb, TPB)), dim3(TPB), 0, sx, nfb, mail + M_NF, c->fb_fragbase.as<i32>(), c->d_scan.as<u32>(), ps_score, c->bl_alnlen.as<i32>(), c->bl_score.as<i32>());
+	if (c->profiling) dp_count_cells(c, (i32)nju, len1, len2, sx);      // (measurement: sum of m*n and m+n over the jobs, read with the final mailbox)
 	i32 *h_len = c->p_blk.as<i32>(), *h_score = h_len + nfb, *h_fragbase = h_score + nfb;
 	GSA_CHECK(c, hipMemcpyAsync(h_len, c->bl_alnlen.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
 	GSA_CHECK(c, hipMemcpyAsync(h_score, c->bl_score.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
