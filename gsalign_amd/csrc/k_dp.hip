@@ -115,10 +115,12 @@ struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; }
 #define DPT(...)
 #endif
 #define DP_LOOK 21
+#define DP_LDS_M 3072         // longest reference fragment for which four stripes share a workgroup (3 boundary columns in LDS)
 
-__global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__restrict__ sjobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
+template <int WPB>
+__global__ void __launch_bounds__(64 * WPB) k_dp_stripe(i32 nsj, const StripeJob *__restrict__ sjobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
                                                    const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2, uint8_t *dirbase, u32 *bndbase, u32 *ctr,
-                                                   uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, u32 ep)
+                                                   uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, u32 ep, i32 lds_c1, i32 lds_rows)
 {
 	extern __shared__ __attribute__((aligned(16))) int8_t C1[];        // the reference fragment as nt4 codes
 	__shared__ __attribute__((aligned(16))) uint8_t tile[DP_TILE_ROWS * 64];
@@ -127,15 +129,21 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 	int lo = 0, hi = nsj;
 	while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sjobs[mid].first_block <= (i32)blockIdx.x) lo = mid; else hi = mid; }
 	const StripeJob sj = sjobs[lo];
-	const int p = (int)blockIdx.x - sj.first_block, m = sj.m, n = sj.n, P = sj.P, lane = threadIdx.x;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int p = ((int)blockIdx.x - sj.first_block) * WPB + wave, m = sj.m, n = sj.n, P = sj.P;
 	const uint8_t *s1 = pool1 + off1[sj.job], *s2 = pool2 + off2[sj.job];
 	const size_t pitch = (size_t)(m + 63) * 64;                         // direction bytes of one stripe
 	const int mpad64 = (m + 64 + 63) & ~63;                             // C1 is readable one 64-row block past the end
 	uint8_t *dir = dirbase + sj.diroff;
 	u32 *bnd_in = bndbase + sj.bndoff + (size_t)(p - 1) * m, *bnd_out = bndbase + sj.bndoff + (size_t)p * m;
 	u32 *err = ctr;                                                     // ctr[0]: spin-bound error flag
-	for (int t = lane; t < m; t += 64) C1[t] = (int8_t)(gsa_nt4(s1[t]) << 2);      // pre-multiplied: bit offset into the score table
-	for (int t = m + lane; t < mpad64; t += 64) C1[t] = 16;
+	for (int t = threadIdx.x; t < m; t += 64 * WPB) C1[t] = (int8_t)(gsa_nt4(s1[t]) << 2);      // pre-multiplied: bit offset into the score table
+	for (int t = m + threadIdx.x; t < mpad64; t += 64 * WPB) C1[t] = 16;
+	// WPB > 1: the stripes of one workgroup hand their boundary column over through LDS (same granules, tag 0 = not yet)
+	u32 *lds_bnd = (u32 *)(C1 + lds_c1);
+	if (WPB > 1) for (int t = threadIdx.x; t < (WPB - 1) * lds_rows; t += 64 * WPB) lds_bnd[t] = 0;
+	u32 *lin = lds_bnd + (size_t)(wave > 0 ? wave - 1 : 0) * lds_rows, *lout = lds_bnd + (size_t)(wave < WPB - 1 ? wave : 0) * lds_rows;
+	const bool out_lds = WPB > 1 && wave < WPB - 1;
 	const int t = p * 64 + lane;
 	const int Wp = n - p * 64 < 64 ? n - p * 64 : 64;
 	const int cq = t < n ? gsa_nt4(s2[t]) : 4;
@@ -146,13 +154,17 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 	int u = t ? 2 : 0, y = 0;
 	u32 bin = 0, gnext = 0;
 	__syncthreads();
+	if (p >= P) return;                                 // (a workgroup's spare waves only helped to stage the fragment)
 	const int nl = m + Wp - 1;
 	DPT(const unsigned long long T0c = wall_clock64();)
 	int wref = 16;                                      // 4 * reference code of my row on the current diagonal (travels one lane up per diagonal)
 	int creg = 16;                                      // lane q: 4 * code of reference row (rl & ~63) + q
 	uint8_t *dirp = dir + (size_t)p * pitch;
 	// boundary granules are fetched ONE BLOCK AHEAD (8 rows per block) so their L2 latency overlaps the block before
-	if (p > 0) { const int row = (lane & (DP_G - 1)) < m ? (lane & (DP_G - 1)) : m - 1; gnext = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+	if (p > 0) {
+		const int row = (lane & (DP_G - 1)) < m ? (lane & (DP_G - 1)) : m - 1;
+		gnext = (WPB > 1 && wave > 0) ? __hip_atomic_load(&lin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 	asm volatile("" :: "v"(gnext));                      // the first prefetch is complete before the loop: inside it, waits then only count stores issued after a prefetch
 	const int jjoff = lane < Wp ? lane : 0x40000000;    // lanes beyond the stripe never become valid
 	const bool pub_stripe = p < P - 1;                  // (then Wp == 64 and lane 63 owns the boundary column)
@@ -160,11 +172,12 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 	int pk = 0;                                         // x | v << 8 of my column after the current diagonal
 	int hist = 0;                                       // lane 63 - q: pk of lane 63 q diagonals ago (boundary rows travel one lane down per diagonal)
 	// one anti-diagonal; K2 is the position inside the 16-row block (a literal in the unrolled body)
-#define DP_STEP(K2, FIRST)                                                                                           \
+#define DP_LOADG(MODE, ROW) ((MODE) == 2 ? __hip_atomic_load(&lin[ROW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(&bnd_in[ROW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+#define DP_STEP(K2, MODE)                                                                                            \
 	{                                                                                                           \
 		const int rl_ = rl0 + (K2);                                                                             \
 		if (((K2) & (DP_G - 1)) == 0) {                                                                                  \
-			if (FIRST) bin = (rl_ == 0 && lane == 0) ? 0u : 0x200u;    /* t = 0 boundary: x1 = 0, v1 = q, except for the very first cell (:157-164) */ \
+			if ((MODE) == 0) bin = (rl_ == 0 && lane == 0) ? 0u : 0x200u;    /* t = 0 boundary: x1 = 0, v1 = q, except for the very first cell (:157-164) */ \
 			else if (rl_ < m) {                                                                                 \
 				/* boundary rows rl_ .. rl_+DP_G-1 from stripe p-1: spin until every granule carries its tag */       \
 				const int row = rl_ + (lane & (DP_G - 1));                                                               \
@@ -175,13 +188,13 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 					do {                                                                                        \
 						if (++spins > (1u << 20) || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; } \
 						__builtin_amdgcn_s_sleep(1);                                                            \
-						if (need) g = __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+						if (need) g = DP_LOADG(MODE, row);                                                          \
 					} while (!__all(!need || (g >> 16) == ep));                                                  \
 				}                                                                                               \
 				bin = g & 0xffffu;                                                                              \
 				/* every lane loads (clamped row): an unconditional load lands in gnext without a copy that would wait for it */ \
 				const int rown = row + DP_G < m ? row + DP_G : m - 1;                                           \
-				gnext = __hip_atomic_load(&bnd_in[rown], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           \
+				gnext = DP_LOADG(MODE, rown);                                                                     \
 			}                                                                                                   \
 		}                                                                                                       \
 		wref = wave_shr1(wref, __builtin_amdgcn_readlane(creg, cbase + (K2)));                                  \
@@ -208,29 +221,36 @@ __global__ void __launch_bounds__(64) k_dp_stripe(i32 nsj, const StripeJob *__re
 		if (((K2) & (DP_G - 1)) == DP_G - 2 && pub_stripe && rl_ >= 62 + DP_G) {                                                       \
 			/* rows rl_-62-DP_G .. rl_-63 of the boundary column are complete: one store of DP_G tagged granules */ \
 			const int row = rl_ - 126 + lane;                                                                   \
-			if (lane >= 64 - DP_G && row < m) __hip_atomic_store(&bnd_out[row], (ep << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+			if (lane >= 64 - DP_G && row < m) {                                                                 \
+				if (out_lds) __hip_atomic_store(&lout[row], (ep << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+				else __hip_atomic_store(&bnd_out[row], (ep << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+			}                                                                                                   \
 		}                                                                                                       \
 	}
 	// (two copies of the loop: stripe 0 has no boundary loads in flight, and keeping it apart keeps its waits off the stores)
-#define DP_LOOP(FIRST)                                                                                          \
+#define DP_LOOP(MODE)                                                                                           \
 	for (int rl0 = 0; rl0 < nl; rl0 += 16) {                                                                    \
 		if ((rl0 & 63) == 0) creg = C1[rl0 + lane];                                                             \
 		const int cbase = rl0 & 63;                                                                             \
 		uint8_t *rowp = dirp + ((size_t)rl0 << 6);                                                              \
 		if (rl0 + 16 <= nl) {                                                                                   \
-			DP_STEP(0, FIRST) DP_STEP(1, FIRST) DP_STEP(2, FIRST) DP_STEP(3, FIRST) DP_STEP(4, FIRST) DP_STEP(5, FIRST) DP_STEP(6, FIRST) DP_STEP(7, FIRST) \
-			DP_STEP(8, FIRST) DP_STEP(9, FIRST) DP_STEP(10, FIRST) DP_STEP(11, FIRST) DP_STEP(12, FIRST) DP_STEP(13, FIRST) DP_STEP(14, FIRST) DP_STEP(15, FIRST) \
+			DP_STEP(0, MODE) DP_STEP(1, MODE) DP_STEP(2, MODE) DP_STEP(3, MODE) DP_STEP(4, MODE) DP_STEP(5, MODE) DP_STEP(6, MODE) DP_STEP(7, MODE) \
+			DP_STEP(8, MODE) DP_STEP(9, MODE) DP_STEP(10, MODE) DP_STEP(11, MODE) DP_STEP(12, MODE) DP_STEP(13, MODE) DP_STEP(14, MODE) DP_STEP(15, MODE) \
 		} else {                                                                                                \
-			for (int k2 = 0; rl0 + k2 < nl; k2++) DP_STEP(k2, FIRST)                                            \
+			for (int k2 = 0; rl0 + k2 < nl; k2++) DP_STEP(k2, MODE)                                            \
 		}                                                                                                       \
 	}
-	if (p == 0) { DP_LOOP(1) } else { DP_LOOP(0) }
+	if (p == 0) { DP_LOOP(0) } else if (WPB > 1 && wave > 0) { DP_LOOP(2) } else { DP_LOOP(1) }
 #undef DP_LOOP
 #undef DP_STEP
+#undef DP_LOADG
 	if (pub_stripe) {
 		// the last (partial) block of boundary rows: lane 63 - q holds row m-1-q
 		const int row = m - 64 + lane;
-		if (lane >= 64 - DP_G && row >= 0) __hip_atomic_store(&bnd_out[row], (ep << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (lane >= 64 - DP_G && row >= 0) {
+			if (out_lds) __hip_atomic_store(&lout[row], (ep << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			else __hip_atomic_store(&bnd_out[row], (ep << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
 	}
 	DPT(if (p == 0 && lane == 0) ctr[sj.ctr + 40] = (u32)(wall_clock64() - T0c); if (p == P - 1 && lane == 0) ctr[sj.ctr + 41] = (u32)(wall_clock64() - T0c);)
 	// ---- ticket: the last stripe to finish does the traceback ----
@@ -385,6 +405,10 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	int mmax = 1;
 	for (const Lg &g : large) if (g.m > mmax) mmax = g.m;
 	const int mpad = (mmax + 64 + 63) & ~63;
+	// reference fragments up to DP_LDS_M bases: four stripes per workgroup, boundary columns through LDS
+	const int wpb = mmax <= DP_LDS_M ? 4 : 1;
+	const int lds_rows = (mmax + 15) & ~15;
+	const size_t dyn_lds = (size_t)mpad + (wpb > 1 ? (size_t)(wpb - 1) * lds_rows * 4 : 0);
 	if (mpad > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 153600 bases");
 	hipEvent_t ev_fork = c->ev[10], ev_j2 = c->ev[12];
 	// the many small jobs run on a second stream, concurrently with the striped ones
@@ -412,7 +436,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 			StripeJob s; s.job = g.job; s.m = g.m; s.n = g.n; s.P = (g.n + 63) / 64;
 			s.diroff = dbytes; dbytes += cells + 128;
 			s.bndoff = bwords; bwords += (i64)(s.P - 1) * g.m;
-			s.ctr = nctr++; s.first_block = nblocks; nblocks += s.P;
+			s.ctr = nctr++; s.first_block = nblocks; nblocks += (s.P + wpb - 1) / wpb;
 			sj[k] = s;
 		}
 		const size_t last = first + cnt;
@@ -427,7 +451,8 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 		if (c->dp_epoch == 0 || c->d_dp_bnd.cap != bnd_cap0) { GSA_CHECK(c, hipMemsetAsync(bnd, 0, c->d_dp_bnd.cap, st)); if (c->dp_epoch == 0) c->dp_epoch = 1; }
 		GSA_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nctr + 64) * 4, st));
 		GSA_CHECK(c, hipMemcpyAsync(d_sj, sj, cnt * sizeof(StripeJob), hipMemcpyHostToDevice, st));
-		hipLaunchKernelGGL(k_dp_stripe, dim3((unsigned)nblocks), dim3(64), (size_t)mpad, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch);
+		if (wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)nblocks), dim3(256), dyn_lds, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows);
+		else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)nblocks), dim3(64), dyn_lds, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows);
 		GSA_CHECK(c, hipGetLastError());
 		GSA_CHECK(c, hipMemcpyAsync(mail + M_DPERR2, ctr, 4, hipMemcpyDeviceToDevice, st));
 		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })
