@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__re
 // window id per seed = (number of starts up to and including it) - 1; the same pass builds the
 // (window, bucket) sort keys and clears the per-window accumulators
 struct OpWindowKeys {
-	i64 na; const i32 *a_q; const i64 *a_r; const i32 *uniq, *ws;
+	i64 na; const i32 *a_q; const i64 *a_r; const i32 *uniq, *ws; i64 bmin; int bbits;
 	i32 *wsEx; u64 *key; u32 *val; unsigned long long *wbest, *wsum; i32 *wn;
 	__device__ i32 value(i64 i, int) const { return ws[i]; }
 	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
@@ -222,8 +222,8 @@ struct OpWindowKeys {
 		wsEx[i] = ex[0];
 		const i32 w = ex[0] + v[0] - 1;
 		const i64 pd = a_r[i] - a_q[i];
-		const u32 b = (u32)(i32)(pd >> 4) ^ 0x80000000u;
-		key[i] = uniq[i] ? (((u64)(u32)w << 32) | b) : ~0ull;       // non-unique seeds sort to the end
+		const u64 b = (u64)((pd >> 4) - bmin);                     // bucket, shifted to be non-negative: as few key bits as the contig needs
+		key[i] = uniq[i] ? (((u64)(u32)w << bbits) | b) : ~0ull;    // non-unique seeds sort to the end
 		val[i] = (u32)i;
 		wbest[i] = 0; wsum[i] = 0; wn[i] = 0;
 	}
@@ -239,7 +239,7 @@ struct OpRunHeads {
 
 // run r = [rs[r], rs[r+1]) ; the last run ends at nU (number of unique seeds)
 __global__ void k_window_mode(i64 na, const i32 *__restrict__ headEx, const i32 *__restrict__ rs, const u64 *__restrict__ key, const i32 *__restrict__ cuEx,
-                              unsigned long long *wbest)
+                              int bbits, unsigned long long *wbest)
 {
 	GID(na);
 	const i32 nRuns = headEx[na];
@@ -247,19 +247,19 @@ __global__ void k_window_mode(i64 na, const i32 *__restrict__ headEx, const i32 
 	const i32 nU = cuEx[na];
 	const i32 b = rs[i], e = (i + 1 < nRuns) ? rs[i + 1] : nU;
 	const u64 k = key[b];
-	const u32 w = (u32)(k >> 32);
+	const u32 w = (u32)(k >> bbits);
 	// first maximum in ascending key order (RefinePDFmap, GSAlign.cpp:251)
-	atomicMax(&wbest[w], ((unsigned long long)(u32)(e - b) << 32) | (0xFFFFFFFFu - (u32)k));
+	atomicMax(&wbest[w], ((unsigned long long)(u32)(e - b) << 32) | (0xFFFFFFFFu - (u32)(k & ((1ull << bbits) - 1))));
 }
 
-__global__ void k_window_avg(i64 na, const u64 *__restrict__ key, const u32 *__restrict__ val, const i32 *__restrict__ cuEx,
+__global__ void k_window_avg(i64 na, int bbits, const u64 *__restrict__ key, const u32 *__restrict__ val, const i32 *__restrict__ cuEx,
                              const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const unsigned long long *__restrict__ wbest,
                              unsigned long long *wsum, i32 *wn)
 {
 	GID(na);
 	if (i >= cuEx[na]) return;
-	const u64 k = key[i]; const u32 w = (u32)(k >> 32);
-	const i32 kk = (i32)((u32)k ^ 0x80000000u), mode = (i32)((0xFFFFFFFFu - (u32)wbest[w]) ^ 0x80000000u);
+	const u64 k = key[i]; const u32 w = (u32)(k >> bbits);
+	const i32 kk = (i32)(k & ((1ull << bbits) - 1)), mode = (i32)(0xFFFFFFFFu - (u32)wbest[w]);      // (shifted buckets: only their difference is used)
 	i64 dk = (i64)kk - mode; if (dk < 0) dk = -dk;
 	if (dk < 3) {                                                    // surviving bucket (:256)
 		const u32 s = val[i];
@@ -268,7 +268,7 @@ __global__ void k_window_avg(i64 na, const u64 *__restrict__ key, const u32 *__r
 	}
 }
 
-__global__ void k_outlier_kill(i64 na, const u64 *__restrict__ key, const u32 *__restrict__ val, const i32 *__restrict__ cuEx,
+__global__ void k_outlier_kill(i64 na, int bbits, const u64 *__restrict__ key, const u32 *__restrict__ val, const i32 *__restrict__ cuEx,
                                const i32 *__restrict__ head, const i32 *__restrict__ headEx, const i32 *__restrict__ rs,
                                const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const unsigned long long *__restrict__ wbest,
                                const unsigned long long *__restrict__ wsum, const i32 *__restrict__ wn, i64 G, i32 max_indel, i32 *alive)
@@ -276,8 +276,8 @@ __global__ void k_outlier_kill(i64 na, const u64 *__restrict__ key, const u32 *_
 	GID(na);
 	const i32 nU = cuEx[na];
 	if (i >= nU) return;
-	const u64 k = key[i]; const u32 w = (u32)(k >> 32);
-	const i32 kk = (i32)((u32)k ^ 0x80000000u), mode = (i32)((0xFFFFFFFFu - (u32)wbest[w]) ^ 0x80000000u);
+	const u64 k = key[i]; const u32 w = (u32)(k >> bbits);
+	const i32 kk = (i32)(k & ((1ull << bbits) - 1)), mode = (i32)(0xFFFFFFFFu - (u32)wbest[w]);      // (shifted buckets: only their difference is used)
 	i64 dk = (i64)kk - mode; if (dk < 0) dk = -dk;
 	const i32 nRuns = headEx[na];
 	const i32 r = headEx[i] + head[i] - 1;
@@ -439,15 +439,18 @@ int stage2_chain(gsa_ctx *c)
 	if (getenv("GSA_DEBUG_CHAIN")) { i32 nc_ = 0, nb_ = 0; hipStreamSynchronize(st); hipMemcpy(&nc_, candEx + na, 4, hipMemcpyDeviceToHost); hipMemcpy(&nb_, brkEx + na, 4, hipMemcpyDeviceToHost); fprintf(stderr, "[gsa] stage 2: %lld seeds, %d window-start candidates, %d breaks\n", (long long)na, nc_, nb_); }
 	// C. outliers
 	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);
-	{ OpWindowKeys op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, wsEx, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(),
+	// (window, bucket) keys: bucket = PosDiff >> 4 shifted by its minimum, so the sort only runs over the bits in use
+	const i64 bmin = ((-(i64)c->qlen) >> 4) - 1;
+	const int bbits = ceil_log2_u64((u64)(((2 * c->G + c->qlen) >> 4) - bmin + 2)), wbits = ceil_log2_u64((u64)na + 1);
+	{ OpWindowKeys op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, bmin, bbits, wsEx, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(),
 	                      c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>() }; RC((lb_launch<1>(c, na, op))); }
-	RC(prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, 64));
+	RC(prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, bbits + wbits));
 	i32 *head = c->d_flag.as<i32>(), *headEx = c->d_scan.as<i32>(), *rs = c->a_runinfo.as<i32>();
 	{ OpRunHeads op = { na, c->d_key_b.as<u64>(), head, headEx, rs }; RC((lb_launch<1>(c, na, op))); }
-	LAUNCH(k_window_mode, na, na, headEx, rs, c->d_key_b.as<u64>(), cuEx, c->w_best.as<unsigned long long>());
-	LAUNCH(k_window_avg, na, na, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), cuEx, c->a_q.as<i32>(), c->a_r.as<i64>(), c->w_best.as<unsigned long long>(),
+	LAUNCH(k_window_mode, na, na, headEx, rs, c->d_key_b.as<u64>(), cuEx, bbits, c->w_best.as<unsigned long long>());
+	LAUNCH(k_window_avg, na, na, bbits, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), cuEx, c->a_q.as<i32>(), c->a_r.as<i64>(), c->w_best.as<unsigned long long>(),
 	       c->w_sum.as<unsigned long long>(), c->w_n.as<i32>());
-	LAUNCH(k_outlier_kill, na, na, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), cuEx, head, headEx, rs, c->a_q.as<i32>(), c->a_r.as<i64>(),
+	LAUNCH(k_outlier_kill, na, na, bbits, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), cuEx, head, headEx, rs, c->a_q.as<i32>(), c->a_r.as<i64>(),
 	       c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->G, c->prm.MaxIndelSize, alive);
 	// D. multi-hit positions
 	i32 *auEx = c->a_aurank.as<i32>(), *aulist = c->a_aulist.as<i32>();
