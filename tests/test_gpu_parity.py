@@ -126,6 +126,7 @@ def test_midsize_pair_2pct(oracle_built, tmp_path):
     (2000000, 3, 0.01, 12, {}),                       # 1 %
     (600000, 2, 0.02, 13, dict(sen=1, clr=50)),       # -sen: 5-bp stride, many tiny groups, candidate-buffer growth
     (800000, 2, 0.08, 14, dict(slen=12, idy=60)),     # high divergence, short seeds
+    (12000000, 1, 0.02, 21, {}),                      # 12 Mb contig: window chain in global memory, > 2048 striped DP jobs, multi-tile scans
 ])
 def test_scaled_pairs_vs_oracle(oracle_built, tmp_path, total, ncontig, div, seed, params):
     """Larger synthetic pairs than the committed fixtures; index from OUR builder, result vs the oracle."""
