@@ -148,15 +148,24 @@ int host_stage8_finish(gsa_ctx *c)
 	if (hm[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	if (hm[M_DPERR2]) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
 	if (c->profiling) { const unsigned long long *cc = (const unsigned long long *)(hm + M_CELLS); c->counters[4] += cc[0]; c->counters[6] += cc[1]; }
+	if (hm[M_DPERR3]) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out (early launch)");
 	// the large DP jobs finished after the records left: their (aln_len, score) arrive as a patch list
+	// (first the ones that only turned up in the job list, then the ones launched from the leaf table;
+	//  record -1 = an early job whose leaf the list logic dropped)
 	{
 		gsa_frag *fr = c->p_frags.as<gsa_frag>();
 		const i32 *pt = c->p_patch.as<i32>();
-		for (i32 g = 0; g < c->n_large; g++) {
+		const i32 np = c->n_large + c->n_early;
+		for (i32 g = 0; g < np; g++) {
 			const i32 rec = pt[3 * g], L = pt[3 * g + 1], sc = pt[3 * g + 2];
+			if (rec < 0) continue;
 			fr[rec].aln_len = L;
 			const size_t k = (size_t)(std::upper_bound(fragbase, fragbase + nfb, rec) - fragbase) - 1;      // block of the record
 			bl_len[k] += L; bl_score[k] += sc;
+			if (c->profiling && g >= c->n_large) {
+				const i32 *e = &c->h_early[3 * (size_t)(g - c->n_large)];
+				c->counters[4] += (u64)e[1] * (u64)e[2]; c->counters[5] += 1; c->counters[6] += (u64)(e[1] + e[2]);
+			}
 		}
 	}
 	auto t0 = std::chrono::steady_clock::now();

@@ -18,7 +18,7 @@ struct Leaf {
 
 // Device "mailbox" (i32[MAIL_N]) of the counts the stages produce; the host reads the whole
 // box in ONE pinned copy where it needs them instead of one read-back per count.
-enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_TICKET = 48, M_NBRAW = 49, M_NR2 = 50, M_NF = 51, M_NJOB = 52, M_OPSTOT = 53, M_NALN = 54, M_DPERR = 55, M_NLARGE = 56, M_DPERR2 = 57, M_CELLS = 58 /* two u64: sum m*n, sum m+n */, MAIL_N = 64 };
+enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_TICKET = 48, M_NBRAW = 49, M_NR2 = 50, M_NF = 51, M_NJOB = 52, M_OPSTOT = 53, M_NALN = 54, M_DPERR = 55, M_NLARGE = 56, M_DPERR2 = 57, M_CELLS = 58 /* two u64: sum m*n, sum m+n */, M_NEARLY = 62, M_DPERR3 = 63, MAIL_N = 64 };
 #define LEAF_CHUNK 1024      // leaves copied together with the mailbox (more -> a second copy)
 
 struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf range
@@ -112,6 +112,9 @@ struct gsa_ctx {
 	DevBuf f_type, f_mism, f_alnlen, f_job, f_score;
 	DevBuf j_frag, j_opsoff, j_nops, d_ops, j_cells;
 	DevBuf d_dp_bnd, d_dp_ctr, d_dp_jobs, d_dp_large;   // striped DP: boundary granules, tickets, job descriptors, (job,m,n) of the large jobs
+	// large DP gaps are known once the leaf table exists: they are launched there (stream_aux[0]) and run under stages 6-7
+	DevBuf e_id, e_rec, e_list, e_off1, e_off2, e_opsoff, e_nops, e_ops, e_rev, r_head, f_early;
+	i32 n_early = 0; bool early_in_flight = false; std::vector<i32> h_early;      // (seed, m, n) per early job
 	u32 dp_epoch = 0;                              // tag of the boundary granules of the current striped launch
 	DevBuf p_dp, p_sj;                             // pinned: mailbox + large-job list, stripe job descriptors
 	DevBuf d_aln1, d_aln2, d_alnoff;
@@ -157,6 +160,9 @@ i64 frags_count(gsa_ctx *c);          // k_extend.hip  (record count, fetched fr
 int stage78_extend(gsa_ctx *c);       // k_extend.hip  (S7: classification, DP, gapped strings, block sums)
 int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res);   // k_gapsim.hip
 void dp_count_cells(gsa_ctx *c, i32 n_ub, const i32 *len1, const i32 *len2, hipStream_t stream);   // k_dp.hip (profiling)
+struct LgJob { i32 job, m, n; };
+int launch_stripes(gsa_ctx *c, hipStream_t ss, std::vector<LgJob> &large, const uint8_t *pool1, const i64 *off1, const uint8_t *pool2, const i64 *off2,
+                   uint8_t *ops, const i64 *ops_off, i32 *ops_len, uint8_t *rev, int err_slot);   // k_dp.hip
 struct Ksw2Launch { i32 n = 0, nsmall = 0, nlarge = 0; bool small_in_flight = false; };      // what run_ksw2_jobs left running
 int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, const i32 *len1,
                   const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total, Ksw2Launch *out);   // k_dp.hip

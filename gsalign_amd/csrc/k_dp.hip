@@ -15,8 +15,8 @@
 #include "gsa_ctx.h"
 #include "gsa_dp.h"
 #include "gsa_scan.h"
+#include "gsa_gap.h"
 
-#define SMALL_ROWS 128
 #define SMALL_WAVES 4
 
 __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const i32 *__restrict__ order, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
@@ -332,7 +332,7 @@ struct OpClassify {
 	{
 		if (j >= mail[M_NJOB]) return 0;
 		const i32 m = len1[j], n = len2[j];
-		return (n <= 64 && m + n - 1 <= SMALL_ROWS) ? 0 : 1;
+		return dp_is_large(m, n) ? 1 : 0;
 	}
 	__device__ void emit(i64 j, const i32 *v, const i32 *ex) const
 	{
@@ -362,6 +362,69 @@ void dp_count_cells(gsa_ctx *c, i32 n_ub, const i32 *len1, const i32 *len2, hipS
 }
 
 #define LG_CHUNK 2048       // large-job triples copied together with the mailbox (more -> a second copy)
+
+// Striped kernel for a list of large jobs on stream `ss` (batches so that the direction bytes of one batch fit the
+// budget).  The direction / boundary / ticket buffers are shared: two launches must not be in flight together.
+int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const uint8_t *pool1, const i64 *off1, const uint8_t *pool2, const i64 *off2,
+                   uint8_t *ops, const i64 *ops_off, i32 *ops_len, uint8_t *rev, int err_slot)
+{
+	if (large.empty()) return GSA_OK;
+	i32 *mail = c->d_mail.as<i32>();
+	std::sort(large.begin(), large.end(), [](const LgJob &a, const LgJob &b) { const i64 ca = (i64)a.m * a.n, cb = (i64)b.m * b.n; return ca != cb ? ca > cb : a.job < b.job; });   // largest first: they are the critical path
+	int mmax = 1;
+	for (const LgJob &g : large) if (g.m > mmax) mmax = g.m;
+	const int mpad = (mmax + 64 + 63) & ~63;
+	// reference fragments up to DP_LDS_M bases: four stripes per workgroup, boundary columns through LDS
+	const int wpb = mmax <= DP_LDS_M ? 4 : 1;
+	const int lds_rows = (mmax + 15) & ~15;
+	const size_t dyn_lds = (size_t)mpad + (wpb > 1 ? (size_t)(wpb - 1) * lds_rows * 4 : 0);
+	if (mpad > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 153600 bases");
+	const i64 budget = 12ll << 30;
+	size_t first = 0;
+	while (first < large.size()) {
+		// descriptors are staged in pinned memory: the upload is asynchronous
+		size_t cnt = 0;
+		{ size_t l = first; i64 db = 128; while (l < large.size()) { const i64 cells = (((i64)large[l].n + 63) / 64) * ((i64)large[l].m + 63) * 64; if (l > first && db + cells > budget) break; db += cells + 128; l++; } cnt = l - first; }
+		if (!pin_ensure<StripeJob>(c, c->p_sj, cnt + 1)) return GSA_ERR_NOMEM;
+		StripeJob *sj = c->p_sj.as<StripeJob>();
+		i64 dbytes = 128, bwords = 0; i32 nctr = 1, nblocks = 0;
+		for (size_t k = 0; k < cnt; k++) {
+			const LgJob &g = large[first + k];
+			const i64 cells = (((i64)g.n + 63) / 64) * ((i64)g.m + 63) * 64;   // stripe-local direction bytes
+			StripeJob s; s.job = g.job; s.m = g.m; s.n = g.n; s.P = (g.n + 63) / 64;
+			s.diroff = dbytes; dbytes += cells + 128;
+			s.bndoff = bwords; bwords += (i64)(s.P - 1) * g.m;
+			s.ctr = nctr++; s.first_block = nblocks; nblocks += (s.P + wpb - 1) / wpb;
+			sj[k] = s;
+		}
+		const size_t last = first + cnt;
+		uint8_t *dir = dev_ensure<uint8_t>(c, c->d_scan2, (size_t)dbytes + 512);
+		const size_t bnd_cap0 = c->d_dp_bnd.cap;
+		u32 *bnd = dev_ensure<u32>(c, c->d_dp_bnd, (size_t)bwords + 64);
+		u32 *ctr = dev_ensure<u32>(c, c->d_dp_ctr, (size_t)nctr + 64);
+		StripeJob *d_sj = dev_ensure<StripeJob>(c, c->d_dp_jobs, cnt + 1);
+		if (!dir || !bnd || !ctr || !d_sj) return GSA_ERR_NOMEM;
+		// boundary granules carry the launch epoch as their tag: cleared only when the buffer is new or the epoch wraps
+		c->dp_epoch = (c->dp_epoch + 1) & 0xffffu;
+		if (c->dp_epoch == 0 || c->d_dp_bnd.cap != bnd_cap0) { GSA_CHECK(c, hipMemsetAsync(bnd, 0, c->d_dp_bnd.cap, st)); if (c->dp_epoch == 0) c->dp_epoch = 1; }
+		GSA_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nctr + 64) * 4, st));
+		GSA_CHECK(c, hipMemcpyAsync(d_sj, sj, cnt * sizeof(StripeJob), hipMemcpyHostToDevice, st));
+		if (wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)nblocks), dim3(256), dyn_lds, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows);
+		else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)nblocks), dim3(64), dyn_lds, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows);
+		GSA_CHECK(c, hipGetLastError());
+		GSA_CHECK(c, hipMemcpyAsync(mail + err_slot, ctr, 4, hipMemcpyDeviceToDevice, st));
+		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })
+		if (last < large.size()) {
+			// the staging buffer and the direction bytes are reused by the next batch
+			i32 *h = c->h_mail;
+			GSA_CHECK(c, hipMemcpyAsync(h, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
+			GSA_CHECK(c, hipStreamSynchronize(st));
+			if (h[err_slot]) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
+		}
+		first = last;
+	}
+	return GSA_OK;
+}
 
 // All pointers are device pointers; the job count sits in mail[M_NJOB] (<= n_ub).  Jobs that do not fit
 // the small kernel are processed in batches so that the direction bytes of one batch fit the budget.
@@ -399,17 +462,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 		GSA_CHECK(c, hipMemcpyAsync(h + MAIL_N, d_lg, (size_t)nlarge * 12, hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipStreamSynchronize(st));
 	}
-	struct Lg { i32 job, m, n; };
-	std::vector<Lg> large((const Lg *)(h + MAIL_N), (const Lg *)(h + MAIL_N) + nlarge);
-	std::sort(large.begin(), large.end(), [](const Lg &a, const Lg &b) { const i64 ca = (i64)a.m * a.n, cb = (i64)b.m * b.n; return ca != cb ? ca > cb : a.job < b.job; });   // largest first: they are the critical path
-	int mmax = 1;
-	for (const Lg &g : large) if (g.m > mmax) mmax = g.m;
-	const int mpad = (mmax + 64 + 63) & ~63;
-	// reference fragments up to DP_LDS_M bases: four stripes per workgroup, boundary columns through LDS
-	const int wpb = mmax <= DP_LDS_M ? 4 : 1;
-	const int lds_rows = (mmax + 15) & ~15;
-	const size_t dyn_lds = (size_t)mpad + (wpb > 1 ? (size_t)(wpb - 1) * lds_rows * 4 : 0);
-	if (mpad > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 153600 bases");
+	std::vector<LgJob> large((const LgJob *)(h + MAIL_N), (const LgJob *)(h + MAIL_N) + nlarge);
 	hipEvent_t ev_fork = c->ev[10], ev_j2 = c->ev[12];
 	// the many small jobs run on a second stream, concurrently with the striped ones
 	if (nsmall > 0) {
@@ -421,48 +474,11 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 		GSA_CHECK(c, hipEventRecord(ev_j2, c->stream_aux[1]));
 		out->small_in_flight = true;
 	}
-	const i64 budget = 12ll << 30;
-	size_t first = 0;
-	while (first < large.size()) {
-		// descriptors are staged in pinned memory: the upload is asynchronous
-		size_t cnt = 0;
-		{ size_t l = first; i64 db = 128; while (l < large.size()) { const i64 cells = (((i64)large[l].n + 63) / 64) * ((i64)large[l].m + 63) * 64; if (l > first && db + cells > budget) break; db += cells + 128; l++; } cnt = l - first; }
-		if (!pin_ensure<StripeJob>(c, c->p_sj, cnt + 1)) return GSA_ERR_NOMEM;
-		StripeJob *sj = c->p_sj.as<StripeJob>();
-		i64 dbytes = 128, bwords = 0; i32 nctr = 1, nblocks = 0;
-		for (size_t k = 0; k < cnt; k++) {
-			const Lg &g = large[first + k];
-			const i64 cells = (((i64)g.n + 63) / 64) * ((i64)g.m + 63) * 64;   // stripe-local direction bytes
-			StripeJob s; s.job = g.job; s.m = g.m; s.n = g.n; s.P = (g.n + 63) / 64;
-			s.diroff = dbytes; dbytes += cells + 128;
-			s.bndoff = bwords; bwords += (i64)(s.P - 1) * g.m;
-			s.ctr = nctr++; s.first_block = nblocks; nblocks += (s.P + wpb - 1) / wpb;
-			sj[k] = s;
-		}
-		const size_t last = first + cnt;
-		uint8_t *dir = dev_ensure<uint8_t>(c, c->d_scan2, (size_t)dbytes + 512);
-		const size_t bnd_cap0 = c->d_dp_bnd.cap;
-		u32 *bnd = dev_ensure<u32>(c, c->d_dp_bnd, (size_t)bwords + 64);
-		u32 *ctr = dev_ensure<u32>(c, c->d_dp_ctr, (size_t)nctr + 64);
-		StripeJob *d_sj = dev_ensure<StripeJob>(c, c->d_dp_jobs, cnt + 1);
-		if (!dir || !bnd || !ctr || !d_sj) return GSA_ERR_NOMEM;
-		// boundary granules carry the launch epoch as their tag: cleared only when the buffer is new or the epoch wraps
-		c->dp_epoch = (c->dp_epoch + 1) & 0xffffu;
-		if (c->dp_epoch == 0 || c->d_dp_bnd.cap != bnd_cap0) { GSA_CHECK(c, hipMemsetAsync(bnd, 0, c->d_dp_bnd.cap, st)); if (c->dp_epoch == 0) c->dp_epoch = 1; }
-		GSA_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nctr + 64) * 4, st));
-		GSA_CHECK(c, hipMemcpyAsync(d_sj, sj, cnt * sizeof(StripeJob), hipMemcpyHostToDevice, st));
-		if (wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)nblocks), dim3(256), dyn_lds, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows);
-		else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)nblocks), dim3(64), dyn_lds, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows);
-		GSA_CHECK(c, hipGetLastError());
-		GSA_CHECK(c, hipMemcpyAsync(mail + M_DPERR2, ctr, 4, hipMemcpyDeviceToDevice, st));
-		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })
-		if (last < large.size()) {
-			// the staging buffer and the direction bytes are reused by the next batch
-			GSA_CHECK(c, hipMemcpyAsync(h, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
-			GSA_CHECK(c, hipStreamSynchronize(st));
-			if (h[M_DPERR2]) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
-		}
-		first = last;
+	if (nlarge > 0) {
+		// (large gaps are normally launched early, from the leaf table; whatever turns up here shares their buffers)
+		if (c->early_in_flight) GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[14], 0));
+		int rc = launch_stripes(c, st, large, pool1, off1, pool2, off2, ops, ops_off, ops_len, rev, M_DPERR2);
+		if (rc) return rc;
 	}
 	// (no join: the caller decides what else runs behind the small kernel on stream_aux[1]; event ev[12] marks its end)
 	return GSA_OK;

@@ -9,6 +9,7 @@
 #include "gsa_ctx.h"
 #include "gsa_fm.h"
 #include "gsa_scan.h"
+#include "gsa_gap.h"
 
 #define TPB 256
 #define GID(n) i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (n)) return
@@ -16,7 +17,6 @@
 #define ENS(T, buf, n) do { if (!dev_ensure<T>(c, c->buf, (size_t)(n))) return GSA_ERR_NOMEM; } while (0)
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
-enum { FT_SEED = 0, FT_DEL = 1, FT_INS = 2, FT_EQ = 3, FT_DP = 4 };
 
 __device__ __forceinline__ i32 find_block(const i32 *__restrict__ base, i32 nfb, i64 slot)
 {
@@ -29,8 +29,8 @@ __device__ __forceinline__ i32 find_block(const i32 *__restrict__ base, i32 nfb,
 // per seed slot: the seed record and, if a gap follows (IdentifyNormalPairs :241-265), the gap record,
 // classified (GenerateFragAlignment :311-342)
 struct OpSlots {
-	i32 nfb; const i32 *seedbase, *sbeg, *q, *len; const i64 *r; const uint8_t *query, *ref;
-	gsa_frag *frag; i32 *ftype, *fmism, *fragbase, *mail;
+	i32 nfb; const i32 *seedbase, *sbeg, *q, *len; const i64 *r; const uint8_t *query, *ref; const i32 *e_id;
+	gsa_frag *frag; i32 *ftype, *fmism, *fragbase, *fearly, *e_rec, *mail;
 	__device__ void slot(i64 i, i32 &k, i32 &s, i32 &n) const
 	{
 		k = find_block(seedbase, nfb, i);
@@ -48,24 +48,15 @@ struct OpSlots {
 		const i32 p = ex[0];
 		if (i == seedbase[k]) fragbase[k] = p;
 		gsa_frag f; f.bseed = 1; f.qpos = q[s]; f.qlen = len[s]; f.rlen = len[s]; f.rpos = r[s]; f.aln_off = 0; f.aln_len = 0; f._pad = 0;
-		frag[p] = f; ftype[p] = FT_SEED; fmism[p] = 0;
+		frag[p] = f; ftype[p] = FT_SEED; fmism[p] = 0; fearly[p] = -1;
 		if (v[0] == 2) {
 			i32 qg = q[s + 1] - (q[s] + len[s]); if (qg < 0) qg = 0;
 			i64 rg64 = r[s + 1] - (r[s] + len[s]); i32 rg = rg64 < 0 ? 0 : (i32)rg64;
 			gsa_frag g; g.bseed = 0; g.qpos = q[s] + len[s]; g.rpos = r[s] + len[s]; g.qlen = qg; g.rlen = rg; g.aln_off = 0; g.aln_len = 0; g._pad = 0;
-			i32 t, mism = 0;
-			if (qg == 0) t = FT_DEL;
-			else if (rg == 0) t = FT_INS;
-			else {
-				t = FT_DP;
-				if (qg == rg) {
-					// CheckFragPairMismatch: positions where the QUERY is ambiguous are skipped
-					const uint8_t *qs = query + g.qpos, *rs = ref + g.rpos;
-					for (i32 x = 0; x < qg && mism <= GSA_MAX_MISMATCH; x++) { const int a = gsa_nt4(qs[x]); if (a != 4 && a != gsa_nt4(rs[x])) mism++; }
-					if (mism <= GSA_MAX_MISMATCH) t = FT_EQ;
-				}
-			}
+			i32 mism; const i32 t = classify_gap(query, ref, g.qpos, g.rpos, qg, rg, mism);
 			frag[p + 1] = g; ftype[p + 1] = t; fmism[p + 1] = mism;
+			const i32 e = e_id[s];                            // a large DP gap launched from the leaf table: link job and record
+			fearly[p + 1] = e; if (e >= 0) e_rec[e] = p + 1;
 		}
 	}
 	__device__ void done(const i32 *t) const { mail[M_NF] = t[0]; }
@@ -76,13 +67,13 @@ struct OpSlots {
 // gapped strings, and of a DP job's op string, then do not depend on the DP results, and everything
 // that is not a large DP job can be written while the striped kernel still runs.
 struct OpDpJobs {
-	const i32 *ftype; const gsa_frag *frag;
+	const i32 *ftype, *fearly; const gsa_frag *frag;
 	i32 *jfrag; i64 *off1; i32 *len1; i64 *off2; i32 *len2; i64 *opsoff; i32 *fjob, *alen; i64 *aoff; i32 *mail;
 	__device__ i32 value(i64 i, int c) const
 	{
 		if (i >= mail[M_NF]) return 0;
 		const i32 t = ftype[i];
-		if (c == 0) return t == FT_DP ? 1 : 0;
+		if (c == 0) return (t == FT_DP && fearly[i] < 0) ? 1 : 0;      // (early jobs are already running)
 		if (t == FT_DEL) return frag[i].rlen;
 		if (t == FT_INS || t == FT_EQ) return frag[i].qlen;
 		if (t == FT_DP) return frag[i].rlen + frag[i].qlen;
@@ -92,7 +83,7 @@ struct OpDpJobs {
 	{
 		if (i >= mail[M_NF]) return;
 		alen[i] = v[1]; aoff[i] = ex[1];                      // (alen of a DP gap: replaced by the op count)
-		if (!v[0]) { fjob[i] = -1; return; }
+		if (!v[0]) { fjob[i] = (ftype[i] == FT_DP) ? -2 - fearly[i] : -1; return; }      // <= -2: early job -2 - fjob
 		const i32 j = ex[0];
 		jfrag[j] = (i32)i; off1[j] = frag[i].rpos; len1[j] = frag[i].rlen; off2[j] = frag[i].qpos; len2[j] = frag[i].qlen; opsoff[j] = ex[1];
 		fjob[i] = j;
@@ -110,14 +101,14 @@ struct OpRecSums {
 
 // one DP record written by a whole 256-thread workgroup: 256 positions per pass, prefix counts of the
 // consumed bases across the workgroup.  Returns the score (identical pairs) in every thread.
-__device__ i32 write_dp_record_wg(i64 i, i32 L, const i32 *__restrict__ fjob, const i64 *__restrict__ aoff, const uint8_t *__restrict__ ops, const i64 *__restrict__ opsoff,
+__device__ i32 write_dp_record_wg(i64 i, i32 L, const uint8_t *__restrict__ op, const i64 *__restrict__ aoff,
                                   const uint8_t *__restrict__ query, const uint8_t *__restrict__ ref, gsa_frag *frag, uint8_t *aln1, uint8_t *aln2,
                                   int *s_w1, int *s_w2, int *s_sc)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const gsa_frag f = frag[i];
 	const i64 o = aoff[i];
-	const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos, *op = ops + opsoff[fjob[i]];
+	const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos;
 	i32 i1 = 0, i2 = 0, score = 0;
 	if (tid == 0) *s_sc = 0;
 	for (i32 base = 0; base < L; base += 256) {
@@ -168,7 +159,8 @@ __global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_
 		const i64 i = (i64)blockIdx.x * 256 + tid;
 		if (i < nf) {
 			const i32 t = ftype[i];
-			const i32 Lr = t == FT_DP ? (jlarge[fjob[i]] ? -1 : nops[fjob[i]]) : alen[i];       // -1: a large DP job, written after the striped kernel
+			const i32 fj = fjob[i];
+			const i32 Lr = t == FT_DP ? ((fj < 0 || jlarge[fj]) ? -1 : nops[fj]) : alen[i];       // -1: a large DP job, written after the striped kernel
 			if (t == FT_SEED) { const i32 l = frag[i].qlen; c_len[i] = l; c_score[i] = l; }
 			else if (Lr < 0) { c_len[i] = 0; c_score[i] = 0; frag[i].aln_off = aoff[i]; frag[i].aln_len = 0; }
 			else if (Lr > MAT_SERIAL) s_list[atomicAdd(&s_n, 1)] = tid;
@@ -231,17 +223,20 @@ __global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_
 
 // The records of the large DP jobs, after the striped kernel: one workgroup per job; (record, aln_len,
 // score) go to a patch list the host applies to the records and block sums it already holds.
-__global__ void __launch_bounds__(256) k_materialize_large(i32 nlarge, const i32 *__restrict__ lg, const i32 *__restrict__ jfrag, const i32 *__restrict__ fjob, const i32 *__restrict__ nops,
+// Two sources: jobs launched early from the leaf table (rec_of = e_rec, -1 = their leaf was dropped) and
+// whatever large job only turned up in the job list (lg != nullptr: job = lg[3g], record = jfrag[job]).
+__global__ void __launch_bounds__(256) k_materialize_large(i32 nlarge, const i32 *__restrict__ lg, const i32 *__restrict__ rec_of, const i32 *__restrict__ nops,
                                                             const i64 *__restrict__ aoff, const uint8_t *__restrict__ ops, const i64 *__restrict__ opsoff,
                                                             const uint8_t *__restrict__ query, const uint8_t *__restrict__ ref, gsa_frag *frag, uint8_t *aln1, uint8_t *aln2, i32 *patch)
 {
 	__shared__ int s_w1[4], s_w2[4], s_sc;
 	const int g = blockIdx.x;
 	if (g >= nlarge) return;
-	const i32 job = lg[3 * g];
-	const i64 i = jfrag[job];
+	const i32 job = lg ? lg[3 * g] : g;
+	const i64 i = rec_of[job];
+	if (i < 0) { if (threadIdx.x == 0) { patch[3 * g] = -1; patch[3 * g + 1] = 0; patch[3 * g + 2] = 0; } return; }
 	const i32 L = nops[job];
-	const i32 sc = write_dp_record_wg(i, L, fjob, aoff, ops, opsoff, query, ref, frag, aln1, aln2, s_w1, s_w2, &s_sc);
+	const i32 sc = write_dp_record_wg(i, L, ops + opsoff[job], aoff, query, ref, frag, aln1, aln2, s_w1, s_w2, &s_sc);
 	if (threadIdx.x == 0) { patch[3 * g] = (i32)i; patch[3 * g + 1] = L; patch[3 * g + 2] = sc; }
 }
 
@@ -290,8 +285,10 @@ int stage7_fill(gsa_ctx *c)
 	GSA_CHECK(c, hipMemcpyAsync(c->fb_sbeg.p, sbeg, (size_t)nfb * 4, hipMemcpyHostToDevice, st));
 	const i64 nfu = c->nf_ub;
 	ENS(gsa_frag, f_rec, nfu + 1); ENS(i32, f_type, nfu + 1); ENS(i32, f_mism, nfu + 1); ENS(i32, f_score, nfu + 1); ENS(i32, f_job, nfu + 1); ENS(i32, f_alnlen, nfu + 1);
-	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), c->fb_sbeg.as<i32>(), c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
-	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), c->fb_fragbase.as<i32>(), c->d_mail.as<i32>() };
+	ENS(i32, f_early, nfu + 2);
+	if (c->n_early > 0) GSA_CHECK(c, hipMemsetAsync(c->e_rec.p, 0xff, (size_t)c->n_early * 4, st));      // -1: no record (yet)
+	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), c->fb_sbeg.as<i32>(), c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref, c->e_id.as<i32>(),
+	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), c->fb_fragbase.as<i32>(), c->f_early.as<i32>(), c->e_rec.as<i32>(), c->d_mail.as<i32>() };
 	RC((lb_launch<1, 1>(c, ns, op)));      // (one slot per thread: the mismatch count of a gap is a serial loop)
 	c->n_frags = -1;
 	return GSA_OK;
@@ -315,7 +312,7 @@ int stage78_extend(gsa_ctx *c)
 	ENS(i64, w_best, nju + 1); ENS(i64, w_sum, nju + 1); ENS(i32, a_uniq, nju + 1); ENS(i32, a_cu, nju + 1);
 	i64 *off1 = c->w_best.as<i64>(), *off2 = c->w_sum.as<i64>(); i32 *len1 = c->a_uniq.as<i32>(), *len2 = c->a_cu.as<i32>();
 	ENS(i64, d_alnoff, nfu + 2);
-	{ OpDpJobs op = { c->f_type.as<i32>(), c->f_rec.as<gsa_frag>(), c->j_frag.as<i32>(), off1, len1, off2, len2, c->j_opsoff.as<i64>(), c->f_job.as<i32>(),
+	{ OpDpJobs op = { c->f_type.as<i32>(), c->f_early.as<i32>(), c->f_rec.as<gsa_frag>(), c->j_frag.as<i32>(), off1, len1, off2, len2, c->j_opsoff.as<i64>(), c->f_job.as<i32>(),
 	                  c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), mail }; RC((lb_launch<2>(c, nfu, op))); }
 	ENS(uint8_t, d_ops, c->span_ub + 64); ENS(uint8_t, d_aln1, c->span_ub + 64); ENS(uint8_t, d_aln2, c->span_ub + 64);
 	ENS(i32, d_flag, nfu + 2); ENS(u32, d_scan, nfu + 2); ENS(u32, d_flag2, nfu + 2); ENS(i32, bl_alnlen, nfb + 1); ENS(i32, bl_score, nfb + 1);
@@ -326,7 +323,7 @@ int stage78_extend(gsa_ctx *c)
 	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN]; c->n_large = kl.nlarge;
 	const size_t nfr = (size_t)c->n_frags;
 	if (!pin_ensure<gsa_frag>(c, c->p_frags, nfr) || !pin_ensure<char>(c, c->p_aln1, (size_t)c->n_aln) || !pin_ensure<char>(c, c->p_aln2, (size_t)c->n_aln) ||
-	    !pin_ensure<i32>(c, c->p_blk, (size_t)3 * (nfb + 1) + MAIL_N + 8) || !pin_ensure<i32>(c, c->p_patch, 3 * (size_t)kl.nlarge + 4)) return GSA_ERR_NOMEM;
+	    !pin_ensure<i32>(c, c->p_blk, (size_t)3 * (nfb + 1) + MAIL_N + 8) || !pin_ensure<i32>(c, c->p_patch, 3 * ((size_t)kl.nlarge + (size_t)c->n_early) + 4)) return GSA_ERR_NOMEM;
 	// ---- behind the small jobs (stream_aux[1]; when there is no small job it starts at the fork) ----
 	if (!kl.small_in_flight) { GSA_CHECK(c, hipEventRecord(c->ev[10], st)); GSA_CHECK(c, hipStreamWaitEvent(sx, c->ev[10], 0)); }
 	const i32 *jlarge = c->d_dp_large.as<i32>() + 3 * ((size_t)nju + 1);
@@ -345,13 +342,21 @@ int stage78_extend(gsa_ctx *c)
 	GSA_CHECK(c, hipMemcpyAsync(h_fragbase, c->fb_fragbase.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
 	if (nfr) GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, nfr * sizeof(gsa_frag), hipMemcpyDeviceToHost, sx));
 	GSA_CHECK(c, hipEventRecord(c->ev[13], sx));
-	// ---- behind the striped kernel (main stream) ----
-	if (kl.nlarge > 0) {
-		ENS(i32, d_patch, 3 * (size_t)kl.nlarge + 4);
-		hipLaunchKernelGGL(k_materialize_large, dim3((unsigned)kl.nlarge), dim3(256), 0, st, kl.nlarge, c->d_dp_large.as<i32>(), c->j_frag.as<i32>(), c->f_job.as<i32>(), c->j_nops.as<i32>(),
-		                   c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
-		                   c->f_rec.as<gsa_frag>(), c->d_aln1.as<uint8_t>(), c->d_aln2.as<uint8_t>(), c->d_patch.as<i32>());
-		GSA_CHECK(c, hipMemcpyAsync(c->p_patch.p, c->d_patch.p, 3 * (size_t)kl.nlarge * 4, hipMemcpyDeviceToHost, st));
+	// ---- behind the striped kernels ----
+	const size_t npatch = (size_t)kl.nlarge + (size_t)c->n_early;
+	if (npatch > 0) {
+		ENS(i32, d_patch, 3 * npatch + 4);
+		if (kl.nlarge > 0)
+			hipLaunchKernelGGL(k_materialize_large, dim3((unsigned)kl.nlarge), dim3(256), 0, st, kl.nlarge, c->d_dp_large.as<i32>(), c->j_frag.as<i32>(), c->j_nops.as<i32>(),
+			                   c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
+			                   c->f_rec.as<gsa_frag>(), c->d_aln1.as<uint8_t>(), c->d_aln2.as<uint8_t>(), c->d_patch.as<i32>());
+		if (c->n_early > 0) {
+			GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[14], 0));      // the early striped launch (stream_aux[0])
+			hipLaunchKernelGGL(k_materialize_large, dim3((unsigned)c->n_early), dim3(256), 0, st, c->n_early, (const i32 *)nullptr, c->e_rec.as<i32>(), c->e_nops.as<i32>(),
+			                   c->d_alnoff.as<i64>(), c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
+			                   c->f_rec.as<gsa_frag>(), c->d_aln1.as<uint8_t>(), c->d_aln2.as<uint8_t>(), c->d_patch.as<i32>() + 3 * (size_t)kl.nlarge);
+		}
+		GSA_CHECK(c, hipMemcpyAsync(c->p_patch.p, c->d_patch.p, 3 * npatch * 4, hipMemcpyDeviceToHost, st));
 	}
 	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[13], 0));      // the other strings are written, the records are on the host
 	if (c->n_aln) {

@@ -13,8 +13,10 @@
 // all blocks gives every block the same fixed point as the per-block loop.
 #include "gsa_ctx.h"
 #include "gsa_scan.h"
+#include "gsa_gap.h"
 
 #define TPB 256
+#define EARLY_CHUNK 512      // large gaps copied together with the leaf table (more -> a second copy)
 #define GID(n) i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (n)) return
 #define LAUNCH(k, n, ...) hipLaunchKernelGGL(k, dim3(grid_for((size_t)(n), TPB)), dim3(TPB), 0, st, __VA_ARGS__)
 #define ENS(T, buf, n) do { if (!dev_ensure<T>(c, c->buf, (size_t)(n))) return GSA_ERR_NOMEM; } while (0)
@@ -105,7 +107,7 @@ __global__ void k_gap_apply(i32 nj, const i32 *__restrict__ jseed, const i32 *__
 // trimmed lengths, 32-bit wrapping -- only differences over a leaf are ever used.
 struct OpChrCuts {
 	i64 n; DevIndex di; const i64 *r; const i32 *bid, *cut4, *len;
-	i32 *cut5, *lstart; u32 *ps; i32 *mail;
+	i32 *cut5, *lstart, *head; u32 *ps; i32 *mail;
 	__device__ void cuts(i64 i, i32 &c5, i32 &h) const
 	{
 		c5 = 0; h = 1;
@@ -123,10 +125,40 @@ struct OpChrCuts {
 	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
 	{
 		i32 c5, h; cuts(i, c5, h);
-		cut5[i] = c5; ps[i] = (u32)ex[1];
+		cut5[i] = c5; ps[i] = (u32)ex[1]; head[i] = v[0];
 		if (v[0]) lstart[ex[0]] = (i32)i;
 	}
-	__device__ void done(const i32 *t) const { mail[M_NL] = t[0]; ps[n] = (u32)t[1]; }
+	__device__ void done(const i32 *t) const { mail[M_NL] = t[0]; ps[n] = (u32)t[1]; head[n] = 1; }
+};
+
+// The large DP gaps (the ones that need the striped kernel, the contig's latency floor) are final as soon as
+// the leaves are: a gap between two seeds of one leaf.  They are listed here and launched at once, two
+// stages before their records exist; stage 6 links record and job through e_id[] (per seed: early job or -1).
+// Gaps of leaves the host list logic drops later are computed in vain.
+struct OpEarlyLarge {
+	i64 n; const i32 *q, *len; const i64 *r; const i32 *head; const uint8_t *query, *ref;
+	i32 *e_id, *e_list; i64 *off1, *off2, *opsoff; i32 *mail;
+	__device__ bool gap(i64 s, i32 &qp, i64 &rp, i32 &qg, i32 &rg) const
+	{
+		if (s + 1 >= n || head[s + 1]) return false;
+		qp = q[s] + len[s]; rp = r[s] + len[s];
+		qg = q[s + 1] - qp; if (qg < 0) qg = 0;
+		const i64 rg64 = r[s + 1] - rp; rg = rg64 < 0 ? 0 : (i32)rg64;
+		if (!dp_is_large(rg, qg)) return false;                   // (cheap test first: the mismatch count is a serial loop)
+		i32 mism;
+		return classify_gap(query, ref, qp, rp, qg, rg, mism) == FT_DP;
+	}
+	__device__ i32 value(i64 s, int c) const { i32 qp, qg, rg; i64 rp; if (!gap(s, qp, rp, qg, rg)) return 0; return c == 0 ? 1 : qg + rg; }
+	__device__ void emit(i64 s, const i32 *v, const i32 *ex) const
+	{
+		e_id[s] = v[0] ? ex[0] : -1;
+		if (!v[0]) return;
+		i32 qp, qg, rg; i64 rp; gap(s, qp, rp, qg, rg);
+		const i32 e = ex[0];
+		e_list[3 * e] = e; e_list[3 * e + 1] = rg; e_list[3 * e + 2] = qg;
+		off1[e] = rp; off2[e] = qp; opsoff[e] = ex[1];
+	}
+	__device__ void done(const i32 *t) const { mail[M_NEARLY] = t[0]; mail[M_NJ] = t[1]; }      // (M_NJ is free again: total op-string room)
 };
 
 __global__ void k_leaf_emit(i64 n, const i32 *__restrict__ mail, const i32 *__restrict__ lstart, const i32 *__restrict__ q,
@@ -195,18 +227,46 @@ int stage345_refine(gsa_ctx *c)
 	// S5 cuts + leaf table
 	ENS(i32, a_next, nr + 1); ENS(u32, d_flag, nr + 2);
 	i32 *lstart = c->a_next.as<i32>(); u32 *ps = c->d_flag.as<u32>();
-	{ OpChrCuts op = { nr, c->di, c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, c->r_len.as<i32>(), cut5, lstart, ps, mail }; RC((lb_launch<2>(c, nr, op))); }
+	ENS(i32, r_head, nr + 2);
+	{ OpChrCuts op = { nr, c->di, c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, c->r_len.as<i32>(), cut5, lstart, c->r_head.as<i32>(), ps, mail }; RC((lb_launch<2>(c, nr, op))); }
 	ENS(Leaf, d_leaf, nr + 1);
 	LAUNCH(k_leaf_emit, nr, nr, mail, lstart, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, cut5, ps,
 	       c->blk_score.as<i32>(), c->d_leaf.as<Leaf>());
-	// the leaf count and the first LEAF_CHUNK leaves come back together
-	const size_t first = (size_t)std::min<i64>(nr, LEAF_CHUNK);
-	if (!pin_ensure<Leaf>(c, c->p_leaf, (size_t)LEAF_CHUNK)) return GSA_ERR_NOMEM;
-	GSA_CHECK(c, hipMemcpyAsync(c->h_mail + M_NL, mail + M_NL, sizeof(i32), hipMemcpyDeviceToHost, st));
+	// large DP gaps of the leaves (launched below, as soon as the list is on the host)
+	ENS(i32, e_id, nr + 2); ENS(i32, e_list, 3 * (nr + 1)); ENS(i64, e_off1, nr + 1); ENS(i64, e_off2, nr + 1); ENS(i64, e_opsoff, nr + 2); ENS(i32, e_nops, nr + 1); ENS(i32, e_rec, nr + 1);
+	{ OpEarlyLarge op = { nr, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_head.as<i32>(), c->d_query.as<uint8_t>(), c->di.ref,
+	                      c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail }; RC((lb_launch<2, 1>(c, nr, op))); }
+	// the leaf count, the first LEAF_CHUNK leaves and the first EARLY_CHUNK large gaps come back together
+	const size_t first = (size_t)std::min<i64>(nr, LEAF_CHUNK), first_e = (size_t)std::min<i64>(nr, EARLY_CHUNK);
+	if (!pin_ensure<Leaf>(c, c->p_leaf, (size_t)LEAF_CHUNK) || !pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * EARLY_CHUNK)) return GSA_ERR_NOMEM;
+	GSA_CHECK(c, hipMemcpyAsync(c->h_mail, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipMemcpyAsync(c->p_leaf.p, c->d_leaf.p, first * sizeof(Leaf), hipMemcpyDeviceToHost, st));
+	GSA_CHECK(c, hipMemcpyAsync(c->p_dp.as<i32>() + MAIL_N, c->e_list.p, first_e * 12, hipMemcpyDeviceToHost, st));
 	if (c->profiling) hipEventRecord(c->ev[7], st);
 	GSA_CHECK(c, hipStreamSynchronize(st));
-	const i32 nl = c->h_mail[M_NL];
+	if (c->h_mail[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
+	const i32 nl = c->h_mail[M_NL], ne = c->h_mail[M_NEARLY];
+	c->n_early = ne; c->early_in_flight = false;
+	if (ne > 0) {
+		if ((size_t)ne > first_e) {
+			if (!pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * (size_t)ne)) return GSA_ERR_NOMEM;
+			GSA_CHECK(c, hipMemcpyAsync(c->p_dp.as<i32>() + MAIL_N, c->e_list.p, (size_t)ne * 12, hipMemcpyDeviceToHost, st));
+			GSA_CHECK(c, hipStreamSynchronize(st));
+		}
+		const i32 *el = c->p_dp.as<i32>() + MAIL_N;
+		c->h_early.assign(el, el + 3 * (size_t)ne);
+		std::vector<LgJob> large((const LgJob *)el, (const LgJob *)el + ne);
+		const i64 eops = c->h_mail[M_NJ];
+		ENS(uint8_t, e_ops, eops + 64); ENS(uint8_t, e_rev, eops + 64);
+		// fork: the striped kernel runs on stream_aux[0] under everything up to the gapped strings of stage 7
+		GSA_CHECK(c, hipEventRecord(c->ev[11], st));
+		GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[0], c->ev[11], 0));
+		GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR3, 0, sizeof(i32), c->stream_aux[0]));
+		RC(launch_stripes(c, c->stream_aux[0], large, c->di.ref, c->e_off1.as<i64>(), c->d_query.as<uint8_t>(), c->e_off2.as<i64>(),
+		                  c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->e_nops.as<i32>(), c->e_rev.as<uint8_t>(), M_DPERR3));
+		GSA_CHECK(c, hipEventRecord(c->ev[14], c->stream_aux[0]));
+		c->early_in_flight = true;
+	}
 	if ((size_t)nl > first) {
 		if (!pin_ensure<Leaf>(c, c->p_leaf, (size_t)nl)) return GSA_ERR_NOMEM;
 		GSA_CHECK(c, hipMemcpyAsync(c->p_leaf.p, c->d_leaf.p, (size_t)nl * sizeof(Leaf), hipMemcpyDeviceToHost, st));
