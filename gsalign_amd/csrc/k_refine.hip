@@ -261,7 +261,6 @@ int stage345_refine(gsa_ctx *c)
 		// fork: the striped kernel runs on stream_aux[0] under everything up to the gapped strings of stage 7
 		GSA_CHECK(c, hipEventRecord(c->ev[11], st));
 		GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[0], c->ev[11], 0));
-		GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR3, 0, sizeof(i32), c->stream_aux[0]));
 		RC(launch_stripes(c, c->stream_aux[0], large, c->di.ref, c->e_off1.as<i64>(), c->d_query.as<uint8_t>(), c->e_off2.as<i64>(),
 		                  c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->e_nops.as<i32>(), c->e_rev.as<uint8_t>(), M_DPERR3));
 		GSA_CHECK(c, hipEventRecord(c->ev[14], c->stream_aux[0]));
