@@ -158,7 +158,7 @@ int stage345_refine(gsa_ctx *c);      // k_refine.hip  (device part of S3, S4, S
 int stage7_fill(gsa_ctx *c);          // k_extend.hip  (S6: gap records of the final block list)
 i64 frags_count(gsa_ctx *c);          // k_extend.hip  (record count, fetched from the mailbox when still unknown)
 int stage78_extend(gsa_ctx *c);       // k_extend.hip  (S7: classification, DP, gapped strings, block sums)
-int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res);   // k_gapsim.hip
+int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res);   // k_gapsim.hip
 void dp_count_cells(gsa_ctx *c, i32 n_ub, const i32 *len1, const i32 *len2, hipStream_t stream);   // k_dp.hip (profiling)
 struct LgJob { i32 job, m, n; };
 int launch_stripes(gsa_ctx *c, hipStream_t ss, std::vector<LgJob> &large, const uint8_t *pool1, const i64 *off1, const uint8_t *pool2, const i64 *off2,

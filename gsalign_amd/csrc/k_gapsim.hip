@@ -66,52 +66,57 @@ __device__ void kmer_hist(const uint8_t *__restrict__ s, int len, u32 *hist, int
 	}
 }
 
-__global__ void __launch_bounds__(GS_T) k_gapsim(DevIndex di, const uint8_t *__restrict__ query, i32 n, const i32 *__restrict__ q1a, const i32 *__restrict__ q2a,
+__global__ void __launch_bounds__(GS_T) k_gapsim(DevIndex di, const uint8_t *__restrict__ query, i32 n_host, const i32 *__restrict__ d_n, const i32 *__restrict__ q1a, const i32 *__restrict__ q2a,
                                                 const i64 *__restrict__ r1a, const i64 *__restrict__ r2a, i32 *res)
 {
 	__shared__ u32 h1[KBINS], h2[KBINS];
 	__shared__ int s_acc, s_flag;
-	const int job = blockIdx.x, lane = threadIdx.x;
-	if (job >= n) return;
-	const i32 q1 = q1a[job], q2 = q2a[job]; const i64 r1 = r1a[job], r2 = r2a[job];
-	const int q_len = q2 - q1, r_len = (int)(r2 - r1);
-	bool sim = false;
-	if (lane == 0) s_acc = 0;
-	__syncthreads();
-	if (r1 - q1 == r2 - q2) {
-		int idy = 0;
-		for (int p = lane; p < q_len; p += GS_T) {
-			const int a = gsa_nt4(di.ref[r1 + p]), b = gsa_nt4(query[q1 + p]);
-			idy += (a == b || a == 4 || b == 4);
-		}
-		for (int o = 32; o; o >>= 1) idy += __shfl_xor(idy, o);
-		if ((lane & 63) == 0 && idy) atomicAdd(&s_acc, idy);
-		__syncthreads();
-		if ((double)s_acc >= q_len * 0.5) sim = true;
-		__syncthreads();
+	const int lane = threadIdx.x;
+	const i32 n = d_n ? *d_n : n_host;                  // (job count on the device when the host has not looked yet)
+	for (int job = blockIdx.x; job < n; job += gridDim.x) {
+		const i32 q1 = q1a[job], q2 = q2a[job]; const i64 r1 = r1a[job], r2 = r2a[job];
+		const int q_len = q2 - q1, r_len = (int)(r2 - r1);
+		bool sim = false;
 		if (lane == 0) s_acc = 0;
 		__syncthreads();
+		if (r1 - q1 == r2 - q2) {
+			int idy = 0;
+			for (int p = lane; p < q_len; p += GS_T) {
+				const int a = gsa_nt4(di.ref[r1 + p]), b = gsa_nt4(query[q1 + p]);
+				idy += (a == b || a == 4 || b == 4);
+			}
+			for (int o = 32; o; o >>= 1) idy += __shfl_xor(idy, o);
+			if ((lane & 63) == 0 && idy) atomicAdd(&s_acc, idy);
+			__syncthreads();
+			if ((double)s_acc >= q_len * 0.5) sim = true;
+			__syncthreads();
+			if (lane == 0) s_acc = 0;
+			__syncthreads();
+		}
+		if (!sim && q_len <= GSA_MAX_SEED_GAP && r_len <= GSA_MAX_SEED_GAP) {
+			for (int b = lane; b < KBINS; b += GS_T) { h1[b] = 0; h2[b] = 0; }
+			__syncthreads();
+			kmer_hist(query + q1, q_len, h1, lane, &s_flag);
+			kmer_hist(di.ref + r1, r_len, h2, lane, &s_flag);
+			__syncthreads();
+			int common = 0;
+			for (int b = lane; b < KBINS; b += GS_T) common += (int)(h1[b] < h2[b] ? h1[b] : h2[b]);
+			for (int o = 32; o; o >>= 1) common += __shfl_xor(common, o);
+			if ((lane & 63) == 0 && common) atomicAdd(&s_acc, common);
+			__syncthreads();
+			if ((double)s_acc > (q_len + r_len) * 0.1) sim = true;
+		}
+		if (lane == 0) res[job] = sim ? 1 : 0;
+		__syncthreads();
 	}
-	if (!sim && q_len <= GSA_MAX_SEED_GAP && r_len <= GSA_MAX_SEED_GAP) {
-		for (int b = lane; b < KBINS; b += GS_T) { h1[b] = 0; h2[b] = 0; }
-		__syncthreads();
-		kmer_hist(query + q1, q_len, h1, lane, &s_flag);
-		kmer_hist(di.ref + r1, r_len, h2, lane, &s_flag);
-		__syncthreads();
-		int common = 0;
-		for (int b = lane; b < KBINS; b += GS_T) common += (int)(h1[b] < h2[b] ? h1[b] : h2[b]);
-		for (int o = 32; o; o >>= 1) common += __shfl_xor(common, o);
-		if ((lane & 63) == 0 && common) atomicAdd(&s_acc, common);
-		__syncthreads();
-		if ((double)s_acc > (q_len + r_len) * 0.1) sim = true;
-	}
-	if (lane == 0) res[job] = sim ? 1 : 0;
 }
 
-int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res)
+int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res)
 {
+	// n = job count, or with d_n != nullptr an upper bound (the grid is capped, workgroups loop over the jobs)
 	if (n <= 0) return GSA_OK;
-	hipLaunchKernelGGL(k_gapsim, dim3(n), dim3(GS_T), 0, c->stream, c->di, c->d_query.as<uint8_t>(), n, d_q1, d_q2, d_r1, d_r2, d_res);
+	const i32 grid = d_n ? (n < 1024 ? n : 1024) : n;
+	hipLaunchKernelGGL(k_gapsim, dim3(grid), dim3(GS_T), 0, c->stream, c->di, c->d_query.as<uint8_t>(), n, d_n, d_q1, d_q2, d_r1, d_r2, d_res);
 	GSA_CHECK(c, hipGetLastError());
 	return GSA_OK;
 }
@@ -129,7 +134,7 @@ extern "C" int gsa_gap_similarity_batch(gsa_ctx *c, int32_t n, const int32_t *q1
 	GSA_CHECK(c, hipMalloc(&dr1, n * 8)); GSA_CHECK(c, hipMalloc(&dr2, n * 8));
 	GSA_CHECK(c, hipMemcpyAsync(dq1, q1, n * 4, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(dq2, q2, n * 4, hipMemcpyHostToDevice, st));
 	GSA_CHECK(c, hipMemcpyAsync(dr1, r1, n * 8, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(dr2, r2, n * 8, hipMemcpyHostToDevice, st));
-	int rc = run_gapsim_jobs(c, n, dq1, dq2, dr1, dr2, dres);
+	int rc = run_gapsim_jobs(c, n, nullptr, dq1, dq2, dr1, dr2, dres);
 	if (rc == GSA_OK) { GSA_CHECK(c, hipMemcpyAsync(similar, dres, n * 4, hipMemcpyDeviceToHost, st)); GSA_CHECK(c, hipStreamSynchronize(st)); }
 	hipFree(dq1); hipFree(dq2); hipFree(dres); hipFree(dr1); hipFree(dr2);
 	return rc;

@@ -95,9 +95,10 @@ struct OpGapCuts {
 	__device__ void done(const i32 *t) const { mail[M_NJ] = t[0]; }
 };
 
-__global__ void k_gap_apply(i32 nj, const i32 *__restrict__ jseed, const i32 *__restrict__ res, i32 *cut4)
+__global__ void k_gap_apply(i64 ub, const i32 *__restrict__ d_nj, const i32 *__restrict__ jseed, const i32 *__restrict__ res, i32 *cut4)
 {
-	GID(nj);
+	GID(ub);
+	if (i >= *d_nj) return;
 	if (!res[i]) cut4[jseed[i]] = 1;
 }
 
@@ -106,7 +107,7 @@ __global__ void k_gap_apply(i32 nj, const i32 *__restrict__ jseed, const i32 *__
 // holding the piece's first seed" == "copy index changes".  Second component: prefix sums of the
 // trimmed lengths, 32-bit wrapping -- only differences over a leaf are ever used.
 struct OpChrCuts {
-	i64 n; DevIndex di; const i64 *r; const i32 *bid, *cut4, *len;
+	i64 ub; const i32 *d_n; DevIndex di; const i64 *r; const i32 *bid, *cut4, *len;
 	i32 *cut5, *lstart, *head; u32 *ps; i32 *mail;
 	__device__ void cuts(i64 i, i32 &c5, i32 &h) const
 	{
@@ -121,14 +122,16 @@ struct OpChrCuts {
 			}
 		}
 	}
-	__device__ i32 value(i64 i, int c) const { if (c == 1) return len[i]; i32 c5, h; cuts(i, c5, h); return h; }
+	__device__ i32 value(i64 i, int c) const { if (i >= *d_n) return 0; if (c == 1) return len[i]; i32 c5, h; cuts(i, c5, h); return h; }
 	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
 	{
+		ps[i] = (u32)ex[1];                                    // (behind the last seed: the total)
+		if (i >= *d_n) { head[i] = 1; return; }
 		i32 c5, h; cuts(i, c5, h);
-		cut5[i] = c5; ps[i] = (u32)ex[1]; head[i] = v[0];
+		cut5[i] = c5; head[i] = v[0];
 		if (v[0]) lstart[ex[0]] = (i32)i;
 	}
-	__device__ void done(const i32 *t) const { mail[M_NL] = t[0]; ps[n] = (u32)t[1]; head[n] = 1; }
+	__device__ void done(const i32 *t) const { mail[M_NL] = t[0]; ps[ub] = (u32)t[1]; head[ub] = 1; }
 };
 
 // The large DP gaps (the ones that need the striped kernel, the contig's latency floor) are final as soon as
@@ -136,11 +139,11 @@ struct OpChrCuts {
 // stages before their records exist; stage 6 links record and job through e_id[] (per seed: early job or -1).
 // Gaps of leaves the host list logic drops later are computed in vain.
 struct OpEarlyLarge {
-	i64 n; const i32 *q, *len; const i64 *r; const i32 *head; const uint8_t *query, *ref;
+	const i32 *d_n; const i32 *q, *len; const i64 *r; const i32 *head; const uint8_t *query, *ref;
 	i32 *e_id, *e_list; i64 *off1, *off2, *opsoff; i32 *mail;
 	__device__ bool gap(i64 s, i32 &qp, i64 &rp, i32 &qg, i32 &rg) const
 	{
-		if (s + 1 >= n || head[s + 1]) return false;
+		if (s + 1 >= *d_n || head[s + 1]) return false;
 		qp = q[s] + len[s]; rp = r[s] + len[s];
 		qg = q[s + 1] - qp; if (qg < 0) qg = 0;
 		const i64 rg64 = r[s + 1] - rp; rg = rg64 < 0 ? 0 : (i32)rg64;
@@ -161,14 +164,14 @@ struct OpEarlyLarge {
 	__device__ void done(const i32 *t) const { mail[M_NEARLY] = t[0]; mail[M_NJ] = t[1]; }      // (M_NJ is free again: total op-string room)
 };
 
-__global__ void k_leaf_emit(i64 n, const i32 *__restrict__ mail, const i32 *__restrict__ lstart, const i32 *__restrict__ q,
+__global__ void k_leaf_emit(i64 ub, const i32 *__restrict__ d_n, const i32 *__restrict__ mail, const i32 *__restrict__ lstart, const i32 *__restrict__ q,
                             const i32 *__restrict__ len, const i64 *__restrict__ r, const i32 *__restrict__ bid, const i32 *__restrict__ cut4,
                             const i32 *__restrict__ cut5, const u32 *__restrict__ ps, const i32 *__restrict__ blk_score, Leaf *leaf)
 {
-	GID(n);
+	GID(ub);
 	const i32 nl = mail[M_NL];
 	if (i >= nl) return;
-	const i32 s = lstart[i], e = (i + 1 < nl) ? lstart[i + 1] : (i32)n;
+	const i32 s = lstart[i], e = (i + 1 < nl) ? lstart[i + 1] : *d_n;
 	Leaf L;
 	L.beg = s; L.end = e; L.sumlen = (i32)(ps[e] - ps[s]);
 	L.q_first = q[s]; L.q_last_end = q[e - 1] + len[e - 1]; L.r_first = r[s]; L.r_last_end = r[e - 1] + len[e - 1];
@@ -193,9 +196,15 @@ int stage345_refine(gsa_ctx *c)
 	i32 *jq1 = c->a_uniq.as<i32>(), *jq2 = c->a_cu.as<i32>(), *jseed = c->a_brk.as<i32>(); i64 *jr1 = c->w_best.as<i64>(), *jr2 = c->w_sum.as<i64>();
 	{ OpTakeInBlock op = { c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_bid.as<i32>(),
 	                       c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), mail }; RC((lb_launch<1>(c, ub, op))); }
-	// S3: passes until nothing dies.  A pass that kills nothing is the identity, so the passes are
-	// issued two at a time with the S4 gap scan behind them and the host looks at the kill flags
-	// once per batch.  The count ping-pongs between two mailbox slots.
+	// S3: passes until nothing dies.  A pass that kills nothing is the identity, so two passes are issued
+	// and then EVERYTHING behind them -- S4 gap scan + similarity jobs, S5 cuts, leaf table, the list of
+	// large DP gaps -- with the live seed count read on the device; the host looks once, at the end, and
+	// only if the second pass still killed something the tail is redone after two more passes.
+	ENS(i32, a_next, ub + 1); ENS(u32, d_flag, ub + 2); ENS(i32, r_head, ub + 2); ENS(Leaf, d_leaf, ub + 1);
+	ENS(i32, e_id, ub + 2); ENS(i32, e_list, 3 * (ub + 1)); ENS(i64, e_off1, ub + 1); ENS(i64, e_off2, ub + 1); ENS(i64, e_opsoff, ub + 2); ENS(i32, e_nops, ub + 1); ENS(i32, e_rec, ub + 1);
+	i32 *lstart = c->a_next.as<i32>(); u32 *ps = c->d_flag.as<u32>();
+	if (!pin_ensure<Leaf>(c, c->p_leaf, (size_t)LEAF_CHUNK) || !pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * EARLY_CHUNK)) return GSA_ERR_NOMEM;
+	const size_t first = (size_t)std::min<i64>(ub, LEAF_CHUNK), first_e = (size_t)std::min<i64>(ub, EARLY_CHUNK);
 	GSA_CHECK(c, hipMemsetAsync(mail + M_ANY, 0, 32 * sizeof(i32), st));
 	int round = 0, cur = M_NR, oth = M_NR2;
 	for (;;) {
@@ -206,9 +215,21 @@ int stage345_refine(gsa_ctx *c)
 			std::swap(c->r_q, c->r_tmp_q); std::swap(c->r_len, c->r_tmp_len); std::swap(c->r_r, c->r_tmp_r); std::swap(c->r_bid, c->r_tmp_bid);
 			std::swap(cur, oth);
 		}
-		// S4 cuts + job list (speculative: valid if the last pass killed nothing)
+		// S4 cuts + similarity jobs
 		{ OpGapCuts op = { cur, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, jq1, jq2, jr1, jr2, jseed, mail }; RC((lb_launch<1>(c, ub, op))); }
+		RC(run_gapsim_jobs(c, (i32)ub, mail + M_NJ, jq1, jq2, jr1, jr2, c->r_simres.as<i32>()));
+		LAUNCH(k_gap_apply, ub, ub, mail + M_NJ, jseed, c->r_simres.as<i32>(), cut4);
+		// S5 cuts + leaf table + large DP gaps of the leaves
+		{ OpChrCuts op = { ub, mail + cur, c->di, c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, c->r_len.as<i32>(), cut5, lstart, c->r_head.as<i32>(), ps, mail }; RC((lb_launch<2>(c, ub, op))); }
+		LAUNCH(k_leaf_emit, ub, ub, mail + cur, mail, lstart, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, cut5, ps,
+		       c->blk_score.as<i32>(), c->d_leaf.as<Leaf>());
+		{ OpEarlyLarge op = { mail + cur, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_head.as<i32>(), c->d_query.as<uint8_t>(), c->di.ref,
+		                      c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail }; RC((lb_launch<2, 1>(c, ub, op))); }
+		// the mailbox, the first LEAF_CHUNK leaves and the first EARLY_CHUNK large gaps come back together
 		GSA_CHECK(c, hipMemcpyAsync(c->h_mail, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
+		GSA_CHECK(c, hipMemcpyAsync(c->p_leaf.p, c->d_leaf.p, first * sizeof(Leaf), hipMemcpyDeviceToHost, st));
+		GSA_CHECK(c, hipMemcpyAsync(c->p_dp.as<i32>() + MAIL_N, c->e_list.p, first_e * 12, hipMemcpyDeviceToHost, st));
+		if (c->profiling) hipEventRecord(c->ev[7], st);
 		GSA_CHECK(c, hipStreamSynchronize(st));
 		if (c->h_mail[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 		if (!c->h_mail[M_ANY + ((round - 1) & 31)]) break;
@@ -217,33 +238,9 @@ int stage345_refine(gsa_ctx *c)
 	}
 	collect_events(c);
 	c->n_b = c->h_mail[M_NB]; c->n_c = c->h_mail[M_NC]; c->n_blocks2 = c->h_mail[M_NBLK];
-	const i64 nr = c->h_mail[cur]; const i32 nj = c->h_mail[M_NJ];
-	c->n_r = nr;
+	const i64 nr = c->h_mail[cur];
+	c->n_r = nr; c->n_early = 0; c->early_in_flight = false;
 	if (c->n_blocks2 == 0 || nr == 0) { c->n_r = 0; return GSA_OK; }
-	if (nj > 0) {
-		RC(run_gapsim_jobs(c, nj, jq1, jq2, jr1, jr2, c->r_simres.as<i32>()));
-		LAUNCH(k_gap_apply, nj, nj, jseed, c->r_simres.as<i32>(), cut4);
-	}
-	// S5 cuts + leaf table
-	ENS(i32, a_next, nr + 1); ENS(u32, d_flag, nr + 2);
-	i32 *lstart = c->a_next.as<i32>(); u32 *ps = c->d_flag.as<u32>();
-	ENS(i32, r_head, nr + 2);
-	{ OpChrCuts op = { nr, c->di, c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, c->r_len.as<i32>(), cut5, lstart, c->r_head.as<i32>(), ps, mail }; RC((lb_launch<2>(c, nr, op))); }
-	ENS(Leaf, d_leaf, nr + 1);
-	LAUNCH(k_leaf_emit, nr, nr, mail, lstart, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, cut5, ps,
-	       c->blk_score.as<i32>(), c->d_leaf.as<Leaf>());
-	// large DP gaps of the leaves (launched below, as soon as the list is on the host)
-	ENS(i32, e_id, nr + 2); ENS(i32, e_list, 3 * (nr + 1)); ENS(i64, e_off1, nr + 1); ENS(i64, e_off2, nr + 1); ENS(i64, e_opsoff, nr + 2); ENS(i32, e_nops, nr + 1); ENS(i32, e_rec, nr + 1);
-	{ OpEarlyLarge op = { nr, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_head.as<i32>(), c->d_query.as<uint8_t>(), c->di.ref,
-	                      c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail }; RC((lb_launch<2, 1>(c, nr, op))); }
-	// the leaf count, the first LEAF_CHUNK leaves and the first EARLY_CHUNK large gaps come back together
-	const size_t first = (size_t)std::min<i64>(nr, LEAF_CHUNK), first_e = (size_t)std::min<i64>(nr, EARLY_CHUNK);
-	if (!pin_ensure<Leaf>(c, c->p_leaf, (size_t)LEAF_CHUNK) || !pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * EARLY_CHUNK)) return GSA_ERR_NOMEM;
-	GSA_CHECK(c, hipMemcpyAsync(c->h_mail, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipMemcpyAsync(c->p_leaf.p, c->d_leaf.p, first * sizeof(Leaf), hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipMemcpyAsync(c->p_dp.as<i32>() + MAIL_N, c->e_list.p, first_e * 12, hipMemcpyDeviceToHost, st));
-	if (c->profiling) hipEventRecord(c->ev[7], st);
-	GSA_CHECK(c, hipStreamSynchronize(st));
 	if (c->h_mail[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	const i32 nl = c->h_mail[M_NL], ne = c->h_mail[M_NEARLY];
 	c->n_early = ne; c->early_in_flight = false;
