@@ -10,7 +10,7 @@
 enum { CNT_OCCBLK = 0, CNT_LF = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 4, CNT_DPJOBS = 5, CNT_DPMN = 6, CNT_CAND = 8, CNT_OVERFLOW = 9, CNT_OCCBLK_ALL = 10 };
 
 #define SEED_WG 256
-#define NSUB 1024               // speculative sub-ranges per chunk (work items of the workgroup)
+#define NSUB 384               // speculative sub-ranges per chunk (work items of the workgroup)
 #define PATH_WORDS 320          // 10240 on-path bits per chunk
 #define QP_WORDS (GSA_CHUNK / 16 + 4)
 #define QN_WORDS (GSA_CHUNK / 32 + 4)
