@@ -120,8 +120,8 @@ class Aligner:
         p = self._params(**params)
         self._ck(self.lib.gsa_set_params(self.ctx, C.byref(p)))
 
-    def set_profiling(self, on: bool, count_blocks: bool = False):
-        self._ck(self.lib.gsa_set_profiling(self.ctx, (1 if on else 0) | (2 if count_blocks else 0)))
+    def set_profiling(self, on: bool, count_blocks: bool = False, seed_only: bool = False):
+        self._ck(self.lib.gsa_set_profiling(self.ctx, (1 if on else 0) | (2 if count_blocks else 0) | (4 if seed_only else 0)))
 
     def set_query(self, seq: np.ndarray):
         seq = np.ascontiguousarray(seq, dtype=np.uint8)

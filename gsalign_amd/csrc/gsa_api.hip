@@ -21,8 +21,9 @@ int build_block_view(gsa_ctx *c);              // gsa_blocks.cpp
 
 void collect_events(gsa_ctx *c)
 {
-	if (!c->profiling) { c->ev_pending = 0; return; }
+	if (!c->profiling && !c->prof_seed) { c->ev_pending = 0; return; }
 	float ms;
+	if ((c->ev_pending & 1) && !c->profiling) { if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->kernel_ms[0] = ms; c->ev_pending = 0; (void)hipGetLastError(); return; }
 	if (c->ev_pending & 1) {
 		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->kernel_ms[0] = ms;
 		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->kernel_ms[1] = ms;
@@ -138,7 +139,7 @@ void gsa_destroy(gsa_ctx *c)
 	delete c;
 }
 
-int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->profiling = (enable & 1) != 0; c->count_blocks = (enable & 2) != 0; return GSA_OK; }
+int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->profiling = (enable & 1) != 0; c->count_blocks = (enable & 2) != 0; c->prof_seed = (enable & 4) != 0; return GSA_OK; }
 
 int gsa_set_query(gsa_ctx *c, const char *query, int32_t qlen)
 {

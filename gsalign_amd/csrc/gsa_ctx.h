@@ -37,6 +37,7 @@ struct gsa_ctx {
 	Params prm;
 	DevIndex di;
 	bool profiling = false;
+	bool prof_seed = false;                        // time the seed kernel only (two events instead of ten per contig)
 	bool count_blocks = false;                     // run the accounting build of the seed kernel (exact algorithmic Occ-block count)
 	u64 dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	hipEvent_t ev[16];
