@@ -127,7 +127,7 @@ void gsa_destroy(gsa_ctx *c)
 		&c->b_q, &c->b_len, &c->b_r, &c->b_gb, &c->b_ge, &c->c_q, &c->c_len, &c->c_r, &c->c_gb, &c->c_ge, &c->c_bid, &c->blk_beg, &c->blk_end, &c->blk_score,
 		&c->r_q, &c->r_len, &c->r_r, &c->r_bid, &c->r_tmp_q, &c->r_tmp_len, &c->r_tmp_r, &c->r_tmp_bid, &c->r_cut4, &c->r_cut5, &c->r_simjob, &c->r_simres, &c->d_leaf,
 		&c->fb_seedbase, &c->fb_sbeg, &c->fb_fragbase, &c->f_rec, &c->f_type, &c->f_mism, &c->f_alnlen, &c->f_job, &c->f_score,
-		&c->d_dp_bnd, &c->d_dp_ctr, &c->d_dp_jobs, &c->d_dp_large, &c->d_patch,
+		&c->d_dp_tiny, &c->d_dp_bnd, &c->d_dp_ctr, &c->d_dp_jobs, &c->d_dp_large, &c->d_patch,
 		&c->e_id, &c->e_rec, &c->e_list, &c->e_off1, &c->e_off2, &c->e_opsoff, &c->e_nops, &c->e_ops, &c->e_rev, &c->r_head, &c->f_early, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_aln1, &c->d_aln2, &c->d_alnoff, &c->bl_alnlen, &c->bl_score };
 	for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
 	if (c->h_cnt) hipHostFree(c->h_cnt);

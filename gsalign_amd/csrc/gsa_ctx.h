@@ -18,7 +18,7 @@ struct Leaf {
 
 // Device "mailbox" (i32[MAIL_N]) of the counts the stages produce; the host reads the whole
 // box in ONE pinned copy where it needs them instead of one read-back per count.
-enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_TICKET = 48, M_NBRAW = 49, M_NR2 = 50, M_NF = 51, M_NJOB = 52, M_OPSTOT = 53, M_NALN = 54, M_DPERR = 55, M_NLARGE = 56, M_DPERR2 = 57, M_CELLS = 58 /* two u64: sum m*n, sum m+n */, M_NEARLY = 62, M_DPERR3 = 63, MAIL_N = 64 };
+enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_NTINY = 40, M_TICKET = 48, M_NBRAW = 49, M_NR2 = 50, M_NF = 51, M_NJOB = 52, M_OPSTOT = 53, M_NALN = 54, M_DPERR = 55, M_NLARGE = 56, M_DPERR2 = 57, M_CELLS = 58 /* two u64: sum m*n, sum m+n */, M_NEARLY = 62, M_DPERR3 = 63, MAIL_N = 64 };
 #define LEAF_CHUNK 1024      // leaves copied together with the mailbox (more -> a second copy)
 
 struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf range
@@ -112,6 +112,7 @@ struct gsa_ctx {
 	DevBuf f_rec;                                  // gsa_frag records
 	DevBuf f_type, f_mism, f_alnlen, f_job, f_score;
 	DevBuf j_frag, j_opsoff, j_nops, d_ops, j_cells;
+	DevBuf d_dp_tiny;                              // order array of the four-per-wavefront DP kernel
 	DevBuf d_dp_bnd, d_dp_ctr, d_dp_jobs, d_dp_large;   // striped DP: boundary granules, tickets, job descriptors, (job,m,n) of the large jobs
 	// large DP gaps are known once the leaf table exists: they are launched there (stream_aux[0]) and run under stages 6-7
 	DevBuf e_id, e_rec, e_list, e_off1, e_off2, e_opsoff, e_nops, e_ops, e_rev, r_head, f_early;

@@ -79,6 +79,86 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 }
 
 // ---------------------------------------------------------------------------
+// k_dp_tiny: the bulk of the jobs is a handful of bases on either side (median 11 x 11), so FOUR
+// alignments share a wavefront: n <= 16 target columns each, one per 16-lane DPP row (row_shr:1 never
+// crosses a row), at most TINY_ROWS anti-diagonals.  Same systolic scheme as k_dp_small; the four
+// tracebacks run on four lanes at once.
+// ---------------------------------------------------------------------------
+#define TINY_ROWS 64
+#define TINY_WAVES 4
+__device__ __forceinline__ int row_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false); }   // lane t of a row <- lane t-1, row start <- fill
+
+__global__ void __launch_bounds__(64 * TINY_WAVES) k_dp_tiny(i32 n_jobs, const i32 *__restrict__ order, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
+                                                              const i32 *__restrict__ len1, const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2,
+                                                              const i32 *__restrict__ len2, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len)
+{
+	__shared__ uint8_t s_dir[TINY_WAVES][TINY_ROWS * 64];
+	__shared__ uint8_t s_ref[TINY_WAVES][4][TINY_ROWS];         // nt4 codes of the four reference fragments
+	__shared__ uint8_t s_rev[TINY_WAVES][4][TINY_ROWS + 32];
+	__shared__ int s_n[TINY_WAVES][4];
+	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 4, tl = lane & 15;
+	const i32 slot = (blockIdx.x * TINY_WAVES + w) * 4 + q;
+	if ((blockIdx.x * TINY_WAVES + w) * 4 >= n_jobs) return;
+	const bool have = slot < n_jobs;
+	const i32 job = have ? order[slot] : 0;
+	const int m = have ? len1[job] : 0, n = have ? len2[job] : 0;
+	const uint8_t *s1 = pool1 + off1[job], *s2 = pool2 + off2[job];
+	uint8_t *dir = s_dir[w];
+	for (int k = tl; k < TINY_ROWS; k += 16) s_ref[w][q][k] = (uint8_t)(k < m ? gsa_nt4(s1[k]) : 4);
+	const int cq = tl < n ? gsa_nt4(s2[tl]) : 4;
+	int u = tl ? 2 : 0, v = 0, x = 0, y = 0, wref = 4;
+	// the longest of the four decides how many diagonals the wavefront runs
+	int nr = have ? m + n - 1 : 0;
+	nr = max(max(__builtin_amdgcn_readlane(nr, 0), __builtin_amdgcn_readlane(nr, 16)), max(__builtin_amdgcn_readlane(nr, 32), __builtin_amdgcn_readlane(nr, 48)));
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	int inb = s_ref[w][q][0];
+	for (int r = 0; r < nr; r++) {
+		const int inb_next = s_ref[w][q][r + 1 < TINY_ROWS ? r + 1 : TINY_ROWS - 1];      // (one diagonal ahead: off the recurrence chain)
+		wref = row_shr1(wref, r < m ? inb : 4);
+		const int xt1 = row_shr1(x, 0), vt1 = row_shr1(v, r ? 2 : 0);                     // (r-1,t-1); boundary for t = 0 (:157-164)
+		const int jj = r - tl;
+		if (tl < n && jj >= 0 && jj < m) {
+			int un, vn, xn, yn;
+			const int d = dp_cell(xt1, vt1, u, y, cq, wref, un, vn, xn, yn);
+			u = un; v = vn; x = xn; y = yn;
+			dir[r * 64 + lane] = (uint8_t)d;
+		}
+		inb = inb_next;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	if (tl == 0 && have) {
+		uint8_t *rev = s_rev[w][q];
+		int i = n - 1, j = m - 1, state = 0, k = 0;
+		while (i >= 0 && j >= 0) {
+			const u32 tmp = dir[(i + j) * 64 + (q << 4) + i];
+			int ns = state;                                                 // ksw_backtrack automaton (:38-52), branch-free
+			if (ns != 0 && !((tmp >> (ns + 2)) & 1)) ns = 0;
+			if (ns == 0) ns = (int)(tmp & 7);
+			state = ns;
+			const int isM = ns == 0 ? 1 : 0, isD = (ns == 1 || ns == 3) ? 1 : 0;
+			rev[k++] = (uint8_t)(isM ? 'M' : (isD ? 'D' : 'I'));
+			i -= isM | isD; j -= isM | (1 - isD);
+		}
+		for (; i >= 0; --i) rev[k++] = 'D';
+		for (; j >= 0; --j) rev[k++] = 'I';
+		s_n[w][q] = k;
+	}
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	if (have) {
+		const int nops = s_n[w][q];
+		uint8_t *op = ops + ops_off[job];
+		for (int p = tl; p < nops; p += 16) op[p] = s_rev[w][q][nops - 1 - p];
+		if (tl == 0) ops_len[job] = nops;
+	}
+}
+
+// ---------------------------------------------------------------------------
 // k_dp_stripe: every alignment that does not fit the small kernel.  The n target
 // columns are cut into stripes of 64; ONE WAVEFRONT PER STRIPE, on whatever CU the
 // dispatcher picks, so a 1.5k x 1.5k problem runs on ~25 CUs instead of one.
@@ -327,12 +407,13 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(i32 nsj, const StripeJob
 // Size classes on the device: one fused pass (gsa_scan.h) lists the jobs that need the striped kernel
 // as (job, m, n) triples and packs the others into the small kernel's order array.
 struct OpClassify {
-	const i32 *len1, *len2; i32 *order, *lg, *jlarge, *mail;
-	__device__ i32 value(i64 j, int) const
+	const i32 *len1, *len2; i32 *order, *order_tiny, *lg, *jlarge, *mail;
+	__device__ i32 value(i64 j, int c) const
 	{
 		if (j >= mail[M_NJOB]) return 0;
 		const i32 m = len1[j], n = len2[j];
-		return dp_is_large(m, n) ? 1 : 0;
+		if (c == 0) return dp_is_large(m, n) ? 1 : 0;
+		return (n <= 16 && m + n - 1 <= TINY_ROWS) ? 1 : 0;            // four of these share a wavefront
 	}
 	__device__ void emit(i64 j, const i32 *v, const i32 *ex) const
 	{
@@ -341,9 +422,10 @@ struct OpClassify {
 		if (m <= 0 || n <= 0) mail[M_DPERR] = 2;
 		jlarge[j] = v[0];
 		if (v[0]) { i32 *e = lg + 3 * (size_t)ex[0]; e[0] = (i32)j; e[1] = m; e[2] = n; }
-		else order[j - ex[0]] = (i32)j;
+		else if (v[1]) order_tiny[ex[1]] = (i32)j;
+		else order[j - ex[0] - ex[1]] = (i32)j;
 	}
-	__device__ void done(const i32 *t) const { mail[M_NLARGE] = t[0]; }
+	__device__ void done(const i32 *t) const { mail[M_NLARGE] = t[0]; mail[M_NTINY] = t[1]; }
 };
 
 // sums of m*n and m+n over the jobs (measurement only)
@@ -437,13 +519,14 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	hipStream_t st = c->stream;
 	i32 *mail = c->d_mail.as<i32>();
 	i32 *d_order = dev_ensure<i32>(c, c->d_flag2, (size_t)n_ub + 2);
+	i32 *d_order_tiny = dev_ensure<i32>(c, c->d_dp_tiny, (size_t)n_ub + 2);
 	i32 *d_lg = dev_ensure<i32>(c, c->d_dp_large, 4 * ((size_t)n_ub + 1));      // (job, m, n) triples of the large jobs, then one flag per job
 	i32 *d_jlarge = d_lg ? d_lg + 3 * ((size_t)n_ub + 1) : nullptr;
 	uint8_t *rev = dev_ensure<uint8_t>(c, c->d_i64a, (size_t)ops_total + 64);
-	if (!d_order || !d_lg || !rev) return GSA_ERR_NOMEM;
+	if (!d_order || !d_order_tiny || !d_lg || !rev) return GSA_ERR_NOMEM;
 	if (!pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * LG_CHUNK)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR, 0, 7 * sizeof(i32), st));                    // M_DPERR, M_NLARGE, M_DPERR2, M_CELLS (2 x u64)
-	{ OpClassify op = { len1, len2, d_order, d_lg, d_jlarge, mail }; int rc = lb_launch<1>(c, n_ub, op); if (rc) return rc; }
+	{ OpClassify op = { len1, len2, d_order, d_order_tiny, d_lg, d_jlarge, mail }; int rc = lb_launch<2>(c, n_ub, op); if (rc) return rc; }
 	i32 *h = c->p_dp.as<i32>();
 	const size_t first_lg = (size_t)std::min<i64>(n_ub, LG_CHUNK);
 	GSA_CHECK(c, hipMemcpyAsync(h, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
@@ -451,8 +534,8 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	GSA_CHECK(c, hipStreamSynchronize(st));
 	if (h[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	if (h[M_DPERR]) return gsa_fail(c, GSA_ERR_ARG, "DP job with an empty side");
-	const i32 n = h[M_NJOB], nlarge = h[M_NLARGE], nsmall = n - nlarge;
-	out->n = n; out->nsmall = nsmall; out->nlarge = nlarge;
+	const i32 n = h[M_NJOB], nlarge = h[M_NLARGE], ntiny = h[M_NTINY], nsmall = n - nlarge - ntiny;
+	out->n = n; out->nsmall = nsmall + ntiny; out->nlarge = nlarge;
 	if (n <= 0) return GSA_OK;
 	c->counters[5] += (u64)n;
 	if ((size_t)nlarge > first_lg) {
@@ -465,11 +548,17 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	std::vector<LgJob> large((const LgJob *)(h + MAIL_N), (const LgJob *)(h + MAIL_N) + nlarge);
 	hipEvent_t ev_fork = c->ev[10], ev_j2 = c->ev[12];
 	// the many small jobs run on a second stream, concurrently with the striped ones
-	if (nsmall > 0) {
+	if (nsmall + ntiny > 0) {
 		GSA_CHECK(c, hipEventRecord(ev_fork, st));
 		GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], ev_fork, 0));
-		const unsigned nb = (unsigned)((nsmall + SMALL_WAVES - 1) / SMALL_WAVES);
-		hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, c->stream_aux[1], nsmall, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len);
+		if (ntiny > 0) {
+			const unsigned nb = (unsigned)((ntiny + 4 * TINY_WAVES - 1) / (4 * TINY_WAVES));
+			hipLaunchKernelGGL(k_dp_tiny, dim3(nb), dim3(64 * TINY_WAVES), 0, c->stream_aux[1], ntiny, d_order_tiny, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len);
+		}
+		if (nsmall > 0) {
+			const unsigned nb = (unsigned)((nsmall + SMALL_WAVES - 1) / SMALL_WAVES);
+			hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, c->stream_aux[1], nsmall, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len);
+		}
 		GSA_CHECK(c, hipGetLastError());
 		GSA_CHECK(c, hipEventRecord(ev_j2, c->stream_aux[1]));
 		out->small_in_flight = true;
