@@ -452,7 +452,12 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 {
 	if (large.empty()) return GSA_OK;
 	i32 *mail = c->d_mail.as<i32>();
-	std::sort(large.begin(), large.end(), [](const LgJob &a, const LgJob &b) { const i64 ca = (i64)a.m * a.n, cb = (i64)b.m * b.n; return ca != cb ? ca > cb : a.job < b.job; });   // largest first: they are the critical path
+	// largest first: they are the critical path (only the head of a long list is ordered: the rest fills the machine anyway)
+	{
+		auto by_cells = [](const LgJob &a, const LgJob &b) { const i64 ca = (i64)a.m * a.n, cb = (i64)b.m * b.n; return ca != cb ? ca > cb : a.job < b.job; };
+		if (large.size() > 512) std::partial_sort(large.begin(), large.begin() + 256, large.end(), by_cells);
+		else std::sort(large.begin(), large.end(), by_cells);
+	}
 	int mmax = 1;
 	for (const LgJob &g : large) if (g.m > mmax) mmax = g.m;
 	const int mpad = (mmax + 64 + 63) & ~63;

@@ -16,7 +16,7 @@
 #include "gsa_gap.h"
 
 #define TPB 256
-#define EARLY_CHUNK 512      // large gaps copied together with the leaf table (more -> a second copy)
+#define EARLY_CHUNK 4096     // large gaps copied together with the leaf table (more -> a second copy)
 #define GID(n) i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (n)) return
 #define LAUNCH(k, n, ...) hipLaunchKernelGGL(k, dim3(grid_for((size_t)(n), TPB)), dim3(TPB), 0, st, __VA_ARGS__)
 #define ENS(T, buf, n) do { if (!dev_ensure<T>(c, c->buf, (size_t)(n))) return GSA_ERR_NOMEM; } while (0)
