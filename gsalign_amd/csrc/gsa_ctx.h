@@ -85,6 +85,7 @@ struct gsa_ctx {
 	DevBuf a_uniq, a_cu, a_alive, a_ws, a_wid;
 	DevBuf a_next, a_brk, a_aurank, a_aulist, a_runinfo;
 	DevBuf w_best, w_sum, w_n;
+	DevBuf d_btab;                                 // (window, bucket) -> count hash table of the outlier filter
 	DevBuf d_flag2, d_scan2, d_i64a;
 	i64 n_b = 0, n_c = 0;
 	DevBuf b_q, b_len, b_r, b_gb, b_ge;            // after compaction #1

@@ -211,82 +211,78 @@ __global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__re
 }
 
 // ---- C. outliers: per-window histogram of PosDiff>>4 over unique seeds -----------
-// window id per seed = (number of starts up to and including it) - 1; the same pass builds the
-// (window, bucket) sort keys and clears the per-window accumulators
-struct OpWindowKeys {
-	i64 na; const i32 *a_q; const i64 *a_r; const i32 *uniq, *ws; i64 bmin; int bbits;
-	i32 *wsEx; u64 *key; u32 *val; unsigned long long *wbest, *wsum; i32 *wn;
+// RefinePDFmap counts, per window, the unique seeds per PosDiff>>4 bucket (a std::map).  Here the
+// (window, bucket) counts live in an open-addressing hash table in HBM (one CAS + one add per unique
+// seed, no sort): the same pass that numbers the windows inserts the seeds.
+struct Bucket { unsigned long long key; u32 cnt; u32 pad; };      // cleared to 0xff: key = empty, count = cnt + 1
+#define BKT_EMPTY (~0ull)
+__device__ __forceinline__ u32 bkt_hash(unsigned long long k, int capbits) { return (u32)((k * 0x9E3779B97F4A7C15ull) >> (64 - capbits)); }
+
+// window id per seed = (number of starts up to and including it) - 1
+struct OpWindowBuckets {
+	i64 na; const i32 *a_q; const i64 *a_r; const i32 *uniq, *ws; i64 bmin; int capbits;
+	i32 *wsEx, *slot_of; Bucket *tab; unsigned long long *wbest, *wsum; i32 *wn;
 	__device__ i32 value(i64 i, int) const { return ws[i]; }
 	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
 	{
 		wsEx[i] = ex[0];
-		const i32 w = ex[0] + v[0] - 1;
-		const i64 pd = a_r[i] - a_q[i];
-		const u64 b = (u64)((pd >> 4) - bmin);                     // bucket, shifted to be non-negative: as few key bits as the contig needs
-		key[i] = uniq[i] ? (((u64)(u32)w << bbits) | b) : ~0ull;    // non-unique seeds sort to the end
-		val[i] = (u32)i;
 		wbest[i] = 0; wsum[i] = 0; wn[i] = 0;
+		i32 slot = -1;
+		if (uniq[i]) {
+			const u32 w = (u32)(ex[0] + v[0] - 1);
+			const u32 b = (u32)(((a_r[i] - a_q[i]) >> 4) - bmin);              // bucket, shifted to be non-negative
+			const unsigned long long key = ((unsigned long long)w << 32) | b;
+			const u32 mask = (1u << capbits) - 1;
+			u32 h = bkt_hash(key, capbits);
+			for (;;) {
+				const unsigned long long old = atomicCAS(&tab[h].key, BKT_EMPTY, key);
+				if (old == BKT_EMPTY || old == key) break;
+				h = (h + 1) & mask;
+			}
+			atomicAdd(&tab[h].cnt, 1u);
+			slot = (i32)h;
+		}
+		slot_of[i] = slot;
 	}
 	__device__ void done(const i32 *t) const { wsEx[na] = t[0]; wbest[na] = 0; wsum[na] = 0; wn[na] = 0; }
 };
 
-struct OpRunHeads {
-	i64 na; const u64 *key; i32 *head, *headEx, *rs;
-	__device__ i32 value(i64 i, int) const { return (key[i] != ~0ull && (i == 0 || key[i] != key[i - 1])) ? 1 : 0; }
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const { head[i] = v[0]; headEx[i] = ex[0]; if (v[0]) rs[ex[0]] = (i32)i; }
-	__device__ void done(const i32 *t) const { headEx[na] = t[0]; head[na] = 0; }
-};
-
-// run r = [rs[r], rs[r+1]) ; the last run ends at nU (number of unique seeds)
-__global__ void k_window_mode(i64 na, const i32 *__restrict__ headEx, const i32 *__restrict__ rs, const u64 *__restrict__ key, const i32 *__restrict__ cuEx,
-                              int bbits, unsigned long long *wbest)
+// modal bucket per window: first maximum in ascending bucket order (RefinePDFmap, GSAlign.cpp:251)
+__global__ void k_window_mode(i64 cap, const Bucket *__restrict__ tab, unsigned long long *wbest)
 {
-	GID(na);
-	const i32 nRuns = headEx[na];
-	if (i >= nRuns) return;
-	const i32 nU = cuEx[na];
-	const i32 b = rs[i], e = (i + 1 < nRuns) ? rs[i + 1] : nU;
-	const u64 k = key[b];
-	const u32 w = (u32)(k >> bbits);
-	// first maximum in ascending key order (RefinePDFmap, GSAlign.cpp:251)
-	atomicMax(&wbest[w], ((unsigned long long)(u32)(e - b) << 32) | (0xFFFFFFFFu - (u32)(k & ((1ull << bbits) - 1))));
+	GID(cap);
+	const unsigned long long k = tab[i].key;
+	if (k == BKT_EMPTY) return;
+	atomicMax(&wbest[(u32)(k >> 32)], ((unsigned long long)(tab[i].cnt + 1u) << 32) | (0xFFFFFFFFu - (u32)k));
 }
 
-__global__ void k_window_avg(i64 na, int bbits, const u64 *__restrict__ key, const u32 *__restrict__ val, const i32 *__restrict__ cuEx,
-                             const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const unsigned long long *__restrict__ wbest,
-                             unsigned long long *wsum, i32 *wn)
+__global__ void k_window_avg(i64 na, const i32 *__restrict__ slot_of, const Bucket *__restrict__ tab, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r,
+                             const unsigned long long *__restrict__ wbest, unsigned long long *wsum, i32 *wn)
 {
 	GID(na);
-	if (i >= cuEx[na]) return;
-	const u64 k = key[i]; const u32 w = (u32)(k >> bbits);
-	const i32 kk = (i32)(k & ((1ull << bbits) - 1)), mode = (i32)(0xFFFFFFFFu - (u32)wbest[w]);      // (shifted buckets: only their difference is used)
-	i64 dk = (i64)kk - mode; if (dk < 0) dk = -dk;
-	if (dk < 3) {                                                    // surviving bucket (:256)
-		const u32 s = val[i];
-		atomicAdd(&wsum[w], (unsigned long long)(a_r[s] - a_q[s]));
+	const i32 sl = slot_of[i];
+	if (sl < 0) return;
+	const unsigned long long k = tab[sl].key; const u32 w = (u32)(k >> 32);
+	const i64 kk = (i64)(u32)k, mode = (i64)(0xFFFFFFFFu - (u32)wbest[w]);      // (shifted buckets: only their difference is used)
+	if (d_llabs(kk - mode) < 3) {                                            // surviving bucket (:256)
+		atomicAdd(&wsum[w], (unsigned long long)(a_r[i] - a_q[i]));
 		atomicAdd(&wn[w], 1);
 	}
 }
 
-__global__ void k_outlier_kill(i64 na, int bbits, const u64 *__restrict__ key, const u32 *__restrict__ val, const i32 *__restrict__ cuEx,
-                               const i32 *__restrict__ head, const i32 *__restrict__ headEx, const i32 *__restrict__ rs,
-                               const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const unsigned long long *__restrict__ wbest,
-                               const unsigned long long *__restrict__ wsum, const i32 *__restrict__ wn, i64 G, i32 max_indel, i32 *alive)
+__global__ void k_outlier_kill(i64 na, const i32 *__restrict__ slot_of, const Bucket *__restrict__ tab, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r,
+                               const unsigned long long *__restrict__ wbest, const unsigned long long *__restrict__ wsum, const i32 *__restrict__ wn,
+                               i64 G, i32 max_indel, i32 *alive)
 {
 	GID(na);
-	const i32 nU = cuEx[na];
-	if (i >= nU) return;
-	const u64 k = key[i]; const u32 w = (u32)(k >> bbits);
-	const i32 kk = (i32)(k & ((1ull << bbits) - 1)), mode = (i32)(0xFFFFFFFFu - (u32)wbest[w]);      // (shifted buckets: only their difference is used)
-	i64 dk = (i64)kk - mode; if (dk < 0) dk = -dk;
-	const i32 nRuns = headEx[na];
-	const i32 r = headEx[i] + head[i] - 1;
-	const i32 rl = ((r + 1 < nRuns) ? rs[r + 1] : nU) - rs[r];
-	const i32 cnt = dk < 3 ? rl : 0;                                 // counts are read after zeroing (App. B #23)
-	const i64 avg = wn[w] > 0 ? (i64)wsum[w] / wn[w] : G;            // C division: truncation toward zero
-	const u32 s = val[i];
-	const i64 pd = a_r[s] - a_q[s];
-	if (d_llabs(avg - pd) > max_indel && cnt < 3) alive[s] = 0;      // GSAlign.cpp:290, Min_PD_Freq = 3
+	const i32 sl = slot_of[i];
+	if (sl < 0) return;
+	const unsigned long long k = tab[sl].key; const u32 w = (u32)(k >> 32);
+	const i64 kk = (i64)(u32)k, mode = (i64)(0xFFFFFFFFu - (u32)wbest[w]);
+	const i32 cnt = d_llabs(kk - mode) < 3 ? (i32)(tab[sl].cnt + 1u) : 0;       // counts are read after zeroing (App. B #23)
+	const i64 avg = wn[w] > 0 ? (i64)wsum[w] / wn[w] : G;                      // C division: truncation toward zero
+	const i64 pd = a_r[i] - a_q[i];
+	if (d_llabs(avg - pd) > max_indel && cnt < 3) alive[i] = 0;               // GSAlign.cpp:290, Min_PD_Freq = 3
 }
 
 // ---- D. multi-hit query positions (GSAlign.cpp:178-225,341-350) -------------------
@@ -439,18 +435,18 @@ int stage2_chain(gsa_ctx *c)
 	if (getenv("GSA_DEBUG_CHAIN")) { i32 nc_ = 0, nb_ = 0; hipStreamSynchronize(st); hipMemcpy(&nc_, candEx + na, 4, hipMemcpyDeviceToHost); hipMemcpy(&nb_, brkEx + na, 4, hipMemcpyDeviceToHost); fprintf(stderr, "[gsa] stage 2: %lld seeds, %d window-start candidates, %d breaks\n", (long long)na, nc_, nb_); }
 	// C. outliers
 	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);
-	// (window, bucket) keys: bucket = PosDiff >> 4 shifted by its minimum, so the sort only runs over the bits in use
 	const i64 bmin = ((-(i64)c->qlen) >> 4) - 1;
-	const int bbits = ceil_log2_u64((u64)(((2 * c->G + c->qlen) >> 4) - bmin + 2)), wbits = ceil_log2_u64((u64)na + 1);
-	{ OpWindowKeys op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, bmin, bbits, wsEx, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(),
-	                      c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>() }; RC((lb_launch<1>(c, na, op))); }
-	RC(prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, bbits + wbits));
-	i32 *head = c->d_flag.as<i32>(), *headEx = c->d_scan.as<i32>(), *rs = c->a_runinfo.as<i32>();
-	{ OpRunHeads op = { na, c->d_key_b.as<u64>(), head, headEx, rs }; RC((lb_launch<1>(c, na, op))); }
-	LAUNCH(k_window_mode, na, na, headEx, rs, c->d_key_b.as<u64>(), cuEx, bbits, c->w_best.as<unsigned long long>());
-	LAUNCH(k_window_avg, na, na, bbits, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), cuEx, c->a_q.as<i32>(), c->a_r.as<i64>(), c->w_best.as<unsigned long long>(),
+	int capbits = 10; while ((1ull << capbits) < 2 * (u64)na) capbits++;      // load factor <= 1/2
+	const i64 cap = 1ll << capbits;
+	ENS(Bucket, d_btab, cap);
+	GSA_CHECK(c, hipMemsetAsync(c->d_btab.p, 0xff, (size_t)cap * sizeof(Bucket), st));
+	i32 *slot_of = c->a_runinfo.as<i32>();
+	{ OpWindowBuckets op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, bmin, capbits, wsEx, slot_of, c->d_btab.as<Bucket>(),
+	                         c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>() }; RC((lb_launch<1>(c, na, op))); }
+	LAUNCH(k_window_mode, cap, cap, c->d_btab.as<Bucket>(), c->w_best.as<unsigned long long>());
+	LAUNCH(k_window_avg, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(), c->w_best.as<unsigned long long>(),
 	       c->w_sum.as<unsigned long long>(), c->w_n.as<i32>());
-	LAUNCH(k_outlier_kill, na, na, bbits, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), cuEx, head, headEx, rs, c->a_q.as<i32>(), c->a_r.as<i64>(),
+	LAUNCH(k_outlier_kill, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(),
 	       c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->G, c->prm.MaxIndelSize, alive);
 	// D. multi-hit positions
 	i32 *auEx = c->a_aurank.as<i32>(), *aulist = c->a_aulist.as<i32>();
