@@ -31,22 +31,35 @@ __device__ void kmer_hist(const uint8_t *__restrict__ s, int len, u32 *hist, int
 	if (lane == 0) *s_flag = 0;
 	__syncthreads();
 	int hasN = 0;
-	for (int p = lane; p < len; p += GS_T) hasN |= (s[p] == 'N');
+	// (eight positions per thread and pass: one 16-byte window read; both sequence buffers are padded)
+	for (int p = lane * 8; p < len; p += GS_T * 8) {
+		unsigned long long w0; __builtin_memcpy(&w0, s + p, 8);
+		for (int b = 0; b < 8; b++) hasN |= (p + b < len && (uint8_t)(w0 >> (8 * b)) == 'N');
+	}
 	if (hasN) *s_flag = 1;
 	__syncthreads();
 	hasN = *s_flag;
 	__syncthreads();
 	if (!hasN) {
 		// wid_0 = direct id; wid_p (p>=1) = ((wid_{p-1} & 0xFF) << 2) + v[p+4], which depends on v[p..p+4] only
-		for (int p = lane; p + 5 <= len; p += GS_T) {
-			u32 id;
-			if (p == 0) id = kmer_id_direct(s, 0);
-			else {
-				u32 t = 0;
-				for (int i = 0; i < 4; i++) t = (t << 2) + gsa_nt4(s[p + i]);
-				id = ((t & 0xFF) << 2) + gsa_nt4(s[p + 4]);
+		for (int p0 = lane * 8; p0 + 5 <= len; p0 += GS_T * 8) {
+			unsigned long long w0, w1; __builtin_memcpy(&w0, s + p0, 8); __builtin_memcpy(&w1, s + p0 + 8, 8);
+			u32 cd[12];
+#pragma unroll
+			for (int b = 0; b < 12; b++) cd[b] = (u32)gsa_nt4((uint8_t)((b < 8 ? w0 >> (8 * b) : w1 >> (8 * (b - 8)))));
+#pragma unroll
+			for (int b = 0; b < 8; b++) {
+				const int p = p0 + b;
+				if (p + 5 > len) break;
+				u32 id;
+				if (p == 0) { id = 0; for (int i = 0; i < 5; i++) id = (id << 2) + cd[i]; }
+				else {
+					u32 t = 0;
+					for (int i = 0; i < 4; i++) t = (t << 2) + cd[b + i];
+					id = ((t & 0xFF) << 2) + cd[b + 4];
+				}
+				atomicAdd(&hist[id], 1u);
 			}
-			atomicAdd(&hist[id], 1u);
 		}
 	} else if (lane == 0) {
 		u32 wid, count = 0, head = 0, tail = 0;
