@@ -289,7 +289,7 @@ int stage7_fill(gsa_ctx *c)
 	if (c->n_early > 0) GSA_CHECK(c, hipMemsetAsync(c->e_rec.p, 0xff, (size_t)c->n_early * 4, st));      // -1: no record (yet)
 	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), c->fb_sbeg.as<i32>(), c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref, c->e_id.as<i32>(),
 	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), c->fb_fragbase.as<i32>(), c->f_early.as<i32>(), c->e_rec.as<i32>(), c->d_mail.as<i32>() };
-	RC((lb_launch<1, 1>(c, ns, op)));      // (one slot per thread: the mismatch count of a gap is a serial loop)
+	RC((lb_launch<1>(c, ns, op)));
 	c->n_frags = -1;
 	return GSA_OK;
 }

@@ -224,7 +224,7 @@ int stage345_refine(gsa_ctx *c)
 		LAUNCH(k_leaf_emit, ub, ub, mail + cur, mail, lstart, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, cut5, ps,
 		       c->blk_score.as<i32>(), c->d_leaf.as<Leaf>());
 		{ OpEarlyLarge op = { mail + cur, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_head.as<i32>(), c->d_query.as<uint8_t>(), c->di.ref,
-		                      c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail }; RC((lb_launch<2, 1>(c, ub, op))); }
+		                      c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail }; RC((lb_launch<2>(c, ub, op))); }
 		// the mailbox, the first LEAF_CHUNK leaves and the first EARLY_CHUNK large gaps come back together
 		GSA_CHECK(c, hipMemcpyAsync(c->h_mail, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipMemcpyAsync(c->p_leaf.p, c->d_leaf.p, first * sizeof(Leaf), hipMemcpyDeviceToHost, st));
