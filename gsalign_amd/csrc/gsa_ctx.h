@@ -32,7 +32,7 @@ struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf ra
 struct gsa_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
-	hipStream_t stream_aux[2] = {nullptr, nullptr};   // the DP size classes run concurrently
+	hipStream_t stream_aux[3] = {nullptr, nullptr, nullptr};   // [0] early striped DP, [1] small DP + strings + sums, [2] records to the host
 	std::string err;
 	Params prm;
 	DevIndex di;
@@ -168,6 +168,7 @@ int launch_stripes(gsa_ctx *c, hipStream_t ss, std::vector<LgJob> &large, const 
                    uint8_t *ops, const i64 *ops_off, i32 *ops_len, uint8_t *rev, int err_slot);   // k_dp.hip
 struct Ksw2Launch { i32 n = 0, nsmall = 0, nlarge = 0; bool small_in_flight = false; };      // what run_ksw2_jobs left running
 int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, const i32 *len1,
-                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total, Ksw2Launch *out);   // k_dp.hip
+                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total, Ksw2Launch *out,
+                  const i32 *jfrag = nullptr, gsa_frag *frag = nullptr);   // k_dp.hip  (jfrag/frag: the small kernels also set aln_len of the job's record)
 
 #endif

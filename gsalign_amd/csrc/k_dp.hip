@@ -21,7 +21,8 @@
 
 __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const i32 *__restrict__ order, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
                                                                 const i32 *__restrict__ len1, const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2,
-                                                                const i32 *__restrict__ len2, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len)
+                                                                const i32 *__restrict__ len2, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len,
+                                                                const i32 *__restrict__ jfrag, gsa_frag *frag)
 {
 	__shared__ uint8_t s_dir[SMALL_WAVES][SMALL_ROWS * 64];
 	__shared__ uint8_t s_rev[SMALL_WAVES][SMALL_ROWS + 64];
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 	const int nops = s_n[w];
 	uint8_t *op = ops + ops_off[job];
 	for (int p = lane; p < nops; p += 64) op[p] = rev[nops - 1 - p];
-	if (lane == 0) ops_len[job] = nops;
+	if (lane == 0) { ops_len[job] = nops; if (frag) frag[jfrag[job]].aln_len = nops; }      // (the job's record is final with this)
 }
 
 // ---------------------------------------------------------------------------
@@ -90,7 +91,8 @@ __device__ __forceinline__ int row_shr1(int v, int fill) { return __builtin_amdg
 
 __global__ void __launch_bounds__(64 * TINY_WAVES) k_dp_tiny(i32 n_jobs, const i32 *__restrict__ order, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
                                                               const i32 *__restrict__ len1, const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2,
-                                                              const i32 *__restrict__ len2, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len)
+                                                              const i32 *__restrict__ len2, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len,
+                                                              const i32 *__restrict__ jfrag, gsa_frag *frag)
 {
 	__shared__ uint8_t s_dir[TINY_WAVES][TINY_ROWS * 64];
 	__shared__ uint8_t s_ref[TINY_WAVES][4][TINY_ROWS];         // nt4 codes of the four reference fragments
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(64 * TINY_WAVES) k_dp_tiny(i32 n_jobs, const i
 		const int nops = s_n[w][q];
 		uint8_t *op = ops + ops_off[job];
 		for (int p = tl; p < nops; p += 16) op[p] = s_rev[w][q][nops - 1 - p];
-		if (tl == 0) ops_len[job] = nops;
+		if (tl == 0) { ops_len[job] = nops; if (frag) frag[jfrag[job]].aln_len = nops; }
 	}
 }
 
@@ -517,7 +519,8 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 // the small kernel are processed in batches so that the direction bytes of one batch fit the budget.
 // Returns with the work enqueued: errors of the last batch land in the mailbox (M_DPERR, M_DPERR2).
 int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, const i32 *len1,
-                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total, Ksw2Launch *out)
+                  const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total, Ksw2Launch *out,
+                  const i32 *jfrag, gsa_frag *frag)
 {
 	*out = Ksw2Launch();
 	if (n_ub <= 0) return GSA_OK;
@@ -558,11 +561,11 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 		GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], ev_fork, 0));
 		if (ntiny > 0) {
 			const unsigned nb = (unsigned)((ntiny + 4 * TINY_WAVES - 1) / (4 * TINY_WAVES));
-			hipLaunchKernelGGL(k_dp_tiny, dim3(nb), dim3(64 * TINY_WAVES), 0, c->stream_aux[1], ntiny, d_order_tiny, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len);
+			hipLaunchKernelGGL(k_dp_tiny, dim3(nb), dim3(64 * TINY_WAVES), 0, c->stream_aux[1], ntiny, d_order_tiny, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag);
 		}
 		if (nsmall > 0) {
 			const unsigned nb = (unsigned)((nsmall + SMALL_WAVES - 1) / SMALL_WAVES);
-			hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, c->stream_aux[1], nsmall, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len);
+			hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, c->stream_aux[1], nsmall, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag);
 		}
 		GSA_CHECK(c, hipGetLastError());
 		GSA_CHECK(c, hipEventRecord(ev_j2, c->stream_aux[1]));

@@ -67,7 +67,7 @@ struct OpSlots {
 // gapped strings, and of a DP job's op string, then do not depend on the DP results, and everything
 // that is not a large DP job can be written while the striped kernel still runs.
 struct OpDpJobs {
-	const i32 *ftype, *fearly; const gsa_frag *frag;
+	const i32 *ftype, *fearly; gsa_frag *frag;
 	i32 *jfrag; i64 *off1; i32 *len1; i64 *off2; i32 *len2; i64 *opsoff; i32 *fjob, *alen; i64 *aoff; i32 *mail;
 	__device__ i32 value(i64 i, int c) const
 	{
@@ -83,6 +83,9 @@ struct OpDpJobs {
 	{
 		if (i >= mail[M_NF]) return;
 		alen[i] = v[1]; aoff[i] = ex[1];                      // (alen of a DP gap: replaced by the op count)
+		// the record's own string fields: final here for everything but a DP gap (its length comes from the DP kernel
+		// of its size class, or from the host's patch list for the striped ones), so the records can leave early
+		if (ftype[i] != FT_SEED) { frag[i].aln_off = ex[1]; frag[i].aln_len = ftype[i] == FT_DP ? 0 : v[1]; }
 		if (!v[0]) { fjob[i] = (ftype[i] == FT_DP) ? -2 - fearly[i] : -1; return; }      // <= -2: early job -2 - fjob
 		const i32 j = ex[0];
 		jfrag[j] = (i32)i; off1[j] = frag[i].rpos; len1[j] = frag[i].rlen; off2[j] = frag[i].qpos; len2[j] = frag[i].qlen; opsoff[j] = ex[1];
@@ -162,7 +165,7 @@ __global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_
 			const i32 fj = fjob[i];
 			const i32 Lr = t == FT_DP ? ((fj < 0 || jlarge[fj]) ? -1 : nops[fj]) : alen[i];       // -1: a large DP job, written after the striped kernel
 			if (t == FT_SEED) { const i32 l = frag[i].qlen; c_len[i] = l; c_score[i] = l; }
-			else if (Lr < 0) { c_len[i] = 0; c_score[i] = 0; frag[i].aln_off = aoff[i]; frag[i].aln_len = 0; }
+			else if (Lr < 0) { c_len[i] = 0; c_score[i] = 0; }
 			else if (Lr > MAT_SERIAL) s_list[atomicAdd(&s_n, 1)] = tid;
 			else {
 				const gsa_frag f = frag[i];
@@ -183,7 +186,7 @@ __global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_
 						score += (gsa_nt4(a1) == gsa_nt4(a2));             // CountIdenticalPairs (:38-47)
 					}
 				}
-				c_len[i] = L; c_score[i] = score; frag[i].aln_off = o; frag[i].aln_len = L;
+				c_len[i] = L; c_score[i] = score;
 			}
 		}
 	}
@@ -217,7 +220,7 @@ __global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_
 			}
 			for (int d = 32; d; d >>= 1) score += __shfl_xor(score, d);
 		}
-		if (lane == 0) { c_len[i] = L; c_score[i] = score; frag[i].aln_off = o; frag[i].aln_len = L; }
+		if (lane == 0) { c_len[i] = L; c_score[i] = score; }
 	}
 }
 
@@ -317,7 +320,8 @@ int stage78_extend(gsa_ctx *c)
 	ENS(uint8_t, d_ops, c->span_ub + 64); ENS(uint8_t, d_aln1, c->span_ub + 64); ENS(uint8_t, d_aln2, c->span_ub + 64);
 	ENS(i32, d_flag, nfu + 2); ENS(u32, d_scan, nfu + 2); ENS(u32, d_flag2, nfu + 2); ENS(i32, bl_alnlen, nfb + 1); ENS(i32, bl_score, nfb + 1);
 	Ksw2Launch kl;
-	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub, &kl));
+	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub, &kl,
+	                 c->j_frag.as<i32>(), c->f_rec.as<gsa_frag>()));
 	// (run_ksw2_jobs read the mailbox: the record count and the size of the string pools are known now)
 	const i32 *hm = c->p_dp.as<i32>();
 	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN]; c->n_large = kl.nlarge;
@@ -326,6 +330,14 @@ int stage78_extend(gsa_ctx *c)
 	    !pin_ensure<i32>(c, c->p_blk, (size_t)3 * (nfb + 1) + MAIL_N + 8) || !pin_ensure<i32>(c, c->p_patch, 3 * ((size_t)kl.nlarge + (size_t)c->n_early) + 4)) return GSA_ERR_NOMEM;
 	// ---- behind the small jobs (stream_aux[1]; when there is no small job it starts at the fork) ----
 	if (!kl.small_in_flight) { GSA_CHECK(c, hipEventRecord(c->ev[10], st)); GSA_CHECK(c, hipStreamWaitEvent(sx, c->ev[10], 0)); }
+	// the records are final behind the small DP kernels (their DP gaps got their lengths there): they leave on a third stream
+	// while the strings are still being written
+	{
+		hipStream_t sc = c->stream_aux[2];
+		GSA_CHECK(c, hipStreamWaitEvent(sc, kl.small_in_flight ? c->ev[12] : c->ev[10], 0));
+		if (nfr) GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, nfr * sizeof(gsa_frag), hipMemcpyDeviceToHost, sc));
+		GSA_CHECK(c, hipEventRecord(c->ev[15], sc));
+	}
 	const i32 *jlarge = c->d_dp_large.as<i32>() + 3 * ((size_t)nju + 1);
 	i32 *c_len = c->d_flag.as<i32>(), *c_score = c->f_score.as<i32>();
 	hipLaunchKernelGGL(k_materialize, dim3((unsigned)((nfu + 255) / 256)), dim3(256), 0, sx, mail + M_NF, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(),
@@ -340,7 +352,6 @@ int stage78_extend(gsa_ctx *c)
 	GSA_CHECK(c, hipMemcpyAsync(h_len, c->bl_alnlen.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
 	GSA_CHECK(c, hipMemcpyAsync(h_score, c->bl_score.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
 	GSA_CHECK(c, hipMemcpyAsync(h_fragbase, c->fb_fragbase.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
-	if (nfr) GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, nfr * sizeof(gsa_frag), hipMemcpyDeviceToHost, sx));
 	GSA_CHECK(c, hipEventRecord(c->ev[13], sx));
 	// ---- behind the striped kernels ----
 	const size_t npatch = (size_t)kl.nlarge + (size_t)c->n_early;
@@ -358,7 +369,8 @@ int stage78_extend(gsa_ctx *c)
 		}
 		GSA_CHECK(c, hipMemcpyAsync(c->p_patch.p, c->d_patch.p, 3 * npatch * 4, hipMemcpyDeviceToHost, st));
 	}
-	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[13], 0));      // the other strings are written, the records are on the host
+	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[13], 0));      // the other strings are written
+	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[15], 0));      // the records are on the host
 	if (c->n_aln) {
 		GSA_CHECK(c, hipMemcpyAsync(c->p_aln1.p, c->d_aln1.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipMemcpyAsync(c->p_aln2.p, c->d_aln2.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, st));
