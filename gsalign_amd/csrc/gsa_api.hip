@@ -72,7 +72,7 @@ int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa
 	(void)hipGetLastError();
 	CK(hipStreamCreate(&c->stream));
 	CK(hipStreamCreate(&c->stream_aux[0])); CK(hipStreamCreate(&c->stream_aux[1])); CK(hipStreamCreate(&c->stream_aux[2]));
-	for (int i = 0; i < 16; i++) CK(hipEventCreate(&c->ev[i]));
+	for (int i = 0; i < 24; i++) CK(hipEventCreate(&c->ev[i]));
 	const size_t bwt_bytes = ((idx->bwt_words + 15) / 16) * 64;          // whole 64-byte blocks
 	CK(hipMalloc(&c->d_bwt.p, bwt_bytes + 64)); c->d_bwt.cap = bwt_bytes + 64;
 	CK(hipMemset(c->d_bwt.p, 0, bwt_bytes + 64));
@@ -128,12 +128,12 @@ void gsa_destroy(gsa_ctx *c)
 		&c->r_q, &c->r_len, &c->r_r, &c->r_bid, &c->r_tmp_q, &c->r_tmp_len, &c->r_tmp_r, &c->r_tmp_bid, &c->r_cut4, &c->r_cut5, &c->r_simjob, &c->r_simres, &c->d_leaf,
 		&c->fb_seedbase, &c->fb_sbeg, &c->fb_fragbase, &c->f_rec, &c->f_type, &c->f_mism, &c->f_alnlen, &c->f_job, &c->f_score,
 		&c->d_dp_tiny, &c->d_dp_bnd, &c->d_dp_ctr, &c->d_dp_jobs, &c->d_dp_large, &c->d_patch,
-		&c->e_id, &c->e_rec, &c->e_list, &c->e_off1, &c->e_off2, &c->e_opsoff, &c->e_nops, &c->e_ops, &c->e_rev, &c->r_head, &c->f_early, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_aln1, &c->d_aln2, &c->d_alnoff, &c->bl_alnlen, &c->bl_score };
+		&c->e_id, &c->e_rec, &c->e_list, &c->e_off1, &c->e_off2, &c->e_opsoff, &c->e_nops, &c->e_ops, &c->e_rev, &c->r_head, &c->f_early, &c->r_orig, &c->r_tmp_orig, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_aln1, &c->d_aln2, &c->d_alnoff, &c->bl_alnlen, &c->bl_score };
 	for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
 	if (c->h_mail) hipHostFree(c->h_mail);
-	for (DevBuf *b : { &c->p_frags, &c->p_aln1, &c->p_aln2, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_patch }) if (b->p) hipHostFree(b->p);
-	for (int i = 0; i < 16; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+	for (DevBuf *b : { &c->p_frags, &c->p_aln1, &c->p_aln2, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_patch, &c->p_early }) if (b->p) hipHostFree(b->p);
+	for (int i = 0; i < 24; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 3; i++) if (c->stream_aux[i]) hipStreamDestroy(c->stream_aux[i]);
 	if (c->stream) hipStreamDestroy(c->stream);
 	delete c;
@@ -146,7 +146,7 @@ int gsa_set_query(gsa_ctx *c, const char *query, int32_t qlen)
 	if (!c || !query || qlen < 0) return GSA_ERR_ARG;
 	GSA_CHECK(c, hipSetDevice(c->device));
 	if (c->early_in_flight) { GSA_CHECK(c, hipStreamSynchronize(c->stream_aux[0])); c->early_in_flight = false; }
-	c->n_early = 0;
+	c->n_early = 0; c->early_listed = false; c->early_consumed = false;
 	if (!dev_ensure<uint8_t>(c, c->d_query, (size_t)qlen + 64)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemcpyAsync(c->d_query.p, query, (size_t)qlen, hipMemcpyHostToDevice, c->stream));
 	c->h_query.assign(query, (size_t)qlen);
@@ -178,7 +178,7 @@ int gsa_run_to(gsa_ctx *c, int stage)
 	}
 	// stages 1-2 leave work in flight (no count read-backs); the call returns with the stream idle
 	if (rc == GSA_OK) { GSA_CHECK(c, hipStreamSynchronize(c->stream)); collect_events(c); }
-	if (c->early_in_flight && (rc != GSA_OK || c->stage < 8)) GSA_CHECK(c, hipStreamSynchronize(c->stream_aux[0]));      // a stage view (or an error) must not leave the early DP launch running
+	if (c->early_in_flight && (rc != GSA_OK || !c->early_consumed)) GSA_CHECK(c, hipStreamSynchronize(c->stream_aux[0]));      // a stage view (or an error) must not leave the early DP launch running
 	return rc;
 }
 

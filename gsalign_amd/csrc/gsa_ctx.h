@@ -18,7 +18,7 @@ struct Leaf {
 
 // Device "mailbox" (i32[MAIL_N]) of the counts the stages produce; the host reads the whole
 // box in ONE pinned copy where it needs them instead of one read-back per count.
-enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_NTINY = 40, M_TICKET = 48, M_NBRAW = 49, M_NR2 = 50, M_NF = 51, M_NJOB = 52, M_OPSTOT = 53, M_NALN = 54, M_DPERR = 55, M_NLARGE = 56, M_DPERR2 = 57, M_CELLS = 58 /* two u64: sum m*n, sum m+n */, M_NEARLY = 62, M_DPERR3 = 63, MAIL_N = 64 };
+enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_NTINY = 40, M_TICKET = 48, M_NBRAW = 49, M_NR2 = 50, M_NF = 51, M_NJOB = 52, M_OPSTOT = 53, M_NALN = 54, M_DPERR = 55, M_NLARGE = 56, M_DPERR2 = 57, M_CELLS = 58 /* two u64: sum m*n, sum m+n */, M_DPERR3 = 41, M_NEARLY = 62, M_EOPS = 63, MAIL_N = 64 };
 #define LEAF_CHUNK 1024      // leaves copied together with the mailbox (more -> a second copy)
 
 struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf range
@@ -40,7 +40,7 @@ struct gsa_ctx {
 	bool prof_seed = false;                        // time the seed kernel only (two events instead of ten per contig)
 	bool count_blocks = false;                     // run the accounting build of the seed kernel (exact algorithmic Occ-block count)
 	u64 dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	hipEvent_t ev[16];
+	hipEvent_t ev[24];
 	float kernel_ms[8];
 	u64 counters[8];
 
@@ -116,7 +116,9 @@ struct gsa_ctx {
 	DevBuf d_dp_tiny;                              // order array of the four-per-wavefront DP kernel
 	DevBuf d_dp_bnd, d_dp_ctr, d_dp_jobs, d_dp_large;   // striped DP: boundary granules, tickets, job descriptors, (job,m,n) of the large jobs
 	// large DP gaps are known once the leaf table exists: they are launched there (stream_aux[0]) and run under stages 6-7
-	DevBuf e_id, e_rec, e_list, e_off1, e_off2, e_opsoff, e_nops, e_ops, e_rev, r_head, f_early;
+	DevBuf e_id, e_rec, e_list, e_off1, e_off2, e_opsoff, e_nops, e_ops, e_rev, r_head, f_early, r_orig, r_tmp_orig, p_early;
+	bool early_consumed = false;                   // stage 7 enqueued its wait for the early launch (else gsa_run_to waits before it returns)
+	bool early_listed = false;                     // stage 2 left the list of large gaps on its way to the host (event ev[16])
 	i32 n_early = 0; bool early_in_flight = false; std::vector<i32> h_early;      // (seed, m, n) per early job
 	u32 dp_epoch = 0;                              // tag of the boundary granules of the current striped launch
 	DevBuf p_dp, p_sj;                             // pinned: mailbox + large-job list, stripe job descriptors
@@ -155,6 +157,7 @@ int build_dense_sa(gsa_ctx *c, u64 n_sa);   // k_seed.hip
 int build_presence(gsa_ctx *c);             // k_seed.hip  (after MinSeedLength changed)
 int stage1_seed(gsa_ctx *c);          // k_seed.hip
 int stage2_chain(gsa_ctx *c);         // k_chain.hip
+int launch_early_dp(gsa_ctx *c);      // k_chain.hip  (striped DP for the large gaps listed at the end of stage 2)
 int stage2_fetch_host(gsa_ctx *c);    // k_chain.hip  (counts + S2 block table for the stage-2 view)
 void collect_events(gsa_ctx *c);      // gsa_api.hip  (deferred hipEventElapsedTime of stages 1-2)
 int stage345_refine(gsa_ctx *c);      // k_refine.hip  (device part of S3, S4, S5 + leaf table)

@@ -18,6 +18,7 @@
 // ascending key order, bucket counts are read after zeroing.
 #include "gsa_ctx.h"
 #include "gsa_scan.h"
+#include "gsa_gap.h"
 
 #define TPB 256
 #define GID(n) i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i >= (n)) return
@@ -398,6 +399,71 @@ __global__ void k_seed_block_id(const i32 *__restrict__ nptr, const i32 *__restr
 	bid[i] = bkeep[b] ? bkeepEx[b] : -1;
 }
 
+// ---- F. the large DP gaps, two stages early ------------------------------------------
+// The striped DP of the largest gap is the contig's latency floor, and almost every gap between two
+// consecutive seeds of an S2 block survives S3-S6 unchanged.  So the large ones (the ones that will need
+// the striped kernel) are listed HERE and launched while S3-S6 still run; stage 6 takes a result only if
+// the gap it finds is exactly the one listed (same coordinates), anything else -- a gap S3 changed, a
+// gap S4 keeps although it looked hopeless -- goes the normal way later.  Gaps beyond MaxSeedGap are
+// always cut by S4 and are not listed; what S4's similarity test or the list logic drops was computed
+// in vain.
+struct OpEarlyGaps {
+	const i32 *q, *len; const i64 *r; const i32 *bid; const uint8_t *query, *ref;
+	i32 *e_id, *e_list; i64 *off1, *off2, *opsoff; i32 *mail;
+	__device__ bool gap(i64 s, i32 &qp, i64 &rp, i32 &qg, i32 &rg) const
+	{
+		if (s + 1 >= mail[M_NC] || bid[s] < 0 || bid[s + 1] != bid[s]) return false;
+		qp = q[s] + len[s]; rp = r[s] + len[s];
+		qg = q[s + 1] - qp; if (qg < 0) qg = 0;
+		const i64 rg64 = r[s + 1] - rp; rg = rg64 < 0 ? 0 : (i32)rg64;
+		if (qg > GSA_MAX_SEED_GAP || rg64 > GSA_MAX_SEED_GAP || !dp_is_large(rg, qg)) return false;      // (cheap tests first)
+		i32 mism;
+		return classify_gap(query, ref, qp, rp, qg, rg, mism) == FT_DP;
+	}
+	__device__ i32 value(i64 s, int c) const { i32 qp, qg, rg; i64 rp; if (!gap(s, qp, rp, qg, rg)) return 0; return c == 0 ? 1 : qg + rg; }
+	__device__ void emit(i64 s, const i32 *v, const i32 *ex) const
+	{
+		e_id[s] = v[0] ? ex[0] : -1;
+		if (!v[0]) return;
+		i32 qp, qg, rg; i64 rp; gap(s, qp, rp, qg, rg);
+		const i32 e = ex[0];
+		e_list[3 * e] = e; e_list[3 * e + 1] = rg; e_list[3 * e + 2] = qg;
+		off1[e] = rp; off2[e] = qp; opsoff[e] = ex[1];
+	}
+	__device__ void done(const i32 *t) const { mail[M_NEARLY] = t[0]; mail[M_EOPS] = t[1]; }
+};
+#define EARLY_CHUNK 4096      // large gaps copied with the first look (more -> a second copy)
+
+// host side of F: called from stage 3 once its passes are enqueued (the list has arrived long before)
+int launch_early_dp(gsa_ctx *c)
+{
+	if (!c->early_listed) return GSA_OK;      // (nothing listed, or already launched)
+	c->early_listed = false;
+	GSA_CHECK(c, hipEventSynchronize(c->ev[16]));
+	const i32 *h = c->p_early.as<i32>();
+	const i32 ne = h[0]; const i64 eops = h[1];
+	if (ne <= 0) return GSA_OK;
+	const size_t first_e = (size_t)std::min<i64>(c->n_a, EARLY_CHUNK);
+	hipStream_t sa = c->stream_aux[0];
+	if ((size_t)ne > first_e) {
+		if (!pin_ensure<i32>(c, c->p_early, 4 + 3 * (size_t)ne)) return GSA_ERR_NOMEM;
+		h = c->p_early.as<i32>();
+		GSA_CHECK(c, hipMemcpyAsync(c->p_early.as<i32>() + 4, c->e_list.p, (size_t)ne * 12, hipMemcpyDeviceToHost, sa));
+		GSA_CHECK(c, hipStreamSynchronize(sa));
+	}
+	c->h_early.assign(h + 4, h + 4 + 3 * (size_t)ne);
+	std::vector<LgJob> large((const LgJob *)(h + 4), (const LgJob *)(h + 4) + ne);
+	if (!dev_ensure<uint8_t>(c, c->e_ops, (size_t)eops + 64) || !dev_ensure<uint8_t>(c, c->e_rev, (size_t)eops + 64) || !dev_ensure<i32>(c, c->e_nops, (size_t)ne + 1) || !dev_ensure<i32>(c, c->e_rec, (size_t)ne + 1)) return GSA_ERR_NOMEM;
+	// stream_aux[0] already waits for the list (ev[16] was recorded behind it on the main stream)
+	GSA_CHECK(c, hipStreamWaitEvent(sa, c->ev[16], 0));
+	int rc = launch_stripes(c, sa, large, c->di.ref, c->e_off1.as<i64>(), c->d_query.as<uint8_t>(), c->e_off2.as<i64>(),
+	                        c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->e_nops.as<i32>(), c->e_rev.as<uint8_t>(), M_DPERR3);
+	if (rc) return rc;
+	GSA_CHECK(c, hipEventRecord(c->ev[14], sa));
+	c->n_early = ne; c->early_in_flight = true;
+	return GSA_OK;
+}
+
 #define LAUNCH(k, n, ...) hipLaunchKernelGGL(k, dim3(grid_for((size_t)(n), TPB)), dim3(TPB), 0, st, __VA_ARGS__)
 #define ENS(T, buf, n) do { if (!dev_ensure<T>(c, c->buf, (size_t)(n))) return GSA_ERR_NOMEM; } while (0)
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
@@ -406,6 +472,7 @@ int stage2_chain(gsa_ctx *c)
 {
 	hipStream_t st = c->stream;
 	c->n_blocks2 = 0; c->n_c = 0; c->n_b = 0; c->n_a = 0; c->blocks.clear(); c->s2_host = true;
+	c->n_early = 0; c->early_listed = false;
 	c->h_blk_beg.clear(); c->h_blk_end.clear(); c->h_blk_score.clear();
 	const i64 n = c->n_seeds;
 	if (n == 0) return GSA_OK;
@@ -468,6 +535,15 @@ int stage2_chain(gsa_ctx *c)
 	                       c->blk_beg.as<i32>(), c->blk_end.as<i32>(), c->blk_score.as<i32>(), mail }; RC((lb_launch<1>(c, na, op))); }
 	LAUNCH(k_seed_block_id, na, mail + M_NC, bhead, bheadEx, bkeep, bkeepEx, c->c_bid.as<i32>());
 	if (c->profiling) { hipEventRecord(c->ev[5], st); c->ev_pending |= 2; }
+	// F. list the large DP gaps; the list travels to the host while stage 3 is being enqueued
+	ENS(i32, e_id, na + 2); ENS(i32, e_list, 3 * (na + 1)); ENS(i64, e_off1, na + 1); ENS(i64, e_off2, na + 1); ENS(i64, e_opsoff, na + 2);
+	{ OpEarlyGaps op = { c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_bid.as<i32>(), c->d_query.as<uint8_t>(), c->di.ref,
+	                     c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail }; RC((lb_launch<2>(c, na, op))); }
+	if (!pin_ensure<i32>(c, c->p_early, 4 + 3 * (size_t)EARLY_CHUNK)) return GSA_ERR_NOMEM;
+	GSA_CHECK(c, hipMemcpyAsync(c->p_early.p, mail + M_NEARLY, 2 * sizeof(i32), hipMemcpyDeviceToHost, st));      // M_NEARLY, M_EOPS
+	GSA_CHECK(c, hipMemcpyAsync(c->p_early.as<i32>() + 4, c->e_list.p, (size_t)std::min<i64>(na, EARLY_CHUNK) * 12, hipMemcpyDeviceToHost, st));
+	GSA_CHECK(c, hipEventRecord(c->ev[16], st));
+	c->early_listed = true;
 	return GSA_OK;      // counts stay in the mailbox; stage 3 reads them with its own first read-back
 }
 

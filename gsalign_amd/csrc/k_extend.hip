@@ -29,7 +29,7 @@ __device__ __forceinline__ i32 find_block(const i32 *__restrict__ base, i32 nfb,
 // per seed slot: the seed record and, if a gap follows (IdentifyNormalPairs :241-265), the gap record,
 // classified (GenerateFragAlignment :311-342)
 struct OpSlots {
-	i32 nfb; const i32 *seedbase, *sbeg, *q, *len; const i64 *r; const uint8_t *query, *ref; const i32 *e_id;
+	i32 nfb; const i32 *seedbase, *sbeg, *q, *len; const i64 *r; const uint8_t *query, *ref; const i32 *e_id, *r_orig, *e_list; const i64 *e_off1, *e_off2;
 	gsa_frag *frag; i32 *ftype, *fmism, *fragbase, *fearly, *e_rec, *mail;
 	__device__ void slot(i64 i, i32 &k, i32 &s, i32 &n) const
 	{
@@ -55,7 +55,9 @@ struct OpSlots {
 			gsa_frag g; g.bseed = 0; g.qpos = q[s] + len[s]; g.rpos = r[s] + len[s]; g.qlen = qg; g.rlen = rg; g.aln_off = 0; g.aln_len = 0; g._pad = 0;
 			i32 mism; const i32 t = classify_gap(query, ref, g.qpos, g.rpos, qg, rg, mism);
 			frag[p + 1] = g; ftype[p + 1] = t; fmism[p + 1] = mism;
-			const i32 e = e_id[s];                            // a large DP gap launched from the leaf table: link job and record
+			// a large DP gap stage 2 launched early: the result counts only if this is exactly the gap it listed
+			i32 e = e_id[r_orig[s]];
+			if (e >= 0 && !(t == FT_DP && e_off2[e] == g.qpos && e_off1[e] == g.rpos && e_list[3 * e + 1] == rg && e_list[3 * e + 2] == qg)) e = -1;
 			fearly[p + 1] = e; if (e >= 0) e_rec[e] = p + 1;
 		}
 	}
@@ -290,7 +292,7 @@ int stage7_fill(gsa_ctx *c)
 	ENS(gsa_frag, f_rec, nfu + 1); ENS(i32, f_type, nfu + 1); ENS(i32, f_mism, nfu + 1); ENS(i32, f_score, nfu + 1); ENS(i32, f_job, nfu + 1); ENS(i32, f_alnlen, nfu + 1);
 	ENS(i32, f_early, nfu + 2);
 	if (c->n_early > 0) GSA_CHECK(c, hipMemsetAsync(c->e_rec.p, 0xff, (size_t)c->n_early * 4, st));      // -1: no record (yet)
-	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), c->fb_sbeg.as<i32>(), c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref, c->e_id.as<i32>(),
+	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), c->fb_sbeg.as<i32>(), c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref, c->e_id.as<i32>(), c->r_orig.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(),
 	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), c->fb_fragbase.as<i32>(), c->f_early.as<i32>(), c->e_rec.as<i32>(), c->d_mail.as<i32>() };
 	RC((lb_launch<1>(c, ns, op)));
 	c->n_frags = -1;
@@ -363,6 +365,7 @@ int stage78_extend(gsa_ctx *c)
 			                   c->f_rec.as<gsa_frag>(), c->d_aln1.as<uint8_t>(), c->d_aln2.as<uint8_t>(), c->d_patch.as<i32>());
 		if (c->n_early > 0) {
 			GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[14], 0));      // the early striped launch (stream_aux[0])
+			c->early_consumed = true;
 			hipLaunchKernelGGL(k_materialize_large, dim3((unsigned)c->n_early), dim3(256), 0, st, c->n_early, (const i32 *)nullptr, c->e_rec.as<i32>(), c->e_nops.as<i32>(),
 			                   c->d_alnoff.as<i64>(), c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
 			                   c->f_rec.as<gsa_frag>(), c->d_aln1.as<uint8_t>(), c->d_aln2.as<uint8_t>(), c->d_patch.as<i32>() + 3 * (size_t)kl.nlarge);

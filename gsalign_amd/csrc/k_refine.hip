@@ -26,13 +26,13 @@
 //  host-known upper bound of every count, is the seed count -- the live counts sit in the mailbox)
 struct OpTakeInBlock {      // seeds that belong to a kept S2 block
 	const i32 *c_q, *c_len; const i64 *c_r; const i32 *c_bid;
-	i32 *r_q, *r_len; i64 *r_r; i32 *r_bid, *mail;
+	i32 *r_q, *r_len; i64 *r_r; i32 *r_bid, *r_orig, *mail;      // r_orig: index in the stage-2 seed arrays (links stage-2's early DP launches to the final gaps)
 	__device__ i32 value(i64 i, int) const { return (i < mail[M_NC] && c_bid[i] >= 0) ? 1 : 0; }
 	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
 	{
 		if (!v[0]) return;
 		const i32 p = ex[0];
-		r_q[p] = c_q[i]; r_len[p] = c_len[i]; r_r[p] = c_r[i]; r_bid[p] = c_bid[i];
+		r_q[p] = c_q[i]; r_len[p] = c_len[i]; r_r[p] = c_r[i]; r_bid[p] = c_bid[i]; r_orig[p] = (i32)i;
 	}
 	__device__ void done(const i32 *t) const { mail[M_NR] = t[0]; }
 };
@@ -40,8 +40,8 @@ struct OpTakeInBlock {      // seeds that belong to a kept S2 block
 // one RemoveOverlaps pass (ProcessCandidateAlignment.cpp:197-226) + its compaction; the seed count
 // is read from mail[nin] and written to mail[nout] (two slots: other tiles still read the old one)
 struct OpOverlapPass {
-	const i32 *q, *len; const i64 *r; const i32 *bid;
-	i32 *oq, *olen; i64 *orr; i32 *obid, *mail; int nin, nout, anyslot;
+	const i32 *q, *len; const i64 *r; const i32 *bid, *orig;
+	i32 *oq, *olen; i64 *orr; i32 *obid, *oorig, *mail; int nin, nout, anyslot;
 	__device__ i32 trim(i64 i, i32 &l) const
 	{
 		const i64 n = mail[nin];
@@ -62,7 +62,7 @@ struct OpOverlapPass {
 		if (!v[0]) { mail[anyslot] = 1; return; }
 		i32 l; trim(i, l);
 		const i32 p = ex[0];
-		oq[p] = q[i]; olen[p] = l; orr[p] = r[i]; obid[p] = bid[i];
+		oq[p] = q[i]; olen[p] = l; orr[p] = r[i]; obid[p] = bid[i]; oorig[p] = orig[i];
 	}
 	__device__ void done(const i32 *t) const { mail[nout] = t[0]; }
 };
@@ -134,36 +134,6 @@ struct OpChrCuts {
 	__device__ void done(const i32 *t) const { mail[M_NL] = t[0]; ps[ub] = (u32)t[1]; head[ub] = 1; }
 };
 
-// The large DP gaps (the ones that need the striped kernel, the contig's latency floor) are final as soon as
-// the leaves are: a gap between two seeds of one leaf.  They are listed here and launched at once, two
-// stages before their records exist; stage 6 links record and job through e_id[] (per seed: early job or -1).
-// Gaps of leaves the host list logic drops later are computed in vain.
-struct OpEarlyLarge {
-	const i32 *d_n; const i32 *q, *len; const i64 *r; const i32 *head; const uint8_t *query, *ref;
-	i32 *e_id, *e_list; i64 *off1, *off2, *opsoff; i32 *mail;
-	__device__ bool gap(i64 s, i32 &qp, i64 &rp, i32 &qg, i32 &rg) const
-	{
-		if (s + 1 >= *d_n || head[s + 1]) return false;
-		qp = q[s] + len[s]; rp = r[s] + len[s];
-		qg = q[s + 1] - qp; if (qg < 0) qg = 0;
-		const i64 rg64 = r[s + 1] - rp; rg = rg64 < 0 ? 0 : (i32)rg64;
-		if (!dp_is_large(rg, qg)) return false;                   // (cheap test first: the mismatch count is a serial loop)
-		i32 mism;
-		return classify_gap(query, ref, qp, rp, qg, rg, mism) == FT_DP;
-	}
-	__device__ i32 value(i64 s, int c) const { i32 qp, qg, rg; i64 rp; if (!gap(s, qp, rp, qg, rg)) return 0; return c == 0 ? 1 : qg + rg; }
-	__device__ void emit(i64 s, const i32 *v, const i32 *ex) const
-	{
-		e_id[s] = v[0] ? ex[0] : -1;
-		if (!v[0]) return;
-		i32 qp, qg, rg; i64 rp; gap(s, qp, rp, qg, rg);
-		const i32 e = ex[0];
-		e_list[3 * e] = e; e_list[3 * e + 1] = rg; e_list[3 * e + 2] = qg;
-		off1[e] = rp; off2[e] = qp; opsoff[e] = ex[1];
-	}
-	__device__ void done(const i32 *t) const { mail[M_NEARLY] = t[0]; mail[M_NJ] = t[1]; }      // (M_NJ is free again: total op-string room)
-};
-
 __global__ void k_leaf_emit(i64 ub, const i32 *__restrict__ d_n, const i32 *__restrict__ mail, const i32 *__restrict__ lstart, const i32 *__restrict__ q,
                             const i32 *__restrict__ len, const i64 *__restrict__ r, const i32 *__restrict__ bid, const i32 *__restrict__ cut4,
                             const i32 *__restrict__ cut5, const u32 *__restrict__ ps, const i32 *__restrict__ blk_score, Leaf *leaf)
@@ -194,25 +164,25 @@ int stage345_refine(gsa_ctx *c)
 	ENS(i32, a_uniq, ub + 1); ENS(i32, a_cu, ub + 1); ENS(i64, w_best, ub + 1); ENS(i64, w_sum, ub + 1); ENS(i32, a_brk, ub + 1);
 	i32 *cut4 = c->r_cut4.as<i32>(), *cut5 = c->r_cut5.as<i32>();
 	i32 *jq1 = c->a_uniq.as<i32>(), *jq2 = c->a_cu.as<i32>(), *jseed = c->a_brk.as<i32>(); i64 *jr1 = c->w_best.as<i64>(), *jr2 = c->w_sum.as<i64>();
+	ENS(i32, r_orig, ub + 1); ENS(i32, r_tmp_orig, ub + 1);
 	{ OpTakeInBlock op = { c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_bid.as<i32>(),
-	                       c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), mail }; RC((lb_launch<1>(c, ub, op))); }
+	                       c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), c->r_orig.as<i32>(), mail }; RC((lb_launch<1>(c, ub, op))); }
 	// S3: passes until nothing dies.  A pass that kills nothing is the identity, so two passes are issued
 	// and then EVERYTHING behind them -- S4 gap scan + similarity jobs, S5 cuts, leaf table, the list of
 	// large DP gaps -- with the live seed count read on the device; the host looks once, at the end, and
 	// only if the second pass still killed something the tail is redone after two more passes.
 	ENS(i32, a_next, ub + 1); ENS(u32, d_flag, ub + 2); ENS(i32, r_head, ub + 2); ENS(Leaf, d_leaf, ub + 1);
-	ENS(i32, e_id, ub + 2); ENS(i32, e_list, 3 * (ub + 1)); ENS(i64, e_off1, ub + 1); ENS(i64, e_off2, ub + 1); ENS(i64, e_opsoff, ub + 2); ENS(i32, e_nops, ub + 1); ENS(i32, e_rec, ub + 1);
 	i32 *lstart = c->a_next.as<i32>(); u32 *ps = c->d_flag.as<u32>();
-	if (!pin_ensure<Leaf>(c, c->p_leaf, (size_t)LEAF_CHUNK) || !pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * EARLY_CHUNK)) return GSA_ERR_NOMEM;
-	const size_t first = (size_t)std::min<i64>(ub, LEAF_CHUNK), first_e = (size_t)std::min<i64>(ub, EARLY_CHUNK);
+	if (!pin_ensure<Leaf>(c, c->p_leaf, (size_t)LEAF_CHUNK)) return GSA_ERR_NOMEM;
+	const size_t first = (size_t)std::min<i64>(ub, LEAF_CHUNK);
 	GSA_CHECK(c, hipMemsetAsync(mail + M_ANY, 0, 32 * sizeof(i32), st));
 	int round = 0, cur = M_NR, oth = M_NR2;
 	for (;;) {
 		for (int k = 0; k < 2; k++, round++) {
-			OpOverlapPass op = { c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(),
-			                     c->r_tmp_q.as<i32>(), c->r_tmp_len.as<i32>(), c->r_tmp_r.as<i64>(), c->r_tmp_bid.as<i32>(), mail, cur, oth, M_ANY + (round & 31) };
+			OpOverlapPass op = { c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), c->r_orig.as<i32>(),
+			                     c->r_tmp_q.as<i32>(), c->r_tmp_len.as<i32>(), c->r_tmp_r.as<i64>(), c->r_tmp_bid.as<i32>(), c->r_tmp_orig.as<i32>(), mail, cur, oth, M_ANY + (round & 31) };
 			RC((lb_launch<1>(c, ub, op)));
-			std::swap(c->r_q, c->r_tmp_q); std::swap(c->r_len, c->r_tmp_len); std::swap(c->r_r, c->r_tmp_r); std::swap(c->r_bid, c->r_tmp_bid);
+			std::swap(c->r_q, c->r_tmp_q); std::swap(c->r_len, c->r_tmp_len); std::swap(c->r_r, c->r_tmp_r); std::swap(c->r_bid, c->r_tmp_bid); std::swap(c->r_orig, c->r_tmp_orig);
 			std::swap(cur, oth);
 		}
 		// S4 cuts + similarity jobs
@@ -223,13 +193,12 @@ int stage345_refine(gsa_ctx *c)
 		{ OpChrCuts op = { ub, mail + cur, c->di, c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, c->r_len.as<i32>(), cut5, lstart, c->r_head.as<i32>(), ps, mail }; RC((lb_launch<2>(c, ub, op))); }
 		LAUNCH(k_leaf_emit, ub, ub, mail + cur, mail, lstart, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, cut5, ps,
 		       c->blk_score.as<i32>(), c->d_leaf.as<Leaf>());
-		{ OpEarlyLarge op = { mail + cur, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_head.as<i32>(), c->d_query.as<uint8_t>(), c->di.ref,
-		                      c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail }; RC((lb_launch<2>(c, ub, op))); }
-		// the mailbox, the first LEAF_CHUNK leaves and the first EARLY_CHUNK large gaps come back together
+		// the mailbox and the first LEAF_CHUNK leaves come back together
 		GSA_CHECK(c, hipMemcpyAsync(c->h_mail, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipMemcpyAsync(c->p_leaf.p, c->d_leaf.p, first * sizeof(Leaf), hipMemcpyDeviceToHost, st));
-		GSA_CHECK(c, hipMemcpyAsync(c->p_dp.as<i32>() + MAIL_N, c->e_list.p, first_e * 12, hipMemcpyDeviceToHost, st));
 		if (c->profiling) hipEventRecord(c->ev[7], st);
+		// everything of S3-S5 is enqueued: now start the striped DP for the large gaps stage 2 listed (its own stream)
+		RC(launch_early_dp(c));
 		GSA_CHECK(c, hipStreamSynchronize(st));
 		if (c->h_mail[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 		if (!c->h_mail[M_ANY + ((round - 1) & 31)]) break;
@@ -239,30 +208,10 @@ int stage345_refine(gsa_ctx *c)
 	collect_events(c);
 	c->n_b = c->h_mail[M_NB]; c->n_c = c->h_mail[M_NC]; c->n_blocks2 = c->h_mail[M_NBLK];
 	const i64 nr = c->h_mail[cur];
-	c->n_r = nr; c->n_early = 0; c->early_in_flight = false;
+	c->n_r = nr;
 	if (c->n_blocks2 == 0 || nr == 0) { c->n_r = 0; return GSA_OK; }
 	if (c->h_mail[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
-	const i32 nl = c->h_mail[M_NL], ne = c->h_mail[M_NEARLY];
-	c->n_early = ne; c->early_in_flight = false;
-	if (ne > 0) {
-		if ((size_t)ne > first_e) {
-			if (!pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * (size_t)ne)) return GSA_ERR_NOMEM;
-			GSA_CHECK(c, hipMemcpyAsync(c->p_dp.as<i32>() + MAIL_N, c->e_list.p, (size_t)ne * 12, hipMemcpyDeviceToHost, st));
-			GSA_CHECK(c, hipStreamSynchronize(st));
-		}
-		const i32 *el = c->p_dp.as<i32>() + MAIL_N;
-		c->h_early.assign(el, el + 3 * (size_t)ne);
-		std::vector<LgJob> large((const LgJob *)el, (const LgJob *)el + ne);
-		const i64 eops = c->h_mail[M_NJ];
-		ENS(uint8_t, e_ops, eops + 64); ENS(uint8_t, e_rev, eops + 64);
-		// fork: the striped kernel runs on stream_aux[0] under everything up to the gapped strings of stage 7
-		GSA_CHECK(c, hipEventRecord(c->ev[11], st));
-		GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[0], c->ev[11], 0));
-		RC(launch_stripes(c, c->stream_aux[0], large, c->di.ref, c->e_off1.as<i64>(), c->d_query.as<uint8_t>(), c->e_off2.as<i64>(),
-		                  c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->e_nops.as<i32>(), c->e_rev.as<uint8_t>(), M_DPERR3));
-		GSA_CHECK(c, hipEventRecord(c->ev[14], c->stream_aux[0]));
-		c->early_in_flight = true;
-	}
+	const i32 nl = c->h_mail[M_NL];
 	if ((size_t)nl > first) {
 		if (!pin_ensure<Leaf>(c, c->p_leaf, (size_t)nl)) return GSA_ERR_NOMEM;
 		GSA_CHECK(c, hipMemcpyAsync(c->p_leaf.p, c->d_leaf.p, (size_t)nl * sizeof(Leaf), hipMemcpyDeviceToHost, st));
