@@ -564,8 +564,12 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 			hipLaunchKernelGGL(k_dp_tiny, dim3(nb), dim3(64 * TINY_WAVES), 0, c->stream_aux[1], ntiny, d_order_tiny, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag);
 		}
 		if (nsmall > 0) {
+			// (the two size classes side by side: the one-per-wavefront kernel on stream_aux[2], joined below)
+			hipStream_t s2 = ntiny > 0 ? c->stream_aux[2] : c->stream_aux[1];
+			if (ntiny > 0) GSA_CHECK(c, hipStreamWaitEvent(s2, ev_fork, 0));
 			const unsigned nb = (unsigned)((nsmall + SMALL_WAVES - 1) / SMALL_WAVES);
-			hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, c->stream_aux[1], nsmall, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag);
+			hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, s2, nsmall, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag);
+			if (ntiny > 0) { GSA_CHECK(c, hipEventRecord(c->ev[18], s2)); GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], c->ev[18], 0)); }
 		}
 		GSA_CHECK(c, hipGetLastError());
 		GSA_CHECK(c, hipEventRecord(ev_j2, c->stream_aux[1]));

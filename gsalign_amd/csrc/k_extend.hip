@@ -345,6 +345,7 @@ int stage78_extend(gsa_ctx *c)
 	hipLaunchKernelGGL(k_materialize, dim3((unsigned)((nfu + 255) / 256)), dim3(256), 0, sx, mail + M_NF, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(),
 	                   jlarge, c->j_nops.as<i32>(), c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
 	                   c->f_rec.as<gsa_frag>(), c->d_aln1.as<uint8_t>(), c->d_aln2.as<uint8_t>(), c_len, c_score);
+	GSA_CHECK(c, hipEventRecord(c->ev[17], sx));      // the strings of everything but the large jobs are written
 	// per-block sums via prefix sums (the large jobs' records count as zero here, the host adds them from the patch list)
 	u32 *ps_score = c->d_flag2.as<u32>();      // (the small kernel's order array is free again)
 	{ OpRecSums op = { nfu, c_len, c_score, c->d_scan.as<u32>(), ps_score, mail }; RC((lb_launch<2>(c, nfu, op, sx))); }
@@ -372,12 +373,13 @@ int stage78_extend(gsa_ctx *c)
 		}
 		GSA_CHECK(c, hipMemcpyAsync(c->p_patch.p, c->d_patch.p, 3 * npatch * 4, hipMemcpyDeviceToHost, st));
 	}
-	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[13], 0));      // the other strings are written
-	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[15], 0));      // the records are on the host
+	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[17], 0));      // the other strings are written
 	if (c->n_aln) {
 		GSA_CHECK(c, hipMemcpyAsync(c->p_aln1.p, c->d_aln1.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipMemcpyAsync(c->p_aln2.p, c->d_aln2.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, st));
 	}
+	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[13], 0));      // per-block sums are on the host
+	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[15], 0));      // the records are on the host
 	GSA_CHECK(c, hipMemcpyAsync(c->p_blk.as<i32>() + 3 * (nfb + 1), mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
 	if (c->profiling) hipEventRecord(c->ev[9], st);
 	GSA_CHECK(c, hipGetLastError());
