@@ -14,18 +14,16 @@ __device__ __forceinline__ i32 classify_gap(const uint8_t *__restrict__ query, c
 	if (qg == 0) return FT_DEL;
 	if (rg == 0) return FT_INS;
 	if (qg == rg) {
-		// CheckFragPairMismatch: positions where the QUERY is ambiguous are skipped.  Eight bases per pair of
-		// loads (both buffers are padded): the count only matters while it stays <= GSA_MAX_MISMATCH.
+		// CheckFragPairMismatch: positions where the QUERY is ambiguous are skipped.  32 positions per round,
+		// all 64 loads in flight before the first compare (one thread does this inside a fused pass, so the
+		// longest gap's load latency is the pass's duration); the count only matters while <= GSA_MAX_MISMATCH.
 		const uint8_t *qs = query + qpos, *rs = ref + rpos;
-		for (i32 x = 0; x < qg && mism <= GSA_MAX_MISMATCH; x += 8) {
-			unsigned long long wq, wr;
-			__builtin_memcpy(&wq, qs + x, 8); __builtin_memcpy(&wr, rs + x, 8);
-			const i32 lim = qg - x < 8 ? qg - x : 8;
+		for (i32 x = 0; x < qg && mism <= GSA_MAX_MISMATCH; x += 32) {
+			uint8_t bq[32], br[32];
 #pragma unroll
-			for (int b = 0; b < 8; b++) {
-				const int a = gsa_nt4((uint8_t)(wq >> (8 * b))), r = gsa_nt4((uint8_t)(wr >> (8 * b)));
-				if (b < lim && a != 4 && a != r) mism++;
-			}
+			for (int b = 0; b < 32; b++) { const i32 p = x + b < qg ? x + b : qg - 1; bq[b] = qs[p]; br[b] = rs[p]; }
+#pragma unroll
+			for (int b = 0; b < 32; b++) { const int a = gsa_nt4(bq[b]); if (x + b < qg && a != 4 && a != gsa_nt4(br[b])) mism++; }
 		}
 		if (mism <= GSA_MAX_MISMATCH) return FT_EQ;
 	}

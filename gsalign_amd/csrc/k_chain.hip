@@ -420,12 +420,21 @@ struct OpEarlyGaps {
 		i32 mism;
 		return classify_gap(query, ref, qp, rp, qg, rg, mism) == FT_DP;
 	}
-	__device__ i32 value(i64 s, int c) const { i32 qp, qg, rg; i64 rp; if (!gap(s, qp, rp, qg, rg)) return 0; return c == 0 ? 1 : qg + rg; }
+	// (component 0 is asked first and leaves its verdict in e_id[s], so the mismatch loop of a gap runs once)
+	__device__ i32 value(i64 s, int c) const
+	{
+		if (c == 1) { if (!e_id[s]) return 0; const i32 qp = q[s] + len[s]; const i64 rp = r[s] + len[s]; return (q[s + 1] - qp) + (i32)(r[s + 1] - rp); }
+		i32 qp, qg, rg; i64 rp;
+		const bool g = gap(s, qp, rp, qg, rg);
+		e_id[s] = g ? 1 : 0;
+		return g ? 1 : 0;
+	}
 	__device__ void emit(i64 s, const i32 *v, const i32 *ex) const
 	{
 		e_id[s] = v[0] ? ex[0] : -1;
 		if (!v[0]) return;
-		i32 qp, qg, rg; i64 rp; gap(s, qp, rp, qg, rg);
+		const i32 qp = q[s] + len[s]; const i64 rp = r[s] + len[s];
+		const i32 qg = q[s + 1] - qp, rg = (i32)(r[s + 1] - rp);
 		const i32 e = ex[0];
 		e_list[3 * e] = e; e_list[3 * e + 1] = rg; e_list[3 * e + 2] = qg;
 		off1[e] = rp; off2[e] = qp; opsoff[e] = ex[1];
