@@ -18,12 +18,21 @@ __device__ __forceinline__ i32 classify_gap(const uint8_t *__restrict__ query, c
 		// all 64 loads in flight before the first compare (one thread does this inside a fused pass, so the
 		// longest gap's load latency is the pass's duration); the count only matters while <= GSA_MAX_MISMATCH.
 		const uint8_t *qs = query + qpos, *rs = ref + rpos;
-		for (i32 x = 0; x < qg && mism <= GSA_MAX_MISMATCH; x += 32) {
-			uint8_t bq[32], br[32];
+		if (qg <= 8) {
+			// the usual case, a SNP or two: a handful of loads, not a 32-wide round
+			uint8_t bq[8], br[8];
 #pragma unroll
-			for (int b = 0; b < 32; b++) { const i32 p = x + b < qg ? x + b : qg - 1; bq[b] = qs[p]; br[b] = rs[p]; }
+			for (int b = 0; b < 8; b++) { if (b < qg) { bq[b] = qs[b]; br[b] = rs[b]; } else { bq[b] = 'N'; br[b] = 'N'; } }
 #pragma unroll
-			for (int b = 0; b < 32; b++) { const int a = gsa_nt4(bq[b]); if (x + b < qg && a != 4 && a != gsa_nt4(br[b])) mism++; }
+			for (int b = 0; b < 8; b++) { const int a = gsa_nt4(bq[b]); if (b < qg && a != 4 && a != gsa_nt4(br[b])) mism++; }
+		} else {
+			for (i32 x = 0; x < qg && mism <= GSA_MAX_MISMATCH; x += 32) {
+				uint8_t bq[32], br[32];
+#pragma unroll
+				for (int b = 0; b < 32; b++) { const i32 p = x + b < qg ? x + b : qg - 1; bq[b] = qs[p]; br[b] = rs[p]; }
+#pragma unroll
+				for (int b = 0; b < 32; b++) { const int a = gsa_nt4(bq[b]); if (x + b < qg && a != 4 && a != gsa_nt4(br[b])) mism++; }
+			}
 		}
 		if (mism <= GSA_MAX_MISMATCH) return FT_EQ;
 	}
