@@ -29,8 +29,8 @@ __device__ __forceinline__ i32 find_block(const i32 *__restrict__ base, i32 nfb,
 // per seed slot: the seed record and, if a gap follows (IdentifyNormalPairs :241-265), the gap record,
 // classified (GenerateFragAlignment :311-342)
 struct OpSlots {
-	i32 nfb; const i32 *seedbase, *sbeg, *q, *len; const i64 *r; const uint8_t *query, *ref; const i32 *e_id, *r_orig, *e_list; const i64 *e_off1, *e_off2;
-	gsa_frag *frag; i32 *ftype, *fmism, *fragbase, *fearly, *e_rec, *mail;
+	i32 nfb; const i32 *seedbase, *sbeg, *q, *len; const i64 *r; const i32 *e_id, *r_orig;
+	gsa_frag *frag; i32 *ftype, *fmism, *fragbase, *fearly, *mail;
 	__device__ void slot(i64 i, i32 &k, i32 &s, i32 &n) const
 	{
 		k = find_block(seedbase, nfb, i);
@@ -53,16 +53,30 @@ struct OpSlots {
 			i32 qg = q[s + 1] - (q[s] + len[s]); if (qg < 0) qg = 0;
 			i64 rg64 = r[s + 1] - (r[s] + len[s]); i32 rg = rg64 < 0 ? 0 : (i32)rg64;
 			gsa_frag g; g.bseed = 0; g.qpos = q[s] + len[s]; g.rpos = r[s] + len[s]; g.qlen = qg; g.rlen = rg; g.aln_off = 0; g.aln_len = 0; g._pad = 0;
-			i32 mism; const i32 t = classify_gap(query, ref, g.qpos, g.rpos, qg, rg, mism);
-			frag[p + 1] = g; ftype[p + 1] = t; fmism[p + 1] = mism;
-			// a large DP gap stage 2 launched early: the result counts only if this is exactly the gap it listed
-			i32 e = e_id[r_orig[s]];
-			if (e >= 0 && !(t == FT_DP && e_off2[e] == g.qpos && e_off1[e] == g.rpos && e_list[3 * e + 1] == rg && e_list[3 * e + 2] == qg)) e = -1;
-			fearly[p + 1] = e; if (e >= 0) e_rec[e] = p + 1;
+			// (class, mismatch count and the link to an early DP launch: k_gap_class, one thread per record)
+			frag[p + 1] = g; ftype[p + 1] = FT_DP; fmism[p + 1] = 0;
+			fearly[p + 1] = e_id[r_orig[s]];
 		}
 	}
 	__device__ void done(const i32 *t) const { mail[M_NF] = t[0]; }
 };
+
+// class of every gap record (GenerateFragAlignment :311-342) -- a kernel of its own, one thread per record: the
+// mismatch count of an equal-length gap is a serial loop over its bases, too heavy for a thread of a fused pass
+// -- and the link to a large DP gap stage 2 launched early: the result counts only if this is exactly the gap
+// it listed.
+__global__ void k_gap_class(i64 ub, const i32 *__restrict__ mail, const gsa_frag *__restrict__ frag, const uint8_t *__restrict__ query, const uint8_t *__restrict__ ref,
+                            const i32 *__restrict__ e_list, const i64 *__restrict__ e_off1, const i64 *__restrict__ e_off2, i32 *ftype, i32 *fmism, i32 *fearly, i32 *e_rec)
+{
+	GID(ub);
+	if (i >= mail[M_NF] || ftype[i] == FT_SEED) return;
+	const gsa_frag g = frag[i];
+	i32 mism; const i32 t = classify_gap(query, ref, g.qpos, g.rpos, g.qlen, g.rlen, mism);
+	ftype[i] = t; fmism[i] = mism;
+	i32 e = fearly[i];
+	if (e >= 0 && !(t == FT_DP && e_off2[e] == g.qpos && e_off1[e] == g.rpos && e_list[3 * e + 1] == g.rlen && e_list[3 * e + 2] == g.qlen)) e = -1;
+	fearly[i] = e; if (e >= 0) e_rec[e] = (i32)i;
+}
 
 // DP job list and string offsets in one pass.  Component 0 counts the DP jobs.  Component 1 gives every
 // gap the room it can need AT MOST (a DP gap m+n, the others their exact length): the offsets of the
@@ -292,9 +306,11 @@ int stage7_fill(gsa_ctx *c)
 	ENS(gsa_frag, f_rec, nfu + 1); ENS(i32, f_type, nfu + 1); ENS(i32, f_mism, nfu + 1); ENS(i32, f_score, nfu + 1); ENS(i32, f_job, nfu + 1); ENS(i32, f_alnlen, nfu + 1);
 	ENS(i32, f_early, nfu + 2);
 	if (c->n_early > 0) GSA_CHECK(c, hipMemsetAsync(c->e_rec.p, 0xff, (size_t)c->n_early * 4, st));      // -1: no record (yet)
-	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), c->fb_sbeg.as<i32>(), c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref, c->e_id.as<i32>(), c->r_orig.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(),
-	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), c->fb_fragbase.as<i32>(), c->f_early.as<i32>(), c->e_rec.as<i32>(), c->d_mail.as<i32>() };
+	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), c->fb_sbeg.as<i32>(), c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->e_id.as<i32>(), c->r_orig.as<i32>(),
+	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), c->fb_fragbase.as<i32>(), c->f_early.as<i32>(), c->d_mail.as<i32>() };
 	RC((lb_launch<1>(c, ns, op)));
+	LAUNCH(k_gap_class, nfu, nfu, c->d_mail.as<i32>(), c->f_rec.as<gsa_frag>(), c->d_query.as<uint8_t>(), c->di.ref, c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(),
+	       c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_early.as<i32>(), c->e_rec.as<i32>());
 	c->n_frags = -1;
 	return GSA_OK;
 }
