@@ -127,12 +127,12 @@ void gsa_destroy(gsa_ctx *c)
 		&c->b_q, &c->b_len, &c->b_r, &c->b_gb, &c->b_ge, &c->c_q, &c->c_len, &c->c_r, &c->c_gb, &c->c_ge, &c->c_bid, &c->blk_beg, &c->blk_end, &c->blk_score,
 		&c->r_q, &c->r_len, &c->r_r, &c->r_bid, &c->r_tmp_q, &c->r_tmp_len, &c->r_tmp_r, &c->r_tmp_bid, &c->r_cut4, &c->r_cut5, &c->r_simjob, &c->r_simres, &c->d_leaf,
 		&c->fb_seedbase, &c->fb_sbeg, &c->fb_fragbase, &c->f_rec, &c->f_type, &c->f_mism, &c->f_alnlen, &c->f_job, &c->f_score,
-		&c->d_dp_tiny, &c->d_dp_bnd, &c->d_dp_ctr, &c->d_dp_jobs, &c->d_dp_large, &c->d_patch,
-		&c->e_id, &c->e_rec, &c->e_list, &c->e_off1, &c->e_off2, &c->e_opsoff, &c->e_nops, &c->e_ops, &c->e_rev, &c->r_head, &c->f_early, &c->r_orig, &c->r_tmp_orig, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_aln1, &c->d_aln2, &c->d_alnoff, &c->bl_alnlen, &c->bl_score };
+		&c->d_dp_tiny, &c->d_dp_bnd, &c->d_dp_ctr, &c->d_dp_jobs, &c->d_dp_large, &c->d_tail,
+		&c->e_id, &c->e_rec, &c->e_list, &c->e_off1, &c->e_off2, &c->e_opsoff, &c->e_nops, &c->e_ops, &c->e_rev, &c->r_head, &c->f_early, &c->r_orig, &c->r_tmp_orig, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_alnoff, &c->bl_alnlen, &c->bl_score };
 	for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
 	if (c->h_mail) hipHostFree(c->h_mail);
-	for (DevBuf *b : { &c->p_frags, &c->p_aln1, &c->p_aln2, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_patch, &c->p_early }) if (b->p) hipHostFree(b->p);
+	for (DevBuf *b : { &c->p_frags, &c->p_tail, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_early }) if (b->p) hipHostFree(b->p);
 	for (int i = 0; i < 24; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 3; i++) if (c->stream_aux[i]) hipStreamDestroy(c->stream_aux[i]);
 	if (c->stream) hipStreamDestroy(c->stream);
@@ -235,7 +235,7 @@ int gsa_get_blocks(gsa_ctx *c, gsa_result *out)
 	out->n_blocks = (int32_t)c->h_blocks.size(); out->blocks = c->h_blocks.data();
 	if (c->result_pinned && c->stage == 8) {
 		out->n_frags = c->n_frags; out->n_aln = c->n_aln;
-		out->frags = c->p_frags.as<gsa_frag>(); out->aln1 = c->p_aln1.as<char>(); out->aln2 = c->p_aln2.as<char>();
+		out->frags = c->p_frags.as<gsa_frag>(); out->aln1 = c->h_taln1; out->aln2 = c->h_taln2;
 	} else {
 		out->n_frags = (int64_t)c->h_frags.size(); out->n_aln = (int64_t)c->h_aln1.size();
 		out->frags = c->h_frags.data(); out->aln1 = c->h_aln1.data(); out->aln2 = c->h_aln2.data();

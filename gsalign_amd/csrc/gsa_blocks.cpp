@@ -144,17 +144,17 @@ int host_stage8_finish(gsa_ctx *c)
 	GSA_CHECK(c, hipStreamSynchronize(c->stream));
 	if (c->profiling) { float ms; if (hipEventElapsedTime(&ms, c->ev[8], c->ev[9]) == hipSuccess) c->kernel_ms[5] = ms; (void)hipGetLastError(); }
 	i32 *bl_len = c->p_blk.as<i32>(), *bl_score = bl_len + nfb, *fragbase = bl_score + nfb;
-	const i32 *hm = c->p_blk.as<i32>() + 3 * (nfb + 1);
+	const i32 *hm = c->h_tmail;
 	if (hm[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
-	if (hm[M_DPERR2]) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
+	if (hm[M_DPERR2]) { c->dp_dirty = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
 	if (c->profiling) { const unsigned long long *cc = (const unsigned long long *)(hm + M_CELLS); c->counters[4] += cc[0]; c->counters[6] += cc[1]; }
-	if (c->n_early > 0 && hm[M_DPERR3]) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out (early launch)");
+	if (c->n_early > 0 && hm[M_DPERR3]) { c->dp_dirty = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out (early launch)"); }
 	// the large DP jobs finished after the records left: their (aln_len, score) arrive as a patch list
 	// (first the ones that only turned up in the job list, then the ones launched from the leaf table;
 	//  record -1 = an early job whose leaf the list logic dropped)
 	{
 		gsa_frag *fr = c->p_frags.as<gsa_frag>();
-		const i32 *pt = c->p_patch.as<i32>();
+		const i32 *pt = c->h_tpatch;
 		const i32 np = c->n_large + c->n_early;
 		for (i32 g = 0; g < np; g++) {
 			const i32 rec = pt[3 * g], L = pt[3 * g + 1], sc = pt[3 * g + 2];

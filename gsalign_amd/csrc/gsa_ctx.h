@@ -107,7 +107,8 @@ struct gsa_ctx {
 	// ---- stages 7-8 ----
 	i64 n_frags = 0, n_aln = 0;                    // (n_frags < 0: still in the mailbox, see frags_count())
 	i32 n_large = 0;                               // large DP jobs of the current contig (their records are patched on the host)
-	DevBuf d_patch, p_patch;                       // (record, aln_len, score) of the large jobs: device / pinned
+	DevBuf d_tail, p_tail;                         // final mailbox | patch list | string pool 1 | string pool 2: device / pinned (one copy at the end)
+	const i32 *h_tmail = nullptr, *h_tpatch = nullptr; char *h_taln1 = nullptr, *h_taln2 = nullptr;      // the parts of p_tail
 	i64 nf_ub = 0, span_ub = 0;                    // host-known upper bounds: records, and bases in gaps (ops / gapped strings)
 	DevBuf fb_seedbase, fb_sbeg, fb_fragbase;      // per final block
 	DevBuf f_rec;                                  // gsa_frag records
@@ -120,14 +121,15 @@ struct gsa_ctx {
 	bool early_consumed = false;                   // stage 7 enqueued its wait for the early launch (else gsa_run_to waits before it returns)
 	bool early_listed = false;                     // stage 2 left the list of large gaps on its way to the host (event ev[16])
 	i32 n_early = 0; bool early_in_flight = false; std::vector<i32> h_early;      // (seed, m, n) per early job
+	bool dp_dirty = true;                          // ticket counters / error words of the striped DP need clearing (fresh buffer, or a failed launch)
 	u32 dp_epoch = 0;                              // tag of the boundary granules of the current striped launch
 	DevBuf p_dp, p_sj;                             // pinned: mailbox + large-job list, stripe job descriptors
-	DevBuf d_aln1, d_aln2, d_alnoff;
+	DevBuf d_alnoff;
 	DevBuf bl_alnlen, bl_score;
 	std::vector<gsa_frag> h_frags; std::vector<gsa_block> h_blocks; std::vector<char> h_aln1, h_aln2;
 	int frags_stage = 0;                           // stage for which h_frags/h_blocks were built
 	// stage-8 results land in pinned host memory (one async D2H each, no pageable staging)
-	DevBuf p_frags, p_aln1, p_aln2, p_blk; bool result_pinned = false;
+	DevBuf p_frags, p_blk; bool result_pinned = false;
 };
 
 template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n)

@@ -439,7 +439,7 @@ struct OpEarlyGaps {
 		e_list[3 * e] = e; e_list[3 * e + 1] = rg; e_list[3 * e + 2] = qg;
 		off1[e] = rp; off2[e] = qp; opsoff[e] = ex[1];
 	}
-	__device__ void done(const i32 *t) const { mail[M_NEARLY] = t[0]; mail[M_EOPS] = t[1]; }
+	__device__ void done(const i32 *t) const { mail[M_NEARLY] = t[0]; mail[M_EOPS] = t[1]; mail[M_DPERR3] = 0; }
 };
 #define EARLY_CHUNK 4096      // large gaps copied with the first look (more -> a second copy)
 

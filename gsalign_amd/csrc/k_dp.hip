@@ -202,7 +202,7 @@ struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; }
 template <int WPB>
 __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(i32 nsj, const StripeJob *__restrict__ sjobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
                                                    const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2, uint8_t *dirbase, u32 *bndbase, u32 *ctr,
-                                                   uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, u32 ep, i32 lds_c1, i32 lds_rows)
+                                                   uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, u32 ep, i32 lds_c1, i32 lds_rows, u32 *err)
 {
 	extern __shared__ __attribute__((aligned(16))) int8_t C1[];        // the reference fragment as nt4 codes
 	__shared__ __attribute__((aligned(16))) uint8_t tile[DP_TILE_ROWS * 64];
@@ -218,7 +218,6 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(i32 nsj, const StripeJob
 	const int mpad64 = (m + 64 + 63) & ~63;                             // C1 is readable one 64-row block past the end
 	uint8_t *dir = dirbase + sj.diroff;
 	u32 *bnd_in = bndbase + sj.bndoff + (size_t)(p - 1) * m, *bnd_out = bndbase + sj.bndoff + (size_t)p * m;
-	u32 *err = ctr;                                                     // ctr[0]: spin-bound error flag
 	for (int t = threadIdx.x; t < m; t += 64 * WPB) C1[t] = (int8_t)(gsa_nt4(s1[t]) << 2);      // pre-multiplied: bit offset into the score table
 	for (int t = m + threadIdx.x; t < mpad64; t += 64 * WPB) C1[t] = 16;
 	// WPB > 1: the stripes of one workgroup hand their boundary column over through LDS (same granules, tag 0 = not yet)
@@ -342,6 +341,7 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(i32 nsj, const StripeJob
 	if (lane == 0) ticket = __hip_atomic_fetch_add(&ctr[sj.ctr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	ticket = (u32)__builtin_amdgcn_readfirstlane((int)ticket);
 	if ((int)ticket != P - 1) return;
+	if (lane == 0) ctr[sj.ctr] = 0;                                     // (nobody else looks again: the counters stay clean for the next launch)
 	DPT(const unsigned long long T1c = wall_clock64(); int ntile = 0, nrun = 0;)
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	uint8_t *rev = revbase + ops_off[sj.job], *op = ops + ops_off[sj.job];
@@ -490,25 +490,26 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		uint8_t *dir = dev_ensure<uint8_t>(c, c->d_scan2, (size_t)dbytes + 512);
 		const size_t bnd_cap0 = c->d_dp_bnd.cap;
 		u32 *bnd = dev_ensure<u32>(c, c->d_dp_bnd, (size_t)bwords + 64);
+		const size_t ctr_cap0 = c->d_dp_ctr.cap;
 		u32 *ctr = dev_ensure<u32>(c, c->d_dp_ctr, (size_t)nctr + 64);
 		StripeJob *d_sj = dev_ensure<StripeJob>(c, c->d_dp_jobs, cnt + 1);
 		if (!dir || !bnd || !ctr || !d_sj) return GSA_ERR_NOMEM;
 		// boundary granules carry the launch epoch as their tag: cleared only when the buffer is new or the epoch wraps
 		c->dp_epoch = (c->dp_epoch + 1) & 0xffffu;
 		if (c->dp_epoch == 0 || c->d_dp_bnd.cap != bnd_cap0) { GSA_CHECK(c, hipMemsetAsync(bnd, 0, c->d_dp_bnd.cap, st)); if (c->dp_epoch == 0) c->dp_epoch = 1; }
-		GSA_CHECK(c, hipMemsetAsync(ctr, 0, ((size_t)nctr + 64) * 4, st));
+		// (the ticket counters are put back to zero by the wave that draws the last ticket; the error word lives in the mailbox)
+		if (c->d_dp_ctr.cap != ctr_cap0 || c->dp_dirty) { GSA_CHECK(c, hipMemsetAsync(ctr, 0, c->d_dp_ctr.cap, st)); GSA_CHECK(c, hipMemsetAsync(mail + err_slot, 0, 4, st)); c->dp_dirty = false; }
 		GSA_CHECK(c, hipMemcpyAsync(d_sj, sj, cnt * sizeof(StripeJob), hipMemcpyHostToDevice, st));
-		if (wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)nblocks), dim3(256), dyn_lds, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows);
-		else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)nblocks), dim3(64), dyn_lds, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows);
+		if (wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)nblocks), dim3(256), dyn_lds, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows, (u32 *)(mail + err_slot));
+		else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)nblocks), dim3(64), dyn_lds, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows, (u32 *)(mail + err_slot));
 		GSA_CHECK(c, hipGetLastError());
-		GSA_CHECK(c, hipMemcpyAsync(mail + err_slot, ctr, 4, hipMemcpyDeviceToDevice, st));
 		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })
 		if (last < large.size()) {
 			// the staging buffer and the direction bytes are reused by the next batch
 			i32 *h = c->h_mail;
 			GSA_CHECK(c, hipMemcpyAsync(h, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
 			GSA_CHECK(c, hipStreamSynchronize(st));
-			if (h[err_slot]) return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
+			if (h[err_slot]) { c->dp_dirty = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
 		}
 		first = last;
 	}
@@ -618,7 +619,7 @@ extern "C" int gsa_ksw2_batch(gsa_ctx *c, int32_t n_pairs, const char *pool1, co
 		GSA_CHECK(c, hipMemcpyAsync(ops_len, d_ol, n * 4, hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipMemcpyAsync(&err, c->d_mail.as<i32>() + M_DPERR2, 4, hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipStreamSynchronize(st));
-		if (err) rc = gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out");
+		if (err) { c->dp_dirty = true; rc = gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
 	}
 	hipFree(d_p1); hipFree(d_p2); hipFree(d_ops); hipFree(d_o1); hipFree(d_o2); hipFree(d_oo); hipFree(d_l1); hipFree(d_l2); hipFree(d_ol);
 	return rc;

@@ -246,11 +246,14 @@ __global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_
 // whatever large job only turned up in the job list (lg != nullptr: job = lg[3g], record = jfrag[job]).
 __global__ void __launch_bounds__(256) k_materialize_large(i32 nlarge, const i32 *__restrict__ lg, const i32 *__restrict__ rec_of, const i32 *__restrict__ nops,
                                                             const i64 *__restrict__ aoff, const uint8_t *__restrict__ ops, const i64 *__restrict__ opsoff,
-                                                            const uint8_t *__restrict__ query, const uint8_t *__restrict__ ref, gsa_frag *frag, uint8_t *aln1, uint8_t *aln2, i32 *patch)
+                                                            const uint8_t *__restrict__ query, const uint8_t *__restrict__ ref, gsa_frag *frag, uint8_t *aln1, uint8_t *aln2, i32 *patch,
+                                                            const i32 *mail_src, i32 *mail_dst)
 {
 	__shared__ int s_w1[4], s_w2[4], s_sc;
 	const int g = blockIdx.x;
 	if (g >= nlarge) return;
+	// the last launch of a contig also puts the (by now final) mailbox in front of the patch list: one copy takes all of it home
+	if (mail_dst && g == 0 && threadIdx.x < MAIL_N) mail_dst[threadIdx.x] = mail_src[threadIdx.x];
 	const i32 job = lg ? lg[3 * g] : g;
 	const i64 i = rec_of[job];
 	if (i < 0) { if (threadIdx.x == 0) { patch[3 * g] = -1; patch[3 * g + 1] = 0; patch[3 * g + 2] = 0; } return; }
@@ -335,7 +338,7 @@ int stage78_extend(gsa_ctx *c)
 	ENS(i64, d_alnoff, nfu + 2);
 	{ OpDpJobs op = { c->f_type.as<i32>(), c->f_early.as<i32>(), c->f_rec.as<gsa_frag>(), c->j_frag.as<i32>(), off1, len1, off2, len2, c->j_opsoff.as<i64>(), c->f_job.as<i32>(),
 	                  c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), mail }; RC((lb_launch<2>(c, nfu, op))); }
-	ENS(uint8_t, d_ops, c->span_ub + 64); ENS(uint8_t, d_aln1, c->span_ub + 64); ENS(uint8_t, d_aln2, c->span_ub + 64);
+	ENS(uint8_t, d_ops, c->span_ub + 64);
 	ENS(i32, d_flag, nfu + 2); ENS(u32, d_scan, nfu + 2); ENS(u32, d_flag2, nfu + 2); ENS(i32, bl_alnlen, nfb + 1); ENS(i32, bl_score, nfb + 1);
 	Ksw2Launch kl;
 	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub, &kl,
@@ -344,8 +347,17 @@ int stage78_extend(gsa_ctx *c)
 	const i32 *hm = c->p_dp.as<i32>();
 	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN]; c->n_large = kl.nlarge;
 	const size_t nfr = (size_t)c->n_frags;
-	if (!pin_ensure<gsa_frag>(c, c->p_frags, nfr) || !pin_ensure<char>(c, c->p_aln1, (size_t)c->n_aln) || !pin_ensure<char>(c, c->p_aln2, (size_t)c->n_aln) ||
-	    !pin_ensure<i32>(c, c->p_blk, (size_t)3 * (nfb + 1) + MAIL_N + 8) || !pin_ensure<i32>(c, c->p_patch, 3 * ((size_t)kl.nlarge + (size_t)c->n_early) + 4)) return GSA_ERR_NOMEM;
+	// everything that can only leave at the very end sits in ONE buffer: final mailbox | patch list of the large DP jobs |
+	// string pool 1 | string pool 2 -- a single copy behind the last kernel instead of a chain of four
+	const size_t npatch = (size_t)kl.nlarge + (size_t)c->n_early;
+	const size_t t_patch = MAIL_N * sizeof(i32), t_aln1 = (t_patch + 12 * npatch + 255) & ~(size_t)255, t_aln2 = (t_aln1 + (size_t)c->n_aln + 255) & ~(size_t)255;
+	const size_t t_total = t_aln2 + (size_t)c->n_aln;
+	if (!pin_ensure<gsa_frag>(c, c->p_frags, nfr) || !pin_ensure<char>(c, c->p_tail, t_total + 256) || !pin_ensure<i32>(c, c->p_blk, (size_t)3 * (nfb + 1) + 8)) return GSA_ERR_NOMEM;
+	ENS(uint8_t, d_tail, t_total + 256);
+	uint8_t *d_tail = c->d_tail.as<uint8_t>(), *d_aln1 = d_tail + t_aln1, *d_aln2 = d_tail + t_aln2;
+	i32 *d_patch = (i32 *)(d_tail + t_patch);
+	c->h_tmail = (const i32 *)c->p_tail.p; c->h_tpatch = (const i32 *)((char *)c->p_tail.p + t_patch);
+	c->h_taln1 = (char *)c->p_tail.p + t_aln1; c->h_taln2 = (char *)c->p_tail.p + t_aln2;
 	// ---- behind the small jobs (stream_aux[1]; when there is no small job it starts at the fork) ----
 	if (!kl.small_in_flight) { GSA_CHECK(c, hipEventRecord(c->ev[10], st)); GSA_CHECK(c, hipStreamWaitEvent(sx, c->ev[10], 0)); }
 	// the records are final behind the small DP kernels (their DP gaps got their lengths there): they leave on a third stream
@@ -360,7 +372,7 @@ int stage78_extend(gsa_ctx *c)
 	i32 *c_len = c->d_flag.as<i32>(), *c_score = c->f_score.as<i32>();
 	hipLaunchKernelGGL(k_materialize, dim3((unsigned)((nfu + 255) / 256)), dim3(256), 0, sx, mail + M_NF, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(),
 	                   jlarge, c->j_nops.as<i32>(), c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
-	                   c->f_rec.as<gsa_frag>(), c->d_aln1.as<uint8_t>(), c->d_aln2.as<uint8_t>(), c_len, c_score);
+	                   c->f_rec.as<gsa_frag>(), d_aln1, d_aln2, c_len, c_score);
 	GSA_CHECK(c, hipEventRecord(c->ev[17], sx));      // the strings of everything but the large jobs are written
 	// per-block sums via prefix sums (the large jobs' records count as zero here, the host adds them from the patch list)
 	u32 *ps_score = c->d_flag2.as<u32>();      // (the small kernel's order array is free again)
@@ -373,30 +385,27 @@ int stage78_extend(gsa_ctx *c)
 	GSA_CHECK(c, hipMemcpyAsync(h_fragbase, c->fb_fragbase.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
 	GSA_CHECK(c, hipEventRecord(c->ev[13], sx));
 	// ---- behind the striped kernels ----
-	const size_t npatch = (size_t)kl.nlarge + (size_t)c->n_early;
+	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[17], 0));      // the other strings are written
+	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[13], 0));      // per-block sums are on the host
+	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[15], 0));      // the records are on the host
 	if (npatch > 0) {
-		ENS(i32, d_patch, 3 * npatch + 4);
 		if (kl.nlarge > 0)
 			hipLaunchKernelGGL(k_materialize_large, dim3((unsigned)kl.nlarge), dim3(256), 0, st, kl.nlarge, c->d_dp_large.as<i32>(), c->j_frag.as<i32>(), c->j_nops.as<i32>(),
 			                   c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
-			                   c->f_rec.as<gsa_frag>(), c->d_aln1.as<uint8_t>(), c->d_aln2.as<uint8_t>(), c->d_patch.as<i32>());
+			                   c->f_rec.as<gsa_frag>(), d_aln1, d_aln2, d_patch, mail, c->n_early > 0 ? (i32 *)nullptr : (i32 *)d_tail);
 		if (c->n_early > 0) {
 			GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[14], 0));      // the early striped launch (stream_aux[0])
 			c->early_consumed = true;
 			hipLaunchKernelGGL(k_materialize_large, dim3((unsigned)c->n_early), dim3(256), 0, st, c->n_early, (const i32 *)nullptr, c->e_rec.as<i32>(), c->e_nops.as<i32>(),
 			                   c->d_alnoff.as<i64>(), c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
-			                   c->f_rec.as<gsa_frag>(), c->d_aln1.as<uint8_t>(), c->d_aln2.as<uint8_t>(), c->d_patch.as<i32>() + 3 * (size_t)kl.nlarge);
+			                   c->f_rec.as<gsa_frag>(), d_aln1, d_aln2, d_patch + 3 * (size_t)kl.nlarge, mail, (i32 *)d_tail);
 		}
-		GSA_CHECK(c, hipMemcpyAsync(c->p_patch.p, c->d_patch.p, 3 * npatch * 4, hipMemcpyDeviceToHost, st));
+		GSA_CHECK(c, hipMemcpyAsync(c->p_tail.p, d_tail, t_total, hipMemcpyDeviceToHost, st));
+	} else {
+		// no large job: the mailbox goes home by itself, the pools (if any) behind it
+		GSA_CHECK(c, hipMemcpyAsync(c->p_tail.p, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
+		if (c->n_aln) GSA_CHECK(c, hipMemcpyAsync((char *)c->p_tail.p + t_aln1, d_aln1, t_total - t_aln1, hipMemcpyDeviceToHost, st));
 	}
-	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[17], 0));      // the other strings are written
-	if (c->n_aln) {
-		GSA_CHECK(c, hipMemcpyAsync(c->p_aln1.p, c->d_aln1.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, st));
-		GSA_CHECK(c, hipMemcpyAsync(c->p_aln2.p, c->d_aln2.p, (size_t)c->n_aln, hipMemcpyDeviceToHost, st));
-	}
-	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[13], 0));      // per-block sums are on the host
-	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[15], 0));      // the records are on the host
-	GSA_CHECK(c, hipMemcpyAsync(c->p_blk.as<i32>() + 3 * (nfb + 1), mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
 	if (c->profiling) hipEventRecord(c->ev[9], st);
 	GSA_CHECK(c, hipGetLastError());
 	return GSA_OK;
