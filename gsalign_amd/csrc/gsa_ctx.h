@@ -123,7 +123,7 @@ struct gsa_ctx {
 	i32 n_early = 0; bool early_in_flight = false; std::vector<i32> h_early;      // (seed, m, n) per early job
 	bool dp_dirty = true;                          // ticket counters / error words of the striped DP need clearing (fresh buffer, or a failed launch)
 	u32 dp_epoch = 0;                              // tag of the boundary granules of the current striped launch
-	DevBuf p_dp, p_sj;                             // pinned: mailbox + large-job list, stripe job descriptors
+	DevBuf p_dp, p_sj, p_sj_early;                 // pinned: mailbox + large-job list; stripe job tables (read by the kernels in place)
 	DevBuf d_alnoff;
 	DevBuf bl_alnlen, bl_score;
 	std::vector<gsa_frag> h_frags; std::vector<gsa_block> h_blocks; std::vector<char> h_aln1, h_aln2;

@@ -200,17 +200,16 @@ struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; }
 #define DP_LDS_M 3072         // longest reference fragment for which four stripes share a workgroup (3 boundary columns in LDS)
 
 template <int WPB>
-__global__ void __launch_bounds__(64 * WPB) k_dp_stripe(i32 nsj, const StripeJob *__restrict__ sjobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
+__global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ blk2job, const StripeJob *__restrict__ sjobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
                                                    const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2, uint8_t *dirbase, u32 *bndbase, u32 *ctr,
                                                    uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, u32 ep, i32 lds_c1, i32 lds_rows, u32 *err)
 {
 	extern __shared__ __attribute__((aligned(16))) int8_t C1[];        // the reference fragment as nt4 codes
 	__shared__ __attribute__((aligned(16))) uint8_t tile[DP_TILE_ROWS * 64];
 	__builtin_amdgcn_s_setprio(3);      // these waves are the contig's latency floor: they issue ahead of whatever else shares the SIMD
-	// which job / stripe am I (uniform)
-	int lo = 0, hi = nsj;
-	while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sjobs[mid].first_block <= (i32)blockIdx.x) lo = mid; else hi = mid; }
-	const StripeJob sj = sjobs[lo];
+	// which job / stripe am I (uniform).  Both tables are read where the host wrote them (pinned memory): two dependent
+	// reads across the link cost less than a copy operation in front of the launch
+	const StripeJob sj = sjobs[blk2job[blockIdx.x]];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int p = ((int)blockIdx.x - sj.first_block) * WPB + wave, m = sj.m, n = sj.n, P = sj.P;
 	const uint8_t *s1 = pool1 + off1[sj.job], *s2 = pool2 + off2[sj.job];
@@ -474,8 +473,13 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		// descriptors are staged in pinned memory: the upload is asynchronous
 		size_t cnt = 0;
 		{ size_t l = first; i64 db = 128; while (l < large.size()) { const i64 cells = (((i64)large[l].n + 63) / 64) * ((i64)large[l].m + 63) * 64; if (l > first && db + cells > budget) break; db += cells + 128; l++; } cnt = l - first; }
-		if (!pin_ensure<StripeJob>(c, c->p_sj, cnt + 1)) return GSA_ERR_NOMEM;
-		StripeJob *sj = c->p_sj.as<StripeJob>();
+		// (the early launch and a late one may be in flight together: each has its own table)
+		DevBuf &psj = err_slot == M_DPERR3 ? c->p_sj_early : c->p_sj;
+		size_t nb_ub = 0;
+		for (size_t k = 0; k < cnt; k++) nb_ub += (size_t)(((large[first + k].n + 63) / 64 + wpb - 1) / wpb);
+		if (!pin_ensure<char>(c, psj, (cnt + 1) * sizeof(StripeJob) + (nb_ub + 1) * 4)) return GSA_ERR_NOMEM;
+		StripeJob *sj = psj.as<StripeJob>();
+		i32 *b2j = (i32 *)(sj + cnt + 1);
 		i64 dbytes = 128, bwords = 0; i32 nctr = 1, nblocks = 0;
 		for (size_t k = 0; k < cnt; k++) {
 			const LgJob &g = large[first + k];
@@ -483,7 +487,8 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 			StripeJob s; s.job = g.job; s.m = g.m; s.n = g.n; s.P = (g.n + 63) / 64;
 			s.diroff = dbytes; dbytes += cells + 128;
 			s.bndoff = bwords; bwords += (i64)(s.P - 1) * g.m;
-			s.ctr = nctr++; s.first_block = nblocks; nblocks += (s.P + wpb - 1) / wpb;
+			s.ctr = nctr++; s.first_block = nblocks;
+			for (int b = 0; b < (s.P + wpb - 1) / wpb; b++) b2j[nblocks++] = (i32)k;
 			sj[k] = s;
 		}
 		const size_t last = first + cnt;
@@ -492,16 +497,14 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		u32 *bnd = dev_ensure<u32>(c, c->d_dp_bnd, (size_t)bwords + 64);
 		const size_t ctr_cap0 = c->d_dp_ctr.cap;
 		u32 *ctr = dev_ensure<u32>(c, c->d_dp_ctr, (size_t)nctr + 64);
-		StripeJob *d_sj = dev_ensure<StripeJob>(c, c->d_dp_jobs, cnt + 1);
-		if (!dir || !bnd || !ctr || !d_sj) return GSA_ERR_NOMEM;
+		if (!dir || !bnd || !ctr) return GSA_ERR_NOMEM;
 		// boundary granules carry the launch epoch as their tag: cleared only when the buffer is new or the epoch wraps
 		c->dp_epoch = (c->dp_epoch + 1) & 0xffffu;
 		if (c->dp_epoch == 0 || c->d_dp_bnd.cap != bnd_cap0) { GSA_CHECK(c, hipMemsetAsync(bnd, 0, c->d_dp_bnd.cap, st)); if (c->dp_epoch == 0) c->dp_epoch = 1; }
 		// (the ticket counters are put back to zero by the wave that draws the last ticket; the error word lives in the mailbox)
 		if (c->d_dp_ctr.cap != ctr_cap0 || c->dp_dirty) { GSA_CHECK(c, hipMemsetAsync(ctr, 0, c->d_dp_ctr.cap, st)); GSA_CHECK(c, hipMemsetAsync(mail + err_slot, 0, 4, st)); c->dp_dirty = false; }
-		GSA_CHECK(c, hipMemcpyAsync(d_sj, sj, cnt * sizeof(StripeJob), hipMemcpyHostToDevice, st));
-		if (wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)nblocks), dim3(256), dyn_lds, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows, (u32 *)(mail + err_slot));
-		else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)nblocks), dim3(64), dyn_lds, st, (i32)cnt, d_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows, (u32 *)(mail + err_slot));
+		if (wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)nblocks), dim3(256), dyn_lds, st, (const i32 *)b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows, (u32 *)(mail + err_slot));
+		else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)nblocks), dim3(64), dyn_lds, st, (const i32 *)b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows, (u32 *)(mail + err_slot));
 		GSA_CHECK(c, hipGetLastError());
 		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })
 		if (last < large.size()) {
