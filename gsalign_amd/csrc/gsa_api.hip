@@ -132,7 +132,7 @@ void gsa_destroy(gsa_ctx *c)
 	for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
 	if (c->h_mail) hipHostFree(c->h_mail);
-	for (DevBuf *b : { &c->p_frags, &c->p_tail, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_sj_early, &c->p_early }) if (b->p) hipHostFree(b->p);
+	for (DevBuf *b : { &c->p_frags, &c->p_tail, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_sj_early, &c->p_jpatch, &c->p_early }) if (b->p) hipHostFree(b->p);
 	for (int i = 0; i < 24; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 3; i++) if (c->stream_aux[i]) hipStreamDestroy(c->stream_aux[i]);
 	if (c->stream) hipStreamDestroy(c->stream);

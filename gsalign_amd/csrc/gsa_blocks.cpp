@@ -140,11 +140,23 @@ int host_stage8_finish(gsa_ctx *c)
 	const size_t nfb = c->blocks.size();
 	c->h_blocks.clear(); c->h_frags.clear(); c->h_aln1.clear(); c->h_aln2.clear(); c->result_pinned = false;
 	if (nfb == 0) return GSA_OK;
-	// stage78_extend left everything in flight: per-block sums, records, patch list, string pools, mailbox
+	// stage78_extend left everything in flight: per-block sums, records, patch list, string pools, mailbox.
+	// The records came early, without the string lengths of their DP gaps: those of the small jobs are patched in while
+	// the striped kernel is still running (the large ones below, from the patch list)
+	GSA_CHECK(c, hipEventSynchronize(c->ev[15]));
+	{
+		gsa_frag *fr = c->p_frags.as<gsa_frag>();
+		const i32 *rec = c->p_jpatch.as<i32>(), *len = rec + c->n_jobs;
+		for (i32 j = 0; j < c->n_jobs; j++) fr[rec[j]].aln_len = len[j];
+	}
 	GSA_CHECK(c, hipStreamSynchronize(c->stream));
 	if (c->profiling) { float ms; if (hipEventElapsedTime(&ms, c->ev[8], c->ev[9]) == hipSuccess) c->kernel_ms[5] = ms; (void)hipGetLastError(); }
 	i32 *bl_len = c->p_blk.as<i32>(), *bl_score = bl_len + nfb, *fragbase = bl_score + nfb;
 	const i32 *hm = c->h_tmail;
+	if (c->n_early > 0 && getenv("GSA_DEBUG_EARLY")) {
+		float a = 0, b = 0; hipEventElapsedTime(&a, c->ev[16], c->ev[20]); hipEventElapsedTime(&b, c->ev[20], c->ev[14]);
+		fprintf(stderr, "[gsa] early DP: list ready -> launch reaches the stream %.1f us, launch -> done %.1f us\n", a * 1e3, b * 1e3);
+	}
 	if (hm[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	if (hm[M_DPERR2]) { c->dp_dirty = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
 	if (c->profiling) { const unsigned long long *cc = (const unsigned long long *)(hm + M_CELLS); c->counters[4] += cc[0]; c->counters[6] += cc[1]; }

@@ -107,6 +107,7 @@ struct gsa_ctx {
 	// ---- stages 7-8 ----
 	i64 n_frags = 0, n_aln = 0;                    // (n_frags < 0: still in the mailbox, see frags_count())
 	i32 n_large = 0;                               // large DP jobs of the current contig (their records are patched on the host)
+	DevBuf p_jpatch; i32 n_jobs = 0;               // pinned: record numbers, then string lengths, of the DP jobs of the job list (the host patches its records)
 	DevBuf d_tail, p_tail;                         // final mailbox | patch list | string pool 1 | string pool 2: device / pinned (one copy at the end)
 	const i32 *h_tmail = nullptr, *h_tpatch = nullptr; char *h_taln1 = nullptr, *h_taln2 = nullptr;      // the parts of p_tail
 	i64 nf_ub = 0, span_ub = 0;                    // host-known upper bounds: records, and bases in gaps (ops / gapped strings)

@@ -465,6 +465,8 @@ int launch_early_dp(gsa_ctx *c)
 	if (!dev_ensure<uint8_t>(c, c->e_ops, (size_t)eops + 64) || !dev_ensure<uint8_t>(c, c->e_rev, (size_t)eops + 64) || !dev_ensure<i32>(c, c->e_nops, (size_t)ne + 1) || !dev_ensure<i32>(c, c->e_rec, (size_t)ne + 1)) return GSA_ERR_NOMEM;
 	// stream_aux[0] already waits for the list (ev[16] was recorded behind it on the main stream)
 	GSA_CHECK(c, hipStreamWaitEvent(sa, c->ev[16], 0));
+	static const bool dbg_early = getenv("GSA_DEBUG_EARLY") != nullptr;
+	if (dbg_early) GSA_CHECK(c, hipEventRecord(c->ev[20], sa));
 	int rc = launch_stripes(c, sa, large, c->di.ref, c->e_off1.as<i64>(), c->d_query.as<uint8_t>(), c->e_off2.as<i64>(),
 	                        c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->e_nops.as<i32>(), c->e_rev.as<uint8_t>(), M_DPERR3);
 	if (rc) return rc;

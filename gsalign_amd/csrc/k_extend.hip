@@ -327,7 +327,7 @@ int stage78_extend(gsa_ctx *c)
 {
 	hipStream_t st = c->stream, sx = c->stream_aux[1];
 	const i32 nfb = (i32)c->blocks.size(); const i64 nfu = c->nf_ub;
-	c->n_aln = 0; c->n_large = 0;
+	c->n_aln = 0; c->n_large = 0; c->n_jobs = 0;
 	if (nfb == 0 || nfu == 0) { c->n_frags = 0; return GSA_OK; }
 	if (c->profiling) hipEventRecord(c->ev[8], st);
 	i32 *mail = c->d_mail.as<i32>();
@@ -338,21 +338,27 @@ int stage78_extend(gsa_ctx *c)
 	ENS(i64, d_alnoff, nfu + 2);
 	{ OpDpJobs op = { c->f_type.as<i32>(), c->f_early.as<i32>(), c->f_rec.as<gsa_frag>(), c->j_frag.as<i32>(), off1, len1, off2, len2, c->j_opsoff.as<i64>(), c->f_job.as<i32>(),
 	                  c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), mail }; RC((lb_launch<2>(c, nfu, op))); }
+	// the records are final here except for the string length of a DP gap: they leave now (all nf_ub of them: the count is
+	// still on the device), on a third stream; the DP gaps' lengths follow as a short list the host patches in
+	hipStream_t sc = c->stream_aux[2];
+	if (!pin_ensure<gsa_frag>(c, c->p_frags, (size_t)nfu + 1)) return GSA_ERR_NOMEM;
+	GSA_CHECK(c, hipEventRecord(c->ev[19], st)); GSA_CHECK(c, hipStreamWaitEvent(sc, c->ev[19], 0));
+	GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, (size_t)nfu * sizeof(gsa_frag), hipMemcpyDeviceToHost, sc));
 	ENS(uint8_t, d_ops, c->span_ub + 64);
 	ENS(i32, d_flag, nfu + 2); ENS(u32, d_scan, nfu + 2); ENS(u32, d_flag2, nfu + 2); ENS(i32, bl_alnlen, nfb + 1); ENS(i32, bl_score, nfb + 1);
 	Ksw2Launch kl;
 	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub, &kl,
-	                 c->j_frag.as<i32>(), c->f_rec.as<gsa_frag>()));
+	                 nullptr, nullptr));
 	// (run_ksw2_jobs read the mailbox: the record count and the size of the string pools are known now)
 	const i32 *hm = c->p_dp.as<i32>();
 	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN]; c->n_large = kl.nlarge;
-	const size_t nfr = (size_t)c->n_frags;
 	// everything that can only leave at the very end sits in ONE buffer: final mailbox | patch list of the large DP jobs |
 	// string pool 1 | string pool 2 -- a single copy behind the last kernel instead of a chain of four
 	const size_t npatch = (size_t)kl.nlarge + (size_t)c->n_early;
 	const size_t t_patch = MAIL_N * sizeof(i32), t_aln1 = (t_patch + 12 * npatch + 255) & ~(size_t)255, t_aln2 = (t_aln1 + (size_t)c->n_aln + 255) & ~(size_t)255;
 	const size_t t_total = t_aln2 + (size_t)c->n_aln;
-	if (!pin_ensure<gsa_frag>(c, c->p_frags, nfr) || !pin_ensure<char>(c, c->p_tail, t_total + 256) || !pin_ensure<i32>(c, c->p_blk, (size_t)3 * (nfb + 1) + 8)) return GSA_ERR_NOMEM;
+	c->n_jobs = hm[M_NJOB];
+	if (!pin_ensure<i32>(c, c->p_jpatch, 2 * (size_t)c->n_jobs + 2) || !pin_ensure<char>(c, c->p_tail, t_total + 256) || !pin_ensure<i32>(c, c->p_blk, (size_t)3 * (nfb + 1) + 8)) return GSA_ERR_NOMEM;
 	ENS(uint8_t, d_tail, t_total + 256);
 	uint8_t *d_tail = c->d_tail.as<uint8_t>(), *d_aln1 = d_tail + t_aln1, *d_aln2 = d_tail + t_aln2;
 	i32 *d_patch = (i32 *)(d_tail + t_patch);
@@ -360,14 +366,13 @@ int stage78_extend(gsa_ctx *c)
 	c->h_taln1 = (char *)c->p_tail.p + t_aln1; c->h_taln2 = (char *)c->p_tail.p + t_aln2;
 	// ---- behind the small jobs (stream_aux[1]; when there is no small job it starts at the fork) ----
 	if (!kl.small_in_flight) { GSA_CHECK(c, hipEventRecord(c->ev[10], st)); GSA_CHECK(c, hipStreamWaitEvent(sx, c->ev[10], 0)); }
-	// the records are final behind the small DP kernels (their DP gaps got their lengths there): they leave on a third stream
-	// while the strings are still being written
-	{
-		hipStream_t sc = c->stream_aux[2];
+	// (record, string length) of the small DP jobs: the record numbers are known since the job list, the lengths behind the small kernels
+	if (c->n_jobs > 0) {
+		GSA_CHECK(c, hipMemcpyAsync(c->p_jpatch.p, c->j_frag.p, (size_t)c->n_jobs * 4, hipMemcpyDeviceToHost, sc));
 		GSA_CHECK(c, hipStreamWaitEvent(sc, kl.small_in_flight ? c->ev[12] : c->ev[10], 0));
-		if (nfr) GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, nfr * sizeof(gsa_frag), hipMemcpyDeviceToHost, sc));
-		GSA_CHECK(c, hipEventRecord(c->ev[15], sc));
+		GSA_CHECK(c, hipMemcpyAsync(c->p_jpatch.as<i32>() + c->n_jobs, c->j_nops.p, (size_t)c->n_jobs * 4, hipMemcpyDeviceToHost, sc));
 	}
+	GSA_CHECK(c, hipEventRecord(c->ev[15], sc));
 	const i32 *jlarge = c->d_dp_large.as<i32>() + 3 * ((size_t)nju + 1);
 	i32 *c_len = c->d_flag.as<i32>(), *c_score = c->f_score.as<i32>();
 	hipLaunchKernelGGL(k_materialize, dim3((unsigned)((nfu + 255) / 256)), dim3(256), 0, sx, mail + M_NF, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(),
