@@ -145,3 +145,35 @@ def test_scaled_pairs_vs_oracle(oracle_built, tmp_path, total, ncontig, div, see
             assert np.array_equal(got[k], v), (name, k)
         assert want["b_score"].size > 0
     o.close(); g.close()
+
+
+def test_degenerate_queries(gpu, ora, golden_dir):
+    """Edge cases against the committed index: empty-ish, ambiguous, unrelated, exact-copy and chunk-edge queries."""
+    refs = synth.read_fasta(os.path.join(golden_dir, "cx.ref.fa"))
+    ref0 = refs[0][1]
+    rng = np.random.default_rng(77)
+    L = min(ref0.size, 60000)
+    cases = {
+        "one_base": np.frombuffer(b"A", np.uint8),
+        "shorter_than_a_seed": ref0[100:110].copy(),
+        "all_N": np.full(25000, ord("N"), np.uint8),
+        "unrelated": synth.random_genome(30000, rng),
+        "exact_copy_no_gaps": ref0[:L].copy(),                             # no gap record, no DP job, empty string pools
+        "exact_copy_reverse_strand": synth.revcomp(ref0[:L]),
+        "chunk_edge_10000": ref0[500:10500].copy(),
+        "chunk_edge_10001": ref0[500:10501].copy(),
+        "chunk_edge_19999": ref0[500:20499].copy(),
+        "lower_case_and_N_runs": None,
+        "one_long_indel": np.concatenate([ref0[:20000], ref0[20900:L]]),   # 900-bp deletion: a striped DP job or a block cut
+        "snv_every_200": None,
+    }
+    m = ref0[:L].copy(); m[5000:5050] = ord("N"); m[7000:9000] = np.frombuffer(bytes(m[7000:9000]).lower(), np.uint8); cases["lower_case_and_N_runs"] = m
+    m = ref0[:L].copy(); idx = np.arange(100, L, 200); m[idx] = np.where(m[idx] == ord("A"), ord("C"), ord("A")); cases["snv_every_200"] = m
+    for name, seq in cases.items():
+        seq = np.ascontiguousarray(seq, np.uint8)
+        ora.set_query(seq); gpu.set_query(seq)
+        assert_stage_equal(gpu.dump_stages(8), ora.dump_stages(8), prefix="")
+        ora.set_query(seq); ora.run_to(8); want = ora.blocks(with_aln=True)
+        gpu.align_contig(seq); got = gpu.blocks_as_dump(with_aln=True)
+        for k, v in want.items():
+            assert np.array_equal(got[k], v), (name, k)
