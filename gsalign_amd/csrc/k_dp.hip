@@ -186,7 +186,8 @@ __global__ void __launch_bounds__(64 * TINY_WAVES) k_dp_tiny(i32 n_jobs, const i
 // workgroup index and was therefore dispatched earlier; spins are bounded.
 // ---------------------------------------------------------------------------
 struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; };
-#define DP_TILE_ROWS 128
+#define DP_TILE_ROWS 160        // local diagonals of a traceback tile (64 diagonal steps need 128)
+#define DP_TILE_SLACK 16        // the prefetched tile reaches this far past the predicted entry
 #ifndef DP_G
 #define DP_G 8               // boundary rows per hand-off block (4, 8 or 16)
 #endif
@@ -348,18 +349,44 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	// lane l looks at the cell e = l % 21 steps ahead along direction g = l / 21 (0: M, 1: D, 2: I)
 	const int g = lane / DP_LOOK, e = lane - g * DP_LOOK;
 	const int dlc = g == 2 ? 0 : -e, drl = g == 0 ? -2 * e : -e;
+	// The next tile is fetched while the current one is walked: an alignment path runs along the diagonal, so from (i, j)
+	// it will enter the stripe to the left near row j - (lc + 1); those diagonals (+-DP_TILE_SLACK for indels on the way)
+	// are loaded into registers now and only written to LDS when the walker gets there.  A wrong guess costs nothing but
+	// the load: the tile is then fetched the plain way.
+	uint4 pf[DP_TILE_ROWS * 4 / 64];
+	int pf_sp = -1, pf_lo = 0, pf_hi = -1;
+	const int rl_max = m - 1 + 63;                                      // last local diagonal of a stripe
 	while (i >= 0 && j >= 0) {
 		i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
 		// tile: stripe sp, local diagonals rl_lo .. rl_hi
 		DPT(ntile++;)
 		const int sp = i >> 6, rl_hi = j + (i & 63);
-		const int rl_lo = rl_hi - (DP_TILE_ROWS - 1) > 0 ? rl_hi - (DP_TILE_ROWS - 1) : 0;
-		{
+		int rl_lo;
+		uint4 *dst = (uint4 *)tile;
+		if (sp == pf_sp && rl_hi <= pf_hi && rl_hi - pf_lo >= 64) {
+			rl_lo = pf_lo;
+			DPT(nrun += 1 << 16;)
+#pragma unroll
+			for (int q2 = 0; q2 < DP_TILE_ROWS * 4 / 64; q2++) dst[q2 * 64 + lane] = pf[q2];
+		} else {
+			rl_lo = rl_hi - (DP_TILE_ROWS - 1) > 0 ? rl_hi - (DP_TILE_ROWS - 1) : 0;
 			const uint4 *src = (const uint4 *)(dir + (size_t)sp * pitch + ((size_t)rl_lo << 6));
 			const int nvec = (rl_hi - rl_lo + 1) * 4;
-			uint4 *dst = (uint4 *)tile;
 #pragma unroll
 			for (int q2 = 0; q2 < DP_TILE_ROWS * 4 / 64; q2++) { const int id = q2 * 64 + lane; if (id < nvec) dst[id] = src[id]; }
+		}
+		pf_sp = -1;
+		{
+			const int jp = j - ((i & 63) + 1);
+			if (sp > 0 && jp >= 0) {
+				int hi = jp + 63 + DP_TILE_SLACK; hi = hi < rl_max ? hi : rl_max;
+				const int lo = hi - (DP_TILE_ROWS - 1) > 0 ? hi - (DP_TILE_ROWS - 1) : 0;
+				const uint4 *src = (const uint4 *)(dir + (size_t)(sp - 1) * pitch + ((size_t)lo << 6));
+				const int nvec = (hi - lo + 1) * 4;
+#pragma unroll
+				for (int q2 = 0; q2 < DP_TILE_ROWS * 4 / 64; q2++) { const int id = q2 * 64 + lane; pf[q2] = src[id < nvec ? id : 0]; }
+				pf_sp = sp - 1; pf_lo = lo; pf_hi = hi;
+			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_wave_barrier();
