@@ -156,6 +156,10 @@ int host_stage8_finish(gsa_ctx *c)
 	if (c->n_early > 0 && getenv("GSA_DEBUG_EARLY")) {
 		float a = 0, b = 0; hipEventElapsedTime(&a, c->ev[16], c->ev[20]); hipEventElapsedTime(&b, c->ev[20], c->ev[14]);
 		fprintf(stderr, "[gsa] early DP: list ready -> launch reaches the stream %.1f us, launch -> done %.1f us\n", a * 1e3, b * 1e3);
+		const int evs[] = { 19, 12, 17, 13, 15, 14 }; const char *nm[] = { "job list", "small DP done", "strings", "block sums home", "records+patch home", "stripes done" };
+		fprintf(stderr, "[gsa]   after the early list (us):");
+		for (int k = 0; k < 6; k++) { float t = 0; if (hipEventElapsedTime(&t, c->ev[16], c->ev[evs[k]]) == hipSuccess) fprintf(stderr, "  %s %.0f", nm[k], t * 1e3); }
+		(void)hipGetLastError(); fprintf(stderr, "\n");
 	}
 	if (hm[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	if (hm[M_DPERR2]) { c->dp_dirty = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
