@@ -153,10 +153,13 @@ int host_stage8_finish(gsa_ctx *c)
 	if (c->profiling) { float ms; if (hipEventElapsedTime(&ms, c->ev[8], c->ev[9]) == hipSuccess) c->kernel_ms[5] = ms; (void)hipGetLastError(); }
 	i32 *bl_len = c->p_blk.as<i32>(), *bl_score = bl_len + nfb, *fragbase = bl_score + nfb;
 	const i32 *hm = c->h_tmail;
-	if (c->n_early > 0 && getenv("GSA_DEBUG_EARLY")) {
+	static const char *dbg_env = getenv("GSA_DEBUG_EARLY"); static int dbg_calls = 0;
+	if (c->n_early > 0 && dbg_env && (atoi(dbg_env) < 2 || (++dbg_calls & 31) == 0)) {
 		float a = 0, b = 0; hipEventElapsedTime(&a, c->ev[16], c->ev[20]); hipEventElapsedTime(&b, c->ev[20], c->ev[14]);
 		fprintf(stderr, "[gsa] early DP: list ready -> launch reaches the stream %.1f us, launch -> done %.1f us\n", a * 1e3, b * 1e3);
 		const int evs[] = { 19, 12, 17, 13, 15, 14 }; const char *nm[] = { "job list", "small DP done", "strings", "block sums home", "records+patch home", "stripes done" };
+		{ float t1 = 0; hipEventElapsedTime(&t1, c->ev[14], c->ev[22]); fprintf(stderr, "[gsa]   stripes done -> last copy done %.0f us\n", t1 * 1e3); }
+		{ float t0 = 0; hipEventElapsedTime(&t0, c->ev[0], c->ev[16]); fprintf(stderr, "[gsa]   seed kernel start -> early list %.0f us\n", t0 * 1e3); }
 		fprintf(stderr, "[gsa]   after the early list (us):");
 		for (int k = 0; k < 6; k++) { float t = 0; if (hipEventElapsedTime(&t, c->ev[16], c->ev[evs[k]]) == hipSuccess) fprintf(stderr, "  %s %.0f", nm[k], t * 1e3); }
 		(void)hipGetLastError(); fprintf(stderr, "\n");

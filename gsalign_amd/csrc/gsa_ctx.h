@@ -32,7 +32,7 @@ struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf ra
 struct gsa_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
-	hipStream_t stream_aux[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] early striped DP, [1] tiny DP + strings + sums, [2] small DP, [3] records to the host
+	hipStream_t stream_aux[3] = {nullptr, nullptr, nullptr};   // [0] early striped DP, [1] tiny DP + strings + sums, [2] records to the host (four streams in all: one per hardware queue)
 	std::string err;
 	Params prm;
 	DevIndex di;

@@ -551,8 +551,8 @@ int stage2_chain(gsa_ctx *c)
 	{ OpEarlyGaps op = { c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_bid.as<i32>(), c->d_query.as<uint8_t>(), c->di.ref,
 	                     c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail }; RC((lb_launch<2>(c, na, op))); }
 	if (!pin_ensure<i32>(c, c->p_early, 4 + 3 * (size_t)EARLY_CHUNK)) return GSA_ERR_NOMEM;
-	GSA_CHECK(c, hipMemcpyAsync(c->p_early.p, mail + M_NEARLY, 2 * sizeof(i32), hipMemcpyDeviceToHost, st));      // M_NEARLY, M_EOPS
-	GSA_CHECK(c, hipMemcpyAsync(c->p_early.as<i32>() + 4, c->e_list.p, (size_t)std::min<i64>(na, EARLY_CHUNK) * 12, hipMemcpyDeviceToHost, st));
+	hipLaunchKernelGGL(k_mirror, dim3(1), dim3(256), 0, st, (const i32 *)(mail + M_NEARLY), 2, c->p_early.as<i32>(),      // M_NEARLY, M_EOPS
+	                   (const i32 *)c->e_list.as<i32>(), c->p_early.as<i32>() + 4, (const i32 *)(mail + M_NEARLY), (i32)std::min<i64>(na, EARLY_CHUNK), 3);
 	GSA_CHECK(c, hipEventRecord(c->ev[16], st));
 	c->early_listed = true;
 	return GSA_OK;      // counts stay in the mailbox; stage 3 reads them with its own first read-back

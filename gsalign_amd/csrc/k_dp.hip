@@ -568,8 +568,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	{ OpClassify op = { len1, len2, d_order, d_order_tiny, d_lg, d_jlarge, mail }; int rc = lb_launch<2>(c, n_ub, op); if (rc) return rc; }
 	i32 *h = c->p_dp.as<i32>();
 	const size_t first_lg = (size_t)std::min<i64>(n_ub, LG_CHUNK);
-	GSA_CHECK(c, hipMemcpyAsync(h, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
-	GSA_CHECK(c, hipMemcpyAsync(h + MAIL_N, d_lg, first_lg * 12, hipMemcpyDeviceToHost, st));
+	hipLaunchKernelGGL(k_mirror, dim3(1), dim3(256), 0, st, (const i32 *)mail, (int)MAIL_N, h, (const i32 *)d_lg, h + MAIL_N, (const i32 *)(mail + M_NLARGE), (i32)first_lg, 3);
 	GSA_CHECK(c, hipStreamSynchronize(st));
 	if (h[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	if (h[M_DPERR]) return gsa_fail(c, GSA_ERR_ARG, "DP job with an empty side");
@@ -595,9 +594,10 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 			hipLaunchKernelGGL(k_dp_tiny, dim3(nb), dim3(64 * TINY_WAVES), 0, c->stream_aux[1], ntiny, d_order_tiny, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag);
 		}
 		if (nsmall > 0) {
-			// (the two size classes side by side: the one-per-wavefront kernel on stream_aux[2], joined below)
-			hipStream_t s2 = ntiny > 0 ? c->stream_aux[2] : c->stream_aux[1];
-			if (ntiny > 0) GSA_CHECK(c, hipStreamWaitEvent(s2, ev_fork, 0));
+			// (the two size classes side by side: the one-per-wavefront kernel stays on the caller's stream, joined below.
+			//  Not a stream of its own: the runtime maps streams onto four hardware queues, a fifth stream shares one --
+			//  with the striped kernel, if it is unlucky)
+			hipStream_t s2 = ntiny > 0 ? st : c->stream_aux[1];
 			const unsigned nb = (unsigned)((nsmall + SMALL_WAVES - 1) / SMALL_WAVES);
 			hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, s2, nsmall, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag);
 			if (ntiny > 0) { GSA_CHECK(c, hipEventRecord(c->ev[18], s2)); GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], c->ev[18], 0)); }

@@ -340,7 +340,7 @@ int stage78_extend(gsa_ctx *c)
 	                  c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), mail }; RC((lb_launch<2>(c, nfu, op))); }
 	// the records are final here except for the string length of a DP gap: they leave now (all nf_ub of them: the count is
 	// still on the device), on a third stream; the DP gaps' lengths follow as a short list the host patches in
-	hipStream_t sc = c->stream_aux[3];
+	hipStream_t sc = c->stream_aux[2];
 	if (!pin_ensure<gsa_frag>(c, c->p_frags, (size_t)nfu + 1)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipEventRecord(c->ev[19], st)); GSA_CHECK(c, hipStreamWaitEvent(sc, c->ev[19], 0));
 	GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, (size_t)nfu * sizeof(gsa_frag), hipMemcpyDeviceToHost, sc));
@@ -412,6 +412,7 @@ int stage78_extend(gsa_ctx *c)
 		if (c->n_aln) GSA_CHECK(c, hipMemcpyAsync((char *)c->p_tail.p + t_aln1, d_aln1, t_total - t_aln1, hipMemcpyDeviceToHost, st));
 	}
 	if (c->profiling) hipEventRecord(c->ev[9], st);
+	{ static const bool dbg = getenv("GSA_DEBUG_EARLY") != nullptr; if (dbg) hipEventRecord(c->ev[22], st); }
 	GSA_CHECK(c, hipGetLastError());
 	return GSA_OK;
 }

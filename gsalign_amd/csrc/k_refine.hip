@@ -136,8 +136,12 @@ struct OpChrCuts {
 
 __global__ void k_leaf_emit(i64 ub, const i32 *__restrict__ d_n, const i32 *__restrict__ mail, const i32 *__restrict__ lstart, const i32 *__restrict__ q,
                             const i32 *__restrict__ len, const i64 *__restrict__ r, const i32 *__restrict__ bid, const i32 *__restrict__ cut4,
-                            const i32 *__restrict__ cut5, const u32 *__restrict__ ps, const i32 *__restrict__ blk_score, Leaf *leaf)
+                            const i32 *__restrict__ cut5, const u32 *__restrict__ ps, const i32 *__restrict__ blk_score, Leaf *leaf,
+                            i32 *hmail, Leaf *hleaf, i32 hleaf_cap)
 {
+	// last kernel in front of the host's look: the mailbox and the first leaves are written straight into pinned memory
+	// (a copy operation behind the kernel costs ~15 us of stream latency each, these stores ride along)
+	if (blockIdx.x == 0 && threadIdx.x < MAIL_N) hmail[threadIdx.x] = mail[threadIdx.x];
 	GID(ub);
 	const i32 nl = mail[M_NL];
 	if (i >= nl) return;
@@ -147,6 +151,7 @@ __global__ void k_leaf_emit(i64 ub, const i32 *__restrict__ d_n, const i32 *__re
 	L.q_first = q[s]; L.q_last_end = q[e - 1] + len[e - 1]; L.r_first = r[s]; L.r_last_end = r[e - 1] + len[e - 1];
 	L.blk = bid[s]; L.cut4 = cut4[s]; L.cut5 = cut5[s]; L.blk_score = blk_score[L.blk];
 	leaf[i] = L;
+	if (i < hleaf_cap) hleaf[i] = L;
 }
 
 int stage345_refine(gsa_ctx *c)
@@ -192,10 +197,8 @@ int stage345_refine(gsa_ctx *c)
 		// S5 cuts + leaf table + large DP gaps of the leaves
 		{ OpChrCuts op = { ub, mail + cur, c->di, c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, c->r_len.as<i32>(), cut5, lstart, c->r_head.as<i32>(), ps, mail }; RC((lb_launch<2>(c, ub, op))); }
 		LAUNCH(k_leaf_emit, ub, ub, mail + cur, mail, lstart, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, cut5, ps,
-		       c->blk_score.as<i32>(), c->d_leaf.as<Leaf>());
-		// the mailbox and the first LEAF_CHUNK leaves come back together
-		GSA_CHECK(c, hipMemcpyAsync(c->h_mail, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
-		GSA_CHECK(c, hipMemcpyAsync(c->p_leaf.p, c->d_leaf.p, first * sizeof(Leaf), hipMemcpyDeviceToHost, st));
+		       c->blk_score.as<i32>(), c->d_leaf.as<Leaf>(), c->h_mail, c->p_leaf.as<Leaf>(), (i32)first);
+		// (the mailbox and the first LEAF_CHUNK leaves are in pinned memory when this kernel is done)
 		if (c->profiling) hipEventRecord(c->ev[7], st);
 		// everything of S3-S5 is enqueued: now start the striped DP for the large gaps stage 2 listed (its own stream)
 		RC(launch_early_dp(c));
