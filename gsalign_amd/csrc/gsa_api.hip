@@ -96,7 +96,7 @@ int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa
 	}
 	CK(hipMalloc(&c->d_chr_end.p, c->h_chr_end.size() * 8)); CK(hipMemcpy(c->d_chr_end.p, c->h_chr_end.data(), c->h_chr_end.size() * 8, hipMemcpyHostToDevice));
 	CK(hipMalloc(&c->d_chr_of_end.p, c->h_chr_of_end.size() * 4)); CK(hipMemcpy(c->d_chr_of_end.p, c->h_chr_of_end.data(), c->h_chr_of_end.size() * 4, hipMemcpyHostToDevice));
-	CK(hipMalloc(&c->d_cnt.p, 16 * sizeof(u64))); c->d_cnt.cap = 16 * sizeof(u64);
+	CK(hipMalloc(&c->d_cnt.p, 16 * sizeof(u64))); c->d_cnt.cap = 16 * sizeof(u64); CK(hipMemset(c->d_cnt.p, 0, 16 * sizeof(u64)));
 	CK(hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(u64)));
 	CK(hipMalloc(&c->d_mail.p, MAIL_N * sizeof(i32))); c->d_mail.cap = MAIL_N * sizeof(i32);
 	CK(hipMemset(c->d_mail.p, 0, MAIL_N * sizeof(i32)));

@@ -552,7 +552,7 @@ int stage2_chain(gsa_ctx *c)
 	                     c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail }; RC((lb_launch<2>(c, na, op))); }
 	if (!pin_ensure<i32>(c, c->p_early, 4 + 3 * (size_t)EARLY_CHUNK)) return GSA_ERR_NOMEM;
 	hipLaunchKernelGGL(k_mirror, dim3(1), dim3(256), 0, st, (const i32 *)(mail + M_NEARLY), 2, c->p_early.as<i32>(),      // M_NEARLY, M_EOPS
-	                   (const i32 *)c->e_list.as<i32>(), c->p_early.as<i32>() + 4, (const i32 *)(mail + M_NEARLY), (i32)std::min<i64>(na, EARLY_CHUNK), 3);
+	                   (const i32 *)c->e_list.as<i32>(), c->p_early.as<i32>() + 4, (const i32 *)(mail + M_NEARLY), (i32)std::min<i64>(na, EARLY_CHUNK), 3, (i32 *)nullptr);
 	GSA_CHECK(c, hipEventRecord(c->ev[16], st));
 	c->early_listed = true;
 	return GSA_OK;      // counts stay in the mailbox; stage 3 reads them with its own first read-back

@@ -568,7 +568,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	{ OpClassify op = { len1, len2, d_order, d_order_tiny, d_lg, d_jlarge, mail }; int rc = lb_launch<2>(c, n_ub, op); if (rc) return rc; }
 	i32 *h = c->p_dp.as<i32>();
 	const size_t first_lg = (size_t)std::min<i64>(n_ub, LG_CHUNK);
-	hipLaunchKernelGGL(k_mirror, dim3(1), dim3(256), 0, st, (const i32 *)mail, (int)MAIL_N, h, (const i32 *)d_lg, h + MAIL_N, (const i32 *)(mail + M_NLARGE), (i32)first_lg, 3);
+	hipLaunchKernelGGL(k_mirror, dim3(1), dim3(256), 0, st, (const i32 *)mail, (int)MAIL_N, h, (const i32 *)d_lg, h + MAIL_N, (const i32 *)(mail + M_NLARGE), (i32)first_lg, 3, (i32 *)nullptr);
 	GSA_CHECK(c, hipStreamSynchronize(st));
 	if (h[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	if (h[M_DPERR]) return gsa_fail(c, GSA_ERR_ARG, "DP job with an empty side");

@@ -285,7 +285,10 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		for (int o = 32; o; o >>= 1) h += __shfl_down(h, o);
 		if ((j & 63) == 0 && h) atomicAdd(&s_hits, h);
 		__syncthreads();
-		if (j == 0) { cand_cnt[chunk] = nc; chunk_hits[chunk] = (i32)s_hits; atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand); }
+		if (j == 0) {
+			cand_cnt[chunk] = nc; chunk_hits[chunk] = (i32)s_hits; if (chunk == 0) chunk_hits[gridDim.x] = 0; atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand);
+			if (s_hits) atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)s_hits);      // the contig's total: all the host needs to go on
+		}
 	}
 }
 
@@ -468,8 +471,7 @@ int stage1_seed(gsa_ctx *c)
 		if (attempt == 8) return gsa_fail(c, GSA_ERR_LIMIT, "seed buffers keep overflowing");
 		const size_t ctot = ccap * (size_t)n_chunks;
 		if (!dev_ensure<i32>(c, c->d_cand_s, ctot) || !dev_ensure<i32>(c, c->d_cand_len, ctot) || !dev_ensure<u64>(c, c->d_cand_x0, ctot) || !dev_ensure<i32>(c, c->d_cand_freq, ctot) || !dev_ensure<u32>(c, c->d_cand_cnt, (size_t)n_chunks)) return GSA_ERR_NOMEM;
-		GSA_CHECK(c, hipMemsetAsync(cnt, 0, 16 * sizeof(u64), st));
-		GSA_CHECK(c, hipMemsetAsync(c->d_chunk_hits.as<i32>() + n_chunks, 0, sizeof(i32), st));
+		// (the counters were left at zero by the previous contig's mirror kernel; chunk_hits[n_chunks] = 0 is written by chunk 0)
 		if (c->profiling || c->prof_seed) hipEventRecord(c->ev[0], st);
 		if (c->count_blocks)
 			hipLaunchKernelGGL((k_seed_wg<true, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
@@ -480,12 +482,15 @@ int stage1_seed(gsa_ctx *c)
 			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
 			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>());
 		if (c->profiling || c->prof_seed) hipEventRecord(c->ev[1], st);
+		// the counters go to pinned memory by a mirror kernel (no copy operation); the host waits for that, not for the
+		// scan of the per-chunk hit counts behind it
+		hipLaunchKernelGGL(k_mirror, dim3(1), dim3(256), 0, st, (const i32 *)cnt, 32, (i32 *)c->h_cnt, (const i32 *)nullptr, (i32 *)nullptr, (const i32 *)nullptr, 0, 0, (i32 *)cnt);
+		GSA_CHECK(c, hipEventRecord(c->ev[21], st));
 		int rcs = prim_exscan_i32(c, c->d_chunk_hits.as<i32>(), c->d_chunk_base.as<i32>(), (size_t)n_chunks + 1);
 		if (rcs) return rcs;
-		GSA_CHECK(c, hipMemcpyAsync(c->h_cnt, cnt, 16 * sizeof(u64), hipMemcpyDeviceToHost, st));
-		GSA_CHECK(c, hipMemcpyAsync(c->h_mail, c->d_chunk_base.as<i32>() + n_chunks, sizeof(i32), hipMemcpyDeviceToHost, st));
-		GSA_CHECK(c, hipStreamSynchronize(st));
-		const i32 tot = c->h_mail[0];
+		GSA_CHECK(c, hipEventSynchronize(c->ev[21]));
+		if (c->h_cnt[CNT_HITS] >= (1ull << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");
+		const i32 tot = (i32)c->h_cnt[CNT_HITS];
 		if (c->h_cnt[CNT_CAND] > ccap) { ccap = (size_t)c->h_cnt[CNT_CAND] + 256; c->cand_cap_per_chunk = ccap; continue; }
 		n_hits = tot;
 		break;
