@@ -81,8 +81,8 @@ def cpu_baseline(px, qry, tmp):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)      # the first ~50 contigs of a process can run 10 % slow (clock / power state ramp); a step is 1.2 ms
     ap.add_argument("--genome", type=int, default=5_000_000)
     ap.add_argument("--divergence", type=float, default=0.02)
     ap.add_argument("--no-cpu-baseline", action="store_true")
