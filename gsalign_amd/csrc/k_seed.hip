@@ -131,9 +131,9 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 				kk = kn ? 0 : k - (k >= di.primary); ll = ln ? 0 : l - (l >= di.primary);
 			}
 			const FmBlock bk = fm_load(di.bwt, kk >> 7), bl = fm_load(di.bwt, ll >> 7);
-			struct __attribute__((packed, aligned(4))) W3 { u32 a, b, c; };
-			const W3 w3 = *(const W3 *)(di.ref2 + (mode == M_TEXT ? (tp >> 4) : 0));      // 12 bytes of packed text, one access
-			const u32 r0 = w3.a, r1 = w3.b, r2 = w3.c;
+			struct __attribute__((packed, aligned(4))) W5 { u32 a, b, c, d, e; };
+			const W5 w5 = *(const W5 *)(di.ref2 + (mode == M_TEXT ? (tp >> 4) : 0));      // 20 bytes of packed text: a 64-base window
+			const u32 r0 = w5.a, r1 = w5.b, r2 = w5.c, r3 = w5.d, r4 = w5.e;
 			// one k-mer table entry: 16 bytes (one load) when the text is below 2^32, else 32
 			ulonglong2 e0 = {0, 0}, e1 = {0, 0};
 			if (E16) {
@@ -143,13 +143,34 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 				const ulonglong2 *pe = (const ulonglong2 *)((di.kmer ? di.kmer : (const u64 *)di.bwt) + (mode == M_KMER ? ((size_t)kid << 2) : 0));
 				e0 = pe[0]; e1 = pe[1];
 			}
+			// presence bits of s and of the three starts behind it: a search that dies below MinSeedLength moves on by ONE base,
+			// so walks cross the 14 bases in front of a mismatch start by start -- four of those per memory round trip
+			u32 pidk[3] = {0, 0, 0};
+			if (mode == M_KMER && di.pres_k) {
+#pragma unroll
+				for (int k2 = 0; k2 < 3; k2++) pidk[k2] = (u32)(q_bits64(qp, s + 1 + k2 < clen ? s + 1 + k2 : 0) & ((1ull << (2 * di.pres_k)) - 1));
+			}
 			const u32 pw = di.pres ? di.pres[mode == M_KMER ? (pid >> 5) : 0] : ~0u;
+			u32 pwk[3];
+#pragma unroll
+			for (int k2 = 0; k2 < 3; k2++) pwk[k2] = di.pres ? di.pres[mode == M_KMER ? (pidk[k2] >> 5) : 0] : ~0u;
 			const u64 sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
 			// ---- consume phase: straight-line, one predicated block per mode ----
 			bool ended = false;
 			if (mode == M_KMER) {
 				if (!((pw >> (pid & 31)) & 1u)) {       // the first MinSeedLength bases do not occur: no seed here, next start s+1
 					memo[s] = 1; s += 1; mode = M_ADV;
+					// ... and the same for the starts behind it, as long as nothing else is known about them (the advance step
+					// below owns every other rule: sub-range end, memoised hop, ambiguous bases, too close to the chunk end)
+					const int L = prm.MinSeedLength < 32 ? prm.MinSeedLength : 32;
+#pragma unroll
+					for (int k2 = 0; k2 < 3; k2++) {
+						if (s >= bend || memo[s]) break;
+						const u32 nb = q_nbits32(qn, s);
+						if (s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0) break;
+						if ((pwk[k2] >> (pidk[k2] & 31)) & 1u) break;          // occurs: needs its table entry (next iteration)
+						memo[s] = 1; s += 1;
+					}
 				} else {
 					const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k, walk it base by base
 					if (hit) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; }
@@ -159,9 +180,10 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 			} else if (mode == M_LOC) {
 				tp = (i64)sav + (pos - s); mode = M_TEXT;
 			} else if (mode == M_TEXT) {
-				const int got = text_match32(r0, r1, r2, tp, (i64)di.seq_len, qp, qn, pos, clen);
+				int got = text_match32(r0, r1, r2, tp, (i64)di.seq_len, qp, qn, pos, clen);
+				if (got == 32) got += text_match32(r2, r3, r4, tp + 32, (i64)di.seq_len, qp, qn, pos + 32, clen);
 				pos += got; tp += got;
-				ended = got < 32;
+				ended = got < 64;
 			} else if (mode == M_FM) {
 				const bool can = pos < clen && !q_isn(qn, pos < clen ? pos : 0);
 				const bool ok = can && fm_extend_loaded(di, ik, q_code(qp, pos < clen ? pos : 0), bk, bl, kk, ll, kn, ln, blk);
@@ -424,7 +446,7 @@ int build_presence(gsa_ctx *c)
 int build_dense_sa(gsa_ctx *c, u64 n_sa)
 {
 	{
-		const u64 words = c->di.seq_len / 16 + 4;
+		const u64 words = c->di.seq_len / 16 + 8;      // (the 64-base text window reads five words from any base)
 		if (!dev_ensure<u32>(c, c->d_ref2, words)) return GSA_ERR_NOMEM;
 		hipLaunchKernelGGL(k_pack_ref, dim3(grid_for(words, 256)), dim3(256), 0, c->stream, c->di.ref, c->di.seq_len, c->d_ref2.as<u32>(), words);
 		GSA_CHECK(c, hipGetLastError());
