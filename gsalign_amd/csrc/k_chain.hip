@@ -123,53 +123,84 @@ __global__ void k_next_window(i64 na, const i32 *__restrict__ a_q, const i32 *__
 // moves, and only then marks the starts.  Exactly the reference's segmentation (GSAlign.cpp:326-338).
 #define WALK_T 1024
 #define WALK_MAXTILES 8192
-#define WALK_LDS_CAND 24576      // up to this many candidates the chain itself sits in LDS (16-bit hop lengths, with 2048 tiles)
+#define WALK_LDS_CAND 20480      // up to this many candidates the whole problem sits in LDS (16-bit candidate ranks)
 __global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, const i32 *__restrict__ next, const i32 *__restrict__ nextk, i32 *ws)
 {
-	__shared__ i32 buf[2 * WALK_MAXTILES];
+	// one LDS arena, carved differently by the two paths: 16 KB tile bounds + 3 x 40 KB ranks + 2 x 2.5 KB bits here,
+	// 2 x 32 KB tile entries / exits in the global-memory path
+	__shared__ __attribute__((aligned(16))) i32 buf[2 * 2048 + 3 * WALK_LDS_CAND / 2 + 2 * WALK_LDS_CAND / 32];
+	static_assert(sizeof(buf) >= 2 * WALK_MAXTILES * sizeof(i32), "arena too small for the global-memory path");
+	uint16_t *s_nk = (uint16_t *)(buf + 2 * 2048);
+	uint16_t (*s_J)[WALK_LDS_CAND] = (uint16_t (*)[WALK_LDS_CAND])(s_nk + WALK_LDS_CAND);
+	u32 *s_on = (u32 *)(s_nk + 3 * WALK_LDS_CAND), *s_start = s_on + WALK_LDS_CAND / 32;
 	__shared__ int changed;
 	const int tid = threadIdx.x;
 	const i32 nC = candEx[na];
 	if (nC <= WALK_LDS_CAND) {
-		// candidate space: nk[k] = rank of the next start after candidate k; a hop is one LDS read
-		uint16_t *nk = (uint16_t *)buf;                      // hop length; 0xffff = look it up in global memory
-		i32 *entry = buf + WALK_LDS_CAND / 2, *exit_ = entry + 2048;
+		// Candidate space, everything in LDS.  nk[k] = hop to the next start after candidate k.  The array is cut into
+		// tiles; (1) one lane per tile computes, for EVERY candidate of its tile, where a walk from it leaves the tile
+		// (backwards: leave(k) = next(k) if that is outside, else leave(next(k))); (2) the tile entries of the true chain
+		// are the orbit of candidate 0 under leave(): pointer doubling, log2(tiles) rounds; (3) one lane per tile walks
+		// from its entry and sets a bit per start, all lanes scatter the marks.  (The earlier version re-walked tiles
+		// until no exit moved: 28 passes on the bench.)
+		uint16_t *nk = s_nk;
+		i32 *tile_kb = buf, *tile_ke = buf + 2048;
 		i64 ts = 256; while ((na + ts - 1) / ts > 2048) ts <<= 1;
 		const int nt = (int)((na + ts - 1) / ts);
-		for (int k = tid; k < nC; k += WALK_T) { const i32 d = nextk[k] - k; nk[k] = (uint16_t)(d < 0xffff ? d : 0xffff); }
-#define WALK_HOP(k) { const i32 d_ = nk[k]; k = d_ != 0xffff ? k + d_ : nextk[k]; }
-		for (int t = tid; t < nt; t += WALK_T) { entry[t] = candEx[(i64)t * ts]; exit_[t] = -1; }
-		__syncthreads();
-		for (;;) {
-			for (int t = tid; t < nt; t += WALK_T) {
-				if (exit_[t] >= 0) continue;
-				const i64 pe = (i64)(t + 1) * ts < na ? (i64)(t + 1) * ts : na;
-				const i32 ke = candEx[pe];
-				i32 k = entry[t];
-				while (k < ke) WALK_HOP(k)
-				exit_[t] = k;
-			}
-			if (tid == 0) changed = 0;
-			__syncthreads();
-			bool moved[2];
-			for (int t = tid, q = 0; t < nt; t += WALK_T, q++) {
-				moved[q] = false;
-				if (t == 0) continue;
-				const i32 ne = exit_[t - 1];
-				if (ne != entry[t]) { entry[t] = ne; moved[q] = true; changed = 1; }
-			}
-			__syncthreads();
-			const int again = changed;
-			for (int t = tid, q = 0; t < nt; t += WALK_T, q++) if (moved[q]) exit_[t] = -1;
-			__syncthreads();
-			if (!again) break;
+		for (int k0 = tid; k0 < nC; k0 += 8 * WALK_T) {
+			i32 d[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) { const int k = k0 + u * WALK_T; d[u] = k < nC ? nextk[k] - k : 0; }
+#pragma unroll
+			for (int u = 0; u < 8; u++) { const int k = k0 + u * WALK_T; if (k < nC) nk[k] = (uint16_t)(d[u] < 0xffff ? d[u] : 0xffff); }
 		}
+		for (int w = tid; w < (nC + 31) / 32; w += WALK_T) { s_on[w] = 0; s_start[w] = 0; }
 		for (int t = tid; t < nt; t += WALK_T) {
 			const i64 pe = (i64)(t + 1) * ts < na ? (i64)(t + 1) * ts : na;
-			const i32 ke = candEx[pe];
-			for (i32 k = entry[t]; k < ke;) { ws[clist[k]] = 1; WALK_HOP(k) }
+			tile_kb[t] = candEx[(i64)t * ts]; tile_ke[t] = candEx[pe];
 		}
-#undef WALK_HOP
+		__syncthreads();
+#define WALK_NEXT(k) (nk[k] != 0xffff ? (k) + (i32)nk[k] : nextk[k])
+		// (1) where does a walk from k leave k's tile (0xffff: past the last candidate)
+		for (int t = tid; t < nt; t += WALK_T) {
+			const i32 kb = tile_kb[t], ke = tile_ke[t];
+			for (i32 k = ke - 1; k >= kb; k--) {
+				const i32 nx = WALK_NEXT(k);
+				s_J[0][k] = nx >= ke ? (uint16_t)(nx < nC ? nx : 0xffff) : s_J[0][nx];
+			}
+		}
+		if (tid == 0 && nC > 0) s_on[0] = 1u;
+		__syncthreads();
+		// (2) orbit of candidate 0
+		int cur = 0;
+		for (int span = 1; span < nt; span <<= 1) {
+			for (int k = tid; k < nC; k += WALK_T) {
+				const u32 j = s_J[cur][k];
+				if (j != 0xffff) {
+					if ((s_on[k >> 5] >> (k & 31)) & 1u) atomicOr(&s_on[j >> 5], 1u << (j & 31));
+					s_J[cur ^ 1][k] = s_J[cur][j];
+				} else s_J[cur ^ 1][k] = 0xffff;
+			}
+			__syncthreads();
+			cur ^= 1;
+		}
+		// (3) marks
+		for (int t = tid; t < nt; t += WALK_T) {
+			const i32 kb = tile_kb[t], ke = tile_ke[t];
+			i32 e = -1;
+			for (i32 k = kb; k < ke; k++) if ((s_on[k >> 5] >> (k & 31)) & 1u) { e = k; break; }
+			if (e < 0) continue;
+			for (i32 k = e; k < ke; k = WALK_NEXT(k)) atomicOr(&s_start[k >> 5], 1u << (k & 31));
+		}
+		__syncthreads();
+		for (int k0 = tid; k0 < nC; k0 += 8 * WALK_T) {
+			i32 p[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) { const int k = k0 + u * WALK_T; p[u] = (k < nC && ((s_start[k >> 5] >> (k & 31)) & 1u)) ? clist[k] : -1; }
+#pragma unroll
+			for (int u = 0; u < 8; u++) if (p[u] >= 0) ws[p[u]] = 1;
+		}
+#undef WALK_NEXT
 		return;
 	}
 	// position space, the chain stays in global memory
