@@ -77,6 +77,8 @@ struct gsa_ctx {
 	DevBuf s_q, s_len, s_r, s_gid;                 // seeds in (PosDiff,qPos) order + group id
 	DevBuf d_flag, d_scan;                         // generic i32 flag / scan arrays (n+1)
 	i32 n_groups = 0;
+	bool pd_path = false, seed_view_ready = false, pdbm_dirty = true; i64 pd_words = 0;      // groups from the PosDiff bitmap (no PosDiff sort on the hot path)
+	DevBuf d_pdbm, d_gpre, d_key_c, d_val_c;      // bitmap of occupied PosDiff values, group starts below each word, (group, qPos, rank) keys
 	DevBuf g_beg;                                  // group start indices (n_groups+1)
 
 	// ---- stage 2 ---- (arrays over seeds of active groups, (group,qPos,rPos) order)
@@ -159,6 +161,7 @@ template <class T> static inline T *pin_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 int build_dense_sa(gsa_ctx *c, u64 n_sa);   // k_seed.hip
 int build_presence(gsa_ctx *c);             // k_seed.hip  (after MinSeedLength changed)
 int stage1_seed(gsa_ctx *c);          // k_seed.hip
+int seed_view_sort(gsa_ctx *c);       // k_seed.hip  (PosDiff-sorted seeds + groups: stage-1 view, or front of stage 2 without the PosDiff bitmap)
 int stage2_chain(gsa_ctx *c);         // k_chain.hip
 int launch_early_dp(gsa_ctx *c);      // k_chain.hip  (striped DP for the large gaps listed at the end of stage 2)
 int stage2_fetch_host(gsa_ctx *c);    // k_chain.hip  (counts + S2 block table for the stage-2 view)

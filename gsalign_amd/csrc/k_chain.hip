@@ -47,6 +47,62 @@ __global__ void k_gather_active(i64 na, const u32 *__restrict__ perm, const i32 
 	a_gb[i] = g_beg[g]; a_ge[i] = g_beg[g + 1];
 }
 
+// ---- A'. the same order without the PosDiff sort ---------------------------------------
+// Group starts from the bitmap of occupied PosDiff values (k_seed_select sets it): PosDiff b starts a group iff it is
+// occupied and none of b-1 .. b-MaxIndelSize is (GSAlign.cpp SeedGrouping: a jump of more than MaxIndelSize between
+// consecutive sorted values).  MaxIndelSize <= 31 here, so a word and its predecessor decide.
+__device__ __forceinline__ u32 pd_starts(const u32 *__restrict__ bm, i64 w, int max_indel)
+{
+	const u64 m = ((u64)bm[w] << 32) | (w > 0 ? bm[w - 1] : 0u);
+	if (max_indel <= 0) return (u32)(m >> 32);
+	u64 sm = m << 1; int cov = 1;                 // OR of m shifted up by 1 .. cov
+	while (2 * cov <= max_indel) { sm |= sm << cov; cov *= 2; }
+	if (cov < max_indel) sm |= sm << (max_indel - cov);
+	return (u32)((m & ~sm) >> 32);
+}
+struct OpPdScan {
+	const u32 *bm; int max_indel; i32 *gpre, *mail; i64 nw;
+	__device__ i32 value(i64 w, int) const { return __popc(pd_starts(bm, w, max_indel)); }
+	__device__ void emit(i64 w, const i32 *, const i32 *ex) const { gpre[w] = ex[0]; }
+	__device__ void done(const i32 *t) const { mail[M_NG] = t[0]; }
+};
+// key = (group, qPos, rank among the hits of the same start); val = index of the hit
+__global__ void k_pd_keys(i64 n, const u64 *__restrict__ hkey, const u32 *__restrict__ hval, const u32 *__restrict__ bm, const i32 *__restrict__ gpre, int max_indel, int qbits,
+                          u64 *key, u32 *val)
+{
+	GID(n);
+	const u64 k = hkey[i];
+	const i64 pd = (i64)(k >> qbits); const u32 q = (u32)(k & ((1ull << qbits) - 1));
+	const i64 w = pd >> 5; const int b = (int)(pd & 31);
+	const u32 st = pd_starts(bm, w, max_indel);
+	const i32 gid = gpre[w] + __popc(st & (b == 31 ? ~0u : ((2u << b) - 1))) - 1;
+	key[i] = ((u64)(u32)gid << (qbits + 7)) | ((u64)q << 7) | (hval[i] >> 16);
+	val[i] = (u32)i;
+}
+__global__ void k_pd_clear(i64 n, const u64 *__restrict__ hkey, int qbits, u32 *bm)
+{
+	GID(n);
+	bm[(i64)(hkey[i] >> qbits) >> 5] = 0;
+}
+__global__ void k_pd_heads(i64 n, const u64 *__restrict__ key, int gshift, i32 *g_beg)
+{
+	GID(n);
+	const i32 g = (i32)(key[i] >> gshift);
+	if (i == 0 || (i32)(key[i - 1] >> gshift) != g) g_beg[g] = (i32)i;
+	if (i == n - 1) g_beg[g + 1] = (i32)n;
+}
+__global__ void k_pd_gather(i64 n, const u64 *__restrict__ key, const u32 *__restrict__ perm, const u64 *__restrict__ hkey, const u32 *__restrict__ hval, int gshift, int qbits, i32 qlen,
+                            const i32 *__restrict__ g_beg, i32 *a_q, i32 *a_len, i64 *a_r, i32 *a_gb, i32 *a_ge)
+{
+	GID(n);
+	const u32 src = perm[i];
+	const u64 k = hkey[src];
+	const i32 q = (i32)(k & ((1ull << qbits) - 1)); const i64 pd = (i64)(k >> qbits) - qlen;
+	a_q[i] = q; a_len[i] = (i32)(hval[src] & 0xffffu); a_r[i] = pd + q;
+	const i32 g = (i32)(key[i] >> gshift);
+	a_gb[i] = g_beg[g]; a_ge[i] = g_beg[g + 1];
+}
+
 // ---- B. unique flags, break flags, window-start candidates -------------------------
 // (each struct below is one fused pass: value -> exclusive scan -> emit, see gsa_scan.h)
 // uniq: no other seed of the group shares qPos (GSAlign.cpp:316-325)
@@ -522,14 +578,30 @@ int stage2_chain(gsa_ctx *c)
 	if (c->profiling) hipEventRecord(c->ev[4], st);
 	// A. all seeds in (group, qPos, rPos) order
 	const i64 na = n; c->n_a = na;
-	ENS(i64, d_i64a, n + 2); ENS(i32, d_flag2, n + 2); ENS(i32, d_scan2, n + 2);
-	ENS(u64, d_key_a, n); ENS(u64, d_key_b, n); ENS(u32, d_val_a, n); ENS(u32, d_val_b, n);
-	LAUNCH(k_group_keys, n, n, c->s_q.as<i32>(), c->s_gid.as<i32>(), c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>());
+	ENS(i64, d_i64a, n + 2); ENS(i32, d_flag2, n + 2); ENS(i32, d_scan2, n + 2); ENS(i32, d_flag, n + 1); ENS(i32, d_scan, n + 1);
 	const int gbits = ceil_log2_u64((u64)n + 1);
-	RC(prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + gbits));
 	ENS(i32, a_q, na); ENS(i32, a_len, na); ENS(i64, a_r, na); ENS(i32, a_gb, na); ENS(i32, a_ge, na);
-	LAUNCH(k_gather_active, na, na, c->d_val_b.as<u32>(), c->s_q.as<i32>(), c->s_len.as<i32>(), c->s_r.as<i64>(), c->s_gid.as<i32>(), c->g_beg.as<i32>(),
-	       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>());
+	if (c->pd_path && c->qbits + 7 + gbits <= 64) {
+		// group ids from the PosDiff bitmap, then ONE sort by (group, qPos, rank) straight from the located hits
+		const i64 nw = c->pd_words;
+		ENS(i32, d_gpre, nw + 2); ENS(u64, d_key_c, n); ENS(u32, d_val_c, n); ENS(u64, d_key_b, n); ENS(u32, d_val_b, n); ENS(i32, g_beg, n + 2);
+		i32 *mail_ = c->d_mail.as<i32>();
+		{ OpPdScan op = { c->d_pdbm.as<u32>(), c->prm.MaxIndelSize, c->d_gpre.as<i32>(), mail_, nw }; RC((lb_launch<1>(c, nw, op))); }
+		LAUNCH(k_pd_keys, n, n, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->d_pdbm.as<u32>(), c->d_gpre.as<i32>(), c->prm.MaxIndelSize, c->qbits, c->d_key_c.as<u64>(), c->d_val_c.as<u32>());
+		LAUNCH(k_pd_clear, n, n, c->d_key_a.as<u64>(), c->qbits, c->d_pdbm.as<u32>());
+		c->pdbm_dirty = false;
+		RC(prim_sort_pairs_u64_u32(c, c->d_key_c.as<u64>(), c->d_key_b.as<u64>(), c->d_val_c.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + 7 + gbits));
+		LAUNCH(k_pd_heads, n, n, c->d_key_b.as<u64>(), c->qbits + 7, c->g_beg.as<i32>());
+		LAUNCH(k_pd_gather, n, n, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->qbits + 7, c->qbits, c->qlen, c->g_beg.as<i32>(),
+		       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>());
+	} else {
+		RC(seed_view_sort(c));
+		ENS(u64, d_key_a, n); ENS(u64, d_key_b, n); ENS(u32, d_val_a, n); ENS(u32, d_val_b, n);
+		LAUNCH(k_group_keys, n, n, c->s_q.as<i32>(), c->s_gid.as<i32>(), c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>());
+		RC(prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + gbits));
+		LAUNCH(k_gather_active, na, na, c->d_val_b.as<u32>(), c->s_q.as<i32>(), c->s_len.as<i32>(), c->s_r.as<i64>(), c->s_gid.as<i32>(), c->g_beg.as<i32>(),
+		       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>());
+	}
 	// B. unique / break flags, window chain
 	ENS(i32, a_uniq, na + 1); ENS(i32, a_cu, na + 1); ENS(i32, a_alive, na + 1); ENS(i32, a_brk, na + 1); ENS(i32, a_aurank, na + 1);
 	ENS(i32, a_aulist, na + 1); ENS(i32, a_next, na + 1); ENS(i32, a_ws, na + 1); ENS(i32, a_wid, na + 1); ENS(i32, a_runinfo, na + 1);

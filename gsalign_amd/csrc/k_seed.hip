@@ -321,12 +321,14 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, const u32 *__restrict__ cand_cnt, const i32 *__restrict__ cand_s, const i32 *__restrict__ cand_len,
                                                       const u64 *__restrict__ cand_x0, const i32 *__restrict__ cand_freq, const u32 *__restrict__ onpath,
-                                                      const i32 *__restrict__ hit_base, i32 qlen, int qbits, u64 *key, u32 *val)
+                                                      const i32 *__restrict__ hit_base, i32 qlen, int qbits, u64 *key, u32 *val, u32 *pdbm)
 {
 	__shared__ u32 s_off;
+	__shared__ unsigned long long s_w[64]; __shared__ u32 s_b[64];
 	const u32 chunk = blockIdx.x, nc = cand_cnt[chunk];
 	const size_t cbase = (size_t)chunk * cand_cap;
 	if (threadIdx.x == 0) s_off = 0;
+	if (threadIdx.x < 64) { s_w[threadIdx.x] = ~0ull; s_b[threadIdx.x] = 0; }
 	__syncthreads();
 	const u64 base = (u64)hit_base[chunk];
 	for (u32 i = threadIdx.x; i < nc; i += blockDim.x) {
@@ -339,9 +341,29 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 		for (u32 h = 0; h < f; h++) {
 			const u64 r = fm_locate(di, x0 + h);
 			const i64 pd = (i64)r - s + qlen;
+			// the hits of one start, ranked by position: the tie-break of the (group, qPos) order, which the reference gets
+			// from a stable sort of the PosDiff order
+			u32 rank = 0;
+			if (f > 1) for (u32 h2 = 0; h2 < f; h2++) rank += fm_locate(di, x0 + h2) < r ? 1u : 0u;
 			key[off + h] = ((u64)pd << qbits) | (u32)s;
-			val[off + h] = len;
+			val[off + h] = len | (rank << 16);
+			// occupied PosDiff values: groups without sorting by PosDiff (k_chain.hip).  Collected per workgroup in LDS, one
+			// global OR per touched word at the end: a chunk's hits sit in two or three words and the whole contig's main
+			// diagonal in one cache line -- an atomic (or even a look) per hit queues 75 k operations on that line
+			if (pdbm) {
+				const unsigned long long w = (unsigned long long)(pd >> 5); const u32 bit = 1u << (pd & 31);
+				int hh = (int)(w & 63), tries = 0;
+				for (; tries < 64; tries++, hh = (hh + 1) & 63) {
+					const unsigned long long prev = atomicCAS(&s_w[hh], ~0ull, w);
+					if (prev == ~0ull || prev == w) { atomicOr(&s_b[hh], bit); break; }
+				}
+				if (tries == 64) atomicOr(&pdbm[w], bit);
+			}
 		}
+	}
+	if (pdbm) {
+		__syncthreads();
+		if (threadIdx.x < 64 && s_w[threadIdx.x] != ~0ull) atomicOr(&pdbm[s_w[threadIdx.x]], s_b[threadIdx.x]);
 	}
 }
 
@@ -360,7 +382,7 @@ struct OpDecodeGroup {
 	{
 		const u64 k = key[i];
 		const i32 qp = (i32)(k & ((1ull << qbits) - 1)); const i64 pd = (i64)(k >> qbits) - qlen;
-		s_q[i] = qp; s_len[i] = (i32)val[i]; s_r[i] = pd + qp;
+		s_q[i] = qp; s_len[i] = (i32)(val[i] & 0xffffu); s_r[i] = pd + qp;
 		const i32 g = ex[0] + v[0] - 1;
 		s_gid[i] = g;
 		if (v[0]) g_beg[g] = (i32)i;
@@ -519,10 +541,22 @@ int stage1_seed(gsa_ctx *c)
 		break;
 	}
 	const size_t hcap = (size_t)n_hits + 64;
+	// Groups: a new group starts where the sorted PosDiff values jump by more than MaxIndelSize.  With a bitmap of the
+	// occupied PosDiff values that needs no sort: group id = number of group starts at or below a hit's PosDiff (a scan
+	// over the bitmap, stage 2).  The PosDiff-sorted view of the seeds (stage-1 view of the C ABI) is then built on demand.
+	const u64 pd_words = (((u64)(2 * c->G) + (u64)qlen + 2) >> 5) + 2;
+	c->pd_path = n_hits > 0 && c->prm.MaxIndelSize >= 0 && c->prm.MaxIndelSize <= 31 && pd_words <= 64ull * (u64)n_hits + 65536 && !getenv("GSA_NO_PDBITMAP");
+	c->seed_view_ready = false;
+	if (c->pd_path) {
+		const size_t cap0 = c->d_pdbm.cap;
+		if (!dev_ensure<u32>(c, c->d_pdbm, (size_t)pd_words + 2)) return GSA_ERR_NOMEM;
+		if (c->d_pdbm.cap != cap0 || c->pdbm_dirty) GSA_CHECK(c, hipMemsetAsync(c->d_pdbm.p, 0, c->d_pdbm.cap, st));
+		c->pdbm_dirty = true; c->pd_words = (i64)pd_words;
+	}
 	if (n_hits > 0) {
 		if (!dev_ensure<u64>(c, c->d_key_a, hcap) || !dev_ensure<u32>(c, c->d_val_a, hcap)) return GSA_ERR_NOMEM;
 		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), 0, st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
-		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), qlen, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>());
+		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), qlen, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr);
 	}
 	if (c->profiling) hipEventRecord(c->ev[2], st);
 	c->counters[0] = c->h_cnt[CNT_OCCBLK]; c->counters[1] = 0; c->counters[2] = (u64)n_hits; c->counters[3] = (u64)n_hits; c->counters[7] = c->h_cnt[CNT_OCCBLK_ALL];
@@ -530,7 +564,22 @@ int stage1_seed(gsa_ctx *c)
 	c->n_seeds = n_hits;
 	if (n_hits == 0) { if (c->profiling) { GSA_CHECK(c, hipStreamSynchronize(st)); float ms; hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms; } return GSA_OK; }
 	if (n_hits >= (1ll << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");
-	const size_t n = (size_t)n_hits;
+	if (c->pd_path) {
+		if (c->profiling) hipEventRecord(c->ev[3], st);
+		c->n_groups = -1; c->ev_pending |= 1;
+		return GSA_OK;
+	}
+	return seed_view_sort(c);
+}
+
+// Seeds in PosDiff order with their group ids (CompByPosDiff + SeedGrouping, a5/a6): always for the stage-1 view of
+// the C ABI, and as the front of stage 2 when the PosDiff bitmap does not apply.
+int seed_view_sort(gsa_ctx *c)
+{
+	if (c->seed_view_ready || c->n_seeds == 0) return GSA_OK;
+	hipStream_t st = c->stream;
+	const i32 qlen = c->qlen;
+	const size_t n = (size_t)c->n_seeds, hcap = n + 64;
 	if (!dev_ensure<u64>(c, c->d_key_b, hcap) || !dev_ensure<u32>(c, c->d_val_b, hcap)) return GSA_ERR_NOMEM;
 	int rc = prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), n, 0, c->qbits + c->pdbits);
 	if (rc) return rc;
@@ -542,10 +591,11 @@ int stage1_seed(gsa_ctx *c)
 		rc = lb_launch<1>(c, (i64)n, op);
 		if (rc) return rc;
 	}
-	if (c->profiling) hipEventRecord(c->ev[3], st);
+	if (c->profiling && !c->pd_path) hipEventRecord(c->ev[3], st);
 	// the group count stays on the device (mailbox); nothing downstream needs it on the host
 	c->n_groups = -1;
-	c->ev_pending |= 1;
+	if (!c->pd_path) c->ev_pending |= 1;
+	c->seed_view_ready = true;
 	return GSA_OK;
 }
 
