@@ -177,3 +177,69 @@ def test_degenerate_queries(gpu, ora, golden_dir):
         gpu.align_contig(seq); got = gpu.blocks_as_dump(with_aln=True)
         for k, v in want.items():
             assert np.array_equal(got[k], v), (name, k)
+
+
+def _check_result_invariants(idx, qry, r):
+    """Size-independent properties of a finished result (sizes the oracle cannot reach): records tile their block, seeds are
+    exact matches, gapped strings spell exactly the two fragments, lengths and scores are what the strings say."""
+    NT4 = np.full(256, 4, np.uint8)
+    for k, ch in enumerate("ACGT"):
+        NT4[ord(ch)] = k; NT4[ord(ch.lower())] = k
+    text = idx.ref                                      # 2G ASCII bases: forward strand, then its reverse complement (indexio.unpack_pac)
+    assert text.size == 2 * idx.G
+    B, F, a1, a2 = r["blocks"], r["frags"], r["aln1"], r["aln2"]
+    assert B.size > 0
+    # records of a block are consecutive and tile it in both sequences
+    for b in B:
+        f = F[b["frag_off"]:b["frag_off"] + b["n_frag"]]
+        assert np.array_equal(f["qpos"][1:], (f["qpos"] + f["qlen"])[:-1]) and np.array_equal(f["rpos"][1:], (f["rpos"] + f["rlen"])[:-1])
+        seed = f["bseed"] != 0
+        assert b["aln_len"] == int(f["qlen"][seed].sum()) + int(f["aln_len"][~seed].sum())
+    used = np.concatenate([np.arange(o, o + n) for o, n in zip(B["frag_off"], B["n_frag"])])
+    Fu = F[used]
+    seed = Fu["bseed"] != 0
+    # seeds: equal lengths, identical bases (case-insensitive)
+    S = Fu[seed]
+    assert np.array_equal(S["qlen"], S["rlen"])
+    def gather(arr, pos, ln):
+        ln = ln.astype(np.int64); tot = int(ln.sum())
+        if tot == 0:
+            return np.zeros(0, arr.dtype)
+        starts = np.repeat(pos.astype(np.int64) - np.concatenate([[0], np.cumsum(ln)[:-1]]), ln)
+        return arr[starts + np.arange(tot, dtype=np.int64)]
+    assert np.array_equal(NT4[gather(qry, S["qpos"], S["qlen"])], NT4[gather(text, S["rpos"], S["rlen"])])
+    # gaps: the two strings, gap characters removed, spell the reference and the query fragment
+    Gp = Fu[~seed]
+    s1 = gather(a1, Gp["aln_off"], Gp["aln_len"]); s2 = gather(a2, Gp["aln_off"], Gp["aln_len"])
+    assert s1.size == s2.size and not np.any((s1 == ord("-")) & (s2 == ord("-")))
+    assert np.array_equal(s1[s1 != ord("-")], gather(text, Gp["rpos"], Gp["rlen"]))
+    assert np.array_equal(s2[s2 != ord("-")], gather(qry, Gp["qpos"], Gp["qlen"]))
+    # block score = seed bases + identical columns of the gaps (CountIdenticalPairs, ProcessCandidateAlignment.cpp:38-47)
+    ident = (NT4[s1] == NT4[s2]).astype(np.int64)
+    csum = np.concatenate([[0], np.cumsum(ident)])
+    ge = np.cumsum(Gp["aln_len"].astype(np.int64)); gb = ge - Gp["aln_len"]
+    gap_score = csum[ge] - csum[gb]
+    per_frag = np.zeros(Fu.size, np.int64); per_frag[seed] = S["qlen"]; per_frag[~seed] = gap_score
+    fe = np.cumsum(B["n_frag"].astype(np.int64)); fb = fe - B["n_frag"]
+    cs = np.concatenate([[0], np.cumsum(per_frag)])
+    assert np.array_equal(cs[fe] - cs[fb], B["score"].astype(np.int64))
+
+
+@pytest.mark.parametrize("total,ncontig,div,seed", [(24000000, 2, 0.015, 31), (100000000, 1, 0.01, 32)])
+def test_full_size_result_invariants(tmp_path, total, ncontig, div, seed):
+    """BASELINE-sized and larger pairs: no oracle at this size, so the result is checked against itself and the inputs."""
+    from gsalign_amd import hostlib
+    refs, qrys = synth.make_pair(total, ncontig, div, seed=seed)
+    if ncontig > 1:
+        qrys[-1] = (qrys[-1][0], synth.revcomp(qrys[-1][1]))
+    rf, px = str(tmp_path / "r.fa"), str(tmp_path / "r")
+    synth.write_fasta(rf, refs); hostlib.build_index(rf, px)
+    idx = indexio.load_index(px)
+    g = capi.Aligner(idx)
+    for name, seq in qrys:
+        g.align_contig(seq)
+        r = g.blocks()
+        _check_result_invariants(idx, seq, r)
+        cov = int(r["blocks"]["aln_len"].sum())
+        assert cov > 0.9 * seq.size, (name, cov)
+    g.close()
