@@ -361,7 +361,6 @@ int stage78_extend(gsa_ctx *c)
 	if (!pin_ensure<i32>(c, c->p_jpatch, 2 * (size_t)c->n_jobs + 2) || !pin_ensure<char>(c, c->p_tail, t_total + 256) || !pin_ensure<i32>(c, c->p_blk, (size_t)3 * (nfb + 1) + 8)) return GSA_ERR_NOMEM;
 	ENS(uint8_t, d_tail, t_total + 256);
 	uint8_t *d_tail = c->d_tail.as<uint8_t>(), *d_aln1 = d_tail + t_aln1, *d_aln2 = d_tail + t_aln2;
-	i32 *d_patch = (i32 *)(d_tail + t_patch);
 	c->h_tmail = (const i32 *)c->p_tail.p; c->h_tpatch = (const i32 *)((char *)c->p_tail.p + t_patch);
 	c->h_taln1 = (char *)c->p_tail.p + t_aln1; c->h_taln2 = (char *)c->p_tail.p + t_aln2;
 	// ---- behind the small jobs (stream_aux[1]; when there is no small job it starts at the fork) ----
@@ -373,12 +372,20 @@ int stage78_extend(gsa_ctx *c)
 		GSA_CHECK(c, hipMemcpyAsync(c->p_jpatch.as<i32>() + c->n_jobs, c->j_nops.p, (size_t)c->n_jobs * 4, hipMemcpyDeviceToHost, sc));
 	}
 	GSA_CHECK(c, hipEventRecord(c->ev[15], sc));
+	// the string pools go home behind the small gaps' strings too (same stream, idle by then): the large jobs' strings are
+	// written straight into the pinned copy later, so nothing is left to copy behind the striped kernel
+	const bool pools_early = npatch > 0 && c->n_aln > 0;
 	const i32 *jlarge = c->d_dp_large.as<i32>() + 3 * ((size_t)nju + 1);
 	i32 *c_len = c->d_flag.as<i32>(), *c_score = c->f_score.as<i32>();
 	hipLaunchKernelGGL(k_materialize, dim3((unsigned)((nfu + 255) / 256)), dim3(256), 0, sx, mail + M_NF, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(),
 	                   jlarge, c->j_nops.as<i32>(), c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
 	                   c->f_rec.as<gsa_frag>(), d_aln1, d_aln2, c_len, c_score);
 	GSA_CHECK(c, hipEventRecord(c->ev[17], sx));      // the strings of everything but the large jobs are written
+	if (pools_early) {
+		GSA_CHECK(c, hipStreamWaitEvent(sc, c->ev[17], 0));
+		GSA_CHECK(c, hipMemcpyAsync((char *)c->p_tail.p + t_aln1, d_aln1, t_total - t_aln1, hipMemcpyDeviceToHost, sc));
+		GSA_CHECK(c, hipEventRecord(c->ev[23], sc));
+	}
 	// per-block sums via prefix sums (the large jobs' records count as zero here, the host adds them from the patch list)
 	u32 *ps_score = c->d_flag2.as<u32>();      // (the small kernel's order array is free again)
 	{ OpRecSums op = { nfu, c_len, c_score, c->d_scan.as<u32>(), ps_score, mail }; RC((lb_launch<2>(c, nfu, op, sx))); }
@@ -394,18 +401,21 @@ int stage78_extend(gsa_ctx *c)
 	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[13], 0));      // per-block sums are on the host
 	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[15], 0));      // the records are on the host
 	if (npatch > 0) {
+		// the large jobs' records: strings, patch list and the final mailbox are stored straight into pinned memory by the
+		// kernels (coalesced rows of 256 bytes): the host only waits for the last kernel
+		if (pools_early) GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[23], 0));      // (the pools' copy must not overwrite them)
+		uint8_t *h_aln1 = (uint8_t *)c->h_taln1, *h_aln2 = (uint8_t *)c->h_taln2; i32 *h_patch = (i32 *)c->h_tpatch, *h_mail = (i32 *)c->h_tmail;
 		if (kl.nlarge > 0)
 			hipLaunchKernelGGL(k_materialize_large, dim3((unsigned)kl.nlarge), dim3(256), 0, st, kl.nlarge, c->d_dp_large.as<i32>(), c->j_frag.as<i32>(), c->j_nops.as<i32>(),
 			                   c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
-			                   c->f_rec.as<gsa_frag>(), d_aln1, d_aln2, d_patch, mail, c->n_early > 0 ? (i32 *)nullptr : (i32 *)d_tail);
+			                   c->f_rec.as<gsa_frag>(), h_aln1, h_aln2, h_patch, mail, c->n_early > 0 ? (i32 *)nullptr : h_mail);
 		if (c->n_early > 0) {
 			GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[14], 0));      // the early striped launch (stream_aux[0])
 			c->early_consumed = true;
 			hipLaunchKernelGGL(k_materialize_large, dim3((unsigned)c->n_early), dim3(256), 0, st, c->n_early, (const i32 *)nullptr, c->e_rec.as<i32>(), c->e_nops.as<i32>(),
 			                   c->d_alnoff.as<i64>(), c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
-			                   c->f_rec.as<gsa_frag>(), d_aln1, d_aln2, d_patch + 3 * (size_t)kl.nlarge, mail, (i32 *)d_tail);
+			                   c->f_rec.as<gsa_frag>(), h_aln1, h_aln2, h_patch + 3 * (size_t)kl.nlarge, mail, h_mail);
 		}
-		GSA_CHECK(c, hipMemcpyAsync(c->p_tail.p, d_tail, t_total, hipMemcpyDeviceToHost, st));
 	} else {
 		// no large job: the mailbox goes home by itself, the pools (if any) behind it
 		GSA_CHECK(c, hipMemcpyAsync(c->p_tail.p, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
