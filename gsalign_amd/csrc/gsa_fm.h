@@ -15,8 +15,13 @@
 
 __device__ __forceinline__ int gsa_nt4(uint8_t c)
 {
-	// nst_nt4_table (BWT_Index/bntseq.c:40-57): ACGT/acgt -> 0..3, everything else 4
-	switch (c | 0x20) { case 'a': return 0; case 'c': return 1; case 'g': return 2; case 't': return 3; default: return 4; }
+	// nst_nt4_table (BWT_Index/bntseq.c:40-57): ACGT/acgt -> 0..3, everything else 4.  Pure ALU: as a switch the
+	// compiler turns it into a lookup table in memory, i.e. a dependent load per base inside every base-wise loop.
+	const u32 l = (u32)(c | 0x20) - 'a';                              // a 0, c 2, g 6, t 19
+	const u32 x = (l >> 1) & 3;                                       // a 0, c 1, g 3 (t apart)
+	const bool ok = l < 32 && ((0x00080045u >> l) & 1u);
+	const u32 code = l == 19 ? 3u : (x ^ (x >> 1));                   // a 0, c 1, g 3 ^ 1 = 2, t 3
+	return ok ? (int)code : 4;
 }
 
 struct FmBlock { uint4 c0, c1, w0, w1; };

@@ -344,18 +344,28 @@ __global__ void k_window_mode(i64 cap, const Bucket *__restrict__ tab, unsigned 
 	atomicMax(&wbest[(u32)(k >> 32)], ((unsigned long long)(tab[i].cnt + 1u) << 32) | (0xFFFFFFFFu - (u32)k));
 }
 
+// (the seeds of a window are neighbours: their contributions are summed along the wavefront first, one pair of atomics
+//  per window and wavefront instead of one per seed)
 __global__ void k_window_avg(i64 na, const i32 *__restrict__ slot_of, const Bucket *__restrict__ tab, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r,
-                             const unsigned long long *__restrict__ wbest, unsigned long long *wsum, i32 *wn)
+                             const unsigned long long *__restrict__ wbest, const i32 *__restrict__ ws, const i32 *__restrict__ wsEx, unsigned long long *wsum, i32 *wn)
 {
-	GID(na);
-	const i32 sl = slot_of[i];
-	if (sl < 0) return;
-	const unsigned long long k = tab[sl].key; const u32 w = (u32)(k >> 32);
-	const i64 kk = (i64)(u32)k, mode = (i64)(0xFFFFFFFFu - (u32)wbest[w]);      // (shifted buckets: only their difference is used)
-	if (d_llabs(kk - mode) < 3) {                                            // surviving bucket (:256)
-		atomicAdd(&wsum[w], (unsigned long long)(a_r[i] - a_q[i]));
-		atomicAdd(&wn[w], 1);
+	const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	u32 w = 0xffffffffu; unsigned long long vs = 0; i32 vn = 0;
+	if (i < na) {
+		w = (u32)(wsEx[i] + ws[i] - 1);
+		const i32 sl = slot_of[i];
+		if (sl >= 0) {
+			const i64 kk = (i64)(u32)tab[sl].key, mode = (i64)(0xFFFFFFFFu - (u32)wbest[w]);      // (shifted buckets: only their difference is used)
+			if (d_llabs(kk - mode) < 3) { vs = (unsigned long long)(a_r[i] - a_q[i]); vn = 1; }     // surviving bucket (:256)
+		}
 	}
+	for (int d = 1; d < 64; d <<= 1) {
+		const u32 ow = __shfl_up(w, d); const unsigned long long os = __shfl_up(vs, d); const i32 on = __shfl_up(vn, d);
+		if (lane >= d && ow == w) { vs += os; vn += on; }
+	}
+	const u32 nw = __shfl_down(w, 1);
+	if (i < na && vn > 0 && (lane == 63 || nw != w)) { atomicAdd(&wsum[w], vs); atomicAdd(&wn[w], vn); }
 }
 
 __global__ void k_outlier_kill(i64 na, const i32 *__restrict__ slot_of, const Bucket *__restrict__ tab, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r,
@@ -625,7 +635,7 @@ int stage2_chain(gsa_ctx *c)
 	{ OpWindowBuckets op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, bmin, capbits, wsEx, slot_of, c->d_btab.as<Bucket>(),
 	                         c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>() }; RC((lb_launch<1>(c, na, op))); }
 	LAUNCH(k_window_mode, cap, cap, c->d_btab.as<Bucket>(), c->w_best.as<unsigned long long>());
-	LAUNCH(k_window_avg, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(), c->w_best.as<unsigned long long>(),
+	LAUNCH(k_window_avg, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(), c->w_best.as<unsigned long long>(), ws, wsEx,
 	       c->w_sum.as<unsigned long long>(), c->w_n.as<i32>());
 	LAUNCH(k_outlier_kill, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(),
 	       c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->G, c->prm.MaxIndelSize, alive);
