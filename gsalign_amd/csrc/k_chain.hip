@@ -79,11 +79,6 @@ __global__ void k_pd_keys(i64 n, const u64 *__restrict__ hkey, const u32 *__rest
 	key[i] = ((u64)(u32)gid << (qbits + 7)) | ((u64)q << 7) | (hval[i] >> 16);
 	val[i] = (u32)i;
 }
-__global__ void k_pd_clear(i64 n, const u64 *__restrict__ hkey, int qbits, u32 *bm)
-{
-	GID(n);
-	bm[(i64)(hkey[i] >> qbits) >> 5] = 0;
-}
 __global__ void k_pd_heads(i64 n, const u64 *__restrict__ key, int gshift, i32 *g_beg)
 {
 	GID(n);
@@ -92,13 +87,14 @@ __global__ void k_pd_heads(i64 n, const u64 *__restrict__ key, int gshift, i32 *
 	if (i == n - 1) g_beg[g + 1] = (i32)n;
 }
 __global__ void k_pd_gather(i64 n, const u64 *__restrict__ key, const u32 *__restrict__ perm, const u64 *__restrict__ hkey, const u32 *__restrict__ hval, int gshift, int qbits, i32 qlen,
-                            const i32 *__restrict__ g_beg, i32 *a_q, i32 *a_len, i64 *a_r, i32 *a_gb, i32 *a_ge)
+                            const i32 *__restrict__ g_beg, i32 *a_q, i32 *a_len, i64 *a_r, i32 *a_gb, i32 *a_ge, u32 *bm)
 {
 	GID(n);
 	const u32 src = perm[i];
 	const u64 k = hkey[src];
 	const i32 q = (i32)(k & ((1ull << qbits) - 1)); const i64 pd = (i64)(k >> qbits) - qlen;
 	a_q[i] = q; a_len[i] = (i32)(hval[src] & 0xffffu); a_r[i] = pd + q;
+	bm[(pd + qlen) >> 5] = 0;                       // (the bitmap is done with: wiped for the next contig by the hits that set it)
 	const i32 g = (i32)(key[i] >> gshift);
 	a_gb[i] = g_beg[g]; a_ge[i] = g_beg[g + 1];
 }
@@ -196,7 +192,7 @@ __global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__re
 		// Candidate space, everything in LDS.  nk[k] = hop to the next start after candidate k.  The array is cut into
 		// tiles; (1) one lane per tile computes, for EVERY candidate of its tile, where a walk from it leaves the tile
 		// (backwards: leave(k) = next(k) if that is outside, else leave(next(k))); (2) the tile entries of the true chain
-		// are the orbit of candidate 0 under leave(): pointer doubling, log2(tiles) rounds; (3) one lane per tile walks
+		// are the orbit of candidate 0 under leave(), chased by one lane; (3) one lane per tile walks
 		// from its entry and sets a bit per start, all lanes scatter the marks.  (The earlier version re-walked tiles
 		// until no exit moved: 28 passes on the bench.)
 		uint16_t *nk = s_nk;
@@ -225,21 +221,13 @@ __global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__re
 				s_J[0][k] = nx >= ke ? (uint16_t)(nx < nC ? nx : 0xffff) : s_J[0][nx];
 			}
 		}
-		if (tid == 0 && nC > 0) s_on[0] = 1u;
 		__syncthreads();
-		// (2) orbit of candidate 0
-		int cur = 0;
-		for (int span = 1; span < nt; span <<= 1) {
-			for (int k = tid; k < nC; k += WALK_T) {
-				const u32 j = s_J[cur][k];
-				if (j != 0xffff) {
-					if ((s_on[k >> 5] >> (k & 31)) & 1u) atomicOr(&s_on[j >> 5], 1u << (j & 31));
-					s_J[cur ^ 1][k] = s_J[cur][j];
-				} else s_J[cur ^ 1][k] = 0xffff;
-			}
-			__syncthreads();
-			cur ^= 1;
+		// (2) orbit of candidate 0: one lane chases it (one dependent LDS read per tile, ~30 ns each: 9 us for 300 tiles;
+		//     pointer doubling over all candidates took 23)
+		if (tid == 0 && nC > 0) {
+			for (u32 k = 0; k != 0xffff; k = s_J[0][k]) s_on[k >> 5] |= 1u << (k & 31);
 		}
+		__syncthreads();
 		// (3) marks
 		for (int t = tid; t < nt; t += WALK_T) {
 			const i32 kb = tile_kb[t], ke = tile_ke[t];
@@ -598,12 +586,11 @@ int stage2_chain(gsa_ctx *c)
 		i32 *mail_ = c->d_mail.as<i32>();
 		{ OpPdScan op = { c->d_pdbm.as<u32>(), c->prm.MaxIndelSize, c->d_gpre.as<i32>(), mail_, nw }; RC((lb_launch<1>(c, nw, op))); }
 		LAUNCH(k_pd_keys, n, n, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->d_pdbm.as<u32>(), c->d_gpre.as<i32>(), c->prm.MaxIndelSize, c->qbits, c->d_key_c.as<u64>(), c->d_val_c.as<u32>());
-		LAUNCH(k_pd_clear, n, n, c->d_key_a.as<u64>(), c->qbits, c->d_pdbm.as<u32>());
-		c->pdbm_dirty = false;
 		RC(prim_sort_pairs_u64_u32(c, c->d_key_c.as<u64>(), c->d_key_b.as<u64>(), c->d_val_c.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + 7 + gbits));
 		LAUNCH(k_pd_heads, n, n, c->d_key_b.as<u64>(), c->qbits + 7, c->g_beg.as<i32>());
 		LAUNCH(k_pd_gather, n, n, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->qbits + 7, c->qbits, c->qlen, c->g_beg.as<i32>(),
-		       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>());
+		       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), c->d_pdbm.as<u32>());
+		c->pdbm_dirty = false;
 	} else {
 		RC(seed_view_sort(c));
 		ENS(u64, d_key_a, n); ENS(u64, d_key_b, n); ENS(u32, d_val_a, n); ENS(u32, d_val_b, n);
