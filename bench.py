@@ -124,10 +124,12 @@ def main():
         return None
 
     def timed_step():
-        gpu.run_to(8)                # S1..S7 + identity filter; records and gapped strings land in host memory
+        gpu.run_to(8)                # S1..S7 + identity filter; blocks, records and gapped strings land in host memory
+        if world == 1:
+            return gpu.raw_result().n_blocks      # (one rank: nothing to gather, the result is where the caller reads it)
         recs = gpu.block_records()
-        shard.gather_block_records(recs, np.full(recs.shape[0], rank, np.int32), device=dev if world > 1 else None)
-        return recs
+        shard.gather_block_records(recs, np.full(recs.shape[0], rank, np.int32), device=dev)
+        return recs.shape[0]
 
     for _ in range(args.warmup):
         step(); timed_step()
@@ -185,7 +187,7 @@ def main():
                             "note": "1 direction byte per DP cell + the two fragments; time is the whole extend stage (job list, DP, strings, results to the host); the large gaps start earlier, under the refine stage"},
             "stage_ms": {"seed_search": float(tm[0]), "locate": float(tm[1]), "sort_group": float(tm[2]), "chain": float(tm[3]), "refine": float(tm[4]), "extend": float(tm[5]), "host_lists": float(tm[7])},
             "counters": {"occ_blocks_algorithmic": alg_occ_blocks, "occ_blocks_read": int(cnt[7]), "lf_steps": int(cnt[1]), "hits": int(cnt[2]), "dp_cells": int(cnt[4]), "dp_jobs": int(cnt[5]),
-                         "blocks": int(res.shape[0]), "records": int(gpu.raw_result().n_frags)},
+                         "blocks": int(res), "records": int(gpu.raw_result().n_frags)},
         }
         if not args.no_cpu_baseline:
             try:
