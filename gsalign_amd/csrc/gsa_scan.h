@@ -22,7 +22,11 @@ struct LbArgs {
 	u32 *ticket;                     // never reset: tile = ticket - base
 	u32 base, epoch;
 	i32 *err;                        // set when a spin runs into its bound (a bug, not a state)
+	u32 *finished;                   // tiles that are through (only Ops with a finish() hook count; the last one resets it)
 };
+#include <type_traits>
+template <class T, class = void> struct lb_has_finish : std::false_type {};
+template <class T> struct lb_has_finish<T, std::void_t<decltype(&T::finish)>> : std::true_type {};
 
 __device__ __forceinline__ unsigned long long lb_pack(u32 epoch, u32 flag, u32 val) { return ((unsigned long long)(epoch & 0x3fffffffu) << 34) | ((unsigned long long)flag << 32) | val; }
 
@@ -117,6 +121,20 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 		}
 	}
 	if (n == 0 && tile == 0 && tid == 0) { i32 tt[NV]; for (int c = 0; c < NV; c++) tt[c] = 0; op.done(tt); }
+	// Ops with a finish(tid) hook: the workgroup that is through LAST runs it (all 256 threads) -- everything every tile
+	// emitted is visible to it.  Used to put counts and list heads into pinned memory for the host without another launch.
+	if constexpr (lb_has_finish<Op>::value) {
+		__shared__ int s_last;
+		__syncthreads();
+		if (tid == 0) {
+			__threadfence();
+			const u32 t = atomicAdd(lb.finished, 1u);
+			s_last = t == gridDim.x - 1 ? 1 : 0;
+			if (s_last) { *lb.finished = 0; __threadfence(); }
+		}
+		__syncthreads();
+		if (s_last) op.finish(tid);
+	}
 }
 
 // The host's look at device results without a copy operation: one small workgroup writes some mailbox words and the head
@@ -152,7 +170,7 @@ static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op, hipStream_t stream 
 	}
 	LbArgs lb;
 	lb.status[0] = c->d_lb_status[0].as<unsigned long long>(); lb.status[1] = c->d_lb_status[1].as<unsigned long long>();
-	lb.ticket = c->d_mail.as<u32>() + M_TICKET; lb.base = c->lb_base; lb.epoch = c->lb_epoch; lb.err = c->d_mail.as<i32>() + M_LBERR;
+	lb.ticket = c->d_mail.as<u32>() + M_TICKET; lb.base = c->lb_base; lb.epoch = c->lb_epoch; lb.err = c->d_mail.as<i32>() + M_LBERR; lb.finished = c->d_mail.as<u32>() + M_LBDONE;
 	hipLaunchKernelGGL((k_lb_pass<NV, Op, ITEMS>), dim3((unsigned)tiles), dim3(LB_TPB), 0, stream, n, op, lb);
 	GSA_CHECK(c, hipGetLastError());
 	c->lb_base += (u32)tiles;

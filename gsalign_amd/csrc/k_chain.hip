@@ -525,6 +525,15 @@ struct OpEarlyGaps {
 		off1[e] = rp; off2[e] = qp; opsoff[e] = ex[1];
 	}
 	__device__ void done(const i32 *t) const { mail[M_NEARLY] = t[0]; mail[M_EOPS] = t[1]; mail[M_DPERR3] = 0; }
+	// the last tile puts the two counts and the head of the list into pinned memory: the host launches from there
+	i32 *h_early; i32 h_cap;
+	__device__ void finish(int tid) const
+	{
+		const i32 ne = __hip_atomic_load(&mail[M_NEARLY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (tid == 0) { h_early[0] = ne; h_early[1] = __hip_atomic_load(&mail[M_EOPS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		const i32 w = 3 * (ne < h_cap ? ne : h_cap);
+		for (i32 t = tid; t < w; t += LB_TPB) h_early[4 + t] = __hip_atomic_load(&e_list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 };
 #define EARLY_CHUNK 4096      // large gaps copied with the first look (more -> a second copy)
 
@@ -643,11 +652,10 @@ int stage2_chain(gsa_ctx *c)
 	// F. list the large DP gaps (right behind the block heads: the block filter is not needed for that); the list travels
 	// to the host while the rest of stage 2 and stage 3 are being enqueued
 	ENS(i32, e_id, na + 2); ENS(i32, e_list, 3 * (na + 1)); ENS(i64, e_off1, na + 1); ENS(i64, e_off2, na + 1); ENS(i64, e_opsoff, na + 2);
-	{ OpEarlyGaps op = { c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), bhead, c->d_query.as<uint8_t>(), c->di.ref,
-	                     c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail }; RC((lb_launch<2>(c, na, op))); }
 	if (!pin_ensure<i32>(c, c->p_early, 4 + 3 * (size_t)EARLY_CHUNK)) return GSA_ERR_NOMEM;
-	hipLaunchKernelGGL(k_mirror, dim3(1), dim3(256), 0, st, (const i32 *)(mail + M_NEARLY), 2, c->p_early.as<i32>(),      // M_NEARLY, M_EOPS
-	                   (const i32 *)c->e_list.as<i32>(), c->p_early.as<i32>() + 4, (const i32 *)(mail + M_NEARLY), (i32)std::min<i64>(na, EARLY_CHUNK), 3, (i32 *)nullptr);
+	{ OpEarlyGaps op = { c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), bhead, c->d_query.as<uint8_t>(), c->di.ref,
+	                     c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail,
+	                     c->p_early.as<i32>(), (i32)std::min<i64>(na, EARLY_CHUNK) }; RC((lb_launch<2>(c, na, op))); }
 	GSA_CHECK(c, hipEventRecord(c->ev[16], st));
 	c->early_listed = true;
 	i32 *bkeep = c->a_ws.as<i32>(), *bkeepEx = c->a_wid.as<i32>();

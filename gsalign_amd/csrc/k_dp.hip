@@ -454,6 +454,14 @@ struct OpClassify {
 		else order[j - ex[0] - ex[1]] = (i32)j;
 	}
 	__device__ void done(const i32 *t) const { mail[M_NLARGE] = t[0]; mail[M_NTINY] = t[1]; }
+	// the last tile puts the mailbox and the head of the large-job list into pinned memory (the host launches from there)
+	i32 *h_out; i32 h_cap;
+	__device__ void finish(int tid) const
+	{
+		if (tid < MAIL_N) h_out[tid] = __hip_atomic_load(&mail[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		i32 nl = __hip_atomic_load(&mail[M_NLARGE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (nl > h_cap) nl = h_cap;
+		for (i32 t = tid; t < 3 * nl; t += LB_TPB) h_out[MAIL_N + t] = __hip_atomic_load(&lg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
 };
 
 // sums of m*n and m+n over the jobs (measurement only)
@@ -565,10 +573,9 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	if (!d_order || !d_order_tiny || !d_lg || !rev) return GSA_ERR_NOMEM;
 	if (!pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * LG_CHUNK)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR, 0, 7 * sizeof(i32), st));                    // M_DPERR, M_NLARGE, M_DPERR2, M_CELLS (2 x u64)
-	{ OpClassify op = { len1, len2, d_order, d_order_tiny, d_lg, d_jlarge, mail }; int rc = lb_launch<2>(c, n_ub, op); if (rc) return rc; }
 	i32 *h = c->p_dp.as<i32>();
 	const size_t first_lg = (size_t)std::min<i64>(n_ub, LG_CHUNK);
-	hipLaunchKernelGGL(k_mirror, dim3(1), dim3(256), 0, st, (const i32 *)mail, (int)MAIL_N, h, (const i32 *)d_lg, h + MAIL_N, (const i32 *)(mail + M_NLARGE), (i32)first_lg, 3, (i32 *)nullptr);
+	{ OpClassify op = { len1, len2, d_order, d_order_tiny, d_lg, d_jlarge, mail, h, (i32)first_lg }; int rc = lb_launch<2>(c, n_ub, op); if (rc) return rc; }
 	GSA_CHECK(c, hipStreamSynchronize(st));
 	if (h[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	if (h[M_DPERR]) return gsa_fail(c, GSA_ERR_ARG, "DP job with an empty side");

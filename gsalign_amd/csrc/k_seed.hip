@@ -7,7 +7,7 @@
 #include "gsa_fm.h"
 #include "gsa_scan.h"
 
-enum { CNT_OCCBLK = 0, CNT_LF = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 4, CNT_DPJOBS = 5, CNT_DPMN = 6, CNT_CAND = 8, CNT_OVERFLOW = 9, CNT_OCCBLK_ALL = 10 };
+enum { CNT_OCCBLK = 0, CNT_DONE = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 4, CNT_DPJOBS = 5, CNT_DPMN = 6, CNT_CAND = 8, CNT_OVERFLOW = 9, CNT_OCCBLK_ALL = 10 };
 
 #define SEED_WG 256
 #define NSUB 384               // speculative sub-ranges per chunk (work items of the workgroup)
@@ -64,7 +64,7 @@ __device__ __forceinline__ int text_match32(u32 r0, u32 r1, u32 r2, i64 tp, i64 
 // ---------------------------------------------------------------------------
 template <bool COUNT, bool E16>
 __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
-                                                      i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits)
+                                                      i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt)
 {
 	__shared__ u32 s_ncand, s_queue, s_hits;
 	__shared__ int changed;
@@ -312,6 +312,19 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 			if (s_hits) atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)s_hits);      // the contig's total: all the host needs to go on
 		}
 	}
+	// the workgroup that is through last puts the counters into pinned memory (the host waits for this kernel, nothing
+	// else) and leaves them at zero for the next contig
+	__shared__ int s_last;
+	__syncthreads();
+	if (j == 0) {
+		__threadfence();
+		s_last = atomicAdd((unsigned long long *)&cnt[CNT_DONE], 1ull) == (unsigned long long)gridDim.x - 1 ? 1 : 0;
+	}
+	__syncthreads();
+	if (s_last && j < 16) {
+		hcnt[j] = j == CNT_DONE ? 0 : __hip_atomic_load(&cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		cnt[j] = 0;
+	}
 }
 
 // ---------------------------------------------------------------------------
@@ -520,16 +533,15 @@ int stage1_seed(gsa_ctx *c)
 		if (c->profiling || c->prof_seed) hipEventRecord(c->ev[0], st);
 		if (c->count_blocks)
 			hipLaunchKernelGGL((k_seed_wg<true, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
-			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>());
+			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>(), c->h_cnt);
 		else
 			if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
-			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>());
+			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>(), c->h_cnt);
 			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
-			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>());
+			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>(), c->h_cnt);
 		if (c->profiling || c->prof_seed) hipEventRecord(c->ev[1], st);
-		// the counters go to pinned memory by a mirror kernel (no copy operation); the host waits for that, not for the
-		// scan of the per-chunk hit counts behind it
-		hipLaunchKernelGGL(k_mirror, dim3(1), dim3(256), 0, st, (const i32 *)cnt, 32, (i32 *)c->h_cnt, (const i32 *)nullptr, (i32 *)nullptr, (const i32 *)nullptr, 0, 0, (i32 *)cnt);
+		// (the counters are in pinned memory when the seed kernel is done; the host waits for that, not for the scan of the
+		//  per-chunk hit counts behind it)
 		GSA_CHECK(c, hipEventRecord(c->ev[21], st));
 		int rcs = prim_exscan_i32(c, c->d_chunk_hits.as<i32>(), c->d_chunk_base.as<i32>(), (size_t)n_chunks + 1);
 		if (rcs) return rcs;
