@@ -137,19 +137,6 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 	}
 }
 
-// The host's look at device results without a copy operation: one small workgroup writes some mailbox words and the head
-// of a list straight into pinned memory.  (A copy operation costs ~15 us of stream latency on this runtime; these stores
-// ride on a 5 us kernel.)
-static __global__ void __launch_bounds__(256) k_mirror(const i32 *__restrict__ words, int nwords, i32 *hwords,
-                                                        const i32 *__restrict__ list, i32 *hlist, const i32 *__restrict__ count, i32 cap_items, int words_per_item, i32 *clear = nullptr)
-{
-	for (int t = threadIdx.x; t < nwords; t += 256) { hwords[t] = words[t]; if (clear) clear[t] = 0; }      // (clear: counters that start the next contig at zero)
-	if (!list) return;
-	i32 n = *count; if (n > cap_items) n = cap_items;
-	const i64 w = (i64)n * words_per_item;
-	for (i64 t = threadIdx.x; t < w; t += 256) hlist[t] = list[t];
-}
-
 // host side: one fused pass on the context's stream
 template <int NV, int ITEMS = LB_ITEMS, class Op>
 static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op, hipStream_t stream = nullptr)
