@@ -72,7 +72,7 @@ int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa
 	(void)hipGetLastError();
 	CK(hipStreamCreate(&c->stream));
 	CK(hipStreamCreate(&c->stream_aux[0])); CK(hipStreamCreate(&c->stream_aux[1])); CK(hipStreamCreate(&c->stream_aux[2]));
-	for (int i = 0; i < 24; i++) CK(hipEventCreate(&c->ev[i]));
+	for (int i = 0; i < 28; i++) CK(hipEventCreate(&c->ev[i]));
 	const size_t bwt_bytes = ((idx->bwt_words + 15) / 16) * 64;          // whole 64-byte blocks
 	CK(hipMalloc(&c->d_bwt.p, bwt_bytes + 64)); c->d_bwt.cap = bwt_bytes + 64;
 	CK(hipMemset(c->d_bwt.p, 0, bwt_bytes + 64));
@@ -133,7 +133,7 @@ void gsa_destroy(gsa_ctx *c)
 	if (c->h_cnt) hipHostFree(c->h_cnt);
 	if (c->h_mail) hipHostFree(c->h_mail);
 	for (DevBuf *b : { &c->p_frags, &c->p_tail, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_sj_early, &c->p_jpatch, &c->p_early }) if (b->p) hipHostFree(b->p);
-	for (int i = 0; i < 24; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+	for (int i = 0; i < 28; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 3; i++) if (c->stream_aux[i]) hipStreamDestroy(c->stream_aux[i]);
 	if (c->stream) hipStreamDestroy(c->stream);
 	delete c;

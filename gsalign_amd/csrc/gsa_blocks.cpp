@@ -159,6 +159,8 @@ int host_stage8_finish(gsa_ctx *c)
 		fprintf(stderr, "[gsa] early DP: list ready -> launch reaches the stream %.1f us, launch -> done %.1f us\n", a * 1e3, b * 1e3);
 		const int evs[] = { 19, 12, 17, 13, 15, 14 }; const char *nm[] = { "job list", "small DP done", "strings", "block sums home", "records+patch home", "stripes done" };
 		{ float t1 = 0; hipEventElapsedTime(&t1, c->ev[14], c->ev[22]); fprintf(stderr, "[gsa]   stripes done -> last copy done %.0f us\n", t1 * 1e3); }
+		{ float a = 0, b = 0, d = 0, e = 0, f = 0; hipEventElapsedTime(&a, c->ev[0], c->ev[1]); hipEventElapsedTime(&b, c->ev[1], c->ev[24]); hipEventElapsedTime(&d, c->ev[24], c->ev[25]); hipEventElapsedTime(&e, c->ev[25], c->ev[26]); hipEventElapsedTime(&f, c->ev[26], c->ev[16]);
+		  fprintf(stderr, "[gsa]   front: seed kernel %.0f | to the (group, qPos) order %.0f | windows + outliers %.0f | multi-hits, compaction, noise %.0f | heads + early list %.0f us\n", a * 1e3, b * 1e3, d * 1e3, e * 1e3, f * 1e3); (void)hipGetLastError(); }
 		{ float t0 = 0; hipEventElapsedTime(&t0, c->ev[0], c->ev[16]); fprintf(stderr, "[gsa]   seed kernel start -> early list %.0f us\n", t0 * 1e3); }
 		fprintf(stderr, "[gsa]   after the early list (us):");
 		for (int k = 0; k < 6; k++) { float t = 0; if (hipEventElapsedTime(&t, c->ev[16], c->ev[evs[k]]) == hipSuccess) fprintf(stderr, "  %s %.0f", nm[k], t * 1e3); }

@@ -40,7 +40,7 @@ struct gsa_ctx {
 	bool prof_seed = false;                        // time the seed kernel only (two events instead of ten per contig)
 	bool count_blocks = false;                     // run the accounting build of the seed kernel (exact algorithmic Occ-block count)
 	u64 dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-	hipEvent_t ev[24];
+	hipEvent_t ev[28];
 	float kernel_ms[8];
 	u64 counters[8];
 

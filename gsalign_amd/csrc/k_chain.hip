@@ -608,6 +608,8 @@ int stage2_chain(gsa_ctx *c)
 		LAUNCH(k_gather_active, na, na, c->d_val_b.as<u32>(), c->s_q.as<i32>(), c->s_len.as<i32>(), c->s_r.as<i64>(), c->s_gid.as<i32>(), c->g_beg.as<i32>(),
 		       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>());
 	}
+	static const bool dbg_tl = getenv("GSA_DEBUG_EARLY") != nullptr;
+	if (dbg_tl) hipEventRecord(c->ev[24], st);
 	// B. unique / break flags, window chain
 	ENS(i32, a_uniq, na + 1); ENS(i32, a_cu, na + 1); ENS(i32, a_alive, na + 1); ENS(i32, a_brk, na + 1); ENS(i32, a_aurank, na + 1);
 	ENS(i32, a_aulist, na + 1); ENS(i32, a_next, na + 1); ENS(i32, a_ws, na + 1); ENS(i32, a_wid, na + 1); ENS(i32, a_runinfo, na + 1);
@@ -635,6 +637,7 @@ int stage2_chain(gsa_ctx *c)
 	       c->w_sum.as<unsigned long long>(), c->w_n.as<i32>());
 	LAUNCH(k_outlier_kill, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(),
 	       c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->G, c->prm.MaxIndelSize, alive);
+	if (dbg_tl) hipEventRecord(c->ev[25], st);
 	// D. multi-hit positions
 	i32 *auEx = c->a_aurank.as<i32>(), *aulist = c->a_aulist.as<i32>();
 	{ OpAliveUnique op = { na, uniq, alive, auEx, aulist }; RC((lb_launch<1>(c, na, op))); }
@@ -646,6 +649,7 @@ int stage2_chain(gsa_ctx *c)
 	ENS(i32, c_q, na); ENS(i32, c_len, na + 1); ENS(i64, c_r, na); ENS(i32, c_gb, na); ENS(i32, c_bid, na);
 	{ OpNoise op = { c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(),
 	                 c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), mail }; RC((lb_launch<1>(c, na, op))); }
+	if (dbg_tl) hipEventRecord(c->ev[26], st);
 	// block cuts + AddAlnBlock
 	i32 *bhead = c->a_uniq.as<i32>(), *bheadEx = c->a_cu.as<i32>(), *bstart = c->a_brk.as<i32>();
 	{ OpBlockHeads op = { na, c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), bhead, bheadEx, bstart, c->d_flag2.as<u32>(), mail }; RC((lb_launch<2>(c, na, op))); }
