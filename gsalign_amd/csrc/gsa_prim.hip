@@ -24,9 +24,16 @@ int prim_sort_pairs_u64_u32(gsa_ctx *c, const u64 *kin, u64 *kout, const u32 *vi
 	// At a bacterial contig's 75 k pairs rocPRIM runs its merge sort (Onesweep forced by config is 100 us slower there):
 	// 2048-item block sorts save two merge launches against the default tuning (measured: 512 x 4 best of five shapes)
 	using cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::merge_sort_config<512, 512, 4>, rocprim::default_config>;
-	GSA_CHECK(c, rocprim::radix_sort_pairs<cfg>(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+	if (n <= (1u << 18)) {
+		GSA_CHECK(c, rocprim::radix_sort_pairs<cfg>(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+		int rc = ensure_tmp(c, bytes); if (rc) return rc;
+		GSA_CHECK(c, rocprim::radix_sort_pairs<cfg>(c->tmp.p, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+		return GSA_OK;
+	}
+	// (larger inputs: the library's own tuning)
+	GSA_CHECK(c, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
 	int rc = ensure_tmp(c, bytes); if (rc) return rc;
-	GSA_CHECK(c, rocprim::radix_sort_pairs<cfg>(c->tmp.p, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+	GSA_CHECK(c, rocprim::radix_sort_pairs(c->tmp.p, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
 	return GSA_OK;
 }
 
