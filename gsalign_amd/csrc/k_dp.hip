@@ -207,7 +207,11 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 {
 	extern __shared__ __attribute__((aligned(16))) int8_t C1[];        // the reference fragment as nt4 codes
 	__shared__ __attribute__((aligned(16))) uint8_t tile[DP_TILE_ROWS * 64];
-	__builtin_amdgcn_s_setprio(3);      // these waves are the contig's latency floor: they issue ahead of whatever else shares the SIMD
+	// The LARGEST jobs are the contig's latency floor (the list is sorted by cells: they are the first workgroups): their
+	// waves issue ahead of whatever else shares the SIMD.  The mass of smaller jobs behind them does not get that: on a
+	// 50 Mb contig they are 10 000 workgroups, and at raised priority they starve the record / small-DP path beside them
+	// (its passes ran 5-10x slower), which is the longer path there.
+	if (blockIdx.x < 96) __builtin_amdgcn_s_setprio(3);
 	// which job / stripe am I (uniform).  Both tables are read where the host wrote them (pinned memory): two dependent
 	// reads across the link cost less than a copy operation in front of the launch
 	const StripeJob sj = sjobs[blk2job[blockIdx.x]];
