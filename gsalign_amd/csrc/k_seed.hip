@@ -9,7 +9,9 @@
 
 enum { CNT_OCCBLK = 0, CNT_DONE = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 4, CNT_DPJOBS = 5, CNT_DPMN = 6, CNT_CAND = 8, CNT_OVERFLOW = 9, CNT_OCCBLK_ALL = 10 };
 
-#define SEED_WG 256
+#ifndef SEED_WG
+#define SEED_WG 128             // lanes per chunk: one per sub-range (256 lanes with 128 sub-ranges left two of four waves idle: 0.157 -> 0.139 ms)
+#endif
 #ifndef NSUB
 #define NSUB 128               // speculative sub-ranges per chunk (work items of the workgroup; swept 64 .. 512 on the bench: with 64-base
                                // text windows and four presence bits per round trip fewer, longer walks win -- 384 was best before them)
