@@ -16,6 +16,9 @@ enum { CNT_OCCBLK = 0, CNT_DONE = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 
 #define NSUB 128               // speculative sub-ranges per chunk (work items of the workgroup; swept 64 .. 512 on the bench: with 64-base
                                // text windows and four presence bits per round trip fewer, longer walks win -- 384 was best before them)
 #endif
+#ifndef PLOOK
+#define PLOOK 3                 // presence bits looked up beside the one of the current start
+#endif
 #define PATH_WORDS 320          // 10240 on-path bits per chunk
 #define QP_WORDS (GSA_CHUNK / 16 + 4)
 #define QN_WORDS (GSA_CHUNK / 32 + 4)
@@ -150,15 +153,15 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 			}
 			// presence bits of s and of the three starts behind it: a search that dies below MinSeedLength moves on by ONE base,
 			// so walks cross the 14 bases in front of a mismatch start by start -- four of those per memory round trip
-			u32 pidk[3] = {0, 0, 0};
+			u32 pidk[PLOOK]; for (int k2 = 0; k2 < PLOOK; k2++) pidk[k2] = 0;
 			if (mode == M_KMER && di.pres_k) {
 #pragma unroll
-				for (int k2 = 0; k2 < 3; k2++) pidk[k2] = (u32)(q_bits64(qp, s + 1 + k2 < clen ? s + 1 + k2 : 0) & ((1ull << (2 * di.pres_k)) - 1));
+				for (int k2 = 0; k2 < PLOOK; k2++) pidk[k2] = (u32)(q_bits64(qp, s + 1 + k2 < clen ? s + 1 + k2 : 0) & ((1ull << (2 * di.pres_k)) - 1));
 			}
 			const u32 pw = di.pres ? di.pres[mode == M_KMER ? (pid >> 5) : 0] : ~0u;
-			u32 pwk[3];
+			u32 pwk[PLOOK];
 #pragma unroll
-			for (int k2 = 0; k2 < 3; k2++) pwk[k2] = di.pres ? di.pres[mode == M_KMER ? (pidk[k2] >> 5) : 0] : ~0u;
+			for (int k2 = 0; k2 < PLOOK; k2++) pwk[k2] = di.pres ? di.pres[mode == M_KMER ? (pidk[k2] >> 5) : 0] : ~0u;
 			const u64 sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
 			// ---- consume phase: straight-line, one predicated block per mode ----
 			bool ended = false;
@@ -169,7 +172,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 					// below owns every other rule: sub-range end, memoised hop, ambiguous bases, too close to the chunk end)
 					const int L = prm.MinSeedLength < 32 ? prm.MinSeedLength : 32;
 #pragma unroll
-					for (int k2 = 0; k2 < 3; k2++) {
+					for (int k2 = 0; k2 < PLOOK; k2++) {
 						if (s >= bend || memo[s]) break;
 						const u32 nb = q_nbits32(qn, s);
 						if (s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0) break;
