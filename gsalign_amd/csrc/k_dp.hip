@@ -198,6 +198,8 @@ struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; }
 #define DPT(...)
 #endif
 #define DP_LOOK 21
+#define DP_CLASS_M 768          // size classes of a long job list: reference fragments above / up to this (see launch_stripes)
+#define DP_CLASS_MIN_JOBS 4096
 #define DP_LDS_M 3072         // longest reference fragment for which four stripes share a workgroup (3 boundary columns in LDS)
 
 template <int WPB>
@@ -498,14 +500,17 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		if (large.size() > 512) std::partial_sort(large.begin(), large.begin() + 256, large.end(), by_cells);
 		else std::sort(large.begin(), large.end(), by_cells);
 	}
-	int mmax = 1;
-	for (const LgJob &g : large) if (g.m > mmax) mmax = g.m;
-	const int mpad = (mmax + 64 + 63) & ~63;
-	// reference fragments up to DP_LDS_M bases: four stripes per workgroup, boundary columns through LDS
-	const int wpb = mmax <= DP_LDS_M ? 4 : 1;
-	const int lds_rows = (mmax + 15) & ~15;
-	const size_t dyn_lds = (size_t)mpad + (wpb > 1 ? (size_t)(wpb - 1) * lds_rows * 4 : 0);
-	if (mpad > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 153600 bases");
+	// Size classes.  Every workgroup of a launch reserves the LDS the launch's LONGEST reference fragment needs (the code
+	// string + three boundary columns): with thousands of jobs that caps the chip at 3 workgroups per CU although almost
+	// all of them are small.  Long lists are therefore launched as two kernels, back to back on the stream: fragments
+	// above DP_CLASS_M first (the critical ones), the rest behind them with a quarter of the LDS.  Short lists (a bacterial
+	// contig: 700 jobs) stay one launch -- there the second kernel would only wait for the longest job of the first.
+	size_t n_hi = large.size();
+	if (large.size() >= DP_CLASS_MIN_JOBS) {
+		auto it = std::stable_partition(large.begin(), large.end(), [](const LgJob &g) { return g.m > DP_CLASS_M; });
+		n_hi = (size_t)(it - large.begin());
+	}
+	for (const LgJob &g : large) if (((g.m + 64 + 63) & ~63) > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 153600 bases");
 	const i64 budget = 12ll << 30;
 	size_t first = 0;
 	while (first < large.size()) {
@@ -514,21 +519,36 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		{ size_t l = first; i64 db = 128; while (l < large.size()) { const i64 cells = (((i64)large[l].n + 63) / 64) * ((i64)large[l].m + 63) * 64; if (l > first && db + cells > budget) break; db += cells + 128; l++; } cnt = l - first; }
 		// (the early launch and a late one may be in flight together: each has its own table)
 		DevBuf &psj = err_slot == M_DPERR3 ? c->p_sj_early : c->p_sj;
+		// the one or two segments of this batch: [first, split) above the class limit, [split, first + cnt) below
+		const size_t split = std::min(std::max(n_hi, first), first + cnt);
+		struct Seg { size_t b, e; int mmax, wpb, mpad, lds_rows; size_t dyn_lds; i32 *b2j; i32 nblocks; } seg[2] = { { first, split }, { split, first + cnt } };
 		size_t nb_ub = 0;
-		for (size_t k = 0; k < cnt; k++) nb_ub += (size_t)(((large[first + k].n + 63) / 64 + wpb - 1) / wpb);
-		if (!pin_ensure<char>(c, psj, (cnt + 1) * sizeof(StripeJob) + (nb_ub + 1) * 4)) return GSA_ERR_NOMEM;
+		for (Seg &sg : seg) {
+			sg.mmax = 1;
+			for (size_t k = sg.b; k < sg.e; k++) if (large[k].m > sg.mmax) sg.mmax = large[k].m;
+			sg.mpad = (sg.mmax + 64 + 63) & ~63;
+			sg.wpb = sg.mmax <= DP_LDS_M ? 4 : 1;      // reference fragments up to DP_LDS_M bases: four stripes per workgroup, boundary columns through LDS
+			sg.lds_rows = (sg.mmax + 15) & ~15;
+			sg.dyn_lds = (size_t)sg.mpad + (sg.wpb > 1 ? (size_t)(sg.wpb - 1) * sg.lds_rows * 4 : 0);
+			for (size_t k = sg.b; k < sg.e; k++) nb_ub += (size_t)(((large[k].n + 63) / 64 + sg.wpb - 1) / sg.wpb);
+		}
+		if (!pin_ensure<char>(c, psj, (cnt + 1) * sizeof(StripeJob) + (nb_ub + 2) * 4)) return GSA_ERR_NOMEM;
 		StripeJob *sj = psj.as<StripeJob>();
-		i32 *b2j = (i32 *)(sj + cnt + 1);
-		i64 dbytes = 128, bwords = 0; i32 nctr = 1, nblocks = 0;
-		for (size_t k = 0; k < cnt; k++) {
-			const LgJob &g = large[first + k];
-			const i64 cells = (((i64)g.n + 63) / 64) * ((i64)g.m + 63) * 64;   // stripe-local direction bytes
-			StripeJob s; s.job = g.job; s.m = g.m; s.n = g.n; s.P = (g.n + 63) / 64;
-			s.diroff = dbytes; dbytes += cells + 128;
-			s.bndoff = bwords; bwords += (i64)(s.P - 1) * g.m;
-			s.ctr = nctr++; s.first_block = nblocks;
-			for (int b = 0; b < (s.P + wpb - 1) / wpb; b++) b2j[nblocks++] = (i32)k;
-			sj[k] = s;
+		i32 *b2j_all = (i32 *)(sj + cnt + 1);
+		i64 dbytes = 128, bwords = 0; i32 nctr = 1; size_t b2j_used = 0;
+		for (Seg &sg : seg) {
+			sg.b2j = b2j_all + b2j_used; sg.nblocks = 0;
+			for (size_t k = sg.b; k < sg.e; k++) {
+				const LgJob &g = large[k];
+				const i64 cells = (((i64)g.n + 63) / 64) * ((i64)g.m + 63) * 64;   // stripe-local direction bytes
+				StripeJob s; s.job = g.job; s.m = g.m; s.n = g.n; s.P = (g.n + 63) / 64;
+				s.diroff = dbytes; dbytes += cells + 128;
+				s.bndoff = bwords; bwords += (i64)(s.P - 1) * g.m;
+				s.ctr = nctr++; s.first_block = sg.nblocks;
+				for (int b = 0; b < (s.P + sg.wpb - 1) / sg.wpb; b++) sg.b2j[sg.nblocks++] = (i32)(k - first);
+				sj[k - first] = s;
+			}
+			b2j_used += (size_t)sg.nblocks;
 		}
 		const size_t last = first + cnt;
 		uint8_t *dir = dev_ensure<uint8_t>(c, c->d_scan2, (size_t)dbytes + 512);
@@ -542,8 +562,11 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		if (c->dp_epoch == 0 || c->d_dp_bnd.cap != bnd_cap0) { GSA_CHECK(c, hipMemsetAsync(bnd, 0, c->d_dp_bnd.cap, st)); if (c->dp_epoch == 0) c->dp_epoch = 1; }
 		// (the ticket counters are put back to zero by the wave that draws the last ticket; the error word lives in the mailbox)
 		if (c->d_dp_ctr.cap != ctr_cap0 || c->dp_dirty) { GSA_CHECK(c, hipMemsetAsync(ctr, 0, c->d_dp_ctr.cap, st)); GSA_CHECK(c, hipMemsetAsync(mail + err_slot, 0, 4, st)); c->dp_dirty = false; }
-		if (wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)nblocks), dim3(256), dyn_lds, st, (const i32 *)b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows, (u32 *)(mail + err_slot));
-		else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)nblocks), dim3(64), dyn_lds, st, (const i32 *)b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)mpad, (i32)lds_rows, (u32 *)(mail + err_slot));
+		for (const Seg &sg : seg) {
+			if (sg.nblocks == 0) continue;
+			if (sg.wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)sg.nblocks), dim3(256), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)sg.mpad, (i32)sg.lds_rows, (u32 *)(mail + err_slot));
+			else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)sg.nblocks), dim3(64), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)sg.mpad, (i32)sg.lds_rows, (u32 *)(mail + err_slot));
+		}
 		GSA_CHECK(c, hipGetLastError());
 		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })
 		if (last < large.size()) {
