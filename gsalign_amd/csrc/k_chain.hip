@@ -575,6 +575,43 @@ int launch_early_dp(gsa_ctx *c)
 #define ENS(T, buf, n) do { if (!dev_ensure<T>(c, c->buf, (size_t)(n))) return GSA_ERR_NOMEM; } while (0)
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
+// The same segmentation for contigs whose chain does not fit one workgroup's LDS: the three steps of k_walk_windows as
+// grid-wide kernels over global memory (leave() per tile, the orbit of candidate 0 by pointer doubling -- a chase would
+// pay a global round trip per tile --, marks).  All in candidate space: nextk[k] = rank of the next start after k.
+#define WALKG_TS 256
+__global__ void k_walkg_leave(i64 na, i32 nt, const i32 *__restrict__ candEx, const i32 *__restrict__ nextk, i32 *J, i32 *on)
+{
+	const i32 t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nt) return;
+	const i32 nC = candEx[na];
+	const i64 pe = (i64)(t + 1) * WALKG_TS < na ? (i64)(t + 1) * WALKG_TS : na;
+	const i32 kb = candEx[(i64)t * WALKG_TS], ke = candEx[pe];
+	for (i32 k = ke - 1; k >= kb; k--) {
+		const i32 nx = nextk[k];
+		J[k] = nx >= ke ? (nx < nC ? nx : nC) : J[nx];      // (J[nx] was written by this thread a moment ago)
+		on[k] = k == 0 ? 1 : 0;
+	}
+}
+__global__ void k_walkg_double(i64 na, const i32 *__restrict__ candEx, const i32 *__restrict__ Jin, i32 *Jout, i32 *on)
+{
+	const i32 nC = candEx[na];
+	const i32 k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= nC) return;
+	const i32 j = Jin[k];
+	if (j < nC) { if (on[k]) on[j] = 1; Jout[k] = Jin[j]; } else Jout[k] = nC;
+}
+__global__ void k_walkg_mark(i64 na, i32 nt, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, const i32 *__restrict__ nextk, const i32 *__restrict__ on, i32 *ws)
+{
+	const i32 t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= nt) return;
+	const i64 pe = (i64)(t + 1) * WALKG_TS < na ? (i64)(t + 1) * WALKG_TS : na;
+	const i32 kb = candEx[(i64)t * WALKG_TS], ke = candEx[pe];
+	i32 e = -1;
+	for (i32 k = kb; k < ke; k++) if (on[k]) { e = k; break; }      // (the orbit enters a tile at most once)
+	if (e < 0) return;
+	for (i32 k = e; k < ke; k = nextk[k]) ws[clist[k]] = 1;
+}
+
 int stage2_chain(gsa_ctx *c)
 {
 	hipStream_t st = c->stream;
@@ -622,7 +659,17 @@ int stage2_chain(gsa_ctx *c)
 	i32 *candf = c->d_flag.as<i32>(), *candEx = c->d_scan.as<i32>(), *clist = c->a_runinfo.as<i32>();
 	{ OpCand op = { na, c->a_gb.as<i32>(), c->a_ge.as<i32>(), cuEx, brk, candf, candEx, clist, ws }; RC((lb_launch<1>(c, na, op))); }
 	LAUNCH(k_next_window, na, na, c->a_q.as<i32>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, cuEx, brk, brkEx, blist, candf, candEx, clist, next, c->d_flag2.as<i32>());
-	hipLaunchKernelGGL(k_walk_windows, dim3(1), dim3(WALK_T), 0, st, na, candEx, clist, next, c->d_flag2.as<i32>(), ws);
+	if (na <= 100000) hipLaunchKernelGGL(k_walk_windows, dim3(1), dim3(WALK_T), 0, st, na, candEx, clist, next, c->d_flag2.as<i32>(), ws);
+	else {
+		// (large contigs: grid-wide kernels, see k_walkg_leave; candidates <= seeds, so seed-sized scratch)
+		const i32 nt = (i32)((na + WALKG_TS - 1) / WALKG_TS);
+		ENS(i32, w_j0, na + 2); ENS(i32, w_j1, na + 2); ENS(i32, w_on, na + 2);
+		i32 *J0 = c->w_j0.as<i32>(), *J1 = c->w_j1.as<i32>(), *on = c->w_on.as<i32>();
+		const i32 *nextk = c->d_flag2.as<i32>();
+		LAUNCH(k_walkg_leave, nt, na, nt, candEx, nextk, J0, on);
+		for (i32 span = 1; span < nt; span <<= 1) { LAUNCH(k_walkg_double, na, na, candEx, J0, J1, on); std::swap(J0, J1); }
+		LAUNCH(k_walkg_mark, nt, na, nt, candEx, clist, nextk, on, ws);
+	}
 	if (getenv("GSA_DEBUG_CHAIN")) { i32 nc_ = 0, nb_ = 0; hipStreamSynchronize(st); hipMemcpy(&nc_, candEx + na, 4, hipMemcpyDeviceToHost); hipMemcpy(&nb_, brkEx + na, 4, hipMemcpyDeviceToHost); fprintf(stderr, "[gsa] stage 2: %lld seeds, %d window-start candidates, %d breaks\n", (long long)na, nc_, nb_); }
 	// C. outliers
 	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);
