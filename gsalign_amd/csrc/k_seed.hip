@@ -16,6 +16,9 @@ enum { CNT_OCCBLK = 0, CNT_DONE = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 
 #define NSUB 128               // speculative sub-ranges per chunk (work items of the workgroup; swept 64 .. 512 on the bench: with 64-base
                                // text windows and four presence bits per round trip fewer, longer walks win -- 384 was best before them)
 #endif
+#ifndef ADV_STEPS
+#define ADV_STEPS 4             // advance steps (hops over memoised / ambiguous positions, opening a search) per round trip
+#endif
 #ifndef PLOOK
 #define PLOOK 3                 // presence bits looked up beside the one of the current start
 #endif
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 			// ---- advance: ONE step per iteration (no inner loop): take an item / hop over a memoised or
 			// ambiguous position / open the next search ----
 			// (a few steps per iteration: hops over memoised / ambiguous positions cost no memory access)
-			for (int step = 0; step < 4 && mode == M_ADV; step++) {
+			for (int step = 0; step < ADV_STEPS && mode == M_ADV; step++) {
 				if (need_item) {
 					if (rounds == 0) { const u32 it_ = atomicAdd(&s_queue, 1u); item = it_ < (u32)nitems ? (int)it_ : -1; }
 					else if (dirty) { dirty = 0; item = fb_item; }
