@@ -127,6 +127,7 @@ def test_midsize_pair_2pct(oracle_built, tmp_path):
     (600000, 2, 0.02, 13, dict(sen=1, clr=50)),       # -sen: 5-bp stride, many tiny groups, candidate-buffer growth
     (800000, 2, 0.08, 14, dict(slen=12, idy=60)),     # high divergence, short seeds
     (12000000, 1, 0.02, 21, {}),                      # 12 Mb contig: window chain in global memory, > 2048 striped DP jobs, multi-tile scans
+    (50000000, 1, 0.02, 22, {}),                      # 50 Mb contig: two size classes of striped jobs, grid-wide window chain, > 4096 early gaps
     (3000000, 2, 0.05, 15, {}),                       # 5 %: short seeds, dense gaps, many small DP jobs
     (1000000, 1, 0.02, 16, dict(ind=40)),             # MaxIndelSize > 31: grouping by the PosDiff sort instead of the bitmap
     (1500000, 1, 0.003, 17, dict(sen=1, clr=50)),     # -sen at low divergence: long seeds cut every 5 bases, multi-kb gaps
