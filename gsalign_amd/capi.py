@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libgsa_hip.so")
 
 EXPORTS = [
     "gsa_default_params", "gsa_create", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig",
-    "gsa_set_query", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
+    "gsa_set_query", "gsa_rewind", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
     "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling",
 ]
 
@@ -127,6 +127,10 @@ class Aligner:
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         self._q = seq
         self._ck(self.lib.gsa_set_query(self.ctx, seq.ctypes.data_as(C.c_char_p), C.c_int32(seq.size)))
+
+    def rewind(self):
+        """Stage 0 again with the uploaded contig (no new copy)."""
+        self._ck(self.lib.gsa_rewind(self.ctx))
 
     def run_to(self, stage: int):
         self._ck(self.lib.gsa_run_to(self.ctx, stage))

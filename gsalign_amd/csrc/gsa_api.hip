@@ -159,6 +159,20 @@ int gsa_set_query(gsa_ctx *c, const char *query, int32_t qlen)
 	return GSA_OK;
 }
 
+// Back to stage 0 with the same contig: the query stays where gsa_set_query put it (device and host copy).
+int gsa_rewind(gsa_ctx *c)
+{
+	if (!c) return GSA_ERR_ARG;
+	if (c->qlen <= 0) return gsa_fail(c, GSA_ERR_STATE, "gsa_set_query first");
+	GSA_CHECK(c, hipSetDevice(c->device));
+	if (c->early_in_flight) { GSA_CHECK(c, hipStreamSynchronize(c->stream_aux[0])); c->early_in_flight = false; }
+	c->n_early = 0; c->early_listed = false; c->early_consumed = false;
+	c->stage = 0;
+	c->n_seeds = 0; c->n_groups = 0; c->n_blocks2 = 0; c->blocks.clear(); c->frags_stage = 0; c->have_host_seeds = false; c->ev_pending = 0; c->s2_host = false;
+	memset(c->counters, 0, sizeof(c->counters)); memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
+	return GSA_OK;
+}
+
 int gsa_run_to(gsa_ctx *c, int stage)
 {
 	if (!c || stage < 0 || stage > 8) return GSA_ERR_ARG;

@@ -121,6 +121,9 @@ int gsa_align_contig(gsa_ctx *ctx, const char *query, int32_t qlen, gsa_result *
  *  8 GenerateFragAlignment + identity filter    ProcessCandidateAlignment.cpp:290-351, GSAlign.cpp:523-540
  */
 int gsa_set_query(gsa_ctx *ctx, const char *query, int32_t qlen);
+/* back to stage 0 with the contig gsa_set_query uploaded (no new copy): the same alignment can be run again, e.g. with
+ * other parameters (the reference re-reads the contig from its FASTA buffer: GSAlign.cpp:483) */
+int gsa_rewind(gsa_ctx *ctx);
 int gsa_run_to(gsa_ctx *ctx, int stage);
 
 /* stage 1 outputs: SeedVec in final order, and the SeedGrouping ranges */
