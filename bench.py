@@ -3,20 +3,26 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the whole hot path (seed search -> locate -> sort ->
-chaining -> refinement -> gap DP -> gapped strings -> block records on the host)
-over one synthetic query genome that is already resident in HBM.  Workload at
-N=1 = BASELINE.json configs[1] stand-in: a 5 Mb E. coli-sized reference against a
-2 %-diverged query (80 % SNV, 10 % insertions, 10 % deletions of 1..10 bp),
-default -slen 15 -ind 25.  N>1: every rank aligns its own
-query genome (same reference, different mutation seed) against a replicated
-index -- contigs shard with no data-path collective, "weak" scaling; the block
-records of every step are gathered with one RCCL all_gather (gsalign_amd/shard.py).
+One "step" = gsa_align_contig on one query contig: upload of the contig (H2D), seed search -> locate -> sort ->
+chaining -> refinement -> gap DP -> gapped strings, block records and strings back in host memory (D2H) -- the metric
+as SURVEY.md section 8(d) defines it.  The steps rotate over several DISTINCT query contigs (different mutation
+seeds), so a step never finds its own data warm in the Infinity Cache, and they are driven the way a multi-contig run
+drives the library: `--inflight` contexts per GPU (gsa_clone: one device index, one context per host thread), each
+working on its own contig, so that the upload and the seed search of one contig overlap the DP tail of another.
 
-Rank 0 prints ONE JSON line.  Extra objects: "roofline" for the dominant kernel
-(k_seed_chunks: algorithmic bytes = 64 B x Occ blocks it reads, measured with
-hipEvents on the library's stream) and "cpu_baseline" (the real reference,
-oracle/_ref, timed on this host on the same input).
+Workload at N=1 (default `--workload human`): BASELINE.json's target configuration cut to one GPU -- a chr1-sized pair
+(configs[3]): 250 Mb reference with the repeat-stress injection of SURVEY 8(d) (300-bp family over 10 % of the genome +
+a >100-copy tandem array), query = 1 %-diverged copy (>= 98 % identity).  `--workload ecoli` (configs[1] stand-in, 5 Mb,
+2 %) and `--workload yeast` (configs[2]: 16 contigs, 12 Mb, 2 %, -sen) are measured in the same run as
+`extra_workloads` (short loops of their own).  N>1: one process per GPU (this script re-executes itself under
+torch.distributed.run when it is started without one), index replicated, every rank aligns its own query contigs --
+the path shards by contig with no data-path collective ("weak" scaling); one gather of block records over RCCL
+outside the timed region.
+
+Rank 0 prints ONE JSON line.  "roofline" = algorithmic bytes of the WHOLE path by the section-8(d) formula (event
+counters of an accounting pass) / mean step time / 8 TB/s; "kernels" = the three longest kernels with their own
+algorithmic bytes, live hipEvent / stage-timer durations and the PMC traffic from profiles/ when that file was taken
+on the same workload; "cpu_baseline" = the real reference (oracle/_ref) on this host on a bounded sample.
 """
 import argparse
 import json
@@ -24,6 +30,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -32,65 +39,250 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+YEAST_KB = [230, 813, 317, 1532, 577, 270, 1091, 563, 440, 746, 667, 1078, 924, 784, 1091, 948]      # S288C chromosomes I..XVI
+
+WORKLOADS = {
+    # name: genome length(s), divergence, repeat injection, aligner parameters, distinct query genomes
+    "human": dict(lengths=[250_000_000], div=0.01, repeats=True, params={}, n_query=4,
+                  label="human-chr1-sized pair (BASELINE configs[3] on one GPU): 250 Mb reference with repeat injection (300-bp family over 10 %, 150-copy tandem) vs 1 %-diverged query, defaults"),
+    "ecoli": dict(lengths=[5_000_000], div=0.02, repeats=False, params={}, n_query=4,
+                  label="E. coli-sized pair (BASELINE configs[1] stand-in): 5 Mb reference vs 2 %-diverged query, default -slen 15 -ind 25"),
+    "yeast": dict(lengths=[1000 * k for k in YEAST_KB], div=0.02, repeats=False, params=dict(sen=1, clr=50), n_query=2,
+                  label="S. cerevisiae-sized pair (BASELINE configs[2]): 16 contigs / 12 Mb vs 2 %-diverged copy, -sen"),
+}
 
 
-def build_workload(tmp, genome_len, divergence, rank, world):
-    """Reference FASTA + index (rank 0 builds, the others wait) and this rank's query."""
+def relaunch_if_needed(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: become N ranks under torch.distributed.run."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def build_reference(tmp, name, wl, rank, world):
+    """Reference FASTA + index files (rank 0 builds, the others wait) -> (prefix, loaded index, reference contigs)."""
     from gsalign_amd import hostlib, indexio, synth
-    rng = np.random.default_rng(11)
-    ref = synth.random_genome(genome_len, rng)
-    px = os.path.join(tmp, "ref")
+    refs = []
+    for i, ln in enumerate(wl["lengths"]):
+        r = synth.fast_genome(int(ln), 11000 + i)
+        if wl["repeats"]:
+            synth.inject_repeats(r, 11000 + i)
+        refs.append((f"chr{i + 1}", r))
+    px = os.path.join(tmp, f"{name}_{sum(wl['lengths'])}")
+    done = px + ".done"
     if rank == 0:
-        synth.write_fasta(px + ".fa", [("chr1", ref)])
-        hostlib.build_index(px + ".fa", px)
-        open(px + ".done", "w").close()
+        if not os.path.exists(done):
+            synth.write_fasta(px + ".fa", refs)
+            hostlib.build_index(px + ".fa", px)
+            open(done, "w").close()
     else:
-        while not os.path.exists(px + ".done"):
-            time.sleep(0.05)
-    idx = indexio.load_index(px)
-    qry = synth.mutate(ref, divergence, np.random.default_rng(1000 + rank))
-    return px, idx, qry
+        while not os.path.exists(done):
+            time.sleep(0.1)
+    return px, indexio.load_index(px), refs
 
 
-def cpu_baseline(px, qry, tmp):
-    """The real reference (oracle/_ref) on this host: (a) its hot path only, one thread,
-    through libgsref; (b) the unmodified CLI with all cores, whole program."""
+def make_queries(wl, refs, rank):
+    """n_query distinct query genomes (lists of contigs), each a differently mutated copy of the reference."""
+    from gsalign_amd import synth
+    out = []
+    for k in range(wl["n_query"]):
+        out.append([synth.fast_mutate(r, wl["div"], 7000 + 100 * rank + 10 * k + i) for i, (_, r) in enumerate(refs)])
+    return out
+
+
+class Runner:
+    """`inflight` contexts on one GPU sharing one device index; steps are handed to them through a counter."""
+
+    def __init__(self, idx, device, inflight, params):
+        from gsalign_amd import capi
+        self.ctx = [capi.Aligner(idx, device=device, **params)]
+        for _ in range(inflight - 1):
+            self.ctx.append(self.ctx[0].clone())
+
+    def close(self):
+        for c in self.ctx[1:]:
+            c.close()
+        self.ctx[0].close()
+
+    def run(self, n_steps, step_of, seed_ms=None):
+        """Align the contigs of n_steps steps (step_of(n) = flat list of contig buffers in step order), spread over the contexts."""
+        work = step_of(n_steps)
+        nxt = [0]; lock = threading.Lock(); errs = []
+
+        def loop(g):
+            try:
+                while True:
+                    with lock:
+                        i = nxt[0]; nxt[0] += 1
+                    if i >= len(work):
+                        return
+                    g.align_contig_raw(work[i])
+                    if seed_ms is not None:
+                        seed_ms.append(float(g.timings()[0]))
+            except Exception as e:      # noqa: BLE001
+                errs.append(repr(e))
+
+        if len(self.ctx) == 1:
+            loop(self.ctx[0])
+        else:
+            th = [threading.Thread(target=loop, args=(g,)) for g in self.ctx]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+        if errs:
+            raise RuntimeError("; ".join(errs))
+
+
+def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup):
+    """One workload: returns the per-rank measurements (dict).  A step = every contig of one query genome."""
+    px, idx, refs = build_reference(tmp, name, wl, rank, world)
+    genomes = make_queries(wl, refs, rank)
+    run = Runner(idx, local_rank, args.inflight, wl["params"])
+    g0 = run.ctx[0]
+    pinned = [[g0.pinned_copy(c) for c in gq] for gq in genomes]       # contigs live in pinned host memory (gsa_host_alloc), like a loader's buffers
+    bp_per_step = float(np.mean([sum(c.size for c in gq) for gq in genomes]))
+
+    def step_list(n):
+        out = []
+        for s in range(n):
+            out.extend(pinned[s % len(pinned)])
+        return out
+
+    # -- accounting pass (untimed): the event counters of SURVEY 8(d), exact, averaged over the distinct query genomes
+    cnt = np.zeros(8, np.float64)
+    g0.set_profiling(True, count_blocks=True)
+    for gq in pinned:
+        for c in gq:
+            g0.align_contig_raw(c); cnt += g0.counters().astype(np.float64)
+    cnt /= len(pinned)
+    # -- stage split (untimed, one context alone): hipEvent stage timers
+    g0.set_profiling(True)
+    tm = np.zeros(8, np.float64); occ_read = 0.0
+    for gq in pinned:
+        for c in gq:
+            g0.align_contig_raw(c); tm += g0.timings().astype(np.float64); occ_read += float(g0.counters()[7])
+    tm /= len(pinned); occ_read /= len(pinned)
+    res = g0.raw_result(); n_blocks, n_frags, n_aln = int(res.n_blocks), int(res.n_frags), int(res.n_aln)
+    for g in run.ctx:
+        g.set_profiling(False, seed_only=True)      # timed steps: two events per contig around the seed-search kernel
+    run.run(warmup, step_list)
+    seed_ms = []
+    sync(); t0 = time.perf_counter()
+    run.run(steps, step_list, seed_ms)
+    sync(); t_total = time.perf_counter() - t0
+    recs = g0.block_records()
+    run.close()
+    per_step = len(pinned[0])
+    alg = {"occ_blocks": 64.0 * cnt[0], "lf_steps": 64.0 * cnt[1], "sa_reads": 8.0 * cnt[2], "query": bp_per_step, "seeds": 16.0 * cnt[3],
+           "dp_cells": cnt[4], "dp_fragments": cnt[6]}
+    return dict(px=px, refs=refs, genomes=genomes, t_total=t_total, bp=bp_per_step * steps, bp_per_step=bp_per_step, steps=steps, alg=alg, cnt=cnt, tm=tm,
+                seed_kernel_ms=float(np.sum(seed_ms)) / max(1, steps), occ_read=occ_read, recs=recs, n_blocks=n_blocks, n_frags=n_frags, n_aln=n_aln, contigs_per_step=per_step)
+
+
+def pmc_traffic(name):
+    """PMC traffic per step of the top kernels, from the separate rocprofv3 --pmc passes (tools/pmc_top.sh -> profiles/r02_pmc_<workload>.json)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", f"r02_pmc_{name}.json")))
+    except Exception:      # noqa: BLE001
+        return None
+
+
+def summarise(name, wl, m, t_max, total_bp, world, args):
+    """JSON fields of one workload from rank 0's measurements + the whole-job time and bases."""
+    ms_step = 1000.0 * t_max / m["steps"]
+    alg_total = float(sum(m["alg"].values()))
+    achieved = alg_total / (ms_step * 1e-3) / 1e9
+    pmc = pmc_traffic(name)
+    kern = []
+    tm, cnt = m["tm"], m["cnt"]
+    seed_alg = m["alg"]["occ_blocks"] + m["alg"]["query"]
+    dp_alg = m["alg"]["dp_cells"] + m["alg"]["dp_fragments"]
+    loc_alg = m["alg"]["lf_steps"] + m["alg"]["sa_reads"] + m["alg"]["seeds"]
+    for kname, ms, ab, key in (("k_seed_wg (seed search, S1)", m["seed_kernel_ms"] if m["seed_kernel_ms"] > 0 else float(tm[0]), seed_alg, "k_seed_wg"),
+                               ("k_dp_stripe + k_dp_small/tiny + k_materialize (extend stage, S7)", float(tm[5]), dp_alg, "k_dp_stripe"),
+                               ("k_seed_select + sort + group (locate/order, S1 tail)", float(tm[1] + tm[2]), loc_alg, "k_seed_select")):
+        a = ab / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        tr = None
+        if pmc and key in pmc.get("kernels", {}):
+            tr = float(pmc["kernels"][key]["traffic_bytes_per_step"])
+        kern.append({"kernel": kname, "ms_per_step": ms, "algorithmic_bytes_per_step": ab, "achieved": a, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": tr})
+    traffic = float(pmc["traffic_bytes_per_step"]) if pmc and "traffic_bytes_per_step" in pmc else None
+    return {
+        "value": total_bp / t_max / 1e9, "ms_per_step": ms_step,
+        "config": {"workload": wl["label"] + f"; {len(m['genomes'])} distinct query genomes rotating; step = gsa_align_contig per contig incl. H2D of the query and D2H of records + strings",
+                   "query_bp_per_step": int(m["bp_per_step"]), "contigs_per_step": m["contigs_per_step"], "inflight_contexts_per_gpu": args.inflight,
+                   "parallelism": f"contig-shard x{world}, index replicated", "aligner_params": wl["params"]},
+        "roofline": {"bound": "hbm", "kernel": "whole hot path S1-S7 (SURVEY 8(d) formula: 64 N_occblk + 64 N_lf + 8 N_sa + L_query + 16 N_seed + N_dpcells + sum(m+n))",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_step": alg_total, "terms": m["alg"], "bytes_per_query_base": alg_total / m["bp_per_step"]},
+        "kernels": kern,
+        "stage_ms_one_context_alone": {"seed_search": float(tm[0]), "locate": float(tm[1]), "sort_group": float(tm[2]), "chain": float(tm[3]), "refine": float(tm[4]),
+                                       "extend": float(tm[5]), "host_lists": float(tm[7])},
+        "counters_per_step": {"occ_blocks_algorithmic": int(cnt[0]), "occ_blocks_read": int(m["occ_read"]), "lf_steps_algorithmic": int(cnt[1]), "hits": int(cnt[2]), "seeds": int(cnt[3]),
+                              "dp_cells": int(cnt[4]), "dp_jobs": int(cnt[5]), "blocks_last_contig": m["n_blocks"], "records_last_contig": m["n_frags"], "string_bytes_last_contig": m["n_aln"]},
+    }
+
+
+def cpu_baseline(px, qry, tmp, budget_bp):
+    """The real reference (oracle/_ref) on this host, on a bounded sample of the same workload (the first budget_bp bases of
+    one query contig against the FULL index): (a) its hot path S1-S7 at one thread through libgsref; (b) the unmodified CLI
+    with all cores, whole program, and the same with a 1 kb query -- the difference is its hot path + output at N threads."""
     from gsalign_amd import synth
     from oracle import oracle_py as op
-    qfa = os.path.join(tmp, "cpu_q.fa")
-    synth.write_fasta(qfa, [("q", qry)])
+    sample = qry[:budget_bp]
+    qfa = os.path.join(tmp, "cpu_q.fa"); tiny = os.path.join(tmp, "cpu_tiny.fa")
+    synth.write_fasta(qfa, [("q", sample)]); synth.write_fasta(tiny, [("t", sample[:1000])])
     cores = os.cpu_count() or 1
     if not op.have_ref():
-        # fall back to our own restatement ("port")
         from gsalign_amd import indexio
         o = op.Oracle(indexio.load_index(px))
-        o.set_query(qry); t = time.time(); o.run_to(8); dt = time.time() - t; o.close()
-        return {"value": qry.size / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port", "sample": f"{qry.size} bp query, oracle restatement S1-S7, 1 thread, {dt:.2f} s"}
+        o.set_query(sample); t = time.time(); o.run_to(8); dt = time.time() - t; o.close()
+        return {"value": sample.size / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port", "sample": f"first {sample.size} bp of one query contig, oracle restatement S1-S7, 1 thread, {dt:.2f} s"}
     code = ("import sys,time;sys.path.insert(0,%r);import numpy as np;from oracle import oracle_py as op;from gsalign_amd import synth;"
             "r=op.RefLib(%r);q=synth.read_fasta(%r)[0][1];r.set_query(q);t=time.time();r.run_to(8);print(time.time()-t)" % (ROOT, px, qfa))
     t1 = float(subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1])
     nthr = min(cores, 32)
     t = time.time(); op.ref_run_cli(px, qfa, os.path.join(tmp, "cpu_out"), threads=nthr); tn = time.time() - t
-    v1, vn = qry.size / t1 / 1e9, qry.size / tn / 1e9
+    t = time.time(); op.ref_run_cli(px, tiny, os.path.join(tmp, "cpu_out0"), threads=nthr); t0 = time.time() - t
+    v1 = sample.size / t1 / 1e9
+    thot = max(tn - t0, 1e-3); vn = sample.size / thot / 1e9
     best_cores, best = (1, v1) if v1 >= vn else (nthr, vn)
     return {"value": best, "unit": "Gbp/s", "cores": best_cores, "kind": "reference",
-            "sample": f"{qry.size} bp query vs {qry.size // 1} bp-class reference; reference hot path S1-S7 at -t 1: {t1:.2f} s ({v1:.5f} Gbp/s); "
-                      f"unmodified reference CLI -t {nthr} whole program: {tn:.2f} s ({vn:.5f} Gbp/s); host has {cores} logical cores"}
+            "sample": f"first {sample.size} bp of one query contig vs the full index; reference hot path S1-S7 at -t 1 (libgsref): {t1:.2f} s = {v1:.5f} Gbp/s; "
+                      f"unmodified reference CLI -t {nthr}: {tn:.2f} s whole program, {t0:.2f} s with a 1 kb query (index load + unpack) -> {thot:.2f} s for hot path + output = {vn:.5f} Gbp/s; "
+                      f"host has {cores} logical cores"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=100)      # the first ~50 contigs of a process can run 10 % slow (clock / power state ramp); a step is 1.2 ms
-    ap.add_argument("--genome", type=int, default=5_000_000)
-    ap.add_argument("--divergence", type=float, default=0.02)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--workload", default="human", choices=sorted(WORKLOADS))
+    ap.add_argument("--genome", type=int, default=0, help="override the reference length of a one-contig workload")
+    ap.add_argument("--divergence", type=float, default=-1.0)
+    ap.add_argument("--inflight", type=int, default=2, help="contexts (host threads) per GPU working on different contigs")
+    ap.add_argument("--extra", default="ecoli,yeast", help="further workloads measured in the same run (short loops); '' = none")
+    ap.add_argument("--hwq", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bases of one query contig the CPU baseline is timed on")
     args = ap.parse_args()
+    relaunch_if_needed(args)
+    if args.hwq > 0:
+        os.environ["GPU_MAX_HW_QUEUES"] = str(args.hwq)      # (the runtime's default is 4 hardware queues per process; `inflight` contexts x 4 streams share them)
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr); sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: libgsa_hip.so has no CPU path", file=sys.stderr); sys.exit(2)
     torch.cuda.set_device(local_rank)
@@ -99,110 +291,62 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from gsalign_amd import capi, shard
-    tmp = os.environ.get("GSA_BENCH_TMP") or os.path.join(tempfile.gettempdir(), f"gsa_bench_{os.environ.get('MASTER_PORT', 'single')}_{args.genome}")
+    from gsalign_amd import shard
+    tmp = os.environ.get("GSA_BENCH_TMP") or os.path.join(tempfile.gettempdir(), f"gsa_bench_{os.environ.get('MASTER_PORT', 'single')}")
     os.makedirs(tmp, exist_ok=True)
-    if rank == 0 and os.path.exists(os.path.join(tmp, "ref.done")):
-        os.remove(os.path.join(tmp, "ref.done"))
+    if rank == 0:
+        for fn in os.listdir(tmp):
+            if fn.endswith(".done") and not os.environ.get("GSA_BENCH_KEEP"):
+                os.remove(os.path.join(tmp, fn))
     if world > 1:
         dist.barrier()
-    px, idx, qry = build_workload(tmp, args.genome, args.divergence, rank, world)
-    gpu = capi.Aligner(idx, device=local_rank)
-    # algorithmic bytes of the dominant kernel: one untimed pass of the accounting build
-    gpu.set_profiling(True, count_blocks=True)
-    gpu.set_query(qry); gpu.run_to(1)
-    alg_occ_blocks = int(gpu.counters()[0])
-    gpu.set_profiling(True)
 
     def sync():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
-    def step():
-        gpu.set_query(qry)           # query upload: not part of the timed metric (inputs resident in HBM)
-        return None
+    def whole_job(m):
+        tt = torch.tensor([m["t_total"]], dtype=torch.float64, device=dev); tb = torch.tensor([m["bp"]], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX); dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        return float(tt.item()), float(tb.item())
 
-    def timed_step():
-        # S1..S7 + identity filter; blocks, records and gapped strings land in this rank's host memory.  The path shards by
-        # contig and every rank emits its own contigs' MAF / VCF: there is no exchange step, so no collective in a step.
-        gpu.run_to(8)
-        return gpu.raw_result().n_blocks
-
-    for _ in range(args.warmup):
-        step(); timed_step()
-    # stage split and DP counters: one untimed pass with all stage timers (ten hipEvents per contig);
-    # the timed steps only time the dominant kernel (two events)
-    step(); timed_step()
-    cnt = gpu.counters(); tm = gpu.timings()
-    gpu.set_profiling(False, seed_only=True)
-    step(); timed_step()
-    # the timed region: K steps between one barrier + synchronize on either side.  A step is the whole hot path of the
-    # resident contig (gsa_rewind puts the context back to stage 0 without a new upload); it ends with its results in
-    # host memory, so steps do not overlap.
-    seed_ms, occ_blocks = [], []
-    step()
-    sync(); t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gpu.rewind()
-        res = timed_step()
-        seed_ms.append(float(gpu.timings()[0])); occ_blocks.append(alg_occ_blocks)
-    sync(); t_total = time.perf_counter() - t0
+    wl = dict(WORKLOADS[args.workload])
+    if args.genome > 0 and len(wl["lengths"]) == 1:
+        wl["lengths"] = [args.genome]; wl["label"] += f" [reference length overridden: {args.genome}]"
+    if args.divergence >= 0:
+        wl["div"] = args.divergence; wl["label"] += f" [divergence overridden: {args.divergence}]"
+    m = measure(args.workload, wl, args, tmp, rank, world, local_rank, sync, args.steps, args.warmup)
+    t_max, total_bp = whole_job(m)
     if world > 1:
         # once, outside the timed region: the block records of the last contig of every rank on every rank (what a merged
         # report would start from) -- keeps the RCCL path exercised, costs the metric nothing
-        recs = gpu.block_records()
-        allrecs, _ = shard.gather_block_records(recs, np.full(recs.shape[0], rank, np.int32), device=dev)
-        assert allrecs.shape[0] >= recs.shape[0]
-    tt = torch.tensor([t_total], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    t_max = float(tt.item())
-    total_bp = qry.size * args.steps
-    tb = torch.tensor([float(total_bp)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
-    value = float(tb.item()) / t_max / 1e9
-
+        allrecs, _ = shard.gather_block_records(m["recs"], np.full(m["recs"].shape[0], rank, np.int32), device=dev)
+        assert allrecs.shape[0] >= m["recs"].shape[0]
+    out = None
     if rank == 0:
-        alg_bytes = 64.0 * float(np.mean(occ_blocks)); k_ms = float(np.mean(seed_ms))
-        # HBM traffic of the same kernel comes from separate rocprofv3 --pmc passes (profiles/r01_pmc_seed.json);
-        # it is only quoted when this run is the workload those passes were taken on
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_seed.json")))
-            if pmc["workload"]["genome"] == args.genome and abs(pmc["workload"]["divergence"] - args.divergence) < 1e-12 and world == 1:
-                traffic = float(pmc["traffic_bytes"])
-        except Exception:
-            traffic = None
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        out = {
-            "metric": "aligned query Gbp/s (whole node)", "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * t_max / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 integer",
-            "data": "synthetic",
-            "config": {"workload": f"E. coli-sized synthetic pair: {args.genome} bp reference vs {args.divergence * 100:g} %-diverged query per GPU, default -slen 15 -ind 25 (BASELINE configs[1] stand-in)",
-                       "query_bp_per_gpu": int(qry.size), "parallelism": f"contig-shard x{world}, index replicated",
-                       "vcf_concordance": "bit-identical MAF/VCF vs reference on tests/golden (tests/test_gpu_cli.py)"},
-            # dominant kernel by algorithmic traffic: the seed search (94 % of the path's algorithmic bytes)
-            "roofline": {"bound": "hbm", "kernel": "k_seed_wg", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
-                         "note": "algorithmic bytes = 64 B x Occ blocks the reference's walk reads; the kernel itself reads fewer (k-mer table, dense SA, text compare): see counters.occ_blocks_read"},
-            # longest kernel by time: the striped gap DP -- bound by the m+n anti-diagonal dependency chain of the largest gap, not by bandwidth
-            "roofline_dp": {"bound": "hbm", "kernel": "k_dp_stripe+k_dp_small", "achieved": (float(cnt[4]) + float(cnt[6])) / (float(tm[5]) * 1e-3) / 1e9 if tm[5] > 0 else 0.0,
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ((float(cnt[4]) + float(cnt[6])) / (float(tm[5]) * 1e-3) / 1e9 / HBM_PEAK_GBS) if tm[5] > 0 else 0.0,
-                            "traffic": None, "algorithmic_bytes_per_launch": float(cnt[4]) + float(cnt[6]), "stage_ms": float(tm[5]),
-                            "note": "1 direction byte per DP cell + the two fragments; time is the whole extend stage (job list, DP, strings, results to the host); the large gaps start earlier, under the refine stage"},
-            "stage_ms": {"seed_search": float(tm[0]), "locate": float(tm[1]), "sort_group": float(tm[2]), "chain": float(tm[3]), "refine": float(tm[4]), "extend": float(tm[5]), "host_lists": float(tm[7])},
-            "counters": {"occ_blocks_algorithmic": alg_occ_blocks, "occ_blocks_read": int(cnt[7]), "lf_steps": int(cnt[1]), "hits": int(cnt[2]), "dp_cells": int(cnt[4]), "dp_jobs": int(cnt[5]),
-                         "blocks": int(res), "records": int(gpu.raw_result().n_frags)},
-        }
-        if not args.no_cpu_baseline:
+        out = {"metric": "aligned query Gbp/s (whole node)", "value": None, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic"}
+        out.update(summarise(args.workload, wl, m, t_max, total_bp, world, args))
+        out["config"]["vcf_concordance"] = "bit-identical MAF/VCF vs reference on tests/golden (tests/test_gpu_cli.py)"
+    extras = []
+    for name in [x for x in args.extra.split(",") if x and x != args.workload]:
+        w2 = WORKLOADS[name]
+        st = 50 if name == "ecoli" else 6
+        m2 = measure(name, w2, args, tmp, rank, world, local_rank, sync, st, max(2, st // 5))
+        t2, b2 = whole_job(m2)
+        if rank == 0:
+            e = {"workload": name, "steps": st, "unit": "Gbp/s"}
+            e.update(summarise(name, w2, m2, t2, b2, world, args)); extras.append(e)
+    if rank == 0:
+        out["extra_workloads"] = extras
+        if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(px, qry, tmp)
-            except Exception as e:   # never lose the GPU line to a baseline hiccup
+                out["cpu_baseline"] = cpu_baseline(m["px"], m["genomes"][0][0], tmp, args.cpu_sample)
+            except Exception as e:   # never lose the GPU line to a baseline hiccup      # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
         print(json.dumps(out))
-    gpu.close()
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgsa_hip.so")
 
 EXPORTS = [
-    "gsa_default_params", "gsa_create", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig",
+    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig",
     "gsa_set_query", "gsa_rewind", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
     "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling",
 ]
@@ -67,6 +67,11 @@ def load_library() -> C.CDLL:
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
     lib = C.CDLL(LIB_PATH)
     lib.gsa_create.argtypes = [C.c_int, C.POINTER(IndexView), C.POINTER(Params), C.POINTER(C.c_void_p)]
+    lib.gsa_create_opts.argtypes = [C.c_int, C.POINTER(IndexView), C.POINTER(Params), C.c_uint32, C.POINTER(C.c_void_p)]
+    lib.gsa_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.gsa_host_alloc.restype = C.c_void_p
+    lib.gsa_host_alloc.argtypes = [C.c_size_t]
+    lib.gsa_host_free.argtypes = [C.c_void_p]
     lib.gsa_last_error.restype = C.c_char_p
     lib.gsa_last_error.argtypes = [C.c_void_p]
     lib.gsa_seed_count.restype = C.c_int64
@@ -90,9 +95,17 @@ class GsaError(RuntimeError):
 class Aligner:
     """One gsa_ctx on one GPU."""
 
-    def __init__(self, idx, device: int = 0, **params):
+    def __init__(self, idx, device: int = 0, wide: bool = False, _clone_of=None, **params):
         self.lib = load_library()
         self.idx = idx
+        self._pinned = []
+        if _clone_of is not None:
+            self.ctx = C.c_void_p()
+            rc = self.lib.gsa_clone(_clone_of.ctx, C.byref(self.ctx))
+            if rc != 0:
+                raise GsaError(f"gsa_clone -> {rc}: {self.lib.gsa_last_error(None).decode()}")
+            self._parent = _clone_of        # keeps the index owner alive
+            return
         self._ref = np.ascontiguousarray(idx.ref)
         v = IndexView()
         v.primary = int(idx.hdr[0])
@@ -105,9 +118,25 @@ class Aligner:
         v.chr_len = _p(idx.chr_len, C.c_int32); v.n_chr = len(idx.chr_len)
         self.ctx = C.c_void_p()
         p = self._params(**params)
-        rc = self.lib.gsa_create(device, C.byref(v), C.byref(p), C.byref(self.ctx))
+        # wide=True: GSA_CREATE_WIDE, the >= 2^32-row device layout on any index; plain gsa_create otherwise (it honours GSA_FORCE_WIDE)
+        rc = self.lib.gsa_create_opts(device, C.byref(v), C.byref(p), 1, C.byref(self.ctx)) if wide else self.lib.gsa_create(device, C.byref(v), C.byref(p), C.byref(self.ctx))
         if rc != 0:
             raise GsaError(f"gsa_create -> {rc}: {self.lib.gsa_last_error(None).decode()}")
+
+    def clone(self) -> "Aligner":
+        """A further context on the same GPU sharing this one's device index (gsa_clone)."""
+        return Aligner(self.idx, _clone_of=self)
+
+    def pinned_copy(self, seq: np.ndarray) -> np.ndarray:
+        """seq copied into pinned host memory from gsa_host_alloc (what a FASTA loader of an integrated host reads into)."""
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        p = self.lib.gsa_host_alloc(seq.size + 64)
+        if not p:
+            raise GsaError("gsa_host_alloc failed")
+        self._pinned.append(p)
+        buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(seq.size,))
+        buf[:] = seq
+        return buf
 
     def _params(self, slen=15, ind=25, clr=200, alen=200, idy=70, sen=0, one=0) -> Params:
         return Params(slen, ind, clr, alen, idy, sen, one)
@@ -250,9 +279,19 @@ class Aligner:
         self._ck(self.lib.gsa_gap_similarity_batch(self.ctx, C.c_int32(q1.size), _p(q1, C.c_int32), _p(q2, C.c_int32), _p(r1, C.c_int64), _p(r2, C.c_int64), _p(res, C.c_int32)))
         return res
 
+    def align_contig_raw(self, seq: np.ndarray) -> Result:
+        """gsa_align_contig without copying the result out (views into library-owned memory)."""
+        self._q = seq
+        res = Result()
+        self._ck(self.lib.gsa_align_contig(self.ctx, seq.ctypes.data_as(C.c_char_p), C.c_int32(seq.size), C.byref(res)))
+        return res
+
     def close(self):
         if self.ctx:
             self.lib.gsa_destroy(self.ctx); self.ctx = C.c_void_p()
+        for p in self._pinned:
+            self.lib.gsa_host_free(p)
+        self._pinned = []
 
 
 def apply_ops(s1: bytes, s2: bytes, ops: bytes):

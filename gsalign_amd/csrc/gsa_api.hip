@@ -7,7 +7,7 @@
 #include <cstring>
 #include "gsa_ctx.h"
 
-static std::string g_create_error;
+static thread_local std::string g_create_error;
 
 int gsa_fail(gsa_ctx *ctx, int code, const std::string &msg)
 {
@@ -34,6 +34,20 @@ void collect_events(gsa_ctx *c)
 	(void)hipGetLastError();
 }
 
+// what every context owns, shared index or not: streams, events, counters, mailbox
+static int ctx_private_init(gsa_ctx *c)
+{
+	GSA_CHECK(c, hipStreamCreate(&c->stream));
+	for (int i = 0; i < 3; i++) GSA_CHECK(c, hipStreamCreate(&c->stream_aux[i]));
+	for (int i = 0; i < 28; i++) GSA_CHECK(c, hipEventCreate(&c->ev[i]));
+	GSA_CHECK(c, hipMalloc(&c->d_cnt.p, 16 * sizeof(u64))); c->d_cnt.cap = 16 * sizeof(u64); GSA_CHECK(c, hipMemset(c->d_cnt.p, 0, 16 * sizeof(u64)));
+	GSA_CHECK(c, hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(u64)));
+	GSA_CHECK(c, hipMalloc(&c->d_mail.p, MAIL_N * sizeof(i32))); c->d_mail.cap = MAIL_N * sizeof(i32);
+	GSA_CHECK(c, hipMemset(c->d_mail.p, 0, MAIL_N * sizeof(i32)));
+	GSA_CHECK(c, hipHostMalloc((void **)&c->h_mail, MAIL_N * sizeof(i32)));
+	return GSA_OK;
+}
+
 extern "C" {
 
 void gsa_default_params(gsa_params *p)
@@ -45,34 +59,52 @@ void gsa_default_params(gsa_params *p)
 
 const char *gsa_last_error(gsa_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+// Back to stage 0: nothing of the previous run may still be in flight or half-consumed (the early striped DP launch
+// writes e_* buffers the next stage 2 would reuse).
+static int reset_run_state(gsa_ctx *c)
+{
+	if (c->early_in_flight) { GSA_CHECK(c, hipStreamSynchronize(c->stream_aux[0])); c->early_in_flight = false; }
+	c->n_early = 0; c->early_listed = false; c->early_consumed = false;
+	c->stage = 0;
+	c->n_seeds = 0; c->n_groups = 0; c->n_blocks2 = 0; c->blocks.clear(); c->frags_stage = 0; c->have_host_seeds = false; c->ev_pending = 0; c->s2_host = false;
+	memset(c->counters, 0, sizeof(c->counters)); memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
+	return GSA_OK;
+}
+
 int gsa_set_params(gsa_ctx *c, const gsa_params *p)
 {
 	if (!c || !p) return GSA_ERR_ARG;
 	if (p->min_seed_len < 1 || p->max_indel < 0) return gsa_fail(c, GSA_ERR_ARG, "bad parameter");
+	GSA_CHECK(c, hipSetDevice(c->device));
+	if (int rc = reset_run_state(c)) return rc;
 	c->prm.MinSeedLength = p->sensitive ? 10 : p->min_seed_len;         // main.cpp:323
 	c->prm.MaxIndelSize = p->max_indel; c->prm.MinAlnBlockScore = p->min_block_score; c->prm.MinAlnLength = p->min_aln_len;
 	c->prm.MinSeqIdy = p->min_identity; c->prm.bSensitive = p->sensitive ? 1 : 0; c->prm.OneOnOne = p->one_on_one ? 1 : 0;
-	c->stage = 0;
 	return build_presence(c);
 }
 
 int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa_ctx **out)
+{
+	const char *w = getenv("GSA_FORCE_WIDE");        // whole runs (CLI, test-suite) under the >= 2^32-row layout
+	return gsa_create_opts(device, idx, prm, (w && *w && *w != '0') ? GSA_CREATE_WIDE : 0u, out);
+}
+
+int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm, uint32_t flags, gsa_ctx **out)
 {
 	if (!idx || !out || !idx->bwt || !idx->sa || !idx->ref || !idx->chr_len || idx->n_chr <= 0 || idx->G <= 0) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create: bad index view");
 	if (idx->L2[4] != (uint64_t)(2 * idx->G)) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create: L2[4] != 2G");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gsa_fail(nullptr, GSA_ERR_HIP, "no HIP device available (libgsa_hip.so has no CPU path)");
 	if (device < 0 || device >= ndev) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create: bad device ordinal");
+	if (flags & ~(uint32_t)GSA_CREATE_WIDE) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create_opts: unknown flag");
 	gsa_ctx *c = new gsa_ctx();
-	c->device = device;
+	c->device = device; c->force_wide = (flags & GSA_CREATE_WIDE) != 0;
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gsa_fail(nullptr, GSA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); gsa_destroy(c); return GSA_ERR_HIP; } } while (0)
 	CK(hipSetDevice(device));
 	(void)hipSetDeviceFlags(hipDeviceScheduleSpin);      // host waits spin instead of sleeping: the pipeline has ~20 short count read-backs per contig
 	(void)hipGetLastError();
-	CK(hipStreamCreate(&c->stream));
-	CK(hipStreamCreate(&c->stream_aux[0])); CK(hipStreamCreate(&c->stream_aux[1])); CK(hipStreamCreate(&c->stream_aux[2]));
-	for (int i = 0; i < 28; i++) CK(hipEventCreate(&c->ev[i]));
+	if (int rcp = ctx_private_init(c)) { g_create_error = c->err; gsa_destroy(c); return rcp; }
 	const size_t bwt_bytes = ((idx->bwt_words + 15) / 16) * 64;          // whole 64-byte blocks
 	CK(hipMalloc(&c->d_bwt.p, bwt_bytes + 64)); c->d_bwt.cap = bwt_bytes + 64;
 	CK(hipMemset(c->d_bwt.p, 0, bwt_bytes + 64));
@@ -96,11 +128,6 @@ int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa
 	}
 	CK(hipMalloc(&c->d_chr_end.p, c->h_chr_end.size() * 8)); CK(hipMemcpy(c->d_chr_end.p, c->h_chr_end.data(), c->h_chr_end.size() * 8, hipMemcpyHostToDevice));
 	CK(hipMalloc(&c->d_chr_of_end.p, c->h_chr_of_end.size() * 4)); CK(hipMemcpy(c->d_chr_of_end.p, c->h_chr_of_end.data(), c->h_chr_of_end.size() * 4, hipMemcpyHostToDevice));
-	CK(hipMalloc(&c->d_cnt.p, 16 * sizeof(u64))); c->d_cnt.cap = 16 * sizeof(u64); CK(hipMemset(c->d_cnt.p, 0, 16 * sizeof(u64)));
-	CK(hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(u64)));
-	CK(hipMalloc(&c->d_mail.p, MAIL_N * sizeof(i32))); c->d_mail.cap = MAIL_N * sizeof(i32);
-	CK(hipMemset(c->d_mail.p, 0, MAIL_N * sizeof(i32)));
-	CK(hipHostMalloc((void **)&c->h_mail, MAIL_N * sizeof(i32)));
 #undef CK
 	c->di.primary = idx->primary; for (int i = 0; i < 5; i++) c->di.L2[i] = idx->L2[i]; c->di.L2[0] = 0;
 	c->di.seq_len = idx->L2[4];
@@ -128,7 +155,10 @@ void gsa_destroy(gsa_ctx *c)
 		&c->r_q, &c->r_len, &c->r_r, &c->r_bid, &c->r_tmp_q, &c->r_tmp_len, &c->r_tmp_r, &c->r_tmp_bid, &c->r_cut4, &c->r_cut5, &c->r_simjob, &c->r_simres, &c->d_leaf,
 		&c->fb_seedbase, &c->fb_sbeg, &c->fb_fragbase, &c->f_rec, &c->f_type, &c->f_mism, &c->f_alnlen, &c->f_job, &c->f_score,
 		&c->d_dp_tiny, &c->d_dp_bnd, &c->d_dp_ctr, &c->d_dp_jobs, &c->d_dp_large, &c->d_tail,
-		&c->e_id, &c->e_rec, &c->e_list, &c->e_off1, &c->e_off2, &c->e_opsoff, &c->e_nops, &c->e_ops, &c->e_rev, &c->r_head, &c->f_early, &c->r_orig, &c->r_tmp_orig, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_alnoff, &c->bl_alnlen, &c->bl_score };
+		&c->e_id, &c->e_rec, &c->e_list, &c->e_off1, &c->e_off2, &c->e_opsoff, &c->e_nops, &c->e_ops, &c->e_rev, &c->r_head, &c->f_early, &c->r_orig, &c->r_tmp_orig, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_alnoff, &c->bl_alnlen, &c->bl_score,
+		&c->leaf[0], &c->leaf[1], &c->leaf[2], &c->leaf[3], &c->leaf[4], &c->leaf[5], &c->leaf[6], &c->leaf[7], &c->leaf[8] };
+	// (a gsa_clone context borrows the index through `di` only: its index DevBufs are empty, a presence bitmap it built after
+	//  a parameter change is its own)
 	for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
 	if (c->h_mail) hipHostFree(c->h_mail);
@@ -139,23 +169,51 @@ void gsa_destroy(gsa_ctx *c)
 	delete c;
 }
 
+// A second context on the same GPU that shares `parent`'s device-resident index (read-only: BWT + Occ, both SAs, k-mer
+// table, packed and ASCII text, chromosome table) and owns everything else.  What the reference does with N pthreads
+// on one contig, a host does here with N contexts on N contigs: while one contig sits in the dependency chain of its
+// largest DP problem, the next one's seed search and chaining fill the idle CUs, and its upload overlaps both.
+int gsa_clone(gsa_ctx *parent, gsa_ctx **out)
+{
+	if (!parent || !out) return GSA_ERR_ARG;
+	if (hipSetDevice(parent->device) != hipSuccess) return gsa_fail(nullptr, GSA_ERR_HIP, "hipSetDevice");
+	gsa_ctx *c = new gsa_ctx();
+	c->device = parent->device; c->force_wide = parent->force_wide;
+	c->index_owner = parent->index_owner ? parent->index_owner : parent;
+	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
+	if (int rc = ctx_private_init(c)) { g_create_error = c->err; gsa_destroy(c); return rc; }
+	c->di = parent->di; c->G = parent->G;
+	c->h_chr_end = parent->h_chr_end; c->h_chr_fwd = parent->h_chr_fwd; c->h_chr_of_end = parent->h_chr_of_end; c->h_chr_len = parent->h_chr_len;
+	c->prm = parent->prm;
+	*out = c;
+	return GSA_OK;
+}
+
+// Pinned host memory for query contigs: a FASTA loader that reads into such a buffer makes the upload of
+// gsa_align_contig one asynchronous DMA transfer (pageable memory is staged through the runtime's bounce buffers).
+void *gsa_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	return p;
+}
+void gsa_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->profiling = (enable & 1) != 0; c->count_blocks = (enable & 2) != 0; c->prof_seed = (enable & 4) != 0; return GSA_OK; }
 
 int gsa_set_query(gsa_ctx *c, const char *query, int32_t qlen)
 {
 	if (!c || !query || qlen < 0) return GSA_ERR_ARG;
 	GSA_CHECK(c, hipSetDevice(c->device));
-	if (c->early_in_flight) { GSA_CHECK(c, hipStreamSynchronize(c->stream_aux[0])); c->early_in_flight = false; }
-	c->n_early = 0; c->early_listed = false; c->early_consumed = false;
+	if (int rc = reset_run_state(c)) return rc;
 	if (!dev_ensure<uint8_t>(c, c->d_query, (size_t)qlen + 64)) return GSA_ERR_NOMEM;
+	// (a buffer from gsa_host_alloc is pinned: the copy is one DMA transfer the seed kernel queues behind; pageable memory is
+	// staged by the runtime)
 	GSA_CHECK(c, hipMemcpyAsync(c->d_query.p, query, (size_t)qlen, hipMemcpyHostToDevice, c->stream));
-	c->h_query.assign(query, (size_t)qlen);
-	c->qlen = qlen; c->stage = 0;
+	c->qlen = qlen;
 	c->qbits = ceil_log2_u64((u64)qlen + 1); if (c->qbits < 1) c->qbits = 1;
 	c->pdbits = ceil_log2_u64((u64)(2 * c->G) + (u64)qlen + 2);
 	if (c->qbits + c->pdbits > 64) return gsa_fail(c, GSA_ERR_LIMIT, "contig too long for the 64-bit seed key");
-	c->n_seeds = 0; c->n_groups = 0; c->n_blocks2 = 0; c->blocks.clear(); c->frags_stage = 0; c->have_host_seeds = false; c->ev_pending = 0; c->s2_host = false;
-	memset(c->counters, 0, sizeof(c->counters)); memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
 	return GSA_OK;
 }
 
@@ -165,12 +223,7 @@ int gsa_rewind(gsa_ctx *c)
 	if (!c) return GSA_ERR_ARG;
 	if (c->qlen <= 0) return gsa_fail(c, GSA_ERR_STATE, "gsa_set_query first");
 	GSA_CHECK(c, hipSetDevice(c->device));
-	if (c->early_in_flight) { GSA_CHECK(c, hipStreamSynchronize(c->stream_aux[0])); c->early_in_flight = false; }
-	c->n_early = 0; c->early_listed = false; c->early_consumed = false;
-	c->stage = 0;
-	c->n_seeds = 0; c->n_groups = 0; c->n_blocks2 = 0; c->blocks.clear(); c->frags_stage = 0; c->have_host_seeds = false; c->ev_pending = 0; c->s2_host = false;
-	memset(c->counters, 0, sizeof(c->counters)); memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
-	return GSA_OK;
+	return reset_run_state(c);
 }
 
 int gsa_run_to(gsa_ctx *c, int stage)

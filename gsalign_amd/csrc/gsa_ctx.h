@@ -18,7 +18,7 @@ struct Leaf {
 
 // Device "mailbox" (i32[MAIL_N]) of the counts the stages produce; the host reads the whole
 // box in ONE pinned copy where it needs them instead of one read-back per count.
-enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_NTINY = 40, M_TICKET = 48, M_NBRAW = 49, M_NR2 = 50, M_NF = 51, M_NJOB = 52, M_OPSTOT = 53, M_NALN = 54, M_DPERR = 55, M_NLARGE = 56, M_DPERR2 = 57, M_CELLS = 58 /* two u64: sum m*n, sum m+n */, M_DPERR3 = 41, M_LBDONE = 42, M_NEARLY = 62, M_EOPS = 63, MAIL_N = 64 };
+enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_NTINY = 40, M_TICKET = 48, M_NBRAW = 49, M_NR2 = 50, M_NF = 51, M_NJOB = 52, M_OPSTOT = 53, M_NALN = 54, M_DPERR = 55, M_NLARGE = 56, M_DPERR2 = 57, M_CELLS = 58 /* two u64: sum m*n, sum m+n */, M_DPERR3 = 41, M_LBDONE = 42, M_LFSTEPS = 44 /* u64, accounting build */, M_NEARLY = 62, M_EOPS = 63, MAIL_N = 64 };
 #define LEAF_CHUNK 1024      // leaves copied together with the mailbox (more -> a second copy)
 
 struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf range
@@ -36,6 +36,8 @@ struct gsa_ctx {
 	std::string err;
 	Params prm;
 	DevIndex di;
+	gsa_ctx *index_owner = nullptr;                // gsa_clone: the context whose device index this one borrows (nullptr = own)
+	bool force_wide = false;                       // GSA_CREATE_WIDE: 64-bit dense SA + 32-byte k-mer entries whatever the text length (the >= 2^32-row layout)
 	bool profiling = false;
 	bool prof_seed = false;                        // time the seed kernel only (two events instead of ten per contig)
 	bool count_blocks = false;                     // run the accounting build of the seed kernel (exact algorithmic Occ-block count)
@@ -51,11 +53,11 @@ struct gsa_ctx {
 
 	// query
 	DevBuf d_query; i32 qlen = 0; int stage = 0;
-	std::string h_query;
 	int qbits = 1, pdbits = 1;
 
 	// scratch for rocPRIM
 	DevBuf tmp;
+	DevBuf leaf[9];                                // device staging of the leaf operators' batches (kept: a batch call allocates nothing once warm)
 	// device counters block (u64[16]) + pinned host mirror
 	DevBuf d_cnt; u64 *h_cnt = nullptr;
 	DevBuf d_mail; i32 *h_mail = nullptr;          // count mailbox + pinned mirror

@@ -19,8 +19,18 @@ int gsah_c_build_index(const char *fasta, const char *prefix, char *err)
 // get_result(user, contig_index, seq, len, &result) is called once per contig, in order.
 typedef int (*gsah_result_cb)(void *user, int contig, const char *seq, int len, gsa_result *out);
 
+int gsah_c_emit_fmt(const char *index_prefix, const char *query_fa, const char *maf_path, const char *vcf_path, const char *reference_label,
+                    int allow_dup, int fmt, gsah_result_cb cb, void *user, char *err);
+
 int gsah_c_emit(const char *index_prefix, const char *query_fa, const char *maf_path, const char *vcf_path, const char *reference_label,
                 int allow_dup, gsah_result_cb cb, void *user, char *err)
+{
+	return gsah_c_emit_fmt(index_prefix, query_fa, maf_path, vcf_path, reference_label, allow_dup, 1, cb, user, err);
+}
+
+// fmt 1: MAF (OutputMAF), fmt 2: ALN (OutputAlignment) -- the -fmt flag of the CLI (main.cpp:284)
+int gsah_c_emit_fmt(const char *index_prefix, const char *query_fa, const char *maf_path, const char *vcf_path, const char *reference_label,
+                    int allow_dup, int fmt, gsah_result_cb cb, void *user, char *err)
 {
 	std::string e; HostIndex idx; std::vector<QueryContig> qs;
 	if (!gsah_load_index(index_prefix, idx, e) || !gsah_load_query(query_fa, qs, e)) { if (err) { strncpy(err, e.c_str(), 255); err[255] = 0; } return -1; }
@@ -32,7 +42,8 @@ int gsah_c_emit(const char *index_prefix, const char *query_fa, const char *maf_
 		ContigResult cr; cr.assign(res);
 		FILE *fp = fopen(maf_path, ci == 0 ? "w" : "a");         // tools.cpp:158-163
 		if (!fp) { if (err) strcpy(err, "cannot open MAF output"); return -3; }
-		em.maf(fp, ci == 0, qs[ci], cr); fclose(fp);
+		if (fmt == 2) em.aln(fp, qs[ci], cr); else em.maf(fp, ci == 0, qs[ci], cr);
+		fclose(fp);
 		em.variants((int)ci, qs[ci], cr);
 	}
 	FILE *fp = fopen(vcf_path, "w");

@@ -34,59 +34,79 @@ bool read_file(const std::string &path, std::vector<uint8_t> &out)
 }
 
 // ---- SA-IS (Nong, Zhang, Chan): suffix array of T[0..n), T[n-1] = unique smallest ----
-template <class Ch>
-void induce(const Ch *T, int32_t *SA, int32_t n, int32_t K, const std::vector<bool> &isS, std::vector<int32_t> &bkt, const std::vector<int32_t> &cnt)
+// I = index type: int32_t up to 2^31 - 2 suffixes (a reference of 1 Gbp: the text is forward + reverse complement + '$'),
+// int64_t beyond (a 3.1 Gbp human reference = 6.2 G suffixes, 8 bytes each).
+template <class Ch, class I>
+void induce(const Ch *T, I *SA, I n, I K, const std::vector<bool> &isS, std::vector<I> &bkt, const std::vector<I> &cnt)
 {
-	int32_t sum = 0;
-	for (int32_t c = 0; c < K; c++) { bkt[c] = sum; sum += cnt[c]; }                 // bucket starts
-	for (int32_t i = 0; i < n; i++) { int32_t j = SA[i] - 1; if (SA[i] > 0 && !isS[j]) SA[bkt[T[j]]++] = j; }
+	I sum = 0;
+	for (I c = 0; c < K; c++) { bkt[c] = sum; sum += cnt[c]; }                 // bucket starts
+	for (I i = 0; i < n; i++) { I j = SA[i] - 1; if (SA[i] > 0 && !isS[j]) SA[bkt[T[j]]++] = j; }
 	sum = 0;
-	for (int32_t c = 0; c < K; c++) { sum += cnt[c]; bkt[c] = sum; }                 // bucket ends
-	for (int32_t i = n - 1; i >= 0; i--) { int32_t j = SA[i] - 1; if (SA[i] > 0 && isS[j]) SA[--bkt[T[j]]] = j; }
+	for (I c = 0; c < K; c++) { sum += cnt[c]; bkt[c] = sum; }                 // bucket ends
+	for (I i = n - 1; i >= 0; i--) { I j = SA[i] - 1; if (SA[i] > 0 && isS[j]) SA[--bkt[T[j]]] = j; }
 }
 
-template <class Ch>
-void sais(const Ch *T, int32_t *SA, int32_t n, int32_t K)
+template <class Ch, class I>
+void sais(const Ch *T, I *SA, I n, I K)
 {
 	if (n == 1) { SA[0] = 0; return; }
-	std::vector<bool> isS(n);
+	std::vector<bool> isS((size_t)n);
 	isS[n - 1] = true;
-	for (int32_t i = n - 2; i >= 0; i--) isS[i] = T[i] < T[i + 1] || (T[i] == T[i + 1] && isS[i + 1]);
-	auto isLMS = [&](int32_t i) { return i > 0 && isS[i] && !isS[i - 1]; };
-	std::vector<int32_t> cnt(K, 0), bkt(K);
-	for (int32_t i = 0; i < n; i++) cnt[T[i]]++;
-	auto ends = [&]() { int32_t s = 0; for (int32_t c = 0; c < K; c++) { s += cnt[c]; bkt[c] = s; } };
+	for (I i = n - 2; i >= 0; i--) isS[i] = T[i] < T[i + 1] || (T[i] == T[i + 1] && isS[i + 1]);
+	auto isLMS = [&](I i) { return i > 0 && isS[i] && !isS[i - 1]; };
+	std::vector<I> cnt((size_t)K, 0), bkt((size_t)K);
+	for (I i = 0; i < n; i++) cnt[T[i]]++;
+	auto ends = [&]() { I s = 0; for (I c = 0; c < K; c++) { s += cnt[c]; bkt[c] = s; } };
 	// 1. sort LMS substrings
-	std::fill(SA, SA + n, -1);
+	std::fill(SA, SA + n, (I)-1);
 	ends();
-	for (int32_t i = 1; i < n; i++) if (isLMS(i)) SA[--bkt[T[i]]] = i;
+	for (I i = 1; i < n; i++) if (isLMS(i)) SA[--bkt[T[i]]] = i;
 	induce(T, SA, n, K, isS, bkt, cnt);
-	int32_t n1 = 0;
-	for (int32_t i = 0; i < n; i++) if (isLMS(SA[i])) SA[n1++] = SA[i];
-	std::fill(SA + n1, SA + n, -1);
-	int32_t name = 0, prev = -1;
-	for (int32_t i = 0; i < n1; i++) {
-		int32_t pos = SA[i]; bool diff = false;
+	I n1 = 0;
+	for (I i = 0; i < n; i++) if (isLMS(SA[i])) SA[n1++] = SA[i];
+	std::fill(SA + n1, SA + n, (I)-1);
+	I name = 0, prev = -1;
+	for (I i = 0; i < n1; i++) {
+		I pos = SA[i]; bool diff = false;
 		if (prev < 0) diff = true;
-		else for (int32_t d = 0;; d++) {
+		else for (I d = 0;; d++) {
 			if (pos + d >= n || prev + d >= n || T[pos + d] != T[prev + d] || isS[pos + d] != isS[prev + d]) { diff = true; break; }
 			if (d > 0 && (isLMS(pos + d) || isLMS(prev + d))) { diff = !(isLMS(pos + d) && isLMS(prev + d)); break; }
 		}
 		if (diff) { name++; prev = pos; }
 		SA[n1 + (pos >> 1)] = name - 1;
 	}
-	for (int32_t i = n - 1, j = n - 1; i >= n1; i--) if (SA[i] >= 0) SA[j--] = SA[i];
-	int32_t *s1 = SA + n - n1, *SA1 = SA;
+	for (I i = n - 1, j = n - 1; i >= n1; i--) if (SA[i] >= 0) SA[j--] = SA[i];
+	I *s1 = SA + n - n1, *SA1 = SA;
 	// 2. order of the LMS suffixes
-	if (name < n1) sais<int32_t>(s1, SA1, n1, name);
-	else for (int32_t i = 0; i < n1; i++) SA1[s1[i]] = i;
+	if (name < n1) sais<I, I>(s1, SA1, n1, name);
+	else for (I i = 0; i < n1; i++) SA1[s1[i]] = i;
 	// 3. induce everything from the sorted LMS suffixes
-	for (int32_t i = 1, j = 0; i < n; i++) if (isLMS(i)) s1[j++] = i;
-	for (int32_t i = 0; i < n1; i++) SA1[i] = s1[SA1[i]];
-	std::fill(SA + n1, SA + n, -1);
+	for (I i = 1, j = 0; i < n; i++) if (isLMS(i)) s1[j++] = i;
+	for (I i = 0; i < n1; i++) SA1[i] = s1[SA1[i]];
+	std::fill(SA + n1, SA + n, (I)-1);
 	ends();
-	for (int32_t i = n1 - 1; i >= 0; i--) { int32_t j = SA[i]; SA[i] = -1; SA[--bkt[T[j]]] = j; }
+	for (I i = n1 - 1; i >= 0; i--) { I j = SA[i]; SA[i] = -1; SA[--bkt[T[j]]] = j; }
 	induce(T, SA, n, K, isS, bkt, cnt);
+}
+
+// BWT without '$' (2 bits per symbol, MSB first in each word), primary row and the SA samples of every 32nd row, from the
+// suffix array of T = text + '$' (symbols 1..4, T[S] = 0)
+template <class I>
+void derive_bwt_sa(const std::vector<uint8_t> &T, int64_t S, std::vector<uint32_t> &packed, uint64_t &primary, std::vector<uint64_t> &sa)
+{
+	const I n = (I)(S + 1);
+	std::vector<I> SA((size_t)n);
+	sais<uint8_t, I>(T.data(), SA.data(), n, (I)5);
+	int64_t k = 0;
+	for (I i = 0; i < n; i++) {
+		if (SA[i] == 0) { primary = (uint64_t)i; continue; }
+		const uint32_t c = T[SA[i] - 1] - 1;
+		packed[k >> 4] |= c << ((~k & 15) << 1);
+		k++;
+	}
+	for (uint64_t i = 1; i < sa.size(); i++) sa[i] = (uint64_t)SA[32 * i];
 }
 
 struct FaRec { std::string name, comment, seq; };
@@ -220,7 +240,6 @@ bool gsah_build_index(const std::string &fasta, const std::string &prefix, std::
 	}
 	const int64_t G = (int64_t)codes.size();
 	if (G <= 0) { err = "empty reference"; return false; }
-	if (2 * G + 1 >= (1ll << 31)) { err = "reference too long for the 32-bit suffix sorter (> 1 Gbp)"; return false; }
 	// .pac (forward only; bntseq.c:192-201)
 	{
 		std::vector<uint8_t> pac((size_t)((G >> 2) + ((G & 3) ? 1 : 0)), 0);
@@ -248,26 +267,23 @@ bool gsah_build_index(const std::string &fasta, const std::string &prefix, std::
 		fclose(fp);
 	}
 	// ---- text = forward + reverse complement, then '$' ----
-	const int64_t S = 2 * G; const int32_t n = (int32_t)(S + 1);
-	std::vector<uint8_t> T((size_t)n);
+	const int64_t S = 2 * G;
+	std::vector<uint8_t> T((size_t)S + 1);
 	for (int64_t i = 0; i < G; i++) { T[i] = codes[i] + 1; T[S - 1 - i] = (3 - codes[i]) + 1; }
 	T[S] = 0;
-	std::vector<int32_t> SA((size_t)n);
-	sais<uint8_t>(T.data(), SA.data(), n, 5);
-	// ---- BWT without '$', primary, L2 ----
+	{ std::vector<uint8_t>().swap(codes); }
+	// ---- suffix array -> BWT without '$', primary, L2, SA samples (bwt_cal_sa, bwt.c:101-123) ----
 	uint64_t primary = 0, L2[5] = {0, 0, 0, 0, 0};
 	std::vector<uint32_t> packed((size_t)((S + 15) / 16), 0);
-	{
-		int64_t k = 0;
-		for (int32_t i = 0; i < n; i++) {
-			if (SA[i] == 0) { primary = (uint64_t)i; continue; }
-			const uint32_t c = T[SA[i] - 1] - 1;
-			packed[k >> 4] |= c << ((~k & 15) << 1);
-			k++;
-		}
-		for (int64_t i = 0; i < S; i++) L2[T[i]]++;            // T[i] in 1..4 -> L2[1..4] counts
-		for (int c = 1; c < 5; c++) L2[c] += L2[c - 1];
-	}
+	const uint64_t n_sa = (uint64_t)(S + 32) / 32;
+	std::vector<uint64_t> sa(n_sa);
+	// (GSA_INDEX_64BIT=1 forces the wide suffix sorter on any input: how the tests reach it with a small fixture)
+	const char *f64 = getenv("GSA_INDEX_64BIT");
+	if (S + 1 < (1ll << 31) - 1 && !(f64 && *f64 && *f64 != '0')) derive_bwt_sa<int32_t>(T, S, packed, primary, sa);
+	else derive_bwt_sa<int64_t>(T, S, packed, primary, sa);
+	for (int64_t i = 0; i < S; i++) L2[T[i]]++;            // T[i] in 1..4 -> L2[1..4] counts
+	for (int c = 1; c < 5; c++) L2[c] += L2[c - 1];
+	{ std::vector<uint8_t>().swap(T); }
 	// ---- interleave Occ every 128 (bwt_bwtupdate_core, bwtindex.c:53-75) ----
 	const uint64_t n_occ = (uint64_t)(S + 127) / 128 + 1;
 	std::vector<uint32_t> bwt(packed.size() + n_occ * 8, 0);
@@ -286,11 +302,9 @@ bool gsah_build_index(const std::string &fasta, const std::string &prefix, std::
 		fput(fp, &primary, 8); fput(fp, &L2[1], 32); fput(fp, bwt.data(), bwt.size() * 4);
 		fclose(fp);
 	}
-	// ---- SA sampled every 32 rows (bwt_cal_sa + bwt_dump_sa, bwt.c:101-123,185-196) ----
+	// ---- SA sampled every 32 rows (bwt_dump_sa, bwt.c:185-196) ----
 	{
-		const uint64_t n_sa = (uint64_t)(S + 32) / 32, intv = 32, seq_len = (uint64_t)S;
-		std::vector<uint64_t> sa(n_sa);
-		for (uint64_t i = 1; i < n_sa; i++) sa[i] = (uint64_t)SA[32 * i];
+		const uint64_t intv = 32, seq_len = (uint64_t)S;
 		FILE *fp = fopen((prefix + ".sa").c_str(), "wb"); if (!fp) { err = "cannot write .sa"; return false; }
 		fput(fp, &primary, 8); fput(fp, &L2[1], 32); fput(fp, &intv, 8); fput(fp, &seq_len, 8); fput(fp, sa.data() + 1, (n_sa - 1) * 8);
 		fclose(fp);

@@ -664,10 +664,10 @@ extern "C" int gsa_ksw2_batch(gsa_ctx *c, int32_t n_pairs, const char *pool1, co
 		if (off2[i] + len2[i] > p2) p2 = off2[i] + len2[i];
 		if (ops_off[i] + len1[i] + len2[i] > po) po = ops_off[i] + len1[i] + len2[i];
 	}
-	uint8_t *d_p1, *d_p2, *d_ops; i64 *d_o1, *d_o2, *d_oo; i32 *d_l1, *d_l2, *d_ol;
-	GSA_CHECK(c, hipMalloc(&d_p1, p1 + 1)); GSA_CHECK(c, hipMalloc(&d_p2, p2 + 1)); GSA_CHECK(c, hipMalloc(&d_ops, po + 1));
-	GSA_CHECK(c, hipMalloc(&d_o1, n * 8)); GSA_CHECK(c, hipMalloc(&d_o2, n * 8)); GSA_CHECK(c, hipMalloc(&d_oo, n * 8));
-	GSA_CHECK(c, hipMalloc(&d_l1, n * 4)); GSA_CHECK(c, hipMalloc(&d_l2, n * 4)); GSA_CHECK(c, hipMalloc(&d_ol, n * 4));
+	uint8_t *d_p1 = dev_ensure<uint8_t>(c, c->leaf[0], (size_t)p1 + 1), *d_p2 = dev_ensure<uint8_t>(c, c->leaf[1], (size_t)p2 + 1), *d_ops = dev_ensure<uint8_t>(c, c->leaf[2], (size_t)po + 1);
+	i64 *d_o1 = dev_ensure<i64>(c, c->leaf[3], n), *d_o2 = dev_ensure<i64>(c, c->leaf[4], n), *d_oo = dev_ensure<i64>(c, c->leaf[5], n);
+	i32 *d_l1 = dev_ensure<i32>(c, c->leaf[6], n), *d_l2 = dev_ensure<i32>(c, c->leaf[7], n), *d_ol = dev_ensure<i32>(c, c->leaf[8], n);
+	if (!d_p1 || !d_p2 || !d_ops || !d_o1 || !d_o2 || !d_oo || !d_l1 || !d_l2 || !d_ol) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemcpyAsync(d_p1, pool1, p1, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(d_p2, pool2, p2, hipMemcpyHostToDevice, st));
 	GSA_CHECK(c, hipMemcpyAsync(d_o1, off1, n * 8, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(d_o2, off2, n * 8, hipMemcpyHostToDevice, st));
 	GSA_CHECK(c, hipMemcpyAsync(d_oo, ops_off, n * 8, hipMemcpyHostToDevice, st));
@@ -685,6 +685,5 @@ extern "C" int gsa_ksw2_batch(gsa_ctx *c, int32_t n_pairs, const char *pool1, co
 		GSA_CHECK(c, hipStreamSynchronize(st));
 		if (err) { c->dp_dirty = true; rc = gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
 	}
-	hipFree(d_p1); hipFree(d_p2); hipFree(d_ops); hipFree(d_o1); hipFree(d_o2); hipFree(d_oo); hipFree(d_l1); hipFree(d_l2); hipFree(d_ol);
 	return rc;
 }

@@ -142,13 +142,12 @@ extern "C" int gsa_gap_similarity_batch(gsa_ctx *c, int32_t n, const int32_t *q1
 	for (int i = 0; i < n; i++)
 		if (q1[i] < 0 || q2[i] < q1[i] || q2[i] > c->qlen || r1[i] < 0 || r2[i] < r1[i] || r2[i] > 2 * c->G) return gsa_fail(c, GSA_ERR_ARG, "gap window out of range");
 	hipStream_t st = c->stream;
-	i32 *dq1, *dq2, *dres; i64 *dr1, *dr2;
-	GSA_CHECK(c, hipMalloc(&dq1, n * 4)); GSA_CHECK(c, hipMalloc(&dq2, n * 4)); GSA_CHECK(c, hipMalloc(&dres, n * 4));
-	GSA_CHECK(c, hipMalloc(&dr1, n * 8)); GSA_CHECK(c, hipMalloc(&dr2, n * 8));
+	i32 *dq1 = dev_ensure<i32>(c, c->leaf[0], (size_t)n), *dq2 = dev_ensure<i32>(c, c->leaf[1], (size_t)n), *dres = dev_ensure<i32>(c, c->leaf[2], (size_t)n);
+	i64 *dr1 = dev_ensure<i64>(c, c->leaf[3], (size_t)n), *dr2 = dev_ensure<i64>(c, c->leaf[4], (size_t)n);
+	if (!dq1 || !dq2 || !dres || !dr1 || !dr2) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemcpyAsync(dq1, q1, n * 4, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(dq2, q2, n * 4, hipMemcpyHostToDevice, st));
 	GSA_CHECK(c, hipMemcpyAsync(dr1, r1, n * 8, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(dr2, r2, n * 8, hipMemcpyHostToDevice, st));
 	int rc = run_gapsim_jobs(c, n, nullptr, dq1, dq2, dr1, dr2, dres);
 	if (rc == GSA_OK) { GSA_CHECK(c, hipMemcpyAsync(similar, dres, n * 4, hipMemcpyDeviceToHost, st)); GSA_CHECK(c, hipStreamSynchronize(st)); }
-	hipFree(dq1); hipFree(dq2); hipFree(dres); hipFree(dr1); hipFree(dr2);
 	return rc;
 }

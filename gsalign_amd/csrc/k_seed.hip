@@ -391,6 +391,25 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 	}
 }
 
+// Accounting build only: the LF steps bwt_sa would walk for every located hit (the row is sampled every 32 ROWS, so the
+// walk ends at the first row divisible by 32: bwt_search.cpp:129-139).  The hot path reads the dense SA instead; this
+// is the algorithmic figure of SURVEY.md section 8(d).
+__global__ void __launch_bounds__(256) k_count_lf(DevIndex di, u32 cand_cap, const u32 *__restrict__ cand_cnt, const i32 *__restrict__ cand_s, const u64 *__restrict__ cand_x0,
+                                                   const i32 *__restrict__ cand_freq, const u32 *__restrict__ onpath, unsigned long long *out)
+{
+	const u32 chunk = blockIdx.x, nc = cand_cnt[chunk];
+	const size_t cbase = (size_t)chunk * cand_cap;
+	unsigned long long steps = 0;
+	for (u32 i = threadIdx.x; i < nc; i += blockDim.x) {
+		const i32 p = cand_s[cbase + i] - (i32)chunk * GSA_CHUNK;
+		if (!((onpath[(size_t)chunk * PATH_WORDS + (p >> 5)] >> (p & 31)) & 1u)) continue;
+		const u32 f = (u32)cand_freq[cbase + i];
+		for (u32 h = 0; h < f; h++) { u32 st = 0; (void)fm_locate_walk(di, cand_x0[cbase + i] + h, st); steps += st; }
+	}
+	for (int o = 32; o; o >>= 1) steps += __shfl_down(steps, o);
+	if ((threadIdx.x & 63) == 0 && steps) atomicAdd(out, steps);
+}
+
 // sorted keys -> SoA seeds + group ids (SeedGrouping, a6): one fused pass (gsa_scan.h); a new group
 // starts where PosDiff jumps by more than MaxIndelSize
 struct OpDecodeGroup {
@@ -499,7 +518,7 @@ int build_dense_sa(gsa_ctx *c, u64 n_sa)
 		c->di.ref2 = c->d_ref2.as<u32>();
 	}
 	const u64 rows = c->di.seq_len + 1;
-	const bool use32 = c->di.seq_len < 0xFFFFFFF0ull;
+	const bool use32 = c->di.seq_len < 0xFFFFFFF0ull && !c->force_wide;
 	if (use32) { if (!dev_ensure<u32>(c, c->d_sa_dense, rows + 32)) return GSA_ERR_NOMEM; c->di.sa32 = c->d_sa_dense.as<u32>(); c->di.sa64 = nullptr; }
 	else { if (!dev_ensure<u64>(c, c->d_sa_dense, rows + 32)) return GSA_ERR_NOMEM; c->di.sa64 = c->d_sa_dense.as<u64>(); c->di.sa32 = nullptr; }
 	hipLaunchKernelGGL(k_densify_sa, dim3(grid_for(n_sa, 256)), dim3(256), 0, c->stream, c->di, n_sa, (u32 *)c->di.sa32, (u64 *)c->di.sa64);
@@ -513,7 +532,7 @@ int build_dense_sa(gsa_ctx *c, u64 n_sa)
 		k += 2; if (k > 14) k = 14;
 		if (k >= 2) {
 			const size_t n = (size_t)1 << (2 * k);
-			const int e16 = c->di.seq_len < 0xFFFFFFF0ull ? 1 : 0;
+			const int e16 = (c->di.seq_len < 0xFFFFFFF0ull && !c->force_wide) ? 1 : 0;
 			if (!dev_ensure<u64>(c, c->d_kmer, e16 ? n * 2 : n * 4)) return GSA_ERR_NOMEM;
 			hipLaunchKernelGGL(k_build_kmer, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->di, k, c->d_kmer.as<u64>(), e16);
 			c->di.kmer_e16 = e16;
@@ -582,7 +601,17 @@ int stage1_seed(gsa_ctx *c)
 		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), qlen, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr);
 	}
 	if (c->profiling) hipEventRecord(c->ev[2], st);
-	c->counters[0] = c->h_cnt[CNT_OCCBLK]; c->counters[1] = 0; c->counters[2] = (u64)n_hits; c->counters[3] = (u64)n_hits; c->counters[7] = c->h_cnt[CNT_OCCBLK_ALL];
+	u64 lf_steps = 0;
+	if (c->count_blocks && n_hits > 0) {
+		unsigned long long *d_lf = (unsigned long long *)(c->d_mail.as<i32>() + M_LFSTEPS);
+		GSA_CHECK(c, hipMemsetAsync(d_lf, 0, 8, st));
+		hipLaunchKernelGGL(k_count_lf, dim3((unsigned)n_chunks), dim3(256), 0, st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_x0.as<u64>(),
+		                   c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), d_lf);
+		GSA_CHECK(c, hipMemcpyAsync(&c->h_cnt[CNT_DONE], d_lf, 8, hipMemcpyDeviceToHost, st));      // (h_cnt[CNT_DONE] is always 0 after the seed kernel: a free pinned slot)
+		GSA_CHECK(c, hipStreamSynchronize(st));
+		lf_steps = c->h_cnt[CNT_DONE];
+	}
+	c->counters[0] = c->h_cnt[CNT_OCCBLK]; c->counters[1] = lf_steps; c->counters[2] = (u64)n_hits; c->counters[3] = (u64)n_hits; c->counters[7] = c->h_cnt[CNT_OCCBLK_ALL];
 	c->dbg[0] = c->h_cnt[11]; c->dbg[1] = c->h_cnt[12]; c->dbg[2] = c->h_cnt[13]; c->dbg[3] = c->h_cnt[14]; c->dbg[4] = c->h_cnt[15]; c->dbg[5] = c->h_cnt[7];
 	c->n_seeds = n_hits;
 	if (n_hits == 0) { if (c->profiling) { GSA_CHECK(c, hipStreamSynchronize(st)); float ms; hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms; } return GSA_OK; }
@@ -649,9 +678,9 @@ extern "C" int gsa_bwt_search_batch(gsa_ctx *c, int32_t n, const int32_t *start,
 	if (n == 0) return GSA_OK;
 	for (int i = 0; i < n; i++) if (start[i] < 0 || start[i] >= c->qlen || stop[i] > c->qlen || stop[i] <= start[i]) return gsa_fail(c, GSA_ERR_ARG, "window out of range");
 	hipStream_t st = c->stream;
-	i32 *d_start = nullptr, *d_stop = nullptr, *d_len = nullptr, *d_freq = nullptr; i64 *d_loc = nullptr;
-	GSA_CHECK(c, hipMalloc(&d_start, n * 4)); GSA_CHECK(c, hipMalloc(&d_stop, n * 4)); GSA_CHECK(c, hipMalloc(&d_len, n * 4)); GSA_CHECK(c, hipMalloc(&d_freq, n * 4));
-	GSA_CHECK(c, hipMalloc(&d_loc, (size_t)n * GSA_MAX_SEED_FREQ * 8));
+	i32 *d_start = dev_ensure<i32>(c, c->leaf[0], (size_t)n), *d_stop = dev_ensure<i32>(c, c->leaf[1], (size_t)n), *d_len = dev_ensure<i32>(c, c->leaf[2], (size_t)n), *d_freq = dev_ensure<i32>(c, c->leaf[3], (size_t)n);
+	i64 *d_loc = dev_ensure<i64>(c, c->leaf[4], (size_t)n * GSA_MAX_SEED_FREQ);
+	if (!d_start || !d_stop || !d_len || !d_freq || !d_loc) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemcpyAsync(d_start, start, n * 4, hipMemcpyHostToDevice, st));
 	GSA_CHECK(c, hipMemcpyAsync(d_stop, stop, n * 4, hipMemcpyHostToDevice, st));
 	hipLaunchKernelGGL(k_search_batch, dim3(grid_for(n, 64)), dim3(64), 0, st, c->di, c->d_query.as<uint8_t>(), c->prm, n, d_start, d_stop, d_len, d_freq, d_loc);
@@ -659,6 +688,5 @@ extern "C" int gsa_bwt_search_batch(gsa_ctx *c, int32_t n, const int32_t *start,
 	GSA_CHECK(c, hipMemcpyAsync(out_freq, d_freq, n * 4, hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipMemcpyAsync(out_loc, d_loc, (size_t)n * GSA_MAX_SEED_FREQ * 8, hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipStreamSynchronize(st));
-	hipFree(d_start); hipFree(d_stop); hipFree(d_len); hipFree(d_freq); hipFree(d_loc);
 	return GSA_OK;
 }

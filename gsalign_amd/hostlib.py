@@ -52,8 +52,8 @@ def result_from_dump(d: dict, keep: list):
     return r
 
 
-def emit(index_prefix: str, query_fa: str, maf_path: str, vcf_path: str, reference_label: str, per_contig, allow_dup: bool = True) -> None:
-    """per_contig(ci, seq_uint8) -> dump dict of the finished contig (stage 8 layout)."""
+def emit(index_prefix: str, query_fa: str, maf_path: str, vcf_path: str, reference_label: str, per_contig, allow_dup: bool = True, fmt: int = 1) -> None:
+    """per_contig(ci, seq_uint8) -> dump dict of the finished contig (stage 8 layout).  fmt 1 = MAF, 2 = ALN (written to maf_path)."""
     keep: list = []
 
     def cb(user, ci, seq, ln, out):
@@ -63,7 +63,7 @@ def emit(index_prefix: str, query_fa: str, maf_path: str, vcf_path: str, referen
         return 0
 
     err = C.create_string_buffer(256)
-    rc = load().gsah_c_emit(index_prefix.encode(), query_fa.encode(), maf_path.encode(), vcf_path.encode(), reference_label.encode(),
-                            1 if allow_dup else 0, RESULT_CB(cb), None, err)
+    rc = load().gsah_c_emit_fmt(index_prefix.encode(), query_fa.encode(), maf_path.encode(), vcf_path.encode(), reference_label.encode(),
+                                1 if allow_dup else 0, fmt, RESULT_CB(cb), None, err)
     if rc != 0:
         raise RuntimeError(f"gsah_c_emit -> {rc}: {err.value.decode()}")

@@ -69,6 +69,59 @@ def mutate(ref: np.ndarray, d: float, rng: np.random.Generator) -> np.ndarray:
     return res
 
 
+# ---------------------------------------------------------------------------
+# The same generator family in C++ (csrc/host/synth.cpp, counter-based RNG): a 250 Mb pair in seconds.
+# ---------------------------------------------------------------------------
+def _hostlib():
+    import ctypes as C
+    from . import hostlib
+    lib = hostlib.load()
+    lib.gsah_c_synth_genome.argtypes = [C.c_int64, C.c_uint64, C.c_void_p]
+    lib.gsah_c_synth_repeats.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int]
+    lib.gsah_c_synth_repeats.restype = C.c_int64
+    lib.gsah_c_synth_mutate.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_void_p, C.c_int64]
+    lib.gsah_c_synth_mutate.restype = C.c_int64
+    return lib
+
+
+def fast_genome(n: int, seed: int = 11) -> np.ndarray:
+    out = np.empty(n, np.uint8)
+    _hostlib().gsah_c_synth_genome(n, seed, out.ctypes.data)
+    return out
+
+
+def inject_repeats(seq: np.ndarray, seed: int = 11, frac: float = 0.10, fam_len: int = 300, copy_div: float = 0.10,
+                   tandem_unit: int = 40, tandem_copies: int = 150) -> int:
+    """Repeat-stress variant of SURVEY.md section 8(d), in place: a 300-bp family (copies 10 % divergent) covering `frac`
+    of the genome plus one tandem array with more than MaxSeedFreq copies.  Returns the number of family copies."""
+    assert seq.flags.c_contiguous and seq.dtype == np.uint8
+    return int(_hostlib().gsah_c_synth_repeats(seq.ctypes.data, seq.size, seed, frac, fam_len, copy_div, tandem_unit, tandem_copies))
+
+
+def fast_mutate(ref: np.ndarray, d: float, seed: int) -> np.ndarray:
+    ref = np.ascontiguousarray(ref, np.uint8)
+    cap = ref.size + ref.size // 32 + 4096
+    out = np.empty(cap, np.uint8)
+    n = int(_hostlib().gsah_c_synth_mutate(ref.ctypes.data, ref.size, d, seed, out.ctypes.data, cap))
+    assert n >= 0
+    return out[:n]
+
+
+def make_pair_fast(total_len: int, n_contigs: int, d: float, seed: int = 11, repeats: bool = False, lengths=None):
+    """(ref_contigs, qry_contigs) from the C++ generator; `lengths` overrides the equal split."""
+    if lengths is None:
+        base = total_len // n_contigs
+        lengths = [base] * (n_contigs - 1) + [total_len - base * (n_contigs - 1)]
+    refs, qrys = [], []
+    for i, ln in enumerate(lengths):
+        r = fast_genome(int(ln), seed * 1000 + i)
+        if repeats:
+            inject_repeats(r, seed * 1000 + i)
+        refs.append((f"chr{i + 1}", r))
+        qrys.append((f"qry{i + 1}", fast_mutate(r, d, seed * 1000 + 500 + i)))
+    return refs, qrys
+
+
 def write_fasta(path: str, contigs: list[tuple[str, np.ndarray]], width: int = 70) -> None:
     with open(path, "wb") as fh:
         for name, seq in contigs:

@@ -14,6 +14,7 @@
  */
 #ifndef GSA_HIP_H
 #define GSA_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -97,7 +98,22 @@ typedef struct {
 
 /* ---- life cycle --------------------------------------------------------- */
 int  gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa_ctx **out);
+/* gsa_create with layout options.  GSA_CREATE_WIDE: the device layout of a text with >= 2^32 BWT rows (64-bit dense SA,
+ * 32-byte k-mer entries) whatever the text length -- what a full human index (bwt_t::seq_len = 6.2 G, structure.h:28-38)
+ * gets by itself; on a small index it lets the tests drive that code path.  gsa_create honours the environment variable
+ * GSA_FORCE_WIDE=1 the same way. */
+#define GSA_CREATE_WIDE 1u
+int  gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm, uint32_t flags, gsa_ctx **out);
+/* A further context on the same GPU that borrows `parent`'s device-resident index (read-only) and owns everything else.
+ * The reference runs -t N threads inside one contig (GSAlign.cpp:477-526); contigs are independent (all per-contig state
+ * is cleared at GSAlign.cpp:490), so a host drives N contexts from N threads on N contigs instead and the GPU overlaps
+ * them.  Each context is single-threaded; `parent` must outlive its clones. */
+int  gsa_clone(gsa_ctx *parent, gsa_ctx **out);
 void gsa_destroy(gsa_ctx *ctx);
+/* Pinned host memory for query contigs (QueryChrVec[i].seq, main.cpp:82-114): the upload inside gsa_align_contig is then
+ * one asynchronous DMA transfer.  Any other host memory works too (staged by the runtime). */
+void *gsa_host_alloc(size_t bytes);
+void  gsa_host_free(void *p);
 int  gsa_set_params(gsa_ctx *ctx, const gsa_params *prm);
 const char *gsa_last_error(gsa_ctx *ctx);   /* ctx may be NULL: error of the last failed gsa_create */
 

@@ -16,6 +16,8 @@ What is written (all data, no reference source):
   ksw2_pairs.npz                2000+ (ref_frag, qry_frag) -> (aln1, aln2) from the reference's ksw2_alignment
   gapsim.npz                    CalGapSimilarity known answers on the cx pair
   small.*                       a 60 kb two-contig pair with its own index, MAF, VCF (quick CLI test)
+  cx_<variant>.{maf,aln,vcf}.gz outputs of the unmodified reference CLI on cx under -unique / -fmt 2 / -one / -idy 95 /
+                                -one -ind 40 -clr 300 -alen 1000 (`--cli-variants` writes only these)
 """
 import gzip
 import os
@@ -73,7 +75,40 @@ def main():
     import subprocess
     subprocess.run([sys.executable, os.path.abspath(__file__), "--func", tmp], check=True)
     shutil.rmtree(tmp)
+    cli_variants()
     print("golden fixtures written to", HERE)
+
+
+CLI_VARIANTS = {        # tag -> (extra flags, output kinds)
+    "unique": (["-unique"], ("maf", "vcf")),
+    "fmt2": (["-fmt", "2"], ("aln", "vcf")),
+    "one": (["-one"], ("maf", "vcf")),
+    "idy95": (["-idy", "95"], ("maf", "vcf")),
+    "combo": (["-one", "-ind", "40", "-clr", "300", "-alen", "1000", "-unique"], ("maf", "vcf")),
+    "sen_fmt2": (["-sen", "-fmt", "2"], ("aln",)),
+}
+
+
+def cli_variants():
+    """Flag variants of the reference CLI on the committed cx index (tests/golden/cx.*.gz), -t 1."""
+    op.build(ref=True)
+    assert op.have_ref()
+    tmp = tempfile.mkdtemp(prefix="gsa_golden_cli_")
+    for fn in os.listdir(HERE):
+        if fn.startswith("cx.") and fn.endswith(".gz"):
+            with gzip.open(os.path.join(HERE, fn), "rb") as a, open(os.path.join(tmp, fn[:-3]), "wb") as b:
+                shutil.copyfileobj(a, b)
+    cwd = os.getcwd(); os.chdir(tmp)
+    for tag, (flags, kinds) in CLI_VARIANTS.items():
+        op.ref_run_cli("cx", "cx.qry.fa", f"o_{tag}", flags)
+        for k in kinds:
+            gz(f"o_{tag}.{k}", f"{HERE}/cx_{tag}.{k}.gz")
+    # -no_vcf: the MAF is the default one and no VCF is written
+    op.ref_run_cli("cx", "cx.qry.fa", "o_novcf", ["-no_vcf"])
+    assert not os.path.exists("o_novcf.vcf")
+    assert open("o_novcf.maf", "rb").read() == gzip.open(f"{HERE}/cx.maf.gz", "rb").read()
+    os.chdir(cwd); shutil.rmtree(tmp)
+    print("CLI variant goldens written")
 
 
 def func_vectors(tmp):
@@ -147,5 +182,7 @@ def func_vectors(tmp):
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--func":
         func_vectors(sys.argv[2])
+    elif len(sys.argv) > 1 and sys.argv[1] == "--cli-variants":
+        cli_variants()
     else:
         main()

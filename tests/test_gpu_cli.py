@@ -15,11 +15,20 @@ def run_cli(cwd, *args):
     subprocess.run([hostlib.CLI_PATH, *args], cwd=cwd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
-@pytest.mark.parametrize("name,extra,maf,vcf", [("cx", [], "cx.maf", "cx.vcf"), ("cx", ["-sen"], "cx_sen.maf", "cx_sen.vcf"), ("small", [], "small.maf", "small.vcf")])
+@pytest.mark.parametrize("name,extra,maf,vcf", [
+    ("cx", [], "cx.maf", "cx.vcf"), ("cx", ["-sen"], "cx_sen.maf", "cx_sen.vcf"), ("small", [], "small.maf", "small.vcf"),
+    # flag variants, goldens from the unmodified reference CLI (tests/golden/make_golden.py --cli-variants)
+    ("cx", ["-unique"], "cx_unique.maf", "cx_unique.vcf"), ("cx", ["-fmt", "2"], "cx_fmt2.aln", "cx_fmt2.vcf"), ("cx", ["-one"], "cx_one.maf", "cx_one.vcf"),
+    ("cx", ["-idy", "95"], "cx_idy95.maf", "cx_idy95.vcf"), ("cx", ["-one", "-ind", "40", "-clr", "300", "-alen", "1000", "-unique"], "cx_combo.maf", "cx_combo.vcf"),
+    ("cx", ["-sen", "-fmt", "2"], "cx_sen_fmt2.aln", "cx_sen.vcf"), ("cx", ["-no_vcf"], "cx.maf", None)])
 def test_cli_golden(golden_dir, tmp_path, name, extra, maf, vcf):
     run_cli(golden_dir, "-i", name, "-q", f"{name}.qry.fa", "-o", str(tmp_path / "out"), "-t", "1", *extra)
-    assert open(tmp_path / "out.maf", "rb").read() == open(os.path.join(golden_dir, maf), "rb").read()
-    assert open(tmp_path / "out.vcf", "rb").read() == open(os.path.join(golden_dir, vcf), "rb").read()
+    kind = maf.rsplit(".", 1)[1]
+    assert open(tmp_path / f"out.{kind}", "rb").read() == open(os.path.join(golden_dir, maf), "rb").read()
+    if vcf:
+        assert open(tmp_path / "out.vcf", "rb").read() == open(os.path.join(golden_dir, vcf), "rb").read()
+    else:
+        assert not os.path.exists(tmp_path / "out.vcf")                   # -no_vcf (main.cpp:280)
 
 
 def test_cli_builds_its_own_index_and_matches_live_reference(oracle_built, tmp_path):

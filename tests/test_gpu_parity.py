@@ -12,9 +12,11 @@ from gsalign_amd import capi, indexio, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def gpu(cx_index):
-    a = capi.Aligner(cx_index)
+@pytest.fixture(scope="module", params=["narrow", "wide"])
+def gpu(request, cx_index):
+    """Every test on the committed index runs twice: with the layout the text length selects (32-bit dense SA, 16-byte
+    k-mer entries) and with GSA_CREATE_WIDE, the layout of a text with >= 2^32 BWT rows (a full human index)."""
+    a = capi.Aligner(cx_index, wide=(request.param == "wide"))
     yield a
     a.close()
 
@@ -70,8 +72,9 @@ def test_stages_vs_golden(gpu, cx_queries, golden, params):
     gpu.set_params()
 
 
-@pytest.mark.parametrize("seed,params", [(41, {}), (42, dict(sen=1, clr=50)), (43, dict(one=1, ind=40, clr=300, alen=1000)), (44, dict(idy=95, slen=12))])
-def test_stages_vs_oracle_fresh_inputs(oracle_built, tmp_path, seed, params):
+@pytest.mark.parametrize("seed,params,wide", [(41, {}, False), (42, dict(sen=1, clr=50), False), (43, dict(one=1, ind=40, clr=300, alen=1000), False), (44, dict(idy=95, slen=12), False),
+                                              (45, {}, True), (46, dict(sen=1, clr=50), True)])
+def test_stages_vs_oracle_fresh_inputs(oracle_built, tmp_path, seed, params, wide):
     # a fresh complex pair; index built by the reference's bwt_index when oracle/_ref travelled, else skip
     if not oracle_built.have_ref():
         pytest.skip("oracle/_ref not present")
@@ -79,7 +82,7 @@ def test_stages_vs_oracle_fresh_inputs(oracle_built, tmp_path, seed, params):
     rf, px = str(tmp_path / "r.fa"), str(tmp_path / "r")
     synth.write_fasta(rf, refs); oracle_built.ref_build_index(rf, px)
     idx = indexio.load_index(px)
-    o = oracle_built.Oracle(idx, params); g = capi.Aligner(idx, **params)
+    o = oracle_built.Oracle(idx, params); g = capi.Aligner(idx, wide=wide, **params)
     for name, seq in qrys:
         o.set_query(seq); g.set_query(seq)
         want = o.dump_stages(8)
@@ -131,17 +134,23 @@ def test_midsize_pair_2pct(oracle_built, tmp_path):
     (3000000, 2, 0.05, 15, {}),                       # 5 %: short seeds, dense gaps, many small DP jobs
     (1000000, 1, 0.02, 16, dict(ind=40)),             # MaxIndelSize > 31: grouping by the PosDiff sort instead of the bitmap
     (1500000, 1, 0.003, 17, dict(sen=1, clr=50)),     # -sen at low divergence: long seeds cut every 5 bases, multi-kb gaps
+    (3000000, 1, 0.01, 18, dict(alen=5000)),          # -alen 5000 (BASELINE configs[4]): only long blocks survive AddAlnBlock / the re-split rules
+    (2000000, 3, 0.01, 12, dict(wide=True)),          # the >= 2^32-row layout (GSA_CREATE_WIDE) on the cases above ...
+    (600000, 2, 0.02, 13, dict(sen=1, clr=50, wide=True)),
+    (12000000, 1, 0.02, 21, dict(wide=True)),         # ... including the grid-wide paths of a 12 Mb contig
+    (3000000, 1, 0.01, 18, dict(alen=5000, wide=True)),
 ])
 def test_scaled_pairs_vs_oracle(oracle_built, tmp_path, total, ncontig, div, seed, params):
     """Larger synthetic pairs than the committed fixtures; index from OUR builder, result vs the oracle."""
     from gsalign_amd import hostlib
+    params = dict(params); wide = params.pop("wide", False)
     refs, qrys = synth.make_pair(total, ncontig, div, seed=seed)
     if ncontig > 1:
         qrys[-1] = (qrys[-1][0], synth.revcomp(qrys[-1][1]))
     rf, px = str(tmp_path / "r.fa"), str(tmp_path / "r")
     synth.write_fasta(rf, refs); hostlib.build_index(rf, px)
     idx = indexio.load_index(px)
-    o = oracle_built.Oracle(idx, params); g = capi.Aligner(idx, **params)
+    o = oracle_built.Oracle(idx, params); g = capi.Aligner(idx, wide=wide, **params)
     for name, seq in qrys:
         o.set_query(seq); o.run_to(8); want = o.blocks(with_aln=True)
         g.align_contig(seq); got = g.blocks_as_dump(with_aln=True)
@@ -149,6 +158,94 @@ def test_scaled_pairs_vs_oracle(oracle_built, tmp_path, total, ncontig, div, see
             assert np.array_equal(got[k], v), (name, k)
         assert want["b_score"].size > 0
     o.close(); g.close()
+
+
+# S. cerevisiae S288C chromosome lengths I..XVI (kb, rounded): BASELINE configs[2] is this genome against a 2 %-divergent copy, -sen
+YEAST_KB = [230, 813, 317, 1532, 577, 270, 1091, 563, 440, 746, 667, 1078, 924, 784, 1091, 948]
+
+
+def _build(tmp_path, refs):
+    from gsalign_amd import hostlib
+    rf, px = str(tmp_path / "r.fa"), str(tmp_path / "r")
+    synth.write_fasta(rf, refs); hostlib.build_index(rf, px)
+    return indexio.load_index(px)
+
+
+def _same_as_oracle(o, g, qrys):
+    for name, seq in qrys:
+        o.set_query(seq); o.run_to(8); want = o.blocks(with_aln=True)
+        g.align_contig(seq); got = g.blocks_as_dump(with_aln=True)
+        for k, v in want.items():
+            assert np.array_equal(got[k], v), (name, k)
+
+
+def test_config3_yeast_sized_sen(oracle_built, tmp_path):
+    """BASELINE configs[2] as SURVEY 8(d) specifies it: 16 contigs totalling 12 Mb, 2 % divergence, -sen (forces -slen 10,
+    5-bp seed stride, -clr 50): ~3 M seeds, ~10^5 seed groups per Mb.  Every block, record and gapped string vs the oracle."""
+    params = dict(sen=1, clr=50)
+    refs, qrys = synth.make_pair_fast(0, 16, 0.02, seed=52, lengths=[1000 * k for k in YEAST_KB])
+    qrys[3] = (qrys[3][0], synth.revcomp(qrys[3][1]))
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx, params); g = capi.Aligner(idx, **params)
+    _same_as_oracle(o, g, qrys)
+    assert int(g.counters()[3]) > 100000
+    o.close(); g.close()
+
+
+@pytest.mark.parametrize("total,div,seed,params", [
+    (12000000, 0.02, 51, {}),                          # SURVEY 8(d) repeat-stress variant at yeast size, defaults
+    (2000000, 0.01, 53, dict(sen=1, clr=50)),          # the same under -sen (start+5 stride through the repeats)
+    (3000000, 0.02, 54, dict(wide=True)),              # and in the >= 2^32-row layout
+])
+def test_repeat_stress_vs_oracle(oracle_built, tmp_path, total, div, seed, params):
+    """A 300-bp family (copies 10 % divergent) covering 10 % of the genome + a 150-copy tandem array of a 40-bp unit:
+    searches that end with more than MaxSeedFreq hits and restart one base further (bwt_search.cpp:177-182,
+    GSAlign.cpp:91), multi-hit seeds (up to 100 located hits each), query positions with several hits per group."""
+    params = dict(params); wide = params.pop("wide", False)
+    refs, qrys = synth.make_pair_fast(total, 1, div, seed=seed, repeats=True)
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx, params); g = capi.Aligner(idx, wide=wide, **params)
+    _same_as_oracle(o, g, qrys)
+    c = g.counters()
+    assert int(c[2]) > 0 and int(c[2]) == int(o.counters()[2])      # same number of located hits
+    o.close(); g.close()
+
+
+def test_two_contexts_share_one_index(oracle_built, tmp_path):
+    """gsa_clone: two contexts on one GPU, one device index, driven from two host threads on different contigs at the
+    same time -- results identical to the oracle's (and so to a single context's)."""
+    import threading
+    refs, qrys = synth.make_pair_fast(4000000, 8, 0.02, seed=55)
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx)
+    want = []
+    for name, seq in qrys:
+        o.set_query(seq); o.run_to(8); want.append(o.blocks(with_aln=True))
+    o.close()
+    g0 = capi.Aligner(idx); ctxs = [g0, g0.clone(), g0.clone()]
+    errs = []
+
+    def work(k):
+        try:
+            g = ctxs[k]
+            for rep in range(3):
+                for ci in range(k, len(qrys), len(ctxs)):
+                    g.align_contig(g.pinned_copy(qrys[ci][1]) if rep == 1 else qrys[ci][1])
+                    got = g.blocks_as_dump(with_aln=True)
+                    for key, v in want[ci].items():
+                        assert np.array_equal(got[key], v), (k, ci, key)
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(ctxs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for g in ctxs[1:]:
+        g.close()
+    g0.close()
 
 
 def test_degenerate_queries(gpu, ora, golden_dir):
@@ -229,11 +326,12 @@ def _check_result_invariants(idx, qry, r):
     assert np.array_equal(cs[fe] - cs[fb], B["score"].astype(np.int64))
 
 
-@pytest.mark.parametrize("total,ncontig,div,seed", [(24000000, 2, 0.015, 31), (100000000, 1, 0.01, 32)])
-def test_full_size_result_invariants(tmp_path, total, ncontig, div, seed):
-    """BASELINE-sized and larger pairs: no oracle at this size, so the result is checked against itself and the inputs."""
+@pytest.mark.parametrize("total,ncontig,div,seed,repeats", [(24000000, 2, 0.015, 31, False), (250000000, 1, 0.01, 32, True)])
+def test_full_size_result_invariants(tmp_path, total, ncontig, div, seed, repeats):
+    """BASELINE-sized pairs (configs[3]: one 250 Mb chromosome at 1 %, with the repeat-stress injection): no oracle at this
+    size, so the result is checked against itself and the inputs."""
     from gsalign_amd import hostlib
-    refs, qrys = synth.make_pair(total, ncontig, div, seed=seed)
+    refs, qrys = synth.make_pair_fast(total, ncontig, div, seed=seed, repeats=repeats)
     if ncontig > 1:
         qrys[-1] = (qrys[-1][0], synth.revcomp(qrys[-1][1]))
     rf, px = str(tmp_path / "r.fa"), str(tmp_path / "r")

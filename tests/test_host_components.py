@@ -23,10 +23,27 @@ def test_index_builder_byte_identical(golden_dir, tmp_path, name):
         assert filecmp.cmp(f"{px}.{ext}", os.path.join(golden_dir, f"{name}.{ext}"), shallow=False), f"{name}.{ext} differs from the reference's"
 
 
-@pytest.mark.parametrize("name,params,maf,vcf", [("cx", {}, "cx.maf", "cx.vcf"), ("cx", dict(sen=1, clr=50), "cx_sen.maf", "cx_sen.vcf"), ("small", {}, "small.maf", "small.vcf")])
+@pytest.mark.parametrize("name", ["cx", "small"])
+def test_index_builder_64bit_suffix_sorter(golden_dir, tmp_path, name, monkeypatch):
+    """References above 1 Gbp (2G + 1 >= 2^31 suffixes: BASELINE configs[4], 3.1 Gbp) take the 64-bit instance of the suffix
+    sorter; GSA_INDEX_64BIT=1 forces it on the fixtures.  Same bytes as the reference's bwt_index (bwtindex.c:77-149)."""
+    monkeypatch.setenv("GSA_INDEX_64BIT", "1")
+    px = str(tmp_path / name)
+    hostlib.build_index(os.path.join(golden_dir, f"{name}.ref.fa"), px)
+    for ext in ("pac", "ann", "amb", "bwt", "sa"):
+        assert filecmp.cmp(f"{px}.{ext}", os.path.join(golden_dir, f"{name}.{ext}"), shallow=False), f"{name}.{ext} differs from the reference's"
+
+
+@pytest.mark.parametrize("name,params,maf,vcf", [
+    ("cx", {}, "cx.maf", "cx.vcf"), ("cx", dict(sen=1, clr=50), "cx_sen.maf", "cx_sen.vcf"), ("small", {}, "small.maf", "small.vcf"),
+    # flag variants of the reference CLI (tests/golden/make_golden.py --cli-variants): -unique, -fmt 2, -one, -idy 95, a combination, -sen -fmt 2
+    ("cx", dict(unique=1), "cx_unique.maf", "cx_unique.vcf"), ("cx", dict(fmt=2), "cx_fmt2.aln", "cx_fmt2.vcf"), ("cx", dict(one=1), "cx_one.maf", "cx_one.vcf"),
+    ("cx", dict(idy=95), "cx_idy95.maf", "cx_idy95.vcf"), ("cx", dict(one=1, ind=40, clr=300, alen=1000, unique=1), "cx_combo.maf", "cx_combo.vcf"),
+    ("cx", dict(sen=1, clr=50, fmt=2), "cx_sen_fmt2.aln", None)])
 def test_emitters_byte_identical(oracle_built, golden_dir, tmp_path, name, params, maf, vcf):
     from gsalign_amd import indexio
     px = os.path.join(golden_dir, name)
+    params = dict(params); unique = params.pop("unique", 0); fmt = params.pop("fmt", 1)
     o = oracle_built.Oracle(indexio.load_index(px), params)
 
     def per_contig(ci, seq):
@@ -34,7 +51,8 @@ def test_emitters_byte_identical(oracle_built, golden_dir, tmp_path, name, param
         return o.blocks(with_aln=True)
 
     out_maf, out_vcf = str(tmp_path / "o.maf"), str(tmp_path / "o.vcf")
-    hostlib.emit(px, os.path.join(golden_dir, f"{name}.qry.fa"), out_maf, out_vcf, name, per_contig)
+    hostlib.emit(px, os.path.join(golden_dir, f"{name}.qry.fa"), out_maf, out_vcf, name, per_contig, allow_dup=not unique, fmt=fmt)
     o.close()
     assert open(out_maf, "rb").read() == open(os.path.join(golden_dir, maf), "rb").read()
-    assert open(out_vcf, "rb").read() == open(os.path.join(golden_dir, vcf), "rb").read()
+    if vcf:
+        assert open(out_vcf, "rb").read() == open(os.path.join(golden_dir, vcf), "rb").read()
