@@ -99,6 +99,7 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	if (flags & ~(uint32_t)GSA_CREATE_WIDE) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create_opts: unknown flag");
 	gsa_ctx *c = new gsa_ctx();
 	c->device = device; c->force_wide = (flags & GSA_CREATE_WIDE) != 0;
+	if (const char *b = getenv("GSA_SEED_BUDGET")) c->seed_budget = (u32)atoi(b);
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gsa_fail(nullptr, GSA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); gsa_destroy(c); return GSA_ERR_HIP; } } while (0)
 	CK(hipSetDevice(device));
@@ -148,7 +149,7 @@ void gsa_destroy(gsa_ctx *c)
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
 	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->d_query, &c->tmp, &c->d_cnt, &c->d_mail, &c->d_lb_status[0], &c->d_lb_status[1],
-		&c->d_sa_dense, &c->d_kmer, &c->d_pres, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
+		&c->d_sa_dense, &c->d_kmer, &c->d_pres, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_heavy, &c->dn_memo, &c->dn_lf, &c->dn_x0, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
 		&c->d_flag, &c->d_scan, &c->g_beg, &c->w_j0, &c->w_j1, &c->w_on, &c->d_pdbm, &c->d_gpre, &c->d_key_c, &c->d_val_c, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
 		&c->a_next, &c->a_brk, &c->a_aurank, &c->a_aulist, &c->a_runinfo, &c->w_best, &c->w_sum, &c->w_n, &c->d_btab, &c->d_flag2, &c->d_scan2, &c->d_i64a,
 		&c->b_q, &c->b_len, &c->b_r, &c->b_gb, &c->b_ge, &c->c_q, &c->c_len, &c->c_r, &c->c_gb, &c->c_ge, &c->c_bid, &c->blk_beg, &c->blk_end, &c->blk_score,
@@ -179,7 +180,7 @@ int gsa_clone(gsa_ctx *parent, gsa_ctx **out)
 	if (hipSetDevice(parent->device) != hipSuccess) return gsa_fail(nullptr, GSA_ERR_HIP, "hipSetDevice");
 	gsa_ctx *c = new gsa_ctx();
 	c->device = parent->device; c->force_wide = parent->force_wide;
-	c->index_owner = parent->index_owner ? parent->index_owner : parent;
+	c->index_owner = parent->index_owner ? parent->index_owner : parent; c->seed_budget = parent->seed_budget;
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
 	if (int rc = ctx_private_init(c)) { g_create_error = c->err; gsa_destroy(c); return rc; }
 	c->di = parent->di; c->G = parent->G;
@@ -314,6 +315,6 @@ int gsa_get_blocks(gsa_ctx *c, gsa_result *out)
 }
 
 int gsa_get_counters(gsa_ctx *c, uint64_t counters[8]) { if (!c) return GSA_ERR_ARG; memcpy(counters, c->counters, sizeof(c->counters)); return GSA_OK; }
-int gsa_get_timings(gsa_ctx *c, float ms[8]) { if (!c) return GSA_ERR_ARG; memcpy(ms, c->kernel_ms, sizeof(c->kernel_ms)); if (getenv("GSA_DEBUG")) fprintf(stderr, "[gsa] seed rounds max %llu, wave iters sum %llu max %llu; slowest chunk: round 1 %.1f us, resolver %.1f us, up to the marks %.1f us\n", (unsigned long long)c->dbg[0], (unsigned long long)c->dbg[1], (unsigned long long)c->dbg[2], c->dbg[3] * 0.01, c->dbg[4] * 0.01, c->dbg[5] * 0.01); return GSA_OK; }
+int gsa_get_timings(gsa_ctx *c, float ms[8]) { if (!c) return GSA_ERR_ARG; memcpy(ms, c->kernel_ms, sizeof(c->kernel_ms)); if (getenv("GSA_DEBUG")) fprintf(stderr, "[gsa] seed rounds max %llu, dense chunks %llu, wave iters max %llu; slowest chunk: round 1 %.1f us, resolver %.1f us, up to the marks %.1f us\n", (unsigned long long)c->dbg[0], (unsigned long long)c->dbg[1], (unsigned long long)c->dbg[2], c->dbg[3] * 0.01, c->dbg[4] * 0.01, c->dbg[5] * 0.01); return GSA_OK; }
 
 } // extern "C"

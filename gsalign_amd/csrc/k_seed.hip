@@ -7,7 +7,7 @@
 #include "gsa_fm.h"
 #include "gsa_scan.h"
 
-enum { CNT_OCCBLK = 0, CNT_DONE = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 4, CNT_DPJOBS = 5, CNT_DPMN = 6, CNT_CAND = 8, CNT_OVERFLOW = 9, CNT_OCCBLK_ALL = 10 };
+enum { CNT_OCCBLK = 0, CNT_DONE = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 4, CNT_DPJOBS = 5, CNT_DPMN = 6, CNT_CAND = 8, CNT_OVERFLOW = 9, CNT_OCCBLK_ALL = 10, CNT_HEAVY = 12 };
 
 #ifndef SEED_WG
 #define SEED_WG 128             // lanes per chunk: one per sub-range (256 lanes with 128 sub-ranges left two of four waves idle: 0.157 -> 0.139 ms)
@@ -75,10 +75,11 @@ __device__ __forceinline__ int text_match32(u32 r0, u32 r1, u32 r2, i64 tp, i64 
 // ---------------------------------------------------------------------------
 template <bool COUNT, bool E16>
 __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
-                                                      i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt)
+                                                      i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
+                                                      u32 budget, u32 *heavy_list)
 {
 	__shared__ u32 s_ncand, s_queue, s_hits;
-	__shared__ int changed;
+	__shared__ int changed, s_abort;
 	__shared__ u32 qp[QP_WORDS], qn[QN_WORDS];
 	__shared__ uint16_t memo[GSA_CHUNK];      // next(s)-s, 0 = unknown
 	__shared__ uint16_t mblk[COUNT ? GSA_CHUNK : 1];   // Occ blocks the search from s read (accounting build only)
@@ -112,7 +113,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	}
 	for (int p = j; p < clen; p += SEED_WG) memo[p] = 0;
 	for (int p = j; p < PATH_WORDS; p += SEED_WG) bits[p] = 0;
-	if (j == 0) { s_ncand = 0; s_queue = 0; s_hits = 0; s_npend = 0; }
+	if (j == 0) { s_ncand = 0; s_queue = 0; s_hits = 0; s_npend = 0; s_abort = 0; }
 	if (j < NSUB / 32) rewalked[j] = 0;
 	const size_t cbase = (size_t)chunk * cand_cap;      // this chunk's private candidate segment
 	const int S = (clen + NSUB - 1) / NSUB;             // sub-range length (>= 1)
@@ -134,6 +135,10 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		bool need_item = true;
 		while (!__all(mode == M_DONE)) {
 			iters++;
+			// A chunk whose walks exceed the budget (a tandem array with more than MaxSeedFreq copies: every start is searched for
+			// ~100 bases, rejected and followed by start+1 -- thousands of dependent searches on a handful of lanes) is given up
+			// here and searched from EVERY position in parallel by the dense kernels below.
+			if (!COUNT && budget) { if (iters > budget) *(volatile int *)&s_abort = 1; if (*(volatile int *)&s_abort) break; }
 			// ---- request phase (convergent) ----
 			u64 kk = 0, ll = 0; bool kn = true, ln = true;
 			if (mode == M_FM) {
@@ -245,6 +250,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		}
 		rounds++;
 		__syncthreads();
+		if (s_abort) break;
 		if (rounds == 1) t_round0 = wall_clock64() - t_begin;
 		const unsigned long long t_r0 = wall_clock64();
 		// True entries.  A walk that enters sub-range `it` on a memoised position leaves it at exit_of[it]
@@ -294,9 +300,18 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		__syncthreads();
 		if (!again) break;
 	}
+	const bool heavy = s_abort != 0;
+	if (heavy) {
+		if (j == 0) {
+			const u32 hslot = (u32)atomicAdd((unsigned long long *)&cnt[CNT_HEAVY], 1ull);
+			heavy_list[hslot] = (u32)chunk;
+			s_ncand = 0; cand_cnt[chunk] = 0; chunk_hits[chunk] = 0; if (chunk == 0) chunk_hits[gridDim.x] = 0;
+		}
+		__syncthreads();
+	}
 	// mark the true path and count the Occ blocks the reference's walk reads
 	u32 alg_blocks = 0;
-	for (int it = j; it < nitems; it += SEED_WG) {
+	if (!heavy) for (int it = j; it < nitems; it += SEED_WG) {
 		const int bend = (it + 1) * S < clen ? (it + 1) * S : clen;
 		for (int s = entry_of[it]; s < bend;) { atomicOr(&bits[s >> 5], 1u << (s & 31)); if (COUNT) alg_blocks += mblk[s]; s += memo[s]; }
 	}
@@ -304,14 +319,13 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	if ((j & 63) == 0) {
 		if (alg_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK], (unsigned long long)alg_blocks);
 		if (all_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK_ALL], (unsigned long long)all_blocks);
-		atomicAdd((unsigned long long *)&cnt[12], (unsigned long long)iters);
 		atomicMax((unsigned long long *)&cnt[13], (unsigned long long)iters);
 	}
 	if (j == 0) { atomicMax((unsigned long long *)&cnt[11], (unsigned long long)rounds); atomicMax((unsigned long long *)&cnt[14], t_round0); atomicMax((unsigned long long *)&cnt[15], t_resolve); atomicMax((unsigned long long *)&cnt[7], wall_clock64() - t_begin); }
 	__syncthreads();
-	for (int p = j; p < PATH_WORDS; p += SEED_WG) onpath[(size_t)chunk * PATH_WORDS + p] = bits[p];
+	if (!heavy) for (int p = j; p < PATH_WORDS; p += SEED_WG) onpath[(size_t)chunk * PATH_WORDS + p] = bits[p];
 	// how many located hits will this chunk contribute (so that the select kernel needs no global atomic)
-	{
+	if (!heavy) {
 		const u32 nc = s_ncand < cand_cap ? s_ncand : cand_cap;
 		u32 h = 0;
 		for (u32 i = j; i < nc; i += SEED_WG) { const i32 p = cand_s[cbase + i] - (i32)c0; if ((bits[p >> 5] >> (p & 31)) & 1u) h += (u32)cand_freq[cbase + i]; }
@@ -338,56 +352,266 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	}
 }
 
+
+// ---------------------------------------------------------------------------
+// Dense mode: BWT_Search from EVERY start position of a chunk, one lane per start, then the reference's chain
+// (IdentifyLocalMEM, GSAlign.cpp:61-94) by pointer jumping over next(s).  next(s) is a pure function of s, so this is
+// exact; it does up to 10 000 searches per chunk where the speculative kernel above does a few hundred, so it is used
+// where nearly every start is on the chain anyway or the chain cannot be guessed:
+//   * -sen (stride 5 after a seed: walks that start on different residues mod 5 only merge at the next mismatch, so the
+//     true entry of every sub-range depends on its predecessor -- 127 resolver rounds per chunk were measured);
+//   * chunks the speculative kernel gave up on (tandem arrays with more than MaxSeedFreq copies: every start is searched
+//     for ~100 bases, rejected, and followed by start+1 -- 46 ms on one workgroup for a 6-kb array).
+// Same search ladder as above: presence bitmap -> k-mer table -> (Occ steps until one row is left) -> dense SA ->
+// 64-base text windows.  Consecutive lanes hold consecutive starts, so a wavefront's searches end at the same mismatch.
+// ---------------------------------------------------------------------------
+#define DENSE_TPB 256
+#define DENSE_SPAN 512                          // starts per workgroup (two per lane)
+#define DENSE_WGS ((GSA_CHUNK + DENSE_SPAN - 1) / DENSE_SPAN)
+template <bool E16>
+__global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, const u32 *__restrict__ chunk_list,
+                                                              uint16_t *dn_memo, u32 *dn_lf, u64 *dn_x0, u64 *cnt)
+{
+	__shared__ u32 qp[QP_WORDS], qn[QN_WORDS];
+	const u32 slot = blockIdx.x / DENSE_WGS, part = blockIdx.x % DENSE_WGS;
+	const u32 chunk = chunk_list ? chunk_list[slot] : slot;
+	const int j = threadIdx.x;
+	const i64 c0 = (i64)chunk * GSA_CHUNK;
+	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
+	const int span0 = (int)part * DENSE_SPAN, span1 = span0 + DENSE_SPAN < clen ? span0 + DENSE_SPAN : clen;
+	if (span0 >= clen) return;
+	// stage the chunk from the first start of this workgroup to its end (a match may run that far)
+	for (int g = (span0 >> 5) + j; g < QN_WORDS; g += DENSE_TPB) {
+		u32 w0 = 0, w1 = 0, wn = 0;
+		const int p0 = g << 5;
+		if (p0 < clen) {
+			const uint8_t *src = q + c0 + p0;
+			uint8_t b[32];
+			if (p0 + 32 <= clen) { *(uint4 *)&b[0] = *(const uint4 *)src; *(uint4 *)&b[16] = *(const uint4 *)(src + 16); }
+			else { for (int t = 0; t < 32; t++) b[t] = p0 + t < clen ? src[t] : (uint8_t)'N'; }
+#pragma unroll
+			for (int t = 0; t < 32; t++) {
+				const u32 cd = (u32)gsa_nt4(b[t]);
+				if (t < 16) w0 |= (cd & 3) << (2 * t); else w1 |= (cd & 3) << (2 * (t - 16));
+				wn |= (cd > 3 ? 1u : 0u) << t;
+			}
+		}
+		if (2 * g < QP_WORDS) qp[2 * g] = w0;
+		if (2 * g + 1 < QP_WORDS) qp[2 * g + 1] = w1;
+		qn[g] = wn;
+	}
+	__syncthreads();
+	uint16_t *memo = dn_memo + (size_t)slot * GSA_CHUNK; u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; u64 *x0o = dn_x0 + (size_t)slot * GSA_CHUNK;
+	int nextp = span0 + j;                                  // this lane's starts: nextp, nextp + DENSE_TPB
+	int s = 0, pos = 0, mode = M_ADV; u32 kid = 0, pid = 0, blk = 0, all_blocks = 0;
+	FmIntv ik = {0, 0, 0}; i64 tp = 0;
+	const int L = prm.MinSeedLength < 32 ? prm.MinSeedLength : 32;
+	while (!__all(mode == M_DONE)) {
+		// ---- request phase: one pending request per lane, all lanes issue together ----
+		u64 kk = 0, ll = 0; bool kn = true, ln = true;
+		if (mode == M_FM) {
+			const u64 k = ik.x1 - 1, l = ik.x1 - 1 + ik.x2;
+			kn = (k == (u64)-1); ln = (l == (u64)-1);
+			kk = kn ? 0 : k - (k >= di.primary); ll = ln ? 0 : l - (l >= di.primary);
+		}
+		const FmBlock bk = fm_load(di.bwt, kk >> 7), bl = fm_load(di.bwt, ll >> 7);
+		struct __attribute__((packed, aligned(4))) W5 { u32 a, b, c, d, e; };
+		const W5 w5 = *(const W5 *)(di.ref2 + (mode == M_TEXT ? (tp >> 4) : 0));
+		ulonglong2 e0 = {0, 0}, e1 = {0, 0};
+		if (E16) {
+			const uint4 e = ((const uint4 *)(di.kmer ? di.kmer : (const u64 *)di.bwt))[mode == M_KMER ? kid : 0];
+			e0.x = e.x; e0.y = e.y; e1.x = e.z; e1.y = e.w;
+		} else {
+			const ulonglong2 *pe = (const ulonglong2 *)((di.kmer ? di.kmer : (const u64 *)di.bwt) + (mode == M_KMER ? ((size_t)kid << 2) : 0));
+			e0 = pe[0]; e1 = pe[1];
+		}
+		const u32 pw = di.pres ? di.pres[mode == M_KMER ? (pid >> 5) : 0] : ~0u;
+		const u64 sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
+		// ---- consume phase ----
+		bool ended = false;
+		if (mode == M_KMER) {
+			if (!((pw >> (pid & 31)) & 1u)) { ended = true; pos = s; ik.x2 = 0; }      // the first MinSeedLength bases do not occur: no seed here
+			else {
+				const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k, walk it base by base
+				if (hit) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; }
+				mode = M_FM;
+				if (hit && ik.x2 == 1) { tp = (i64)(e1.y - 1) + di.kmer_k; mode = M_TEXT; }
+			}
+		} else if (mode == M_LOC) {
+			tp = (i64)sav + (pos - s); mode = M_TEXT;
+		} else if (mode == M_TEXT) {
+			int got = text_match32(w5.a, w5.b, w5.c, tp, (i64)di.seq_len, qp, qn, pos, clen);
+			if (got == 32) got += text_match32(w5.c, w5.d, w5.e, tp + 32, (i64)di.seq_len, qp, qn, pos + 32, clen);
+			pos += got; tp += got;
+			ended = got < 64;
+		} else if (mode == M_FM) {
+			const bool can = pos < clen && !q_isn(qn, pos < clen ? pos : 0);
+			const bool ok = can && fm_extend_loaded(di, ik, q_code(qp, pos < clen ? pos : 0), bk, bl, kk, ll, kn, ln, blk);
+			ended = !ok;
+			if (ok) { pos++; if (ik.x2 == 1) mode = M_LOC; }
+		}
+		if (ended) {
+			const int len = pos - s;
+			int d = 1; u32 rec = 0;
+			if (len >= prm.MinSeedLength && ik.x2 <= GSA_MAX_SEED_FREQ) { d = prm.bSensitive ? 5 : len + 1; rec = (u32)len | ((u32)ik.x2 << 16); x0o[s] = ik.x0; }
+			memo[s] = (uint16_t)d; lf[s] = rec;
+			all_blocks += blk;
+			mode = M_ADV;
+		}
+		// ---- next start of this lane (starts that need no search are settled here, two per iteration) ----
+		for (int step = 0; step < 2 && mode == M_ADV; step++) {
+			if (nextp >= span1) { mode = M_DONE; break; }
+			s = nextp; nextp += DENSE_TPB;
+			const u32 nb = q_nbits32(qn, s);
+			if ((nb & 1u) || s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0) { memo[s] = 1; lf[s] = 0; continue; }      // ambiguous start, or MinSeedLength out of reach
+			ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
+			if (di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
+				const u64 qb = q_bits64(qp, s);
+				kid = (u32)qb & ((1u << (2 * di.kmer_k)) - 1); mode = M_KMER;
+				pid = di.pres_k ? (u32)(qb & ((1ull << (2 * di.pres_k)) - 1)) : 0;
+			}
+		}
+	}
+	for (int o = 32; o; o >>= 1) all_blocks += __shfl_down(all_blocks, o);
+	if ((j & 63) == 0 && all_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK_ALL], (unsigned long long)all_blocks);
+}
+
+// The chain of a dense chunk: orbit of 0 under p -> p + memo[p], marked by pointer doubling (jump_k = next^(2^k); the
+// marked set doubles per round), then the accepted on-chain matches go to the chunk's candidate segment in the layout
+// k_seed_wg leaves (so everything downstream is the same).
+__global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ chunk_list, u32 n_total_chunks, i32 qlen, const uint16_t *__restrict__ dn_memo, const u32 *__restrict__ dn_lf,
+                                                        const u64 *__restrict__ dn_x0, u64 *cnt, i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt,
+                                                        u32 *onpath, i32 *chunk_hits, u64 *hcnt)
+{
+	__shared__ uint16_t jmp[2][GSA_CHUNK];
+	__shared__ u32 bits[PATH_WORDS];
+	__shared__ u32 s_n, s_hits;
+	__shared__ int s_last;
+	const u32 slot = blockIdx.x, chunk = chunk_list ? chunk_list[slot] : slot;
+	const int j = threadIdx.x;
+	const i64 c0 = (i64)chunk * GSA_CHUNK;
+	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
+	const uint16_t *memo = dn_memo + (size_t)slot * GSA_CHUNK;
+	for (int p = j; p < clen; p += 256) { const int t = p + memo[p]; jmp[0][p] = (uint16_t)(t < clen ? t : 0xffff); }
+	for (int w = j; w < PATH_WORDS; w += 256) bits[w] = w == 0 ? 1u : 0u;
+	if (j == 0) { s_n = 0; s_hits = 0; }
+	__syncthreads();
+	int cur = 0;
+	for (int span = 1; span < clen; span <<= 1) {
+		for (int p = j; p < clen; p += 256) {
+			const int t = jmp[cur][p];
+			if (t != 0xffff) {
+				if ((bits[p >> 5] >> (p & 31)) & 1u) atomicOr(&bits[t >> 5], 1u << (t & 31));
+				jmp[cur ^ 1][p] = jmp[cur][t];
+			} else jmp[cur ^ 1][p] = 0xffff;
+		}
+		__syncthreads();
+		cur ^= 1;
+	}
+	const size_t cbase = (size_t)chunk * cand_cap;
+	const u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; const u64 *x0 = dn_x0 + (size_t)slot * GSA_CHUNK;
+	u32 h = 0;
+	for (int p = j; p < clen; p += 256) {
+		if (!((bits[p >> 5] >> (p & 31)) & 1u)) continue;
+		const u32 rec = lf[p];
+		if (!rec) continue;
+		const u32 k = atomicAdd(&s_n, 1u);
+		if (k < cand_cap) { cand_s[cbase + k] = (i32)(c0 + p); cand_len[cbase + k] = (i32)(rec & 0xffffu); cand_x0[cbase + k] = x0[p]; cand_freq[cbase + k] = (i32)(rec >> 16); h += rec >> 16; }
+	}
+	for (int o = 32; o; o >>= 1) h += __shfl_down(h, o);
+	if ((j & 63) == 0 && h) atomicAdd(&s_hits, h);
+	for (int w = j; w < PATH_WORDS; w += 256) onpath[(size_t)chunk * PATH_WORDS + w] = bits[w];
+	__syncthreads();
+	if (j == 0) {
+		cand_cnt[chunk] = s_n < cand_cap ? s_n : cand_cap; chunk_hits[chunk] = (i32)s_hits; if (slot == 0) chunk_hits[n_total_chunks] = 0;
+		atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_n);
+		if (s_hits) atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)s_hits);
+		__threadfence();
+		s_last = atomicAdd((unsigned long long *)&cnt[CNT_DONE], 1ull) == (unsigned long long)gridDim.x - 1 ? 1 : 0;
+	}
+	__syncthreads();
+	// the last workgroup puts the counters into pinned memory and leaves them at zero (as k_seed_wg does)
+	if (s_last && j < 16) {
+		hcnt[j] = j == CNT_DONE ? 0 : __hip_atomic_load(&cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		cnt[j] = 0;
+	}
+}
+
 // ---------------------------------------------------------------------------
 // Candidate -> seeds: keep the matches whose start lies on the true chain, locate
 // every hit through the dense SA (a3: one read instead of ~31 dependent LF steps)
 // and emit the 64-bit sort key ((PosDiff + qlen) << qbits) | qPos with the length.
 // ---------------------------------------------------------------------------
+// One workgroup per chunk.  Phase A: the on-chain candidates get their output ranges by a scan over the candidate index
+// (deterministic order).  Phase B: one lane per HIT -- a seed with 100 hits is 100 lanes, not a 100-iteration loop of one
+// lane -- which finds its candidate by binary search over the offsets (LDS), locates its row and ranks itself among the
+// hits of its start by position: the tie-break of the (group, qPos) order, which the reference gets from a stable sort
+// of the PosDiff order (the f rows of one start are re-read by f lanes: L1/L2 hits on the dense SA).
+#define SEL_HASH 256
 __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, const u32 *__restrict__ cand_cnt, const i32 *__restrict__ cand_s, const i32 *__restrict__ cand_len,
                                                       const u64 *__restrict__ cand_x0, const i32 *__restrict__ cand_freq, const u32 *__restrict__ onpath,
                                                       const i32 *__restrict__ hit_base, i32 qlen, int qbits, u64 *key, u32 *val, u32 *pdbm)
 {
-	__shared__ u32 s_off;
-	__shared__ unsigned long long s_w[64]; __shared__ u32 s_b[64];
+	extern __shared__ u32 s_offs[];                    // exclusive prefix of the hit counts of the chunk's candidates (0 for off-chain ones), [nc + 1]
+	__shared__ unsigned long long s_w[SEL_HASH]; __shared__ u32 s_b[SEL_HASH];
+	__shared__ u32 s_wsum[4], s_run;
 	const u32 chunk = blockIdx.x, nc = cand_cnt[chunk];
 	const size_t cbase = (size_t)chunk * cand_cap;
-	if (threadIdx.x == 0) s_off = 0;
-	if (threadIdx.x < 64) { s_w[threadIdx.x] = ~0ull; s_b[threadIdx.x] = 0; }
+	const int j = threadIdx.x, lane = j & 63, wv = j >> 6;
+	for (int t = j; t < SEL_HASH; t += 256) { s_w[t] = ~0ull; s_b[t] = 0; }
+	if (j == 0) s_run = 0;
+	__syncthreads();
+	for (u32 i0 = 0; i0 < nc; i0 += 256) {
+		const u32 i = i0 + j;
+		u32 f = 0;
+		if (i < nc) {
+			const i32 p = cand_s[cbase + i] - (i32)chunk * GSA_CHUNK;
+			if ((onpath[(size_t)chunk * PATH_WORDS + (p >> 5)] >> (p & 31)) & 1u) f = (u32)cand_freq[cbase + i];
+		}
+		u32 inc = f;
+		for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+		if (lane == 63) s_wsum[wv] = inc;
+		__syncthreads();
+		u32 wo = 0; for (int w = 0; w < wv; w++) wo += s_wsum[w];
+		const u32 run = s_run;
+		if (i < nc) s_offs[i] = run + wo + inc - f;
+		__syncthreads();
+		if (j == 255) s_run = run + wo + inc;
+		__syncthreads();
+	}
+	const u32 total = s_run;
+	if (j == 0) s_offs[nc] = total;
 	__syncthreads();
 	const u64 base = (u64)hit_base[chunk];
-	for (u32 i = threadIdx.x; i < nc; i += blockDim.x) {
-		const i32 s = cand_s[cbase + i];
-		const i32 p = s - (i32)chunk * GSA_CHUNK;
-		if (!((onpath[(size_t)chunk * PATH_WORDS + (p >> 5)] >> (p & 31)) & 1u)) continue;
-		const u32 f = (u32)cand_freq[cbase + i];
-		const u64 off = base + atomicAdd(&s_off, f);
-		const u64 x0 = cand_x0[cbase + i]; const u32 len = (u32)cand_len[cbase + i];
-		for (u32 h = 0; h < f; h++) {
-			const u64 r = fm_locate(di, x0 + h);
-			const i64 pd = (i64)r - s + qlen;
-			// the hits of one start, ranked by position: the tie-break of the (group, qPos) order, which the reference gets
-			// from a stable sort of the PosDiff order
-			u32 rank = 0;
-			if (f > 1) for (u32 h2 = 0; h2 < f; h2++) rank += fm_locate(di, x0 + h2) < r ? 1u : 0u;
-			key[off + h] = ((u64)pd << qbits) | (u32)s;
-			val[off + h] = len | (rank << 16);
-			// occupied PosDiff values: groups without sorting by PosDiff (k_chain.hip).  Collected per workgroup in LDS, one
-			// global OR per touched word at the end: a chunk's hits sit in two or three words and the whole contig's main
-			// diagonal in one cache line -- an atomic (or even a look) per hit queues 75 k operations on that line
-			if (pdbm) {
-				const unsigned long long w = (unsigned long long)(pd >> 5); const u32 bit = 1u << (pd & 31);
-				int hh = (int)(w & 63), tries = 0;
-				for (; tries < 64; tries++, hh = (hh + 1) & 63) {
-					const unsigned long long prev = atomicCAS(&s_w[hh], ~0ull, w);
-					if (prev == ~0ull || prev == w) { atomicOr(&s_b[hh], bit); break; }
-				}
-				if (tries == 64) atomicOr(&pdbm[w], bit);
+	for (u32 t = j; t < total; t += 256) {
+		// the candidate whose range holds hit t: the last i with s_offs[i] <= t (empty ranges share their start with the next one)
+		u32 lo = 0, hi = nc;
+		while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_offs[mid] <= t) lo = mid; else hi = mid; }
+		const u32 i = lo, h = t - s_offs[i];
+		const i32 s = cand_s[cbase + i]; const u32 f = (u32)cand_freq[cbase + i], len = (u32)cand_len[cbase + i]; const u64 x0 = cand_x0[cbase + i];
+		const u64 r = fm_locate(di, x0 + h);
+		const i64 pd = (i64)r - s + qlen;
+		u32 rank = 0;
+		if (f > 1) for (u32 h2 = 0; h2 < f; h2++) rank += fm_locate(di, x0 + h2) < r ? 1u : 0u;
+		key[base + t] = ((u64)pd << qbits) | (u32)s;
+		val[base + t] = len | (rank << 16);
+		// occupied PosDiff values: groups without sorting by PosDiff (k_chain.hip).  Collected per workgroup in LDS, one
+		// global OR per touched word at the end: a chunk's hits sit in two or three words and the whole contig's main
+		// diagonal in one cache line -- an atomic (or even a look) per hit queues 75 k operations on that line.  Hits of
+		// repeats scatter over the genome: after a few probes they go straight to their own (uncontended) word.
+		if (pdbm) {
+			const unsigned long long w = (unsigned long long)(pd >> 5); const u32 bit = 1u << (pd & 31);
+			int hh = (int)((w * 0x9E3779B1ull) >> 7) & (SEL_HASH - 1), tries = 0;
+			for (; tries < 4; tries++, hh = (hh + 1) & (SEL_HASH - 1)) {
+				const unsigned long long prev = atomicCAS(&s_w[hh], ~0ull, w);
+				if (prev == ~0ull || prev == w) { atomicOr(&s_b[hh], bit); break; }
 			}
+			if (tries == 4) atomicOr(&pdbm[w], bit);
 		}
 	}
 	if (pdbm) {
 		__syncthreads();
-		if (threadIdx.x < 64 && s_w[threadIdx.x] != ~0ull) atomicOr(&pdbm[s_w[threadIdx.x]], s_b[threadIdx.x]);
+		for (int t = j; t < SEL_HASH; t += 256) if (s_w[t] != ~0ull) atomicOr(&pdbm[s_w[t]], s_b[t]);
 	}
 }
 
@@ -555,31 +779,62 @@ int stage1_seed(gsa_ctx *c)
 	if (!dev_ensure<u32>(c, c->d_onpath, (size_t)n_chunks * PATH_WORDS) || !dev_ensure<i32>(c, c->d_chunk_hits, (size_t)n_chunks + 1) || !dev_ensure<i32>(c, c->d_chunk_base, (size_t)n_chunks + 1)) return GSA_ERR_NOMEM;
 	i64 n_hits = 0;
 	u64 *cnt = c->d_cnt.as<u64>();
+	// Dense mode (one search per start position, k_dense_search): every chunk under -sen, otherwise only the chunks the
+	// speculative kernel gives up on.  The accounting build walks everything the reference's way and takes neither path.
+	const bool dense_all = c->prm.bSensitive && !c->count_blocks;
+	const u32 budget = c->count_blocks ? 0u : c->seed_budget;
+	if (dense_all && ccap < GSA_CHUNK / 5 + 64) { ccap = GSA_CHUNK / 5 + 64; c->cand_cap_per_chunk = ccap; }      // one accepted start in five at most
+	u64 occ_all = 0;
 	for (int attempt = 0;; attempt++) {
 		if (attempt == 8) return gsa_fail(c, GSA_ERR_LIMIT, "seed buffers keep overflowing");
 		const size_t ctot = ccap * (size_t)n_chunks;
 		if (!dev_ensure<i32>(c, c->d_cand_s, ctot) || !dev_ensure<i32>(c, c->d_cand_len, ctot) || !dev_ensure<u64>(c, c->d_cand_x0, ctot) || !dev_ensure<i32>(c, c->d_cand_freq, ctot) || !dev_ensure<u32>(c, c->d_cand_cnt, (size_t)n_chunks)) return GSA_ERR_NOMEM;
-		// (the counters were left at zero by the previous contig's mirror kernel; chunk_hits[n_chunks] = 0 is written by chunk 0)
+		if (!dense_all && !dev_ensure<u32>(c, c->d_heavy, (size_t)n_chunks)) return GSA_ERR_NOMEM;
+		// (the counters were left at zero by the previous contig's last workgroup; chunk_hits[n_chunks] = 0 is written by chunk 0)
 		if (c->profiling || c->prof_seed) hipEventRecord(c->ev[0], st);
-		if (c->count_blocks)
-			hipLaunchKernelGGL((k_seed_wg<true, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
-			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>(), c->h_cnt);
-		else
-			if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
-			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>(), c->h_cnt);
-			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt,
-			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>(), c->h_cnt);
-		if (c->profiling || c->prof_seed) hipEventRecord(c->ev[1], st);
-		// (the counters are in pinned memory when the seed kernel is done; the host waits for that, not for the scan of the
-		//  per-chunk hit counts behind it)
-		GSA_CHECK(c, hipEventRecord(c->ev[21], st));
-		int rcs = prim_exscan_i32(c, c->d_chunk_hits.as<i32>(), c->d_chunk_base.as<i32>(), (size_t)n_chunks + 1);
-		if (rcs) return rcs;
-		GSA_CHECK(c, hipEventSynchronize(c->ev[21]));
-		if (c->h_cnt[CNT_HITS] >= (1ull << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");
-		const i32 tot = (i32)c->h_cnt[CNT_HITS];
-		if (c->h_cnt[CNT_CAND] > ccap) { ccap = (size_t)c->h_cnt[CNT_CAND] + 256; c->cand_cap_per_chunk = ccap; continue; }
-		n_hits = tot;
+		u64 hits = 0, maxcand = 0, n_heavy = dense_all ? (u64)n_chunks : 0;
+		occ_all = 0;
+		if (!dense_all) {
+#define GSA_SEED_ARGS c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt, c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, \
+			c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>(), c->h_cnt, budget, c->d_heavy.as<u32>()
+			if (c->count_blocks) hipLaunchKernelGGL((k_seed_wg<true, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, GSA_SEED_ARGS);
+			else if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, GSA_SEED_ARGS);
+			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, GSA_SEED_ARGS);
+#undef GSA_SEED_ARGS
+			if (c->profiling || c->prof_seed) hipEventRecord(c->ev[1], st);
+			// (the counters are in pinned memory when the seed kernel is done; the host waits for that, not for the scan of the
+			//  per-chunk hit counts behind it)
+			GSA_CHECK(c, hipEventRecord(c->ev[21], st));
+			int rcs = prim_exscan_i32(c, c->d_chunk_hits.as<i32>(), c->d_chunk_base.as<i32>(), (size_t)n_chunks + 1);
+			if (rcs) return rcs;
+			GSA_CHECK(c, hipEventSynchronize(c->ev[21]));
+			hits = c->h_cnt[CNT_HITS]; maxcand = c->h_cnt[CNT_CAND]; n_heavy = c->h_cnt[CNT_HEAVY]; occ_all = c->h_cnt[CNT_OCCBLK_ALL];
+			c->dbg[0] = c->h_cnt[11]; c->dbg[1] = n_heavy; c->dbg[2] = c->h_cnt[13]; c->dbg[3] = c->h_cnt[14]; c->dbg[4] = c->h_cnt[15]; c->dbg[5] = c->h_cnt[7];
+			c->counters[0] = c->h_cnt[CNT_OCCBLK];
+		}
+		if (n_heavy > 0) {
+			const size_t nd = (size_t)n_heavy * GSA_CHUNK;
+			if (!dev_ensure<uint16_t>(c, c->dn_memo, nd) || !dev_ensure<u32>(c, c->dn_lf, nd) || !dev_ensure<u64>(c, c->dn_x0, nd)) return GSA_ERR_NOMEM;
+			const u32 *list = dense_all ? (const u32 *)nullptr : c->d_heavy.as<u32>();
+			if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true>), dim3((unsigned)(n_heavy * DENSE_WGS)), dim3(DENSE_TPB), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, list,
+			                                       c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt);
+			else hipLaunchKernelGGL((k_dense_search<false>), dim3((unsigned)(n_heavy * DENSE_WGS)), dim3(DENSE_TPB), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, list,
+			                        c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt);
+			hipLaunchKernelGGL(k_dense_resolve, dim3((unsigned)n_heavy), dim3(256), 0, st, list, (u32)n_chunks, qlen, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt,
+			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(),
+			                   c->d_chunk_hits.as<i32>(), c->h_cnt);
+			GSA_CHECK(c, hipGetLastError());
+			if (c->profiling || c->prof_seed) hipEventRecord(c->ev[1], st);
+			GSA_CHECK(c, hipEventRecord(c->ev[21], st));
+			int rcs = prim_exscan_i32(c, c->d_chunk_hits.as<i32>(), c->d_chunk_base.as<i32>(), (size_t)n_chunks + 1);
+			if (rcs) return rcs;
+			GSA_CHECK(c, hipEventSynchronize(c->ev[21]));
+			hits += c->h_cnt[CNT_HITS]; if (c->h_cnt[CNT_CAND] > maxcand) maxcand = c->h_cnt[CNT_CAND]; occ_all += c->h_cnt[CNT_OCCBLK_ALL];
+			if (dense_all) { c->dbg[0] = 0; c->dbg[1] = n_heavy; c->dbg[2] = c->dbg[3] = c->dbg[4] = c->dbg[5] = 0; c->counters[0] = 0; }
+		}
+		if (hits >= (1ull << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");
+		if (maxcand > ccap) { ccap = (size_t)maxcand + 256; c->cand_cap_per_chunk = ccap; continue; }
+		n_hits = (i64)hits;
 		break;
 	}
 	const size_t hcap = (size_t)n_hits + 64;
@@ -597,7 +852,7 @@ int stage1_seed(gsa_ctx *c)
 	}
 	if (n_hits > 0) {
 		if (!dev_ensure<u64>(c, c->d_key_a, hcap) || !dev_ensure<u32>(c, c->d_val_a, hcap)) return GSA_ERR_NOMEM;
-		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), 0, st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
+		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), (ccap + 2) * sizeof(u32), st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
 		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), qlen, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr);
 	}
 	if (c->profiling) hipEventRecord(c->ev[2], st);
@@ -611,8 +866,7 @@ int stage1_seed(gsa_ctx *c)
 		GSA_CHECK(c, hipStreamSynchronize(st));
 		lf_steps = c->h_cnt[CNT_DONE];
 	}
-	c->counters[0] = c->h_cnt[CNT_OCCBLK]; c->counters[1] = lf_steps; c->counters[2] = (u64)n_hits; c->counters[3] = (u64)n_hits; c->counters[7] = c->h_cnt[CNT_OCCBLK_ALL];
-	c->dbg[0] = c->h_cnt[11]; c->dbg[1] = c->h_cnt[12]; c->dbg[2] = c->h_cnt[13]; c->dbg[3] = c->h_cnt[14]; c->dbg[4] = c->h_cnt[15]; c->dbg[5] = c->h_cnt[7];
+	c->counters[1] = lf_steps; c->counters[2] = (u64)n_hits; c->counters[3] = (u64)n_hits; c->counters[7] = occ_all;
 	c->n_seeds = n_hits;
 	if (n_hits == 0) { if (c->profiling) { GSA_CHECK(c, hipStreamSynchronize(st)); float ms; hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms; } return GSA_OK; }
 	if (n_hits >= (1ll << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Seed-search kernel under repeats: time + in-kernel counters per reference variant (GPU box).
+usage: seed_probe.py [genome_len] [variants: none,family,tandem,both,sen]"""
+import os, sys, time, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from gsalign_amd import synth, hostlib, indexio, capi
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+variants = (sys.argv[2] if len(sys.argv) > 2 else "none,family,tandem,both").split(",")
+os.environ["GSA_DEBUG"] = "1"
+tmp = tempfile.mkdtemp(prefix="seedprobe_")
+for v in variants:
+    r = synth.fast_genome(n, 11000)
+    div, prm = 0.01, {}
+    if v == "family": synth.inject_repeats(r, 11000, tandem_unit=0, tandem_copies=0)
+    elif v == "tandem": synth.inject_repeats(r, 11000, frac=0.0)
+    elif v == "both": synth.inject_repeats(r, 11000)
+    elif v == "sen": div, prm = 0.02, dict(sen=1, clr=50)
+    px = os.path.join(tmp, v)
+    synth.write_fasta(px + ".fa", [("chr1", r)]); t = time.time(); hostlib.build_index(px + ".fa", px); tb = time.time() - t
+    idx = indexio.load_index(px)
+    q = synth.fast_mutate(r, div, 7000)
+    g = capi.Aligner(idx, **prm)
+    g.set_profiling(True)
+    for rep in range(2):
+        g.set_query(q); g.run_to(1)
+    tm = g.timings(); c = g.counters()
+    print(f"== {v}: n={n} index build {tb:.1f}s  seed_search {tm[0]:.3f} ms locate {tm[1]:.3f} sort {tm[2]:.3f}  hits {int(c[2])} occ_read {int(c[7])}", flush=True)
+    g.set_query(q); g.run_to(8); tm = g.timings()
+    print("   stages:", [round(float(x), 3) for x in tm], flush=True)
+    g.close()
