@@ -30,7 +30,6 @@ import os
 import subprocess
 import sys
 import tempfile
-import threading
 import time
 
 import numpy as np
@@ -110,34 +109,11 @@ class Runner:
             c.close()
         self.ctx[0].close()
 
-    def run(self, n_steps, step_of, seed_ms=None):
-        """Align the contigs of n_steps steps (step_of(n) = flat list of contig buffers in step order), spread over the contexts."""
-        work = step_of(n_steps)
-        nxt = [0]; lock = threading.Lock(); errs = []
-
-        def loop(g):
-            try:
-                while True:
-                    with lock:
-                        i = nxt[0]; nxt[0] += 1
-                    if i >= len(work):
-                        return
-                    g.align_contig_raw(work[i])
-                    if seed_ms is not None:
-                        seed_ms.append(float(g.timings()[0]))
-            except Exception as e:      # noqa: BLE001
-                errs.append(repr(e))
-
-        if len(self.ctx) == 1:
-            loop(self.ctx[0])
-        else:
-            th = [threading.Thread(target=loop, args=(g,)) for g in self.ctx]
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-        if errs:
-            raise RuntimeError("; ".join(errs))
+    def run(self, n_steps, step_of):
+        """Align the contigs of n_steps steps (step_of(n) = flat list of contig buffers in step order) on the contexts:
+        gsa_align_many, i.e. one host thread per context inside the library."""
+        from gsalign_amd import capi
+        capi.align_many(self.ctx, step_of(n_steps))
 
 
 def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup):
@@ -171,11 +147,10 @@ def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup):
     tm /= len(pinned); occ_read /= len(pinned)
     res = g0.raw_result(); n_blocks, n_frags, n_aln = int(res.n_blocks), int(res.n_frags), int(res.n_aln)
     for g in run.ctx:
-        g.set_profiling(False, seed_only=True)      # timed steps: two events per contig around the seed-search kernel
+        g.set_profiling(False)
     run.run(warmup, step_list)
-    seed_ms = []
     sync(); t0 = time.perf_counter()
-    run.run(steps, step_list, seed_ms)
+    run.run(steps, step_list)
     sync(); t_total = time.perf_counter() - t0
     recs = g0.block_records()
     run.close()
@@ -183,7 +158,7 @@ def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup):
     alg = {"occ_blocks": 64.0 * cnt[0], "lf_steps": 64.0 * cnt[1], "sa_reads": 8.0 * cnt[2], "query": bp_per_step, "seeds": 16.0 * cnt[3],
            "dp_cells": cnt[4], "dp_fragments": cnt[6]}
     return dict(px=px, refs=refs, genomes=genomes, t_total=t_total, bp=bp_per_step * steps, bp_per_step=bp_per_step, steps=steps, alg=alg, cnt=cnt, tm=tm,
-                seed_kernel_ms=float(np.sum(seed_ms)) / max(1, steps), occ_read=occ_read, recs=recs, n_blocks=n_blocks, n_frags=n_frags, n_aln=n_aln, contigs_per_step=per_step)
+                occ_read=occ_read, recs=recs, n_blocks=n_blocks, n_frags=n_frags, n_aln=n_aln, contigs_per_step=per_step)
 
 
 def pmc_traffic(name):
@@ -205,7 +180,7 @@ def summarise(name, wl, m, t_max, total_bp, world, args):
     seed_alg = m["alg"]["occ_blocks"] + m["alg"]["query"]
     dp_alg = m["alg"]["dp_cells"] + m["alg"]["dp_fragments"]
     loc_alg = m["alg"]["lf_steps"] + m["alg"]["sa_reads"] + m["alg"]["seeds"]
-    for kname, ms, ab, key in (("k_seed_wg (seed search, S1)", m["seed_kernel_ms"] if m["seed_kernel_ms"] > 0 else float(tm[0]), seed_alg, "k_seed_wg"),
+    for kname, ms, ab, key in (("k_seed_wg + k_dense_search (seed search, S1)", float(tm[0]), seed_alg, "k_seed_wg"),
                                ("k_dp_stripe + k_dp_small/tiny + k_materialize (extend stage, S7)", float(tm[5]), dp_alg, "k_dp_stripe"),
                                ("k_seed_select + sort + group (locate/order, S1 tail)", float(tm[1] + tm[2]), loc_alg, "k_seed_select")):
         a = ab / (ms * 1e-3) / 1e9 if ms > 0 else 0.0

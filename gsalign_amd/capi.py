@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgsa_hip.so")
 
 EXPORTS = [
-    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig",
+    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many",
     "gsa_set_query", "gsa_rewind", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
     "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling",
 ]
@@ -82,6 +82,25 @@ def load_library() -> C.CDLL:
         if fn.argtypes is None:
             fn.argtypes = None
     return lib
+
+
+RESULT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(Result))
+
+
+def align_many(aligners, contigs, on_result=None) -> None:
+    """gsa_align_many: `contigs` (uint8 arrays) on the given contexts, one host thread per context inside the library.
+    on_result(contig_index, Result) runs on the worker threads (the Result is valid during the call only)."""
+    lib = aligners[0].lib
+    n = len(contigs)
+    ctxs = (C.c_void_p * len(aligners))(*[a.ctx for a in aligners])
+    qs = (C.c_char_p * n)(*[C.cast(c.ctypes.data, C.c_char_p) for c in contigs])
+    ql = (C.c_int32 * n)(*[int(c.size) for c in contigs])
+    cb = RESULT_FN((lambda user, ci, res: int(on_result(ci, res.contents) or 0)) if on_result else 0)
+    lib.gsa_align_many.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, RESULT_FN, C.c_void_p]
+    rc = lib.gsa_align_many(ctxs, len(aligners), qs, ql, n, cb, None)
+    if rc != 0:
+        msgs = [lib.gsa_last_error(a.ctx).decode() for a in aligners]
+        raise GsaError(f"gsa_align_many -> {rc}: {'; '.join(m for m in msgs if m)}")
 
 
 def _p(a, t):

@@ -3,8 +3,10 @@
 // Host-side block-list bookkeeping (what the reference does on AlnBlockVec with
 // std::sort) lives in gsa_blocks.cpp.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
+#include <thread>
 #include "gsa_ctx.h"
 
 static thread_local std::string g_create_error;
@@ -100,6 +102,7 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	gsa_ctx *c = new gsa_ctx();
 	c->device = device; c->force_wide = (flags & GSA_CREATE_WIDE) != 0;
 	if (const char *b = getenv("GSA_SEED_BUDGET")) c->seed_budget = (u32)atoi(b);
+	if (const char *b = getenv("GSA_DP_SAFE")) c->dp_safe = atoi(b) != 0;      // (test hook: always take the one-job-per-launch path of the striped DP)
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gsa_fail(nullptr, GSA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); gsa_destroy(c); return GSA_ERR_HIP; } } while (0)
 	CK(hipSetDevice(device));
@@ -254,8 +257,46 @@ int gsa_align_contig(gsa_ctx *c, const char *query, int32_t qlen, gsa_result *ou
 {
 	if (!c || !out) return GSA_ERR_ARG;
 	int rc = gsa_set_query(c, query, qlen); if (rc) return rc;
-	rc = gsa_run_to(c, 8); if (rc) return rc;
+	c->dp_timeout = false;
+	rc = gsa_run_to(c, 8);
+	if (rc == GSA_ERR_STATE && c->dp_timeout && !c->dp_safe) {
+		// a stripe waited longer than its bound for its predecessor (never observed with ticket-ordered stripes; kept as a
+		// safety net): the same contig again with one DP job per launch -- all stripes of a job are resident then
+		c->dp_timeout = false; c->dp_safe = true;
+		rc = gsa_rewind(c);
+		if (rc == GSA_OK) rc = gsa_run_to(c, 8);
+		c->dp_safe = false;
+	}
+	if (rc) return rc;
 	return gsa_get_blocks(c, out);
+}
+
+int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n, gsa_result_fn on_result, void *user)
+{
+	if (!ctx || n_ctx <= 0 || n < 0 || (n > 0 && (!query || !qlen))) return GSA_ERR_ARG;
+	for (int k = 0; k < n_ctx; k++) if (!ctx[k]) return GSA_ERR_ARG;
+	if (n == 0) return GSA_OK;
+	// longest first: with dynamic hand-out this is the longest-processing-time-first rule
+	std::vector<int32_t> order((size_t)n);
+	for (int32_t i = 0; i < n; i++) order[(size_t)i] = i;
+	std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return qlen[a] > qlen[b]; });
+	std::atomic<int32_t> next(0); std::atomic<int> err(GSA_OK);
+	auto loop = [&](gsa_ctx *c) {
+		for (;;) {
+			const int32_t i = next.fetch_add(1);
+			if (i >= n || err.load() != GSA_OK) return;
+			const int32_t ci = order[(size_t)i];
+			gsa_result res;
+			int rc = gsa_align_contig(c, query[ci], qlen[ci], &res);
+			if (rc == GSA_OK && on_result) rc = on_result(user, ci, &res);
+			if (rc != GSA_OK) { int ok = GSA_OK; err.compare_exchange_strong(ok, rc); return; }
+		}
+	};
+	std::vector<std::thread> th;
+	for (int k = 1; k < n_ctx && k < n; k++) th.emplace_back(loop, ctx[k]);
+	loop(ctx[0]);
+	for (std::thread &t : th) t.join();
+	return err.load();
 }
 
 int64_t gsa_seed_count(gsa_ctx *c) { return c ? c->n_seeds : 0; }

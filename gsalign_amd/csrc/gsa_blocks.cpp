@@ -167,9 +167,9 @@ int host_stage8_finish(gsa_ctx *c)
 		(void)hipGetLastError(); fprintf(stderr, "\n");
 	}
 	if (hm[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
-	if (hm[M_DPERR2]) { c->dp_dirty = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
+	if (hm[M_DPERR2]) { c->dp_dirty = c->dp_timeout = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
 	if (c->profiling) { const unsigned long long *cc = (const unsigned long long *)(hm + M_CELLS); c->counters[4] += cc[0]; c->counters[6] += cc[1]; }
-	if (c->n_early > 0 && hm[M_DPERR3]) { c->dp_dirty = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out (early launch)"); }
+	if (c->n_early > 0 && hm[M_DPERR3]) { c->dp_dirty = c->dp_timeout = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out (early launch)"); }
 	// the large DP jobs finished after the records left: their (aln_len, score) arrive as a patch list
 	// (first the ones that only turned up in the job list, then the ones launched from the leaf table;
 	//  record -1 = an early job whose leaf the list logic dropped)

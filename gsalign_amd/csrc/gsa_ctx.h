@@ -130,6 +130,7 @@ struct gsa_ctx {
 	bool early_listed = false;                     // stage 2 left the list of large gaps on its way to the host (event ev[16])
 	i32 n_early = 0; bool early_in_flight = false; std::vector<i32> h_early;      // (seed, m, n) per early job
 	bool dp_dirty = true;                          // ticket counters / error words of the striped DP need clearing (fresh buffer, or a failed launch)
+	bool dp_timeout = false, dp_safe = false;      // a striped launch tripped its wait bound; repeat the contig with one job per launch
 	u32 dp_epoch = 0;                              // tag of the boundary granules of the current striped launch
 	DevBuf p_dp, p_sj, p_sj_early;                 // pinned: mailbox + large-job list; stripe job tables (read by the kernels in place)
 	DevBuf d_alnoff;

@@ -2,10 +2,15 @@
 // reference's surface (reference src/main.cpp:14-334): same flags, same defaults
 // (the CODE's defaults: -clr 200, -alen 200), same output files, with the per-contig
 // hot path handed to libgsa_hip.so (gsa_align_contig) instead of GenomeComparison's
-// pthread stages.  Extra flag: -gpu N (device ordinal).
+// pthread stages.  Extra flags: -gpu LIST (device ordinals, comma separated: the query contigs shard over them with the
+// index replicated) and -ctx N (contexts per GPU: gsa_clone, contigs overlap on one device).
+// The contigs go through gsa_align_many (the per-contig loop of GSAlign.cpp:483-548); MAF / VCF are written afterwards in
+// contig order, so the output bytes do not depend on how many GPUs or contexts worked.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <mutex>
 #include <string>
 #include "gsa_host.h"
 
@@ -25,7 +30,8 @@ static void usage(const char *prog, int t, const gsa_params &p, int fmt)
 	fprintf(stderr, "         -sen           Sensitive mode [False]\n");
 	fprintf(stderr, "         -one           set one on one aligment mode[false]\n");
 	fprintf(stderr, "         -no_vcf        do not write the VCF file\n");
-	fprintf(stderr, "         -gpu   INT     GPU ordinal [0]\n\n");
+	fprintf(stderr, "         -gpu   LIST    GPU ordinals, comma separated [0]\n");
+	fprintf(stderr, "         -ctx   INT     contexts per GPU working on different query sequences [2]\n\n");
 }
 
 static bool check_prefix(const char *p)                     // CheckOutputPrefix (main.cpp:116-138)
@@ -48,7 +54,8 @@ static bool first_char_is_header(const char *path)          // CheckInputFile (m
 int main(int argc, char *argv[])
 {
 	gsa_params prm; gsa_default_params(&prm);
-	int threads = 8, fmt = 1, gpu = 0; bool vcf = true, allow_dup = true;
+	int threads = 8, fmt = 1, n_ctx_per_gpu = 2; bool vcf = true, allow_dup = true;
+	std::vector<int> gpus;
 	const char *index_prefix = NULL, *ref_fa = NULL, *query_fa = NULL, *out_prefix = NULL;
 	if (argc == 1 || strcmp(argv[1], "-h") == 0) { usage(argv[0], threads, prm, fmt); return 0; }
 	if (strcmp(argv[1], "index") == 0) {
@@ -73,7 +80,8 @@ int main(int argc, char *argv[])
 		else if (a == "-clr" && i + 1 < argc) prm.min_block_score = atoi(argv[++i]);
 		else if (a == "-fmt" && i + 1 < argc) fmt = atoi(argv[++i]);
 		else if (a == "-o") out_prefix = argv[++i];
-		else if (a == "-gpu" && i + 1 < argc) gpu = atoi(argv[++i]);
+		else if (a == "-gpu" && i + 1 < argc) { for (const char *p = argv[++i]; *p;) { gpus.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; } }
+		else if (a == "-ctx" && i + 1 < argc) { n_ctx_per_gpu = atoi(argv[++i]); if (n_ctx_per_gpu < 1) n_ctx_per_gpu = 1; }
 		else if (a == "-dp" || a == "-d" || a == "-debug") { /* dot-plots / debug output: not supported, ignored */ }
 		else if ((a == "-gp" || a == "-obr") && i + 1 < argc) ++i;
 		else fprintf(stderr, "Warning! Unknow parameter: %s\n", argv[i]);
@@ -96,19 +104,42 @@ int main(int argc, char *argv[])
 	fprintf(stderr, "\tLoad the reference sequences (%d %s)\n", (int)idx.chr_len.size(), idx.chr_len.size() > 1 ? "chromosomes" : "chromosome");
 
 	gsa_index_view view; idx.fill_view(&view);
-	gsa_ctx *ctx = NULL;
-	if (gsa_create(gpu, &view, &prm, &ctx) != GSA_OK) { fprintf(stderr, "GPU initialisation failed: %s\n", gsa_last_error(NULL)); return 2; }
+	if (gpus.empty()) gpus.push_back(0);
+	// one context per GPU owns that device's copy of the index; the others borrow it (gsa_clone)
+	std::vector<gsa_ctx *> ctxs;
+	const size_t want_ctx = std::min(qs.size(), gpus.size() * (size_t)n_ctx_per_gpu);
+	for (size_t g = 0; g < gpus.size() && ctxs.size() < std::max<size_t>(want_ctx, 1); g++) {
+		gsa_ctx *owner = NULL;
+		if (gsa_create(gpus[g], &view, &prm, &owner) != GSA_OK) { fprintf(stderr, "GPU initialisation failed (device %d): %s\n", gpus[g], gsa_last_error(NULL)); return 2; }
+		ctxs.push_back(owner);
+	}
+	for (int k = 1; k < n_ctx_per_gpu; k++)
+		for (size_t g = 0; g < gpus.size() && ctxs.size() < want_ctx; g++) {
+			gsa_ctx *cl = NULL;
+			if (g >= ctxs.size() || gsa_clone(ctxs[g], &cl) != GSA_OK) { fprintf(stderr, "GPU initialisation failed (device %d): %s\n", gpus[g], gsa_last_error(NULL)); return 2; }
+			ctxs.push_back(cl);
+		}
 
 	const std::string maf = std::string(out_prefix) + ".maf", aln = std::string(out_prefix) + ".aln", vcfn = std::string(out_prefix) + ".vcf";
 	Emitter em; em.idx = &idx; em.allow_dup = allow_dup;
 	long long n_aln = 0, tot_len = 0, tot_match = 0, n_dup = 0;
 	fprintf(stderr, "Step2. Sequence analysis for all query chromosomes\n");
+	// the hot path: every contig through gsa_align_contig on whichever context is free; the finished blocks are copied out
+	// of the context by the worker that produced them
+	std::vector<ContigResult> results(qs.size());
+	std::vector<const char *> qptr(qs.size()); std::vector<int32_t> qlen(qs.size());
+	for (size_t ci = 0; ci < qs.size(); ci++) { qptr[ci] = qs[ci].seq.data(); qlen[ci] = (int32_t)qs[ci].seq.size(); }
+	struct Sink { std::vector<ContigResult> *out; } sink = { &results };
+	auto on_result = [](void *user, int32_t ci, const gsa_result *res) -> int { (*((Sink *)user)->out)[(size_t)ci].assign(*res); return 0; };
+	if (gsa_align_many(ctxs.data(), (int32_t)ctxs.size(), qptr.data(), qlen.data(), (int32_t)qs.size(), on_result, &sink) != GSA_OK) {
+		for (gsa_ctx *c : ctxs) if (*gsa_last_error(c)) fprintf(stderr, "GPU error: %s\n", gsa_last_error(c));
+		return 2;
+	}
+	// output in contig order (OutputMAF appends per contig, VarVec grows in contig order: GSAlign.cpp:543-546)
 	for (size_t ci = 0; ci < qs.size(); ci++) {
 		fprintf(stderr, "\tProcess query chromsomoe: %s...\n", qs[ci].name.c_str());
-		gsa_result res;
-		if (gsa_align_contig(ctx, qs[ci].seq.data(), (int32_t)qs[ci].seq.size(), &res) != GSA_OK) { fprintf(stderr, "GPU error: %s\n", gsa_last_error(ctx)); gsa_destroy(ctx); return 2; }
-		if (res.n_blocks == 0) continue;
-		ContigResult cr; cr.assign(res);
+		ContigResult &cr = results[ci];
+		if (cr.blocks.empty()) continue;
 		long long len = 0, score = 0;
 		for (size_t b = 0; b < cr.blocks.size(); b++) { len += cr.blocks[b].aln_len; score += cr.blocks[b].score; if (cr.blocks[b].bdup) n_dup++; }
 		n_aln += (long long)cr.blocks.size(); tot_len += len; tot_match += score;
@@ -116,6 +147,7 @@ int main(int argc, char *argv[])
 		if (fmt == 1) { FILE *fp = fopen(maf.c_str(), ci == 0 ? "w" : "a"); if (fp) { em.maf(fp, ci == 0, qs[ci], cr); fclose(fp); } }
 		if (fmt == 2) { FILE *fp = fopen(aln.c_str(), ci == 0 ? "w" : "a"); if (fp) { em.aln(fp, qs[ci], cr); fclose(fp); } }
 		if (vcf) em.variants((int)ci, qs[ci], cr);
+		ContigResult().blocks.swap(cr.blocks); std::vector<gsa_frag>().swap(cr.frags); std::string().swap(cr.aln1); std::string().swap(cr.aln2);
 	}
 	if (n_aln > 0) fprintf(stderr, "\tAlignment#=%d (total alignment length=%lld) ANI=%.2f%%, unique alignment#=%d\n", (int)n_aln, tot_len, 100 * (1.0 * tot_match / tot_len), (int)(n_aln - n_dup));
 	fprintf(stderr, "\tIt took %lld seconds for genome sequence alignment.\n", (long long)(time(NULL) - t0));
@@ -124,6 +156,6 @@ int main(int argc, char *argv[])
 		FILE *fp = fopen(vcfn.c_str(), "w");
 		if (fp) { em.vcf(fp, index_prefix != NULL ? index_prefix : ref_fa); fclose(fp); }
 	}
-	gsa_destroy(ctx);
+	for (size_t k = ctxs.size(); k-- > 0;) gsa_destroy(ctxs[k]);      // clones before the owners of their index
 	return 0;
 }

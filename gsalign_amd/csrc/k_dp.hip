@@ -182,8 +182,10 @@ __global__ void __launch_bounds__(64 * TINY_WAVES) k_dp_tiny(i32 n_jobs, const i
 // possible directions (21 cells each) in one LDS read, a ballot gives the length
 // of the run the automaton of ksw_backtrack would take step by step, and the run
 // is emitted at once.
-// Forward progress: stripe p only waits for stripe p-1, which has a lower
-// workgroup index and was therefore dispatched earlier; spins are bounded.
+// Forward progress: a workgroup takes its place in the launch from a TICKET drawn when it starts (not from its
+// workgroup index), so the stripe p-1 that stripe p waits for belongs to a workgroup that is already running,
+// whatever order the dispatcher starts workgroups in and whatever else competes for the CUs.  The wait is still
+// bounded (2 s of wall clock): a launch that trips it is repeated job by job (gsa_align_contig, dp_safe).
 // ---------------------------------------------------------------------------
 struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; };
 #define DP_TILE_ROWS 160        // local diagonals of a traceback tile (64 diagonal steps need 128)
@@ -198,6 +200,7 @@ struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; }
 #define DPT(...)
 #endif
 #define DP_LOOK 21
+#define DP_WAIT_TICKS 200000000ull   // bound of a hand-off wait: 2 s of the 100 MHz wall clock
 #define DP_CLASS_M 768          // size classes of a long job list: reference fragments above / up to this (see launch_stripes)
 #define DP_CLASS_MIN_JOBS 4096
 #define DP_LDS_M 3072         // longest reference fragment for which four stripes share a workgroup (3 boundary columns in LDS)
@@ -213,12 +216,20 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	// waves issue ahead of whatever else shares the SIMD.  The mass of smaller jobs behind them does not get that: on a
 	// 50 Mb contig they are 10 000 workgroups, and at raised priority they starve the record / small-DP path beside them
 	// (its passes ran 5-10x slower), which is the longer path there.
-	if (blockIdx.x < 96) __builtin_amdgcn_s_setprio(3);
+	__shared__ u32 s_bid;
+	if (threadIdx.x == 0) {
+		const u32 tk = __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (tk == gridDim.x - 1) __hip_atomic_store(&ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // last ticket of this launch: clean for the next one
+		s_bid = tk;
+	}
+	__syncthreads();
+	const u32 bid = s_bid;
+	if (bid < 96) __builtin_amdgcn_s_setprio(3);
 	// which job / stripe am I (uniform).  Both tables are read where the host wrote them (pinned memory): two dependent
 	// reads across the link cost less than a copy operation in front of the launch
-	const StripeJob sj = sjobs[blk2job[blockIdx.x]];
+	const StripeJob sj = sjobs[blk2job[bid]];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int p = ((int)blockIdx.x - sj.first_block) * WPB + wave, m = sj.m, n = sj.n, P = sj.P;
+	const int p = ((int)bid - sj.first_block) * WPB + wave, m = sj.m, n = sj.n, P = sj.P;
 	const uint8_t *s1 = pool1 + off1[sj.job], *s2 = pool2 + off2[sj.job];
 	const size_t pitch = (size_t)(m + 63) * 64;                         // direction bytes of one stripe
 	const int mpad64 = (m + 64 + 63) & ~63;                             // C1 is readable one 64-row block past the end
@@ -271,9 +282,9 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 				const bool need = lane < DP_G && row < m;                                                          \
 				u32 g = gnext;                                                                                  \
 				if (!__all(!need || (g >> 16) == ep)) {      /* (first look outside the loop: its wait only covers the prefetch) */ \
-					u32 spins = 0;                                                                              \
+					u32 spins = 0; const unsigned long long t_wait0 = wall_clock64();                          \
 					do {                                                                                        \
-						if (++spins > (1u << 20) || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; } \
+						if ((++spins & 255) == 0 && (wall_clock64() - t_wait0 > DP_WAIT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; } \
 						__builtin_amdgcn_s_sleep(1);                                                            \
 						if (need) g = DP_LOADG(MODE, row);                                                          \
 					} while (!__all(!need || (g >> 16) == ep));                                                  \
@@ -516,7 +527,8 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 	while (first < large.size()) {
 		// descriptors are staged in pinned memory: the upload is asynchronous
 		size_t cnt = 0;
-		{ size_t l = first; i64 db = 128; while (l < large.size()) { const i64 cells = (((i64)large[l].n + 63) / 64) * ((i64)large[l].m + 63) * 64; if (l > first && db + cells > budget) break; db += cells + 128; l++; } cnt = l - first; }
+		if (c->dp_safe) cnt = 1;      // (retry after a hand-off time-out: one job per launch, every stripe of it resident at once)
+		else { size_t l = first; i64 db = 128; while (l < large.size()) { const i64 cells = (((i64)large[l].n + 63) / 64) * ((i64)large[l].m + 63) * 64; if (l > first && db + cells > budget) break; db += cells + 128; l++; } cnt = l - first; }
 		// (the early launch and a late one may be in flight together: each has its own table)
 		DevBuf &psj = err_slot == M_DPERR3 ? c->p_sj_early : c->p_sj;
 		// the one or two segments of this batch: [first, split) above the class limit, [split, first + cnt) below
@@ -574,7 +586,7 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 			i32 *h = c->h_mail;
 			GSA_CHECK(c, hipMemcpyAsync(h, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
 			GSA_CHECK(c, hipStreamSynchronize(st));
-			if (h[err_slot]) { c->dp_dirty = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
+			if (h[err_slot]) { c->dp_dirty = c->dp_timeout = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
 		}
 		first = last;
 	}
@@ -683,7 +695,7 @@ extern "C" int gsa_ksw2_batch(gsa_ctx *c, int32_t n_pairs, const char *pool1, co
 		GSA_CHECK(c, hipMemcpyAsync(ops_len, d_ol, n * 4, hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipMemcpyAsync(&err, c->d_mail.as<i32>() + M_DPERR2, 4, hipMemcpyDeviceToHost, st));
 		GSA_CHECK(c, hipStreamSynchronize(st));
-		if (err) { c->dp_dirty = true; rc = gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
+		if (err) { c->dp_dirty = c->dp_timeout = true; rc = gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
 	}
 	return rc;
 }

@@ -124,6 +124,17 @@ const char *gsa_last_error(gsa_ctx *ctx);   /* ctx may be NULL: error of the las
  * query = raw contig bytes exactly as loaded from FASTA (any case, IUPAC ok). */
 int gsa_align_contig(gsa_ctx *ctx, const char *query, int32_t qlen, gsa_result *out);
 
+/* ---- the per-contig loop itself ------------------------------------------
+ * Replaces the loop `for (QueryChrIdx = 0; QueryChrIdx < iQueryChrNum; ...)` of GenomeComparison() (GSAlign.cpp:483-548):
+ * n contigs on n_ctx contexts -- contexts of different GPUs (gsa_create per device) and/or several contexts of one GPU
+ * (gsa_clone) -- one host thread per context, contigs handed out longest first.  Contigs are independent in the
+ * reference (all per-contig state is cleared at GSAlign.cpp:490), so results do not depend on n_ctx.
+ * on_result(user, contig, res) is called by the worker that finished `contig`, possibly from several threads at once;
+ * *res is valid during the callback only.  Returns the first error (the failing context holds the text). */
+typedef int (*gsa_result_fn)(void *user, int32_t contig, const gsa_result *res);
+int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n,
+                   gsa_result_fn on_result, void *user);
+
 /* ---- stage-level entry points (what the parity tests drive) --------------
  * gsa_set_query uploads a contig; gsa_run_to(stage) advances the same
  * eight-stage sequence the oracle uses:

@@ -20,7 +20,9 @@ def run_cli(cwd, *args):
     # flag variants, goldens from the unmodified reference CLI (tests/golden/make_golden.py --cli-variants)
     ("cx", ["-unique"], "cx_unique.maf", "cx_unique.vcf"), ("cx", ["-fmt", "2"], "cx_fmt2.aln", "cx_fmt2.vcf"), ("cx", ["-one"], "cx_one.maf", "cx_one.vcf"),
     ("cx", ["-idy", "95"], "cx_idy95.maf", "cx_idy95.vcf"), ("cx", ["-one", "-ind", "40", "-clr", "300", "-alen", "1000", "-unique"], "cx_combo.maf", "cx_combo.vcf"),
-    ("cx", ["-sen", "-fmt", "2"], "cx_sen_fmt2.aln", "cx_sen.vcf"), ("cx", ["-no_vcf"], "cx.maf", None)])
+    ("cx", ["-sen", "-fmt", "2"], "cx_sen_fmt2.aln", "cx_sen.vcf"), ("cx", ["-no_vcf"], "cx.maf", None),
+    # the contigs spread over 1 / 4 contexts (gsa_align_many; the default is 2): same bytes whatever worked on them
+    ("cx", ["-ctx", "1"], "cx.maf", "cx.vcf"), ("cx", ["-ctx", "4"], "cx.maf", "cx.vcf"), ("cx", ["-sen", "-ctx", "3", "-gpu", "0"], "cx_sen.maf", "cx_sen.vcf")])
 def test_cli_golden(golden_dir, tmp_path, name, extra, maf, vcf):
     run_cli(golden_dir, "-i", name, "-q", f"{name}.qry.fa", "-o", str(tmp_path / "out"), "-t", "1", *extra)
     kind = maf.rsplit(".", 1)[1]

@@ -211,6 +211,45 @@ def test_repeat_stress_vs_oracle(oracle_built, tmp_path, total, div, seed, param
     o.close(); g.close()
 
 
+def test_striped_dp_fallback_path(oracle_built, tmp_path, monkeypatch):
+    """The safety net behind the striped DP's bounded hand-off wait: one job per launch (GSA_DP_SAFE=1 forces it)."""
+    monkeypatch.setenv("GSA_DP_SAFE", "1")
+    refs, qrys = synth.make_pair_fast(600000, 1, 0.002, seed=57)
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx); g = capi.Aligner(idx)
+    _same_as_oracle(o, g, qrys)
+    assert int(g.counters()[5]) >= 0
+    o.close(); g.close()
+
+
+def test_align_many_contexts(oracle_built, tmp_path):
+    """gsa_align_many: contigs handed to three contexts by the library's own worker threads; every result vs the oracle."""
+    refs, qrys = synth.make_pair_fast(3000000, 6, 0.02, seed=58)
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx)
+    want = []
+    for name, seq in qrys:
+        o.set_query(seq); o.run_to(8); want.append(o.blocks(with_aln=False))
+    o.close()
+    g0 = capi.Aligner(idx); ctxs = [g0, g0.clone(), g0.clone()]
+    got = {}
+
+    def on_result(ci, res):
+        nb = res.n_blocks
+        B = np.ctypeslib.as_array(capi.C.cast(res.blocks, capi.C.POINTER(capi.C.c_uint8)), shape=(nb * 40,)).view(capi.BLOCK_DT).copy()
+        got[ci] = (B["score"].copy(), B["aln_len"].copy(), int(res.n_frags))
+        return 0
+
+    capi.align_many(ctxs, [q for _, q in qrys] * 2, on_result)
+    assert sorted(got) == list(range(2 * len(qrys)))
+    for ci, (sc, al, nf) in got.items():
+        w = want[ci % len(qrys)]
+        assert np.array_equal(sc, w["b_score"]) and np.array_equal(al, w["b_aln_len"]) and nf == int(w["b_nfrag"].sum()), ci
+    for g in ctxs[1:]:
+        g.close()
+    g0.close()
+
+
 def test_two_contexts_share_one_index(oracle_built, tmp_path):
     """gsa_clone: two contexts on one GPU, one device index, driven from two host threads on different contigs at the
     same time -- results identical to the oracle's (and so to a single context's)."""
