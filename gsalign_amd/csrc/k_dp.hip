@@ -208,7 +208,7 @@ struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; }
 template <int WPB>
 __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ blk2job, const StripeJob *__restrict__ sjobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
                                                    const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2, uint8_t *dirbase, u32 *bndbase, u32 *ctr,
-                                                   uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, u32 ep, i32 lds_c1, i32 lds_rows, u32 *err)
+                                                   uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, u32 ep, i32 lds_c1, i32 lds_rows, u32 *err, i32 tick_slot)
 {
 	extern __shared__ __attribute__((aligned(16))) int8_t C1[];        // the reference fragment as nt4 codes
 	__shared__ __attribute__((aligned(16))) uint8_t tile[DP_TILE_ROWS * 64];
@@ -218,8 +218,8 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	// (its passes ran 5-10x slower), which is the longer path there.
 	__shared__ u32 s_bid;
 	if (threadIdx.x == 0) {
-		const u32 tk = __hip_atomic_fetch_add(&ctr[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (tk == gridDim.x - 1) __hip_atomic_store(&ctr[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // last ticket of this launch: clean for the next one
+		const u32 tk = __hip_atomic_fetch_add(&ctr[tick_slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (tk == gridDim.x - 1) __hip_atomic_store(&ctr[tick_slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // last ticket of this launch: clean for the next one
 		s_bid = tk;
 	}
 	__syncthreads();
@@ -547,7 +547,7 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		if (!pin_ensure<char>(c, psj, (cnt + 1) * sizeof(StripeJob) + (nb_ub + 2) * 4)) return GSA_ERR_NOMEM;
 		StripeJob *sj = psj.as<StripeJob>();
 		i32 *b2j_all = (i32 *)(sj + cnt + 1);
-		i64 dbytes = 128, bwords = 0; i32 nctr = 1; size_t b2j_used = 0;
+		i64 dbytes = 128, bwords = 0; i32 nctr = 2; size_t b2j_used = 0;      // (ctr[0], ctr[1]: launch tickets of the two size classes)
 		for (Seg &sg : seg) {
 			sg.b2j = b2j_all + b2j_used; sg.nblocks = 0;
 			for (size_t k = sg.b; k < sg.e; k++) {
@@ -574,10 +574,13 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		if (c->dp_epoch == 0 || c->d_dp_bnd.cap != bnd_cap0) { GSA_CHECK(c, hipMemsetAsync(bnd, 0, c->d_dp_bnd.cap, st)); if (c->dp_epoch == 0) c->dp_epoch = 1; }
 		// (the ticket counters are put back to zero by the wave that draws the last ticket; the error word lives in the mailbox)
 		if (c->d_dp_ctr.cap != ctr_cap0 || c->dp_dirty) { GSA_CHECK(c, hipMemsetAsync(ctr, 0, c->d_dp_ctr.cap, st)); GSA_CHECK(c, hipMemsetAsync(mail + err_slot, 0, 4, st)); c->dp_dirty = false; }
-		for (const Seg &sg : seg) {
+		// (the two classes back to back on one stream.  Side by side on two streams -- the few long jobs at raised priority --
+		//  was measured at 250 Mb: same step time, the refinement passes beside them starve instead: the chip is busy either way)
+		for (int si = 0; si < 2; si++) {
+			const Seg &sg = seg[si];
 			if (sg.nblocks == 0) continue;
-			if (sg.wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)sg.nblocks), dim3(256), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)sg.mpad, (i32)sg.lds_rows, (u32 *)(mail + err_slot));
-			else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)sg.nblocks), dim3(64), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)sg.mpad, (i32)sg.lds_rows, (u32 *)(mail + err_slot));
+			if (sg.wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)sg.nblocks), dim3(256), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)sg.mpad, (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
+			else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)sg.nblocks), dim3(64), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)sg.mpad, (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
 		}
 		GSA_CHECK(c, hipGetLastError());
 		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })

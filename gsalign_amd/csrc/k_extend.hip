@@ -352,6 +352,7 @@ int stage78_extend(gsa_ctx *c)
 	// (run_ksw2_jobs read the mailbox: the record count and the size of the string pools are known now)
 	const i32 *hm = c->p_dp.as<i32>();
 	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN]; c->n_large = kl.nlarge;
+	{ static const bool dbg = getenv("GSA_DEBUG") != nullptr; if (dbg) fprintf(stderr, "[gsa] DP jobs %d (small+tiny %d), striped: %d listed early at stage 2, %d launched late\n", kl.n, kl.nsmall, c->n_early, kl.nlarge); }
 	// everything that can only leave at the very end sits in ONE buffer: final mailbox | patch list of the large DP jobs |
 	// string pool 1 | string pool 2 -- a single copy behind the last kernel instead of a chain of four
 	const size_t npatch = (size_t)kl.nlarge + (size_t)c->n_early;
