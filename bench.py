@@ -235,6 +235,47 @@ def cpu_baseline(px, qry, tmp, budget_bp):
                       f"host has {cores} logical cores"}
 
 
+def dry_main(args):
+    """--dry: the launcher, the rank plumbing and the two exchanges of the multi-GPU path on CPU (gloo) with a stub in place
+    of the aligner -- what tests/test_bench_launcher.py runs at world size 2.  Prints the same JSON shape; no performance claim."""
+    import torch
+    import torch.distributed as dist
+    from gsalign_amd import capi, shard
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr); sys.exit(2)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(100 + rank)
+    contigs = [rng.integers(65, 69, size=n).astype(np.uint8) for n in (40000, 30000, 20000, 10000)]
+
+    def stub(ci, c):
+        B = np.zeros(1, capi.BLOCK_DT); B["score"] = int(c.sum() % 100000); B["n_frag"] = 1
+        F = np.zeros(1, capi.FRAG_DT); F["qpos"] = ci
+        return dict(blocks=B, frags=F, aln1=c[:8].copy(), aln2=c[8:16].copy())
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        [stub(i, c) for i, c in enumerate(contigs)]
+    sync(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mine = {i: stub(i, c) for i, c in enumerate(contigs)}
+    sync(); t = time.perf_counter() - t0
+    tt = torch.tensor([t], dtype=torch.float64); tb = torch.tensor([float(sum(c.size for c in contigs) * args.steps)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX); dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+    allr = shard.gather_results({rank * 100 + i: r for i, r in mine.items()}, capi.BLOCK_DT, capi.FRAG_DT)
+    assert len(allr) == world * len(contigs) or world == 1
+    if rank == 0:
+        print(json.dumps({"metric": "aligned query Gbp/s (whole node)", "value": float(tb.item()) / float(tt.item()) / 1e9, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1000.0 * float(tt.item()) / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+                          "data": "dry run: stub aligner on CPU, gloo (launcher / plumbing check only)", "config": {"workload": "dry", "gathered_contigs": len(allr)}}))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,10 +287,13 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="contexts (host threads) per GPU working on different contigs")
     ap.add_argument("--extra", default="ecoli,yeast", help="further workloads measured in the same run (short loops); '' = none")
     ap.add_argument("--hwq", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default)")
+    ap.add_argument("--dry", action="store_true", help="no GPU: stub aligner + gloo, checks the launcher and the rank plumbing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bases of one query contig the CPU baseline is timed on")
     args = ap.parse_args()
     relaunch_if_needed(args)
+    if args.dry:
+        return dry_main(args)
     if args.hwq > 0:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hwq)      # (the runtime's default is 4 hardware queues per process; `inflight` contexts x 4 streams share them)
 

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgsa_hip.so")
 
 EXPORTS = [
-    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many",
+    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many", "gsa_seed_chunks", "gsa_hit_count", "gsa_export_hits", "gsa_import_hits", "gsa_finish_contig",
     "gsa_set_query", "gsa_rewind", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
     "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling",
 ]
@@ -75,6 +75,10 @@ def load_library() -> C.CDLL:
     lib.gsa_last_error.restype = C.c_char_p
     lib.gsa_last_error.argtypes = [C.c_void_p]
     lib.gsa_seed_count.restype = C.c_int64
+    lib.gsa_hit_count.restype = C.c_int64
+    lib.gsa_hit_count.argtypes = [C.c_void_p]
+    lib.gsa_export_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.gsa_import_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     for name in ("gsa_destroy", "gsa_set_params", "gsa_align_contig", "gsa_set_query", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds",
                  "gsa_group_count", "gsa_get_groups", "gsa_get_blocks", "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch",
                  "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling"):
@@ -188,6 +192,39 @@ class Aligner:
         self._q = seq
         res = Result()
         self._ck(self.lib.gsa_align_contig(self.ctx, seq.ctypes.data_as(C.c_char_p), C.c_int32(seq.size), C.byref(res)))
+        return self._result(res)
+
+    # ---- one contig seeded by several GPUs (gsa_seed_chunks ... gsa_finish_contig) ----
+    def seed_chunks(self, seq: np.ndarray, chunk_beg: int, chunk_end: int) -> int:
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        self._q = seq
+        self._ck(self.lib.gsa_seed_chunks(self.ctx, seq.ctypes.data_as(C.c_char_p), C.c_int32(seq.size), C.c_int32(chunk_beg), C.c_int32(chunk_end)))
+        return int(self.lib.gsa_hit_count(self.ctx))
+
+    def export_hits(self, keys_ptr=None, vals_ptr=None):
+        """Hits of this context's chunk range.  Without arguments: two numpy arrays; with pointers (host or device memory of
+        gsa_hit_count entries): copied there."""
+        n = int(self.lib.gsa_hit_count(self.ctx))
+        if keys_ptr is not None:
+            self._ck(self.lib.gsa_export_hits(self.ctx, C.c_void_p(keys_ptr), C.c_void_p(vals_ptr)))
+            return n
+        k = np.zeros(n, np.uint64); v = np.zeros(n, np.uint32)
+        if n:
+            self._ck(self.lib.gsa_export_hits(self.ctx, C.c_void_p(k.ctypes.data), C.c_void_p(v.ctypes.data)))
+        return k, v
+
+    def import_hits(self, keys, vals, n=None):
+        """keys / vals: numpy arrays, or raw pointers (host or device memory) with n."""
+        if n is None:
+            keys = np.ascontiguousarray(keys, np.uint64); vals = np.ascontiguousarray(vals, np.uint32)
+            n = int(keys.size); kp, vp = keys.ctypes.data, vals.ctypes.data
+        else:
+            kp, vp = keys, vals
+        self._ck(self.lib.gsa_import_hits(self.ctx, C.c_void_p(kp), C.c_void_p(vp), C.c_int64(n)))
+
+    def finish_contig(self) -> dict:
+        res = Result()
+        self._ck(self.lib.gsa_finish_contig(self.ctx, C.byref(res)))
         return self._result(res)
 
     def seeds(self):

@@ -67,7 +67,7 @@ static int reset_run_state(gsa_ctx *c)
 {
 	if (c->early_in_flight) { GSA_CHECK(c, hipStreamSynchronize(c->stream_aux[0])); c->early_in_flight = false; }
 	c->n_early = 0; c->early_listed = false; c->early_consumed = false;
-	c->stage = 0;
+	c->stage = 0; c->split = false;
 	c->n_seeds = 0; c->n_groups = 0; c->n_blocks2 = 0; c->blocks.clear(); c->frags_stage = 0; c->have_host_seeds = false; c->ev_pending = 0; c->s2_host = false;
 	memset(c->counters, 0, sizeof(c->counters)); memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
 	return GSA_OK;
@@ -268,6 +268,51 @@ int gsa_align_contig(gsa_ctx *c, const char *query, int32_t qlen, gsa_result *ou
 		c->dp_safe = false;
 	}
 	if (rc) return rc;
+	return gsa_get_blocks(c, out);
+}
+
+// ---- one contig seeded by several GPUs ----
+int gsa_seed_chunks(gsa_ctx *c, const char *query, int32_t qlen, int32_t chunk_beg, int32_t chunk_end)
+{
+	if (!c || chunk_beg < 0 || chunk_end < chunk_beg) return GSA_ERR_ARG;
+	int rc = gsa_set_query(c, query, qlen); if (rc) return rc;
+	c->split = true; c->rng_beg = chunk_beg; c->rng_end = chunk_end;
+	rc = stage1_seed(c);
+	if (rc == GSA_OK) GSA_CHECK(c, hipStreamSynchronize(c->stream));
+	collect_events(c);
+	return rc;
+}
+
+int64_t gsa_hit_count(gsa_ctx *c) { return (c && c->split) ? c->n_seeds : 0; }
+
+int gsa_export_hits(gsa_ctx *c, uint64_t *keys, uint32_t *vals)
+{
+	if (!c || !c->split) return c ? gsa_fail(c, GSA_ERR_STATE, "gsa_seed_chunks first") : GSA_ERR_ARG;
+	if (c->n_seeds == 0) return GSA_OK;
+	if (!keys || !vals) return GSA_ERR_ARG;
+	GSA_CHECK(c, hipSetDevice(c->device));
+	GSA_CHECK(c, hipMemcpyAsync(keys, c->d_key_a.p, (size_t)c->n_seeds * 8, hipMemcpyDefault, c->stream));
+	GSA_CHECK(c, hipMemcpyAsync(vals, c->d_val_a.p, (size_t)c->n_seeds * 4, hipMemcpyDefault, c->stream));
+	GSA_CHECK(c, hipStreamSynchronize(c->stream));
+	return GSA_OK;
+}
+
+int gsa_import_hits(gsa_ctx *c, const uint64_t *keys, const uint32_t *vals, int64_t n)
+{
+	if (!c || n < 0 || (n > 0 && (!keys || !vals))) return GSA_ERR_ARG;
+	if (!c->split || c->stage != 0) return gsa_fail(c, GSA_ERR_STATE, "gsa_seed_chunks first");
+	GSA_CHECK(c, hipSetDevice(c->device));
+	return stage1_import_hits(c, (const u64 *)keys, (const u32 *)vals, n);
+}
+
+int gsa_finish_contig(gsa_ctx *c, gsa_result *out)
+{
+	if (!c || !out) return GSA_ERR_ARG;
+	if (!c->split || c->stage != 0) return gsa_fail(c, GSA_ERR_STATE, "gsa_seed_chunks first");
+	GSA_CHECK(c, hipSetDevice(c->device));
+	int rc = stage1_finish_split(c); if (rc) return rc;
+	c->stage = 1; c->split = false;
+	rc = gsa_run_to(c, 8); if (rc) return rc;
 	return gsa_get_blocks(c, out);
 }
 

@@ -53,6 +53,7 @@ struct gsa_ctx {
 
 	// query
 	DevBuf d_query; i32 qlen = 0; int stage = 0;
+	bool split = false; i64 rng_beg = 0, rng_end = 0;     // gsa_seed_chunks: stage 1 on a chunk range only, the hits of other ranges are imported
 	int qbits = 1, pdbits = 1;
 
 	// scratch for rocPRIM
@@ -167,6 +168,8 @@ template <class T> static inline T *pin_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 int build_dense_sa(gsa_ctx *c, u64 n_sa);   // k_seed.hip
 int build_presence(gsa_ctx *c);             // k_seed.hip  (after MinSeedLength changed)
 int stage1_seed(gsa_ctx *c);          // k_seed.hip
+int stage1_import_hits(gsa_ctx *c, const u64 *keys, const u32 *vals, i64 n);   // k_seed.hip
+int stage1_finish_split(gsa_ctx *c);  // k_seed.hip
 int seed_view_sort(gsa_ctx *c);       // k_seed.hip  (PosDiff-sorted seeds + groups: stage-1 view, or front of stage 2 without the PosDiff bitmap)
 int stage2_chain(gsa_ctx *c);         // k_chain.hip
 int launch_early_dp(gsa_ctx *c);      // k_chain.hip  (striped DP for the large gaps listed at the end of stage 2)

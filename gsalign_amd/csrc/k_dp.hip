@@ -24,7 +24,9 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
                                                                 const i32 *__restrict__ len2, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len,
                                                                 const i32 *__restrict__ jfrag, gsa_frag *frag)
 {
-	__shared__ uint8_t s_dir[SMALL_WAVES][SMALL_ROWS * 64];
+	// direction flags as NIBBLES, two anti-diagonals per byte (only bits 0-1 and 3-4 of ksw2's flag byte are ever set): half
+	// the LDS per alignment -- LDS is what limits how many of these waves a CU holds -- and half the LDS stores
+	__shared__ uint8_t s_dir[SMALL_WAVES][(SMALL_ROWS / 2) * 64];
 	__shared__ uint8_t s_rev[SMALL_WAVES][SMALL_ROWS + 64];
 	__shared__ int s_n[SMALL_WAVES];
 	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -37,27 +39,32 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 	const int cq = lane < n ? gsa_nt4(s2[lane]) : 4;
 	// reference base for lane t at diagonal r is s1[r - t]: it enters at lane 0 and moves one lane up per diagonal
 	const int c1a = lane < m ? gsa_nt4(s1[lane]) : 4, c1b = lane + 64 < m ? gsa_nt4(s1[lane + 64]) : 4;
-	int u = lane ? 2 : 0, v = 0, x = 0, y = 0, wref = 4;
+	int u = lane ? 2 : 0, v = 0, x = 0, y = 0, wref = 4, dacc = 0;
 	const int nr = m + n - 1;
 	for (int r = 0; r < nr; r++) {
 		const int inb = r < m ? (r < 64 ? __shfl(c1a, r) : __shfl(c1b, r - 64)) : 4;      // s1[r] broadcast
 		wref = wave_shr1(wref, inb);
 		const int xt1 = wave_shr1(x, 0), vt1 = wave_shr1(v, r ? 2 : 0);                     // (r-1,t-1); boundary for t = 0 (:157-164)
 		const int jj = r - lane;
+		int d = 0;
 		if (lane < n && jj >= 0 && jj < m) {
 			int un, vn, xn, yn;
-			const int d = dp_cell(xt1, vt1, u, y, cq, wref, un, vn, xn, yn);
+			d = dp_cell(xt1, vt1, u, y, cq, wref, un, vn, xn, yn);
 			u = un; v = vn; x = xn; y = yn;
-			dir[r * 64 + lane] = (uint8_t)d;
 		}
+		const int nib = (d & 3) | ((d & 0x18) >> 1);
+		// (every lane stores, cells outside the matrix are never read)
+		if (r & 1) dir[(r >> 1) * 64 + lane] = (uint8_t)(dacc | (nib << 4)); else dacc = nib;
 	}
+	if (nr & 1) dir[(nr >> 1) * 64 + lane] = (uint8_t)dacc;
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	if (lane == 0) {
 		int i = n - 1, j = m - 1, state = 0, k = 0;
 		while (i >= 0 && j >= 0) {
-			const u32 tmp = dir[(i + j) * 64 + i];
+			const u32 nb = ((u32)dir[((i + j) >> 1) * 64 + i] >> (((i + j) & 1) << 2)) & 15u;
+			const u32 tmp = (nb & 3u) | ((nb & 0xCu) << 1);
 			int ns = state;                                                 // ksw_backtrack automaton (:38-52), branch-free
 			if (ns != 0 && !((tmp >> (ns + 2)) & 1)) ns = 0;
 			if (ns == 0) ns = (int)(tmp & 7);
@@ -199,6 +206,20 @@ struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; }
 #else
 #define DPT(...)
 #endif
+// -DDP_EXP=bits: timing experiments only (results are wrong): 1 = no direction stores, 2 = no traceback
+#ifndef DP_EXP
+#define DP_EXP 0
+#endif
+#if DP_EXP & 1
+#define DPX_STORE(...)
+#else
+#define DPX_STORE(...) __VA_ARGS__
+#endif
+#if DP_EXP & 2
+#define DPX_TB(...) __VA_ARGS__
+#else
+#define DPX_TB(...)
+#endif
 #define DP_LOOK 21
 #define DP_WAIT_TICKS 200000000ull   // bound of a hand-off wait: 2 s of the 100 MHz wall clock
 #define DP_CLASS_M 768          // size classes of a long job list: reference fragments above / up to this (see launch_stripes)
@@ -211,7 +232,10 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
                                                    uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, u32 ep, i32 lds_c1, i32 lds_rows, u32 *err, i32 tick_slot)
 {
 	extern __shared__ __attribute__((aligned(16))) int8_t C1[];        // the reference fragment as nt4 codes
-	__shared__ __attribute__((aligned(16))) uint8_t tile[DP_TILE_ROWS * 64];
+	// The traceback tile ALIASES the forward pass's LDS (codes + boundary columns): the wave that walks back drew the last
+	// ticket of its job, so every stripe of the job -- every other wave of this workgroup -- is through with them.  LDS
+	// per workgroup is what limits how many jobs (and which other kernels of the contig) a CU holds.
+	uint8_t *tile = (uint8_t *)C1;
 	// The LARGEST jobs are the contig's latency floor (the list is sorted by cells: they are the first workgroups): their
 	// waves issue ahead of whatever else shares the SIMD.  The mass of smaller jobs behind them does not get that: on a
 	// 50 Mb contig they are 10 000 workgroups, and at raised priority they starve the record / small-DP path beside them
@@ -308,13 +332,13 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 			z = z < 7 ? z : 7;                                                                                  \
 			const int un = z - v1, vn = z - u;                                                                  \
 			z -= 2; a -= z; b -= z;                                                                             \
-			if (a > 0) d |= 0x08; else a = 0;                                                                   \
-			if (b > 0) d |= 0x10; else b = 0;                                                                   \
+			a = a > 0 ? a : 0; b = b > 0 ? b : 0;       /* x, y; flag bits 3, 4 = "is positive" = min(., 1) */           \
+			d |= ((a < 1 ? a : 1) << 3) | ((b < 1 ? b : 1) << 4);                                               \
 			u = un; y = b; pk = a | (vn << 8); dlast = d;                                                       \
 		}                                                                                                       \
 		/* stored by every lane (slots of cells outside the matrix are never read): a straight-line store    \
 		   keeps the vmcnt bookkeeping exact, so waiting for a boundary prefetch does not drain the stores */ \
-		rowp[((K2) << 6) + lane] = (uint8_t)dlast;                                                              \
+		DPX_STORE(rowp[((K2) << 6) + lane] = (uint8_t)dlast;)                                                   \
 		hist = __builtin_amdgcn_update_dpp(pk, hist, 0x130, 0xf, 0xf, false);      /* wave_shl:1, lane 63 takes pk */ \
 		if (((K2) & (DP_G - 1)) == DP_G - 2 && pub_stripe && rl_ >= 62 + DP_G) {                                                       \
 			/* rows rl_-62-DP_G .. rl_-63 of the boundary column are complete: one store of DP_G tagged granules */ \
@@ -358,6 +382,7 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	if (lane == 0) ticket = __hip_atomic_fetch_add(&ctr[sj.ctr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	ticket = (u32)__builtin_amdgcn_readfirstlane((int)ticket);
 	if ((int)ticket != P - 1) return;
+	DPX_TB(if (lane == 0) ops_len[sj.job] = 0; return;)
 	if (lane == 0) ctr[sj.ctr] = 0;                                     // (nobody else looks again: the counters stay clean for the next launch)
 	DPT(const unsigned long long T1c = wall_clock64(); int ntile = 0, nrun = 0;)
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -542,6 +567,7 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 			sg.wpb = sg.mmax <= DP_LDS_M ? 4 : 1;      // reference fragments up to DP_LDS_M bases: four stripes per workgroup, boundary columns through LDS
 			sg.lds_rows = (sg.mmax + 15) & ~15;
 			sg.dyn_lds = (size_t)sg.mpad + (sg.wpb > 1 ? (size_t)(sg.wpb - 1) * sg.lds_rows * 4 : 0);
+			if (sg.dyn_lds < (size_t)DP_TILE_ROWS * 64) sg.dyn_lds = (size_t)DP_TILE_ROWS * 64;      // (the traceback tile lives in the same bytes)
 			for (size_t k = sg.b; k < sg.e; k++) nb_ub += (size_t)(((large[k].n + 63) / 64 + sg.wpb - 1) / sg.wpb);
 		}
 		if (!pin_ensure<char>(c, psj, (cnt + 1) * sizeof(StripeJob) + (nb_ub + 2) * 4)) return GSA_ERR_NOMEM;

@@ -550,8 +550,10 @@ __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ c
 #define SEL_HASH 256
 __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, const u32 *__restrict__ cand_cnt, const i32 *__restrict__ cand_s, const i32 *__restrict__ cand_len,
                                                       const u64 *__restrict__ cand_x0, const i32 *__restrict__ cand_freq, const u32 *__restrict__ onpath,
-                                                      const i32 *__restrict__ hit_base, i32 qlen, int qbits, u64 *key, u32 *val, u32 *pdbm)
+                                                      const i32 *__restrict__ hit_base, i32 qlen, i32 s_off, int qbits, u64 *key, u32 *val, u32 *pdbm)
 {
+	// (qlen = length of the whole contig, s_off = contig position of the first chunk searched: not 0 when only a chunk range
+	//  of the contig was seeded on this GPU, gsa_seed_chunks)
 	extern __shared__ u32 s_offs[];                    // exclusive prefix of the hit counts of the chunk's candidates (0 for off-chain ones), [nc + 1]
 	__shared__ unsigned long long s_w[SEL_HASH]; __shared__ u32 s_b[SEL_HASH];
 	__shared__ u32 s_wsum[4], s_run;
@@ -588,7 +590,7 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 		u32 lo = 0, hi = nc;
 		while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_offs[mid] <= t) lo = mid; else hi = mid; }
 		const u32 i = lo, h = t - s_offs[i];
-		const i32 s = cand_s[cbase + i]; const u32 f = (u32)cand_freq[cbase + i], len = (u32)cand_len[cbase + i]; const u64 x0 = cand_x0[cbase + i];
+		const i32 s = cand_s[cbase + i] + s_off; const u32 f = (u32)cand_freq[cbase + i], len = (u32)cand_len[cbase + i]; const u64 x0 = cand_x0[cbase + i];
 		const u64 r = fm_locate(di, x0 + h);
 		const i64 pd = (i64)r - s + qlen;
 		u32 rank = 0;
@@ -613,6 +615,15 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 		__syncthreads();
 		for (int t = j; t < SEL_HASH; t += 256) if (s_w[t] != ~0ull) atomicOr(&pdbm[s_w[t]], s_b[t]);
 	}
+}
+
+// PosDiff bitmap bits of hits that arrived from another GPU (gsa_import_hits)
+__global__ void __launch_bounds__(256) k_pd_from_keys(i64 n, const u64 *__restrict__ key, int qbits, u32 *pdbm)
+{
+	const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const u64 pd = key[i] >> qbits;
+	atomicOr(&pdbm[pd >> 5], 1u << (pd & 31));
 }
 
 // Accounting build only: the LF steps bwt_sa would walk for every located hit (the row is sampled every 32 ROWS, so the
@@ -768,12 +779,50 @@ int build_dense_sa(gsa_ctx *c, u64 n_sa)
 	return GSA_OK;
 }
 
+// grow a device buffer keeping its first `keep` elements
+template <class T> static T *dev_grow_keep(gsa_ctx *c, DevBuf &b, size_t n, size_t keep)
+{
+	if ((n ? n : 1) * sizeof(T) <= b.cap) return (T *)b.p;
+	DevBuf nb;
+	if (!dev_ensure<T>(c, nb, n + n / 2)) return nullptr;
+	if (keep && b.p) { if (hipMemcpyAsync(nb.p, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { hipFree(nb.p); gsa_fail(c, GSA_ERR_HIP, "hipMemcpyAsync"); return nullptr; } }
+	if (b.p) { hipStreamSynchronize(c->stream); hipFree(b.p); }
+	b = nb;
+	return (T *)b.p;
+}
+
+// Groups without the PosDiff sort: decide whether the bitmap of occupied PosDiff values is kept for this contig and clear it
+static int prepare_pd_bitmap(gsa_ctx *c, i64 n_hits)
+{
+	const u64 pd_words = (((u64)(2 * c->G) + (u64)c->qlen + 2) >> 5) + 2;
+	// (a chunk range: the hit count of the whole contig is not known here; the bitmap is kept whenever MaxIndelSize allows it)
+	c->pd_path = (n_hits > 0 || c->split) && c->prm.MaxIndelSize >= 0 && c->prm.MaxIndelSize <= 31 && (c->split || pd_words <= 64ull * (u64)n_hits + 65536) && !getenv("GSA_NO_PDBITMAP");
+	c->seed_view_ready = false;
+	if (c->pd_path) {
+		const size_t cap0 = c->d_pdbm.cap;
+		if (!dev_ensure<u32>(c, c->d_pdbm, (size_t)pd_words + 2)) return GSA_ERR_NOMEM;
+		if (c->d_pdbm.cap != cap0 || c->pdbm_dirty) GSA_CHECK(c, hipMemsetAsync(c->d_pdbm.p, 0, c->d_pdbm.cap, c->stream));
+		c->pdbm_dirty = true; c->pd_words = (i64)pd_words;
+	}
+	return GSA_OK;
+}
+
+// Stage 1 for the whole contig, or -- c->split -- for the chunk range [rng_beg, rng_end) of it: chunks are searched
+// independently (GSAlign.cpp:61-94: a thread takes 10 000-bp chunks off a counter; seeds never cross a chunk edge), so a
+// long contig can be seeded by several GPUs and the hits sent to the GPU that chains it.  The
+// kernels see the range as a contig of its own (pointer + length); only the select kernel needs the absolute position.
 int stage1_seed(gsa_ctx *c)
 {
-	const i32 qlen = c->qlen;
 	hipStream_t st = c->stream;
+	const bool split = c->split;
+	const i64 all_chunks = ((i64)c->qlen + GSA_CHUNK - 1) / GSA_CHUNK;
+	const i64 cb = split ? c->rng_beg : 0, ce = split ? (c->rng_end < all_chunks ? c->rng_end : all_chunks) : all_chunks;
+	const i32 s_off = (i32)(cb * GSA_CHUNK);
+	const i32 qlen_full = c->qlen;
+	const i32 qlen = ce > cb ? (i32)(((i64)ce * GSA_CHUNK < (i64)qlen_full ? (i64)ce * GSA_CHUNK : (i64)qlen_full) - s_off) : 0;
+	const uint8_t *d_q = c->d_query.as<uint8_t>() + s_off;
 	c->n_seeds = 0; c->n_groups = 0;
-	if (qlen <= 0) return GSA_OK;
+	if (qlen <= 0) return split ? prepare_pd_bitmap(c, 0) : GSA_OK;
 	const i64 n_chunks = ((i64)qlen + GSA_CHUNK - 1) / GSA_CHUNK;
 	size_t ccap = c->cand_cap_per_chunk;                // candidate slots per chunk (grows on overflow)
 	if (!dev_ensure<u32>(c, c->d_onpath, (size_t)n_chunks * PATH_WORDS) || !dev_ensure<i32>(c, c->d_chunk_hits, (size_t)n_chunks + 1) || !dev_ensure<i32>(c, c->d_chunk_base, (size_t)n_chunks + 1)) return GSA_ERR_NOMEM;
@@ -795,7 +844,7 @@ int stage1_seed(gsa_ctx *c)
 		u64 hits = 0, maxcand = 0, n_heavy = dense_all ? (u64)n_chunks : 0;
 		occ_all = 0;
 		if (!dense_all) {
-#define GSA_SEED_ARGS c->di, c->d_query.as<uint8_t>(), qlen, c->prm, cnt, c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, \
+#define GSA_SEED_ARGS c->di, d_q, qlen, c->prm, cnt, c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, \
 			c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>(), c->h_cnt, budget, c->d_heavy.as<u32>()
 			if (c->count_blocks) hipLaunchKernelGGL((k_seed_wg<true, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, GSA_SEED_ARGS);
 			else if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, GSA_SEED_ARGS);
@@ -816,9 +865,9 @@ int stage1_seed(gsa_ctx *c)
 			const size_t nd = (size_t)n_heavy * GSA_CHUNK;
 			if (!dev_ensure<uint16_t>(c, c->dn_memo, nd) || !dev_ensure<u32>(c, c->dn_lf, nd) || !dev_ensure<u64>(c, c->dn_x0, nd)) return GSA_ERR_NOMEM;
 			const u32 *list = dense_all ? (const u32 *)nullptr : c->d_heavy.as<u32>();
-			if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true>), dim3((unsigned)(n_heavy * DENSE_WGS)), dim3(DENSE_TPB), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, list,
+			if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true>), dim3((unsigned)(n_heavy * DENSE_WGS)), dim3(DENSE_TPB), 0, st, c->di, d_q, qlen, c->prm, list,
 			                                       c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt);
-			else hipLaunchKernelGGL((k_dense_search<false>), dim3((unsigned)(n_heavy * DENSE_WGS)), dim3(DENSE_TPB), 0, st, c->di, c->d_query.as<uint8_t>(), qlen, c->prm, list,
+			else hipLaunchKernelGGL((k_dense_search<false>), dim3((unsigned)(n_heavy * DENSE_WGS)), dim3(DENSE_TPB), 0, st, c->di, d_q, qlen, c->prm, list,
 			                        c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt);
 			hipLaunchKernelGGL(k_dense_resolve, dim3((unsigned)n_heavy), dim3(256), 0, st, list, (u32)n_chunks, qlen, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt,
 			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(),
@@ -841,19 +890,11 @@ int stage1_seed(gsa_ctx *c)
 	// Groups: a new group starts where the sorted PosDiff values jump by more than MaxIndelSize.  With a bitmap of the
 	// occupied PosDiff values that needs no sort: group id = number of group starts at or below a hit's PosDiff (a scan
 	// over the bitmap, stage 2).  The PosDiff-sorted view of the seeds (stage-1 view of the C ABI) is then built on demand.
-	const u64 pd_words = (((u64)(2 * c->G) + (u64)qlen + 2) >> 5) + 2;
-	c->pd_path = n_hits > 0 && c->prm.MaxIndelSize >= 0 && c->prm.MaxIndelSize <= 31 && pd_words <= 64ull * (u64)n_hits + 65536 && !getenv("GSA_NO_PDBITMAP");
-	c->seed_view_ready = false;
-	if (c->pd_path) {
-		const size_t cap0 = c->d_pdbm.cap;
-		if (!dev_ensure<u32>(c, c->d_pdbm, (size_t)pd_words + 2)) return GSA_ERR_NOMEM;
-		if (c->d_pdbm.cap != cap0 || c->pdbm_dirty) GSA_CHECK(c, hipMemsetAsync(c->d_pdbm.p, 0, c->d_pdbm.cap, st));
-		c->pdbm_dirty = true; c->pd_words = (i64)pd_words;
-	}
+	if (int rcp = prepare_pd_bitmap(c, n_hits)) return rcp;
 	if (n_hits > 0) {
 		if (!dev_ensure<u64>(c, c->d_key_a, hcap) || !dev_ensure<u32>(c, c->d_val_a, hcap)) return GSA_ERR_NOMEM;
 		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), (ccap + 2) * sizeof(u32), st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
-		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), qlen, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr);
+		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), qlen_full, s_off, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr);
 	}
 	if (c->profiling) hipEventRecord(c->ev[2], st);
 	u64 lf_steps = 0;
@@ -868,6 +909,7 @@ int stage1_seed(gsa_ctx *c)
 	}
 	c->counters[1] = lf_steps; c->counters[2] = (u64)n_hits; c->counters[3] = (u64)n_hits; c->counters[7] = occ_all;
 	c->n_seeds = n_hits;
+	if (split) return GSA_OK;                 // (the tail of stage 1 runs in gsa_finish_contig, on the hits of all ranges)
 	if (n_hits == 0) { if (c->profiling) { GSA_CHECK(c, hipStreamSynchronize(st)); float ms; hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms; } return GSA_OK; }
 	if (n_hits >= (1ll << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");
 	if (c->pd_path) {
@@ -903,6 +945,32 @@ int seed_view_sort(gsa_ctx *c)
 	if (!c->pd_path) c->ev_pending |= 1;
 	c->seed_view_ready = true;
 	return GSA_OK;
+}
+
+// hits of another GPU's chunk range behind this context's own ones (keys / vals: host or device memory)
+int stage1_import_hits(gsa_ctx *c, const u64 *keys, const u32 *vals, i64 n)
+{
+	if (n <= 0) return GSA_OK;
+	if (c->n_seeds + n >= (1ll << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");
+	const size_t have = (size_t)c->n_seeds, want = have + (size_t)n + 64;
+	if (!dev_grow_keep<u64>(c, c->d_key_a, want, have) || !dev_grow_keep<u32>(c, c->d_val_a, want, have)) return GSA_ERR_NOMEM;
+	GSA_CHECK(c, hipMemcpyAsync(c->d_key_a.as<u64>() + have, keys, (size_t)n * 8, hipMemcpyDefault, c->stream));
+	GSA_CHECK(c, hipMemcpyAsync(c->d_val_a.as<u32>() + have, vals, (size_t)n * 4, hipMemcpyDefault, c->stream));
+	if (c->pd_path) hipLaunchKernelGGL(k_pd_from_keys, dim3(grid_for((size_t)n, 256)), dim3(256), 0, c->stream, n, c->d_key_a.as<u64>() + have, c->qbits, c->d_pdbm.as<u32>());
+	GSA_CHECK(c, hipGetLastError());
+	GSA_CHECK(c, hipStreamSynchronize(c->stream));      // (the caller's buffers are free again)
+	c->n_seeds += n;
+	return GSA_OK;
+}
+
+// the tail of stage 1 once the hits of every chunk range are here
+int stage1_finish_split(gsa_ctx *c)
+{
+	c->counters[2] = c->counters[3] = (u64)c->n_seeds;
+	c->seed_view_ready = false;
+	if (c->n_seeds == 0) return GSA_OK;
+	if (c->pd_path) { c->n_groups = -1; return GSA_OK; }
+	return seed_view_sort(c);
 }
 
 // ---------------------------------------------------------------------------

@@ -135,6 +135,19 @@ typedef int (*gsa_result_fn)(void *user, int32_t contig, const gsa_result *res);
 int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n,
                    gsa_result_fn on_result, void *user);
 
+/* ---- one long contig on several GPUs ---------------------------------------
+ * IdentifyLocalMEM hands 10 000-bp chunks of the contig to whichever thread is free (GSAlign.cpp:61-94) and seeds never
+ * cross a chunk edge, so the seed search of one contig splits by chunk range: every GPU runs gsa_seed_chunks on its range
+ * [chunk_beg, chunk_end) of the SAME contig, the hits (sort key + length/rank word per located hit) travel to the GPU
+ * that owns the contig (gsa_export_hits -> any transport -> gsa_import_hits; buffers may be host or device memory), and
+ * the owner runs the rest -- SeedGrouping ... GenerateFragAlignment -- with gsa_finish_contig.  The result is the one
+ * gsa_align_contig gives (hit order does not matter: the seeds are sorted next). */
+int gsa_seed_chunks(gsa_ctx *ctx, const char *query, int32_t qlen, int32_t chunk_beg, int32_t chunk_end);
+int64_t gsa_hit_count(gsa_ctx *ctx);
+int gsa_export_hits(gsa_ctx *ctx, uint64_t *keys, uint32_t *vals);
+int gsa_import_hits(gsa_ctx *ctx, const uint64_t *keys, const uint32_t *vals, int64_t n);
+int gsa_finish_contig(gsa_ctx *ctx, gsa_result *out);
+
 /* ---- stage-level entry points (what the parity tests drive) --------------
  * gsa_set_query uploads a contig; gsa_run_to(stage) advances the same
  * eight-stage sequence the oracle uses:

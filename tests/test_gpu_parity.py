@@ -250,6 +250,42 @@ def test_align_many_contexts(oracle_built, tmp_path):
     g0.close()
 
 
+@pytest.mark.parametrize("params", [{}, dict(sen=1, clr=50), dict(ind=40)])
+def test_contig_seeded_in_chunk_ranges(oracle_built, tmp_path, params):
+    """SURVEY 8(e) for one long contig: stage 1 on three chunk ranges by three contexts (what three GPUs would do), the hits
+    of the other ranges imported by the owner -- once through host memory, once device to device -- which finishes the
+    contig: identical to the oracle (and to gsa_align_contig on one context)."""
+    refs, qrys = synth.make_pair_fast(1500000, 1, 0.02, seed=59, repeats=True)
+    q = qrys[0][1]
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx, params)
+    o.set_query(q); o.run_to(8); want = o.blocks(with_aln=True); o.close()
+    own = capi.Aligner(idx, **params); a = own.clone(); b = own.clone()
+    a.set_params(**params); b.set_params(**params)
+    n_chunks = (q.size + 9999) // 10000
+    cuts = [0, n_chunks // 3, n_chunks // 3 + 1, n_chunks + 5]          # (a one-chunk range and a range that overshoots the contig)
+    n0 = own.seed_chunks(q, cuts[0], cuts[1]); n1 = a.seed_chunks(q, cuts[1], cuts[2]); n2 = b.seed_chunks(q, cuts[2], cuts[3])
+    k1, v1 = a.export_hits(); own.import_hits(k1, v1)                    # through host memory (any transport)
+    import ctypes
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")                    # (the runtime libgsa_hip.so itself uses)
+    dk, dv = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dk), ctypes.c_size_t(8 * max(n2, 1))) == 0 and hip.hipMalloc(ctypes.byref(dv), ctypes.c_size_t(4 * max(n2, 1))) == 0
+    b.export_hits(dk.value, dv.value)
+    own.import_hits(dk.value, dv.value, n2)                              # device to device (what an RCCL recv buffer is)
+    hip.hipFree(dk); hip.hipFree(dv)
+    own.finish_contig()
+    got = own.blocks_as_dump(with_aln=True)
+    for k, v in want.items():
+        assert np.array_equal(got[k], v), k
+    assert n0 + n1 + n2 == int(own.counters()[3]) and min(n0, n2) > 0
+    # the same context takes whole contigs again afterwards
+    own.align_contig(q); got = own.blocks_as_dump(with_aln=True)
+    for k, v in want.items():
+        assert np.array_equal(got[k], v), k
+    for g in (a, b, own):
+        g.close()
+
+
 def test_two_contexts_share_one_index(oracle_built, tmp_path):
     """gsa_clone: two contexts on one GPU, one device index, driven from two host threads on different contigs at the
     same time -- results identical to the oracle's (and so to a single context's)."""
