@@ -161,6 +161,35 @@ def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup):
                 occ_read=occ_read, recs=recs, n_blocks=n_blocks, n_frags=n_frags, n_aln=n_aln, contigs_per_step=per_step)
 
 
+def measure_split(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup, dev):
+    """--split (BASELINE configs[3]: ONE chr1-sized contig on N GPUs): every rank seeds its chunk range of the same contig
+    (gsa_seed_chunks), the hits go to the owner (shard.exchange_hits: point-to-point over RCCL), the owner chains, extends
+    and holds the result (gsa_finish_contig); the owner rotates with the step.  Strong scaling: the job's bases are counted once."""
+    from gsalign_amd import shard
+    px, idx, refs = build_reference(tmp, name, wl, rank, world)
+    genomes = make_queries(wl, refs, 0)                     # the SAME query contigs on every rank
+    run = Runner(idx, local_rank, 1, wl["params"]); g0 = run.ctx[0]
+    pinned = [g0.pinned_copy(gq[0]) for gq in genomes]
+    n_chunks = [(q.size + 9999) // 10000 for q in pinned]
+
+    def step(s):
+        k = s % len(pinned); owner = s % world
+        b, e = shard.split_chunks(n_chunks[k], world)[rank]
+        g0.seed_chunks(pinned[k], b, e)
+        shard.exchange_hits(g0, owner, device=dev)
+        if rank == owner:
+            g0.finish_contig()
+    for s in range(warmup):
+        step(s)
+    sync(); t0 = time.perf_counter()
+    for s in range(steps):
+        step(s)
+    sync(); t_total = time.perf_counter() - t0
+    bp_per_step = float(np.mean([q.size for q in pinned]))
+    run.close()
+    return dict(t_total=t_total, bp=bp_per_step * steps / world, bp_per_step=bp_per_step, steps=steps)
+
+
 def pmc_traffic(name):
     """PMC traffic per step of the top kernels, from the separate rocprofv3 --pmc passes (tools/pmc_top.sh -> profiles/r02_pmc_<workload>.json)."""
     try:
@@ -287,6 +316,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="contexts (host threads) per GPU working on different contigs")
     ap.add_argument("--extra", default="ecoli,yeast", help="further workloads measured in the same run (short loops); '' = none")
     ap.add_argument("--hwq", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default)")
+    ap.add_argument("--split", action="store_true", help="N > 1 only: ONE contig per step, its seed search sharded by chunk range over the ranks (strong scaling)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo: plumbing checks)")
+    ap.add_argument("--same-gpu", action="store_true", help="plumbing check on a one-GPU box: every rank uses GPU 0 (with --backend gloo)")
     ap.add_argument("--dry", action="store_true", help="no GPU: stub aligner + gloo, checks the launcher and the rank plumbing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bases of one query contig the CPU baseline is timed on")
@@ -304,11 +336,16 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr); sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: libgsa_hip.so has no CPU path", file=sys.stderr); sys.exit(2)
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world); dev = torch.device("cpu")
 
     from gsalign_amd import shard
     tmp = os.environ.get("GSA_BENCH_TMP") or os.path.join(tempfile.gettempdir(), f"gsa_bench_{os.environ.get('MASTER_PORT', 'single')}")
@@ -336,6 +373,16 @@ def main():
         wl["lengths"] = [args.genome]; wl["label"] += f" [reference length overridden: {args.genome}]"
     if args.divergence >= 0:
         wl["div"] = args.divergence; wl["label"] += f" [divergence overridden: {args.divergence}]"
+    if args.split and world > 1 and len(wl["lengths"]) == 1:
+        m = measure_split(args.workload, wl, args, tmp, rank, world, local_rank, sync, args.steps, args.warmup, dev)
+        t_max, total_bp = whole_job(m)
+        if rank == 0:
+            print(json.dumps({"metric": "aligned query Gbp/s (whole node)", "value": total_bp / t_max / 1e9, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": 1000.0 * t_max / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                              "config": {"workload": wl["label"] + "; ONE contig per step, S1 sharded by chunk range over the ranks, hits to the (rotating) owner over RCCL, S2-S7 on the owner",
+                                         "query_bp_per_step": int(m["bp_per_step"]), "parallelism": f"chunk-range shard x{world} of one contig, index replicated"}}))
+        dist.barrier(); dist.destroy_process_group()
+        return
     m = measure(args.workload, wl, args, tmp, rank, world, local_rank, sync, args.steps, args.warmup)
     t_max, total_bp = whole_job(m)
     if world > 1:
