@@ -146,6 +146,46 @@ void Emitter::aln(FILE *fp, const QueryContig &q, ContigResult &r) const
 	}
 }
 
+bool Emitter::dotplot(const std::string &gp_path, const std::string &out_prefix, const QueryContig &q, const ContigResult &r) const
+{
+	static const char *colors[10] = { "red", "blue", "web-green", "dark-magenta", "orange", "yellow", "turquoise", "dark-yellow", "violet", "dark-grey" };
+	if (r.blocks.empty()) return false;
+	const int nchr = (int)idx->chr_len.size();
+	std::vector<int> sum((size_t)nchr, 0);
+	for (const gsa_block &b : r.blocks) if (b.score > 0) sum[(size_t)b.chr] += b.score;
+	std::vector<std::pair<int, int64_t> > top;                          // reference sequences with >= 1000 identical columns, best five
+	for (int i = 0; i < nchr; i++) if (sum[(size_t)i] >= 1000) top.push_back(std::make_pair(i, (int64_t)sum[(size_t)i]));
+	if (top.empty()) return false;
+	std::sort(top.begin(), top.end(), [](const std::pair<int, int64_t> &a, const std::pair<int, int64_t> &b) { return a.second > b.second; });
+	if (top.size() > 5) top.resize(5);
+	FILE *gp = fopen(gp_path.c_str(), "w"); if (!gp) return false;
+	const std::string data = out_prefix + "." + q.name;
+	std::vector<FILE *> fh((size_t)nchr, (FILE *)NULL);
+	for (size_t i = 0; i < top.size(); i++) {
+		const std::string fn = data + "vs" + idx->chr_name[(size_t)top[i].first];
+		fh[(size_t)top[i].first] = fopen(fn.c_str(), "w");
+		if (fh[(size_t)top[i].first]) fprintf(fh[(size_t)top[i].first], "0 0\n0 0\n\n");
+	}
+	fprintf(gp, "set terminal postscript color solid 'Courier' 15\nset output '%s-%s.ps'\nset grid\nset border 1\n", out_prefix.c_str(), q.name.c_str());
+	for (size_t i = 0; i < top.size(); i++) fprintf(gp, "set style line %d lw 4 pt 0 ps 0.5 lc '%s'\n", (int)i + 1, colors[i]);
+	fprintf(gp, "set xrange[1:*]\nset yrange[1:*]\nset xlabel 'Query (%s)'\nset ylabel 'Ref'\n", q.name.c_str());
+	fprintf(gp, "plot ");
+	for (size_t i = 0; i < top.size(); i++) {
+		const std::string &cn = idx->chr_name[(size_t)top[i].first];
+		fprintf(gp, "'%svs%s' title '%s' with lp ls %d%s", data.c_str(), cn.c_str(), cn.c_str(), (int)i + 1, i + 1 != top.size() ? ", " : "\n\n");
+	}
+	for (const gsa_block &b : r.blocks) {
+		if (b.score <= 0 || !fh[(size_t)b.chr]) continue;
+		const gsa_frag &first = r.frags[b.frag_off], &last = r.frags[b.frag_off + b.n_frag - 1];
+		int d, c, g0, g1;
+		idx->coordinate(first.rpos, &d, &c, &g0); idx->coordinate(last.rpos + last.rlen - 1, &d, &c, &g1);
+		fprintf(fh[(size_t)b.chr], "%d %d\n%d %d\n\n", first.qpos + 1, g0, last.qpos + last.qlen, g1);
+	}
+	for (FILE *f : fh) if (f) fclose(f);
+	fclose(gp);
+	return true;
+}
+
 void Emitter::variants(int query_idx, const QueryContig &q, const ContigResult &r)
 {
 	const std::string &ref = idx->ref;

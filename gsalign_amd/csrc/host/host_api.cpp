@@ -52,4 +52,16 @@ int gsah_c_emit_fmt(const char *index_prefix, const char *query_fa, const char *
 	return 0;
 }
 
+// OutputDotplot for one contig: script + data files (no gnuplot run).  Returns 1 if something was written.
+int gsah_c_dotplot(const char *index_prefix, const char *query_fa, int contig, const char *gp_path, const char *out_prefix, gsah_result_cb cb, void *user, char *err)
+{
+	std::string e; HostIndex idx; std::vector<QueryContig> qs;
+	if (!gsah_load_index(index_prefix, idx, e) || !gsah_load_query(query_fa, qs, e) || contig < 0 || contig >= (int)qs.size()) { if (err) { strncpy(err, e.c_str(), 255); err[255] = 0; } return -1; }
+	gsa_result res; memset(&res, 0, sizeof(res));
+	if (cb(user, contig, qs[(size_t)contig].seq.data(), (int)qs[(size_t)contig].seq.size(), &res) != 0) return -2;
+	ContigResult cr; cr.assign(res);
+	Emitter em; em.idx = &idx;
+	return em.dotplot(gp_path, out_prefix, qs[(size_t)contig], cr) ? 1 : 0;
+}
+
 } // extern "C"

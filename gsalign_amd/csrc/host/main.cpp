@@ -54,7 +54,7 @@ static bool first_char_is_header(const char *path)          // CheckInputFile (m
 int main(int argc, char *argv[])
 {
 	gsa_params prm; gsa_default_params(&prm);
-	int threads = 8, fmt = 1, n_ctx_per_gpu = 2; bool vcf = true, allow_dup = true;
+	int threads = 8, fmt = 1, n_ctx_per_gpu = 2; bool vcf = true, allow_dup = true, dotplot = false;
 	std::vector<int> gpus;
 	const char *index_prefix = NULL, *ref_fa = NULL, *query_fa = NULL, *out_prefix = NULL;
 	if (argc == 1 || strcmp(argv[1], "-h") == 0) { usage(argv[0], threads, prm, fmt); return 0; }
@@ -82,7 +82,8 @@ int main(int argc, char *argv[])
 		else if (a == "-o") out_prefix = argv[++i];
 		else if (a == "-gpu" && i + 1 < argc) { for (const char *p = argv[++i]; *p;) { gpus.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; } }
 		else if (a == "-ctx" && i + 1 < argc) { n_ctx_per_gpu = atoi(argv[++i]); if (n_ctx_per_gpu < 1) n_ctx_per_gpu = 1; }
-		else if (a == "-dp" || a == "-d" || a == "-debug") { /* dot-plots / debug output: not supported, ignored */ }
+		else if (a == "-dp") dotplot = true;
+		else if (a == "-d" || a == "-debug") { /* debug printers: not reproduced */ }
 		else if ((a == "-gp" || a == "-obr") && i + 1 < argc) ++i;
 		else fprintf(stderr, "Warning! Unknow parameter: %s\n", argv[i]);
 	}
@@ -103,6 +104,18 @@ int main(int argc, char *argv[])
 	if (!gsah_load_index(prefix, idx, err)) { fprintf(stderr, "\n\nError! Please check your input! (%s)\n", err.c_str()); return 1; }
 	fprintf(stderr, "\tLoad the reference sequences (%d %s)\n", (int)idx.chr_len.size(), idx.chr_len.size() > 1 ? "chromosomes" : "chromosome");
 
+	// FindGnuPlotPath (main.cpp:169-191): -dp needs a gnuplot binary; without one the reference plots nothing either
+	std::string gnuplot;
+	if (dotplot) {
+		const char *path = getenv("PATH");
+		for (std::string p = path ? path : ""; !p.empty();) {
+			const size_t k = p.find(':'); const std::string dir = p.substr(0, k);
+			FILE *fp = fopen((dir + "/gnuplot").c_str(), "r");
+			if (fp) { fclose(fp); gnuplot = dir + "/gnuplot"; break; }
+			if (k == std::string::npos) break;
+			p = p.substr(k + 1);
+		}
+	}
 	gsa_index_view view; idx.fill_view(&view);
 	if (gpus.empty()) gpus.push_back(0);
 	// one context per GPU owns that device's copy of the index; the others borrow it (gsa_clone)
@@ -147,6 +160,14 @@ int main(int argc, char *argv[])
 		if (fmt == 1) { FILE *fp = fopen(maf.c_str(), ci == 0 ? "w" : "a"); if (fp) { em.maf(fp, ci == 0, qs[ci], cr); fclose(fp); } }
 		if (fmt == 2) { FILE *fp = fopen(aln.c_str(), ci == 0 ? "w" : "a"); if (fp) { em.aln(fp, qs[ci], cr); fclose(fp); } }
 		if (vcf) em.variants((int)ci, qs[ci], cr);
+		if (dotplot && !gnuplot.empty()) {                               // GSAlign.cpp:546: only when gnuplot was found (main.cpp:324)
+			const std::string gp = std::string(out_prefix) + ".gp";
+			if (em.dotplot(gp, out_prefix, qs[ci], cr)) {
+				fprintf(stderr, "\t\tGenerate dotplot for query sequence (%s-%s.ps)\n", out_prefix, qs[ci].name.c_str());
+				if (system((gnuplot + " " + gp).c_str()) != 0) fprintf(stderr, "\t\tgnuplot failed\n");
+				if (system(("rm " + std::string(out_prefix) + "." + qs[ci].name + "*").c_str()) != 0) { /* nothing to remove */ }
+			}
+		}
 		ContigResult().blocks.swap(cr.blocks); std::vector<gsa_frag>().swap(cr.frags); std::string().swap(cr.aln1); std::string().swap(cr.aln2);
 	}
 	if (n_aln > 0) fprintf(stderr, "\tAlignment#=%d (total alignment length=%lld) ANI=%.2f%%, unique alignment#=%d\n", (int)n_aln, tot_len, 100 * (1.0 * tot_match / tot_len), (int)(n_aln - n_dup));

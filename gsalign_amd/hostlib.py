@@ -67,3 +67,20 @@ def emit(index_prefix: str, query_fa: str, maf_path: str, vcf_path: str, referen
                                 1 if allow_dup else 0, fmt, RESULT_CB(cb), None, err)
     if rc != 0:
         raise RuntimeError(f"gsah_c_emit -> {rc}: {err.value.decode()}")
+
+
+def dotplot(index_prefix: str, query_fa: str, contig: int, gp_path: str, out_prefix: str, per_contig) -> bool:
+    """OutputDotplot (DotPloting.cpp:10-71) for one contig: gnuplot script + data files, gnuplot itself is not run."""
+    keep: list = []
+
+    def cb(user, ci, seq, ln, out):
+        s = np.frombuffer(C.string_at(seq, ln), dtype=np.uint8)
+        r = result_from_dump(per_contig(ci, s), keep)
+        C.memmove(out, C.byref(r), C.sizeof(capi.Result))
+        return 0
+
+    err = C.create_string_buffer(256)
+    rc = load().gsah_c_dotplot(index_prefix.encode(), query_fa.encode(), contig, gp_path.encode(), out_prefix.encode(), RESULT_CB(cb), None, err)
+    if rc < 0:
+        raise RuntimeError(f"gsah_c_dotplot -> {rc}: {err.value.decode()}")
+    return rc == 1
