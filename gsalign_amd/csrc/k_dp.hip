@@ -195,7 +195,8 @@ __global__ void __launch_bounds__(64 * TINY_WAVES) k_dp_tiny(i32 n_jobs, const i
 // bounded (2 s of wall clock): a launch that trips it is repeated job by job (gsa_align_contig, dp_safe).
 // ---------------------------------------------------------------------------
 struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; };
-#define DP_TILE_ROWS 160        // local diagonals of a traceback tile (64 diagonal steps need 128)
+#define DP_TILE_ROWS 160        // local diagonals of a traceback tile (64 diagonal steps need 128); a multiple of 8
+#define DP_STRIPE_BYTES(M) ((((size_t)(M) + 63 + 7) >> 3) << 8)      // (M + 63) anti-diagonals of 64 nibbles, in blocks of eight
 #define DP_TILE_SLACK 16        // the prefetched tile reaches this far past the predicted entry
 #ifndef DP_G
 #define DP_G 8               // boundary rows per hand-off block (4, 8 or 16)
@@ -255,12 +256,16 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const int p = ((int)bid - sj.first_block) * WPB + wave, m = sj.m, n = sj.n, P = sj.P;
 	const uint8_t *s1 = pool1 + off1[sj.job], *s2 = pool2 + off2[sj.job];
-	const size_t pitch = (size_t)(m + 63) * 64;                         // direction bytes of one stripe
+	const size_t pitch = (size_t)DP_STRIPE_BYTES(m);                    // direction nibbles of one stripe: 256 bytes per eight anti-diagonals
 	const int mpad64 = (m + 64 + 63) & ~63;                             // C1 is readable one 64-row block past the end
 	uint8_t *dir = dirbase + sj.diroff;
 	u32 *bnd_in = bndbase + sj.bndoff + (size_t)(p - 1) * m, *bnd_out = bndbase + sj.bndoff + (size_t)p * m;
-	for (int t = threadIdx.x; t < m; t += 64 * WPB) C1[t] = (int8_t)(gsa_nt4(s1[t]) << 2);      // pre-multiplied: bit offset into the score table
-	for (int t = m + threadIdx.x; t < mpad64; t += 64 * WPB) C1[t] = 16;
+	// C1[64 + j] = 4 x nt4 code of reference row j (bit offset into the score table), 16 = "N" for the 64 rows in front and
+	// the rows behind: lane l reads its row rl - l of every anti-diagonal straight from here (one ds_read_u8 per cell; the
+	// DPP chain that carried the code up one lane per diagonal cost three VALU instructions per diagonal)
+	for (int t = threadIdx.x; t < 64; t += 64 * WPB) C1[t] = 16;
+	for (int t = threadIdx.x; t < m; t += 64 * WPB) C1[64 + t] = (int8_t)(gsa_nt4(s1[t]) << 2);
+	for (int t = m + threadIdx.x; t < mpad64; t += 64 * WPB) C1[64 + t] = 16;
 	// WPB > 1: the stripes of one workgroup hand their boundary column over through LDS (same granules, tag 0 = not yet)
 	u32 *lds_bnd = (u32 *)(C1 + lds_c1);
 	if (WPB > 1) for (int t = threadIdx.x; t < (WPB - 1) * lds_rows; t += 64 * WPB) lds_bnd[t] = 0;
@@ -279,9 +284,7 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	if (p >= P) return;                                 // (a workgroup's spare waves only helped to stage the fragment)
 	const int nl = m + Wp - 1;
 	DPT(const unsigned long long T0c = wall_clock64();)
-	int wref = 16;                                      // 4 * reference code of my row on the current diagonal (travels one lane up per diagonal)
-	int creg = 16;                                      // lane q: 4 * code of reference row (rl & ~63) + q
-	uint8_t *dirp = dir + (size_t)p * pitch;
+	u32 *dirp = (u32 *)(dir + (size_t)p * pitch);
 	// boundary granules are fetched ONE BLOCK AHEAD (8 rows per block) so their L2 latency overlaps the block before
 	if (p > 0) {
 		const int row = (lane & (DP_G - 1)) < m ? (lane & (DP_G - 1)) : m - 1;
@@ -290,12 +293,12 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	asm volatile("" :: "v"(gnext));                      // the first prefetch is complete before the loop: inside it, waits then only count stores issued after a prefetch
 	const int jjoff = lane < Wp ? lane : 0x40000000;    // lanes beyond the stripe never become valid
 	const bool pub_stripe = p < P - 1;                  // (then Wp == 64 and lane 63 owns the boundary column)
-	int dlast = 0;
+	int dlast = 0, dacc = 0;
 	int pk = 0;                                         // x | v << 8 of my column after the current diagonal
 	int hist = 0;                                       // lane 63 - q: pk of lane 63 q diagonals ago (boundary rows travel one lane down per diagonal)
 	// one anti-diagonal; K2 is the position inside the 16-row block (a literal in the unrolled body)
 #define DP_LOADG(MODE, ROW) ((MODE) == 2 ? __hip_atomic_load(&lin[ROW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(&bnd_in[ROW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-#define DP_STEP(K2, MODE)                                                                                            \
+#define DP_STEP(K2, MODE, WREF)                                                                                      \
 	{                                                                                                           \
 		const int rl_ = rl0 + (K2);                                                                             \
 		if (((K2) & (DP_G - 1)) == 0) {                                                                                  \
@@ -319,12 +322,11 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 				gnext = DP_LOADG(MODE, rown);                                                                     \
 			}                                                                                                   \
 		}                                                                                                       \
-		wref = wave_shr1(wref, __builtin_amdgcn_readlane(creg, cbase + (K2)));                                  \
 		const int packed = wave_shr1(pk, __builtin_amdgcn_readlane((int)bin, (K2) & (DP_G - 1)));                            \
 		const int jj = rl_ - jjoff;                                                                             \
 		if ((unsigned)jj < (unsigned)m) {                                                                       \
 			const int x1 = packed & 0xff, v1 = packed >> 8;                                                     \
-			int z = (int)__builtin_amdgcn_ubfe(tbl, (u32)wref, 4u);                                             \
+			int z = (int)__builtin_amdgcn_ubfe(tbl, (u32)(WREF), 4u);                                           \
 			int a = x1 + v1, b = y + u;                                                                         \
 			int d = a > z ? 1 : 0; z = z > a ? z : a;                                                           \
 			if (b > z) d = 2;                                                                                   \
@@ -332,13 +334,16 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 			z = z < 7 ? z : 7;                                                                                  \
 			const int un = z - v1, vn = z - u;                                                                  \
 			z -= 2; a -= z; b -= z;                                                                             \
-			a = a > 0 ? a : 0; b = b > 0 ? b : 0;       /* x, y; flag bits 3, 4 = "is positive" = min(., 1) */           \
-			d |= ((a < 1 ? a : 1) << 3) | ((b < 1 ? b : 1) << 4);                                               \
+			a = a > 0 ? a : 0; b = b > 0 ? b : 0;       /* x, y; the "x / y is positive" flags (0x08, 0x10 of ksw2) sit at bits 2, 3 */ \
+			d |= ((a < 1 ? a : 1) << 2) | ((b < 1 ? b : 1) << 3);                                               \
 			u = un; y = b; pk = a | (vn << 8); dlast = d;                                                       \
 		}                                                                                                       \
-		/* stored by every lane (slots of cells outside the matrix are never read): a straight-line store    \
-		   keeps the vmcnt bookkeeping exact, so waiting for a boundary prefetch does not drain the stores */ \
-		DPX_STORE(rowp[((K2) << 6) + lane] = (uint8_t)dlast;)                                                   \
+		/* direction NIBBLES, eight anti-diagonals per dword: lane l keeps the flags of its cells on diagonals 8b .. 8b+7 in   \
+		   one register and the wave stores 256 bytes per eight diagonals (a byte store per diagonal kept the address unit \
+		   busier than the ALU: -25 % kernel time measured without them).  Stored by every lane, cells outside the matrix   \
+		   are never read; straight-line, so the vmcnt bookkeeping of the boundary prefetch stays exact */ \
+		dacc = (int)__builtin_amdgcn_alignbit((u32)dlast, (u32)dacc, 4);                                          \
+		if (((K2) & 7) == 7) { DPX_STORE(rowp[(((K2) >> 3) << 6) + lane] = (u32)dacc;) }                          \
 		hist = __builtin_amdgcn_update_dpp(pk, hist, 0x130, 0xf, 0xf, false);      /* wave_shl:1, lane 63 takes pk */ \
 		if (((K2) & (DP_G - 1)) == DP_G - 2 && pub_stripe && rl_ >= 62 + DP_G) {                                                       \
 			/* rows rl_-62-DP_G .. rl_-63 of the boundary column are complete: one store of DP_G tagged granules */ \
@@ -352,14 +357,17 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	// (two copies of the loop: stripe 0 has no boundary loads in flight, and keeping it apart keeps its waits off the stores)
 #define DP_LOOP(MODE)                                                                                           \
 	for (int rl0 = 0; rl0 < nl; rl0 += 16) {                                                                    \
-		if ((rl0 & 63) == 0) creg = C1[rl0 + lane];                                                             \
-		const int cbase = rl0 & 63;                                                                             \
-		uint8_t *rowp = dirp + ((size_t)rl0 << 6);                                                              \
+		const int8_t *crow = C1 + 64 + rl0 - lane;             /* my reference row on diagonal rl0 */              \
+		u32 *rowp = dirp + ((size_t)(rl0 >> 3) << 6);                                                           \
 		if (rl0 + 16 <= nl) {                                                                                   \
-			DP_STEP(0, MODE) DP_STEP(1, MODE) DP_STEP(2, MODE) DP_STEP(3, MODE) DP_STEP(4, MODE) DP_STEP(5, MODE) DP_STEP(6, MODE) DP_STEP(7, MODE) \
-			DP_STEP(8, MODE) DP_STEP(9, MODE) DP_STEP(10, MODE) DP_STEP(11, MODE) DP_STEP(12, MODE) DP_STEP(13, MODE) DP_STEP(14, MODE) DP_STEP(15, MODE) \
+			int w16[16];                                                                                        \
+			_Pragma("unroll") for (int k2 = 0; k2 < 16; k2++) w16[k2] = crow[k2];                                 \
+			DP_STEP(0, MODE, w16[0]) DP_STEP(1, MODE, w16[1]) DP_STEP(2, MODE, w16[2]) DP_STEP(3, MODE, w16[3]) DP_STEP(4, MODE, w16[4]) DP_STEP(5, MODE, w16[5]) DP_STEP(6, MODE, w16[6]) DP_STEP(7, MODE, w16[7]) \
+			DP_STEP(8, MODE, w16[8]) DP_STEP(9, MODE, w16[9]) DP_STEP(10, MODE, w16[10]) DP_STEP(11, MODE, w16[11]) DP_STEP(12, MODE, w16[12]) DP_STEP(13, MODE, w16[13]) DP_STEP(14, MODE, w16[14]) DP_STEP(15, MODE, w16[15]) \
 		} else {                                                                                                \
-			for (int k2 = 0; rl0 + k2 < nl; k2++) DP_STEP(k2, MODE)                                            \
+			for (int k2 = 0; rl0 + k2 < nl; k2++) DP_STEP(k2, MODE, crow[k2])                                      \
+			/* the last, partial dword of the stripe */                                                         \
+			if (nl & 7) { DPX_STORE(dirp[((size_t)(nl >> 3) << 6) + lane] = (u32)dacc >> (4 * (8 - (nl & 7)));) }   \
 		}                                                                                                       \
 	}
 	if (p == 0) { DP_LOOP(0) } else if (WPB > 1 && wave > 0) { DP_LOOP(2) } else { DP_LOOP(1) }
@@ -395,9 +403,12 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	// it will enter the stripe to the left near row j - (lc + 1); those diagonals (+-DP_TILE_SLACK for indels on the way)
 	// are loaded into registers now and only written to LDS when the walker gets there.  A wrong guess costs nothing but
 	// the load: the tile is then fetched the plain way.
-	uint4 pf[DP_TILE_ROWS * 4 / 64];
+	// (a tile = DP_TILE_ROWS / 8 blocks of eight diagonals = 5 KB; block-aligned)
+	constexpr int TB_BLKS = DP_TILE_ROWS / 8, TB_VEC = TB_BLKS * 16 / 64;
+	uint4 pf[TB_VEC];
 	int pf_sp = -1, pf_lo = 0, pf_hi = -1;
 	const int rl_max = m - 1 + 63;                                      // last local diagonal of a stripe
+	const u32 *tile32 = (const u32 *)tile;
 	while (i >= 0 && j >= 0) {
 		i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);
 		// tile: stripe sp, local diagonals rl_lo .. rl_hi
@@ -409,25 +420,26 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 			rl_lo = pf_lo;
 			DPT(nrun += 1 << 16;)
 #pragma unroll
-			for (int q2 = 0; q2 < DP_TILE_ROWS * 4 / 64; q2++) dst[q2 * 64 + lane] = pf[q2];
+			for (int q2 = 0; q2 < TB_VEC; q2++) dst[q2 * 64 + lane] = pf[q2];
 		} else {
-			rl_lo = rl_hi - (DP_TILE_ROWS - 1) > 0 ? rl_hi - (DP_TILE_ROWS - 1) : 0;
-			const uint4 *src = (const uint4 *)(dir + (size_t)sp * pitch + ((size_t)rl_lo << 6));
-			const int nvec = (rl_hi - rl_lo + 1) * 4;
+			const int b_hi = rl_hi >> 3, b_lo = b_hi - (TB_BLKS - 1) > 0 ? b_hi - (TB_BLKS - 1) : 0;
+			rl_lo = b_lo << 3;
+			const uint4 *src = (const uint4 *)(dir + (size_t)sp * pitch + ((size_t)b_lo << 8));
+			const int nvec = (b_hi - b_lo + 1) * 16;
 #pragma unroll
-			for (int q2 = 0; q2 < DP_TILE_ROWS * 4 / 64; q2++) { const int id = q2 * 64 + lane; if (id < nvec) dst[id] = src[id]; }
+			for (int q2 = 0; q2 < TB_VEC; q2++) { const int id = q2 * 64 + lane; if (id < nvec) dst[id] = src[id]; }
 		}
 		pf_sp = -1;
 		{
 			const int jp = j - ((i & 63) + 1);
 			if (sp > 0 && jp >= 0) {
 				int hi = jp + 63 + DP_TILE_SLACK; hi = hi < rl_max ? hi : rl_max;
-				const int lo = hi - (DP_TILE_ROWS - 1) > 0 ? hi - (DP_TILE_ROWS - 1) : 0;
-				const uint4 *src = (const uint4 *)(dir + (size_t)(sp - 1) * pitch + ((size_t)lo << 6));
-				const int nvec = (hi - lo + 1) * 4;
+				const int pb_hi = hi >> 3, pb_lo = pb_hi - (TB_BLKS - 1) > 0 ? pb_hi - (TB_BLKS - 1) : 0;
+				const uint4 *src = (const uint4 *)(dir + (size_t)(sp - 1) * pitch + ((size_t)pb_lo << 8));
+				const int nvec = (pb_hi - pb_lo + 1) * 16;
 #pragma unroll
-				for (int q2 = 0; q2 < DP_TILE_ROWS * 4 / 64; q2++) { const int id = q2 * 64 + lane; pf[q2] = src[id < nvec ? id : 0]; }
-				pf_sp = sp - 1; pf_lo = lo; pf_hi = hi;
+				for (int q2 = 0; q2 < TB_VEC; q2++) { const int id = q2 * 64 + lane; pf[q2] = src[id < nvec ? id : 0]; }
+				pf_sp = sp - 1; pf_lo = pb_lo << 3; pf_hi = (pb_hi << 3) + 7 < rl_max ? (pb_hi << 3) + 7 : rl_max;
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -442,7 +454,8 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 			if (lc < 0 || rl < rl_lo) break;                       // left the tile: reload
 			const int lc2 = lc + dlc, rl2 = rl + drl;
 			const bool valid = lane < 3 * DP_LOOK && lc2 >= 0 && rl2 >= rl_lo && rl2 - lc2 >= 0;
-			const u32 tmp = valid ? tile[((rl2 - rl_lo) << 6) + lc2] : 0xffu;
+			u32 tmp = 0xffu;
+			if (valid) { const u32 nb = (tile32[(((rl2 - rl_lo) >> 3) << 6) + lc2] >> ((rl2 & 7) << 2)) & 15u; tmp = (nb & 3u) | ((nb & 0xCu) << 1); }      // back to ksw2's flag byte
 			const u32 cur = (u32)__builtin_amdgcn_readfirstlane((int)tmp);
 			// the automaton of ksw_backtrack (:38-52) for the current cell ...
 			int S = state;
@@ -546,14 +559,14 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		auto it = std::stable_partition(large.begin(), large.end(), [](const LgJob &g) { return g.m > DP_CLASS_M; });
 		n_hi = (size_t)(it - large.begin());
 	}
-	for (const LgJob &g : large) if (((g.m + 64 + 63) & ~63) > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 153600 bases");
+	for (const LgJob &g : large) if (((g.m + 64 + 63) & ~63) + 64 > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 153600 bases");
 	const i64 budget = 12ll << 30;
 	size_t first = 0;
 	while (first < large.size()) {
 		// descriptors are staged in pinned memory: the upload is asynchronous
 		size_t cnt = 0;
 		if (c->dp_safe) cnt = 1;      // (retry after a hand-off time-out: one job per launch, every stripe of it resident at once)
-		else { size_t l = first; i64 db = 128; while (l < large.size()) { const i64 cells = (((i64)large[l].n + 63) / 64) * ((i64)large[l].m + 63) * 64; if (l > first && db + cells > budget) break; db += cells + 128; l++; } cnt = l - first; }
+		else { size_t l = first; i64 db = 128; while (l < large.size()) { const i64 cells = (((i64)large[l].n + 63) / 64) * (i64)DP_STRIPE_BYTES(large[l].m); if (l > first && db + cells > budget) break; db += cells + 128; l++; } cnt = l - first; }
 		// (the early launch and a late one may be in flight together: each has its own table)
 		DevBuf &psj = err_slot == M_DPERR3 ? c->p_sj_early : c->p_sj;
 		// the one or two segments of this batch: [first, split) above the class limit, [split, first + cnt) below
@@ -563,11 +576,11 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		for (Seg &sg : seg) {
 			sg.mmax = 1;
 			for (size_t k = sg.b; k < sg.e; k++) if (large[k].m > sg.mmax) sg.mmax = large[k].m;
-			sg.mpad = (sg.mmax + 64 + 63) & ~63;
+			sg.mpad = ((sg.mmax + 64 + 63) & ~63) + 64;      // + the 64 "N" rows in front (see the kernel)
 			sg.wpb = sg.mmax <= DP_LDS_M ? 4 : 1;      // reference fragments up to DP_LDS_M bases: four stripes per workgroup, boundary columns through LDS
 			sg.lds_rows = (sg.mmax + 15) & ~15;
 			sg.dyn_lds = (size_t)sg.mpad + (sg.wpb > 1 ? (size_t)(sg.wpb - 1) * sg.lds_rows * 4 : 0);
-			if (sg.dyn_lds < (size_t)DP_TILE_ROWS * 64) sg.dyn_lds = (size_t)DP_TILE_ROWS * 64;      // (the traceback tile lives in the same bytes)
+			if (sg.dyn_lds < (size_t)DP_TILE_ROWS * 32) sg.dyn_lds = (size_t)DP_TILE_ROWS * 32;      // (the traceback tile -- nibbles -- lives in the same bytes)
 			for (size_t k = sg.b; k < sg.e; k++) nb_ub += (size_t)(((large[k].n + 63) / 64 + sg.wpb - 1) / sg.wpb);
 		}
 		if (!pin_ensure<char>(c, psj, (cnt + 1) * sizeof(StripeJob) + (nb_ub + 2) * 4)) return GSA_ERR_NOMEM;
@@ -578,7 +591,7 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 			sg.b2j = b2j_all + b2j_used; sg.nblocks = 0;
 			for (size_t k = sg.b; k < sg.e; k++) {
 				const LgJob &g = large[k];
-				const i64 cells = (((i64)g.n + 63) / 64) * ((i64)g.m + 63) * 64;   // stripe-local direction bytes
+				const i64 cells = (((i64)g.n + 63) / 64) * (i64)DP_STRIPE_BYTES(g.m);   // stripe-local direction nibbles
 				StripeJob s; s.job = g.job; s.m = g.m; s.n = g.n; s.P = (g.n + 63) / 64;
 				s.diroff = dbytes; dbytes += cells + 128;
 				s.bndoff = bwords; bwords += (i64)(s.P - 1) * g.m;
