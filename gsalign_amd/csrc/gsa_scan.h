@@ -65,6 +65,9 @@ __device__ __forceinline__ i32 lb_tile_prefix(const LbArgs &lb, int comp, int ti
 	return s_bcast[comp];
 }
 
+// a store that the finish() hook of a pass (run by whichever workgroup is through last, possibly on another XCD) will read
+__device__ __forceinline__ void lb_pub(i32 *p, i32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Generic fused pass over i in [0, n):  v = op.value(i, k)  (NV components, k < NV),
 // ex = exclusive prefix sums, then op.emit(i, v, ex);  op.done(totals) once, by the thread
 // that owns the last element (or thread 0 of tile 0 when n == 0).
@@ -125,12 +128,17 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 	// emitted is visible to it.  Used to put counts and list heads into pinned memory for the host without another launch.
 	if constexpr (lb_has_finish<Op>::value) {
 		__shared__ int s_last;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (every wave: its lb_pub stores are done before the tile counts itself)
 		__syncthreads();
 		if (tid == 0) {
-			__threadfence();
-			const u32 t = atomicAdd(lb.finished, 1u);
+			// No agent-scope fence here: on this part that is a write-back of the XCD's whole L2 per TILE (thousands per pass,
+			// while the DP kernels beside it keep the L2s full of dirty direction bytes).  Instead, what finish() reads is
+			// written with lb_pub() -- agent-scope atomic stores, coherent across the XCDs' L2s by themselves -- and is
+			// complete (vmcnt) before this tile counts itself: the barrier above made every wave wait for its stores.
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			const u32 t = __hip_atomic_fetch_add(lb.finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			s_last = t == gridDim.x - 1 ? 1 : 0;
-			if (s_last) { *lb.finished = 0; __threadfence(); }
+			if (s_last) __hip_atomic_store(lb.finished, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		__syncthreads();
 		if (s_last) op.finish(tid);

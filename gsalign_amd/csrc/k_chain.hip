@@ -523,10 +523,10 @@ struct OpEarlyGaps {
 		const i32 qp = q[s] + len[s]; const i64 rp = r[s] + len[s];
 		const i32 qg = q[s + 1] - qp, rg = (i32)(r[s + 1] - rp);
 		const i32 e = ex[0];
-		e_list[3 * e] = e; e_list[3 * e + 1] = rg; e_list[3 * e + 2] = qg;
+		lb_pub(&e_list[3 * e], e); lb_pub(&e_list[3 * e + 1], rg); lb_pub(&e_list[3 * e + 2], qg);      // (finish() reads the list)
 		off1[e] = rp; off2[e] = qp; opsoff[e] = ex[1];
 	}
-	__device__ void done(const i32 *t) const { mail[M_NEARLY] = t[0]; mail[M_EOPS] = t[1]; mail[M_DPERR3] = 0; }
+	__device__ void done(const i32 *t) const { lb_pub(&mail[M_NEARLY], t[0]); lb_pub(&mail[M_EOPS], t[1]); lb_pub(&mail[M_DPERR3], 0); }
 	// the last tile puts the two counts and the head of the list into pinned memory: the host launches from there
 	i32 *h_early; i32 h_cap;
 	__device__ void finish(int tid) const

@@ -241,8 +241,9 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	// waves issue ahead of whatever else shares the SIMD.  The mass of smaller jobs behind them does not get that: on a
 	// 50 Mb contig they are 10 000 workgroups, and at raised priority they starve the record / small-DP path beside them
 	// (its passes ran 5-10x slower), which is the longer path there.
-	__shared__ u32 s_bid;
+	__shared__ u32 s_bid, s_tick;
 	if (threadIdx.x == 0) {
+		s_tick = 0;
 		const u32 tk = __hip_atomic_fetch_add(&ctr[tick_slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (tk == gridDim.x - 1) __hip_atomic_store(&ctr[tick_slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // last ticket of this launch: clean for the next one
 		s_bid = tk;
@@ -384,16 +385,34 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	}
 	DPT(if (p == 0 && lane == 0) ctr[sj.ctr + 40] = (u32)(wall_clock64() - T0c); if (p == P - 1 && lane == 0) ctr[sj.ctr + 41] = (u32)(wall_clock64() - T0c);)
 	// ---- ticket: the last stripe to finish does the traceback ----
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	// A job whose stripes all sit in THIS workgroup (n <= 64 WPB: 14 of the 22 thousand striped jobs of a human-sized contig)
+	// synchronises at workgroup scope with an LDS ticket; agent scope -- stripes in workgroups on other XCDs, whose L2s are not
+	// coherent with each other -- means an L2 write-back per stripe and an invalidate in front of the traceback.
+	// Longer jobs: the stripes of a workgroup first count themselves in LDS, only the last one of each workgroup pays the
+	// agent-scope release and draws the job's global ticket (one per workgroup instead of one per stripe).
+	const bool one_wg = WPB > 1 && P <= WPB;
+	const int first_p = ((int)bid - sj.first_block) * WPB;                 // stripes of this workgroup: first_p .. first_p + mine - 1
+	const int mine = P - first_p < WPB ? P - first_p : WPB, n_wg = (P + WPB - 1) / WPB;
 	u32 ticket = 0;
-	if (lane == 0) ticket = __hip_atomic_fetch_add(&ctr[sj.ctr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	ticket = (u32)__builtin_amdgcn_readfirstlane((int)ticket);
-	if ((int)ticket != P - 1) return;
+	if (WPB > 1) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (lane == 0) ticket = __hip_atomic_fetch_add(&s_tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		ticket = (u32)__builtin_amdgcn_readfirstlane((int)ticket);
+		if ((int)ticket != mine - 1) return;
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+	}
+	if (!one_wg) {
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (lane == 0) ticket = __hip_atomic_fetch_add(&ctr[sj.ctr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		ticket = (u32)__builtin_amdgcn_readfirstlane((int)ticket);
+		if ((int)ticket != (WPB > 1 ? n_wg : P) - 1) return;
+		if (lane == 0) ctr[sj.ctr] = 0;                                     // (nobody else looks again: the counters stay clean for the next launch)
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	}
 	DPX_TB(if (lane == 0) ops_len[sj.job] = 0; return;)
-	if (lane == 0) ctr[sj.ctr] = 0;                                     // (nobody else looks again: the counters stay clean for the next launch)
 	DPT(const unsigned long long T1c = wall_clock64(); int ntile = 0, nrun = 0;)
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	uint8_t *rev = revbase + ops_off[sj.job], *op = ops + ops_off[sj.job];
 	int i = n - 1, j = m - 1, state = 0, k = 0;
 	// lane l looks at the cell e = l % 21 steps ahead along direction g = l / 21 (0: M, 1: D, 2: I)
@@ -502,13 +521,13 @@ struct OpClassify {
 	{
 		if (j >= mail[M_NJOB]) return;
 		const i32 m = len1[j], n = len2[j];
-		if (m <= 0 || n <= 0) mail[M_DPERR] = 2;
+		if (m <= 0 || n <= 0) lb_pub(&mail[M_DPERR], 2);
 		jlarge[j] = v[0];
-		if (v[0]) { i32 *e = lg + 3 * (size_t)ex[0]; e[0] = (i32)j; e[1] = m; e[2] = n; }
+		if (v[0]) { i32 *e = lg + 3 * (size_t)ex[0]; lb_pub(&e[0], (i32)j); lb_pub(&e[1], m); lb_pub(&e[2], n); }      // (finish() reads the list)
 		else if (v[1]) order_tiny[ex[1]] = (i32)j;
 		else order[j - ex[0] - ex[1]] = (i32)j;
 	}
-	__device__ void done(const i32 *t) const { mail[M_NLARGE] = t[0]; mail[M_NTINY] = t[1]; }
+	__device__ void done(const i32 *t) const { lb_pub(&mail[M_NLARGE], t[0]); lb_pub(&mail[M_NTINY], t[1]); }
 	// the last tile puts the mailbox and the head of the large-job list into pinned memory (the host launches from there)
 	i32 *h_out; i32 h_cap;
 	__device__ void finish(int tid) const

@@ -340,9 +340,10 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	// the workgroup that is through last puts the counters into pinned memory (the host waits for this kernel, nothing
 	// else) and leaves them at zero for the next contig
 	__shared__ int s_last;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (every wave: its counter atomics are done before the workgroup counts itself)
 	__syncthreads();
 	if (j == 0) {
-		__threadfence();
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (counters are device atomics; an agent-scope fence is an L2 write-back per workgroup here)
 		s_last = atomicAdd((unsigned long long *)&cnt[CNT_DONE], 1ull) == (unsigned long long)gridDim.x - 1 ? 1 : 0;
 	}
 	__syncthreads();
@@ -526,7 +527,8 @@ __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ c
 		cand_cnt[chunk] = s_n < cand_cap ? s_n : cand_cap; chunk_hits[chunk] = (i32)s_hits; if (slot == 0) chunk_hits[n_total_chunks] = 0;
 		atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_n);
 		if (s_hits) atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)s_hits);
-		__threadfence();
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (counters are device atomics; an agent-scope fence is an L2 write-back per workgroup here)
 		s_last = atomicAdd((unsigned long long *)&cnt[CNT_DONE], 1ull) == (unsigned long long)gridDim.x - 1 ? 1 : 0;
 	}
 	__syncthreads();
