@@ -343,13 +343,16 @@ int stage78_extend(gsa_ctx *c)
 	hipStream_t sc = c->stream_aux[2];
 	if (!pin_ensure<gsa_frag>(c, c->p_frags, (size_t)nfu + 1)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipEventRecord(c->ev[19], st)); GSA_CHECK(c, hipStreamWaitEvent(sc, c->ev[19], 0));
-	GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, (size_t)nfu * sizeof(gsa_frag), hipMemcpyDeviceToHost, sc));
 	ENS(uint8_t, d_ops, c->span_ub + 64);
 	ENS(i32, d_flag, nfu + 2); ENS(u32, d_scan, nfu + 2); ENS(u32, d_flag2, nfu + 2); ENS(i32, bl_alnlen, nfb + 1); ENS(i32, bl_score, nfb + 1);
 	Ksw2Launch kl;
 	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub, &kl,
 	                 nullptr, nullptr));
 	// (run_ksw2_jobs read the mailbox: the record count and the size of the string pools are known now)
+	// The records leave only now, behind the host's look at the size classes: a 166 MB copy (a 250 Mb contig) in flight keeps
+	// the link busy for 3 ms, and the few bytes the classification pass stores into pinned memory for that look queued
+	// behind it -- the small-DP kernels started 3 ms late.
+	GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, (size_t)nfu * sizeof(gsa_frag), hipMemcpyDeviceToHost, sc));
 	const i32 *hm = c->p_dp.as<i32>();
 	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN]; c->n_large = kl.nlarge;
 	{ static const bool dbg = getenv("GSA_DEBUG") != nullptr; if (dbg) fprintf(stderr, "[gsa] DP jobs %d (small+tiny %d), striped: %d listed early at stage 2, %d launched late\n", kl.n, kl.nsmall, c->n_early, kl.nlarge); }

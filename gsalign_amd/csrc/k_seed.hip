@@ -73,6 +73,25 @@ __device__ __forceinline__ int text_match32(u32 r0, u32 r1, u32 r2, i64 tp, i64 
 // matches become seeds.  Query (2-bit packed + N bitmap), memo, exits and on-path
 // bits live in LDS.
 // ---------------------------------------------------------------------------
+#define LHOP_N 512
+__device__ __forceinline__ int memo_get(const uint8_t *memo, const u32 *lhop, int s)
+{
+	const int v = memo[s];
+	if (v < 255) return v;
+	for (u32 h = ((u32)s * 40503u) >> 7;; h++) { const u32 e = lhop[h & (LHOP_N - 1)]; if ((e >> 16) == (u32)s + 1) return (int)(e & 0xffffu); }
+}
+__device__ __forceinline__ void memo_set(uint8_t *memo, u32 *lhop, int s, int d, int *abort_flag)
+{
+	if (d < 255) { memo[s] = (uint8_t)d; return; }
+	const u32 e = ((u32)(s + 1) << 16) | (u32)d;
+	u32 h = ((u32)s * 40503u) >> 7;
+	for (int tries = 0; tries < LHOP_N; tries++, h++) {
+		const u32 old = atomicCAS(&lhop[h & (LHOP_N - 1)], 0u, e);
+		if (old == 0 || old == e) { memo[s] = 255; return; }      // (two walks that reach the same start store the same hop: next(s) is a function of s)
+	}
+	*(volatile int *)abort_flag = 1;                                // table full: the chunk is redone by the dense kernels
+}
+
 template <bool COUNT, bool E16>
 __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
@@ -81,7 +100,11 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	__shared__ u32 s_ncand, s_queue, s_hits;
 	__shared__ int changed, s_abort;
 	__shared__ u32 qp[QP_WORDS], qn[QN_WORDS];
-	__shared__ uint16_t memo[GSA_CHUNK];      // next(s)-s, 0 = unknown
+	// next(s) - s per position, 0 = unknown, as BYTES: hops of 255 and more (a match of >= 254 bases: at most a few dozen
+	// starts of a chunk) keep their value in a small hash table beside it.  20 KB of u16 were what limited a CU to six of
+	// these workgroups; a full table (never seen) sends the chunk to the dense kernels like an exhausted budget does.
+	__shared__ uint8_t memo[GSA_CHUNK];
+	__shared__ u32 lhop[LHOP_N];              // (s + 1) << 16 | hop, 0 = free
 	__shared__ uint16_t mblk[COUNT ? GSA_CHUNK : 1];   // Occ blocks the search from s read (accounting build only)
 	__shared__ u32 bits[PATH_WORDS];
 	__shared__ uint16_t entry_of[NSUB], exit_of[NSUB];
@@ -112,6 +135,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		qn[g] = wn;
 	}
 	for (int p = j; p < clen; p += SEED_WG) memo[p] = 0;
+	for (int p = j; p < LHOP_N; p += SEED_WG) lhop[p] = 0;
 	for (int p = j; p < PATH_WORDS; p += SEED_WG) bits[p] = 0;
 	if (j == 0) { s_ncand = 0; s_queue = 0; s_hits = 0; s_npend = 0; s_abort = 0; }
 	if (j < NSUB / 32) rewalked[j] = 0;
@@ -138,7 +162,8 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 			// A chunk whose walks exceed the budget (a tandem array with more than MaxSeedFreq copies: every start is searched for
 			// ~100 bases, rejected and followed by start+1 -- thousands of dependent searches on a handful of lanes) is given up
 			// here and searched from EVERY position in parallel by the dense kernels below.
-			if (!COUNT && budget) { if (iters > budget) *(volatile int *)&s_abort = 1; if (*(volatile int *)&s_abort) break; }
+			if (!COUNT && budget && iters > budget) *(volatile int *)&s_abort = 1;
+			if (*(volatile int *)&s_abort) break;
 			// ---- request phase (convergent) ----
 			u64 kk = 0, ll = 0; bool kn = true, ln = true;
 			if (mode == M_FM) {
@@ -215,7 +240,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 					else cnt[CNT_OVERFLOW] = 1;
 					d = prm.bSensitive ? 5 : len + 1;
 				}
-				memo[s] = (uint16_t)d; if (COUNT) mblk[s] = (uint16_t)blk;
+				memo_set(memo, lhop, s, d, &s_abort); if (COUNT) mblk[s] = (uint16_t)blk;
 				all_blocks += blk;
 				s += d; mode = M_ADV;
 			}
@@ -232,7 +257,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 					s = entry_of[item]; bend = (item + 1) * S < clen ? (item + 1) * S : clen;
 				}
 				if (s >= bend) { exit_of[item] = (uint16_t)s; need_item = true; continue; }
-				const int m_ = memo[s];
+				const int m_ = memo_get(memo, lhop, s);
 				if (m_) { s += m_; continue; }
 				const u32 nb = q_nbits32(qn, s);
 				const int L = prm.MinSeedLength < 32 ? prm.MinSeedLength : 32;
@@ -313,7 +338,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	u32 alg_blocks = 0;
 	if (!heavy) for (int it = j; it < nitems; it += SEED_WG) {
 		const int bend = (it + 1) * S < clen ? (it + 1) * S : clen;
-		for (int s = entry_of[it]; s < bend;) { atomicOr(&bits[s >> 5], 1u << (s & 31)); if (COUNT) alg_blocks += mblk[s]; s += memo[s]; }
+		for (int s = entry_of[it]; s < bend;) { atomicOr(&bits[s >> 5], 1u << (s & 31)); if (COUNT) alg_blocks += mblk[s]; s += memo_get(memo, lhop, s); }
 	}
 	for (int o = 32; o; o >>= 1) { alg_blocks += __shfl_down(alg_blocks, o); all_blocks += __shfl_down(all_blocks, o); }
 	if ((j & 63) == 0) {
@@ -367,14 +392,15 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 // 64-base text windows.  Consecutive lanes hold consecutive starts, so a wavefront's searches end at the same mismatch.
 // ---------------------------------------------------------------------------
 #define DENSE_TPB 256
-#define DENSE_SPAN 512                          // starts per workgroup (two per lane)
-#define DENSE_WGS ((GSA_CHUNK + DENSE_SPAN - 1) / DENSE_SPAN)
-template <bool E16>
+// SPAN = starts per workgroup: 512 (two per lane) when every chunk is dense (-sen), 256 for the few chunks the speculative
+// kernel gave up on (their searches are ~100 dependent Occ steps each: one per lane halves the latency of that detour)
+#define DENSE_WGS(SPAN) ((GSA_CHUNK + (SPAN) - 1) / (SPAN))
+template <bool E16, int DENSE_SPAN>
 __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, const u32 *__restrict__ chunk_list,
                                                               uint16_t *dn_memo, u32 *dn_lf, u64 *dn_x0, u64 *cnt)
 {
 	__shared__ u32 qp[QP_WORDS], qn[QN_WORDS];
-	const u32 slot = blockIdx.x / DENSE_WGS, part = blockIdx.x % DENSE_WGS;
+	const u32 slot = blockIdx.x / DENSE_WGS(DENSE_SPAN), part = blockIdx.x % DENSE_WGS(DENSE_SPAN);
 	const u32 chunk = chunk_list ? chunk_list[slot] : slot;
 	const int j = threadIdx.x;
 	const i64 c0 = (i64)chunk * GSA_CHUNK;
@@ -867,10 +893,10 @@ int stage1_seed(gsa_ctx *c)
 			const size_t nd = (size_t)n_heavy * GSA_CHUNK;
 			if (!dev_ensure<uint16_t>(c, c->dn_memo, nd) || !dev_ensure<u32>(c, c->dn_lf, nd) || !dev_ensure<u64>(c, c->dn_x0, nd)) return GSA_ERR_NOMEM;
 			const u32 *list = dense_all ? (const u32 *)nullptr : c->d_heavy.as<u32>();
-			if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true>), dim3((unsigned)(n_heavy * DENSE_WGS)), dim3(DENSE_TPB), 0, st, c->di, d_q, qlen, c->prm, list,
-			                                       c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt);
-			else hipLaunchKernelGGL((k_dense_search<false>), dim3((unsigned)(n_heavy * DENSE_WGS)), dim3(DENSE_TPB), 0, st, c->di, d_q, qlen, c->prm, list,
-			                        c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt);
+#define GSA_DENSE_ARGS(SPAN) dim3((unsigned)(n_heavy * DENSE_WGS(SPAN))), dim3(DENSE_TPB), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt
+			if (dense_all) { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 512>), GSA_DENSE_ARGS(512)); else hipLaunchKernelGGL((k_dense_search<false, 512>), GSA_DENSE_ARGS(512)); }
+			else { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 256>), GSA_DENSE_ARGS(256)); else hipLaunchKernelGGL((k_dense_search<false, 256>), GSA_DENSE_ARGS(256)); }
+#undef GSA_DENSE_ARGS
 			hipLaunchKernelGGL(k_dense_resolve, dim3((unsigned)n_heavy), dim3(256), 0, st, list, (u32)n_chunks, qlen, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt,
 			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(),
 			                   c->d_chunk_hits.as<i32>(), c->h_cnt);
