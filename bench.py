@@ -42,11 +42,11 @@ YEAST_KB = [230, 813, 317, 1532, 577, 270, 1091, 563, 440, 746, 667, 1078, 924, 
 
 WORKLOADS = {
     # name: genome length(s), divergence, repeat injection, aligner parameters, distinct query genomes
-    "human": dict(lengths=[250_000_000], div=0.01, repeats=True, params={}, n_query=4,
+    "human": dict(lengths=[250_000_000], div=0.01, repeats=True, params={}, n_query=4, inflight=2,
                   label="human-chr1-sized pair (BASELINE configs[3] on one GPU): 250 Mb reference with repeat injection (300-bp family over 10 %, 150-copy tandem) vs 1 %-diverged query, defaults"),
-    "ecoli": dict(lengths=[5_000_000], div=0.02, repeats=False, params={}, n_query=4,
+    "ecoli": dict(lengths=[5_000_000], div=0.02, repeats=False, params={}, n_query=4, inflight=3,
                   label="E. coli-sized pair (BASELINE configs[1] stand-in): 5 Mb reference vs 2 %-diverged query, default -slen 15 -ind 25"),
-    "yeast": dict(lengths=[1000 * k for k in YEAST_KB], div=0.02, repeats=False, params=dict(sen=1, clr=50), n_query=2,
+    "yeast": dict(lengths=[1000 * k for k in YEAST_KB], div=0.02, repeats=False, params=dict(sen=1, clr=50), n_query=2, inflight=2,
                   label="S. cerevisiae-sized pair (BASELINE configs[2]): 16 contigs / 12 Mb vs 2 %-diverged copy, -sen"),
 }
 
@@ -120,7 +120,8 @@ def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup):
     """One workload: returns the per-rank measurements (dict).  A step = every contig of one query genome."""
     px, idx, refs = build_reference(tmp, name, wl, rank, world)
     genomes = make_queries(wl, refs, rank)
-    run = Runner(idx, local_rank, args.inflight, wl["params"])
+    inflight = args.inflight if args.inflight > 0 else wl.get("inflight", 2)
+    run = Runner(idx, local_rank, inflight, wl["params"])
     g0 = run.ctx[0]
     pinned = [[g0.pinned_copy(c) for c in gq] for gq in genomes]       # contigs live in pinned host memory (gsa_host_alloc), like a loader's buffers
     bp_per_step = float(np.mean([sum(c.size for c in gq) for gq in genomes]))
@@ -158,7 +159,7 @@ def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup):
     alg = {"occ_blocks": 64.0 * cnt[0], "lf_steps": 64.0 * cnt[1], "sa_reads": 8.0 * cnt[2], "query": bp_per_step, "seeds": 16.0 * cnt[3],
            "dp_cells": cnt[4], "dp_fragments": cnt[6]}
     return dict(px=px, refs=refs, genomes=genomes, t_total=t_total, bp=bp_per_step * steps, bp_per_step=bp_per_step, steps=steps, alg=alg, cnt=cnt, tm=tm,
-                occ_read=occ_read, recs=recs, n_blocks=n_blocks, n_frags=n_frags, n_aln=n_aln, contigs_per_step=per_step)
+                occ_read=occ_read, recs=recs, n_blocks=n_blocks, n_frags=n_frags, n_aln=n_aln, contigs_per_step=per_step, inflight=inflight)
 
 
 def measure_split(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup, dev):
@@ -221,7 +222,7 @@ def summarise(name, wl, m, t_max, total_bp, world, args):
     return {
         "value": total_bp / t_max / 1e9, "ms_per_step": ms_step,
         "config": {"workload": wl["label"] + f"; {len(m['genomes'])} distinct query genomes rotating; step = gsa_align_contig per contig incl. H2D of the query and D2H of records + strings",
-                   "query_bp_per_step": int(m["bp_per_step"]), "contigs_per_step": m["contigs_per_step"], "inflight_contexts_per_gpu": args.inflight,
+                   "query_bp_per_step": int(m["bp_per_step"]), "contigs_per_step": m["contigs_per_step"], "inflight_contexts_per_gpu": m["inflight"],
                    "parallelism": f"contig-shard x{world}, index replicated", "aligner_params": wl["params"]},
         "roofline": {"bound": "hbm", "kernel": "whole hot path S1-S7 (SURVEY 8(d) formula: 64 N_occblk + 64 N_lf + 8 N_sa + L_query + 16 N_seed + N_dpcells + sum(m+n))",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -313,9 +314,9 @@ def main():
     ap.add_argument("--workload", default="human", choices=sorted(WORKLOADS))
     ap.add_argument("--genome", type=int, default=0, help="override the reference length of a one-contig workload")
     ap.add_argument("--divergence", type=float, default=-1.0)
-    ap.add_argument("--inflight", type=int, default=2, help="contexts (host threads) per GPU working on different contigs")
+    ap.add_argument("--inflight", type=int, default=0, help="contexts (host threads) per GPU working on different contigs (0 = the workload's own: 2, 3 for the 5 Mb one)")
     ap.add_argument("--extra", default="ecoli,yeast", help="further workloads measured in the same run (short loops); '' = none")
-    ap.add_argument("--hwq", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default)")
+    ap.add_argument("--hwq", type=int, default=8, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default of 4; the contexts in flight have 4 streams each)")
     ap.add_argument("--split", action="store_true", help="N > 1 only: ONE contig per step, its seed search sharded by chunk range over the ranks (strong scaling)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo: plumbing checks)")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing check on a one-GPU box: every rank uses GPU 0 (with --backend gloo)")
@@ -396,16 +397,21 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic"}
         out.update(summarise(args.workload, wl, m, t_max, total_bp, world, args))
         out["config"]["vcf_concordance"] = "bit-identical MAF/VCF vs reference on tests/golden (tests/test_gpu_cli.py)"
-    extras = []
-    for name in [x for x in args.extra.split(",") if x and x != args.workload]:
-        w2 = WORKLOADS[name]
-        st = 50 if name == "ecoli" else 6
-        m2 = measure(name, w2, args, tmp, rank, world, local_rank, sync, st, max(2, st // 5))
-        t2, b2 = whole_job(m2)
-        if rank == 0:
-            e = {"workload": name, "steps": st, "unit": "Gbp/s"}
-            e.update(summarise(name, w2, m2, t2, b2, world, args)); extras.append(e)
     if rank == 0:
+        # the further workloads (short loops of their own), each in a process of its own behind the main measurement: in one
+        # process the second workload runs 10-25 % slower whatever the order (measured both ways); N = 1 only
+        extras = []
+        for name in [x for x in args.extra.split(",") if x and x != args.workload and world == 1]:
+            st = 200 if name == "ecoli" else 12
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(st), "--warmup", str(max(2, st // 5)), "--extra", "", "--no-cpu-baseline", "--hwq", str(args.hwq)]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GSA_BENCH_TMP=tmp, GSA_BENCH_KEEP="1"))
+                d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                e = {"workload": name, "steps": st, "unit": "Gbp/s"}
+                e.update({k: d[k] for k in ("value", "ms_per_step", "config", "roofline", "kernels", "stage_ms_one_context_alone", "counters_per_step")})
+                extras.append(e)
+            except Exception as ex:      # noqa: BLE001
+                extras.append({"workload": name, "value": None, "error": repr(ex)[:300]})
         out["extra_workloads"] = extras
         if not args.no_cpu_baseline and world == 1:
             try:

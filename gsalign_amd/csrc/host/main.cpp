@@ -53,6 +53,7 @@ static bool first_char_is_header(const char *path)          // CheckInputFile (m
 
 int main(int argc, char *argv[])
 {
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);        // (-ctx contexts x 4 streams each: the runtime's default is 4 hardware queues per process)
 	gsa_params prm; gsa_default_params(&prm);
 	int threads = 8, fmt = 1, n_ctx_per_gpu = 2; bool vcf = true, allow_dup = true, dotplot = false;
 	std::vector<int> gpus;

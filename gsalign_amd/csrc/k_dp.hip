@@ -295,11 +295,13 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	const int jjoff = lane < Wp ? lane : 0x40000000;    // lanes beyond the stripe never become valid
 	const bool pub_stripe = p < P - 1;                  // (then Wp == 64 and lane 63 owns the boundary column)
 	int dlast = 0, dacc = 0;
+	// blocks of 16 anti-diagonals [rl0, rl0 + 16) on which every lane of a full stripe has a cell: 63 <= rl0, rl0 + 15 < m
+	const int full_lo = Wp == 64 ? 63 : 0x7fffffff, full_hi = m - 15;
 	int pk = 0;                                         // x | v << 8 of my column after the current diagonal
 	int hist = 0;                                       // lane 63 - q: pk of lane 63 q diagonals ago (boundary rows travel one lane down per diagonal)
 	// one anti-diagonal; K2 is the position inside the 16-row block (a literal in the unrolled body)
 #define DP_LOADG(MODE, ROW) ((MODE) == 2 ? __hip_atomic_load(&lin[ROW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(&bnd_in[ROW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-#define DP_STEP(K2, MODE, WREF)                                                                                      \
+#define DP_STEP(K2, MODE, WREF, MASKED)                                                                              \
 	{                                                                                                           \
 		const int rl_ = rl0 + (K2);                                                                             \
 		if (((K2) & (DP_G - 1)) == 0) {                                                                                  \
@@ -325,7 +327,7 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 		}                                                                                                       \
 		const int packed = wave_shr1(pk, __builtin_amdgcn_readlane((int)bin, (K2) & (DP_G - 1)));                            \
 		const int jj = rl_ - jjoff;                                                                             \
-		if ((unsigned)jj < (unsigned)m) {                                                                       \
+		if (!(MASKED) || (unsigned)jj < (unsigned)m) {                                                          \
 			const int x1 = packed & 0xff, v1 = packed >> 8;                                                     \
 			int z = (int)__builtin_amdgcn_ubfe(tbl, (u32)(WREF), 4u);                                           \
 			int a = x1 + v1, b = y + u;                                                                         \
@@ -363,10 +365,17 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 		if (rl0 + 16 <= nl) {                                                                                   \
 			int w16[16];                                                                                        \
 			_Pragma("unroll") for (int k2 = 0; k2 < 16; k2++) w16[k2] = crow[k2];                                 \
-			DP_STEP(0, MODE, w16[0]) DP_STEP(1, MODE, w16[1]) DP_STEP(2, MODE, w16[2]) DP_STEP(3, MODE, w16[3]) DP_STEP(4, MODE, w16[4]) DP_STEP(5, MODE, w16[5]) DP_STEP(6, MODE, w16[6]) DP_STEP(7, MODE, w16[7]) \
-			DP_STEP(8, MODE, w16[8]) DP_STEP(9, MODE, w16[9]) DP_STEP(10, MODE, w16[10]) DP_STEP(11, MODE, w16[11]) DP_STEP(12, MODE, w16[12]) DP_STEP(13, MODE, w16[13]) DP_STEP(14, MODE, w16[14]) DP_STEP(15, MODE, w16[15]) \
+			if (rl0 >= full_lo && rl0 < full_hi) {                                                              \
+				/* every lane has a cell on each of these 16 anti-diagonals (the steady state of a long stripe): no lane mask, \
+				   no register copies around it */                                                              \
+				DP_STEP(0, MODE, w16[0], 0) DP_STEP(1, MODE, w16[1], 0) DP_STEP(2, MODE, w16[2], 0) DP_STEP(3, MODE, w16[3], 0) DP_STEP(4, MODE, w16[4], 0) DP_STEP(5, MODE, w16[5], 0) DP_STEP(6, MODE, w16[6], 0) DP_STEP(7, MODE, w16[7], 0) \
+				DP_STEP(8, MODE, w16[8], 0) DP_STEP(9, MODE, w16[9], 0) DP_STEP(10, MODE, w16[10], 0) DP_STEP(11, MODE, w16[11], 0) DP_STEP(12, MODE, w16[12], 0) DP_STEP(13, MODE, w16[13], 0) DP_STEP(14, MODE, w16[14], 0) DP_STEP(15, MODE, w16[15], 0) \
+			} else {                                                                                            \
+				DP_STEP(0, MODE, w16[0], 1) DP_STEP(1, MODE, w16[1], 1) DP_STEP(2, MODE, w16[2], 1) DP_STEP(3, MODE, w16[3], 1) DP_STEP(4, MODE, w16[4], 1) DP_STEP(5, MODE, w16[5], 1) DP_STEP(6, MODE, w16[6], 1) DP_STEP(7, MODE, w16[7], 1) \
+				DP_STEP(8, MODE, w16[8], 1) DP_STEP(9, MODE, w16[9], 1) DP_STEP(10, MODE, w16[10], 1) DP_STEP(11, MODE, w16[11], 1) DP_STEP(12, MODE, w16[12], 1) DP_STEP(13, MODE, w16[13], 1) DP_STEP(14, MODE, w16[14], 1) DP_STEP(15, MODE, w16[15], 1) \
+			}                                                                                                   \
 		} else {                                                                                                \
-			for (int k2 = 0; rl0 + k2 < nl; k2++) DP_STEP(k2, MODE, crow[k2])                                      \
+			for (int k2 = 0; rl0 + k2 < nl; k2++) DP_STEP(k2, MODE, crow[k2], 1)                                   \
 			/* the last, partial dword of the stripe */                                                         \
 			if (nl & 7) { DPX_STORE(dirp[((size_t)(nl >> 3) << 6) + lane] = (u32)dacc >> (4 * (8 - (nl & 7)));) }   \
 		}                                                                                                       \
