@@ -137,7 +137,7 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	c->di.seq_len = idx->L2[4];
 	c->di.bwt = c->d_bwt.as<uint4>(); c->di.sa = c->d_sa.as<u64>(); c->di.ref = c->d_ref.as<uint8_t>(); c->di.G = idx->G;
 	c->di.chr_end = c->d_chr_end.as<i64>(); c->di.chr_of_end = c->d_chr_of_end.as<i32>(); c->di.n_ends = (i32)c->h_chr_end.size();
-	c->di.sa32 = nullptr; c->di.sa64 = nullptr; c->di.kmer = nullptr; c->di.kmer_k = 0; c->di.kmer_e16 = 0; c->di.ref2 = nullptr; c->di.pres = nullptr; c->di.pres_k = 0;
+	c->di.sa32 = nullptr; c->di.sa64 = nullptr; c->di.kmer = nullptr; c->di.kmer_k = 0; c->di.kmer_lo = nullptr; c->di.kmer_lo_k = 0; c->di.kmer_e16 = 0; c->di.ref2 = nullptr; c->di.pres = nullptr; c->di.pres_k = 0;
 	if (int rcd = build_dense_sa(c, idx->n_sa)) { g_create_error = c->err; gsa_destroy(c); return rcd; }
 	gsa_params dp; gsa_default_params(&dp);
 	int rc = gsa_set_params(c, prm ? prm : &dp);
@@ -152,7 +152,7 @@ void gsa_destroy(gsa_ctx *c)
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
 	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->d_query, &c->tmp, &c->d_cnt, &c->d_mail, &c->d_lb_status[0], &c->d_lb_status[1],
-		&c->d_sa_dense, &c->d_kmer, &c->d_pres, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_heavy, &c->dn_memo, &c->dn_lf, &c->dn_x0, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
+		&c->d_sa_dense, &c->d_kmer, &c->d_kmer_lo, &c->d_pres, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_heavy, &c->dn_memo, &c->dn_lf, &c->dn_x0, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
 		&c->d_flag, &c->d_scan, &c->g_beg, &c->w_j0, &c->w_j1, &c->w_on, &c->d_pdbm, &c->d_gpre, &c->d_key_c, &c->d_val_c, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
 		&c->a_next, &c->a_brk, &c->a_aurank, &c->a_aulist, &c->a_runinfo, &c->w_best, &c->w_sum, &c->w_n, &c->d_btab, &c->d_flag2, &c->d_scan2, &c->d_i64a,
 		&c->b_q, &c->b_len, &c->b_r, &c->b_gb, &c->b_ge, &c->c_q, &c->c_len, &c->c_r, &c->c_gb, &c->c_ge, &c->c_bid, &c->blk_beg, &c->blk_end, &c->blk_score,

@@ -70,6 +70,7 @@ struct gsa_ctx {
 	// ---- stage 1 ----
 	DevBuf d_ref2;                                 // 2-bit packed reference text
 	DevBuf d_kmer;                                 // top-of-tree jump table
+	DevBuf d_kmer_lo;                              // its short companion (MinSeedLength bases), see DevIndex::kmer_lo
 	DevBuf d_pres;                                 // MinSeedLength-mer presence bitmap
 	DevBuf d_sa_dense;                             // one SA entry per BWT row (built at gsa_create)
 	DevBuf d_cand_s, d_cand_len, d_cand_x0, d_cand_freq, d_onpath, d_cand_cnt;

@@ -25,7 +25,7 @@ enum { CNT_OCCBLK = 0, CNT_DONE = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 
 #define PATH_WORDS 320          // 10240 on-path bits per chunk
 #define QP_WORDS (GSA_CHUNK / 16 + 4)
 #define QN_WORDS (GSA_CHUNK / 32 + 4)
-enum { M_DONE = 0, M_FM = 1, M_TEXT = 2, M_KMER = 3, M_LOC = 4, M_ADV = 5 };
+enum { M_DONE = 0, M_FM = 1, M_TEXT = 2, M_KMER = 3, M_LOC = 4, M_ADV = 5, M_KLO = 6 };
 
 // ---- 2-bit packed sequences: base p sits at bits (2*(p&15)) of word p>>4 (LSB first) ----
 __device__ __forceinline__ int q_code(const u32 *qp, int p) { return (qp[p >> 4] >> ((p & 15) << 1)) & 3; }
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 					ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
 					if (!COUNT && di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
 						const u64 qb = q_bits64(qp, s);
-						kid = (u32)qb & ((1u << (2 * di.kmer_k)) - 1); mode = M_KMER;
+						kid = (u32)(qb & ((1ull << (2 * di.kmer_k)) - 1)); mode = M_KMER;
 						pid = di.pres_k ? (u32)(qb & ((1ull << (2 * di.pres_k)) - 1)) : 0;
 					}
 				}
@@ -452,6 +452,13 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 			const ulonglong2 *pe = (const ulonglong2 *)((di.kmer ? di.kmer : (const u64 *)di.bwt) + (mode == M_KMER ? ((size_t)kid << 2) : 0));
 			e0 = pe[0]; e1 = pe[1];
 		}
+		// the short table: for a start whose kmer_k-mer does not occur (its match ends before kmer_k bases) -- the common case
+		// under -sen, where a match of 10..14 bases is a seed -- the interval after kmer_lo_k bases, instead of walking them
+		ulonglong2 l0 = {0, 0}, l1 = {0, 0};
+		if (di.kmer_lo) {
+			if (E16) { const uint4 e = ((const uint4 *)di.kmer_lo)[mode == M_KLO ? kid : 0]; l0.x = e.x; l0.y = e.y; l1.x = e.z; l1.y = e.w; }
+			else { const ulonglong2 *pe = (const ulonglong2 *)(di.kmer_lo + (mode == M_KLO ? ((size_t)kid << 2) : 0)); l0 = pe[0]; l1 = pe[1]; }
+		}
 		const u32 pw = di.pres ? di.pres[mode == M_KMER ? (pid >> 5) : 0] : ~0u;
 		const u64 sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
 		// ---- consume phase ----
@@ -459,11 +466,17 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 		if (mode == M_KMER) {
 			if (!((pw >> (pid & 31)) & 1u)) { ended = true; pos = s; ik.x2 = 0; }      // the first MinSeedLength bases do not occur: no seed here
 			else {
-				const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k, walk it base by base
+				const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k
 				if (hit) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; }
-				mode = M_FM;
+				mode = M_FM;                        // (no short table: walk it base by base from the first base)
 				if (hit && ik.x2 == 1) { tp = (i64)(e1.y - 1) + di.kmer_k; mode = M_TEXT; }
+				if (!hit && di.kmer_lo) { kid = kid & ((1u << (2 * di.kmer_lo_k)) - 1); mode = M_KLO; }      // (the start passed the N / length tests for kmer_k >= kmer_lo_k bases)
 			}
+		} else if (mode == M_KLO) {
+			const bool hit = l1.x != 0;
+			if (hit) { ik.x0 = l0.x; ik.x1 = l0.y; ik.x2 = l1.x; pos = s + di.kmer_lo_k; }
+			mode = M_FM;
+			if (hit && ik.x2 == 1) { tp = (i64)(l1.y - 1) + di.kmer_lo_k; mode = M_TEXT; }
 		} else if (mode == M_LOC) {
 			tp = (i64)sav + (pos - s); mode = M_TEXT;
 		} else if (mode == M_TEXT) {
@@ -494,8 +507,10 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 			ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
 			if (di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
 				const u64 qb = q_bits64(qp, s);
-				kid = (u32)qb & ((1u << (2 * di.kmer_k)) - 1); mode = M_KMER;
+				kid = (u32)(qb & ((1ull << (2 * di.kmer_k)) - 1)); mode = M_KMER;
 				pid = di.pres_k ? (u32)(qb & ((1ull << (2 * di.pres_k)) - 1)) : 0;
+			} else if (di.kmer_lo && s + di.kmer_lo_k <= clen && (nb & ((1u << di.kmer_lo_k) - 1)) == 0) {
+				kid = (u32)(q_bits64(qp, s) & ((1ull << (2 * di.kmer_lo_k)) - 1)); mode = M_KLO;      // (too close to the chunk end or an N for the long table)
 			}
 		}
 	}
@@ -721,8 +736,8 @@ __global__ void __launch_bounds__(256) k_densify_sa(DevIndex di, u64 n_sa, u32 *
 // Needs the dense SA (unique k-mers carry their text position).
 __global__ void __launch_bounds__(256) k_build_kmer(DevIndex di, int k, u64 *tab, int e16)
 {
-	const u32 id = blockIdx.x * blockDim.x + threadIdx.x;
-	if (id >= (1u << (2 * k))) return;
+	const u64 id = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= (1ull << (2 * k))) return;
 	FmIntv ik = fm_init(di, (int)(id & 3));                  // base t of the k-mer = bits 2t..2t+1 (same packing as the query in LDS)
 	u32 blk = 0; bool alive = true;
 	for (int t = 1; t < k && alive; t++) alive = fm_extend(di, ik, (int)((id >> (2 * t)) & 3), blk);
@@ -754,9 +769,26 @@ __global__ void __launch_bounds__(256) k_build_pres(const u32 *__restrict__ ref2
 	atomicOr(&bm[id >> 5], 1u << (id & 31));
 }
 
+// the short companion of the k-mer table (DevIndex::kmer_lo): MinSeedLength bases, when that is less than kmer_k
+static int build_kmer_lo(gsa_ctx *c)
+{
+	const int k = c->prm.MinSeedLength;
+	if (c->di.kmer_lo && c->di.kmer_lo_k == k) return GSA_OK;
+	c->di.kmer_lo = nullptr; c->di.kmer_lo_k = 0;
+	if (!c->di.kmer || k < 8 || k >= c->di.kmer_k || k > 13) return GSA_OK;
+	const size_t n = (size_t)1 << (2 * k);
+	if (!dev_ensure<u64>(c, c->d_kmer_lo, c->di.kmer_e16 ? n * 2 : n * 4)) return GSA_ERR_NOMEM;
+	hipLaunchKernelGGL(k_build_kmer, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->di, k, c->d_kmer_lo.as<u64>(), c->di.kmer_e16);
+	GSA_CHECK(c, hipGetLastError());
+	GSA_CHECK(c, hipStreamSynchronize(c->stream));
+	c->di.kmer_lo = c->d_kmer_lo.as<u64>(); c->di.kmer_lo_k = k;
+	return GSA_OK;
+}
+
 int build_presence(gsa_ctx *c)
 {
 	if (!c->di.ref2) return GSA_OK;                       // (gsa_create sets the parameters after the index is up)
+	if (int rcl = build_kmer_lo(c)) return rcl;
 	int k = c->prm.MinSeedLength < 16 ? c->prm.MinSeedLength : 16;
 	if (k == c->di.pres_k && c->di.pres) return GSA_OK;
 	c->di.pres = nullptr; c->di.pres_k = 0;
@@ -788,15 +820,30 @@ int build_dense_sa(gsa_ctx *c, u64 n_sa)
 	GSA_CHECK(c, hipGetLastError());
 	GSA_CHECK(c, hipStreamSynchronize(c->stream));
 	{
-		// k = ceil(log4(2G)) + 2, capped at 14 (4-8 GiB of 288): nearly all k-mers that occur are unique then (a 10 Mb
-		// text: 96 % at k = 14, 86 % at k = 13), so a search is table -> text comparison with no stepwise Occ walk in
-		// between -- each Occ step is a round trip AND the heaviest block of the search loop
+		// k = ceil(log4(2G)) + 2: nearly all k-mers that occur are unique then (a 10 Mb text: 96 % at k = 14, 86 % at k = 13), so a
+		// search is table -> text comparison with no stepwise Occ walk in between -- each Occ step is a round trip AND the
+		// heaviest block of the search loop.  Capped at 15 and at a quarter of the free device memory (4^15 x 16 B = 16 GiB
+		// of the 288: a human-chromosome-sized text of 5 x 10^8 rows has 34 % unique k-mers at k = 14, 78 % at 15).
 		int k = 0; while ((1ull << (2 * k)) < c->di.seq_len) k++;
-		k += 2; if (k > 14) k = 14;
+		k += 2; if (k > 15) k = 15;      // (not beyond the default MinSeedLength: a start whose first 15 bases occur -- presence bitmap -- must find its entry, else it walks base by base)
+		{
+			size_t fr = 0, tot = 0;
+			if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 8ull << 30; }
+			const size_t esz = (c->di.seq_len < 0xFFFFFFF0ull && !c->force_wide) ? 16 : 32;
+			while (k > 2 && ((size_t)esz << (2 * k)) > fr / 4) k--;
+			if (const char *ek = getenv("GSA_KMER_K")) { const int kk = atoi(ek); if (kk >= 2 && kk <= 16 && ((size_t)esz << (2 * kk)) <= fr / 2) k = kk; }      // (tests: a long table on a short text)
+		}
 		if (k >= 2) {
 			const size_t n = (size_t)1 << (2 * k);
 			const int e16 = (c->di.seq_len < 0xFFFFFFF0ull && !c->force_wide) ? 1 : 0;
-			if (!dev_ensure<u64>(c, c->d_kmer, e16 ? n * 2 : n * 4)) return GSA_ERR_NOMEM;
+			{	// (exactly this size: dev_ensure's growth margin would be 16 GiB on the longest table)
+				const size_t bytes = (e16 ? n * 2 : n * 4) * sizeof(u64);
+				if (c->d_kmer.cap < bytes) {
+					if (c->d_kmer.p) { hipFree(c->d_kmer.p); c->d_kmer.p = nullptr; c->d_kmer.cap = 0; }
+					if (hipMalloc(&c->d_kmer.p, bytes) != hipSuccess) { (void)hipGetLastError(); return gsa_fail(c, GSA_ERR_NOMEM, "hipMalloc (k-mer table)"); }
+					c->d_kmer.cap = bytes;
+				}
+			}
 			hipLaunchKernelGGL(k_build_kmer, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->di, k, c->d_kmer.as<u64>(), e16);
 			c->di.kmer_e16 = e16;
 			GSA_CHECK(c, hipGetLastError());

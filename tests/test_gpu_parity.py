@@ -211,6 +211,20 @@ def test_repeat_stress_vs_oracle(oracle_built, tmp_path, total, div, seed, param
     o.close(); g.close()
 
 
+@pytest.mark.parametrize("k,wide", [(16, False), (15, True)])
+def test_long_kmer_table(oracle_built, tmp_path, monkeypatch, k, wide):
+    """Human-chromosome-sized texts get a k-mer jump table of k = 15 (16 GiB; 32 with wide entries) -- the table length follows
+    the text length, so on a short text GSA_KMER_K forces it (16 too: the kernels take it): same seeds, blocks and strings as
+    the oracle, both entry widths."""
+    monkeypatch.setenv("GSA_KMER_K", str(k))
+    refs, qrys = synth.make_pair_fast(2000000, 2, 0.02, seed=60, repeats=True)
+    qrys[1] = (qrys[1][0], synth.revcomp(qrys[1][1]))
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx); g = capi.Aligner(idx, wide=wide)
+    _same_as_oracle(o, g, qrys)
+    o.close(); g.close()
+
+
 def test_striped_dp_fallback_path(oracle_built, tmp_path, monkeypatch):
     """The safety net behind the striped DP's bounded hand-off wait: one job per launch (GSA_DP_SAFE=1 forces it)."""
     monkeypatch.setenv("GSA_DP_SAFE", "1")
