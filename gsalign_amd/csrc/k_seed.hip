@@ -831,7 +831,7 @@ int build_dense_sa(gsa_ctx *c, u64 n_sa)
 			if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 8ull << 30; }
 			const size_t esz = (c->di.seq_len < 0xFFFFFFF0ull && !c->force_wide) ? 16 : 32;
 			while (k > 2 && ((size_t)esz << (2 * k)) > fr / 4) k--;
-			if (const char *ek = getenv("GSA_KMER_K")) { const int kk = atoi(ek); if (kk >= 2 && kk <= 16 && ((size_t)esz << (2 * kk)) <= fr / 2) k = kk; }      // (tests: a long table on a short text)
+			if (const char *ek = getenv("GSA_KMER_K")) { const int kk = atoi(ek); if (kk >= 2 && kk <= 15 && ((size_t)esz << (2 * kk)) <= fr / 2) k = kk; }      // (tests: a long table on a short text)
 		}
 		if (k >= 2) {
 			const size_t n = (size_t)1 << (2 * k);

@@ -211,10 +211,10 @@ def test_repeat_stress_vs_oracle(oracle_built, tmp_path, total, div, seed, param
     o.close(); g.close()
 
 
-@pytest.mark.parametrize("k,wide", [(16, False), (15, True)])
+@pytest.mark.parametrize("k,wide", [(15, False), (15, True)])
 def test_long_kmer_table(oracle_built, tmp_path, monkeypatch, k, wide):
     """Human-chromosome-sized texts get a k-mer jump table of k = 15 (16 GiB; 32 with wide entries) -- the table length follows
-    the text length, so on a short text GSA_KMER_K forces it (16 too: the kernels take it): same seeds, blocks and strings as
+    the text length, so on a short text GSA_KMER_K forces it: same seeds, blocks and strings as
     the oracle, both entry widths."""
     monkeypatch.setenv("GSA_KMER_K", str(k))
     refs, qrys = synth.make_pair_fast(2000000, 2, 0.02, seed=60, repeats=True)
