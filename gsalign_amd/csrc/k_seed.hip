@@ -628,16 +628,31 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 	if (j == 0) s_offs[nc] = total;
 	__syncthreads();
 	const u64 base = (u64)hit_base[chunk];
-	for (u32 t = j; t < total; t += 256) {
-		// the candidate whose range holds hit t: the last i with s_offs[i] <= t (empty ranges share their start with the next one)
-		u32 lo = 0, hi = nc;
-		while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_offs[mid] <= t) lo = mid; else hi = mid; }
-		const u32 i = lo, h = t - s_offs[i];
-		const i32 s = cand_s[cbase + i] + s_off; const u32 f = (u32)cand_freq[cbase + i], len = (u32)cand_len[cbase + i]; const u64 x0 = cand_x0[cbase + i];
-		const u64 r = fm_locate(di, x0 + h);
+	__shared__ unsigned long long s_r[256];                  // located positions of the 256 hits in flight: a hit ranks itself among its siblings from here
+	for (u32 t0 = 0; t0 < total; t0 += 256) {
+		const u32 t = t0 + j;
+		u32 i = 0, h = 0, f = 0, len = 0; i32 s = 0; u64 x0 = 0, r = 0;
+		if (t < total) {
+			// the candidate whose range holds hit t: the last i with s_offs[i] <= t (empty ranges share their start with the next one)
+			u32 lo = 0, hi = nc;
+			while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_offs[mid] <= t) lo = mid; else hi = mid; }
+			i = lo; h = t - s_offs[i];
+			s = cand_s[cbase + i] + s_off; f = (u32)cand_freq[cbase + i]; len = (u32)cand_len[cbase + i]; x0 = cand_x0[cbase + i];
+			r = fm_locate(di, x0 + h);
+		}
+		s_r[j] = r;
+		__syncthreads();
+		if (t < total) {
 		const i64 pd = (i64)r - s + qlen;
 		u32 rank = 0;
-		if (f > 1) for (u32 h2 = 0; h2 < f; h2++) rank += fm_locate(di, x0 + h2) < r ? 1u : 0u;
+		if (f > 1) {
+			const u32 first = t - h;                            // hit index of sibling 0
+			for (u32 h2 = 0; h2 < f; h2++) {
+				const u32 ts = first + h2;
+				const u64 r2 = (ts >= t0 && ts < t0 + 256) ? s_r[ts - t0] : fm_locate(di, x0 + h2);      // (siblings in another window of 256: the dense SA again)
+				rank += r2 < r ? 1u : 0u;
+			}
+		}
 		key[base + t] = ((u64)pd << qbits) | (u32)s;
 		val[base + t] = len | (rank << 16);
 		// occupied PosDiff values: groups without sorting by PosDiff (k_chain.hip).  Collected per workgroup in LDS, one
@@ -653,6 +668,8 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 			}
 			if (tries == 4) atomicOr(&pdbm[w], bit);
 		}
+		}
+		__syncthreads();
 	}
 	if (pdbm) {
 		__syncthreads();
