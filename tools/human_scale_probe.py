@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] on ONE GPU: a 24-contig reference with GRCh38 chromosome lengths (3.08 Gbp, 6.2 G BWT rows: the wide
+device layout and the 64-bit suffix sorter on their real input), query = 1 %-diverged copy of every chromosome (one of them
+reverse-complemented), -alen 5000, all contigs through gsa_align_many on two contexts.  Result invariants on three contigs,
+throughput of the whole set.  GPU box only (host: ~120 GB, HBM: ~110 GB).   usage: human_scale_probe.py [scale=1.0]"""
+import os, sys, time, tempfile, shutil
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from gsalign_amd import synth, hostlib, indexio, capi
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+MB = [248, 242, 198, 190, 181, 170, 159, 145, 138, 133, 135, 133, 114, 107, 101, 90, 83, 80, 58, 64, 46, 50, 156, 57]
+lens = [int(m * 1e6 * scale) for m in MB]
+tmp = tempfile.mkdtemp(prefix="human_", dir="/tmp")
+try:
+    t = time.time()
+    refs = []
+    for i, n in enumerate(lens):
+        r = synth.fast_genome(n, 41000 + i); synth.inject_repeats(r, 41000 + i); refs.append((f"chr{i + 1}", r))
+    synth.write_fasta(os.path.join(tmp, "r.fa"), refs)
+    print(f"reference: {len(lens)} contigs, {sum(lens)} bp, written in {time.time() - t:.0f} s", flush=True)
+    t = time.time(); hostlib.build_index(os.path.join(tmp, "r.fa"), os.path.join(tmp, "r")); print(f"index built in {time.time() - t:.0f} s", flush=True)
+    t = time.time(); idx = indexio.load_index(os.path.join(tmp, "r")); print(f"index loaded in {time.time() - t:.0f} s, seq_len {idx.seq_len}", flush=True)
+    t = time.time(); g0 = capi.Aligner(idx, alen=5000); g1 = g0.clone(); print(f"gsa_create {time.time() - t:.0f} s", flush=True)
+    qs = [synth.fast_mutate(r, 0.01, 51000 + i) for i, (_, r) in enumerate(refs)]
+    qs[20] = synth.revcomp(qs[20])
+    pinned = [g0.pinned_copy(q) for q in qs]
+    total = sum(q.size for q in qs)
+    keep = {}
+
+    def on_result(ci, res):
+        if ci in (0, 20, 23):
+            keep[ci] = g_of[0]      # placeholder, results are re-read below
+        return 0
+    g_of = [None]
+    for rep in range(2):
+        t = time.time(); capi.align_many([g0, g1], pinned); dt = time.time() - t
+        print(f"pass {rep}: {len(qs)} contigs, {total} bp in {dt * 1e3:.0f} ms = {total / dt / 1e9:.2f} Gbp/s (H2D and D2H included, 2 contexts)", flush=True)
+    from test_gpu_parity import _check_result_invariants
+    for ci in (0, 20, 23):
+        t = time.time(); g0.align_contig(pinned[ci]); dt = time.time() - t
+        r = g0.blocks(); _check_result_invariants(idx, qs[ci], r)
+        cov = int(r["blocks"]["aln_len"].sum())
+        print(f"contig {ci}: {qs[ci].size} bp in {dt * 1e3:.1f} ms, {r['blocks'].size} blocks, coverage {cov / qs[ci].size:.3f}, invariants ok", flush=True)
+        assert cov > 0.9 * qs[ci].size
+    g1.close(); g0.close()
+    print("HUMAN SCALE PROBE OK")
+finally:
+    shutil.rmtree(tmp, ignore_errors=True)
