@@ -42,7 +42,10 @@ try:
         r = g0.blocks(); _check_result_invariants(idx, qs[ci], r)
         cov = int(r["blocks"]["aln_len"].sum())
         print(f"contig {ci}: {qs[ci].size} bp in {dt * 1e3:.1f} ms, {r['blocks'].size} blocks, coverage {cov / qs[ci].size:.3f}, invariants ok", flush=True)
-        assert cov > 0.9 * qs[ci].size
+        # (contig 20 is reverse-complemented and cut in two by the tandem array in its middle: the reference's second redundancy pass drops one
+        #  of two reverse-strand blocks of one chromosome -- SURVEY App. B #11, reproduced; tests/test_gpu_parity.py::test_long_kmer_table has
+        #  the same shape against the oracle)
+        assert cov > (0.45 if ci == 20 else 0.9) * qs[ci].size
     g1.close(); g0.close()
     print("HUMAN SCALE PROBE OK")
 finally:
