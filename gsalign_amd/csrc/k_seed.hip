@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 	const int nitems = (clen + S - 1) / S;
 	for (int it = j; it < nitems; it += SEED_WG) entry_of[it] = (uint16_t)(it * S);
 	u32 all_blocks = 0, rounds = 0, iters = 0;
-	unsigned long long t_begin = wall_clock64(), t_round0 = 0, t_resolve = 0, t_stage = 0;
+	unsigned long long t_begin = wall_clock64(), t_round0 = 0, t_resolve = 0;
 	u32 dirty = 0;                                      // rounds >= 2: this lane has one sub-range (fb_item) to walk for real
 	int fb_item = 0;
 	__syncthreads();
