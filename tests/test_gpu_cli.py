@@ -48,3 +48,14 @@ def test_cli_builds_its_own_index_and_matches_live_reference(oracle_built, tmp_p
     subprocess.run([oracle_built.REF_GSALIGN, "-r", "r.fa", "-q", "q.fa", "-o", "theirs", "-t", "1"], cwd=d, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     assert open(os.path.join(d, "mine.maf"), "rb").read() == open(os.path.join(d, "theirs.maf"), "rb").read()
     assert open(os.path.join(d, "mine.vcf"), "rb").read() == open(os.path.join(d, "theirs.vcf"), "rb").read()
+
+
+def test_cli_config3_and_repeat_stress_vs_live_reference(oracle_built):
+    """Whole programs side by side at BASELINE configs[2] size (16 contigs / 12 Mb / 2 % / -sen) and on the 12 Mb repeat-stress
+    pair: GSAlign_hip (own index, three contexts) vs the unmodified reference CLI at -t 1 -- MAF and VCF byte-identical."""
+    import sys
+    if not oracle_built.have_ref():
+        pytest.skip("oracle/_ref not present")
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_cli_check.py"), "c3,repeat"], capture_output=True, text=True, timeout=900, env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
+    assert r.returncode == 0 and r.stdout.count("IDENTICAL") == 4, r.stdout + r.stderr
