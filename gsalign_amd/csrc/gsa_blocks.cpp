@@ -256,7 +256,7 @@ int build_block_view(gsa_ctx *c)
 	if (c->stage == 7) {
 		const size_t nfb = c->blocks.size();
 		std::vector<i32> fragbase(nfb);
-		if (nfb) GSA_CHECK(c, hipMemcpy(fragbase.data(), c->fb_fragbase.p, nfb * 4, hipMemcpyDeviceToHost));
+		if (nfb) GSA_CHECK(c, hipMemcpy(fragbase.data(), c->bl_alnlen.as<i32>() + 2 * (size_t)nfb, nfb * 4, hipMemcpyDeviceToHost));      // (bl_alnlen | bl_score | fragbase: one buffer)
 		frags_count(c);
 		c->h_frags.resize((size_t)c->n_frags);
 		if (c->n_frags) GSA_CHECK(c, hipMemcpy(c->h_frags.data(), c->f_rec.p, (size_t)c->n_frags * sizeof(gsa_frag), hipMemcpyDeviceToHost));

@@ -681,7 +681,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	uint8_t *rev = dev_ensure<uint8_t>(c, c->d_i64a, (size_t)ops_total + 64);
 	if (!d_order || !d_order_tiny || !d_lg || !rev) return GSA_ERR_NOMEM;
 	if (!pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * LG_CHUNK)) return GSA_ERR_NOMEM;
-	GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR, 0, 7 * sizeof(i32), st));                    // M_DPERR, M_NLARGE, M_DPERR2, M_CELLS (2 x u64)
+	GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR, 0, 8 * sizeof(i32), st));                    // M_DPERR, M_NLARGE, M_DPERR2, -, M_CELLS (2 x u64): one aligned fill (28 bytes at an odd offset were three)
 	i32 *h = c->p_dp.as<i32>();
 	const size_t first_lg = (size_t)std::min<i64>(n_ub, LG_CHUNK);
 	{ OpClassify op = { len1, len2, d_order, d_order_tiny, d_lg, d_jlarge, mail, h, (i32)first_lg }; int rc = lb_launch<2>(c, n_ub, op); if (rc) return rc; }

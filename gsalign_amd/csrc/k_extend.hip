@@ -302,15 +302,18 @@ int stage7_fill(gsa_ctx *c)
 	seedbase[nfb] = (i32)ns;
 	if (span >= (1ll << 31) - 4096 || 2 * ns >= (1ll << 31) - 4096) return gsa_fail(c, GSA_ERR_LIMIT, "contig too large for 32-bit record / gap offsets");
 	c->nf_ub = 2 * ns; c->span_ub = span;
-	ENS(i32, fb_seedbase, nfb + 1); ENS(i32, fb_sbeg, nfb + 1); ENS(i32, fb_fragbase, nfb + 1);
-	GSA_CHECK(c, hipMemcpyAsync(c->fb_seedbase.p, seedbase, (size_t)(nfb + 1) * 4, hipMemcpyHostToDevice, st));
-	GSA_CHECK(c, hipMemcpyAsync(c->fb_sbeg.p, sbeg, (size_t)nfb * 4, hipMemcpyHostToDevice, st));
+	// (one buffer, one copy: seedbase[nfb + 1] | sbeg[nfb], as they sit in the pinned staging area.  Every GPU operation of a
+	//  contig costs the command processor the same few microseconds whatever it does: a 5 Mb contig is ~65 of them and three
+	//  contigs in flight are bound by exactly that)
+	ENS(i32, fb_seedbase, 2 * (size_t)nfb + 2); ENS(i32, bl_alnlen, 3 * (size_t)nfb + 3);
+	GSA_CHECK(c, hipMemcpyAsync(c->fb_seedbase.p, seedbase, (size_t)(2 * nfb + 1) * 4, hipMemcpyHostToDevice, st));
+	i32 *d_sbeg = c->fb_seedbase.as<i32>() + nfb + 1, *d_fragbase = c->bl_alnlen.as<i32>() + 2 * (size_t)nfb;      // bl_alnlen[nfb] | bl_score[nfb] | fragbase[nfb + 1]
 	const i64 nfu = c->nf_ub;
 	ENS(gsa_frag, f_rec, nfu + 1); ENS(i32, f_type, nfu + 1); ENS(i32, f_mism, nfu + 1); ENS(i32, f_score, nfu + 1); ENS(i32, f_job, nfu + 1); ENS(i32, f_alnlen, nfu + 1);
 	ENS(i32, f_early, nfu + 2);
 	if (c->n_early > 0) GSA_CHECK(c, hipMemsetAsync(c->e_rec.p, 0xff, (size_t)c->n_early * 4, st));      // -1: no record (yet)
-	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), c->fb_sbeg.as<i32>(), c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->e_id.as<i32>(), c->r_orig.as<i32>(),
-	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), c->fb_fragbase.as<i32>(), c->f_early.as<i32>(), c->d_mail.as<i32>() };
+	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), d_sbeg, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->e_id.as<i32>(), c->r_orig.as<i32>(),
+	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), d_fragbase, c->f_early.as<i32>(), c->d_mail.as<i32>() };
 	RC((lb_launch<1>(c, ns, op)));
 	LAUNCH(k_gap_class, nfu, nfu, c->d_mail.as<i32>(), c->f_rec.as<gsa_frag>(), c->d_query.as<uint8_t>(), c->di.ref, c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(),
 	       c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_early.as<i32>(), c->e_rec.as<i32>());
@@ -344,7 +347,8 @@ int stage78_extend(gsa_ctx *c)
 	if (!pin_ensure<gsa_frag>(c, c->p_frags, (size_t)nfu + 1)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipEventRecord(c->ev[19], st)); GSA_CHECK(c, hipStreamWaitEvent(sc, c->ev[19], 0));
 	ENS(uint8_t, d_ops, c->span_ub + 64);
-	ENS(i32, d_flag, nfu + 2); ENS(u32, d_scan, nfu + 2); ENS(u32, d_flag2, nfu + 2); ENS(i32, bl_alnlen, nfb + 1); ENS(i32, bl_score, nfb + 1);
+	ENS(i32, d_flag, nfu + 2); ENS(u32, d_scan, nfu + 2); ENS(u32, d_flag2, nfu + 2);
+	i32 *d_blen = c->bl_alnlen.as<i32>(), *d_bscore = d_blen + nfb, *d_fragbase = d_blen + 2 * (size_t)nfb;      // (one buffer since stage 7: one copy home)
 	Ksw2Launch kl;
 	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub, &kl,
 	                 nullptr, nullptr));
@@ -393,12 +397,11 @@ int stage78_extend(gsa_ctx *c)
 	// per-block sums via prefix sums (the large jobs' records count as zero here, the host adds them from the patch list)
 	u32 *ps_score = c->d_flag2.as<u32>();      // (the small kernel's order array is free again)
 	{ OpRecSums op = { nfu, c_len, c_score, c->d_scan.as<u32>(), ps_score, mail }; RC((lb_launch<2>(c, nfu, op, sx))); }
-	hipLaunchKernelGGL(k_block_sums, dim3(grid_for((size_t)nfb, TPB)), dim3(TPB), 0, sx, nfb, mail + M_NF, c->fb_fragbase.as<i32>(), c->d_scan.as<u32>(), ps_score, c->bl_alnlen.as<i32>(), c->bl_score.as<i32>());
+	hipLaunchKernelGGL(k_block_sums, dim3(grid_for((size_t)nfb, TPB)), dim3(TPB), 0, sx, nfb, mail + M_NF, d_fragbase, c->d_scan.as<u32>(), ps_score, d_blen, d_bscore);
 	if (c->profiling) dp_count_cells(c, (i32)nju, len1, len2, sx);      // (measurement: sum of m*n and m+n over the jobs, read with the final mailbox)
 	i32 *h_len = c->p_blk.as<i32>(), *h_score = h_len + nfb, *h_fragbase = h_score + nfb;
-	GSA_CHECK(c, hipMemcpyAsync(h_len, c->bl_alnlen.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
-	GSA_CHECK(c, hipMemcpyAsync(h_score, c->bl_score.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
-	GSA_CHECK(c, hipMemcpyAsync(h_fragbase, c->fb_fragbase.p, (size_t)nfb * 4, hipMemcpyDeviceToHost, sx));
+	GSA_CHECK(c, hipMemcpyAsync(h_len, d_blen, (size_t)3 * nfb * 4, hipMemcpyDeviceToHost, sx));      // h_len | h_score | h_fragbase
+	(void)h_score; (void)h_fragbase;
 	GSA_CHECK(c, hipEventRecord(c->ev[13], sx));
 	// ---- behind the striped kernels ----
 	GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[17], 0));      // the other strings are written
