@@ -34,7 +34,7 @@ struct OpTakeInBlock {      // seeds that belong to a kept S2 block
 		const i32 p = ex[0];
 		r_q[p] = c_q[i]; r_len[p] = c_len[i]; r_r[p] = c_r[i]; r_bid[p] = c_bid[i]; r_orig[p] = (i32)i;
 	}
-	__device__ void done(const i32 *t) const { mail[M_NR] = t[0]; }
+	__device__ void done(const i32 *t) const { mail[M_NR] = t[0]; for (int k = 0; k < 32; k++) mail[M_ANY + k] = 0; }      // (+ the "a seed died" flags of the overlap rounds: no fill operation in front of them)
 };
 
 // one RemoveOverlaps pass (ProcessCandidateAlignment.cpp:197-226) + its compaction; the seed count
@@ -180,8 +180,7 @@ int stage345_refine(gsa_ctx *c)
 	i32 *lstart = c->a_next.as<i32>(); u32 *ps = c->d_flag.as<u32>();
 	if (!pin_ensure<Leaf>(c, c->p_leaf, (size_t)LEAF_CHUNK)) return GSA_ERR_NOMEM;
 	const size_t first = (size_t)std::min<i64>(ub, LEAF_CHUNK);
-	GSA_CHECK(c, hipMemsetAsync(mail + M_ANY, 0, 32 * sizeof(i32), st));
-	int round = 0, cur = M_NR, oth = M_NR2;
+	int round = 0, cur = M_NR, oth = M_NR2;      // (mail[M_ANY ..] was cleared by the pass above)
 	for (;;) {
 		for (int k = 0; k < 2; k++, round++) {
 			OpOverlapPass op = { c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), c->r_orig.as<i32>(),

@@ -73,6 +73,37 @@ __device__ __forceinline__ int text_match32(u32 r0, u32 r1, u32 r2, i64 tp, i64 
 // matches become seeds.  Query (2-bit packed + N bitmap), memo, exits and on-path
 // bits live in LDS.
 // ---------------------------------------------------------------------------
+// Exclusive prefix of the per-chunk hit counts (n1 = chunks + 1 entries, the last one is 0), by the workgroup that is through
+// LAST in a seed kernel: the counts were stored with agent-scope atomics and are read the same way (the other workgroups ran on
+// other XCDs), eight loads in flight per lane.  Was a rocPRIM scan behind the kernel: two more GPU operations per contig.
+template <int TPB>
+__device__ __forceinline__ void wg_exscan_hits(const i32 *hits, i32 *base, int n1)
+{
+	__shared__ i32 s_ws[TPB / 64], s_run;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (tid == 0) s_run = 0;
+	__syncthreads();
+	for (int b0 = 0; b0 < n1; b0 += TPB * 8) {
+		i32 v[8], tsum = 0;
+#pragma unroll
+		for (int k = 0; k < 8; k++) { const int idx = b0 + tid * 8 + k; v[k] = idx < n1 ? __hip_atomic_load(&hits[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; }
+#pragma unroll
+		for (int k = 0; k < 8; k++) tsum += v[k];
+		i32 inc = tsum;
+		for (int o = 1; o < 64; o <<= 1) { const i32 t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+		if (lane == 63) s_ws[wv] = inc;
+		__syncthreads();
+		i32 wo = 0, tot = 0;
+		for (int w = 0; w < TPB / 64; w++) { const i32 x = s_ws[w]; if (w < wv) wo += x; tot += x; }
+		i32 e = s_run + wo + inc - tsum;
+#pragma unroll
+		for (int k = 0; k < 8; k++) { const int idx = b0 + tid * 8 + k; if (idx < n1) base[idx] = e; e += v[k]; }
+		__syncthreads();
+		if (tid == 0) s_run += tot;
+		__syncthreads();
+	}
+}
+
 #define LHOP_N 512
 __device__ __forceinline__ int memo_get(const uint8_t *memo, const u32 *lhop, int s)
 {
@@ -95,7 +126,7 @@ __device__ __forceinline__ void memo_set(uint8_t *memo, u32 *lhop, int s, int d,
 template <bool COUNT, bool E16>
 __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
-                                                      u32 budget, u32 *heavy_list)
+                                                      u32 budget, u32 *heavy_list, i32 *chunk_base)
 {
 	__shared__ u32 s_ncand, s_queue, s_hits;
 	__shared__ int changed, s_abort;
@@ -330,7 +361,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		if (j == 0) {
 			const u32 hslot = (u32)atomicAdd((unsigned long long *)&cnt[CNT_HEAVY], 1ull);
 			heavy_list[hslot] = (u32)chunk;
-			s_ncand = 0; cand_cnt[chunk] = 0; chunk_hits[chunk] = 0; if (chunk == 0) chunk_hits[gridDim.x] = 0;
+			s_ncand = 0; cand_cnt[chunk] = 0; lb_pub(&chunk_hits[chunk], 0); if (chunk == 0) lb_pub(&chunk_hits[gridDim.x], 0);
 		}
 		__syncthreads();
 	}
@@ -358,7 +389,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		if ((j & 63) == 0 && h) atomicAdd(&s_hits, h);
 		__syncthreads();
 		if (j == 0) {
-			cand_cnt[chunk] = nc; chunk_hits[chunk] = (i32)s_hits; if (chunk == 0) chunk_hits[gridDim.x] = 0; atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand);
+			cand_cnt[chunk] = nc; lb_pub(&chunk_hits[chunk], (i32)s_hits); if (chunk == 0) lb_pub(&chunk_hits[gridDim.x], 0); atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand);
 			if (s_hits) atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)s_hits);      // the contig's total: all the host needs to go on
 		}
 	}
@@ -376,6 +407,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		hcnt[j] = j == CNT_DONE ? 0 : __hip_atomic_load(&cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		cnt[j] = 0;
 	}
+	if (s_last) wg_exscan_hits<SEED_WG>(chunk_hits, chunk_base, (int)gridDim.x + 1);
 }
 
 
@@ -523,7 +555,7 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 // k_seed_wg leaves (so everything downstream is the same).
 __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ chunk_list, u32 n_total_chunks, i32 qlen, const uint16_t *__restrict__ dn_memo, const u32 *__restrict__ dn_lf,
                                                         const u64 *__restrict__ dn_x0, u64 *cnt, i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt,
-                                                        u32 *onpath, i32 *chunk_hits, u64 *hcnt)
+                                                        u32 *onpath, i32 *chunk_hits, u64 *hcnt, i32 *chunk_base)
 {
 	__shared__ uint16_t jmp[2][GSA_CHUNK];
 	__shared__ u32 bits[PATH_WORDS];
@@ -565,7 +597,7 @@ __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ c
 	for (int w = j; w < PATH_WORDS; w += 256) onpath[(size_t)chunk * PATH_WORDS + w] = bits[w];
 	__syncthreads();
 	if (j == 0) {
-		cand_cnt[chunk] = s_n < cand_cap ? s_n : cand_cap; chunk_hits[chunk] = (i32)s_hits; if (slot == 0) chunk_hits[n_total_chunks] = 0;
+		cand_cnt[chunk] = s_n < cand_cap ? s_n : cand_cap; lb_pub(&chunk_hits[chunk], (i32)s_hits); if (slot == 0) lb_pub(&chunk_hits[n_total_chunks], 0);
 		atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_n);
 		if (s_hits) atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)s_hits);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -578,6 +610,7 @@ __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ c
 		hcnt[j] = j == CNT_DONE ? 0 : __hip_atomic_load(&cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		cnt[j] = 0;
 	}
+	if (s_last) wg_exscan_hits<256>(chunk_hits, chunk_base, (int)n_total_chunks + 1);      // (every chunk's count: those of the speculative kernel too)
 }
 
 // ---------------------------------------------------------------------------
@@ -937,7 +970,7 @@ int stage1_seed(gsa_ctx *c)
 		occ_all = 0;
 		if (!dense_all) {
 #define GSA_SEED_ARGS c->di, d_q, qlen, c->prm, cnt, c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, \
-			c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>(), c->h_cnt, budget, c->d_heavy.as<u32>()
+			c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>(), c->h_cnt, budget, c->d_heavy.as<u32>(), c->d_chunk_base.as<i32>()
 			if (c->count_blocks) hipLaunchKernelGGL((k_seed_wg<true, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, GSA_SEED_ARGS);
 			else if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, GSA_SEED_ARGS);
 			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, GSA_SEED_ARGS);
@@ -945,9 +978,7 @@ int stage1_seed(gsa_ctx *c)
 			if (c->profiling || c->prof_seed) hipEventRecord(c->ev[1], st);
 			// (the counters are in pinned memory when the seed kernel is done; the host waits for that, not for the scan of the
 			//  per-chunk hit counts behind it)
-			GSA_CHECK(c, hipEventRecord(c->ev[21], st));
-			int rcs = prim_exscan_i32(c, c->d_chunk_hits.as<i32>(), c->d_chunk_base.as<i32>(), (size_t)n_chunks + 1);
-			if (rcs) return rcs;
+			GSA_CHECK(c, hipEventRecord(c->ev[21], st));      // (the exclusive prefix of the per-chunk hit counts is left by the kernel's last workgroup)
 			GSA_CHECK(c, hipEventSynchronize(c->ev[21]));
 			hits = c->h_cnt[CNT_HITS]; maxcand = c->h_cnt[CNT_CAND]; n_heavy = c->h_cnt[CNT_HEAVY]; occ_all = c->h_cnt[CNT_OCCBLK_ALL];
 			c->dbg[0] = c->h_cnt[11]; c->dbg[1] = n_heavy; c->dbg[2] = c->h_cnt[13]; c->dbg[3] = c->h_cnt[14]; c->dbg[4] = c->h_cnt[15]; c->dbg[5] = c->h_cnt[7];
@@ -963,12 +994,10 @@ int stage1_seed(gsa_ctx *c)
 #undef GSA_DENSE_ARGS
 			hipLaunchKernelGGL(k_dense_resolve, dim3((unsigned)n_heavy), dim3(256), 0, st, list, (u32)n_chunks, qlen, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt,
 			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(),
-			                   c->d_chunk_hits.as<i32>(), c->h_cnt);
+			                   c->d_chunk_hits.as<i32>(), c->h_cnt, c->d_chunk_base.as<i32>());
 			GSA_CHECK(c, hipGetLastError());
 			if (c->profiling || c->prof_seed) hipEventRecord(c->ev[1], st);
-			GSA_CHECK(c, hipEventRecord(c->ev[21], st));
-			int rcs = prim_exscan_i32(c, c->d_chunk_hits.as<i32>(), c->d_chunk_base.as<i32>(), (size_t)n_chunks + 1);
-			if (rcs) return rcs;
+			GSA_CHECK(c, hipEventRecord(c->ev[21], st));      // (the exclusive prefix of the per-chunk hit counts is left by the kernel's last workgroup)
 			GSA_CHECK(c, hipEventSynchronize(c->ev[21]));
 			hits += c->h_cnt[CNT_HITS]; if (c->h_cnt[CNT_CAND] > maxcand) maxcand = c->h_cnt[CNT_CAND]; occ_all += c->h_cnt[CNT_OCCBLK_ALL];
 			if (dense_all) { c->dbg[0] = 0; c->dbg[1] = n_heavy; c->dbg[2] = c->dbg[3] = c->dbg[4] = c->dbg[5] = 0; c->counters[0] = 0; }
