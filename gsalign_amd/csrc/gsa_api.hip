@@ -25,7 +25,7 @@ void collect_events(gsa_ctx *c)
 {
 	if (!c->profiling && !c->prof_seed) { c->ev_pending = 0; return; }
 	float ms;
-	if ((c->ev_pending & 1) && !c->profiling) { if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->kernel_ms[0] = ms; c->ev_pending = 0; (void)hipGetLastError(); return; }
+	if ((c->ev_pending & 1) && !c->profiling) { if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) { c->kernel_ms[0] = ms; c->acc_seed_ms += ms; } c->ev_pending = 0; (void)hipGetLastError(); return; }
 	if (c->ev_pending & 1) {
 		if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->kernel_ms[0] = ms;
 		if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) c->kernel_ms[1] = ms;
@@ -203,7 +203,7 @@ void *gsa_host_alloc(size_t bytes)
 }
 void gsa_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
-int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->profiling = (enable & 1) != 0; c->count_blocks = (enable & 2) != 0; c->prof_seed = (enable & 4) != 0; return GSA_OK; }
+int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->acc_seed_ms = 0.0; c->profiling = (enable & 1) != 0; c->count_blocks = (enable & 2) != 0; c->prof_seed = (enable & 4) != 0; return GSA_OK; }
 
 int gsa_set_query(gsa_ctx *c, const char *query, int32_t qlen)
 {
@@ -401,6 +401,6 @@ int gsa_get_blocks(gsa_ctx *c, gsa_result *out)
 }
 
 int gsa_get_counters(gsa_ctx *c, uint64_t counters[8]) { if (!c) return GSA_ERR_ARG; memcpy(counters, c->counters, sizeof(c->counters)); return GSA_OK; }
-int gsa_get_timings(gsa_ctx *c, float ms[8]) { if (!c) return GSA_ERR_ARG; memcpy(ms, c->kernel_ms, sizeof(c->kernel_ms)); if (getenv("GSA_DEBUG")) fprintf(stderr, "[gsa] seed rounds max %llu, dense chunks %llu, wave iters max %llu; slowest chunk: round 1 %.1f us, resolver %.1f us, up to the marks %.1f us\n", (unsigned long long)c->dbg[0], (unsigned long long)c->dbg[1], (unsigned long long)c->dbg[2], c->dbg[3] * 0.01, c->dbg[4] * 0.01, c->dbg[5] * 0.01); return GSA_OK; }
+int gsa_get_timings(gsa_ctx *c, float ms[8]) { if (!c) return GSA_ERR_ARG; memcpy(ms, c->kernel_ms, sizeof(c->kernel_ms)); if (c->prof_seed && !c->profiling) ms[6] = (float)c->acc_seed_ms; if (getenv("GSA_DEBUG")) fprintf(stderr, "[gsa] seed rounds max %llu, dense chunks %llu, wave iters max %llu; slowest chunk: round 1 %.1f us, resolver %.1f us, up to the marks %.1f us\n", (unsigned long long)c->dbg[0], (unsigned long long)c->dbg[1], (unsigned long long)c->dbg[2], c->dbg[3] * 0.01, c->dbg[4] * 0.01, c->dbg[5] * 0.01); return GSA_OK; }
 
 } // extern "C"

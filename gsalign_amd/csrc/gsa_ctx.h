@@ -44,6 +44,7 @@ struct gsa_ctx {
 	u64 dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	hipEvent_t ev[28];
 	float kernel_ms[8];
+	double acc_seed_ms = 0.0;                      // seed-search kernel time summed over the contigs since gsa_set_profiling (flag bit 2), see gsa_get_timings
 	u64 counters[8];
 
 	// index (device)

@@ -209,7 +209,8 @@ int gsa_get_timings(gsa_ctx *ctx, float kernel_ms[8]);
 /* flags: bit 0 = per-stage hipEvent timing; bit 1 = run the ACCOUNTING build of the seed kernel,
  * which also records, per search, how many Occ blocks the reference's walk reads, so that counters[0]
  * is exact (same seeds either way; the default build leaves counters[0] = 0); bit 2 = time the seed
- * search kernel only (kernel_ms[0]; two events per contig instead of ten). */
+ * search kernel only (kernel_ms[0]; two events per contig instead of ten); kernel_ms[6] is then the SUM of that time over
+ * all contigs since the flag was set (what a benchmark divides by its contig count). */
 int gsa_set_profiling(gsa_ctx *ctx, int flags);
 
 #ifdef __cplusplus

@@ -8,7 +8,7 @@ def show(e, name):
     print(" cnt", e["counters_per_step"])
     print(" terms MB", {k: round(v / 1e6, 1) for k, v in e["roofline"]["terms"].items()}, "B/base", round(e["roofline"]["bytes_per_query_base"], 1))
     for k in e["kernels"]:
-        print("  ", k["kernel"][:44], round(k["ms_per_step"], 3), "ms", round(k["achieved"], 1), "GB/s", "traffic", k["traffic"])
+        print("  ", k["kernel"][:28], round(k["ms_per_step"], 3), "ms", round(k["achieved"], 1), "GB/s", "traffic", k["traffic"])
 show(d, "main"); 
 for e in d.get("extra_workloads", []): show(e, e["workload"])
 if "cpu_baseline" in d: print(d["cpu_baseline"])
