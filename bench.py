@@ -113,7 +113,7 @@ class Runner:
         """Align the contigs of n_steps steps (step_of(n) = flat list of contig buffers in step order) on the contexts:
         gsa_align_many, i.e. one host thread per context inside the library."""
         from gsalign_amd import capi
-        capi.align_many(self.ctx, step_of(n_steps))
+        capi.align_many(self.ctx, step_of(n_steps), in_order=True)      # (in step order: consecutive steps are DIFFERENT query genomes)
 
 
 def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup):

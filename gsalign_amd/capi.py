@@ -91,17 +91,18 @@ def load_library() -> C.CDLL:
 RESULT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(Result))
 
 
-def align_many(aligners, contigs, on_result=None) -> None:
+def align_many(aligners, contigs, on_result=None, in_order: bool = False) -> None:
     """gsa_align_many: `contigs` (uint8 arrays) on the given contexts, one host thread per context inside the library.
-    on_result(contig_index, Result) runs on the worker threads (the Result is valid during the call only)."""
+    on_result(contig_index, Result) runs on the worker threads (the Result is valid during the call only).  in_order: hand
+    the contigs out as listed (GSA_MANY_IN_ORDER) instead of longest first."""
     lib = aligners[0].lib
     n = len(contigs)
     ctxs = (C.c_void_p * len(aligners))(*[a.ctx for a in aligners])
     qs = (C.c_char_p * n)(*[C.cast(c.ctypes.data, C.c_char_p) for c in contigs])
     ql = (C.c_int32 * n)(*[int(c.size) for c in contigs])
     cb = RESULT_FN((lambda user, ci, res: int(on_result(ci, res.contents) or 0)) if on_result else 0)
-    lib.gsa_align_many.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, RESULT_FN, C.c_void_p]
-    rc = lib.gsa_align_many(ctxs, len(aligners), qs, ql, n, cb, None)
+    lib.gsa_align_many.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_uint32, RESULT_FN, C.c_void_p]
+    rc = lib.gsa_align_many(ctxs, len(aligners), qs, ql, n, 1 if in_order else 0, cb, None)
     if rc != 0:
         msgs = [lib.gsa_last_error(a.ctx).decode() for a in aligners]
         raise GsaError(f"gsa_align_many -> {rc}: {'; '.join(m for m in msgs if m)}")

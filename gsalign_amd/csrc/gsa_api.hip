@@ -316,15 +316,16 @@ int gsa_finish_contig(gsa_ctx *c, gsa_result *out)
 	return gsa_get_blocks(c, out);
 }
 
-int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n, gsa_result_fn on_result, void *user)
+int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n, uint32_t flags, gsa_result_fn on_result, void *user)
 {
+	if (flags & ~(uint32_t)GSA_MANY_IN_ORDER) return GSA_ERR_ARG;
 	if (!ctx || n_ctx <= 0 || n < 0 || (n > 0 && (!query || !qlen))) return GSA_ERR_ARG;
 	for (int k = 0; k < n_ctx; k++) if (!ctx[k]) return GSA_ERR_ARG;
 	if (n == 0) return GSA_OK;
 	// longest first: with dynamic hand-out this is the longest-processing-time-first rule
 	std::vector<int32_t> order((size_t)n);
 	for (int32_t i = 0; i < n; i++) order[(size_t)i] = i;
-	std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return qlen[a] > qlen[b]; });
+	if (!(flags & GSA_MANY_IN_ORDER)) std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return qlen[a] > qlen[b]; });
 	std::atomic<int32_t> next(0); std::atomic<int> err(GSA_OK);
 	auto loop = [&](gsa_ctx *c) {
 		for (;;) {

@@ -145,7 +145,7 @@ int main(int argc, char *argv[])
 	for (size_t ci = 0; ci < qs.size(); ci++) { qptr[ci] = qs[ci].seq.data(); qlen[ci] = (int32_t)qs[ci].seq.size(); }
 	struct Sink { std::vector<ContigResult> *out; } sink = { &results };
 	auto on_result = [](void *user, int32_t ci, const gsa_result *res) -> int { (*((Sink *)user)->out)[(size_t)ci].assign(*res); return 0; };
-	if (gsa_align_many(ctxs.data(), (int32_t)ctxs.size(), qptr.data(), qlen.data(), (int32_t)qs.size(), on_result, &sink) != GSA_OK) {
+	if (gsa_align_many(ctxs.data(), (int32_t)ctxs.size(), qptr.data(), qlen.data(), (int32_t)qs.size(), 0, on_result, &sink) != GSA_OK) {
 		for (gsa_ctx *c : ctxs) if (*gsa_last_error(c)) fprintf(stderr, "GPU error: %s\n", gsa_last_error(c));
 		return 2;
 	}

@@ -132,8 +132,9 @@ int gsa_align_contig(gsa_ctx *ctx, const char *query, int32_t qlen, gsa_result *
  * on_result(user, contig, res) is called by the worker that finished `contig`, possibly from several threads at once;
  * *res is valid during the callback only.  Returns the first error (the failing context holds the text). */
 typedef int (*gsa_result_fn)(void *user, int32_t contig, const gsa_result *res);
+#define GSA_MANY_IN_ORDER 1u   /* hand the contigs out in the order given (default: longest first) */
 int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n,
-                   gsa_result_fn on_result, void *user);
+                   uint32_t flags, gsa_result_fn on_result, void *user);
 
 /* ---- one long contig on several GPUs ---------------------------------------
  * IdentifyLocalMEM hands 10 000-bp chunks of the contig to whichever thread is free (GSAlign.cpp:61-94) and seeds never
