@@ -46,7 +46,7 @@ struct OpSlots {
 	{
 		i32 k, s, n; slot(i, k, s, n);
 		const i32 p = ex[0];
-		if (i == seedbase[k]) fragbase[k] = p;
+		if (i == seedbase[k]) { fragbase[k] = p; fragbase[k - 2 * (i64)nfb] = 0; fragbase[k - (i64)nfb] = 0; }      // (+ the block's aln_len / score sums start at 0: bl_alnlen[nfb] | bl_score[nfb] | fragbase[] is one buffer)
 		gsa_frag f; f.bseed = 1; f.qpos = q[s]; f.qlen = len[s]; f.rlen = len[s]; f.rpos = r[s]; f.aln_off = 0; f.aln_len = 0; f._pad = 0;
 		frag[p] = f; ftype[p] = FT_SEED; fmism[p] = 0; fearly[p] = -1;
 		if (v[0] == 2) {
@@ -108,14 +108,6 @@ struct OpDpJobs {
 		fjob[i] = j;
 	}
 	__device__ void done(const i32 *t) const { mail[M_NJOB] = t[0]; mail[M_NALN] = t[1]; }
-};
-
-// prefix sums of the records' (aln_len, score) contributions, 32-bit wrapping (only differences over a block are used)
-struct OpRecSums {
-	i64 n; const i32 *c_len, *c_score; u32 *ps_len, *ps_score; i32 *mail;
-	__device__ i32 value(i64 i, int c) const { if (i >= mail[M_NF]) return 0; return c == 0 ? c_len[i] : c_score[i]; }
-	__device__ void emit(i64 i, const i32 *, const i32 *ex) const { ps_len[i] = (u32)ex[0]; ps_score[i] = (u32)ex[1]; }
-	__device__ void done(const i32 *t) const { ps_len[n] = (u32)t[0]; ps_score[n] = (u32)t[1]; }
 };
 
 // one DP record written by a whole 256-thread workgroup: 256 positions per pass, prefix counts of the
@@ -262,11 +254,34 @@ __global__ void __launch_bounds__(256) k_materialize_large(i32 nlarge, const i32
 	if (threadIdx.x == 0) { patch[3 * g] = (i32)i; patch[3 * g + 1] = L; patch[3 * g + 2] = sc; }
 }
 
-__global__ void k_block_sums(i32 nfb, const i32 *__restrict__ nf_ptr, const i32 *__restrict__ fragbase, const u32 *__restrict__ ps_len, const u32 *__restrict__ ps_score, i32 *bl_len, i32 *bl_score)
+// Per-block sums of the records' (aln_len, score) contributions: four records per thread, a workgroup whose 1 024 records lie in
+// one block adds its total with one atomic per sum, the few workgroups that straddle a block edge add per record.  (Was a
+// two-component look-back scan over all records + a difference kernel: at 4 M records the scan's tile chain took 1 ms.)
+#define BR_PER 4
+__global__ void __launch_bounds__(256) k_block_reduce(i32 nfb, const i32 *__restrict__ nf_ptr, const i32 *__restrict__ fragbase, const i32 *__restrict__ c_len, const i32 *__restrict__ c_score,
+                                                       i32 *bl_len, i32 *bl_score)
 {
-	GID(nfb);
-	const i64 b = fragbase[i], e = (i + 1 < nfb) ? fragbase[i + 1] : nf_ptr[0];
-	bl_len[i] = (i32)(ps_len[e] - ps_len[b]); bl_score[i] = (i32)(ps_score[e] - ps_score[b]);
+	__shared__ i32 s_len[4], s_sc[4];
+	const i64 nf = nf_ptr[0];
+	const i64 w0 = (i64)blockIdx.x * 256 * BR_PER;
+	if (w0 >= nf) return;
+	const i64 w1 = w0 + 256 * BR_PER < nf ? w0 + 256 * BR_PER : nf;
+	const i32 kf = find_block(fragbase, nfb, w0), kl = find_block(fragbase, nfb, w1 - 1);
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (kf == kl) {
+		i32 l = 0, sc = 0;
+#pragma unroll
+		for (int k = 0; k < BR_PER; k++) { const i64 i = w0 + (i64)k * 256 + tid; if (i < w1) { l += c_len[i]; sc += c_score[i]; } }
+		for (int o = 32; o; o >>= 1) { l += __shfl_xor(l, o); sc += __shfl_xor(sc, o); }
+		if (lane == 0) { s_len[wv] = l; s_sc[wv] = sc; }
+		__syncthreads();
+		if (tid == 0) { atomicAdd(&bl_len[kf], s_len[0] + s_len[1] + s_len[2] + s_len[3]); atomicAdd(&bl_score[kf], s_sc[0] + s_sc[1] + s_sc[2] + s_sc[3]); }
+	} else {
+		for (int k = 0; k < BR_PER; k++) {
+			const i64 i = w0 + (i64)k * 256 + tid;
+			if (i < w1) { const i32 b = find_block(fragbase, nfb, i); const i32 l = c_len[i], sc = c_score[i]; if (l) atomicAdd(&bl_len[b], l); if (sc) atomicAdd(&bl_score[b], sc); }
+		}
+	}
 }
 
 i64 frags_count(gsa_ctx *c)
@@ -347,7 +362,7 @@ int stage78_extend(gsa_ctx *c)
 	if (!pin_ensure<gsa_frag>(c, c->p_frags, (size_t)nfu + 1)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipEventRecord(c->ev[19], st)); GSA_CHECK(c, hipStreamWaitEvent(sc, c->ev[19], 0));
 	ENS(uint8_t, d_ops, c->span_ub + 64);
-	ENS(i32, d_flag, nfu + 2); ENS(u32, d_scan, nfu + 2); ENS(u32, d_flag2, nfu + 2);
+	ENS(i32, d_flag, nfu + 2);
 	i32 *d_blen = c->bl_alnlen.as<i32>(), *d_bscore = d_blen + nfb, *d_fragbase = d_blen + 2 * (size_t)nfb;      // (one buffer since stage 7: one copy home)
 	Ksw2Launch kl;
 	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub, &kl,
@@ -394,10 +409,8 @@ int stage78_extend(gsa_ctx *c)
 		GSA_CHECK(c, hipMemcpyAsync((char *)c->p_tail.p + t_aln1, d_aln1, t_total - t_aln1, hipMemcpyDeviceToHost, sc));
 		GSA_CHECK(c, hipEventRecord(c->ev[23], sc));
 	}
-	// per-block sums via prefix sums (the large jobs' records count as zero here, the host adds them from the patch list)
-	u32 *ps_score = c->d_flag2.as<u32>();      // (the small kernel's order array is free again)
-	{ OpRecSums op = { nfu, c_len, c_score, c->d_scan.as<u32>(), ps_score, mail }; RC((lb_launch<2>(c, nfu, op, sx))); }
-	hipLaunchKernelGGL(k_block_sums, dim3(grid_for((size_t)nfb, TPB)), dim3(TPB), 0, sx, nfb, mail + M_NF, d_fragbase, c->d_scan.as<u32>(), ps_score, d_blen, d_bscore);
+	// per-block sums (the large jobs' records count as zero here, the host adds them from the patch list)
+	hipLaunchKernelGGL(k_block_reduce, dim3((unsigned)((nfu + 256 * BR_PER - 1) / (256 * BR_PER))), dim3(256), 0, sx, nfb, mail + M_NF, d_fragbase, c_len, c_score, d_blen, d_bscore);
 	if (c->profiling) dp_count_cells(c, (i32)nju, len1, len2, sx);      // (measurement: sum of m*n and m+n over the jobs, read with the final mailbox)
 	i32 *h_len = c->p_blk.as<i32>(), *h_score = h_len + nfb, *h_fragbase = h_score + nfb;
 	GSA_CHECK(c, hipMemcpyAsync(h_len, d_blen, (size_t)3 * nfb * 4, hipMemcpyDeviceToHost, sx));      // h_len | h_score | h_fragbase
