@@ -197,6 +197,7 @@ __global__ void __launch_bounds__(64 * TINY_WAVES) k_dp_tiny(i32 n_jobs, const i
 struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; };
 #define DP_TILE_ROWS 160        // local diagonals of a traceback tile (64 diagonal steps need 128); a multiple of 8
 #define DP_STRIPE_BYTES(M) ((((size_t)(M) + 63 + 7) >> 3) << 8)      // (M + 63) anti-diagonals of 64 nibbles, in blocks of eight
+#define DP_C1_PAD 320           // code bytes around the reference fragment: 128 "N" rows in front (stripe B starts 64 steps late, lane 63 another 63), the rest behind
 #define DP_TILE_SLACK 16        // the prefetched tile reaches this far past the predicted entry
 #ifndef DP_G
 #define DP_G 8               // boundary rows per hand-off block (4, 8 or 16)
@@ -227,16 +228,24 @@ struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; }
 #define DP_CLASS_MIN_JOBS 4096
 #define DP_LDS_M 3072         // longest reference fragment for which four stripes share a workgroup (3 boundary columns in LDS)
 
+// packed 16-bit arithmetic on the two halves of a register, spelled out: the compiler rewrites min(x, 1) and friends into
+// per-half compares and selects (five instructions for one)
+#define PK2(NAME, INS) __device__ __forceinline__ u32 NAME(u32 a, u32 b) { u32 d; asm(INS " %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+PK2(pk_add, "v_pk_add_u16") PK2(pk_sub, "v_pk_sub_u16") PK2(pk_max, "v_pk_max_u16") PK2(pk_min, "v_pk_min_u16")
+__device__ __forceinline__ u32 pk_sub_sat(u32 a, u32 b) { u32 d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }      // max(a - b, 0)
+__device__ __forceinline__ u32 pk_mad(u32 a, u32 b, u32 c) { u32 d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ u32 pk_shl(u32 a, u32 sh) { u32 d; asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(d) : "v"(sh), "v"(a)); return d; }
+
 template <int WPB>
 __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ blk2job, const StripeJob *__restrict__ sjobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
                                                    const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2, uint8_t *dirbase, u32 *bndbase, u32 *ctr,
                                                    uint8_t *revbase, uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, u32 ep, i32 lds_c1, i32 lds_rows, u32 *err, i32 tick_slot)
 {
-	extern __shared__ __attribute__((aligned(16))) int8_t C1[];        // the reference fragment as nt4 codes
+	extern __shared__ __attribute__((aligned(16))) u32 C2[];           // the reference fragment as byte selectors of the two stripes' score tables
 	// The traceback tile ALIASES the forward pass's LDS (codes + boundary columns): the wave that walks back drew the last
 	// ticket of its job, so every stripe of the job -- every other wave of this workgroup -- is through with them.  LDS
 	// per workgroup is what limits how many jobs (and which other kernels of the contig) a CU holds.
-	uint8_t *tile = (uint8_t *)C1;
+	uint8_t *tile = (uint8_t *)C2;
 	// The LARGEST jobs are the contig's latency floor (the list is sorted by cells: they are the first workgroups): their
 	// waves issue ahead of whatever else shares the SIMD.  The mass of smaller jobs behind them does not get that: on a
 	// 50 Mb contig they are 10 000 workgroups, and at raised priority they starve the record / small-DP path beside them
@@ -251,157 +260,191 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	__syncthreads();
 	const u32 bid = s_bid;
 	if (bid < 96) __builtin_amdgcn_s_setprio(3);
-	// which job / stripe am I (uniform).  Both tables are read where the host wrote them (pinned memory): two dependent
-	// reads across the link cost less than a copy operation in front of the launch
+	// which job / pair of stripes am I (uniform).  Both tables are read where the host wrote them (pinned memory): two
+	// dependent reads across the link cost less than a copy operation in front of the launch
 	const StripeJob sj = sjobs[blk2job[bid]];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int p = ((int)bid - sj.first_block) * WPB + wave, m = sj.m, n = sj.n, P = sj.P;
+	const int m = sj.m, n = sj.n, P = sj.P, PP = (P + 1) >> 1;
+	const int pp = ((int)bid - sj.first_block) * WPB + wave;            // stripes 2pp ("A", low halves) and 2pp + 1 ("B", high halves)
 	const uint8_t *s1 = pool1 + off1[sj.job], *s2 = pool2 + off2[sj.job];
 	const size_t pitch = (size_t)DP_STRIPE_BYTES(m);                    // direction nibbles of one stripe: 256 bytes per eight anti-diagonals
-	const int mpad64 = (m + 64 + 63) & ~63;                             // C1 is readable one 64-row block past the end
+	const int nblk = (m + 63 + 7) >> 3;                                 // ... in so many blocks
 	uint8_t *dir = dirbase + sj.diroff;
-	u32 *bnd_in = bndbase + sj.bndoff + (size_t)(p - 1) * m, *bnd_out = bndbase + sj.bndoff + (size_t)p * m;
-	// C1[64 + j] = 4 x nt4 code of reference row j (bit offset into the score table), 16 = "N" for the 64 rows in front and
-	// the rows behind: lane l reads its row rl - l of every anti-diagonal straight from here (one ds_read_u8 per cell; the
-	// DPP chain that carried the code up one lane per diagonal cost three VALU instructions per diagonal)
-	for (int t = threadIdx.x; t < 64; t += 64 * WPB) C1[t] = 16;
-	for (int t = threadIdx.x; t < m; t += 64 * WPB) C1[64 + t] = (int8_t)(gsa_nt4(s1[t]) << 2);
-	for (int t = m + threadIdx.x; t < mpad64; t += 64 * WPB) C1[64 + t] = 16;
-	// WPB > 1: the stripes of one workgroup hand their boundary column over through LDS (same granules, tag 0 = not yet)
-	u32 *lds_bnd = (u32 *)(C1 + lds_c1);
+	u32 *bnd_in = bndbase + sj.bndoff + (size_t)(pp - 1) * m, *bnd_out = bndbase + sj.bndoff + (size_t)pp * m;
+	// C2[128 + j] = v_perm selector of step-row j: byte 0 = code of reference row j (stripe A's table: bytes 0-3 of the pair),
+	// byte 2 = 4 + code of row j - 64 (stripe B lags 64 steps: its table is bytes 4-7), 0x0c ("constant 0") for N and for
+	// the rows in front of and behind the fragment, and in bytes 1, 3.  On step s lane l reads entry s - l.
+	{
+		int fe = (m + DP_C1_PAD + 63) & ~63; fe = fe < (lds_c1 >> 2) ? fe : (lds_c1 >> 2);
+		for (int t = threadIdx.x; t < fe; t += 64 * WPB) {
+			const int j = t - 128, jb = j - 64;
+			const u32 ca = (j >= 0 && j < m) ? (u32)gsa_nt4(s1[j]) : 4u, cb = (jb >= 0 && jb < m) ? (u32)gsa_nt4(s1[jb]) : 4u;
+			C2[t] = (ca < 4 ? ca : 0x0cu) | 0x0c000c00u | ((cb < 4 ? 4u + cb : 0x0cu) << 16);
+		}
+	}
+	// WPB > 1: the waves of one workgroup hand their boundary column over through LDS (same granules, tag 0 = not yet)
+	u32 *lds_bnd = C2 + (lds_c1 >> 2);
 	if (WPB > 1) for (int t = threadIdx.x; t < (WPB - 1) * lds_rows; t += 64 * WPB) lds_bnd[t] = 0;
 	u32 *lin = lds_bnd + (size_t)(wave > 0 ? wave - 1 : 0) * lds_rows, *lout = lds_bnd + (size_t)(wave < WPB - 1 ? wave : 0) * lds_rows;
 	const bool out_lds = WPB > 1 && wave < WPB - 1;
-	const int t = p * 64 + lane;
-	const int Wp = n - p * 64 < 64 ? n - p * 64 : 64;
-	const int cq = t < n ? gsa_nt4(s2[t]) : 4;
-	// z = score + q + e as a 4-bit table over the reference code (ksw2_alignment.cpp:74-95: match 1, mismatch -1, N 0)
-	u32 tbl = 0;
+	// TWO STRIPES PER WAVE, as the two 16-bit halves of every register: u, v, x, y are 0 ... 7 + q + e, so the recurrence runs on
+	// packed 16-bit instructions (v_pk_add / max / min / sub: one instruction for both cells).  Stripe B lags 64 steps behind A:
+	// on step s lane l holds A's cell (row s - l, column 128 pp + l) and B's cell (row s - 64 - l, column 128 pp + 64 + l), and
+	// B's lane 0 takes its left neighbour -- A's lane 63, one step earlier -- from a readlane.
+	const int tA = pp * 128 + lane, tB = tA + 64;
+	const bool hasB = 2 * pp + 1 < P;
+	const int WpB = !hasB ? 0 : (n - pp * 128 - 64 < 64 ? n - pp * 128 - 64 : 64);
+	const int WpA = n - pp * 128 < 64 ? n - pp * 128 : 64;
+	const int cqA = tA < n ? gsa_nt4(s2[tA]) : 4, cqB = tB < n ? gsa_nt4(s2[tB]) : 4;
+	// z = score + q + e (ksw2_alignment.cpp:74-95: match 1, mismatch -1, N 0 -> 7, 5, 6) as a byte table over the reference
+	// code, stored XOR 6 so that the selector's "constant 0" is the N row: z = v_perm(tables, selector) ^ 6 in both halves
+	u32 tblA = 0, tblB = 0;
 #pragma unroll
-	for (int cc = 0; cc < 5; cc++) tbl |= (u32)((cq == 4 || cc == 4) ? 6 : (cq == cc ? 7 : 5)) << (4 * cc);
-	int u = t ? 2 : 0, y = 0;
+	for (int cc = 0; cc < 4; cc++) {
+		tblA |= (u32)(cqA == 4 ? 0 : (cqA == cc ? 7 ^ 6 : 5 ^ 6)) << (8 * cc);
+		tblB |= (u32)(cqB == 4 ? 0 : (cqB == cc ? 7 ^ 6 : 5 ^ 6)) << (8 * cc);
+	}
+	const u32 uinit2 = (tA ? 2u : 0u) | (2u << 16);
+	u32 u2 = uinit2, y2 = 0;
 	u32 bin = 0, gnext = 0;
 	__syncthreads();
-	if (p >= P) return;                                 // (a workgroup's spare waves only helped to stage the fragment)
-	const int nl = m + Wp - 1;
+	if (pp >= PP) return;                               // (a workgroup's spare waves only helped to stage the fragment)
+	const int S_end = hasB ? 64 + m + WpB - 1 : m + WpA - 1;      // steps of this wave
 	DPT(const unsigned long long T0c = wall_clock64();)
-	u32 *dirp = (u32 *)(dir + (size_t)p * pitch);
+	u32 *dirA = (u32 *)(dir + (size_t)(2 * pp) * pitch), *dirB = (u32 *)(dir + (size_t)(2 * pp + 1) * pitch);
 	// boundary granules are fetched ONE BLOCK AHEAD (8 rows per block) so their L2 latency overlaps the block before
-	if (p > 0) {
+	if (pp > 0) {
 		const int row = (lane & (DP_G - 1)) < m ? (lane & (DP_G - 1)) : m - 1;
 		gnext = (WPB > 1 && wave > 0) ? __hip_atomic_load(&lin[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(&bnd_in[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	asm volatile("" :: "v"(gnext));                      // the first prefetch is complete before the loop: inside it, waits then only count stores issued after a prefetch
-	const int jjoff = lane < Wp ? lane : 0x40000000;    // lanes beyond the stripe never become valid
-	const bool pub_stripe = p < P - 1;                  // (then Wp == 64 and lane 63 owns the boundary column)
-	int dlast = 0, dacc = 0;
-	// blocks of 16 anti-diagonals [rl0, rl0 + 16) on which every lane of a full stripe has a cell: 63 <= rl0, rl0 + 15 < m
-	const int full_lo = Wp == 64 ? 63 : 0x7fffffff, full_hi = m - 15;
-	int pk = 0;                                         // x | v << 8 of my column after the current diagonal
-	int hist = 0;                                       // lane 63 - q: pk of lane 63 q diagonals ago (boundary rows travel one lane down per diagonal)
-	// one anti-diagonal; K2 is the position inside the 16-row block (a literal in the unrolled body)
+	const bool pub_stripe = pp < PP - 1;                // (then stripe B is full and its lane 63 owns the boundary column)
+	u32 pk2 = 0;                                        // x | v << 8 of my two columns after the current step: bytes xA, vA, xB, vB
+	u32 hb = 0;                                         // lanes 0-7: stripe B's boundary column (x | v << 8 of its lane 63), the eight rows of the current block
+	const u32 selx = lane ? 0x0c060c04u : 0x0c040c00u, selv = lane ? 0x0c070c05u : 0x0c050c01u;      // x, v of (lane - 1 | boundary, A's lane 63) from (rotated pairs, boundary row)
+	u32 acc = 0, r0 = 0;                   // direction nibbles of the last four steps (per half, oldest on top); those of the four before
+	const u32 c1 = 0x00010001u, c2 = 0x00020002u, c4 = 0x00040004u, c7 = 0x00070007u, c16 = 0x00100010u;
+	// one step; K2 is the position inside the 16-step block (a literal in the unrolled body).  GUARD = 1: the first 128 steps (lanes
+	// that have not reached row 0 yet are put back to the initial state after every step) and the last blocks (stripe A's
+	// direction blocks have an end).  Nothing masks the cells a lane computes outside the matrix -- rows >= m, columns >= n:
+	// their values only ever reach other such cells, and their direction nibbles are never read.
+// lane K of HB takes the wave-uniform VAL (v_writelane_b32; K a literal / not)
+#define DP_WL_LIT(HB, VAL, K) asm("v_writelane_b32 %0, %1, %2" : "+v"(HB) : "s"(VAL), "n"(K));
+#define DP_WL_VAR(HB, VAL, K) if (lane == (K)) HB = (VAL);
 #define DP_LOADG(MODE, ROW) ((MODE) == 2 ? __hip_atomic_load(&lin[ROW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(&bnd_in[ROW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-#define DP_STEP(K2, MODE, WREF, MASKED)                                                                              \
+#define DP_STEP(K2, MODE, WSEL, GUARD, WL)                                                                       \
 	{                                                                                                           \
-		const int rl_ = rl0 + (K2);                                                                             \
-		if (((K2) & (DP_G - 1)) == 0) {                                                                                  \
-			if ((MODE) == 0) bin = (rl_ == 0 && lane == 0) ? 0u : 0x200u;    /* t = 0 boundary: x1 = 0, v1 = q, except for the very first cell (:157-164) */ \
-			else if (rl_ < m) {                                                                                 \
-				/* boundary rows rl_ .. rl_+DP_G-1 from stripe p-1: spin until every granule carries its tag */       \
-				const int row = rl_ + (lane & (DP_G - 1));                                                               \
-				const bool need = lane < DP_G && row < m;                                                          \
+		const int s_ = s0 + (K2);                                                                               \
+		if (((K2) & (DP_G - 1)) == 0) {                                                                         \
+			if ((MODE) == 0) bin = (s_ == 0 && lane == 0) ? 0u : 0x200u;    /* t = 0 boundary: x1 = 0, v1 = q, except for the very first cell (:157-164) */ \
+			else if (s_ < m) {                                                                                  \
+				/* boundary rows s_ .. s_+DP_G-1 from the pair in front: spin until every granule carries its tag */ \
+				const int row = s_ + (lane & (DP_G - 1));                                                       \
+				const bool need = lane < DP_G && row < m;                                                       \
 				u32 g = gnext;                                                                                  \
 				if (!__all(!need || (g >> 16) == ep)) {      /* (first look outside the loop: its wait only covers the prefetch) */ \
 					u32 spins = 0; const unsigned long long t_wait0 = wall_clock64();                          \
 					do {                                                                                        \
 						if ((++spins & 255) == 0 && (wall_clock64() - t_wait0 > DP_WAIT_TICKS || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; } \
 						__builtin_amdgcn_s_sleep(1);                                                            \
-						if (need) g = DP_LOADG(MODE, row);                                                          \
+						if (need) g = DP_LOADG(MODE, row);                                                      \
 					} while (!__all(!need || (g >> 16) == ep));                                                  \
 				}                                                                                               \
 				bin = g & 0xffffu;                                                                              \
 				/* every lane loads (clamped row): an unconditional load lands in gnext without a copy that would wait for it */ \
 				const int rown = row + DP_G < m ? row + DP_G : m - 1;                                           \
-				gnext = DP_LOADG(MODE, rown);                                                                     \
+				gnext = DP_LOADG(MODE, rown);                                                                   \
 			}                                                                                                   \
 		}                                                                                                       \
-		const int packed = wave_shr1(pk, __builtin_amdgcn_readlane((int)bin, (K2) & (DP_G - 1)));                            \
-		const int jj = rl_ - jjoff;                                                                             \
-		if (!(MASKED) || (unsigned)jj < (unsigned)m) {                                                          \
-			const int x1 = packed & 0xff, v1 = packed >> 8;                                                     \
-			int z = (int)__builtin_amdgcn_ubfe(tbl, (u32)(WREF), 4u);                                           \
-			int a = x1 + v1, b = y + u;                                                                         \
-			int d = a > z ? 1 : 0; z = z > a ? z : a;                                                           \
-			if (b > z) d = 2;                                                                                   \
-			z = z > b ? z : b;                                                                                  \
-			z = z < 7 ? z : 7;                                                                                  \
-			const int un = z - v1, vn = z - u;                                                                  \
-			z -= 2; a -= z; b -= z;                                                                             \
-			a = a > 0 ? a : 0; b = b > 0 ? b : 0;       /* x, y; the "x / y is positive" flags (0x08, 0x10 of ksw2) sit at bits 2, 3 */ \
-			d |= ((a < 1 ? a : 1) << 2) | ((b < 1 ? b : 1) << 3);                                               \
-			u = un; y = b; pk = a | (vn << 8); dlast = d;                                                       \
+		/* left neighbours: lane l-1's pair; lane 0 takes (boundary row of A | A's lane 63 for B) */               \
+		/* left neighbours: the pairs rotate one lane up (DPP wave_ror:1); lane 0 -- its own byte selectors -- takes the   \
+		   boundary row for A and A's lane 63 (row s_ - 64, computed one step ago) for B */                          \
+		const u32 bin0 = (u32)__builtin_amdgcn_readlane((int)bin, (K2) & (DP_G - 1));                           \
+		const u32 rot = (u32)__builtin_amdgcn_mov_dpp((int)pk2, 0x13C, 0xf, 0xf, true);                         \
+		WL(hb, (u32)__builtin_amdgcn_readlane((int)pk2, 63) >> 16, (K2) & 7)      /* B's lane 63: boundary row s_ - 128 */ \
+		const u32 x1 = __builtin_amdgcn_perm(rot, bin0, selx), v1 = __builtin_amdgcn_perm(rot, bin0, selv);     \
+		const u32 z0 = __builtin_amdgcn_perm(tblB, tblA, (WSEL)) ^ 0x00060006u;                                 \
+		const u32 a = pk_add(x1, v1), b = pk_add(y2, u2);                                                       \
+		const u32 z1 = pk_max(z0, a), z2 = pk_max(z1, b);                                                       \
+		const u32 ta = pk_min(pk_sub(z1, z0), c1), tb = pk_min(pk_sub(z2, z1), c1);      /* a > z; b > max(z, a): the direction is tb ? 2 : ta */ \
+		const u32 zc = pk_min(z2, c7);                                                                          \
+		const u32 un = pk_sub(zc, v1), vn = pk_sub(zc, u2), zz = pk_sub(zc, c2);                                \
+		const u32 xa = pk_sub_sat(a, zz), yb = pk_sub_sat(b, zz);                                               /* x, y */ \
+		const u32 fa = pk_min(xa, c1), fb = pk_min(yb, c1);                                                     /* the "x / y is positive" flags (0x08, 0x10 of ksw2) */ \
+		/* direction NIBBLES ta | tb << 1 | fa << 2 | fb << 3, four steps per 16-bit half, eight steps per stored dword: the wave \
+		   stores 256 bytes per stripe and eight steps (a byte store per step kept the address unit busier than the ALU) */ \
+		acc = pk_mad(acc, c16, pk_mad(pk_mad(fb, c2, fa), c4, pk_mad(tb, c2, ta)));                             \
+		u2 = un; y2 = yb;                                                                                       \
+		pk2 = __builtin_amdgcn_perm(vn, xa, 0x06020400u);      /* bytes xA, vA, xB, vB (values outside the matrix may not fit a byte: cut, not carried into the neighbour) */ \
+		if (GUARD) {                                                                                            \
+			const u32 keep = (lane <= s_ ? 0xffffu : 0u) | (lane <= s_ - 64 ? 0xffff0000u : 0u);               \
+			u2 = (u2 & keep) | (uinit2 & ~keep); y2 &= keep;                                                    \
 		}                                                                                                       \
-		/* direction NIBBLES, eight anti-diagonals per dword: lane l keeps the flags of its cells on diagonals 8b .. 8b+7 in   \
-		   one register and the wave stores 256 bytes per eight diagonals (a byte store per diagonal kept the address unit \
-		   busier than the ALU: -25 % kernel time measured without them).  Stored by every lane, cells outside the matrix   \
-		   are never read; straight-line, so the vmcnt bookkeeping of the boundary prefetch stays exact */ \
-		dacc = (int)__builtin_amdgcn_alignbit((u32)dlast, (u32)dacc, 4);                                          \
-		if (((K2) & 7) == 7) { DPX_STORE(rowp[(((K2) >> 3) << 6) + lane] = (u32)dacc;) }                          \
-		hist = __builtin_amdgcn_update_dpp(pk, hist, 0x130, 0xf, 0xf, false);      /* wave_shl:1, lane 63 takes pk */ \
-		if (((K2) & (DP_G - 1)) == DP_G - 2 && pub_stripe && rl_ >= 62 + DP_G) {                                                       \
-			/* rows rl_-62-DP_G .. rl_-63 of the boundary column are complete: one store of DP_G tagged granules */ \
-			const int row = rl_ - 126 + lane;                                                                   \
-			if (lane >= 64 - DP_G && row < m) {                                                                 \
-				if (out_lds) __hip_atomic_store(&lout[row], (ep << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-				else __hip_atomic_store(&bnd_out[row], (ep << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+		if (((K2) & 7) == 3) r0 = acc;                                                                  \
+		if (((K2) & 7) == 7) {                                                                                  \
+			const int blk = s_ >> 3;                                                                            \
+			if (!(GUARD) || blk < nblk) { DPX_STORE(dirA[((size_t)blk << 6) + lane] = __builtin_amdgcn_perm(acc, r0, 0x05040100u);) } \
+			if (hasB && (!(GUARD) || (blk >= 8 && blk - 8 < nblk))) { DPX_STORE(dirB[((size_t)(blk - 8) << 6) + lane] = __builtin_amdgcn_perm(acc, r0, 0x07060302u);) } \
+		}                                                                                                       \
+		if (((K2) & 7) == 7 && pub_stripe && s_ >= 135) {                                                       \
+			/* rows s_-135 .. s_-128 of B's boundary column are complete: one store of eight tagged granules */   \
+			const int row = s_ - 135 + lane;                                                                    \
+			if (lane < 8 && row < m) {                                                                          \
+				if (out_lds) __hip_atomic_store(&lout[row], (ep << 16) | hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+				else __hip_atomic_store(&bnd_out[row], (ep << 16) | hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
 			}                                                                                                   \
 		}                                                                                                       \
 	}
-	// (two copies of the loop: stripe 0 has no boundary loads in flight, and keeping it apart keeps its waits off the stores)
+	// (three copies of the loop: the first pair has no boundary loads in flight, and keeping it apart keeps its waits off the stores)
 #define DP_LOOP(MODE)                                                                                           \
-	for (int rl0 = 0; rl0 < nl; rl0 += 16) {                                                                    \
-		const int8_t *crow = C1 + 64 + rl0 - lane;             /* my reference row on diagonal rl0 */              \
-		u32 *rowp = dirp + ((size_t)(rl0 >> 3) << 6);                                                           \
-		if (rl0 + 16 <= nl) {                                                                                   \
-			int w16[16];                                                                                        \
-			_Pragma("unroll") for (int k2 = 0; k2 < 16; k2++) w16[k2] = crow[k2];                                 \
-			if (rl0 >= full_lo && rl0 < full_hi) {                                                              \
-				/* every lane has a cell on each of these 16 anti-diagonals (the steady state of a long stripe): no lane mask, \
-				   no register copies around it */                                                              \
-				DP_STEP(0, MODE, w16[0], 0) DP_STEP(1, MODE, w16[1], 0) DP_STEP(2, MODE, w16[2], 0) DP_STEP(3, MODE, w16[3], 0) DP_STEP(4, MODE, w16[4], 0) DP_STEP(5, MODE, w16[5], 0) DP_STEP(6, MODE, w16[6], 0) DP_STEP(7, MODE, w16[7], 0) \
-				DP_STEP(8, MODE, w16[8], 0) DP_STEP(9, MODE, w16[9], 0) DP_STEP(10, MODE, w16[10], 0) DP_STEP(11, MODE, w16[11], 0) DP_STEP(12, MODE, w16[12], 0) DP_STEP(13, MODE, w16[13], 0) DP_STEP(14, MODE, w16[14], 0) DP_STEP(15, MODE, w16[15], 0) \
+	for (int s0 = 0; s0 < S_end; s0 += 16) {                                                                    \
+		const u32 *crow = C2 + 128 + s0 - lane;                /* my selectors from step s0 on */                  \
+		if (s0 + 16 <= S_end) {                                                                                 \
+			u32 w[16];                                                                                          \
+			_Pragma("unroll") for (int k2 = 0; k2 < 16; k2++) w[k2] = crow[k2];                                   \
+			if (s0 >= 128 && s0 + 16 <= 8 * nblk) {                                                             \
+				/* the steady state of a long stripe pair: every lane is under way, every direction block exists */ \
+				DP_STEP(0, MODE, w[0], 0, DP_WL_LIT) DP_STEP(1, MODE, w[1], 0, DP_WL_LIT) DP_STEP(2, MODE, w[2], 0, DP_WL_LIT) DP_STEP(3, MODE, w[3], 0, DP_WL_LIT) DP_STEP(4, MODE, w[4], 0, DP_WL_LIT) DP_STEP(5, MODE, w[5], 0, DP_WL_LIT) DP_STEP(6, MODE, w[6], 0, DP_WL_LIT) DP_STEP(7, MODE, w[7], 0, DP_WL_LIT) \
+				DP_STEP(8, MODE, w[8], 0, DP_WL_LIT) DP_STEP(9, MODE, w[9], 0, DP_WL_LIT) DP_STEP(10, MODE, w[10], 0, DP_WL_LIT) DP_STEP(11, MODE, w[11], 0, DP_WL_LIT) DP_STEP(12, MODE, w[12], 0, DP_WL_LIT) DP_STEP(13, MODE, w[13], 0, DP_WL_LIT) DP_STEP(14, MODE, w[14], 0, DP_WL_LIT) DP_STEP(15, MODE, w[15], 0, DP_WL_LIT) \
 			} else {                                                                                            \
-				DP_STEP(0, MODE, w16[0], 1) DP_STEP(1, MODE, w16[1], 1) DP_STEP(2, MODE, w16[2], 1) DP_STEP(3, MODE, w16[3], 1) DP_STEP(4, MODE, w16[4], 1) DP_STEP(5, MODE, w16[5], 1) DP_STEP(6, MODE, w16[6], 1) DP_STEP(7, MODE, w16[7], 1) \
-				DP_STEP(8, MODE, w16[8], 1) DP_STEP(9, MODE, w16[9], 1) DP_STEP(10, MODE, w16[10], 1) DP_STEP(11, MODE, w16[11], 1) DP_STEP(12, MODE, w16[12], 1) DP_STEP(13, MODE, w16[13], 1) DP_STEP(14, MODE, w16[14], 1) DP_STEP(15, MODE, w16[15], 1) \
+				DP_STEP(0, MODE, w[0], 1, DP_WL_LIT) DP_STEP(1, MODE, w[1], 1, DP_WL_LIT) DP_STEP(2, MODE, w[2], 1, DP_WL_LIT) DP_STEP(3, MODE, w[3], 1, DP_WL_LIT) DP_STEP(4, MODE, w[4], 1, DP_WL_LIT) DP_STEP(5, MODE, w[5], 1, DP_WL_LIT) DP_STEP(6, MODE, w[6], 1, DP_WL_LIT) DP_STEP(7, MODE, w[7], 1, DP_WL_LIT) \
+				DP_STEP(8, MODE, w[8], 1, DP_WL_LIT) DP_STEP(9, MODE, w[9], 1, DP_WL_LIT) DP_STEP(10, MODE, w[10], 1, DP_WL_LIT) DP_STEP(11, MODE, w[11], 1, DP_WL_LIT) DP_STEP(12, MODE, w[12], 1, DP_WL_LIT) DP_STEP(13, MODE, w[13], 1, DP_WL_LIT) DP_STEP(14, MODE, w[14], 1, DP_WL_LIT) DP_STEP(15, MODE, w[15], 1, DP_WL_LIT) \
 			}                                                                                                   \
 		} else {                                                                                                \
-			for (int k2 = 0; rl0 + k2 < nl; k2++) DP_STEP(k2, MODE, crow[k2], 1)                                   \
-			/* the last, partial dword of the stripe */                                                         \
-			if (nl & 7) { DPX_STORE(dirp[((size_t)(nl >> 3) << 6) + lane] = (u32)dacc >> (4 * (8 - (nl & 7)));) }   \
+			for (int k2 = 0; s0 + k2 < S_end; k2++) DP_STEP(k2, MODE, crow[k2], 1, DP_WL_VAR)                                 \
 		}                                                                                                       \
 	}
-	if (p == 0) { DP_LOOP(0) } else if (WPB > 1 && wave > 0) { DP_LOOP(2) } else { DP_LOOP(1) }
+	if (pp == 0) { DP_LOOP(0) } else if (WPB > 1 && wave > 0) { DP_LOOP(2) } else { DP_LOOP(1) }
 #undef DP_LOOP
 #undef DP_STEP
 #undef DP_LOADG
+	if (S_end & 7) {
+		// the last, partial dwords of the two stripes
+		if (S_end & 3) acc = pk_shl(acc, (u32)(4 * (4 - (S_end & 3))) * 0x00010001u);
+		if ((S_end & 7) < 4) r0 = acc;
+		const int blk = S_end >> 3;
+		if (blk < nblk) { DPX_STORE(dirA[((size_t)blk << 6) + lane] = __builtin_amdgcn_perm(acc, r0, 0x05040100u);) }
+		if (hasB && blk >= 8 && blk - 8 < nblk) { DPX_STORE(dirB[((size_t)(blk - 8) << 6) + lane] = __builtin_amdgcn_perm(acc, r0, 0x07060302u);) }
+	}
 	if (pub_stripe) {
-		// the last (partial) block of boundary rows: lane 63 - q holds row m-1-q
-		const int row = m - 64 + lane;
-		if (lane >= 64 - DP_G && row >= 0) {
-			if (out_lds) __hip_atomic_store(&lout[row], (ep << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			else __hip_atomic_store(&bnd_out[row], (ep << 16) | (u32)(hist & 0xffff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		// the last (partial) block of boundary rows: row m - 1 is lane 63's value after the last step (S_end = m + 127 here)
+		if (lane == (S_end & 7)) hb = (u32)__builtin_amdgcn_readlane((int)pk2, 63) >> 16;
+		const int row = (S_end & ~7) - 128 + lane;
+		if (lane <= (S_end & 7) && row >= 0 && row < m) {
+			if (out_lds) __hip_atomic_store(&lout[row], (ep << 16) | hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			else __hip_atomic_store(&bnd_out[row], (ep << 16) | hb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
-	DPT(if (p == 0 && lane == 0) ctr[sj.ctr + 40] = (u32)(wall_clock64() - T0c); if (p == P - 1 && lane == 0) ctr[sj.ctr + 41] = (u32)(wall_clock64() - T0c);)
-	// ---- ticket: the last stripe to finish does the traceback ----
-	// A job whose stripes all sit in THIS workgroup (n <= 64 WPB: 14 of the 22 thousand striped jobs of a human-sized contig)
+	DPT(if (pp == 0 && lane == 0) ctr[sj.ctr + 40] = (u32)(wall_clock64() - T0c); if (pp == PP - 1 && lane == 0) ctr[sj.ctr + 41] = (u32)(wall_clock64() - T0c);)
+	// ---- ticket: the last wave to finish does the traceback ----
+	// A job whose stripes all sit in THIS workgroup (n <= 128 WPB: most of the 22 thousand striped jobs of a human-sized contig)
 	// synchronises at workgroup scope with an LDS ticket; agent scope -- stripes in workgroups on other XCDs, whose L2s are not
 	// coherent with each other -- means an L2 write-back per stripe and an invalidate in front of the traceback.
-	// Longer jobs: the stripes of a workgroup first count themselves in LDS, only the last one of each workgroup pays the
-	// agent-scope release and draws the job's global ticket (one per workgroup instead of one per stripe).
-	const bool one_wg = WPB > 1 && P <= WPB;
-	const int first_p = ((int)bid - sj.first_block) * WPB;                 // stripes of this workgroup: first_p .. first_p + mine - 1
-	const int mine = P - first_p < WPB ? P - first_p : WPB, n_wg = (P + WPB - 1) / WPB;
+	// Longer jobs: the waves of a workgroup first count themselves in LDS, only the last one of each workgroup pays the
+	// agent-scope release and draws the job's global ticket (one per workgroup instead of one per wave).
+	const bool one_wg = WPB > 1 && PP <= WPB;
+	const int first_p = ((int)bid - sj.first_block) * WPB;                 // pairs of this workgroup: first_p .. first_p + mine - 1
+	const int mine = PP - first_p < WPB ? PP - first_p : WPB, n_wg = (PP + WPB - 1) / WPB;
 	u32 ticket = 0;
 	if (WPB > 1) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -416,7 +459,7 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		if (lane == 0) ticket = __hip_atomic_fetch_add(&ctr[sj.ctr], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		ticket = (u32)__builtin_amdgcn_readfirstlane((int)ticket);
-		if ((int)ticket != (WPB > 1 ? n_wg : P) - 1) return;
+		if ((int)ticket != (WPB > 1 ? n_wg : PP) - 1) return;
 		if (lane == 0) ctr[sj.ctr] = 0;                                     // (nobody else looks again: the counters stay clean for the next launch)
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	}
@@ -483,7 +526,10 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 			const int lc2 = lc + dlc, rl2 = rl + drl;
 			const bool valid = lane < 3 * DP_LOOK && lc2 >= 0 && rl2 >= rl_lo && rl2 - lc2 >= 0;
 			u32 tmp = 0xffu;
-			if (valid) { const u32 nb = (tile32[(((rl2 - rl_lo) >> 3) << 6) + lc2] >> ((rl2 & 7) << 2)) & 15u; tmp = (nb & 3u) | ((nb & 0xCu) << 1); }      // back to ksw2's flag byte
+			if (valid) {      // back to ksw2's flag byte (nibble of step k: half k / 4, oldest on top)
+				const u32 nb = (tile32[(((rl2 - rl_lo) >> 3) << 6) + lc2] >> ((((rl2 & 7) >> 2) << 4) + ((3 - (rl2 & 3)) << 2))) & 15u;
+				tmp = ((nb & 2u) ? 2u : (nb & 1u)) | ((nb & 0xCu) << 1);
+			}
 			const u32 cur = (u32)__builtin_amdgcn_readfirstlane((int)tmp);
 			// the automaton of ksw_backtrack (:38-52) for the current cell ...
 			int S = state;
@@ -587,7 +633,7 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		auto it = std::stable_partition(large.begin(), large.end(), [](const LgJob &g) { return g.m > DP_CLASS_M; });
 		n_hi = (size_t)(it - large.begin());
 	}
-	for (const LgJob &g : large) if (((g.m + 64 + 63) & ~63) + 64 > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 153600 bases");
+	for (const LgJob &g : large) if ((((g.m + 63) & ~63) + DP_C1_PAD) * 4 > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 38000 bases");
 	const i64 budget = 12ll << 30;
 	size_t first = 0;
 	while (first < large.size()) {
@@ -604,12 +650,12 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		for (Seg &sg : seg) {
 			sg.mmax = 1;
 			for (size_t k = sg.b; k < sg.e; k++) if (large[k].m > sg.mmax) sg.mmax = large[k].m;
-			sg.mpad = ((sg.mmax + 64 + 63) & ~63) + 64;      // + the 64 "N" rows in front (see the kernel)
-			sg.wpb = sg.mmax <= DP_LDS_M ? 4 : 1;      // reference fragments up to DP_LDS_M bases: four stripes per workgroup, boundary columns through LDS
+			sg.mpad = ((sg.mmax + 63) & ~63) + DP_C1_PAD;      // + the "N" rows in front and behind (see the kernel)
+			sg.wpb = sg.mmax <= DP_LDS_M ? 4 : 1;      // reference fragments up to DP_LDS_M bases: four waves (eight stripes) per workgroup, boundary columns through LDS
 			sg.lds_rows = (sg.mmax + 15) & ~15;
-			sg.dyn_lds = (size_t)sg.mpad + (sg.wpb > 1 ? (size_t)(sg.wpb - 1) * sg.lds_rows * 4 : 0);
+			sg.dyn_lds = (size_t)sg.mpad * 4 + (sg.wpb > 1 ? (size_t)(sg.wpb - 1) * sg.lds_rows * 4 : 0);      // (one selector dword per row)
 			if (sg.dyn_lds < (size_t)DP_TILE_ROWS * 32) sg.dyn_lds = (size_t)DP_TILE_ROWS * 32;      // (the traceback tile -- nibbles -- lives in the same bytes)
-			for (size_t k = sg.b; k < sg.e; k++) nb_ub += (size_t)(((large[k].n + 63) / 64 + sg.wpb - 1) / sg.wpb);
+			for (size_t k = sg.b; k < sg.e; k++) nb_ub += (size_t)((((large[k].n + 63) / 64 + 1) / 2 + sg.wpb - 1) / sg.wpb);      // (a wave takes two stripes)
 		}
 		if (!pin_ensure<char>(c, psj, (cnt + 1) * sizeof(StripeJob) + (nb_ub + 2) * 4)) return GSA_ERR_NOMEM;
 		StripeJob *sj = psj.as<StripeJob>();
@@ -624,7 +670,7 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 				s.diroff = dbytes; dbytes += cells + 128;
 				s.bndoff = bwords; bwords += (i64)(s.P - 1) * g.m;
 				s.ctr = nctr++; s.first_block = sg.nblocks;
-				for (int b = 0; b < (s.P + sg.wpb - 1) / sg.wpb; b++) sg.b2j[sg.nblocks++] = (i32)(k - first);
+				for (int b = 0; b < ((s.P + 1) / 2 + sg.wpb - 1) / sg.wpb; b++) sg.b2j[sg.nblocks++] = (i32)(k - first);
 				sj[k - first] = s;
 			}
 			b2j_used += (size_t)sg.nblocks;
@@ -646,8 +692,8 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		for (int si = 0; si < 2; si++) {
 			const Seg &sg = seg[si];
 			if (sg.nblocks == 0) continue;
-			if (sg.wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)sg.nblocks), dim3(256), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)sg.mpad, (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
-			else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)sg.nblocks), dim3(64), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)sg.mpad, (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
+			if (sg.wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)sg.nblocks), dim3(256), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
+			else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)sg.nblocks), dim3(64), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
 		}
 		GSA_CHECK(c, hipGetLastError());
 		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""gsa_ksw2_batch against the oracle's ksw2 restatement on random pairs of many shapes (GPU box).
+Shapes are chosen around the striped kernel's edges: query lengths around multiples of 64 and 128 (one wave
+takes two 64-column stripes), very short and very long reference sides, N bases, identical and unrelated pairs.
+usage: dp_fuzz.py [pairs] [seed]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from gsalign_amd import capi
+from oracle import oracle_py
+
+
+def make_pairs(npairs, seed):
+    rng = np.random.default_rng(seed)
+    edge = [1, 2, 3, 16, 17, 63, 64, 65, 66, 127, 128, 129, 130, 191, 192, 193, 255, 256, 257, 319, 320, 321, 383, 384, 385, 448, 511, 512, 513, 640, 700]
+    s1, s2 = [], []
+    for i in range(npairs):
+        kind = i % 8
+        n = int(edge[rng.integers(len(edge))]) if kind < 5 else int(rng.integers(1, 900))
+        if kind == 0: m = int(rng.integers(1, 8))
+        elif kind == 1: m = int(rng.integers(100, 140))
+        elif kind == 2: m = n
+        elif kind == 3: m = max(1, n + int(rng.integers(-20, 21)))
+        elif kind == 4: m = int(rng.integers(1, 1500))
+        else: m = max(1, int(n * rng.uniform(0.5, 1.6)))
+        if m + n - 1 <= 128 and n <= 64 and i % 3: m = 129 + int(rng.integers(0, 300))      # (mostly jobs of the striped kernel)
+        a = rng.integers(0, 4, m).astype(np.uint8)
+        mode = int(rng.integers(0, 6))
+        if mode == 0: b = rng.integers(0, 4, n).astype(np.uint8)                                # unrelated
+        else:
+            # b = a with substitutions and indels, cut / padded to n
+            out = []; j = 0; d = (0.02, 0.08, 0.2, 0.4, 0.0)[mode - 1]
+            while j < m and len(out) < n:
+                r = rng.random()
+                if r < d * 0.6: out.append((int(a[j]) + 1 + int(rng.integers(0, 3))) & 3); j += 1
+                elif r < d * 0.8: out.extend(rng.integers(0, 4, int(rng.integers(1, 12))).tolist())
+                elif r < d: j += int(rng.integers(1, 12))
+                else: out.append(int(a[j])); j += 1
+            out = out[:n]
+            while len(out) < n: out.append(int(rng.integers(0, 4)))
+            b = np.array(out, dtype=np.uint8)
+        A = np.frombuffer(b"ACGT", dtype=np.uint8)[a].copy(); B = np.frombuffer(b"ACGT", dtype=np.uint8)[b].copy()
+        if i % 11 == 0:
+            A[rng.integers(0, m, max(1, m // 30))] = ord("N")
+            B[rng.integers(0, n, max(1, n // 30))] = ord("N")
+        s1.append(A.tobytes()); s2.append(B.tobytes())
+    return s1, s2
+
+
+def main():
+    npairs = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    oracle_py.build(ref=False)
+    s1, s2 = make_pairs(npairs, seed)
+    g = capi.Aligner.for_leaf_operators() if hasattr(capi.Aligner, "for_leaf_operators") else None
+    if g is None:
+        import gzip, shutil, tempfile
+        from gsalign_amd import indexio
+        tmp = tempfile.mkdtemp()
+        for ext in ("bwt", "sa", "pac", "ann", "amb"):
+            with gzip.open(os.path.join(ROOT, "tests", "golden", f"small.{ext}.gz"), "rb") as a, open(os.path.join(tmp, f"small.{ext}"), "wb") as b:
+                shutil.copyfileobj(a, b)
+        g = capi.Aligner(indexio.load_index(os.path.join(tmp, "small")))
+    bad = 0
+    for rep in range(2):      # (twice: the second call reuses buffers, counters and the boundary epoch)
+        ops = g.ksw2_batch(s1, s2)
+        for i in range(npairs):
+            a1, a2 = oracle_py.oracle_ksw2(s1[i], s2[i])
+            if capi.apply_ops(s1[i], s2[i], ops[i]) != (a1, a2):
+                bad += 1
+                if bad <= 10: print(f"MISMATCH rep {rep} pair {i}: m={len(s1[i])} n={len(s2[i])}", flush=True)
+    print(f"dp_fuzz: {npairs} pairs x 2 calls, seed {seed}: {bad} mismatches")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
