@@ -226,7 +226,7 @@ struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; }
 #define DP_WAIT_TICKS 200000000ull   // bound of a hand-off wait: 2 s of the 100 MHz wall clock
 #define DP_CLASS_M 768          // size classes of a long job list: reference fragments above / up to this (see launch_stripes)
 #define DP_CLASS_MIN_JOBS 4096
-#define DP_LDS_M 3072         // longest reference fragment for which four stripes share a workgroup (3 boundary columns in LDS)
+#define DP_LDS_M 3968         // longest reference fragment for which four waves share a workgroup (selectors + 3 boundary columns in 64 KB of LDS)
 
 // packed 16-bit arithmetic on the two halves of a register, spelled out: the compiler rewrites min(x, 1) and friends into
 // per-half compares and selects (five instructions for one)
@@ -628,10 +628,16 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 	// all of them are small.  Long lists are therefore launched as two kernels, back to back on the stream: fragments
 	// above DP_CLASS_M first (the critical ones), the rest behind them with a quarter of the LDS.  Short lists (a bacterial
 	// contig: 700 jobs) stay one launch -- there the second kernel would only wait for the longest job of the first.
-	size_t n_hi = large.size();
-	if (large.size() >= DP_CLASS_MIN_JOBS) {
-		auto it = std::stable_partition(large.begin(), large.end(), [](const LgJob &g) { return g.m > DP_CLASS_M; });
-		n_hi = (size_t)(it - large.begin());
+	// (in front of both: the few fragments above DP_LDS_M, whose boundary columns do not fit LDS -- one wave per workgroup, hand-off
+	//  through HBM; they used to drag the whole upper class down to that layout)
+	size_t n_xl = 0, n_hi = large.size();
+	{
+		auto it0 = std::stable_partition(large.begin(), large.end(), [](const LgJob &g) { return g.m > DP_LDS_M; });
+		n_xl = (size_t)(it0 - large.begin());
+		if (large.size() >= DP_CLASS_MIN_JOBS) {
+			auto it = std::stable_partition(it0, large.end(), [](const LgJob &g) { return g.m > DP_CLASS_M; });
+			n_hi = (size_t)(it - large.begin());
+		}
 	}
 	for (const LgJob &g : large) if ((((g.m + 63) & ~63) + DP_C1_PAD) * 4 > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 38000 bases");
 	const i64 budget = 12ll << 30;
@@ -643,9 +649,9 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		else { size_t l = first; i64 db = 128; while (l < large.size()) { const i64 cells = (((i64)large[l].n + 63) / 64) * (i64)DP_STRIPE_BYTES(large[l].m); if (l > first && db + cells > budget) break; db += cells + 128; l++; } cnt = l - first; }
 		// (the early launch and a late one may be in flight together: each has its own table)
 		DevBuf &psj = err_slot == M_DPERR3 ? c->p_sj_early : c->p_sj;
-		// the one or two segments of this batch: [first, split) above the class limit, [split, first + cnt) below
-		const size_t split = std::min(std::max(n_hi, first), first + cnt);
-		struct Seg { size_t b, e; int mmax, wpb, mpad, lds_rows; size_t dyn_lds; i32 *b2j; i32 nblocks; } seg[2] = { { first, split }, { split, first + cnt } };
+		// the segments of this batch: [first, s0) above DP_LDS_M, [s0, s1) above the class limit, [s1, first + cnt) below
+		const size_t s0 = std::min(std::max(n_xl, first), first + cnt), s1 = std::min(std::max(n_hi, first), first + cnt);
+		struct Seg { size_t b, e; int mmax, wpb, mpad, lds_rows; size_t dyn_lds; i32 *b2j; i32 nblocks; } seg[3] = { { first, s0 }, { s0, s1 }, { s1, first + cnt } };
 		size_t nb_ub = 0;
 		for (Seg &sg : seg) {
 			sg.mmax = 1;
@@ -660,7 +666,7 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		if (!pin_ensure<char>(c, psj, (cnt + 1) * sizeof(StripeJob) + (nb_ub + 2) * 4)) return GSA_ERR_NOMEM;
 		StripeJob *sj = psj.as<StripeJob>();
 		i32 *b2j_all = (i32 *)(sj + cnt + 1);
-		i64 dbytes = 128, bwords = 0; i32 nctr = 2; size_t b2j_used = 0;      // (ctr[0], ctr[1]: launch tickets of the two size classes)
+		i64 dbytes = 128, bwords = 0; i32 nctr = 3; size_t b2j_used = 0;      // (ctr[0 .. 2]: launch tickets of the size classes)
 		for (Seg &sg : seg) {
 			sg.b2j = b2j_all + b2j_used; sg.nblocks = 0;
 			for (size_t k = sg.b; k < sg.e; k++) {
@@ -689,11 +695,19 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		if (c->d_dp_ctr.cap != ctr_cap0 || c->dp_dirty) { GSA_CHECK(c, hipMemsetAsync(ctr, 0, c->d_dp_ctr.cap, st)); GSA_CHECK(c, hipMemsetAsync(mail + err_slot, 0, 4, st)); c->dp_dirty = false; }
 		// (the two classes back to back on one stream.  Side by side on two streams -- the few long jobs at raised priority --
 		//  was measured at 250 Mb: same step time, the refinement passes beside them starve instead: the chip is busy either way)
-		for (int si = 0; si < 2; si++) {
+		const StripeJob *k_sj = sj; const i32 *k_b2j0 = b2j_all;
+		{ static const bool sjdev = getenv("GSA_SJ_DEV") != nullptr;
+		  if (sjdev && err_slot != M_DPERR3) {
+			const size_t bytes = (cnt + 1) * sizeof(StripeJob) + (nb_ub + 2) * 4;
+			char *d = dev_ensure<char>(c, c->d_dp_jobs, bytes); if (!d) return GSA_ERR_NOMEM;
+			GSA_CHECK(c, hipMemcpyAsync(d, sj, bytes, hipMemcpyHostToDevice, st));
+			k_sj = (const StripeJob *)d; k_b2j0 = (const i32 *)(d + (cnt + 1) * sizeof(StripeJob));
+		  } }
+		for (int si = 0; si < 3; si++) {
 			const Seg &sg = seg[si];
 			if (sg.nblocks == 0) continue;
-			if (sg.wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)sg.nblocks), dim3(256), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
-			else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)sg.nblocks), dim3(64), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
+			if (sg.wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)sg.nblocks), dim3(256), sg.dyn_lds, st, k_b2j0 + (sg.b2j - b2j_all), k_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
+			else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)sg.nblocks), dim3(64), sg.dyn_lds, st, k_b2j0 + (sg.b2j - b2j_all), k_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
 		}
 		GSA_CHECK(c, hipGetLastError());
 		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })

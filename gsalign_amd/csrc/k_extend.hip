@@ -254,34 +254,46 @@ __global__ void __launch_bounds__(256) k_materialize_large(i32 nlarge, const i32
 	if (threadIdx.x == 0) { patch[3 * g] = (i32)i; patch[3 * g + 1] = L; patch[3 * g + 2] = sc; }
 }
 
-// Per-block sums of the records' (aln_len, score) contributions: four records per thread, a workgroup whose 1 024 records lie in
-// one block adds its total with one atomic per sum, the few workgroups that straddle a block edge add per record.  (Was a
-// two-component look-back scan over all records + a difference kernel: at 4 M records the scan's tile chain took 1 ms.)
+// Per-block sums of the records' (aln_len, score) contributions.  BR_WGS workgroups, each over one contiguous range of the
+// records in tiles of 1 024: while the tiles lie in one block the workgroup keeps the sums in registers and adds them with one
+// atomic pair when the block changes (a contig has a handful of blocks: one atomic per tile made 4 000 workgroups queue
+// on two addresses, 0.7 ms); the few tiles that straddle a block edge add per record.
+// (Was a two-component look-back scan over all records + a difference kernel: at 4 M records the scan's tile chain took 1 ms.)
 #define BR_PER 4
+#define BR_WGS 512
 __global__ void __launch_bounds__(256) k_block_reduce(i32 nfb, const i32 *__restrict__ nf_ptr, const i32 *__restrict__ fragbase, const i32 *__restrict__ c_len, const i32 *__restrict__ c_score,
                                                        i32 *bl_len, i32 *bl_score)
 {
 	__shared__ i32 s_len[4], s_sc[4];
 	const i64 nf = nf_ptr[0];
-	const i64 w0 = (i64)blockIdx.x * 256 * BR_PER;
-	if (w0 >= nf) return;
-	const i64 w1 = w0 + 256 * BR_PER < nf ? w0 + 256 * BR_PER : nf;
-	const i32 kf = find_block(fragbase, nfb, w0), kl = find_block(fragbase, nfb, w1 - 1);
+	const i64 tiles = (nf + 256 * BR_PER - 1) / (256 * BR_PER), per = (tiles + gridDim.x - 1) / gridDim.x;
+	const i64 t_beg = (i64)blockIdx.x * per, t_end = t_beg + per < tiles ? t_beg + per : tiles;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	if (kf == kl) {
-		i32 l = 0, sc = 0;
-#pragma unroll
-		for (int k = 0; k < BR_PER; k++) { const i64 i = w0 + (i64)k * 256 + tid; if (i < w1) { l += c_len[i]; sc += c_score[i]; } }
+	i32 cur = -1, l = 0, sc = 0;                 // the block the running sums belong to (uniform); per-thread partial sums
+	auto flush = [&]() {
+		if (cur < 0) return;
 		for (int o = 32; o; o >>= 1) { l += __shfl_xor(l, o); sc += __shfl_xor(sc, o); }
 		if (lane == 0) { s_len[wv] = l; s_sc[wv] = sc; }
 		__syncthreads();
-		if (tid == 0) { atomicAdd(&bl_len[kf], s_len[0] + s_len[1] + s_len[2] + s_len[3]); atomicAdd(&bl_score[kf], s_sc[0] + s_sc[1] + s_sc[2] + s_sc[3]); }
-	} else {
-		for (int k = 0; k < BR_PER; k++) {
-			const i64 i = w0 + (i64)k * 256 + tid;
-			if (i < w1) { const i32 b = find_block(fragbase, nfb, i); const i32 l = c_len[i], sc = c_score[i]; if (l) atomicAdd(&bl_len[b], l); if (sc) atomicAdd(&bl_score[b], sc); }
+		if (tid == 0) { atomicAdd(&bl_len[cur], s_len[0] + s_len[1] + s_len[2] + s_len[3]); atomicAdd(&bl_score[cur], s_sc[0] + s_sc[1] + s_sc[2] + s_sc[3]); }
+		__syncthreads();
+		l = 0; sc = 0;
+	};
+	for (i64 t = t_beg; t < t_end; t++) {
+		const i64 w0 = t * 256 * BR_PER, w1 = w0 + 256 * BR_PER < nf ? w0 + 256 * BR_PER : nf;
+		const i32 kf = find_block(fragbase, nfb, w0), kl = find_block(fragbase, nfb, w1 - 1);
+		if (kf == kl) {
+			if (kf != cur) { flush(); cur = kf; }
+#pragma unroll
+			for (int k = 0; k < BR_PER; k++) { const i64 i = w0 + (i64)k * 256 + tid; if (i < w1) { l += c_len[i]; sc += c_score[i]; } }
+		} else {
+			for (int k = 0; k < BR_PER; k++) {
+				const i64 i = w0 + (i64)k * 256 + tid;
+				if (i < w1) { const i32 b = find_block(fragbase, nfb, i); const i32 l1 = c_len[i], s1 = c_score[i]; if (l1) atomicAdd(&bl_len[b], l1); if (s1) atomicAdd(&bl_score[b], s1); }
+			}
 		}
 	}
+	flush();
 }
 
 i64 frags_count(gsa_ctx *c)
@@ -410,7 +422,8 @@ int stage78_extend(gsa_ctx *c)
 		GSA_CHECK(c, hipEventRecord(c->ev[23], sc));
 	}
 	// per-block sums (the large jobs' records count as zero here, the host adds them from the patch list)
-	hipLaunchKernelGGL(k_block_reduce, dim3((unsigned)((nfu + 256 * BR_PER - 1) / (256 * BR_PER))), dim3(256), 0, sx, nfb, mail + M_NF, d_fragbase, c_len, c_score, d_blen, d_bscore);
+	{ const i64 tiles_ub = (nfu + 256 * BR_PER - 1) / (256 * BR_PER);
+	  hipLaunchKernelGGL(k_block_reduce, dim3((unsigned)(tiles_ub < BR_WGS ? tiles_ub : BR_WGS)), dim3(256), 0, sx, nfb, mail + M_NF, d_fragbase, c_len, c_score, d_blen, d_bscore); }
 	if (c->profiling) dp_count_cells(c, (i32)nju, len1, len2, sx);      // (measurement: sum of m*n and m+n over the jobs, read with the final mailbox)
 	i32 *h_len = c->p_blk.as<i32>(), *h_score = h_len + nfb, *h_fragbase = h_score + nfb;
 	GSA_CHECK(c, hipMemcpyAsync(h_len, d_blen, (size_t)3 * nfb * 4, hipMemcpyDeviceToHost, sx));      // h_len | h_score | h_fragbase
