@@ -8,8 +8,8 @@
 //    up per anti-diagonal with DPP wave shifts (systolic array); direction bytes
 //    and the traceback stay in LDS.  No barrier, no global traffic but the result.
 //  * k_dp_stripe  everything else (up to 5000 x 5000): the target columns are cut
-//    into 64-wide stripes, one wavefront per stripe on its own CU, boundary columns
-//    handed over through HBM; see the comment at the kernel.
+//    into 64-wide stripes, one wavefront per PAIR of stripes (packed 16-bit VALU),
+//    boundary columns handed over through LDS / HBM; see the comment at the kernel.
 #include <algorithm>
 #include <cstring>
 #include "gsa_ctx.h"
@@ -169,28 +169,35 @@ __global__ void __launch_bounds__(64 * TINY_WAVES) k_dp_tiny(i32 n_jobs, const i
 
 // ---------------------------------------------------------------------------
 // k_dp_stripe: every alignment that does not fit the small kernel.  The n target
-// columns are cut into stripes of 64; ONE WAVEFRONT PER STRIPE, on whatever CU the
-// dispatcher picks, so a 1.5k x 1.5k problem runs on ~25 CUs instead of one.
-// Stripe p sweeps its own anti-diagonals (local diagonal rl: lane l handles row
-// rl - l), state in registers, left neighbour by a DPP wave shift.  The only
-// inter-stripe dependency is the (x,v) pair of stripe p-1's last column per row;
-// it is handed over through HBM as self-validating 4-byte granules {tag,x|v<<8}
-// written and read with agent-scope relaxed atomics (write-through / L1-bypassing,
-// so no fence and no separate flag; the tag is a 16-bit launch epoch, so the granules
-// need no clearing between launches).
-// The boundary column travels down a second DPP chain and is published 8 rows at a
-// time (one 32-byte store); stripe p fetches 8 rows per poll, one block ahead.
-// Direction bytes go to HBM STRIPE-LOCAL: stripe p owns (m+63) rows of 64 bytes,
-// row = local diagonal, byte = lane -- one coalesced 64-byte store per step with a
-// scalar base, and every traceback tile is one contiguous block.
-// The stripe that finishes last (agent-scope release/acquire around a ticket
-// counter) runs the traceback.  It keeps a DP_TILE_ROWS x 64 tile of the current
-// stripe in LDS and walks it RUN BY RUN: the lanes look ahead along the three
-// possible directions (21 cells each) in one LDS read, a ballot gives the length
+// columns are cut into stripes of 64; ONE WAVEFRONT PER PAIR OF STRIPES, the pairs of a
+// job on whatever CUs the dispatcher picks (four pairs per workgroup), so a 1.5k x 1.5k
+// problem runs on a dozen SIMDs instead of one.
+// A wave keeps stripe 2pp in the low 16-bit halves of its registers and stripe 2pp+1, 64
+// steps behind, in the high halves: the state (u, v, x, y <= 7 + q + e) fits, and the whole
+// recurrence is packed 16-bit VALU (v_pk_add/sub/max/min/mad_u16: one instruction for both
+// cells, 29 VALU instructions per step = 14.5 per cell; the one-stripe version had 34).
+// On step s lane l handles rows s - l (A) and s - 64 - l (B); the left neighbours arrive by
+// one DPP wave rotate of the packed (x | v << 8) pairs, unpacked with per-lane v_perm
+// selectors that give lane 0 the boundary row (A) and A's lane 63 (B).  The substitution
+// score is a v_perm over two 4-byte tables (one per stripe: my query base against A, C, G,
+// T) with a selector per reference row staged in LDS.
+// The only dependency between waves is the (x,v) pair of stripe 2pp+1's last column per row:
+// it is handed over as self-validating 4-byte granules {tag,x|v<<8}, through LDS inside a
+// workgroup and through HBM between workgroups (agent-scope relaxed atomics: write-through /
+// L1-bypassing, so no fence and no separate flag; the tag is a 16-bit launch epoch, so the
+// granules need no clearing between launches), 8 rows per store; the consumer fetches 8 rows
+// per poll, one block ahead.
+// Direction NIBBLES go to HBM STRIPE-LOCAL: stripe p owns (m+63) steps of 64 nibbles, eight
+// steps per stored dword (assembled by packed multiply-adds), and every traceback tile is
+// one contiguous block.
+// The wave that finishes last (LDS ticket inside a workgroup, agent-scope release/acquire
+// around a global ticket between workgroups) runs the traceback.  It keeps a DP_TILE_ROWS x 64
+// tile of the current stripe in LDS and walks it RUN BY RUN: the lanes look ahead along the
+// three possible directions (21 cells each) in one LDS read, a ballot gives the length
 // of the run the automaton of ksw_backtrack would take step by step, and the run
 // is emitted at once.
 // Forward progress: a workgroup takes its place in the launch from a TICKET drawn when it starts (not from its
-// workgroup index), so the stripe p-1 that stripe p waits for belongs to a workgroup that is already running,
+// workgroup index), so the pair pp-1 that pair pp waits for belongs to a workgroup that is already running,
 // whatever order the dispatcher starts workgroups in and whatever else competes for the CUs.  The wait is still
 // bounded (2 s of wall clock): a launch that trips it is repeated job by job (gsa_align_contig, dp_safe).
 // ---------------------------------------------------------------------------
@@ -695,19 +702,11 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		if (c->d_dp_ctr.cap != ctr_cap0 || c->dp_dirty) { GSA_CHECK(c, hipMemsetAsync(ctr, 0, c->d_dp_ctr.cap, st)); GSA_CHECK(c, hipMemsetAsync(mail + err_slot, 0, 4, st)); c->dp_dirty = false; }
 		// (the two classes back to back on one stream.  Side by side on two streams -- the few long jobs at raised priority --
 		//  was measured at 250 Mb: same step time, the refinement passes beside them starve instead: the chip is busy either way)
-		const StripeJob *k_sj = sj; const i32 *k_b2j0 = b2j_all;
-		{ static const bool sjdev = getenv("GSA_SJ_DEV") != nullptr;
-		  if (sjdev && err_slot != M_DPERR3) {
-			const size_t bytes = (cnt + 1) * sizeof(StripeJob) + (nb_ub + 2) * 4;
-			char *d = dev_ensure<char>(c, c->d_dp_jobs, bytes); if (!d) return GSA_ERR_NOMEM;
-			GSA_CHECK(c, hipMemcpyAsync(d, sj, bytes, hipMemcpyHostToDevice, st));
-			k_sj = (const StripeJob *)d; k_b2j0 = (const i32 *)(d + (cnt + 1) * sizeof(StripeJob));
-		  } }
 		for (int si = 0; si < 3; si++) {
 			const Seg &sg = seg[si];
 			if (sg.nblocks == 0) continue;
-			if (sg.wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)sg.nblocks), dim3(256), sg.dyn_lds, st, k_b2j0 + (sg.b2j - b2j_all), k_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
-			else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)sg.nblocks), dim3(64), sg.dyn_lds, st, k_b2j0 + (sg.b2j - b2j_all), k_sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
+			if (sg.wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)sg.nblocks), dim3(256), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
+			else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)sg.nblocks), dim3(64), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
 		}
 		GSA_CHECK(c, hipGetLastError());
 		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + 41, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })
