@@ -53,6 +53,25 @@ def test_ksw2_leaf_operator_golden(gpu):
         assert capi.apply_ops(s1[i], s2[i], ops[i]) == (a1, a2), f"pair {i} m={len(s1[i])} n={len(s2[i])}"
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_ksw2_leaf_operator_edge_shapes(oracle_built, cx_index, seed):
+    """Random pairs around the striped kernel's edges (query lengths around multiples of 64 and 128: a wave takes two
+    64-column stripes; one-row and very long reference sides; N bases; identical and unrelated pairs), each against the
+    oracle's ksw2 (ksw2_alignment.cpp:74-95), called twice so that the second call reuses buffers and epochs."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(GOLDEN)), "tools"))
+    import dp_fuzz
+    s1, s2 = dp_fuzz.make_pairs(1200, seed)
+    a = capi.Aligner(cx_index)
+    try:
+        for rep in range(2):
+            ops = a.ksw2_batch(s1, s2)
+            for i in range(len(s1)):
+                assert capi.apply_ops(s1[i], s2[i], ops[i]) == oracle_built.oracle_ksw2(s1[i], s2[i]), f"rep {rep} pair {i} m={len(s1[i])} n={len(s2[i])}"
+    finally:
+        a.close()
+
+
 def test_gap_similarity_leaf_operator_golden(gpu, cx_queries):
     rows = np.load(os.path.join(GOLDEN, "gapsim.npz"))["rows"]
     for ci in np.unique(rows[:, 0]):
