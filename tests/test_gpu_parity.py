@@ -62,6 +62,8 @@ def test_ksw2_leaf_operator_edge_shapes(oracle_built, cx_index, seed):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(GOLDEN)), "tools"))
     import dp_fuzz
     s1, s2 = dp_fuzz.make_pairs(1200, seed)
+    if seed == 2:      # + long pairs around the LDS limit of the four-wave layout (3968 reference bases) up to 5000 x 5000
+        l1, l2 = dp_fuzz.make_large_pairs(16, seed); s1 += l1; s2 += l2
     a = capi.Aligner(cx_index)
     try:
         for rep in range(2):

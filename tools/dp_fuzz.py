@@ -48,11 +48,35 @@ def make_pairs(npairs, seed):
     return s1, s2
 
 
+def make_large_pairs(npairs, seed):
+    """Few long pairs around the LDS limit of the four-wave layout (reference side 3968) up to the 5000-base gap limit."""
+    rng = np.random.default_rng(seed)
+    s1, s2 = [], []
+    ms = [3967, 3968, 3969, 4100, 4999, 5000, 3000, 2500]
+    for i in range(npairs):
+        m = ms[i % len(ms)]; n = int((65, 128, 129, 1000, 2049, 4097, 5000, 4990)[int(rng.integers(0, 8))])
+        a = rng.integers(0, 4, m).astype(np.uint8)
+        out = []; j = 0; d = (0.02, 0.1, 0.3)[i % 3]
+        while j < m and len(out) < n:
+            r = rng.random()
+            if r < d * 0.6: out.append((int(a[j]) + 1 + int(rng.integers(0, 3))) & 3); j += 1
+            elif r < d * 0.8: out.extend(rng.integers(0, 4, int(rng.integers(1, 30))).tolist())
+            elif r < d: j += int(rng.integers(1, 30))
+            else: out.append(int(a[j])); j += 1
+        out = out[:n]
+        while len(out) < n: out.append(int(rng.integers(0, 4)))
+        A = np.frombuffer(b"ACGT", dtype=np.uint8)[a].copy(); B = np.frombuffer(b"ACGT", dtype=np.uint8)[np.array(out, dtype=np.uint8)].copy()
+        s1.append(A.tobytes()); s2.append(B.tobytes())
+    return s1, s2
+
+
 def main():
     npairs = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     oracle_py.build(ref=False)
     s1, s2 = make_pairs(npairs, seed)
+    if os.environ.get("DP_FUZZ_LARGE"):
+        l1, l2 = make_large_pairs(int(os.environ["DP_FUZZ_LARGE"]), seed); s1 += l1; s2 += l2; npairs = len(s1)
     g = capi.Aligner.for_leaf_operators() if hasattr(capi.Aligner, "for_leaf_operators") else None
     if g is None:
         import gzip, shutil, tempfile
