@@ -181,7 +181,7 @@ int stage345_refine(gsa_ctx *c);      // k_refine.hip  (device part of S3, S4, S
 int stage7_fill(gsa_ctx *c);          // k_extend.hip  (S6: gap records of the final block list)
 i64 frags_count(gsa_ctx *c);          // k_extend.hip  (record count, fetched from the mailbox when still unknown)
 int stage78_extend(gsa_ctx *c);       // k_extend.hip  (S7: classification, DP, gapped strings, block sums)
-int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res);   // k_gapsim.hip
+int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res, const i32 *d_jseed, i32 *d_cut4);   // k_gapsim.hip
 void dp_count_cells(gsa_ctx *c, i32 n_ub, const i32 *len1, const i32 *len2, hipStream_t stream);   // k_dp.hip (profiling)
 struct LgJob { i32 job, m, n; };
 int launch_stripes(gsa_ctx *c, hipStream_t ss, std::vector<LgJob> &large, const uint8_t *pool1, const i64 *off1, const uint8_t *pool2, const i64 *off2,
@@ -189,6 +189,7 @@ int launch_stripes(gsa_ctx *c, hipStream_t ss, std::vector<LgJob> &large, const 
 struct Ksw2Launch { i32 n = 0, nsmall = 0, nlarge = 0; bool small_in_flight = false; };      // what run_ksw2_jobs left running
 int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, const i32 *len1,
                   const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total, Ksw2Launch *out,
-                  const i32 *jfrag = nullptr, gsa_frag *frag = nullptr);   // k_dp.hip  (jfrag/frag: the small kernels also set aln_len of the job's record)
+                  const i32 *jfrag = nullptr, gsa_frag *frag = nullptr, bool mail_clean = false);   // k_dp.hip  (jfrag/frag: the small kernels also set aln_len of the job's record;
+                  // mail_clean: the caller's last pass already zeroed mail[M_DPERR .. M_DPERR + 7])
 
 #endif

@@ -475,15 +475,6 @@ struct OpBlockFilter {
 	__device__ void done(const i32 *t) const { mail[M_NBLK] = t[0]; }
 };
 
-__global__ void k_seed_block_id(const i32 *__restrict__ nptr, const i32 *__restrict__ head, const i32 *__restrict__ headEx, const i32 *__restrict__ bkeep,
-                                const i32 *__restrict__ bkeepEx, i32 *bid)
-{
-	const i64 n = *nptr;
-	GID(n);
-	const i32 b = headEx[i] + head[i] - 1;
-	bid[i] = bkeep[b] ? bkeepEx[b] : -1;
-}
-
 // ---- F. the large DP gaps, two stages early ------------------------------------------
 // The striped DP of the largest gap is the contig's latency floor, and almost every gap between two
 // consecutive seeds of an S2 block survives S3-S6 unchanged.  So the large ones (the ones that will need
@@ -493,13 +484,18 @@ __global__ void k_seed_block_id(const i32 *__restrict__ nptr, const i32 *__restr
 // always cut by S4 and are not listed; what S4's similarity test or the list logic drops was computed
 // in vain.
 struct OpEarlyGaps {
-	const i32 *q, *len; const i64 *r; const i32 *bid; const uint8_t *query, *ref;
+	const i32 *q, *len; const i64 *r; const i32 *head, *headEx, *bkeep, *bkeepEx; i32 *bid; const uint8_t *query, *ref;
+	// the kept block a seed belongs to (-1: its raw block was dropped by AddAlnBlock); written to bid[] by emit() for the
+	// stages behind (was a kernel of its own in front of this pass)
+	__device__ i32 bid_of(i64 i) const { const i32 b = headEx[i] + head[i] - 1; return bkeep[b] ? bkeepEx[b] : -1; }
 	i32 *e_id, *e_list; i64 *off1, *off2, *opsoff; i32 *mail;
+	i32 *e_rec;      // record of an early job, -1 until stage 7 finds it (k_gap_class)
 	__device__ bool gap(i64 s, i32 &qp, i64 &rp, i32 &qg, i32 &rg) const
 	{
 		// same block, and one that AddAlnBlock keeps: the raw blocks it drops are pairs of stray seeds kilobases apart -- listing
 		// their gaps (measured: right behind the block heads, 12 us earlier) costs 0.45 ms of wasted striped DP on a 50 Mb contig
-		if (s + 1 >= mail[M_NC] || bid[s] < 0 || bid[s + 1] != bid[s]) return false;
+		if (s + 1 >= mail[M_NC]) return false;
+		{ const i32 b0 = bid_of(s); if (b0 < 0 || bid_of(s + 1) != b0) return false; }
 		qp = q[s] + len[s]; rp = r[s] + len[s];
 		qg = q[s + 1] - qp; if (qg < 0) qg = 0;
 		const i64 rg64 = r[s + 1] - rp; rg = rg64 < 0 ? 0 : (i32)rg64;
@@ -518,13 +514,14 @@ struct OpEarlyGaps {
 	}
 	__device__ void emit(i64 s, const i32 *v, const i32 *ex) const
 	{
+		if (s < mail[M_NC]) bid[s] = bid_of(s);
 		e_id[s] = v[0] ? ex[0] : -1;
 		if (!v[0]) return;
 		const i32 qp = q[s] + len[s]; const i64 rp = r[s] + len[s];
 		const i32 qg = q[s + 1] - qp, rg = (i32)(r[s + 1] - rp);
 		const i32 e = ex[0];
 		lb_pub(&e_list[3 * e], e); lb_pub(&e_list[3 * e + 1], rg); lb_pub(&e_list[3 * e + 2], qg);      // (finish() reads the list)
-		off1[e] = rp; off2[e] = qp; opsoff[e] = ex[1];
+		off1[e] = rp; off2[e] = qp; opsoff[e] = ex[1]; e_rec[e] = -1;
 	}
 	__device__ void done(const i32 *t) const { lb_pub(&mail[M_NEARLY], t[0]); lb_pub(&mail[M_EOPS], t[1]); lb_pub(&mail[M_DPERR3], 0); }
 	// the last tile puts the two counts and the head of the list into pinned memory: the host launches from there
@@ -706,13 +703,12 @@ int stage2_chain(gsa_ctx *c)
 	ENS(i32, blk_beg, na + 1); ENS(i32, blk_end, na + 1); ENS(i32, blk_score, na + 1);
 	{ OpBlockFilter op = { na, bstart, c->c_q.as<i32>(), c->c_len.as<i32>(), c->d_flag2.as<u32>(), c->prm, bkeep, bkeepEx,
 	                       c->blk_beg.as<i32>(), c->blk_end.as<i32>(), c->blk_score.as<i32>(), mail }; RC((lb_launch<1>(c, na, op))); }
-	LAUNCH(k_seed_block_id, na, mail + M_NC, bhead, bheadEx, bkeep, bkeepEx, c->c_bid.as<i32>());
 	if (c->profiling) { hipEventRecord(c->ev[5], st); c->ev_pending |= 2; }
 	// F. list the large DP gaps; the list travels to the host while stage 3 is being enqueued
-	ENS(i32, e_id, na + 2); ENS(i32, e_list, 3 * (na + 1)); ENS(i64, e_off1, na + 1); ENS(i64, e_off2, na + 1); ENS(i64, e_opsoff, na + 2);
+	ENS(i32, e_id, na + 2); ENS(i32, e_rec, na + 2); ENS(i32, e_list, 3 * (na + 1)); ENS(i64, e_off1, na + 1); ENS(i64, e_off2, na + 1); ENS(i64, e_opsoff, na + 2);
 	if (!pin_ensure<i32>(c, c->p_early, 4 + 3 * (size_t)EARLY_CHUNK)) return GSA_ERR_NOMEM;
-	{ OpEarlyGaps op = { c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_bid.as<i32>(), c->d_query.as<uint8_t>(), c->di.ref,
-	                     c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail,
+	{ OpEarlyGaps op = { c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), bhead, bheadEx, bkeep, bkeepEx, c->c_bid.as<i32>(), c->d_query.as<uint8_t>(), c->di.ref,
+	                     c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail, c->e_rec.as<i32>(),
 	                     c->p_early.as<i32>(), (i32)std::min<i64>(na, EARLY_CHUNK) }; RC((lb_launch<2>(c, na, op))); }
 	GSA_CHECK(c, hipEventRecord(c->ev[16], st));
 	c->early_listed = true;

@@ -727,7 +727,7 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 // Returns with the work enqueued: errors of the last batch land in the mailbox (M_DPERR, M_DPERR2).
 int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, const i32 *len1,
                   const uint8_t *pool2, const i64 *off2, const i32 *len2, uint8_t *ops, const i64 *ops_off, i32 *ops_len, i64 ops_total, Ksw2Launch *out,
-                  const i32 *jfrag, gsa_frag *frag)
+                  const i32 *jfrag, gsa_frag *frag, bool mail_clean)
 {
 	*out = Ksw2Launch();
 	if (n_ub <= 0) return GSA_OK;
@@ -740,7 +740,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	uint8_t *rev = dev_ensure<uint8_t>(c, c->d_i64a, (size_t)ops_total + 64);
 	if (!d_order || !d_order_tiny || !d_lg || !rev) return GSA_ERR_NOMEM;
 	if (!pin_ensure<i32>(c, c->p_dp, (size_t)MAIL_N + 3 * LG_CHUNK)) return GSA_ERR_NOMEM;
-	GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR, 0, 8 * sizeof(i32), st));                    // M_DPERR, M_NLARGE, M_DPERR2, -, M_CELLS (2 x u64): one aligned fill (28 bytes at an odd offset were three)
+	if (!mail_clean) GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR, 0, 8 * sizeof(i32), st));                    // M_DPERR, M_NLARGE, M_DPERR2, -, M_CELLS (2 x u64): one aligned fill (28 bytes at an odd offset were three)
 	i32 *h = c->p_dp.as<i32>();
 	const size_t first_lg = (size_t)std::min<i64>(n_ub, LG_CHUNK);
 	{ OpClassify op = { len1, len2, d_order, d_order_tiny, d_lg, d_jlarge, mail, h, (i32)first_lg }; int rc = lb_launch<2>(c, n_ub, op); if (rc) return rc; }

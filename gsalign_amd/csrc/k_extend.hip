@@ -107,7 +107,11 @@ struct OpDpJobs {
 		jfrag[j] = (i32)i; off1[j] = frag[i].rpos; len1[j] = frag[i].rlen; off2[j] = frag[i].qpos; len2[j] = frag[i].qlen; opsoff[j] = ex[1];
 		fjob[i] = j;
 	}
-	__device__ void done(const i32 *t) const { mail[M_NJOB] = t[0]; mail[M_NALN] = t[1]; }
+	__device__ void done(const i32 *t) const
+	{
+		mail[M_NJOB] = t[0]; mail[M_NALN] = t[1];
+		for (int k = 0; k < 8; k++) mail[M_DPERR + k] = 0;      // the DP kernels' error words and cell counters start clean (saves a fill operation in front of them)
+	}
 };
 
 // one DP record written by a whole 256-thread workgroup: 256 positions per pass, prefix counts of the
@@ -338,7 +342,7 @@ int stage7_fill(gsa_ctx *c)
 	const i64 nfu = c->nf_ub;
 	ENS(gsa_frag, f_rec, nfu + 1); ENS(i32, f_type, nfu + 1); ENS(i32, f_mism, nfu + 1); ENS(i32, f_score, nfu + 1); ENS(i32, f_job, nfu + 1); ENS(i32, f_alnlen, nfu + 1);
 	ENS(i32, f_early, nfu + 2);
-	if (c->n_early > 0) GSA_CHECK(c, hipMemsetAsync(c->e_rec.p, 0xff, (size_t)c->n_early * 4, st));      // -1: no record (yet)
+	// (e_rec[] of the early jobs is -1 since the pass that listed them, OpEarlyGaps)
 	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), d_sbeg, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->e_id.as<i32>(), c->r_orig.as<i32>(),
 	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), d_fragbase, c->f_early.as<i32>(), c->d_mail.as<i32>() };
 	RC((lb_launch<1>(c, ns, op)));
@@ -378,7 +382,7 @@ int stage78_extend(gsa_ctx *c)
 	i32 *d_blen = c->bl_alnlen.as<i32>(), *d_bscore = d_blen + nfb, *d_fragbase = d_blen + 2 * (size_t)nfb;      // (one buffer since stage 7: one copy home)
 	Ksw2Launch kl;
 	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub, &kl,
-	                 nullptr, nullptr));
+	                 nullptr, nullptr, true));
 	// (run_ksw2_jobs read the mailbox: the record count and the size of the string pools are known now)
 	// The records leave only now, behind the host's look at the size classes: a 166 MB copy (a 250 Mb contig) in flight keeps
 	// the link busy for 3 ms, and the few bytes the classification pass stores into pinned memory for that look queued

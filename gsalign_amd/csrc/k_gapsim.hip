@@ -80,7 +80,8 @@ __device__ void kmer_hist(const uint8_t *__restrict__ s, int len, u32 *hist, int
 }
 
 __global__ void __launch_bounds__(GS_T) k_gapsim(DevIndex di, const uint8_t *__restrict__ query, i32 n_host, const i32 *__restrict__ d_n, const i32 *__restrict__ q1a, const i32 *__restrict__ q2a,
-                                                const i64 *__restrict__ r1a, const i64 *__restrict__ r2a, i32 *res)
+                                                const i64 *__restrict__ r1a, const i64 *__restrict__ r2a, i32 *res,
+                                                const i32 *__restrict__ jseed, i32 *cut4)
 {
 	__shared__ u32 h1[KBINS], h2[KBINS];
 	__shared__ int s_acc, s_flag;
@@ -119,17 +120,19 @@ __global__ void __launch_bounds__(GS_T) k_gapsim(DevIndex di, const uint8_t *__r
 			__syncthreads();
 			if ((double)s_acc > (q_len + r_len) * 0.1) sim = true;
 		}
-		if (lane == 0) res[job] = sim ? 1 : 0;
+		// (stage 4 applies the verdict on the spot: a gap whose sides are not similar cuts the block in front of seed jseed[job],
+		//  CheckGapsBetweenSeeds :120-156 -- was a kernel of its own behind this one)
+		if (lane == 0) { res[job] = sim ? 1 : 0; if (cut4 && !sim) cut4[jseed[job]] = 1; }
 		__syncthreads();
 	}
 }
 
-int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res)
+int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_n, const i32 *d_q1, const i32 *d_q2, const i64 *d_r1, const i64 *d_r2, i32 *d_res, const i32 *d_jseed, i32 *d_cut4)
 {
 	// n = job count, or with d_n != nullptr an upper bound (the grid is capped, workgroups loop over the jobs)
 	if (n <= 0) return GSA_OK;
 	const i32 grid = d_n ? (n < 1024 ? n : 1024) : n;
-	hipLaunchKernelGGL(k_gapsim, dim3(grid), dim3(GS_T), 0, c->stream, c->di, c->d_query.as<uint8_t>(), n, d_n, d_q1, d_q2, d_r1, d_r2, d_res);
+	hipLaunchKernelGGL(k_gapsim, dim3(grid), dim3(GS_T), 0, c->stream, c->di, c->d_query.as<uint8_t>(), n, d_n, d_q1, d_q2, d_r1, d_r2, d_res, d_jseed, d_cut4);
 	GSA_CHECK(c, hipGetLastError());
 	return GSA_OK;
 }
@@ -147,7 +150,7 @@ extern "C" int gsa_gap_similarity_batch(gsa_ctx *c, int32_t n, const int32_t *q1
 	if (!dq1 || !dq2 || !dres || !dr1 || !dr2) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemcpyAsync(dq1, q1, n * 4, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(dq2, q2, n * 4, hipMemcpyHostToDevice, st));
 	GSA_CHECK(c, hipMemcpyAsync(dr1, r1, n * 8, hipMemcpyHostToDevice, st)); GSA_CHECK(c, hipMemcpyAsync(dr2, r2, n * 8, hipMemcpyHostToDevice, st));
-	int rc = run_gapsim_jobs(c, n, nullptr, dq1, dq2, dr1, dr2, dres);
+	int rc = run_gapsim_jobs(c, n, nullptr, dq1, dq2, dr1, dr2, dres, nullptr, nullptr);
 	if (rc == GSA_OK) { GSA_CHECK(c, hipMemcpyAsync(similar, dres, n * 4, hipMemcpyDeviceToHost, st)); GSA_CHECK(c, hipStreamSynchronize(st)); }
 	return rc;
 }

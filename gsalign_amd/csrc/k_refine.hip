@@ -95,13 +95,6 @@ struct OpGapCuts {
 	__device__ void done(const i32 *t) const { mail[M_NJ] = t[0]; }
 };
 
-__global__ void k_gap_apply(i64 ub, const i32 *__restrict__ d_nj, const i32 *__restrict__ jseed, const i32 *__restrict__ res, i32 *cut4)
-{
-	GID(ub);
-	if (i >= *d_nj) return;
-	if (!res[i]) cut4[jseed[i]] = 1;
-}
-
 // S5 (CheckAlnBlockSpanMultipleRefChrs, :81-118) + leaf heads.  Within a block
 // rPos is strictly increasing after S3, so "first seed past the end of the copy
 // holding the piece's first seed" == "copy index changes".  Second component: prefix sums of the
@@ -191,8 +184,7 @@ int stage345_refine(gsa_ctx *c)
 		}
 		// S4 cuts + similarity jobs
 		{ OpGapCuts op = { cur, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, jq1, jq2, jr1, jr2, jseed, mail }; RC((lb_launch<1>(c, ub, op))); }
-		RC(run_gapsim_jobs(c, (i32)ub, mail + M_NJ, jq1, jq2, jr1, jr2, c->r_simres.as<i32>()));
-		LAUNCH(k_gap_apply, ub, ub, mail + M_NJ, jseed, c->r_simres.as<i32>(), cut4);
+		RC(run_gapsim_jobs(c, (i32)ub, mail + M_NJ, jq1, jq2, jr1, jr2, c->r_simres.as<i32>(), jseed, cut4));      // (sets cut4 of the dissimilar gaps)
 		// S5 cuts + leaf table + large DP gaps of the leaves
 		{ OpChrCuts op = { ub, mail + cur, c->di, c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, c->r_len.as<i32>(), cut5, lstart, c->r_head.as<i32>(), ps, mail }; RC((lb_launch<2>(c, ub, op))); }
 		LAUNCH(k_leaf_emit, ub, ub, mail + cur, mail, lstart, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, cut5, ps,
