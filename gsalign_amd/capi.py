@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libgsa_hip.so")
 EXPORTS = [
     "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many", "gsa_seed_chunks", "gsa_hit_count", "gsa_export_hits", "gsa_import_hits", "gsa_finish_contig",
     "gsa_set_query", "gsa_rewind", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
-    "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling",
+    "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling", "gsa_bind_host_thread",
 ]
 
 
@@ -86,6 +86,13 @@ def load_library() -> C.CDLL:
         if fn.argtypes is None:
             fn.argtypes = None
     return lib
+
+
+def bind_host_thread(device: int = 0) -> None:
+    """gsa_bind_host_thread: the calling thread moves to the CPUs next to `device` (threads started later inherit that)."""
+    lib = load_library()
+    lib.gsa_bind_host_thread.argtypes = [C.c_int]
+    lib.gsa_bind_host_thread(int(device))
 
 
 RESULT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(Result))

@@ -110,6 +110,11 @@ int  gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *pr
  * them.  Each context is single-threaded; `parent` must outlive its clones. */
 int  gsa_clone(gsa_ctx *parent, gsa_ctx **out);
 void gsa_destroy(gsa_ctx *ctx);
+/* Puts the CALLING host thread on the CPUs of the socket `device` hangs off (sysfs local_cpulist of its PCI function; a no-op
+ * without that information or with GSA_NO_BIND set).  The reference's worker threads (GSAlign.cpp:479, pthread_create) run
+ * wherever the OS puts them, which costs nothing there; a thread that drives a GPU through ~60 short operations per 5 Mb
+ * contig pays the inter-socket hop on every one.  gsa_align_many does this for the threads it starts itself. */
+int  gsa_bind_host_thread(int device);
 /* Pinned host memory for query contigs (QueryChrVec[i].seq, main.cpp:82-114): the upload inside gsa_align_contig is then
  * one asynchronous DMA transfer.  Any other host memory works too (staged by the runtime). */
 void *gsa_host_alloc(size_t bytes);
