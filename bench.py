@@ -99,7 +99,7 @@ def bind_process_to_device_socket(torch, dev_index):
     """Every thread of this process (the HIP runtime's helper threads included: they exist since the device was initialised)
     moves to the CPUs of the socket the GPU hangs off (sysfs local_cpulist).  Small contigs are ~60 short GPU operations with
     five host look-ins each: from the far socket a 5 Mb contig took 0.86 ms, from the near one 0.65 (taskset, two-socket host)."""
-    if os.environ.get("GSA_NO_BIND"):
+    if not os.environ.get("GSA_BIND"):      # opt-in: measured +-: 5 Mb contigs 0.86 -> 0.65-0.75 ms from the far socket, 250 Mb contigs 13.7 -> 14.4 ms
         return None
     try:
         p = torch.cuda.get_device_properties(dev_index)
@@ -123,7 +123,6 @@ class Runner:
 
     def __init__(self, idx, device, inflight, params):
         from gsalign_amd import capi
-        capi.bind_host_thread(device)      # this thread drives context 0 (gsa_align_many places its own threads itself)
         self.ctx = [capi.Aligner(idx, device=device, **params)]
         for _ in range(inflight - 1):
             self.ctx.append(self.ctx[0].clone())

@@ -197,8 +197,9 @@ int gsa_clone(gsa_ctx *parent, gsa_ctx **out)
 
 // Host-thread placement.  A contig of a few Mb is some sixty short GPU operations with five host look-ins: a host thread on
 // the socket the GPU does not hang off pays the inter-socket hop on every doorbell, pinned-memory poll and count read-back
-// (measured on a two-socket MI355X host, 5 Mb contigs, three contexts: 0.86 ms per contig from the far socket, 0.65 from the
-// near one; 250 Mb contigs do not care).  The CPUs local to the device come from sysfs (local_cpulist of its PCI function).
+// (measured on a two-socket MI355X host with the whole process placed by taskset, 5 Mb contigs, three contexts: 0.86 ms per
+// contig from the far socket, 0.65 - 0.75 from the near one.  NOT applied by default anywhere: 250 Mb contigs ran 5 % slower with
+// the driving threads bound -- 14.4 against 13.7 ms per step on the same box -- so placement is the integrator's decision).  The CPUs local to the device come from sysfs (local_cpulist of its PCI function).
 static bool device_local_cpus(int device, cpu_set_t *set)
 {
 	char bus[64] = { 0 };
@@ -375,8 +376,8 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 		}
 	};
 	std::vector<std::thread> th;
-	// (the library's own threads sit on the CPUs next to their GPU; the caller's thread -- context 0 -- is the caller's to place: gsa_bind_host_thread)
-	for (int k = 1; k < n_ctx && k < n; k++) th.emplace_back([&loop](gsa_ctx *c) { (void)gsa_bind_host_thread(c->device); loop(c); }, ctx[k]);
+	// (thread placement is the caller's: gsa_bind_host_thread; the threads started here inherit the caller's affinity)
+	for (int k = 1; k < n_ctx && k < n; k++) th.emplace_back(loop, ctx[k]);
 	loop(ctx[0]);
 	for (std::thread &t : th) t.join();
 	return err.load();

@@ -119,7 +119,7 @@ int main(int argc, char *argv[])
 	}
 	gsa_index_view view; idx.fill_view(&view);
 	if (gpus.empty()) gpus.push_back(0);
-	(void)gsa_bind_host_thread(gpus[0]);      // this thread drives the first context (gsa_align_many places the threads it starts itself)
+	if (getenv("GSA_BIND")) (void)gsa_bind_host_thread(gpus[0]);      // (opt-in: small contigs gain from a near-socket thread, chromosome-sized ones lose 5 %)
 	// one context per GPU owns that device's copy of the index; the others borrow it (gsa_clone)
 	std::vector<gsa_ctx *> ctxs;
 	const size_t want_ctx = std::min(qs.size(), gpus.size() * (size_t)n_ctx_per_gpu);

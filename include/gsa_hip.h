@@ -113,7 +113,9 @@ void gsa_destroy(gsa_ctx *ctx);
 /* Puts the CALLING host thread on the CPUs of the socket `device` hangs off (sysfs local_cpulist of its PCI function; a no-op
  * without that information or with GSA_NO_BIND set).  The reference's worker threads (GSAlign.cpp:479, pthread_create) run
  * wherever the OS puts them, which costs nothing there; a thread that drives a GPU through ~60 short operations per 5 Mb
- * contig pays the inter-socket hop on every one.  gsa_align_many does this for the threads it starts itself. */
+ * contig pays the inter-socket hop on every one (0.86 -> 0.65-0.75 ms per 5 Mb contig); chromosome-sized contigs ran 5 %
+ * slower with bound threads, so nothing in the library calls this by itself: threads started by gsa_align_many inherit the
+ * caller's affinity. */
 int  gsa_bind_host_thread(int device);
 /* Pinned host memory for query contigs (QueryChrVec[i].seq, main.cpp:82-114): the upload inside gsa_align_contig is then
  * one asynchronous DMA transfer.  Any other host memory works too (staged by the runtime). */
