@@ -52,3 +52,17 @@ def test_low_divergence_long_dp_live(op, tmp_path):
     o.set_query(qrys[0][1])
     assert_stage_equal(o.dump_stages(8), want, prefix="c0_")
     o.close()
+
+
+def test_ksw2_edge_shapes_live(op):
+    """The pairs the striped GPU kernel is checked on (tools/dp_fuzz.py: query lengths around multiples of 64 / 128, one-row and
+    1500-row reference sides, N bases, long pairs up to 5000 x 5000), here the restatement against the reference's own
+    ksw2_alignment (ksw2_alignment.cpp:251-273) -- so the GPU test's checker is pinned on exactly those shapes."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import dp_fuzz
+    ref = op.RefLib(None)
+    s1, s2 = dp_fuzz.make_pairs(800, 5)
+    l1, l2 = dp_fuzz.make_large_pairs(8, 5)
+    for a, b in zip(s1 + l1, s2 + l2):
+        assert op.oracle_ksw2(a, b) == ref.ksw2(a, b), (len(a), len(b))
