@@ -146,7 +146,7 @@ void Emitter::aln(FILE *fp, const QueryContig &q, ContigResult &r) const
 	}
 }
 
-bool Emitter::dotplot(const std::string &gp_path, const std::string &out_prefix, const QueryContig &q, const ContigResult &r) const
+bool Emitter::dotplot(const std::string &gp_path, const std::string &out_prefix, const QueryContig &q, const ContigResult &r, std::vector<std::string> *data_files) const
 {
 	static const char *colors[10] = { "red", "blue", "web-green", "dark-magenta", "orange", "yellow", "turquoise", "dark-yellow", "violet", "dark-grey" };
 	if (r.blocks.empty()) return false;
@@ -164,7 +164,7 @@ bool Emitter::dotplot(const std::string &gp_path, const std::string &out_prefix,
 	for (size_t i = 0; i < top.size(); i++) {
 		const std::string fn = data + "vs" + idx->chr_name[(size_t)top[i].first];
 		fh[(size_t)top[i].first] = fopen(fn.c_str(), "w");
-		if (fh[(size_t)top[i].first]) fprintf(fh[(size_t)top[i].first], "0 0\n0 0\n\n");
+		if (fh[(size_t)top[i].first]) { fprintf(fh[(size_t)top[i].first], "0 0\n0 0\n\n"); if (data_files) data_files->push_back(fn); }
 	}
 	fprintf(gp, "set terminal postscript color solid 'Courier' 15\nset output '%s-%s.ps'\nset grid\nset border 1\n", out_prefix.c_str(), q.name.c_str());
 	for (size_t i = 0; i < top.size(); i++) fprintf(gp, "set style line %d lw 4 pt 0 ps 0.5 lc '%s'\n", (int)i + 1, colors[i]);

@@ -58,8 +58,8 @@ struct Emitter {
 	void aln(FILE *fp, const QueryContig &q, ContigResult &r) const;
 	// OutputDotplot (DotPloting.cpp:10-71): gnuplot script `gp_path` + one data file per plotted reference sequence
 	// (`<prefix>.<query>vs<chr>`); returns false when there is nothing to plot.  Running gnuplot on the script and removing
-	// the data files afterwards (DotPloting.cpp:69-70) is the caller's business.
-	bool dotplot(const std::string &gp_path, const std::string &out_prefix, const QueryContig &q, const ContigResult &r) const;
+	// the data files afterwards (DotPloting.cpp:69-70) is the caller's business: `data_files` receives their names.
+	bool dotplot(const std::string &gp_path, const std::string &out_prefix, const QueryContig &q, const ContigResult &r, std::vector<std::string> *data_files = nullptr) const;
 	// VariantIdentification (SeqVariant.cpp:12-119)
 	void variants(int query_idx, const QueryContig &q, const ContigResult &r);
 	// OutputSequenceVariants (SeqVariant.cpp:121-143)

@@ -53,6 +53,8 @@ int gsah_c_emit_fmt(const char *index_prefix, const char *query_fa, const char *
 }
 
 // OutputDotplot for one contig: script + data files (no gnuplot run).  Returns 1 if something was written.
+// The reference plots AFTER OutputMAF (GSAlign.cpp:543-546), which shortens the last record of a block that runs over the end of
+// its reference sequence (tools.cpp:149-220), and the plot shows the shortened block: the MAF emitter runs first here too.
 int gsah_c_dotplot(const char *index_prefix, const char *query_fa, int contig, const char *gp_path, const char *out_prefix, gsah_result_cb cb, void *user, char *err)
 {
 	std::string e; HostIndex idx; std::vector<QueryContig> qs;
@@ -61,6 +63,7 @@ int gsah_c_dotplot(const char *index_prefix, const char *query_fa, int contig, c
 	if (cb(user, contig, qs[(size_t)contig].seq.data(), (int)qs[(size_t)contig].seq.size(), &res) != 0) return -2;
 	ContigResult cr; cr.assign(res);
 	Emitter em; em.idx = &idx;
+	if (!cr.blocks.empty()) { FILE *nul = fopen("/dev/null", "w"); if (nul) { em.maf(nul, false, qs[(size_t)contig], cr); fclose(nul); } }
 	return em.dotplot(gp_path, out_prefix, qs[(size_t)contig], cr) ? 1 : 0;
 }
 

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <functional>
 #include <mutex>
 #include <string>
 #include "gsa_host.h"
@@ -140,21 +141,19 @@ int main(int argc, char *argv[])
 	long long n_aln = 0, tot_len = 0, tot_match = 0, n_dup = 0;
 	fprintf(stderr, "Step2. Sequence analysis for all query chromosomes\n");
 	// the hot path: every contig through gsa_align_contig on whichever context is free; the finished blocks are copied out
-	// of the context by the worker that produced them
-	std::vector<ContigResult> results(qs.size());
+	// of the context by the worker that produced them.  Output is written in contig order AS THE CONTIGS FINISH (OutputMAF
+	// appends per contig, VarVec grows in contig order: GSAlign.cpp:543-546): a result waits only for the contigs in front
+	// of it, is freed once written, and a GPU error keeps what was written before it.  One writer at a time, outside the lock.
 	std::vector<const char *> qptr(qs.size()); std::vector<int32_t> qlen(qs.size());
 	for (size_t ci = 0; ci < qs.size(); ci++) { qptr[ci] = qs[ci].seq.data(); qlen[ci] = (int32_t)qs[ci].seq.size(); }
-	struct Sink { std::vector<ContigResult> *out; } sink = { &results };
-	auto on_result = [](void *user, int32_t ci, const gsa_result *res) -> int { (*((Sink *)user)->out)[(size_t)ci].assign(*res); return 0; };
-	if (gsa_align_many(ctxs.data(), (int32_t)ctxs.size(), qptr.data(), qlen.data(), (int32_t)qs.size(), 0, on_result, &sink) != GSA_OK) {
-		for (gsa_ctx *c : ctxs) if (*gsa_last_error(c)) fprintf(stderr, "GPU error: %s\n", gsa_last_error(c));
-		return 2;
-	}
-	// output in contig order (OutputMAF appends per contig, VarVec grows in contig order: GSAlign.cpp:543-546)
-	for (size_t ci = 0; ci < qs.size(); ci++) {
+	struct Sink {
+		std::mutex mu; std::vector<ContigResult> res; std::vector<char> ready; size_t next = 0; bool writing = false;
+		std::function<void(size_t, ContigResult &)> write;
+	} sink;
+	sink.res.resize(qs.size()); sink.ready.assign(qs.size(), 0);
+	sink.write = [&](size_t ci, ContigResult &cr) {
 		fprintf(stderr, "\tProcess query chromsomoe: %s...\n", qs[ci].name.c_str());
-		ContigResult &cr = results[ci];
-		if (cr.blocks.empty()) continue;
+		if (cr.blocks.empty()) return;
 		long long len = 0, score = 0;
 		for (size_t b = 0; b < cr.blocks.size(); b++) { len += cr.blocks[b].aln_len; score += cr.blocks[b].score; if (cr.blocks[b].bdup) n_dup++; }
 		n_aln += (long long)cr.blocks.size(); tot_len += len; tot_match += score;
@@ -164,13 +163,38 @@ int main(int argc, char *argv[])
 		if (vcf) em.variants((int)ci, qs[ci], cr);
 		if (dotplot && !gnuplot.empty()) {                               // GSAlign.cpp:546: only when gnuplot was found (main.cpp:324)
 			const std::string gp = std::string(out_prefix) + ".gp";
-			if (em.dotplot(gp, out_prefix, qs[ci], cr)) {
+			std::vector<std::string> data_files;
+			if (em.dotplot(gp, out_prefix, qs[ci], cr, &data_files)) {
 				fprintf(stderr, "\t\tGenerate dotplot for query sequence (%s-%s.ps)\n", out_prefix, qs[ci].name.c_str());
 				if (system((gnuplot + " " + gp).c_str()) != 0) fprintf(stderr, "\t\tgnuplot failed\n");
-				if (system(("rm " + std::string(out_prefix) + "." + qs[ci].name + "*").c_str()) != 0) { /* nothing to remove */ }
+				// (the reference shells out to `rm <prefix>.<contig name>*` with the raw FASTA header name, DotPloting.cpp:70: the
+				//  files it means are exactly the data files written above)
+				for (const std::string &fn : data_files) (void)remove(fn.c_str());
 			}
 		}
-		ContigResult().blocks.swap(cr.blocks); std::vector<gsa_frag>().swap(cr.frags); std::string().swap(cr.aln1); std::string().swap(cr.aln2);
+	};
+	auto on_result = [](void *user, int32_t ci, const gsa_result *res) -> int {
+		Sink &sk = *(Sink *)user;
+		sk.res[(size_t)ci].assign(*res);
+		std::unique_lock<std::mutex> lk(sk.mu);
+		sk.ready[(size_t)ci] = 1;
+		if (sk.writing) return 0;                                       // the current writer picks it up when its turn comes
+		sk.writing = true;
+		while (sk.next < sk.ready.size() && sk.ready[sk.next]) {
+			const size_t k = sk.next++;
+			lk.unlock();
+			sk.write(k, sk.res[k]);
+			ContigResult().blocks.swap(sk.res[k].blocks); std::vector<gsa_frag>().swap(sk.res[k].frags); std::string().swap(sk.res[k].aln1); std::string().swap(sk.res[k].aln2);
+			lk.lock();
+		}
+		sk.writing = false;
+		return 0;
+	};
+	const int rc_many = gsa_align_many(ctxs.data(), (int32_t)ctxs.size(), qptr.data(), qlen.data(), (int32_t)qs.size(), 0, on_result, &sink);
+	if (rc_many != GSA_OK) {
+		for (gsa_ctx *c : ctxs) if (*gsa_last_error(c)) fprintf(stderr, "GPU error: %s\n", gsa_last_error(c));
+		fprintf(stderr, "\t%d of %d query sequences were written before the error\n", (int)sink.next, (int)qs.size());
+		return 2;
 	}
 	if (n_aln > 0) fprintf(stderr, "\tAlignment#=%d (total alignment length=%lld) ANI=%.2f%%, unique alignment#=%d\n", (int)n_aln, tot_len, 100 * (1.0 * tot_match / tot_len), (int)(n_aln - n_dup));
 	fprintf(stderr, "\tIt took %lld seconds for genome sequence alignment.\n", (long long)(time(NULL) - t0));

@@ -18,6 +18,10 @@ What is written (all data, no reference source):
   small.*                       a 60 kb two-contig pair with its own index, MAF, VCF (quick CLI test)
   cx_<variant>.{maf,aln,vcf}.gz outputs of the unmodified reference CLI on cx under -unique / -fmt 2 / -one / -idy 95 /
                                 -one -ind 40 -clr 300 -alen 1000 (`--cli-variants` writes only these)
+  cx_dp.json.gz                 -dp: the gnuplot scripts and data files the reference CLI hands to gnuplot, one set per plotted
+                                contig (`--dotplot` writes only this).  The reference plots only when `whereis gnuplot` finds a
+                                binary (main.cpp:169-191,324); none is installed, so a stub `gnuplot` on PATH (written by this
+                                script) keeps the script and the data files it names instead of plotting
 """
 import gzip
 import os
@@ -76,6 +80,7 @@ def main():
     subprocess.run([sys.executable, os.path.abspath(__file__), "--func", tmp], check=True)
     shutil.rmtree(tmp)
     cli_variants()
+    dotplot_golden()
     print("golden fixtures written to", HERE)
 
 
@@ -109,6 +114,62 @@ def cli_variants():
     assert open("o_novcf.maf", "rb").read() == gzip.open(f"{HERE}/cx.maf.gz", "rb").read()
     os.chdir(cwd); shutil.rmtree(tmp)
     print("CLI variant goldens written")
+
+
+GNUPLOT_STUB = """#!/bin/bash
+# stand-in for gnuplot (tests only): keeps the script it is given and the data files the script names
+n=$(ls "$GSA_DP_CAPTURE" | grep -c '\\.gp$')
+cp "$1" "$GSA_DP_CAPTURE/$(printf %03d $n).gp"
+grep -o "'[^']*vs[^']*'" "$1" | tr -d "'" | while read f; do [ -f "$f" ] && cp "$f" "$GSA_DP_CAPTURE/"; done
+exit 0
+"""
+
+
+def write_gnuplot_stub(d):
+    os.makedirs(d, exist_ok=True)
+    fn = os.path.join(d, "gnuplot")
+    with open(fn, "w") as f:
+        f.write(GNUPLOT_STUB)
+    os.chmod(fn, 0o755)
+    return d
+
+
+def collect_dotplot(cap):
+    """capture directory of the stub -> {"scripts": [text per plotted contig, in order], "data": {file name: text}}"""
+    names = sorted(os.listdir(cap))
+    return {"scripts": [open(os.path.join(cap, n)).read() for n in names if n.endswith(".gp")],
+            "data": {n: open(os.path.join(cap, n)).read() for n in names if not n.endswith(".gp")}}
+
+
+def dotplot_golden():
+    """-dp of the reference CLI on the committed cx index, output prefix `dpo`, run from the directory that holds the index."""
+    import json
+    op.build(ref=True)
+    assert op.have_ref()
+    tmp = tempfile.mkdtemp(prefix="gsa_golden_dp_")
+    for fn in os.listdir(HERE):
+        if fn.startswith("cx.") and fn.endswith(".gz"):
+            with gzip.open(os.path.join(HERE, fn), "rb") as a, open(os.path.join(tmp, fn[:-3]), "wb") as b:
+                shutil.copyfileobj(a, b)
+    cap = os.path.join(tmp, "cap"); os.makedirs(cap)
+    bindir = write_gnuplot_stub(os.path.join(tmp, "bin"))
+    env_path, env_cap = os.environ.get("PATH", ""), os.environ.get("GSA_DP_CAPTURE")
+    os.environ["PATH"] = bindir + os.pathsep + env_path; os.environ["GSA_DP_CAPTURE"] = cap
+    cwd = os.getcwd(); os.chdir(tmp)
+    try:
+        op.ref_run_cli("cx", "cx.qry.fa", "dpo", ["-dp"])
+        assert open("dpo.maf", "rb").read() == gzip.open(f"{HERE}/cx.maf.gz", "rb").read()      # (-dp does not change the alignment)
+        assert not [f for f in os.listdir(".") if "vs" in f], "the reference removes its data files"
+    finally:
+        os.chdir(cwd); os.environ["PATH"] = env_path
+        if env_cap is None:
+            del os.environ["GSA_DP_CAPTURE"]
+    d = collect_dotplot(cap)
+    assert len(d["scripts"]) >= 5 and d["data"]
+    with gzip.GzipFile(f"{HERE}/cx_dp.json.gz", "wb", mtime=0) as f:
+        f.write(json.dumps(d, sort_keys=True, indent=0).encode())
+    shutil.rmtree(tmp)
+    print("dot-plot golden written:", len(d["scripts"]), "scripts,", len(d["data"]), "data files")
 
 
 def func_vectors(tmp):
@@ -184,5 +245,7 @@ if __name__ == "__main__":
         func_vectors(sys.argv[2])
     elif len(sys.argv) > 1 and sys.argv[1] == "--cli-variants":
         cli_variants()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--dotplot":
+        dotplot_golden()
     else:
         main()

@@ -33,6 +33,30 @@ def test_cli_golden(golden_dir, tmp_path, name, extra, maf, vcf):
         assert not os.path.exists(tmp_path / "out.vcf")                   # -no_vcf (main.cpp:280)
 
 
+def test_cli_dotplot_golden(golden_dir, tmp_path):
+    """-dp: with a `gnuplot` on PATH (a stub that keeps what it is given -- none is installed here or where the golden was made) the CLI
+    hands gnuplot the same scripts and data files as the unmodified reference CLI did (tests/golden/cx_dp.json.gz), removes its data
+    files afterwards (DotPloting.cpp:69-70) and writes the same MAF."""
+    import json
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden
+    cap = tmp_path / "cap"; cap.mkdir()
+    bindir = make_golden.write_gnuplot_stub(str(tmp_path / "bin"))
+    wd = tmp_path / "wd"; wd.mkdir()
+    for fn in os.listdir(golden_dir):
+        if fn.startswith("cx."):
+            os.symlink(os.path.join(golden_dir, fn), wd / fn)
+    env = dict(os.environ, PATH=bindir + os.pathsep + os.environ.get("PATH", ""), GSA_DP_CAPTURE=str(cap))
+    subprocess.run([hostlib.CLI_PATH, "-i", "cx", "-q", "cx.qry.fa", "-o", "dpo", "-t", "1", "-dp"], cwd=wd, env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    gold = json.load(open(os.path.join(golden_dir, "cx_dp.json")))
+    got = make_golden.collect_dotplot(str(cap))
+    assert got["scripts"] == gold["scripts"] and got["data"] == gold["data"]
+    assert not [f for f in os.listdir(wd) if "vs" in f]
+    assert open(wd / "dpo.maf", "rb").read() == open(os.path.join(golden_dir, "cx.maf"), "rb").read()
+
+
 def test_cli_builds_its_own_index_and_matches_live_reference(oracle_built, tmp_path):
     if not oracle_built.have_ref():
         pytest.skip("oracle/_ref not present")

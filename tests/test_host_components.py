@@ -58,38 +58,28 @@ def test_emitters_byte_identical(oracle_built, golden_dir, tmp_path, name, param
         assert open(out_vcf, "rb").read() == open(os.path.join(golden_dir, vcf), "rb").read()
 
 
-def test_dotplot_script_and_data(oracle_built, golden_dir, tmp_path):
-    """-dp (DotPloting.cpp:10-71).  The reference only plots when a gnuplot binary is installed (main.cpp:324, GSAlign.cpp:546)
-    -- there is none here, so no golden exists; the script and the data files are checked against the blocks they are made from."""
+def test_dotplot_golden(oracle_built, golden_dir, tmp_path, monkeypatch):
+    """-dp (DotPloting.cpp:10-71) against the reference's own bytes: tests/golden/cx_dp.json.gz holds the gnuplot scripts and the data
+    files the unmodified reference CLI handed to (a stub) gnuplot on the cx pair (make_golden.py --dotplot).  The emitter is fed the
+    oracle's blocks per contig; scripts in contig order and every data file must be byte-identical."""
+    import json
     from gsalign_amd import indexio, synth
+    gold = json.load(open(os.path.join(golden_dir, "cx_dp.json")))
     px = os.path.join(golden_dir, "cx")
-    idx = indexio.load_index(px)
-    o = oracle_built.Oracle(idx)
-    dump = {}
+    o = oracle_built.Oracle(indexio.load_index(px))
 
     def per_contig(ci, seq):
-        o.set_query(seq); o.run_to(8); dump.update(o.blocks(with_aln=True)); return dump
+        o.set_query(seq); o.run_to(8); return o.blocks(with_aln=True)
 
-    pre = str(tmp_path / "plot")
-    assert hostlib.dotplot(px, os.path.join(golden_dir, "cx.qry.fa"), 2, pre + ".gp", pre, per_contig)      # q3_bridge: two reference sequences
+    monkeypatch.chdir(tmp_path)                       # the script names its files relative to the output prefix: `dpo`, as in the golden run
+    scripts, data = [], {}
+    for ci in range(len(synth.read_fasta(os.path.join(golden_dir, "cx.qry.fa")))):
+        for fn in os.listdir("."):
+            os.remove(fn)
+        if hostlib.dotplot(px, os.path.join(golden_dir, "cx.qry.fa"), ci, "dpo.gp", "dpo", per_contig):
+            scripts.append(open("dpo.gp").read())
+            data.update({fn: open(fn).read() for fn in os.listdir(".") if fn != "dpo.gp"})
     o.close()
-    qname = synth.read_fasta(os.path.join(golden_dir, "cx.qry.fa"))[2][0]
-    gp = open(pre + ".gp").read()
-    assert gp.startswith("set terminal postscript color solid 'Courier' 15\nset output '%s-%s.ps'\n" % (pre, qname)) and "set xlabel 'Query (%s)'" % qname in gp
-    plotted = [ln for ln in gp.splitlines() if ln.startswith("plot ")][0]
-    score = np.zeros(len(idx.chr_names), np.int64)
-    np.add.at(score, dump["b_chr"], dump["b_score"])
-    want_chr = [i for i in np.argsort(-score, kind="stable") if score[i] >= 1000][:5]
-    assert len(want_chr) == 2 and plotted.count(" with lp ls ") == 2
-    off = np.concatenate([[0], np.cumsum(dump["b_nfrag"])])
-    for rank, ci in enumerate(want_chr):
-        name = idx.chr_names[ci]
-        assert "'%s.%svs%s' title '%s' with lp ls %d" % (pre, qname, name, name, rank + 1) in plotted
-        rows = open("%s.%svs%s" % (pre, qname, name)).read().split("\n\n")
-        assert rows[0] == "0 0\n0 0"
-        segs = [tuple(int(x) for x in r.split()) for r in rows[1:] if r.strip()]
-        blk = [b for b in range(dump["b_score"].size) if dump["b_chr"][b] == ci and dump["b_score"][b] > 0]
-        assert len(segs) == len(blk)
-        for (q0, g0, q1, g1), b in zip(segs, blk):
-            f0, f1 = off[b], off[b + 1] - 1
-            assert q0 == dump["f_qpos"][f0] + 1 and q1 == dump["f_qpos"][f1] + dump["f_qlen"][f1] and g0 == dump["b_gpos"][b]
+    assert scripts == gold["scripts"]
+    assert data == gold["data"]
+
