@@ -3,9 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = gsa_align_contig on one query contig: upload of the contig (H2D), seed search -> locate -> sort ->
-chaining -> refinement -> gap DP -> gapped strings, block records and strings back in host memory (D2H) -- the metric
-as SURVEY.md section 8(d) defines it.  The steps rotate over several DISTINCT query contigs (different mutation
+One "step" = the hot path on one query contig: seed search -> locate -> sort -> chaining -> refinement -> gap DP ->
+gapped strings, block records and strings back in host memory (D2H).  `value` is measured with the query contigs ALREADY
+RESIDENT IN HBM (gsa_align_contig_device: the contract's "inputs resident when the timed region starts"); the same K steps
+are then run again from pinned host buffers (gsa_align_contig: H2D of the contig inside the step) and reported as
+`pcie_inclusive` -- never as `value`.  The steps rotate over several DISTINCT query contigs (different mutation
 seeds), so a step never finds its own data warm in the Infinity Cache, and they are driven the way a multi-contig run
 drives the library: `--inflight` contexts per GPU (gsa_clone: one device index, one context per host thread), each
 working on its own contig, so that the upload and the seed search of one contig overlap the DP tail of another.
@@ -133,8 +135,8 @@ class Runner:
         self.ctx[0].close()
 
     def run(self, n_steps, step_of):
-        """Align the contigs of n_steps steps (step_of(n) = flat list of contig buffers in step order) on the contexts:
-        gsa_align_many, i.e. one host thread per context inside the library."""
+        """Align the contigs of n_steps steps (step_of(n) = flat list of contig buffers -- pinned host arrays or DeviceContig
+        objects -- in step order) on the contexts: gsa_align_many, i.e. one host thread per context inside the library."""
         from gsalign_amd import capi
         capi.align_many(self.ctx, step_of(n_steps), in_order=True)      # (in step order: consecutive steps are DIFFERENT query genomes)
 
@@ -146,13 +148,14 @@ def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup):
     inflight = args.inflight if args.inflight > 0 else wl.get("inflight", 2)
     run = Runner(idx, local_rank, inflight, wl["params"])
     g0 = run.ctx[0]
-    pinned = [[g0.pinned_copy(c) for c in gq] for gq in genomes]       # contigs live in pinned host memory (gsa_host_alloc), like a loader's buffers
+    pinned = [[g0.pinned_copy(c) for c in gq] for gq in genomes]       # contigs in pinned host memory (gsa_host_alloc), like a loader's buffers
+    resident = [[g0.device_copy(c, local_rank) for c in gq] for gq in genomes]      # ... and the same contigs resident in HBM (gsa_device_alloc / gsa_device_upload)
     bp_per_step = float(np.mean([sum(c.size for c in gq) for gq in genomes]))
 
-    def step_list(n):
+    def step_list(n, src=resident):
         out = []
         for s in range(n):
-            out.extend(pinned[s % len(pinned)])
+            out.extend(src[s % len(src)])
         return out
 
     # -- accounting pass (untimed): the event counters of SURVEY 8(d), exact, averaged over the distinct query genomes
@@ -181,13 +184,18 @@ def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup):
     run.run(steps, step_list)
     sync(); t_total = time.perf_counter() - t0
     seed_live_ms = sum(float(g.timings()[6]) for g in run.ctx) / max(1, steps)      # per step (= all contigs of one query genome), beside the other contexts' kernels
+    # the same K steps from pinned HOST buffers: H2D of every contig inside the step (reported beside `value`, never as it)
+    run.run(min(warmup, 2), lambda n: step_list(n, pinned))
+    sync(); t0 = time.perf_counter()
+    run.run(steps, lambda n: step_list(n, pinned))
+    sync(); t_pcie = time.perf_counter() - t0
     recs = g0.block_records()
     run.close()
     per_step = len(pinned[0])
     alg = {"occ_blocks": 64.0 * cnt[0], "lf_steps": 64.0 * cnt[1], "sa_reads": 8.0 * cnt[2], "query": bp_per_step, "seeds": 16.0 * cnt[3],
            "dp_cells": cnt[4], "dp_fragments": cnt[6]}
     return dict(px=px, refs=refs, genomes=genomes, t_total=t_total, bp=bp_per_step * steps, bp_per_step=bp_per_step, steps=steps, alg=alg, cnt=cnt, tm=tm,
-                occ_read=occ_read, seed_live_ms=seed_live_ms, recs=recs, n_blocks=n_blocks, n_frags=n_frags, n_aln=n_aln, contigs_per_step=per_step, inflight=inflight)
+                occ_read=occ_read, seed_live_ms=seed_live_ms, t_pcie=t_pcie, recs=recs, n_blocks=n_blocks, n_frags=n_frags, n_aln=n_aln, contigs_per_step=per_step, inflight=inflight)
 
 
 def measure_split(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup, dev):
@@ -219,10 +227,15 @@ def measure_split(name, wl, args, tmp, rank, world, local_rank, sync, steps, war
     return dict(t_total=t_total, bp=bp_per_step * steps / world, bp_per_step=bp_per_step, steps=steps)
 
 
+PMC_FILE = "profiles/r03_pmc_{name}.json"
+
+
 def pmc_traffic(name):
-    """PMC traffic per step of the top kernels, from the separate rocprofv3 --pmc passes (tools/pmc_top.sh -> profiles/r02_pmc_<workload>.json)."""
+    """PMC traffic per step of the top kernels.  NOT measured in this run: rocprofv3 --pmc needs passes of its own (one counter
+    set per pass, tools/pmc_top.sh -> tools/pmc_top.py -> profiles/r03_pmc_<workload>.json, which names the commit it was taken
+    at); the JSON line says where the number comes from (`traffic_source`)."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", f"r02_pmc_{name}.json")))
+        return json.load(open(os.path.join(ROOT, PMC_FILE.format(name=name))))
     except Exception:      # noqa: BLE001
         return None
 
@@ -237,23 +250,30 @@ def summarise(name, wl, m, t_max, total_bp, world, args):
     tm, cnt = m["tm"], m["cnt"]
     seed_alg = m["alg"]["occ_blocks"] + m["alg"]["query"]
     dp_alg = m["alg"]["dp_cells"] + m["alg"]["dp_fragments"]
-    loc_alg = m["alg"]["lf_steps"] + m["alg"]["sa_reads"] + m["alg"]["seeds"]
+    # locate + order: this kernel reads the DENSE suffix array (8 B per located hit) and writes the seeds; the LF walk the
+    # reference's bwt_sa does for every hit (the `lf_steps` term of the whole-path formula) is work it does not do, so that
+    # term is not its algorithmic traffic
+    loc_alg = m["alg"]["sa_reads"] + m["alg"]["seeds"]
     for kname, ms, ab, key in (("k_seed_wg + k_dense_search (seed search, S1): mean launch duration over the TIMED steps, hipEvents, contexts in flight beside each other", m["seed_live_ms"] if m["seed_live_ms"] > 0 else float(tm[0]), seed_alg, "k_seed_wg"),
                                ("k_dp_stripe + k_dp_small/tiny + k_materialize (extend stage, S7): stage timer, one context alone, untimed pass", float(tm[5]), dp_alg, "k_dp_stripe"),
-                               ("k_seed_select + sort + group (locate/order, S1 tail): stage timer, one context alone, untimed pass", float(tm[1] + tm[2]), loc_alg, "k_seed_select")):
+                               ("k_seed_select + sort + group (locate/order, S1 tail; algorithmic bytes = dense-SA reads + seed records, the reference's LF walk is replaced, not performed): stage timer, one context alone, untimed pass", float(tm[1] + tm[2]), loc_alg, "k_seed_select")):
         a = ab / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         tr = None
         if pmc and key in pmc.get("kernels", {}):
             tr = float(pmc["kernels"][key]["traffic_bytes_per_step"])
         kern.append({"kernel": kname, "ms_per_step": ms, "algorithmic_bytes_per_step": ab, "achieved": a, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": tr})
     traffic = float(pmc["traffic_bytes_per_step"]) if pmc and "traffic_bytes_per_step" in pmc else None
+    traffic_source = (f"{PMC_FILE.format(name=name)} (separate rocprofv3 --pmc passes at commit {pmc.get('commit', '?')}, --inflight 1; not measured in this run)" if pmc else None)
+    ms_pcie = 1000.0 * m["t_pcie"] / m["steps"]
     return {
         "value": total_bp / t_max / 1e9, "ms_per_step": ms_step,
-        "config": {"workload": wl["label"] + f"; {len(m['genomes'])} distinct query genomes rotating; step = gsa_align_contig per contig incl. H2D of the query and D2H of records + strings",
+        "pcie_inclusive": {"value": m["bp_per_step"] * world / (ms_pcie * 1e-3) / 1e9 if ms_pcie > 0 else None, "ms_per_step": ms_pcie, "unit": "Gbp/s",
+                           "note": "same K steps with every contig uploaded from pinned host memory inside the step (gsa_align_contig); rank 0's clock"},
+        "config": {"workload": wl["label"] + f"; {len(m['genomes'])} distinct query genomes rotating, resident in HBM (gsa_align_contig_device); step = S1..S7 per contig incl. D2H of records + strings",
                    "query_bp_per_step": int(m["bp_per_step"]), "contigs_per_step": m["contigs_per_step"], "inflight_contexts_per_gpu": m["inflight"],
                    "parallelism": f"contig-shard x{world}, index replicated", "aligner_params": wl["params"]},
         "roofline": {"bound": "hbm", "kernel": "whole hot path S1-S7 (SURVEY 8(d) formula: 64 N_occblk + 64 N_lf + 8 N_sa + L_query + 16 N_seed + N_dpcells + sum(m+n))",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_step": alg_total, "terms": m["alg"], "bytes_per_query_base": alg_total / m["bp_per_step"]},
         "kernels": kern,
         "stage_ms_one_context_alone": {"seed_search": float(tm[0]), "locate": float(tm[1]), "sort_group": float(tm[2]), "chain": float(tm[3]), "refine": float(tm[4]),
@@ -261,6 +281,20 @@ def summarise(name, wl, m, t_max, total_bp, world, args):
         "counters_per_step": {"occ_blocks_algorithmic": int(cnt[0]), "occ_blocks_read": int(m["occ_read"]), "lf_steps_algorithmic": int(cnt[1]), "hits": int(cnt[2]), "seeds": int(cnt[3]),
                               "dp_cells": int(cnt[4]), "dp_jobs": int(cnt[5]), "blocks_last_contig": m["n_blocks"], "records_last_contig": m["n_frags"], "string_bytes_last_contig": m["n_aln"]},
     }
+
+
+def physical_cores():
+    """Physical cores of this host (logical CPUs / SMT siblings per core); the reference's -t."""
+    n = os.cpu_count() or 1
+    try:
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        per = 0
+        for part in sib.split(","):
+            a, _, b = part.partition("-")
+            per += int(b or a) - int(a) + 1
+        return max(1, n // max(1, per))
+    except Exception:      # noqa: BLE001
+        return n
 
 
 def cpu_baseline(px, qry, tmp, budget_bp):
@@ -281,7 +315,7 @@ def cpu_baseline(px, qry, tmp, budget_bp):
     code = ("import sys,time;sys.path.insert(0,%r);import numpy as np;from oracle import oracle_py as op;from gsalign_amd import synth;"
             "r=op.RefLib(%r);q=synth.read_fasta(%r)[0][1];r.set_query(q);t=time.time();r.run_to(8);print(time.time()-t)" % (ROOT, px, qfa))
     t1 = float(subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1])
-    nthr = min(cores, 32)
+    nthr = physical_cores()                        # the reference's pthread path on all physical cores of this host
     t = time.time(); op.ref_run_cli(px, qfa, os.path.join(tmp, "cpu_out"), threads=nthr); tn = time.time() - t
     t = time.time(); op.ref_run_cli(px, tiny, os.path.join(tmp, "cpu_out0"), threads=nthr); t0 = time.time() - t
     v1 = sample.size / t1 / 1e9
@@ -438,7 +472,7 @@ def main():
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GSA_BENCH_TMP=tmp, GSA_BENCH_KEEP="1"))
                 d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
                 e = {"workload": name, "steps": st, "unit": "Gbp/s"}
-                e.update({k: d[k] for k in ("value", "ms_per_step", "config", "roofline", "kernels", "stage_ms_one_context_alone", "counters_per_step")})
+                e.update({k: d[k] for k in ("value", "ms_per_step", "pcie_inclusive", "config", "roofline", "kernels", "stage_ms_one_context_alone", "counters_per_step")})
                 extras.append(e)
             except Exception as ex:      # noqa: BLE001
                 extras.append({"workload": name, "value": None, "error": repr(ex)[:300]})

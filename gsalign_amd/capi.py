@@ -16,7 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgsa_hip.so")
 
 EXPORTS = [
-    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many", "gsa_seed_chunks", "gsa_hit_count", "gsa_export_hits", "gsa_import_hits", "gsa_finish_contig",
+    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many",
+    "gsa_align_contig_device", "gsa_set_query_device", "gsa_device_alloc", "gsa_device_free", "gsa_device_upload", "gsa_get_seed_stats", "gsa_seed_chunks", "gsa_hit_count", "gsa_export_hits", "gsa_import_hits", "gsa_finish_contig",
     "gsa_set_query", "gsa_rewind", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
     "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling", "gsa_bind_host_thread",
 ]
@@ -47,14 +48,49 @@ class Block(C.Structure):
                 ("bdir", C.c_int32), ("gpos", C.c_int32), ("chr", C.c_int32), ("_pad", C.c_int32)]
 
 
+class Rec(C.Structure):
+    """gsa_rec, 16 bytes: seed {qpos >= 0, len, rpos} or gap {-1 - qlen, rlen, aln_len, aln_off} (include/gsa_hip.h)."""
+    _fields_ = [("w0", C.c_int32), ("w1", C.c_int32), ("w2", C.c_int32), ("w3", C.c_uint32)]
+
+
 class Result(C.Structure):
     _fields_ = [("n_blocks", C.c_int32), ("n_frags", C.c_int64), ("n_aln", C.c_int64), ("blocks", C.POINTER(Block)),
-                ("frags", C.POINTER(Frag)), ("aln1", C.POINTER(C.c_char)), ("aln2", C.POINTER(C.c_char))]
+                ("recs", C.POINTER(Rec)), ("aln1", C.POINTER(C.c_char)), ("aln2", C.POINTER(C.c_char))]
 
 
 FRAG_DT = np.dtype([("bseed", "<i4"), ("qpos", "<i4"), ("qlen", "<i4"), ("rlen", "<i4"), ("rpos", "<i8"), ("aln_off", "<i8"), ("aln_len", "<i4"), ("_pad", "<i4")])
 BLOCK_DT = np.dtype([("score", "<i4"), ("aln_len", "<i4"), ("bdup", "<i4"), ("n_frag", "<i4"), ("frag_off", "<i8"), ("bdir", "<i4"), ("gpos", "<i4"), ("chr", "<i4"), ("_pad", "<i4")])
 SEED_DT = np.dtype([("qpos", "<i4"), ("len", "<i4"), ("rpos", "<i8")])
+REC_DT = np.dtype([("w0", "<i4"), ("w1", "<i4"), ("w2", "<i4"), ("w3", "<u4")])
+
+
+def expand_recs(recs: np.ndarray) -> np.ndarray:
+    """gsa_rec[n] -> gsa_frag[n] (FRAG_DT): numpy form of gsa_expand_frags (include/gsa_hip.h)."""
+    n = recs.size
+    F = np.zeros(n, FRAG_DT)
+    if not n:
+        return F
+    seed = recs["w0"] >= 0
+    rpos = recs.view(np.int64).reshape(-1, 2)[:, 1]
+    F["bseed"] = seed
+    F["qpos"][seed] = recs["w0"][seed]; F["qlen"][seed] = recs["w1"][seed]; F["rlen"][seed] = recs["w1"][seed]; F["rpos"][seed] = rpos[seed]
+    g = np.flatnonzero(~seed)
+    if g.size:
+        assert g[0] > 0 and seed[g - 1].all(), "a gap record follows a seed record"
+        F["qpos"][g] = recs["w0"][g - 1] + recs["w1"][g - 1]; F["rpos"][g] = rpos[g - 1] + recs["w1"][g - 1]
+        F["qlen"][g] = -1 - recs["w0"][g]; F["rlen"][g] = recs["w1"][g]; F["aln_len"][g] = recs["w2"][g]; F["aln_off"][g] = recs["w3"][g]
+    return F
+
+
+def pack_recs(F: np.ndarray) -> np.ndarray:
+    """gsa_frag[n] -> gsa_rec[n]: the inverse (what the library's last pass does on the device)."""
+    R = np.zeros(F.size, REC_DT)
+    seed = F["bseed"] != 0
+    rpos = R.view(np.int64).reshape(-1, 2)[:, 1]
+    R["w0"][seed] = F["qpos"][seed]; R["w1"][seed] = F["qlen"][seed]; rpos[seed] = F["rpos"][seed]
+    g = ~seed
+    R["w0"][g] = -1 - F["qlen"][g]; R["w1"][g] = F["rlen"][g]; R["w2"][g] = F["aln_len"][g]; R["w3"][g] = F["aln_off"][g].astype(np.uint32)
+    return R
 
 
 def build_library() -> None:
@@ -72,6 +108,12 @@ def load_library() -> C.CDLL:
     lib.gsa_host_alloc.restype = C.c_void_p
     lib.gsa_host_alloc.argtypes = [C.c_size_t]
     lib.gsa_host_free.argtypes = [C.c_void_p]
+    lib.gsa_device_alloc.restype = C.c_void_p
+    lib.gsa_device_alloc.argtypes = [C.c_int, C.c_size_t]
+    lib.gsa_device_free.argtypes = [C.c_int, C.c_void_p]
+    lib.gsa_device_upload.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.gsa_align_contig_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(Result)]
+    lib.gsa_set_query_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.gsa_last_error.restype = C.c_char_p
     lib.gsa_last_error.argtypes = [C.c_void_p]
     lib.gsa_seed_count.restype = C.c_int64
@@ -98,18 +140,36 @@ def bind_host_thread(device: int = 0) -> None:
 RESULT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(Result))
 
 
+class DeviceContig:
+    """A query contig resident in device memory (gsa_device_alloc + gsa_device_upload): what gsa_align_contig_device takes."""
+
+    def __init__(self, lib, device: int, seq: np.ndarray):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        self.lib, self.device, self.size = lib, int(device), int(seq.size)
+        self.ptr = lib.gsa_device_alloc(self.device, self.size)
+        if not self.ptr:
+            raise GsaError("gsa_device_alloc failed")
+        if lib.gsa_device_upload(self.device, C.c_void_p(self.ptr), C.c_void_p(seq.ctypes.data), self.size) != 0:
+            raise GsaError("gsa_device_upload failed")
+
+    def free(self):
+        if self.ptr:
+            self.lib.gsa_device_free(self.device, C.c_void_p(self.ptr)); self.ptr = None
+
+
 def align_many(aligners, contigs, on_result=None, in_order: bool = False) -> None:
-    """gsa_align_many: `contigs` (uint8 arrays) on the given contexts, one host thread per context inside the library.
-    on_result(contig_index, Result) runs on the worker threads (the Result is valid during the call only).  in_order: hand
-    the contigs out as listed (GSA_MANY_IN_ORDER) instead of longest first."""
+    """gsa_align_many: `contigs` (uint8 arrays, or DeviceContig objects -- all of one kind) on the given contexts, one host
+    thread per context inside the library.  on_result(contig_index, Result) runs on the worker threads (the Result is valid
+    during the call only).  in_order: hand the contigs out as listed (GSA_MANY_IN_ORDER) instead of longest first."""
     lib = aligners[0].lib
     n = len(contigs)
     ctxs = (C.c_void_p * len(aligners))(*[a.ctx for a in aligners])
-    qs = (C.c_char_p * n)(*[C.cast(c.ctypes.data, C.c_char_p) for c in contigs])
+    on_dev = n > 0 and isinstance(contigs[0], DeviceContig)
+    qs = (C.c_char_p * n)(*[C.cast(c.ptr if on_dev else c.ctypes.data, C.c_char_p) for c in contigs])
     ql = (C.c_int32 * n)(*[int(c.size) for c in contigs])
     cb = RESULT_FN((lambda user, ci, res: int(on_result(ci, res.contents) or 0)) if on_result else 0)
     lib.gsa_align_many.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_uint32, RESULT_FN, C.c_void_p]
-    rc = lib.gsa_align_many(ctxs, len(aligners), qs, ql, n, 1 if in_order else 0, cb, None)
+    rc = lib.gsa_align_many(ctxs, len(aligners), qs, ql, n, (1 if in_order else 0) | (2 if on_dev else 0), cb, None)
     if rc != 0:
         msgs = [lib.gsa_last_error(a.ctx).decode() for a in aligners]
         raise GsaError(f"gsa_align_many -> {rc}: {'; '.join(m for m in msgs if m)}")
@@ -130,6 +190,7 @@ class Aligner:
         self.lib = load_library()
         self.idx = idx
         self._pinned = []
+        self._devbufs = []
         if _clone_of is not None:
             self.ctx = C.c_void_p()
             rc = self.lib.gsa_clone(_clone_of.ctx, C.byref(self.ctx))
@@ -168,6 +229,22 @@ class Aligner:
         buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(seq.size,))
         buf[:] = seq
         return buf
+
+    def device_copy(self, seq: np.ndarray, device: int = 0) -> DeviceContig:
+        """seq uploaded once into device memory (gsa_device_alloc / gsa_device_upload); freed by close()."""
+        d = DeviceContig(self.lib, device, seq)
+        self._devbufs.append(d)
+        return d
+
+    def align_contig_device(self, d: DeviceContig) -> dict:
+        res = Result()
+        self._ck(self.lib.gsa_align_contig_device(self.ctx, C.c_void_p(d.ptr), C.c_int32(d.size), C.byref(res)))
+        return self._result(res)
+
+    def seed_stats(self) -> np.ndarray:
+        st = np.zeros(8, np.uint64)
+        self._ck(self.lib.gsa_get_seed_stats(self.ctx, _p(st, C.c_uint64)))
+        return st
 
     def _params(self, slen=15, ind=25, clr=200, alen=200, idy=70, sen=0, one=0) -> Params:
         return Params(slen, ind, clr, alen, idy, sen, one)
@@ -252,7 +329,8 @@ class Aligner:
     def _result(self, res: Result) -> dict:
         nb, nf, na = res.n_blocks, res.n_frags, res.n_aln
         blocks = np.ctypeslib.as_array(C.cast(res.blocks, C.POINTER(C.c_uint8)), shape=(nb * BLOCK_DT.itemsize,)).view(BLOCK_DT).copy() if nb else np.zeros(0, BLOCK_DT)
-        frags = np.ctypeslib.as_array(C.cast(res.frags, C.POINTER(C.c_uint8)), shape=(nf * FRAG_DT.itemsize,)).view(FRAG_DT).copy() if nf else np.zeros(0, FRAG_DT)
+        recs = np.ctypeslib.as_array(C.cast(res.recs, C.POINTER(C.c_uint8)), shape=(nf * REC_DT.itemsize,)).view(REC_DT).copy() if nf else np.zeros(0, REC_DT)
+        frags = expand_recs(recs)
         a1 = np.ctypeslib.as_array(C.cast(res.aln1, C.POINTER(C.c_uint8)), shape=(na,)).copy() if na else np.zeros(0, np.uint8)
         a2 = np.ctypeslib.as_array(C.cast(res.aln2, C.POINTER(C.c_uint8)), shape=(na,)).copy() if na else np.zeros(0, np.uint8)
         return dict(blocks=blocks, frags=frags, aln1=a1, aln2=a2)
@@ -356,6 +434,9 @@ class Aligner:
         for p in self._pinned:
             self.lib.gsa_host_free(p)
         self._pinned = []
+        for d in self._devbufs:
+            d.free()
+        self._devbufs = []
 
 
 def apply_ops(s1: bytes, s2: bytes, ops: bytes):

@@ -80,6 +80,11 @@ int gsa_set_params(gsa_ctx *c, const gsa_params *p)
 	if (!c || !p) return GSA_ERR_ARG;
 	if (p->min_seed_len < 1 || p->max_indel < 0) return gsa_fail(c, GSA_ERR_ARG, "bad parameter");
 	GSA_CHECK(c, hipSetDevice(c->device));
+	// The presence bitmap and the short k-mer table depend on MinSeedLength and are read by every context cloned FROM this one
+	// (gsa_clone copies the pointers): rebuilding them here -- in place, or freed and reallocated -- would hand those clones a
+	// bitmap of another k or freed memory.  A clone that changes its own parameters builds tables of its own.
+	if (c->n_borrowers.load() > 0 && (p->sensitive ? 10 : p->min_seed_len) != c->prm.MinSeedLength)
+		return gsa_fail(c, GSA_ERR_STATE, "gsa_set_params: contexts cloned from this one read its seed tables -- change -slen / -sen on the clones, or destroy them first");
 	if (int rc = reset_run_state(c)) return rc;
 	c->prm.MinSeedLength = p->sensitive ? 10 : p->min_seed_len;         // main.cpp:323
 	c->prm.MaxIndelSize = p->max_indel; c->prm.MinAlnBlockScore = p->min_block_score; c->prm.MinAlnLength = p->min_aln_len;
@@ -105,6 +110,7 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	c->device = device; c->force_wide = (flags & GSA_CREATE_WIDE) != 0;
 	if (const char *b = getenv("GSA_SEED_BUDGET")) c->seed_budget = (u32)atoi(b);
 	if (const char *b = getenv("GSA_DP_SAFE")) c->dp_safe = atoi(b) != 0;      // (test hook: always take the one-job-per-launch path of the striped DP)
+	if (const char *b = getenv("GSA_DP_FAKE_TIMEOUT")) c->dp_fake_timeout = atoi(b);      // (test hook: the retry after a hand-off time-out)
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gsa_fail(nullptr, GSA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); gsa_destroy(c); return GSA_ERR_HIP; } } while (0)
 	CK(hipSetDevice(device));
@@ -153,13 +159,14 @@ void gsa_destroy(gsa_ctx *c)
 	if (!c) return;
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
+	if (c->lender) c->lender->n_borrowers.fetch_sub(1);      // (`parent` outlives its clones: gsa_hip.h)
 	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->d_query, &c->tmp, &c->d_cnt, &c->d_mail, &c->d_lb_status[0], &c->d_lb_status[1],
 		&c->d_sa_dense, &c->d_kmer, &c->d_kmer_lo, &c->d_pres, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_heavy, &c->dn_memo, &c->dn_lf, &c->dn_x0, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
 		&c->d_flag, &c->d_scan, &c->g_beg, &c->w_j0, &c->w_j1, &c->w_on, &c->d_pdbm, &c->d_gpre, &c->d_key_c, &c->d_val_c, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
 		&c->a_next, &c->a_brk, &c->a_aurank, &c->a_aulist, &c->a_runinfo, &c->w_best, &c->w_sum, &c->w_n, &c->d_btab, &c->d_flag2, &c->d_scan2, &c->d_i64a,
 		&c->b_q, &c->b_len, &c->b_r, &c->b_gb, &c->b_ge, &c->c_q, &c->c_len, &c->c_r, &c->c_gb, &c->c_ge, &c->c_bid, &c->blk_beg, &c->blk_end, &c->blk_score,
 		&c->r_q, &c->r_len, &c->r_r, &c->r_bid, &c->r_tmp_q, &c->r_tmp_len, &c->r_tmp_r, &c->r_tmp_bid, &c->r_cut4, &c->r_cut5, &c->r_simjob, &c->r_simres, &c->d_leaf,
-		&c->fb_seedbase, &c->fb_sbeg, &c->fb_fragbase, &c->f_rec, &c->f_type, &c->f_mism, &c->f_alnlen, &c->f_job, &c->f_score,
+		&c->fb_seedbase, &c->fb_sbeg, &c->fb_fragbase, &c->f_rec, &c->f_rec16, &c->f_type, &c->f_mism, &c->f_alnlen, &c->f_job, &c->f_score,
 		&c->d_dp_tiny, &c->d_dp_bnd, &c->d_dp_ctr, &c->d_dp_jobs, &c->d_dp_large, &c->d_tail,
 		&c->e_id, &c->e_rec, &c->e_list, &c->e_off1, &c->e_off2, &c->e_opsoff, &c->e_nops, &c->e_ops, &c->e_rev, &c->r_head, &c->f_early, &c->r_orig, &c->r_tmp_orig, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_alnoff, &c->bl_alnlen, &c->bl_score,
 		&c->leaf[0], &c->leaf[1], &c->leaf[2], &c->leaf[3], &c->leaf[4], &c->leaf[5], &c->leaf[6], &c->leaf[7], &c->leaf[8] };
@@ -189,6 +196,7 @@ int gsa_clone(gsa_ctx *parent, gsa_ctx **out)
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
 	if (int rc = ctx_private_init(c)) { g_create_error = c->err; gsa_destroy(c); return rc; }
 	c->di = parent->di; c->G = parent->G;
+	c->lender = parent; parent->n_borrowers.fetch_add(1);
 	c->h_chr_end = parent->h_chr_end; c->h_chr_fwd = parent->h_chr_fwd; c->h_chr_of_end = parent->h_chr_of_end; c->h_chr_len = parent->h_chr_len;
 	c->prm = parent->prm;
 	*out = c;
@@ -242,6 +250,15 @@ void gsa_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->acc_seed_ms = 0.0; c->profiling = (enable & 1) != 0; c->count_blocks = (enable & 2) != 0; c->prof_seed = (enable & 4) != 0; return GSA_OK; }
 
+static int query_geometry(gsa_ctx *c, int32_t qlen)
+{
+	c->qlen = qlen;
+	c->qbits = ceil_log2_u64((u64)qlen + 1); if (c->qbits < 1) c->qbits = 1;
+	c->pdbits = ceil_log2_u64((u64)(2 * c->G) + (u64)qlen + 2);
+	if (c->qbits + c->pdbits > 64) return gsa_fail(c, GSA_ERR_LIMIT, "contig too long for the 64-bit seed key");
+	return GSA_OK;
+}
+
 int gsa_set_query(gsa_ctx *c, const char *query, int32_t qlen)
 {
 	if (!c || !query || qlen < 0) return GSA_ERR_ARG;
@@ -251,11 +268,47 @@ int gsa_set_query(gsa_ctx *c, const char *query, int32_t qlen)
 	// (a buffer from gsa_host_alloc is pinned: the copy is one DMA transfer the seed kernel queues behind; pageable memory is
 	// staged by the runtime)
 	GSA_CHECK(c, hipMemcpyAsync(c->d_query.p, query, (size_t)qlen, hipMemcpyHostToDevice, c->stream));
-	c->qlen = qlen;
-	c->qbits = ceil_log2_u64((u64)qlen + 1); if (c->qbits < 1) c->qbits = 1;
-	c->pdbits = ceil_log2_u64((u64)(2 * c->G) + (u64)qlen + 2);
-	if (c->qbits + c->pdbits > 64) return gsa_fail(c, GSA_ERR_LIMIT, "contig too long for the 64-bit seed key");
+	c->q_dev = c->d_query.as<uint8_t>();
+	return query_geometry(c, qlen);
+}
+
+// The contig is already in device memory (a loader that decodes FASTA on the GPU, or a contig kept resident between runs):
+// used in place, no copy.
+int gsa_set_query_device(gsa_ctx *c, const char *d_query, int32_t qlen)
+{
+	if (!c || !d_query || qlen < 0) return GSA_ERR_ARG;
+	if (((uintptr_t)d_query & 15) != 0) return gsa_fail(c, GSA_ERR_ARG, "gsa_set_query_device: the buffer must be 16-byte aligned");
+	GSA_CHECK(c, hipSetDevice(c->device));
+	hipPointerAttribute_t at;
+	if (hipPointerGetAttributes(&at, d_query) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != c->device) { (void)hipGetLastError(); return gsa_fail(c, GSA_ERR_ARG, "gsa_set_query_device: not a device buffer of this context's GPU"); }
+	if (int rc = reset_run_state(c)) return rc;
+	c->q_dev = (const uint8_t *)d_query;
+	return query_geometry(c, qlen);
+}
+
+void *gsa_device_alloc(int device, size_t bytes)
+{
+	void *p = nullptr;
+	if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, (bytes ? bytes : 1) + 64) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+	return p;
+}
+void gsa_device_free(int device, void *p) { if (p && hipSetDevice(device) == hipSuccess) (void)hipFree(p); }
+int gsa_device_upload(int device, void *dst, const void *src, size_t bytes)
+{
+	if (!dst || (!src && bytes)) return GSA_ERR_ARG;
+	if (hipSetDevice(device) != hipSuccess || hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return GSA_ERR_HIP; }
 	return GSA_OK;
+}
+
+// Back to the end of stage 1 of a contig whose hits were imported (gsa_finish_contig's retry): everything later is dropped.
+static int rewind_to_hits(gsa_ctx *c)
+{
+	const i64 n_seeds = c->n_seeds; const i32 n_groups = c->n_groups;
+	if (int rc = reset_run_state(c)) return rc;
+	GSA_CHECK(c, hipStreamSynchronize(c->stream));
+	c->n_seeds = n_seeds; c->n_groups = n_groups; c->counters[2] = c->counters[3] = (u64)n_seeds;
+	c->stage = 1;
+	return stage1_restore_pdbm(c);
 }
 
 // Back to stage 0 with the same contig: the query stays where gsa_set_query put it (device and host copy).
@@ -270,6 +323,9 @@ int gsa_rewind(gsa_ctx *c)
 int gsa_run_to(gsa_ctx *c, int stage)
 {
 	if (!c || stage < 0 || stage > 8) return GSA_ERR_ARG;
+	// (between gsa_seed_chunks and gsa_finish_contig the context holds the hits of a chunk range only: stage 1 here would seed
+	//  that range again and call the result a contig)
+	if (c->split) return gsa_fail(c, GSA_ERR_STATE, "gsa_run_to: a split contig is finished with gsa_finish_contig");
 	GSA_CHECK(c, hipSetDevice(c->device));
 	int rc = GSA_OK;
 	while (c->stage < stage && rc == GSA_OK) {
@@ -290,10 +346,22 @@ int gsa_run_to(gsa_ctx *c, int stage)
 	return rc;
 }
 
+static int align_uploaded(gsa_ctx *c, gsa_result *out);
 int gsa_align_contig(gsa_ctx *c, const char *query, int32_t qlen, gsa_result *out)
 {
 	if (!c || !out) return GSA_ERR_ARG;
 	int rc = gsa_set_query(c, query, qlen); if (rc) return rc;
+	return align_uploaded(c, out);
+}
+int gsa_align_contig_device(gsa_ctx *c, const char *d_query, int32_t qlen, gsa_result *out)
+{
+	if (!c || !out) return GSA_ERR_ARG;
+	int rc = gsa_set_query_device(c, d_query, qlen); if (rc) return rc;
+	return align_uploaded(c, out);
+}
+static int align_uploaded(gsa_ctx *c, gsa_result *out)
+{
+	int rc;
 	c->dp_timeout = false;
 	rc = gsa_run_to(c, 8);
 	if (rc == GSA_ERR_STATE && c->dp_timeout && !c->dp_safe) {
@@ -349,15 +417,27 @@ int gsa_finish_contig(gsa_ctx *c, gsa_result *out)
 	GSA_CHECK(c, hipSetDevice(c->device));
 	int rc = stage1_finish_split(c); if (rc) return rc;
 	c->stage = 1; c->split = false;
-	rc = gsa_run_to(c, 8); if (rc) return rc;
+	c->dp_timeout = false;
+	rc = gsa_run_to(c, 8);
+	if (rc == GSA_ERR_STATE && c->dp_timeout && !c->dp_safe) {
+		// the same safety net as gsa_align_contig: stages 2-8 again with one DP job per launch, from the hits this context
+		// still holds (d_key_a / d_val_a are read-only for stage 2; the PosDiff bitmap it consumed is set again from the keys)
+		c->dp_timeout = false; c->dp_safe = true;
+		rc = rewind_to_hits(c);
+		if (rc == GSA_OK) rc = gsa_run_to(c, 8);
+		c->dp_safe = false;
+	}
+	if (rc) return rc;
 	return gsa_get_blocks(c, out);
 }
 
 int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n, uint32_t flags, gsa_result_fn on_result, void *user)
 {
-	if (flags & ~(uint32_t)GSA_MANY_IN_ORDER) return GSA_ERR_ARG;
+	if (flags & ~(uint32_t)(GSA_MANY_IN_ORDER | GSA_MANY_DEVICE)) return GSA_ERR_ARG;
 	if (!ctx || n_ctx <= 0 || n < 0 || (n > 0 && (!query || !qlen))) return GSA_ERR_ARG;
 	for (int k = 0; k < n_ctx; k++) if (!ctx[k]) return GSA_ERR_ARG;
+	const bool dev_q = (flags & GSA_MANY_DEVICE) != 0;
+	if (dev_q) for (int k = 1; k < n_ctx; k++) if (ctx[k]->device != ctx[0]->device) return gsa_fail(ctx[0], GSA_ERR_ARG, "GSA_MANY_DEVICE: the contexts must share one GPU (the contigs live in its memory)");
 	if (n == 0) return GSA_OK;
 	// longest first: with dynamic hand-out this is the longest-processing-time-first rule
 	std::vector<int32_t> order((size_t)n);
@@ -370,7 +450,7 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 			if (i >= n || err.load() != GSA_OK) return;
 			const int32_t ci = order[(size_t)i];
 			gsa_result res;
-			int rc = gsa_align_contig(c, query[ci], qlen[ci], &res);
+			int rc = dev_q ? gsa_align_contig_device(c, query[ci], qlen[ci], &res) : gsa_align_contig(c, query[ci], qlen[ci], &res);
 			if (rc == GSA_OK && on_result) rc = on_result(user, ci, &res);
 			if (rc != GSA_OK) { int ok = GSA_OK; err.compare_exchange_strong(ok, rc); return; }
 		}
@@ -431,15 +511,16 @@ int gsa_get_blocks(gsa_ctx *c, gsa_result *out)
 	out->n_blocks = (int32_t)c->h_blocks.size(); out->blocks = c->h_blocks.data();
 	if (c->result_pinned && c->stage == 8) {
 		out->n_frags = c->n_frags; out->n_aln = c->n_aln;
-		out->frags = c->p_frags.as<gsa_frag>(); out->aln1 = c->h_taln1; out->aln2 = c->h_taln2;
+		out->recs = c->p_frags.as<gsa_rec>(); out->aln1 = c->h_taln1; out->aln2 = c->h_taln2;
 	} else {
 		out->n_frags = (int64_t)c->h_frags.size(); out->n_aln = (int64_t)c->h_aln1.size();
-		out->frags = c->h_frags.data(); out->aln1 = c->h_aln1.data(); out->aln2 = c->h_aln2.data();
+		out->recs = c->h_frags.data(); out->aln1 = c->h_aln1.data(); out->aln2 = c->h_aln2.data();
 	}
 	return GSA_OK;
 }
 
 int gsa_get_counters(gsa_ctx *c, uint64_t counters[8]) { if (!c) return GSA_ERR_ARG; memcpy(counters, c->counters, sizeof(c->counters)); return GSA_OK; }
-int gsa_get_timings(gsa_ctx *c, float ms[8]) { if (!c) return GSA_ERR_ARG; memcpy(ms, c->kernel_ms, sizeof(c->kernel_ms)); if (c->prof_seed && !c->profiling) ms[6] = (float)c->acc_seed_ms; if (getenv("GSA_DEBUG")) fprintf(stderr, "[gsa] seed rounds max %llu, dense chunks %llu, wave iters max %llu; slowest chunk: round 1 %.1f us, resolver %.1f us, up to the marks %.1f us\n", (unsigned long long)c->dbg[0], (unsigned long long)c->dbg[1], (unsigned long long)c->dbg[2], c->dbg[3] * 0.01, c->dbg[4] * 0.01, c->dbg[5] * 0.01); return GSA_OK; }
+int gsa_get_timings(gsa_ctx *c, float ms[8]) { if (!c) return GSA_ERR_ARG; memcpy(ms, c->kernel_ms, sizeof(c->kernel_ms)); if (c->prof_seed && !c->profiling) ms[6] = (float)c->acc_seed_ms; return GSA_OK; }
+int gsa_get_seed_stats(gsa_ctx *c, uint64_t st[8]) { if (!c) return GSA_ERR_ARG; memcpy(st, c->dbg, sizeof(c->dbg)); return GSA_OK; }
 
 } // extern "C"

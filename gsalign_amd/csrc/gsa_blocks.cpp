@@ -145,42 +145,30 @@ int host_stage8_finish(gsa_ctx *c)
 	// the striped kernel is still running (the large ones below, from the patch list)
 	GSA_CHECK(c, hipEventSynchronize(c->ev[15]));
 	{
-		gsa_frag *fr = c->p_frags.as<gsa_frag>();
+		gsa_rec *fr = c->p_frags.as<gsa_rec>();
 		const i32 *rec = c->p_jpatch.as<i32>(), *len = rec + c->n_jobs;
-		for (i32 j = 0; j < c->n_jobs; j++) fr[rec[j]].aln_len = len[j];
+		for (i32 j = 0; j < c->n_jobs; j++) fr[rec[j]].gap.aln_len = len[j];
 	}
 	GSA_CHECK(c, hipStreamSynchronize(c->stream));
 	if (c->profiling) { float ms; if (hipEventElapsedTime(&ms, c->ev[8], c->ev[9]) == hipSuccess) c->kernel_ms[5] = ms; (void)hipGetLastError(); }
 	i32 *bl_len = c->p_blk.as<i32>(), *bl_score = bl_len + nfb, *fragbase = bl_score + nfb;
 	const i32 *hm = c->h_tmail;
-	static const char *dbg_env = getenv("GSA_DEBUG_EARLY"); static int dbg_calls = 0;
-	if (c->n_early > 0 && dbg_env && (atoi(dbg_env) < 2 || (++dbg_calls & 31) == 0)) {
-		float a = 0, b = 0; hipEventElapsedTime(&a, c->ev[16], c->ev[20]); hipEventElapsedTime(&b, c->ev[20], c->ev[14]);
-		fprintf(stderr, "[gsa] early DP: list ready -> launch reaches the stream %.1f us, launch -> done %.1f us\n", a * 1e3, b * 1e3);
-		const int evs[] = { 19, 12, 17, 13, 15, 14 }; const char *nm[] = { "job list", "small DP done", "strings", "block sums home", "records+patch home", "stripes done" };
-		{ float t1 = 0; hipEventElapsedTime(&t1, c->ev[14], c->ev[22]); fprintf(stderr, "[gsa]   stripes done -> last copy done %.0f us\n", t1 * 1e3); }
-		{ float a = 0, b = 0, d = 0, e = 0, f = 0; hipEventElapsedTime(&a, c->ev[0], c->ev[1]); hipEventElapsedTime(&b, c->ev[1], c->ev[24]); hipEventElapsedTime(&d, c->ev[24], c->ev[25]); hipEventElapsedTime(&e, c->ev[25], c->ev[26]); hipEventElapsedTime(&f, c->ev[26], c->ev[16]);
-		  fprintf(stderr, "[gsa]   front: seed kernel %.0f | to the (group, qPos) order %.0f | windows + outliers %.0f | multi-hits, compaction, noise %.0f | heads + early list %.0f us\n", a * 1e3, b * 1e3, d * 1e3, e * 1e3, f * 1e3); (void)hipGetLastError(); }
-		{ float t0 = 0; hipEventElapsedTime(&t0, c->ev[0], c->ev[16]); fprintf(stderr, "[gsa]   seed kernel start -> early list %.0f us\n", t0 * 1e3); }
-		fprintf(stderr, "[gsa]   after the early list (us):");
-		for (int k = 0; k < 6; k++) { float t = 0; if (hipEventElapsedTime(&t, c->ev[16], c->ev[evs[k]]) == hipSuccess) fprintf(stderr, "  %s %.0f", nm[k], t * 1e3); }
-		(void)hipGetLastError(); fprintf(stderr, "\n");
-	}
 	if (hm[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	if (hm[M_DPERR2]) { c->dp_dirty = c->dp_timeout = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out"); }
+	if (c->dp_fake_timeout > 0 && !c->dp_safe) { c->dp_fake_timeout--; c->dp_dirty = c->dp_timeout = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out (test hook)"); }
 	if (c->profiling) { const unsigned long long *cc = (const unsigned long long *)(hm + M_CELLS); c->counters[4] += cc[0]; c->counters[6] += cc[1]; }
 	if (c->n_early > 0 && hm[M_DPERR3]) { c->dp_dirty = c->dp_timeout = true; return gsa_fail(c, GSA_ERR_STATE, "internal: DP stripe hand-off timed out (early launch)"); }
 	// the large DP jobs finished after the records left: their (aln_len, score) arrive as a patch list
 	// (first the ones that only turned up in the job list, then the ones launched from the leaf table;
 	//  record -1 = an early job whose leaf the list logic dropped)
 	{
-		gsa_frag *fr = c->p_frags.as<gsa_frag>();
+		gsa_rec *fr = c->p_frags.as<gsa_rec>();
 		const i32 *pt = c->h_tpatch;
 		const i32 np = c->n_large + c->n_early;
 		for (i32 g = 0; g < np; g++) {
 			const i32 rec = pt[3 * g], L = pt[3 * g + 1], sc = pt[3 * g + 2];
 			if (rec < 0) continue;
-			fr[rec].aln_len = L;
+			fr[rec].gap.aln_len = L;
 			const size_t k = (size_t)(std::upper_bound(fragbase, fragbase + nfb, rec) - fragbase) - 1;      // block of the record
 			bl_len[k] += L; bl_score[k] += sc;
 			if (c->profiling && g >= c->n_large) {
@@ -245,7 +233,7 @@ int build_block_view(gsa_ctx *c)
 			gsa_block o; memset(&o, 0, sizeof(o));
 			o.score = c->h_blk_score[b]; o.frag_off = (i64)c->h_frags.size(); o.n_frag = c->h_blk_end[b] - c->h_blk_beg[b];
 			for (i32 s = c->h_blk_beg[b]; s < c->h_blk_end[b]; s++) {
-				gsa_frag f; memset(&f, 0, sizeof(f)); f.bseed = 1; f.qpos = q[s]; f.qlen = f.rlen = l[s]; f.rpos = r[s];
+				gsa_rec f; f.seed.qpos = q[s]; f.seed.len = l[s]; f.seed.rpos = r[s];
 				c->h_frags.push_back(f);
 			}
 			c->h_blocks.push_back(o);
@@ -258,8 +246,15 @@ int build_block_view(gsa_ctx *c)
 		std::vector<i32> fragbase(nfb);
 		if (nfb) GSA_CHECK(c, hipMemcpy(fragbase.data(), c->bl_alnlen.as<i32>() + 2 * (size_t)nfb, nfb * 4, hipMemcpyDeviceToHost));      // (bl_alnlen | bl_score | fragbase: one buffer)
 		frags_count(c);
+		// (stage 7 view: the records exist in the device's working layout only -- gsa_frag -- and are packed here)
+		std::vector<gsa_frag> wide((size_t)c->n_frags);
+		if (c->n_frags) GSA_CHECK(c, hipMemcpy(wide.data(), c->f_rec.p, (size_t)c->n_frags * sizeof(gsa_frag), hipMemcpyDeviceToHost));
 		c->h_frags.resize((size_t)c->n_frags);
-		if (c->n_frags) GSA_CHECK(c, hipMemcpy(c->h_frags.data(), c->f_rec.p, (size_t)c->n_frags * sizeof(gsa_frag), hipMemcpyDeviceToHost));
+		for (size_t i = 0; i < wide.size(); i++) {
+			const gsa_frag &w = wide[i]; gsa_rec &o = c->h_frags[i];
+			if (w.bseed) { o.seed.qpos = w.qpos; o.seed.len = w.qlen; o.seed.rpos = w.rpos; }
+			else { o.gap.nqlen = -1 - w.qlen; o.gap.rlen = w.rlen; o.gap.aln_len = w.aln_len; o.gap.aln_off = (uint32_t)w.aln_off; }
+		}
 		for (size_t k = 0; k < nfb; k++) {
 			gsa_block o; memset(&o, 0, sizeof(o));
 			o.score = c->blocks[k].score; o.bdup = c->blocks[k].bdup; o.frag_off = fragbase[k];
@@ -287,7 +282,7 @@ int build_block_view(gsa_ctx *c)
 		const i32 sb = c->h_leaf[hb.leaf_beg].beg, se = c->h_leaf[hb.leaf_end - 1].end;
 		o.n_frag = se - sb;
 		for (i32 s = sb; s < se; s++) {
-			gsa_frag f; memset(&f, 0, sizeof(f)); f.bseed = 1; f.qpos = c->h_r_q[s]; f.qlen = f.rlen = c->h_r_len[s]; f.rpos = c->h_r_r[s];
+			gsa_rec f; f.seed.qpos = c->h_r_q[s]; f.seed.len = c->h_r_len[s]; f.seed.rpos = c->h_r_r[s];
 			c->h_frags.push_back(f);
 		}
 		c->h_blocks.push_back(o);

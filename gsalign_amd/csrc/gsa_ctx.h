@@ -1,6 +1,7 @@
 // gsalign_amd/csrc/gsa_ctx.h -- the context behind the opaque gsa_ctx handle.
 #ifndef GSA_CTX_H
 #define GSA_CTX_H
+#include <atomic>
 #include "gsa_internal.h"
 
 // A leaf = a maximal run of seeds of one S2 block that neither S4 (large gaps)
@@ -37,6 +38,8 @@ struct gsa_ctx {
 	Params prm;
 	DevIndex di;
 	gsa_ctx *index_owner = nullptr;                // gsa_clone: the context whose device index this one borrows (nullptr = own)
+	gsa_ctx *lender = nullptr;                     // gsa_clone: the context `di` was copied from -- its presence bitmap / short k-mer table are read through that copy
+	std::atomic<int> n_borrowers{0};               // live clones made FROM this context (gsa_set_params must not rebuild the tables they read)
 	bool force_wide = false;                       // GSA_CREATE_WIDE: 64-bit dense SA + 32-byte k-mer entries whatever the text length (the >= 2^32-row layout)
 	bool profiling = false;
 	bool prof_seed = false;                        // time the seed kernel only (two events instead of ten per contig)
@@ -54,6 +57,7 @@ struct gsa_ctx {
 
 	// query
 	DevBuf d_query; i32 qlen = 0; int stage = 0;
+	const uint8_t *q_dev = nullptr;                // the contig on the device: d_query (uploaded by gsa_set_query) or the caller's buffer (gsa_set_query_device)
 	bool split = false; i64 rng_beg = 0, rng_end = 0;     // gsa_seed_chunks: stage 1 on a chunk range only, the hits of other ranges are imported
 	int qbits = 1, pdbits = 1;
 
@@ -122,7 +126,8 @@ struct gsa_ctx {
 	const i32 *h_tmail = nullptr, *h_tpatch = nullptr; char *h_taln1 = nullptr, *h_taln2 = nullptr;      // the parts of p_tail
 	i64 nf_ub = 0, span_ub = 0;                    // host-known upper bounds: records, and bases in gaps (ops / gapped strings)
 	DevBuf fb_seedbase, fb_sbeg, fb_fragbase;      // per final block
-	DevBuf f_rec;                                  // gsa_frag records
+	DevBuf f_rec;                                  // gsa_frag records (device working set)
+	DevBuf f_rec16;                                // the same as 16-byte gsa_rec: what goes to the host
 	DevBuf f_type, f_mism, f_alnlen, f_job, f_score;
 	DevBuf j_frag, j_opsoff, j_nops, d_ops, j_cells;
 	DevBuf d_dp_tiny;                              // order array of the four-per-wavefront DP kernel
@@ -134,11 +139,12 @@ struct gsa_ctx {
 	i32 n_early = 0; bool early_in_flight = false; std::vector<i32> h_early;      // (seed, m, n) per early job
 	bool dp_dirty = true;                          // ticket counters / error words of the striped DP need clearing (fresh buffer, or a failed launch)
 	bool dp_timeout = false, dp_safe = false;      // a striped launch tripped its wait bound; repeat the contig with one job per launch
+	int dp_fake_timeout = 0;                       // test hook (GSA_DP_FAKE_TIMEOUT=n at gsa_create): the next n contigs report a hand-off time-out once, so the retry paths run
 	u32 dp_epoch = 0;                              // tag of the boundary granules of the current striped launch
 	DevBuf p_dp, p_sj, p_sj_early;                 // pinned: mailbox + large-job list; stripe job tables (read by the kernels in place)
 	DevBuf d_alnoff;
 	DevBuf bl_alnlen, bl_score;
-	std::vector<gsa_frag> h_frags; std::vector<gsa_block> h_blocks; std::vector<char> h_aln1, h_aln2;
+	std::vector<gsa_rec> h_frags; std::vector<gsa_block> h_blocks; std::vector<char> h_aln1, h_aln2;
 	int frags_stage = 0;                           // stage for which h_frags/h_blocks were built
 	// stage-8 results land in pinned host memory (one async D2H each, no pageable staging)
 	DevBuf p_frags, p_blk; bool result_pinned = false;
@@ -172,6 +178,7 @@ int build_presence(gsa_ctx *c);             // k_seed.hip  (after MinSeedLength 
 int stage1_seed(gsa_ctx *c);          // k_seed.hip
 int stage1_import_hits(gsa_ctx *c, const u64 *keys, const u32 *vals, i64 n);   // k_seed.hip
 int stage1_finish_split(gsa_ctx *c);  // k_seed.hip
+int stage1_restore_pdbm(gsa_ctx *c);  // k_seed.hip  (the PosDiff bitmap again from the hits a finished stage 2 left in d_key_a)
 int seed_view_sort(gsa_ctx *c);       // k_seed.hip  (PosDiff-sorted seeds + groups: stage-1 view, or front of stage 2 without the PosDiff bitmap)
 int stage2_chain(gsa_ctx *c);         // k_chain.hip
 int launch_early_dp(gsa_ctx *c);      // k_chain.hip  (striped DP for the large gaps listed at the end of stage 2)

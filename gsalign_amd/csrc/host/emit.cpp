@@ -60,7 +60,8 @@ int extension(const HostIndex &ix, const gsa_block &b, const gsa_frag &last)
 void ContigResult::assign(const gsa_result &r)
 {
 	blocks.assign(r.blocks, r.blocks + r.n_blocks);
-	frags.assign(r.frags, r.frags + r.n_frags);
+	frags.resize((size_t)r.n_frags);                      // FragPair_t-shaped copies of the 16-byte records
+	gsa_expand_frags(r.recs, r.n_frags, frags.data());
 	aln1.assign(r.aln1, (size_t)r.n_aln); aln2.assign(r.aln2, (size_t)r.n_aln);
 }
 

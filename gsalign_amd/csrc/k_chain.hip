@@ -558,9 +558,7 @@ int launch_early_dp(gsa_ctx *c)
 	if (!dev_ensure<uint8_t>(c, c->e_ops, (size_t)eops + 64) || !dev_ensure<uint8_t>(c, c->e_rev, (size_t)eops + 64) || !dev_ensure<i32>(c, c->e_nops, (size_t)ne + 1) || !dev_ensure<i32>(c, c->e_rec, (size_t)ne + 1)) return GSA_ERR_NOMEM;
 	// stream_aux[0] already waits for the list (ev[16] was recorded behind it on the main stream)
 	GSA_CHECK(c, hipStreamWaitEvent(sa, c->ev[16], 0));
-	static const bool dbg_early = getenv("GSA_DEBUG_EARLY") != nullptr;
-	if (dbg_early) GSA_CHECK(c, hipEventRecord(c->ev[20], sa));
-	int rc = launch_stripes(c, sa, large, c->di.ref, c->e_off1.as<i64>(), c->d_query.as<uint8_t>(), c->e_off2.as<i64>(),
+	int rc = launch_stripes(c, sa, large, c->di.ref, c->e_off1.as<i64>(), c->q_dev, c->e_off2.as<i64>(),
 	                        c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->e_nops.as<i32>(), c->e_rev.as<uint8_t>(), M_DPERR3);
 	if (rc) return rc;
 	GSA_CHECK(c, hipEventRecord(c->ev[14], sa));
@@ -644,8 +642,6 @@ int stage2_chain(gsa_ctx *c)
 		LAUNCH(k_gather_active, na, na, c->d_val_b.as<u32>(), c->s_q.as<i32>(), c->s_len.as<i32>(), c->s_r.as<i64>(), c->s_gid.as<i32>(), c->g_beg.as<i32>(),
 		       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>());
 	}
-	static const bool dbg_tl = getenv("GSA_DEBUG_EARLY") != nullptr;
-	if (dbg_tl) hipEventRecord(c->ev[24], st);
 	// B. unique / break flags, window chain
 	ENS(i32, a_uniq, na + 1); ENS(i32, a_cu, na + 1); ENS(i32, a_alive, na + 1); ENS(i32, a_brk, na + 1); ENS(i32, a_aurank, na + 1);
 	ENS(i32, a_aulist, na + 1); ENS(i32, a_next, na + 1); ENS(i32, a_ws, na + 1); ENS(i32, a_wid, na + 1); ENS(i32, a_runinfo, na + 1);
@@ -667,7 +663,6 @@ int stage2_chain(gsa_ctx *c)
 		for (i32 span = 1; span < nt; span <<= 1) { LAUNCH(k_walkg_double, na, na, candEx, J0, J1, on); std::swap(J0, J1); }
 		LAUNCH(k_walkg_mark, nt, na, nt, candEx, clist, nextk, on, ws);
 	}
-	if (getenv("GSA_DEBUG_CHAIN")) { i32 nc_ = 0, nb_ = 0; hipStreamSynchronize(st); hipMemcpy(&nc_, candEx + na, 4, hipMemcpyDeviceToHost); hipMemcpy(&nb_, brkEx + na, 4, hipMemcpyDeviceToHost); fprintf(stderr, "[gsa] stage 2: %lld seeds, %d window-start candidates, %d breaks\n", (long long)na, nc_, nb_); }
 	// C. outliers
 	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);
 	const i64 bmin = ((-(i64)c->qlen) >> 4) - 1;
@@ -683,7 +678,6 @@ int stage2_chain(gsa_ctx *c)
 	       c->w_sum.as<unsigned long long>(), c->w_n.as<i32>());
 	LAUNCH(k_outlier_kill, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(),
 	       c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->G, c->prm.MaxIndelSize, alive);
-	if (dbg_tl) hipEventRecord(c->ev[25], st);
 	// D. multi-hit positions
 	i32 *auEx = c->a_aurank.as<i32>(), *aulist = c->a_aulist.as<i32>();
 	{ OpAliveUnique op = { na, uniq, alive, auEx, aulist }; RC((lb_launch<1>(c, na, op))); }
@@ -695,7 +689,6 @@ int stage2_chain(gsa_ctx *c)
 	ENS(i32, c_q, na); ENS(i32, c_len, na + 1); ENS(i64, c_r, na); ENS(i32, c_gb, na); ENS(i32, c_bid, na);
 	{ OpNoise op = { c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(),
 	                 c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), mail }; RC((lb_launch<1>(c, na, op))); }
-	if (dbg_tl) hipEventRecord(c->ev[26], st);
 	// block cuts + AddAlnBlock
 	i32 *bhead = c->a_uniq.as<i32>(), *bheadEx = c->a_cu.as<i32>(), *bstart = c->a_brk.as<i32>();
 	{ OpBlockHeads op = { na, c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), bhead, bheadEx, bstart, c->d_flag2.as<u32>(), mail }; RC((lb_launch<2>(c, na, op))); }
@@ -707,7 +700,7 @@ int stage2_chain(gsa_ctx *c)
 	// F. list the large DP gaps; the list travels to the host while stage 3 is being enqueued
 	ENS(i32, e_id, na + 2); ENS(i32, e_rec, na + 2); ENS(i32, e_list, 3 * (na + 1)); ENS(i64, e_off1, na + 1); ENS(i64, e_off2, na + 1); ENS(i64, e_opsoff, na + 2);
 	if (!pin_ensure<i32>(c, c->p_early, 4 + 3 * (size_t)EARLY_CHUNK)) return GSA_ERR_NOMEM;
-	{ OpEarlyGaps op = { c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), bhead, bheadEx, bkeep, bkeepEx, c->c_bid.as<i32>(), c->d_query.as<uint8_t>(), c->di.ref,
+	{ OpEarlyGaps op = { c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), bhead, bheadEx, bkeep, bkeepEx, c->c_bid.as<i32>(), c->q_dev, c->di.ref,
 	                     c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail, c->e_rec.as<i32>(),
 	                     c->p_early.as<i32>(), (i32)std::min<i64>(na, EARLY_CHUNK) }; RC((lb_launch<2>(c, na, op))); }
 	GSA_CHECK(c, hipEventRecord(c->ev[16], st));

@@ -83,7 +83,7 @@ __global__ void k_gap_class(i64 ub, const i32 *__restrict__ mail, const gsa_frag
 // gapped strings, and of a DP job's op string, then do not depend on the DP results, and everything
 // that is not a large DP job can be written while the striped kernel still runs.
 struct OpDpJobs {
-	const i32 *ftype, *fearly; gsa_frag *frag;
+	const i32 *ftype, *fearly; gsa_frag *frag; gsa_rec *rec16;
 	i32 *jfrag; i64 *off1; i32 *len1; i64 *off2; i32 *len2; i64 *opsoff; i32 *fjob, *alen; i64 *aoff; i32 *mail;
 	__device__ i32 value(i64 i, int c) const
 	{
@@ -102,6 +102,12 @@ struct OpDpJobs {
 		// the record's own string fields: final here for everything but a DP gap (its length comes from the DP kernel
 		// of its size class, or from the host's patch list for the striped ones), so the records can leave early
 		if (ftype[i] != FT_SEED) { frag[i].aln_off = ex[1]; frag[i].aln_len = ftype[i] == FT_DP ? 0 : v[1]; }
+		{	// the 16-byte record that travels (gsa_rec, gsa_hip.h): a seed as it is, a gap without its positions
+			const gsa_frag f = frag[i]; gsa_rec r;
+			if (ftype[i] == FT_SEED) { r.seed.qpos = f.qpos; r.seed.len = f.qlen; r.seed.rpos = f.rpos; }
+			else { r.gap.nqlen = -1 - f.qlen; r.gap.rlen = f.rlen; r.gap.aln_len = ftype[i] == FT_DP ? 0 : v[1]; r.gap.aln_off = (u32)ex[1]; }
+			rec16[i] = r;
+		}
 		if (!v[0]) { fjob[i] = (ftype[i] == FT_DP) ? -2 - fearly[i] : -1; return; }      // <= -2: early job -2 - fjob
 		const i32 j = ex[0];
 		jfrag[j] = (i32)i; off1[j] = frag[i].rpos; len1[j] = frag[i].rlen; off2[j] = frag[i].qpos; len2[j] = frag[i].qlen; opsoff[j] = ex[1];
@@ -346,7 +352,7 @@ int stage7_fill(gsa_ctx *c)
 	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), d_sbeg, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->e_id.as<i32>(), c->r_orig.as<i32>(),
 	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), d_fragbase, c->f_early.as<i32>(), c->d_mail.as<i32>() };
 	RC((lb_launch<1>(c, ns, op)));
-	LAUNCH(k_gap_class, nfu, nfu, c->d_mail.as<i32>(), c->f_rec.as<gsa_frag>(), c->d_query.as<uint8_t>(), c->di.ref, c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(),
+	LAUNCH(k_gap_class, nfu, nfu, c->d_mail.as<i32>(), c->f_rec.as<gsa_frag>(), c->q_dev, c->di.ref, c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(),
 	       c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_early.as<i32>(), c->e_rec.as<i32>());
 	c->n_frags = -1;
 	return GSA_OK;
@@ -370,27 +376,27 @@ int stage78_extend(gsa_ctx *c)
 	ENS(i64, w_best, nju + 1); ENS(i64, w_sum, nju + 1); ENS(i32, a_uniq, nju + 1); ENS(i32, a_cu, nju + 1);
 	i64 *off1 = c->w_best.as<i64>(), *off2 = c->w_sum.as<i64>(); i32 *len1 = c->a_uniq.as<i32>(), *len2 = c->a_cu.as<i32>();
 	ENS(i64, d_alnoff, nfu + 2);
-	{ OpDpJobs op = { c->f_type.as<i32>(), c->f_early.as<i32>(), c->f_rec.as<gsa_frag>(), c->j_frag.as<i32>(), off1, len1, off2, len2, c->j_opsoff.as<i64>(), c->f_job.as<i32>(),
+	ENS(gsa_rec, f_rec16, nfu + 1);
+	{ OpDpJobs op = { c->f_type.as<i32>(), c->f_early.as<i32>(), c->f_rec.as<gsa_frag>(), c->f_rec16.as<gsa_rec>(), c->j_frag.as<i32>(), off1, len1, off2, len2, c->j_opsoff.as<i64>(), c->f_job.as<i32>(),
 	                  c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), mail }; RC((lb_launch<2>(c, nfu, op))); }
 	// the records are final here except for the string length of a DP gap: they leave now (all nf_ub of them: the count is
 	// still on the device), on a third stream; the DP gaps' lengths follow as a short list the host patches in
 	hipStream_t sc = c->stream_aux[2];
-	if (!pin_ensure<gsa_frag>(c, c->p_frags, (size_t)nfu + 1)) return GSA_ERR_NOMEM;
+	if (!pin_ensure<gsa_rec>(c, c->p_frags, (size_t)nfu + 1)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipEventRecord(c->ev[19], st)); GSA_CHECK(c, hipStreamWaitEvent(sc, c->ev[19], 0));
 	ENS(uint8_t, d_ops, c->span_ub + 64);
 	ENS(i32, d_flag, nfu + 2);
 	i32 *d_blen = c->bl_alnlen.as<i32>(), *d_bscore = d_blen + nfb, *d_fragbase = d_blen + 2 * (size_t)nfb;      // (one buffer since stage 7: one copy home)
 	Ksw2Launch kl;
-	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->d_query.as<uint8_t>(), off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub, &kl,
+	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->q_dev, off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub, &kl,
 	                 nullptr, nullptr, true));
 	// (run_ksw2_jobs read the mailbox: the record count and the size of the string pools are known now)
 	// The records leave only now, behind the host's look at the size classes: a 166 MB copy (a 250 Mb contig) in flight keeps
 	// the link busy for 3 ms, and the few bytes the classification pass stores into pinned memory for that look queued
-	// behind it -- the small-DP kernels started 3 ms late.
-	GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec.p, (size_t)nfu * sizeof(gsa_frag), hipMemcpyDeviceToHost, sc));
+	// behind it -- the small-DP kernels started 3 ms late.  (Since round 3 the records travel as 16-byte gsa_rec: 66 MB.)
+	GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec16.p, (size_t)nfu * sizeof(gsa_rec), hipMemcpyDeviceToHost, sc));
 	const i32 *hm = c->p_dp.as<i32>();
 	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN]; c->n_large = kl.nlarge;
-	{ static const bool dbg = getenv("GSA_DEBUG") != nullptr; if (dbg) fprintf(stderr, "[gsa] DP jobs %d (small+tiny %d), striped: %d listed early at stage 2, %d launched late\n", kl.n, kl.nsmall, c->n_early, kl.nlarge); }
 	// everything that can only leave at the very end sits in ONE buffer: final mailbox | patch list of the large DP jobs |
 	// string pool 1 | string pool 2 -- a single copy behind the last kernel instead of a chain of four
 	const size_t npatch = (size_t)kl.nlarge + (size_t)c->n_early;
@@ -417,7 +423,7 @@ int stage78_extend(gsa_ctx *c)
 	const i32 *jlarge = c->d_dp_large.as<i32>() + 3 * ((size_t)nju + 1);
 	i32 *c_len = c->d_flag.as<i32>(), *c_score = c->f_score.as<i32>();
 	hipLaunchKernelGGL(k_materialize, dim3((unsigned)((nfu + 255) / 256)), dim3(256), 0, sx, mail + M_NF, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(),
-	                   jlarge, c->j_nops.as<i32>(), c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
+	                   jlarge, c->j_nops.as<i32>(), c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->q_dev, c->di.ref,
 	                   c->f_rec.as<gsa_frag>(), d_aln1, d_aln2, c_len, c_score);
 	GSA_CHECK(c, hipEventRecord(c->ev[17], sx));      // the strings of everything but the large jobs are written
 	if (pools_early) {
@@ -444,13 +450,13 @@ int stage78_extend(gsa_ctx *c)
 		uint8_t *h_aln1 = (uint8_t *)c->h_taln1, *h_aln2 = (uint8_t *)c->h_taln2; i32 *h_patch = (i32 *)c->h_tpatch, *h_mail = (i32 *)c->h_tmail;
 		if (kl.nlarge > 0)
 			hipLaunchKernelGGL(k_materialize_large, dim3((unsigned)kl.nlarge), dim3(256), 0, st, kl.nlarge, c->d_dp_large.as<i32>(), c->j_frag.as<i32>(), c->j_nops.as<i32>(),
-			                   c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
+			                   c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->q_dev, c->di.ref,
 			                   c->f_rec.as<gsa_frag>(), h_aln1, h_aln2, h_patch, mail, c->n_early > 0 ? (i32 *)nullptr : h_mail);
 		if (c->n_early > 0) {
 			GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[14], 0));      // the early striped launch (stream_aux[0])
 			c->early_consumed = true;
 			hipLaunchKernelGGL(k_materialize_large, dim3((unsigned)c->n_early), dim3(256), 0, st, c->n_early, (const i32 *)nullptr, c->e_rec.as<i32>(), c->e_nops.as<i32>(),
-			                   c->d_alnoff.as<i64>(), c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->d_query.as<uint8_t>(), c->di.ref,
+			                   c->d_alnoff.as<i64>(), c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->q_dev, c->di.ref,
 			                   c->f_rec.as<gsa_frag>(), h_aln1, h_aln2, h_patch + 3 * (size_t)kl.nlarge, mail, h_mail);
 		}
 	} else {
@@ -459,7 +465,6 @@ int stage78_extend(gsa_ctx *c)
 		if (c->n_aln) GSA_CHECK(c, hipMemcpyAsync((char *)c->p_tail.p + t_aln1, d_aln1, t_total - t_aln1, hipMemcpyDeviceToHost, st));
 	}
 	if (c->profiling) hipEventRecord(c->ev[9], st);
-	{ static const bool dbg = getenv("GSA_DEBUG_EARLY") != nullptr; if (dbg) hipEventRecord(c->ev[22], st); }
 	GSA_CHECK(c, hipGetLastError());
 	return GSA_OK;
 }

@@ -132,7 +132,7 @@ int run_gapsim_jobs(gsa_ctx *c, i32 n, const i32 *d_n, const i32 *d_q1, const i3
 	// n = job count, or with d_n != nullptr an upper bound (the grid is capped, workgroups loop over the jobs)
 	if (n <= 0) return GSA_OK;
 	const i32 grid = d_n ? (n < 1024 ? n : 1024) : n;
-	hipLaunchKernelGGL(k_gapsim, dim3(grid), dim3(GS_T), 0, c->stream, c->di, c->d_query.as<uint8_t>(), n, d_n, d_q1, d_q2, d_r1, d_r2, d_res, d_jseed, d_cut4);
+	hipLaunchKernelGGL(k_gapsim, dim3(grid), dim3(GS_T), 0, c->stream, c->di, c->q_dev, n, d_n, d_q1, d_q2, d_r1, d_r2, d_res, d_jseed, d_cut4);
 	GSA_CHECK(c, hipGetLastError());
 	return GSA_OK;
 }

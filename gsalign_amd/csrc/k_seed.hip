@@ -945,7 +945,7 @@ int stage1_seed(gsa_ctx *c)
 	const i32 s_off = (i32)(cb * GSA_CHUNK);
 	const i32 qlen_full = c->qlen;
 	const i32 qlen = ce > cb ? (i32)(((i64)ce * GSA_CHUNK < (i64)qlen_full ? (i64)ce * GSA_CHUNK : (i64)qlen_full) - s_off) : 0;
-	const uint8_t *d_q = c->d_query.as<uint8_t>() + s_off;
+	const uint8_t *d_q = c->q_dev + s_off;
 	c->n_seeds = 0; c->n_groups = 0;
 	if (qlen <= 0) return split ? prepare_pd_bitmap(c, 0) : GSA_OK;
 	const i64 n_chunks = ((i64)qlen + GSA_CHUNK - 1) / GSA_CHUNK;
@@ -1094,6 +1094,17 @@ int stage1_finish_split(gsa_ctx *c)
 	return seed_view_sort(c);
 }
 
+// Stage 2 consumed the PosDiff bitmap (k_pd_gather clears the words it read); a second stage 2 on the same hits needs it back.
+int stage1_restore_pdbm(gsa_ctx *c)
+{
+	if (!c->pd_path || c->n_seeds == 0) return GSA_OK;
+	if (c->pdbm_dirty) { GSA_CHECK(c, hipMemsetAsync(c->d_pdbm.p, 0, c->d_pdbm.cap, c->stream)); }
+	hipLaunchKernelGGL(k_pd_from_keys, dim3(grid_for((size_t)c->n_seeds, 256)), dim3(256), 0, c->stream, c->n_seeds, c->d_key_a.as<u64>(), c->qbits, c->d_pdbm.as<u32>());
+	GSA_CHECK(c, hipGetLastError());
+	c->pdbm_dirty = true;
+	return GSA_OK;
+}
+
 // ---------------------------------------------------------------------------
 // leaf operator: BWT_Search for explicit windows (gsa_bwt_search_batch)
 // ---------------------------------------------------------------------------
@@ -1126,7 +1137,7 @@ extern "C" int gsa_bwt_search_batch(gsa_ctx *c, int32_t n, const int32_t *start,
 	if (!d_start || !d_stop || !d_len || !d_freq || !d_loc) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemcpyAsync(d_start, start, n * 4, hipMemcpyHostToDevice, st));
 	GSA_CHECK(c, hipMemcpyAsync(d_stop, stop, n * 4, hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(k_search_batch, dim3(grid_for(n, 64)), dim3(64), 0, st, c->di, c->d_query.as<uint8_t>(), c->prm, n, d_start, d_stop, d_len, d_freq, d_loc);
+	hipLaunchKernelGGL(k_search_batch, dim3(grid_for(n, 64)), dim3(64), 0, st, c->di, c->q_dev, c->prm, n, d_start, d_stop, d_len, d_freq, d_loc);
 	GSA_CHECK(c, hipMemcpyAsync(out_len, d_len, n * 4, hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipMemcpyAsync(out_freq, d_freq, n * 4, hipMemcpyDeviceToHost, st));
 	GSA_CHECK(c, hipMemcpyAsync(out_loc, d_loc, (size_t)n * GSA_MAX_SEED_FREQ * 8, hipMemcpyDeviceToHost, st));

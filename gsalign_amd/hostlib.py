@@ -47,7 +47,8 @@ def result_from_dump(d: dict, keep: list):
     keep.extend([B, F, a1, a2])
     r = capi.Result()
     r.n_blocks = nb; r.n_frags = nf; r.n_aln = a1.size
-    r.blocks = C.cast(B.ctypes.data, C.POINTER(capi.Block)); r.frags = C.cast(F.ctypes.data, C.POINTER(capi.Frag))
+    R = capi.pack_recs(F); keep.append(R)
+    r.blocks = C.cast(B.ctypes.data, C.POINTER(capi.Block)); r.recs = C.cast(R.ctypes.data, C.POINTER(capi.Rec))
     r.aln1 = C.cast(a1.ctypes.data, C.POINTER(C.c_char)); r.aln2 = C.cast(a2.ctypes.data, C.POINTER(C.c_char))
     return r
 

@@ -66,8 +66,9 @@ void gsa_default_params(gsa_params *p);
  * (structure.h:103-113), order = CompByPosDiff (ProcessCandidateAlignment.cpp:3-7) */
 typedef struct { int32_t qpos; int32_t len; int64_t rpos; } gsa_seed;
 
-/* FragPair_t of a finished block.  aln_off/aln_len address the two gapped
- * strings of a non-seed pair inside gsa_result::aln1 / aln2. */
+/* FragPair_t of a finished block (structure.h:103-113), expanded.  aln_off/aln_len address the two gapped strings of a
+ * non-seed pair inside gsa_result::aln1 / aln2.  This is the VIEW type: results travel as the 16-byte gsa_rec defined below and are expanded
+ * with gsa_rec_expand / gsa_expand_frags where a consumer wants FragPair_t-shaped records. */
 typedef struct {
 	int32_t bseed, qpos, qlen, rlen;
 	int64_t rpos;
@@ -76,10 +77,40 @@ typedef struct {
 	int32_t _pad;
 } gsa_frag;
 
+/* The record as it crosses PCIe: 16 bytes instead of gsa_frag's 40; a 250 Mb contig at 1 % divergence has 4.1 M
+ * records.  FillAlnBlockGaps / IdentifyNormalPairs (ProcessCandidateAlignment.cpp:241-276) put at most ONE gap pair
+ * between two consecutive seeds, and it starts where the seed in front of it ends -- so a block's records are
+ * seed [gap] seed [gap] ... seed, a seed needs (qPos, len, rPos), and a gap only its two lengths and its string:
+ * its positions are those of the record in front of it.  w0 >= 0: seed {qpos, len, rpos}; w0 < 0: gap
+ * {-1 - qlen, rlen, aln_len, aln_off} (string offsets fit 32 bits: GSA_ERR_LIMIT guards that per contig). */
+typedef union {
+	struct { int32_t qpos, len; int64_t rpos; } seed;
+	struct { int32_t nqlen, rlen, aln_len; uint32_t aln_off; } gap;
+} gsa_rec;
+
+static inline int gsa_rec_is_seed(const gsa_rec *r) { return r->seed.qpos >= 0; }
+/* record i of `recs` as a FragPair_t (a gap reads the seed in front of it: i > 0 then, by construction) */
+static inline void gsa_rec_expand(const gsa_rec *recs, int64_t i, gsa_frag *f)
+{
+	const gsa_rec *r = recs + i;
+	if (r->seed.qpos >= 0) {
+		f->bseed = 1; f->qpos = r->seed.qpos; f->qlen = f->rlen = r->seed.len; f->rpos = r->seed.rpos; f->aln_off = 0; f->aln_len = 0;
+	} else {
+		const gsa_rec *s = r - 1;
+		f->bseed = 0; f->qpos = s->seed.qpos + s->seed.len; f->rpos = s->seed.rpos + s->seed.len;
+		f->qlen = -1 - r->gap.nqlen; f->rlen = r->gap.rlen; f->aln_off = (int64_t)r->gap.aln_off; f->aln_len = r->gap.aln_len;
+	}
+	f->_pad = 0;
+}
+static inline void gsa_expand_frags(const gsa_rec *recs, int64_t n, gsa_frag *out)
+{
+	for (int64_t i = 0; i < n; i++) gsa_rec_expand(recs, i, out + i);
+}
+
 /* AlnBlock_t (structure.h:115-122) after the identity filter (GSAlign.cpp:529-540) */
 typedef struct {
 	int32_t score, aln_len, bdup, n_frag;
-	int64_t frag_off;          /* first gsa_frag of this block           */
+	int64_t frag_off;          /* first record of this block             */
 	int32_t bdir, gpos, chr;   /* Coordinate_t from GenCoordinateInfo    */
 	int32_t _pad;
 } gsa_block;
@@ -92,7 +123,7 @@ typedef struct {
 	int64_t n_frags;
 	int64_t n_aln;
 	const gsa_block *blocks;
-	const gsa_frag *frags;
+	const gsa_rec *recs;       /* n_frags compact records, block after block (gsa_block::frag_off / n_frag) */
 	const char *aln1, *aln2;   /* reference-side / query-side gapped strings */
 } gsa_result;
 
@@ -107,7 +138,9 @@ int  gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *pr
 /* A further context on the same GPU that borrows `parent`'s device-resident index (read-only) and owns everything else.
  * The reference runs -t N threads inside one contig (GSAlign.cpp:477-526); contigs are independent (all per-contig state
  * is cleared at GSAlign.cpp:490), so a host drives N contexts from N threads on N contigs instead and the GPU overlaps
- * them.  Each context is single-threaded; `parent` must outlive its clones. */
+ * them.  Each context is single-threaded; `parent` must outlive its clones.  While clones of a context are alive,
+ * gsa_set_params on THAT context may not change min_seed_len / sensitive (GSA_ERR_STATE: the clones read its presence bitmap
+ * and short k-mer table); a clone may change its own parameters freely -- it then builds tables of its own. */
 int  gsa_clone(gsa_ctx *parent, gsa_ctx **out);
 void gsa_destroy(gsa_ctx *ctx);
 /* Puts the CALLING host thread on the CPUs of the socket `device` hangs off (sysfs local_cpulist of its PCI function; a no-op
@@ -130,6 +163,14 @@ const char *gsa_last_error(gsa_ctx *ctx);   /* ctx may be NULL: error of the las
  * identity filter, GenCoordinateInfo, final RemoveBadAlnBlocks.
  * query = raw contig bytes exactly as loaded from FASTA (any case, IUPAC ok). */
 int gsa_align_contig(gsa_ctx *ctx, const char *query, int32_t qlen, gsa_result *out);
+/* The same with the contig ALREADY IN DEVICE MEMORY of the context's GPU (a loader that decodes FASTA on the GPU, or contigs
+ * kept resident between runs): used in place, nothing crosses PCIe on the way in.  d_query: 16-byte aligned, qlen raw bytes
+ * as above, valid and unmodified until the call returns.  gsa_device_alloc / gsa_device_upload / gsa_device_free are the
+ * plain-C way to such a buffer for hosts that do not link a HIP runtime themselves. */
+int gsa_align_contig_device(gsa_ctx *ctx, const char *d_query, int32_t qlen, gsa_result *out);
+void *gsa_device_alloc(int device, size_t bytes);
+void  gsa_device_free(int device, void *p);
+int   gsa_device_upload(int device, void *dst, const void *src, size_t bytes);
 
 /* ---- the per-contig loop itself ------------------------------------------
  * Replaces the loop `for (QueryChrIdx = 0; QueryChrIdx < iQueryChrNum; ...)` of GenomeComparison() (GSAlign.cpp:483-548):
@@ -140,6 +181,7 @@ int gsa_align_contig(gsa_ctx *ctx, const char *query, int32_t qlen, gsa_result *
  * *res is valid during the callback only.  Returns the first error (the failing context holds the text). */
 typedef int (*gsa_result_fn)(void *user, int32_t contig, const gsa_result *res);
 #define GSA_MANY_IN_ORDER 1u   /* hand the contigs out in the order given (default: longest first) */
+#define GSA_MANY_DEVICE   2u   /* query[] are device pointers (gsa_align_contig_device); all contexts on one GPU */
 int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n,
                    uint32_t flags, gsa_result_fn on_result, void *user);
 
@@ -168,7 +210,10 @@ int gsa_finish_contig(gsa_ctx *ctx, gsa_result *out);
  *  7 FillAlnBlockGaps                           ProcessCandidateAlignment.cpp:241-276
  *  8 GenerateFragAlignment + identity filter    ProcessCandidateAlignment.cpp:290-351, GSAlign.cpp:523-540
  */
+/* `query` is uploaded asynchronously: the buffer must stay valid and unmodified until the next synchronising call on this
+ * context returns (gsa_run_to, gsa_seed_chunks, gsa_align_contig) -- a loader may not refill a pinned buffer earlier. */
 int gsa_set_query(gsa_ctx *ctx, const char *query, int32_t qlen);
+int gsa_set_query_device(gsa_ctx *ctx, const char *d_query, int32_t qlen);   /* see gsa_align_contig_device */
 /* back to stage 0 with the contig gsa_set_query uploaded (no new copy): the same alignment can be run again, e.g. with
  * other parameters (the reference re-reads the contig from its FASTA buffer: GSAlign.cpp:483) */
 int gsa_rewind(gsa_ctx *ctx);
@@ -220,6 +265,11 @@ int gsa_get_timings(gsa_ctx *ctx, float kernel_ms[8]);
  * search kernel only (kernel_ms[0]; two events per contig instead of ten); kernel_ms[6] is then the SUM of that time over
  * all contigs since the flag was set (what a benchmark divides by its contig count). */
 int gsa_set_profiling(gsa_ctx *ctx, int flags);
+/* How the seed search of the last contig went (IdentifyLocalMEM, GSAlign.cpp:51-107):
+ * [0] most resolver rounds of a chunk, [1] chunks redone by the dense search (every start position in parallel: the
+ * `freq > MaxSeedFreq` reject-and-restart regime of bwt_search.cpp:177-182, or -sen), [2] most wave-iterations of a chunk,
+ * [3..5] slowest chunk: round 1 / resolver / up to the marks, in 10 ns ticks; [6..7] reserved. */
+int gsa_get_seed_stats(gsa_ctx *ctx, uint64_t stats[8]);
 
 #ifdef __cplusplus
 }

@@ -321,6 +321,84 @@ def test_contig_seeded_in_chunk_ranges(oracle_built, tmp_path, params):
         g.close()
 
 
+def test_device_resident_query_and_compact_records(gpu, ora, cx_queries):
+    """gsa_align_contig_device: the contig already in device memory (gsa_device_alloc / gsa_device_upload), used in place -- same
+    result as the host-buffer call; through gsa_align_many with GSA_MANY_DEVICE too.  The result's 16-byte records expand to
+    the oracle's FragPair_t values (blocks_as_dump goes through capi.expand_recs)."""
+    for ci in (0, 2, 6):
+        seq = cx_queries[ci][1]
+        d = gpu.device_copy(seq)
+        gpu.align_contig_device(d)
+        got = gpu.blocks_as_dump(with_aln=True)
+        ora.set_query(seq); ora.run_to(8); want = ora.blocks(with_aln=True)
+        for k, v in want.items():
+            assert np.array_equal(got[k], v), (ci, k)
+    seen = {}
+
+    def on_result(ci, res):
+        seen[ci] = (int(res.n_blocks), int(res.n_frags), int(res.n_aln)); return 0
+    devs = [gpu.device_copy(q) for _, q in cx_queries[:4]]
+    capi.align_many([gpu], devs, on_result)
+    for ci in range(4):
+        gpu.align_contig(cx_queries[ci][1]); r = gpu.raw_result()
+        assert seen[ci] == (int(r.n_blocks), int(r.n_frags), int(r.n_aln)), ci
+    # a host pointer is refused, and so is a misaligned device pointer
+    res = capi.Result()
+    host = np.ascontiguousarray(cx_queries[0][1])
+    assert gpu.lib.gsa_align_contig_device(gpu.ctx, capi.C.c_void_p(host.ctypes.data), capi.C.c_int32(host.size), capi.C.byref(res)) == -1
+    assert gpu.lib.gsa_align_contig_device(gpu.ctx, capi.C.c_void_p(devs[0].ptr + 4), capi.C.c_int32(1000), capi.C.byref(res)) == -1
+
+
+def test_clone_parent_cannot_rebuild_shared_seed_tables(cx_index, cx_queries, ora):
+    """a clone reads its parent's presence bitmap / short k-mer table through copied pointers, so the parent may not
+    rebuild them while clones live (GSA_ERR_STATE); a clone changing its OWN parameters builds its own and stays exact."""
+    g0 = capi.Aligner(cx_index); cl = g0.clone()
+    with pytest.raises(capi.GsaError, match="cloned from this one"):
+        g0.set_params(sen=1, clr=50)
+    g0.set_params(idy=80); g0.set_params()                              # (parameters that do not touch the tables are fine)
+    cl.set_params(sen=1, clr=50)                                        # the clone's own tables
+    seq = cx_queries[3][1]
+    o2 = type(ora)(cx_index, dict(sen=1, clr=50)); o2.set_query(seq); o2.run_to(8); want_sen = o2.blocks(with_aln=True); o2.close()
+    ora.set_query(seq); ora.run_to(8); want = ora.blocks(with_aln=True)
+    cl.align_contig(seq); g0.align_contig(seq)
+    got_sen, got = cl.blocks_as_dump(with_aln=True), g0.blocks_as_dump(with_aln=True)
+    for k, v in want_sen.items():
+        assert np.array_equal(got_sen[k], v), k
+    for k, v in want.items():
+        assert np.array_equal(got[k], v), k
+    cl.close()
+    g0.set_params(sen=1, clr=50); g0.align_contig(seq)                  # no clone left: allowed again
+    got_sen = g0.blocks_as_dump(with_aln=True)
+    for k, v in want_sen.items():
+        assert np.array_equal(got_sen[k], v), k
+    g0.close()
+
+
+def test_split_contig_retry_and_state_rules(oracle_built, tmp_path, monkeypatch):
+    """gsa_finish_contig repeats stages 2-8 with one DP job per launch after a stripe hand-off time-out (forced once
+    by the test hook GSA_DP_FAKE_TIMEOUT), from the hits it still holds; gsa_run_to is refused while a context holds a chunk range."""
+    monkeypatch.setenv("GSA_DP_FAKE_TIMEOUT", "1")
+    refs, qrys = synth.make_pair_fast(1200000, 1, 0.01, seed=61, repeats=True)
+    q = qrys[0][1]
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx); o.set_query(q); o.run_to(8); want = o.blocks(with_aln=True); o.close()
+    own = capi.Aligner(idx); other = own.clone()
+    n_chunks = (q.size + 9999) // 10000
+    own.seed_chunks(q, 0, n_chunks // 2); other.seed_chunks(q, n_chunks // 2, n_chunks)
+    with pytest.raises(capi.GsaError, match="gsa_finish_contig"):
+        own.run_to(8)
+    k, v = other.export_hits(); own.import_hits(k, v)
+    own.finish_contig()                                                  # first pass reports the (fake) time-out, the retry answers
+    got = own.blocks_as_dump(with_aln=True)
+    for key, val in want.items():
+        assert np.array_equal(got[key], val), key
+    own.align_contig(q)                                                  # hook used up: the plain path, same answer
+    got = own.blocks_as_dump(with_aln=True)
+    for key, val in want.items():
+        assert np.array_equal(got[key], val), key
+    other.close(); own.close()
+
+
 def test_two_contexts_share_one_index(oracle_built, tmp_path):
     """gsa_clone: two contexts on one GPU, one device index, driven from two host threads on different contigs at the
     same time -- results identical to the oracle's (and so to a single context's)."""

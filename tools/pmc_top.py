@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""gpurun_out/pmc_<workload>/*.csv (tools/pmc_top.sh) -> profiles/r02_pmc_<workload>.json: HBM traffic per step of the
+"""gpurun_out/pmc_<workload>/*.csv (tools/pmc_top.sh) -> profiles/r03_pmc_<workload>.json: HBM traffic per step of the
 top kernels and of the whole step, from separate rocprofv3 --pmc passes.  Reads: from the request counters
 (TCC_EA0_RDREQ: requests that are not 32-byte ones are 128 bytes wide on gfx950 -- the same correction as
 "FETCH_SIZE x 2" in MI355X_MICROARCH.md, HBM section); writes: WRITE_SIZE (KB) as is (uncalibrated there)."""
-import csv, json, os, sys
+import csv, json, os, subprocess, sys
 from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W = sys.argv[1] if len(sys.argv) > 1 else "human"
@@ -17,6 +17,16 @@ GROUPS = {      # key in the json -> predicate on the (mangled) kernel name
     "k_materialize": lambda k: "k_materialize" in k,
     "copies": lambda k: "copyBuffer" in k or "fillBuffer" in k,
 }
+
+
+def commit():
+    """The commit the counters belong to: the tree gpurun shipped = HEAD (+ '-dirty' when the work tree differs)."""
+    try:
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+        dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True).stdout.strip()
+        return h + ("-dirty" if dirty else "")
+    except Exception:      # noqa: BLE001
+        return "?"
 
 
 def load(fn):
@@ -55,7 +65,7 @@ def main():
            "_method": "reads = (TCC_EA0_RDREQ - RDREQ_32B) x 128 B + RDREQ_32B x 32 B (gfx950: FETCH_SIZE tallies 128-byte requests at 64 B, MI355X_MICROARCH.md HBM section); writes = WRITE_SIZE KB x 1024 (uncalibrated); "
                       "Infinity-Cache hits are counted, so this is L2-miss traffic, an upper bound of HBM bytes; per step = total over the run / hot-path runs x contigs per step "
                       "(seed kernels: / runs with the production seed kernel)",
-           "workload": W, "hot_path_runs": sel, "production_seed_runs": prod, "kernels": {}}
+           "commit": commit(), "workload": W, "hot_path_runs": sel, "production_seed_runs": prod, "kernels": {}}
     tot_r = tot_w = 0.0
     for k, d in acc.items():
         rb, wb = bytes_of(d)
@@ -73,7 +83,7 @@ def main():
                                     "traffic_bytes_per_step": (rb + wb) / runs * contigs_per_step}
     if sel:
         out["traffic_bytes_per_step"] = (tot_r + tot_w) / sel * contigs_per_step
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"r02_pmc_{W}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"r03_pmc_{W}.json"), "w"), indent=1)
     print(json.dumps(out, indent=1)[:3000])
 
 

@@ -3,7 +3,7 @@
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 def show(e, name):
-    print("==", name, "value %.3f Gbp/s  %.3f ms/step  roofline frac %.3f" % (e["value"], e["ms_per_step"], e["roofline"]["frac"]))
+    print("==", name, "value %.3f Gbp/s  %.3f ms/step  roofline frac %.3f" % (e["value"], e["ms_per_step"], e["roofline"]["frac"]), " pcie-inclusive", e.get("pcie_inclusive", {}).get("value"))
     print(" stage", {k: round(v, 3) for k, v in e["stage_ms_one_context_alone"].items()})
     print(" cnt", e["counters_per_step"])
     print(" terms MB", {k: round(v / 1e6, 1) for k, v in e["roofline"]["terms"].items()}, "B/base", round(e["roofline"]["bytes_per_query_base"], 1))

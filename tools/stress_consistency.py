@@ -25,7 +25,7 @@ def on_result(ci, res):
     k = ci % len(contigs)
     nb, nf, na = res.n_blocks, res.n_frags, res.n_aln
     h = zlib.crc32(C.string_at(res.blocks, nb * 40)) if nb else 0
-    h = zlib.crc32(C.string_at(res.frags, nf * 40), h) if nf else h
+    h = zlib.crc32(C.string_at(res.recs, nf * 16), h) if nf else h
     if na:
         h = zlib.crc32(C.string_at(res.aln1, na), h); h = zlib.crc32(C.string_at(res.aln2, na), h)
     with lock:
