@@ -359,7 +359,7 @@ def dry_main(args):
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX); dist.all_reduce(tb, op=dist.ReduceOp.SUM)
     allr = shard.gather_results({rank * 100 + i: r for i, r in mine.items()}, capi.BLOCK_DT, capi.FRAG_DT)
-    assert len(allr) == world * len(contigs) or world == 1
+    assert len(allr) == (world * len(contigs) if rank == 0 else 0) or world == 1      # (only rank 0 receives: point-to-point sends, no padded all_gather)
     if rank == 0:
         print(json.dumps({"metric": "aligned query Gbp/s (whole node)", "value": float(tb.item()) / float(tt.item()) / 1e9, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1000.0 * float(tt.item()) / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libgsa_hip.so")
 
 EXPORTS = [
     "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many",
-    "gsa_align_contig_device", "gsa_set_query_device", "gsa_device_alloc", "gsa_device_free", "gsa_device_upload", "gsa_get_seed_stats", "gsa_seed_chunks", "gsa_hit_count", "gsa_export_hits", "gsa_import_hits", "gsa_finish_contig",
+    "gsa_align_contig_device", "gsa_set_query_device", "gsa_device_alloc", "gsa_device_free", "gsa_device_upload", "gsa_get_seed_stats", "gsa_hit_buffers", "gsa_seed_chunks", "gsa_hit_count", "gsa_export_hits", "gsa_import_hits", "gsa_finish_contig",
     "gsa_set_query", "gsa_rewind", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
     "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling", "gsa_bind_host_thread",
 ]
@@ -284,6 +284,9 @@ class Aligner:
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         self._q = seq
         self._ck(self.lib.gsa_seed_chunks(self.ctx, seq.ctypes.data_as(C.c_char_p), C.c_int32(seq.size), C.c_int32(chunk_beg), C.c_int32(chunk_end)))
+        return int(self.lib.gsa_hit_count(self.ctx))
+
+    def hit_count(self) -> int:
         return int(self.lib.gsa_hit_count(self.ctx))
 
     def export_hits(self, keys_ptr=None, vals_ptr=None):

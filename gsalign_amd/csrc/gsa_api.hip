@@ -431,9 +431,42 @@ int gsa_finish_contig(gsa_ctx *c, gsa_result *out)
 	return gsa_get_blocks(c, out);
 }
 
+// The hits of this context's chunk range where they lie (device memory; valid until the next call on this context): what an
+// owner on the same node imports directly -- gsa_import_hits(owner, keys, vals, n) copies device to device, peer to peer when the
+// two contexts sit on different GPUs.
+int gsa_hit_buffers(gsa_ctx *c, const uint64_t **keys, const uint32_t **vals)
+{
+	if (!c || !keys || !vals) return GSA_ERR_ARG;
+	if (!c->split) return gsa_fail(c, GSA_ERR_STATE, "gsa_seed_chunks first");
+	*keys = c->d_key_a.as<uint64_t>(); *vals = c->d_val_a.as<uint32_t>();
+	return GSA_OK;
+}
+
+// One contig on a group of contexts (the first one owns it): IdentifyLocalMEM hands 10 000-bp chunks to whichever thread is free
+// (GSAlign.cpp:61-94); here every context of the group seeds a contiguous chunk range, the owner imports the others' hits
+// device to device and runs the rest.
+static int align_split(gsa_ctx *const *grp, int n_grp, const char *query, int32_t qlen, gsa_result *out)
+{
+	const int32_t n_chunks = (int32_t)(((int64_t)qlen + GSA_CHUNK - 1) / GSA_CHUNK);
+	std::vector<int> rcs((size_t)n_grp, GSA_OK);
+	std::vector<std::thread> th;
+	auto range = [&](int k, int32_t &b, int32_t &e) { const int32_t base = n_chunks / n_grp, extra = n_chunks % n_grp; b = k * base + (k < extra ? k : extra); e = b + base + (k < extra ? 1 : 0); };
+	for (int k = 1; k < n_grp; k++) th.emplace_back([&, k] { int32_t b, e; range(k, b, e); rcs[(size_t)k] = gsa_seed_chunks(grp[k], query, qlen, b, e); });
+	{ int32_t b, e; range(0, b, e); rcs[0] = gsa_seed_chunks(grp[0], query, qlen, b, e); }
+	for (std::thread &t : th) t.join();
+	for (int k = 0; k < n_grp; k++) if (rcs[(size_t)k] != GSA_OK) { if (k) gsa_fail(grp[0], rcs[(size_t)k], std::string("helper context: ") + gsa_last_error(grp[k])); return rcs[(size_t)k]; }
+	for (int k = 1; k < n_grp; k++) {
+		const uint64_t *kp = nullptr; const uint32_t *vp = nullptr;
+		int rc = gsa_hit_buffers(grp[k], &kp, &vp);
+		if (rc == GSA_OK) rc = gsa_import_hits(grp[0], kp, vp, gsa_hit_count(grp[k]));
+		if (rc != GSA_OK) return rc;
+	}
+	return gsa_finish_contig(grp[0], out);
+}
+
 int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n, uint32_t flags, gsa_result_fn on_result, void *user)
 {
-	if (flags & ~(uint32_t)(GSA_MANY_IN_ORDER | GSA_MANY_DEVICE)) return GSA_ERR_ARG;
+	if (flags & ~(uint32_t)(GSA_MANY_IN_ORDER | GSA_MANY_DEVICE | GSA_MANY_NO_SPLIT)) return GSA_ERR_ARG;
 	if (!ctx || n_ctx <= 0 || n < 0 || (n > 0 && (!query || !qlen))) return GSA_ERR_ARG;
 	for (int k = 0; k < n_ctx; k++) if (!ctx[k]) return GSA_ERR_ARG;
 	const bool dev_q = (flags & GSA_MANY_DEVICE) != 0;
@@ -443,7 +476,34 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 	std::vector<int32_t> order((size_t)n);
 	for (int32_t i = 0; i < n; i++) order[(size_t)i] = i;
 	if (!(flags & GSA_MANY_IN_ORDER)) std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return qlen[a] > qlen[b]; });
-	std::atomic<int32_t> next(0); std::atomic<int> err(GSA_OK);
+	std::atomic<int> err(GSA_OK);
+	// Fewer contigs than contexts (BASELINE configs[3]: one chromosome, two GPUs): contexts would sit idle, so the contexts are
+	// dealt out in GROUPS, one per contig, sized by contig length, and every group seeds its contig by chunk range (align_split).
+	// Only contigs of at least GSA_SPLIT_MIN bases (default 20 Mb: below that the seed search is a fraction of a millisecond and
+	// a second upload of the contig costs more than it saves) get more than one context.
+	static const int64_t split_min = [] { const char *e = getenv("GSA_SPLIT_MIN"); return e ? (int64_t)atoll(e) : 20000000ll; }();
+	if (n < n_ctx && !dev_q && !(flags & GSA_MANY_NO_SPLIT) && (int64_t)qlen[order[0]] >= split_min) {
+		std::vector<int> gsz((size_t)n, 1);
+		for (int left = n_ctx - n; left > 0; left--) {       // the next context goes where a context has the most bases to itself
+			int best = -1; double load = 0;
+			for (int i = 0; i < n; i++) { const int32_t ci = order[(size_t)i]; if ((int64_t)qlen[ci] < split_min) continue; const double l = (double)qlen[ci] / gsz[(size_t)i]; if (l > load) { load = l; best = i; } }
+			if (best < 0) break;
+			gsz[(size_t)best]++;
+		}
+		std::vector<std::thread> th; int at = 0;
+		for (int i = 0; i < n; i++) {
+			const int32_t ci = order[(size_t)i]; gsa_ctx *const *grp = ctx + at; const int ng = gsz[(size_t)i]; at += ng;
+			th.emplace_back([&, ci, grp, ng] {
+				gsa_result res;
+				int rc = ng > 1 ? align_split(grp, ng, query[ci], qlen[ci], &res) : gsa_align_contig(grp[0], query[ci], qlen[ci], &res);
+				if (rc == GSA_OK && on_result) rc = on_result(user, ci, &res);
+				if (rc != GSA_OK) { int ok = GSA_OK; err.compare_exchange_strong(ok, rc); }
+			});
+		}
+		for (std::thread &t : th) t.join();
+		return err.load();
+	}
+	std::atomic<int32_t> next(0);
 	auto loop = [&](gsa_ctx *c) {
 		for (;;) {
 			const int32_t i = next.fetch_add(1);

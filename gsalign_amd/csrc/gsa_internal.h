@@ -44,8 +44,8 @@ struct DevIndex {
 	i32 kmer_k;
 	const u64 *kmer_lo;     // a second, short jump table of kmer_lo_k = MinSeedLength bases (same entry format) for starts whose match ends
 	i32 kmer_lo_k;          //   before kmer_k: built by gsa_set_params when MinSeedLength < kmer_k (-sen: 10), used by the dense search
-	const u32 *pres;        // presence bitmap of all pres_k-mers of the text (pres_k = min(MinSeedLength, 16)); rebuilt by gsa_set_params
-	i32 pres_k;
+	const u32 *pres;        // presence table of all pres_k-mers of the text (pres_k = min(MinSeedLength, 16)), GROUPED: one 32-byte line answers
+	i32 pres_k;             //   for four consecutive start positions (layout: pres4_* in k_seed.hip); rebuilt by gsa_set_params
 };
 
 struct DevBuf {

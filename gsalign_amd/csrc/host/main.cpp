@@ -123,7 +123,8 @@ int main(int argc, char *argv[])
 	if (getenv("GSA_BIND")) (void)gsa_bind_host_thread(gpus[0]);      // (opt-in: small contigs gain from a near-socket thread, chromosome-sized ones lose 5 %)
 	// one context per GPU owns that device's copy of the index; the others borrow it (gsa_clone)
 	std::vector<gsa_ctx *> ctxs;
-	const size_t want_ctx = std::min(qs.size(), gpus.size() * (size_t)n_ctx_per_gpu);
+	// (at least one context per listed GPU: with fewer query sequences than GPUs gsa_align_many seeds a long sequence on several of them)
+	const size_t want_ctx = std::min(std::max(qs.size(), gpus.size()), gpus.size() * (size_t)n_ctx_per_gpu);
 	for (size_t g = 0; g < gpus.size() && ctxs.size() < std::max<size_t>(want_ctx, 1); g++) {
 		gsa_ctx *owner = NULL;
 		if (gsa_create(gpus[g], &view, &prm, &owner) != GSA_OK) { fprintf(stderr, "GPU initialisation failed (device %d): %s\n", gpus[g], gsa_last_error(NULL)); return 2; }

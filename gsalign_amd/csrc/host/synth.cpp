@@ -25,7 +25,7 @@ inline uint64_t mix64(uint64_t x)
 inline uint64_t key_of(uint64_t seed, uint64_t stream) { return mix64(seed * 0x2545F4914F6CDD1Dull + stream); }
 inline uint64_t rnd(uint64_t seed, uint64_t stream, uint64_t i) { return mix64(key_of(seed, stream) ^ i); }
 const char ACGT[5] = "ACGT";
-inline int code_of(char c) { switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; default: return 3; } }
+inline int code_of(char c) { switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; default: return 3; } }
 
 // the event mix on src[0..n) written to o[0..cap); returns the length, or -1 when cap is too small.
 // `stream` separates independent uses of one seed.
@@ -40,7 +40,11 @@ int64_t mutate_into(const char *src, int64_t n, double d, uint64_t seed, uint64_
 		const uint64_t r = mix64(key ^ (uint64_t)i);
 		const uint32_t ev = (uint32_t)(r >> 32);
 		if (ev >= t_del) { o[w++] = src[i++]; continue; }
-		if (ev < t_sub) { o[w++] = ACGT[(code_of(src[i]) + 1 + (int)((r & 0xffff) % 3)) & 3]; i++; }
+		if (ev < t_sub) {
+			// (an N stays an N, a soft-masked base stays lower case)
+			const char c = src[i], sub = ACGT[(code_of(c) + 1 + (int)((r & 0xffff) % 3)) & 3];
+			o[w++] = (c == 'N' || c == 'n') ? c : ((c >= 'a' && c <= 'z') ? (char)(sub | 0x20) : sub); i++;
+		}
 		else if (ev < t_ins) {
 			const int len = 1 + (int)((r & 0xffff) % 10);
 			for (int k = 0; k < len; k++) o[w++] = ACGT[mix64(key2 ^ ((uint64_t)i * 16 + k)) & 3];
@@ -89,6 +93,61 @@ int64_t gsah_c_synth_repeats(char *seq, int64_t n, uint64_t seed, double frac, i
 		for (int64_t k = 0; k < tl; k++) seq[p0 + k] = u[(size_t)(k % tandem_unit)];
 	}
 	return copies;
+}
+
+// Adversarial injection, in place: what real genomes do to a seed search and the i.i.d. text does not.
+//   * n_fam repeat families with a copy-number spectrum: family f has length L_f (80 .. 6000 bp), divergence d_f of its copies
+//     from the family sequence (1 % .. 15 %: a young family with thousands of near-identical copies is the `freq > MaxSeedFreq`
+//     reject-and-restart regime of bwt_search.cpp:177-182 on every start inside a copy) and a copy count from max_copies down by a
+//     factor ~3 per family; together they cover about `frac` of the sequence;
+//   * microsatellites: short tandem arrays (unit 1-6 bp, 20-300 bp long), one per ~15 kb;
+//   * two runs of N (a centromere-like gap), each n_run bases, at 1/3 and 2/3 of the sequence (packed as random bases by the index
+//     builder, bntseq.c:159-176, and skipped by the seed search on the query side);
+//   * soft-masked blocks: lower-case stretches of 200-5000 bases, one per ~60 kb (nst_nt4_table folds case: same alignment).
+// Returns the number of family copies written.
+int64_t gsah_c_synth_adversarial(char *seq, int64_t n, uint64_t seed, double frac, int n_fam, int64_t max_copies, int64_t n_run)
+{
+	if (n < 100000 || n_fam <= 0) return 0;
+	static const int fam_len[8] = { 300, 1200, 150, 6000, 80, 500, 2500, 300 };
+	static const double fam_div[8] = { 0.01, 0.05, 0.03, 0.10, 0.02, 0.15, 0.08, 0.12 };
+	int64_t total = 0;
+	// copy counts: max_copies, max_copies / 3, ... scaled so that the families cover `frac` of the sequence
+	std::vector<int64_t> copies((size_t)n_fam);
+	{
+		double bases = 0; int64_t c = max_copies;
+		for (int f = 0; f < n_fam; f++) { copies[(size_t)f] = c < 2 ? 2 : c; bases += (double)copies[(size_t)f] * fam_len[f & 7]; c /= 3; }
+		const double scale = frac * (double)n / bases;
+		if (scale < 1.0) for (int f = 0; f < n_fam; f++) { copies[(size_t)f] = (int64_t)((double)copies[(size_t)f] * scale); if (copies[(size_t)f] < 2) copies[(size_t)f] = 2; }
+	}
+	for (int f = 0; f < n_fam; f++) {
+		const int L = fam_len[f & 7];
+		if (n < 8 * (int64_t)L) continue;
+		std::vector<char> fam((size_t)L), cp((size_t)L * 12 + 64);
+		gsah_c_synth_genome(L, seed ^ (0xFA111ull + 977ull * (uint64_t)f), fam.data());
+		for (int64_t c = 0; c < copies[(size_t)f]; c++) {
+			int64_t got = mutate_into(fam.data(), L, fam_div[f & 7], seed + 31 * (uint64_t)f, 1000 + 2 * (uint64_t)c, cp.data(), (int64_t)cp.size());
+			if (got < 0) got = 0;
+			for (; got < L; got++) cp[(size_t)got] = ACGT[rnd(seed, 7 + (uint64_t)f, (uint64_t)c * 8192 + (uint64_t)got) & 3];
+			const int64_t pos = (int64_t)(rnd(seed, 300 + (uint64_t)f, (uint64_t)c) % (uint64_t)(n - L));
+			memcpy(seq + pos, cp.data(), (size_t)L);
+			total++;
+		}
+	}
+	for (int64_t k = 0; k < n / 15000; k++) {                              // microsatellites
+		const uint64_t r = rnd(seed, 51, (uint64_t)k);
+		const int unit = 1 + (int)(r % 6), len = 20 + (int)((r >> 8) % 281);
+		const int64_t pos = (int64_t)((r >> 20) % (uint64_t)(n - len));
+		char u[6]; for (int t = 0; t < unit; t++) u[t] = ACGT[(r >> (40 + 2 * t)) & 3];
+		for (int t = 0; t < len; t++) seq[pos + t] = u[t % unit];
+	}
+	for (int64_t k = 0; k < n / 60000; k++) {                              // soft-masked blocks
+		const uint64_t r = rnd(seed, 52, (uint64_t)k);
+		const int len = 200 + (int)(r % 4801);
+		const int64_t pos = (int64_t)((r >> 16) % (uint64_t)(n - len));
+		for (int t = 0; t < len; t++) { const char c = seq[pos + t]; if (c >= 'A' && c <= 'Z' && c != 'N') seq[pos + t] = (char)(c | 0x20); }
+	}
+	if (n_run > 0 && 8 * n_run < n) for (int g = 1; g <= 2; g++) memset(seq + g * (n / 3) - n_run / 2, 'N', (size_t)n_run);
+	return total;
 }
 
 // query = mutated copy of ref; returns the length written (<= cap), or -1 if cap is too small

@@ -57,6 +57,23 @@ __device__ __forceinline__ int text_match32(u32 r0, u32 r1, u32 r2, i64 tp, i64 
 	return n < avail ? n : avail;
 }
 
+// Presence table: does a pres_k-mer occur in the indexed text?  BWT_Search from s reaches MinSeedLength iff the first
+// MinSeedLength bases occur, so an absent pres_k-mer (pres_k <= MinSeedLength) settles a search that yields no seed with ONE read.
+// GROUPED layout (round 3): a walk crosses the ~14 starts in front of a mismatch one by one, so the kernel asks about s, s+1,
+// s+2, s+3 together -- as a plain bitmap indexed by the k-mer those were four reads of four unrelated cache lines (most of the
+// seed kernel's 6.2 GB of fetches per 250 Mb contig, profiles/r02_pmc_human.json).  The four k-mers share the K-3 bases
+// q[s+3 .. s+K): that CORE selects a 32-byte line, and bit 64 i + e_i of the line answers for start s+i, where e_i (6 bits) are
+// the three bases of that k-mer outside the core -- q[s+i .. s+3) and q[s+K .. s+K+i).  A k-mer of the text is therefore entered
+// four times, once per role i.  4^(K-3) lines: 512 MiB for K = 15.  (pres4_line / pres4_bits take the query's 2-bit window from
+// the group's first base; the builder derives the same numbers from the k-mer alone.)
+__device__ __forceinline__ u32 pres4_line(u64 qb, int K) { return (u32)((qb >> 6) & ((1ull << (2 * (K - 3))) - 1)); }
+__device__ __forceinline__ u32 pres4_bit(u64 qb, int K, int i)      // 0 .. 255: position inside the line for start s + i
+{
+	const u32 head = (u32)(qb >> (2 * i)) & ((1u << (2 * (3 - i))) - 1);          // q[s+i .. s+3)
+	const u32 tail = (u32)(qb >> (2 * K)) & ((1u << (2 * i)) - 1);                // q[s+K .. s+K+i)
+	return (u32)i * 64u + (head | (tail << (2 * (3 - i))));
+}
+
 // ---------------------------------------------------------------------------
 // Seed exploration.  Work unit = one 10 000-bp chunk (absolute position, App. B
 // #1).  Inside a chunk the reference walks a CHAIN: next start = start+len+1
@@ -185,7 +202,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		// lanes issue their requests together, wait once, then consume by mode -- so lanes that are in
 		// different searches, or in different phases of a search, never serialise on each other's
 		// memory latency.
-		int item = -1, s = 0, bend = 0, pos = 0, mode = M_ADV; u32 kid = 0, pid = 0;
+		int item = -1, s = 0, bend = 0, pos = 0, mode = M_ADV; u32 kid = 0, pid = 0, pext = 0;
 		FmIntv ik = {0, 0, 0}; u32 blk = 0; i64 tp = 0;
 		bool need_item = true;
 		while (!__all(mode == M_DONE)) {
@@ -216,21 +233,17 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 				e0 = pe[0]; e1 = pe[1];
 			}
 			// presence bits of s and of the three starts behind it: a search that dies below MinSeedLength moves on by ONE base,
-			// so walks cross the 14 bases in front of a mismatch start by start -- four of those per memory round trip
-			u32 pidk[PLOOK]; for (int k2 = 0; k2 < PLOOK; k2++) pidk[k2] = 0;
-			if (mode == M_KMER && di.pres_k) {
-#pragma unroll
-				for (int k2 = 0; k2 < PLOOK; k2++) pidk[k2] = (u32)(q_bits64(qp, s + 1 + k2 < clen ? s + 1 + k2 : 0) & ((1ull << (2 * di.pres_k)) - 1));
-			}
-			const u32 pw = di.pres ? di.pres[mode == M_KMER ? (pid >> 5) : 0] : ~0u;
-			u32 pwk[PLOOK];
-#pragma unroll
-			for (int k2 = 0; k2 < PLOOK; k2++) pwk[k2] = di.pres ? di.pres[mode == M_KMER ? (pidk[k2] >> 5) : 0] : ~0u;
+			// so walks cross the 14 bases in front of a mismatch start by start -- four of those per memory round trip, and since
+			// round 3 all four from ONE 32-byte line (pres4_*)
+			uint4 pl0 = {~0u, ~0u, ~0u, ~0u}, pl1 = {~0u, ~0u, ~0u, ~0u};
+			if (di.pres) { const uint4 *pp = (const uint4 *)di.pres + 2 * (size_t)(mode == M_KMER ? pid : 0); pl0 = pp[0]; pl1 = pp[1]; }
+			// (bit 64 i + e of the line: dword 2 i + (e >> 5); e_i packed in pext, 6 bits each)
+#define PRES4_TEST(I) ((((((pext >> (6 * (I))) & 32u) ? ((I) == 0 ? pl0.y : (I) == 1 ? pl0.w : (I) == 2 ? pl1.y : pl1.w) : ((I) == 0 ? pl0.x : (I) == 1 ? pl0.z : (I) == 2 ? pl1.x : pl1.z)) >> ((pext >> (6 * (I))) & 31u)) & 1u) != 0)
 			const u64 sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
 			// ---- consume phase: straight-line, one predicated block per mode ----
 			bool ended = false;
 			if (mode == M_KMER) {
-				if (!((pw >> (pid & 31)) & 1u)) {       // the first MinSeedLength bases do not occur: no seed here, next start s+1
+				if (!PRES4_TEST(0)) {                  // the first MinSeedLength bases do not occur: no seed here, next start s+1
 					memo[s] = 1; s += 1; mode = M_ADV;
 					// ... and the same for the starts behind it, as long as nothing else is known about them (the advance step
 					// below owns every other rule: sub-range end, memoised hop, ambiguous bases, too close to the chunk end)
@@ -240,7 +253,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 						if (s >= bend || memo[s]) break;
 						const u32 nb = q_nbits32(qn, s);
 						if (s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0) break;
-						if ((pwk[k2] >> (pidk[k2] & 31)) & 1u) break;          // occurs: needs its table entry (next iteration)
+						if (k2 == 0 ? PRES4_TEST(1) : k2 == 1 ? PRES4_TEST(2) : PRES4_TEST(3)) break;          // occurs: needs its table entry (next iteration)
 						memo[s] = 1; s += 1;
 					}
 				} else {
@@ -299,11 +312,14 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 					if (!COUNT && di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
 						const u64 qb = q_bits64(qp, s);
 						kid = (u32)(qb & ((1ull << (2 * di.kmer_k)) - 1)); mode = M_KMER;
-						pid = di.pres_k ? (u32)(qb & ((1ull << (2 * di.pres_k)) - 1)) : 0;
+						// the line of the presence table that answers for s .. s+3, and the four positions inside it
+						pid = di.pres_k ? pres4_line(qb, di.pres_k) : 0;
+						pext = di.pres_k ? ((pres4_bit(qb, di.pres_k, 0) & 63u) | ((pres4_bit(qb, di.pres_k, 1) & 63u) << 6) | ((pres4_bit(qb, di.pres_k, 2) & 63u) << 12) | ((pres4_bit(qb, di.pres_k, 3) & 63u) << 18)) : 0;
 					}
 				}
 			}
 		}
+#undef PRES4_TEST
 		rounds++;
 		__syncthreads();
 		if (s_abort) break;
@@ -462,7 +478,7 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 	__syncthreads();
 	uint16_t *memo = dn_memo + (size_t)slot * GSA_CHUNK; u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; u64 *x0o = dn_x0 + (size_t)slot * GSA_CHUNK;
 	int nextp = span0 + j;                                  // this lane's starts: nextp, nextp + DENSE_TPB
-	int s = 0, pos = 0, mode = M_ADV; u32 kid = 0, pid = 0, blk = 0, all_blocks = 0;
+	int s = 0, pos = 0, mode = M_ADV; u32 kid = 0, pid = 0, pext = 0, blk = 0, all_blocks = 0;
 	FmIntv ik = {0, 0, 0}; i64 tp = 0;
 	const int L = prm.MinSeedLength < 32 ? prm.MinSeedLength : 32;
 	while (!__all(mode == M_DONE)) {
@@ -491,12 +507,13 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 			if (E16) { const uint4 e = ((const uint4 *)di.kmer_lo)[mode == M_KLO ? kid : 0]; l0.x = e.x; l0.y = e.y; l1.x = e.z; l1.y = e.w; }
 			else { const ulonglong2 *pe = (const ulonglong2 *)(di.kmer_lo + (mode == M_KLO ? ((size_t)kid << 2) : 0)); l0 = pe[0]; l1 = pe[1]; }
 		}
-		const u32 pw = di.pres ? di.pres[mode == M_KMER ? (pid >> 5) : 0] : ~0u;
+		// (one start per lane here: role 0 of the group that starts at s -- dword pid of the grouped presence table, bit pext)
+		const u32 pw = di.pres ? di.pres[mode == M_KMER ? pid : 0] : ~0u;
 		const u64 sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
 		// ---- consume phase ----
 		bool ended = false;
 		if (mode == M_KMER) {
-			if (!((pw >> (pid & 31)) & 1u)) { ended = true; pos = s; ik.x2 = 0; }      // the first MinSeedLength bases do not occur: no seed here
+			if (!((pw >> pext) & 1u)) { ended = true; pos = s; ik.x2 = 0; }      // the first MinSeedLength bases do not occur: no seed here
 			else {
 				const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k
 				if (hit) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; }
@@ -540,7 +557,7 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 			if (di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
 				const u64 qb = q_bits64(qp, s);
 				kid = (u32)(qb & ((1ull << (2 * di.kmer_k)) - 1)); mode = M_KMER;
-				pid = di.pres_k ? (u32)(qb & ((1ull << (2 * di.pres_k)) - 1)) : 0;
+				{ const u32 b0 = di.pres_k ? pres4_bit(qb, di.pres_k, 0) : 0; pid = di.pres_k ? pres4_line(qb, di.pres_k) * 8 + (b0 >> 5) : 0; pext = b0 & 31u; }
 			} else if (di.kmer_lo && s + di.kmer_lo_k <= clen && (nb & ((1u << di.kmer_lo_k) - 1)) == 0) {
 				kid = (u32)(q_bits64(qp, s) & ((1ull << (2 * di.kmer_lo_k)) - 1)); mode = M_KLO;      // (too close to the chunk end or an N for the long table)
 			}
@@ -807,16 +824,21 @@ __global__ void __launch_bounds__(256) k_pack_ref(const uint8_t *__restrict__ re
 	out[w] = v;
 }
 
-// Presence bitmap: bit id is set iff the pres_k-mer id (same packing as the query in LDS) occurs in the
-// indexed text.  BWT_Search from s reaches MinSeedLength iff the first MinSeedLength bases occur, so an
-// absent pres_k-mer (pres_k <= MinSeedLength) settles a search that yields no seed with ONE read.
+// (layout of the grouped presence table: comment at pres4_line, top of this file)
 __global__ void __launch_bounds__(256) k_build_pres(const u32 *__restrict__ ref2, u64 seq_len, int k, u32 *bm)
 {
 	const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (p + (u64)k > seq_len) return;
 	const u64 w = p >> 4;
-	const u32 id = (u32)(funnel64(ref2[w], ref2[w + 1], ref2[w + 2], (int)(p & 15) << 1) & ((1ull << (2 * k)) - 1));
-	atomicOr(&bm[id >> 5], 1u << (id & 31));
+	const u64 X = funnel64(ref2[w], ref2[w + 1], ref2[w + 2], (int)(p & 15) << 1) & ((1ull << (2 * k)) - 1);      // the k-mer at p, base t at bits 2t
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		// as member i of the group that starts at p - i: its core is X[3-i .. k-i), the rest are X's first 3-i and last i bases
+		const u32 line = (u32)((X >> (2 * (3 - i))) & ((1ull << (2 * (k - 3))) - 1));
+		const u32 head = (u32)X & ((1u << (2 * (3 - i))) - 1), tail = (u32)(X >> (2 * (k - i))) & ((1u << (2 * i)) - 1);
+		const u32 bit = (u32)i * 64u + (head | (tail << (2 * (3 - i))));
+		atomicOr(&bm[(size_t)line * 8 + (bit >> 5)], 1u << (bit & 31));
+	}
 }
 
 // the short companion of the k-mer table (DevIndex::kmer_lo): MinSeedLength bases, when that is less than kmer_k
@@ -843,7 +865,7 @@ int build_presence(gsa_ctx *c)
 	if (k == c->di.pres_k && c->di.pres) return GSA_OK;
 	c->di.pres = nullptr; c->di.pres_k = 0;
 	if (k < 8) return GSA_OK;                             // short seeds: nearly every k-mer present, nothing to gain
-	const size_t words = ((size_t)1 << (2 * k)) / 32;
+	const size_t words = ((size_t)1 << (2 * (k - 3))) * 8;      // 4^(k-3) lines of 32 bytes
 	if (!dev_ensure<u32>(c, c->d_pres, words)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemsetAsync(c->d_pres.p, 0, words * 4, c->stream));
 	hipLaunchKernelGGL(k_build_pres, dim3(grid_for(c->di.seq_len, 256)), dim3(256), 0, c->stream, c->di.ref2, c->di.seq_len, k, c->d_pres.as<u32>());
@@ -1075,8 +1097,18 @@ int stage1_import_hits(gsa_ctx *c, const u64 *keys, const u32 *vals, i64 n)
 	if (c->n_seeds + n >= (1ll << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");
 	const size_t have = (size_t)c->n_seeds, want = have + (size_t)n + 64;
 	if (!dev_grow_keep<u64>(c, c->d_key_a, want, have) || !dev_grow_keep<u32>(c, c->d_val_a, want, have)) return GSA_ERR_NOMEM;
-	GSA_CHECK(c, hipMemcpyAsync(c->d_key_a.as<u64>() + have, keys, (size_t)n * 8, hipMemcpyDefault, c->stream));
-	GSA_CHECK(c, hipMemcpyAsync(c->d_val_a.as<u32>() + have, vals, (size_t)n * 4, hipMemcpyDefault, c->stream));
+	// (host memory, memory of this GPU, or of another GPU of the node -- then the copy goes peer to peer over xGMI)
+	int src_dev = -1;
+	{ hipPointerAttribute_t at; if (hipPointerGetAttributes(&at, keys) == hipSuccess && at.type == hipMemoryTypeDevice) src_dev = at.device; else (void)hipGetLastError(); }
+	if (src_dev >= 0 && src_dev != c->device) {
+		int can = 0; (void)hipDeviceCanAccessPeer(&can, c->device, src_dev);
+		if (can) { hipError_t e = hipDeviceEnablePeerAccess(src_dev, 0); if (e != hipSuccess) (void)hipGetLastError(); }      // (already enabled is fine)
+		GSA_CHECK(c, hipMemcpyPeerAsync(c->d_key_a.as<u64>() + have, c->device, keys, src_dev, (size_t)n * 8, c->stream));
+		GSA_CHECK(c, hipMemcpyPeerAsync(c->d_val_a.as<u32>() + have, c->device, vals, src_dev, (size_t)n * 4, c->stream));
+	} else {
+		GSA_CHECK(c, hipMemcpyAsync(c->d_key_a.as<u64>() + have, keys, (size_t)n * 8, hipMemcpyDefault, c->stream));
+		GSA_CHECK(c, hipMemcpyAsync(c->d_val_a.as<u32>() + have, vals, (size_t)n * 4, hipMemcpyDefault, c->stream));
+	}
 	if (c->pd_path) hipLaunchKernelGGL(k_pd_from_keys, dim3(grid_for((size_t)n, 256)), dim3(256), 0, c->stream, n, c->d_key_a.as<u64>() + have, c->qbits, c->d_pdbm.as<u32>());
 	GSA_CHECK(c, hipGetLastError());
 	GSA_CHECK(c, hipStreamSynchronize(c->stream));      // (the caller's buffers are free again)

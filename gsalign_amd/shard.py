@@ -3,10 +3,10 @@
 Query contigs are independent in the reference (GSAlign.cpp:483-548: all
 per-contig state is cleared at :490), so the path shards by contig with the index
 replicated on every GPU and NO data-path collective.  The only exchange is the
-gather of finished block records to rank 0, which writes MAF/VCF in contig order:
-one all_gather of counts + one padded all_gather of the 40-byte records -- a few
-KB..MB per contig, far below one xGMI link (about 153 GB/s), so a direct gather
-(not a ring pipeline) is the right shape.
+gather of finished results to rank 0, which writes MAF/VCF in contig order:
+one all_gather of counts + point-to-point sends of the packed results to rank 0 --
+far below one xGMI link (about 153 GB/s), so a direct gather (not a ring pipeline)
+is the right shape.
 
 torch.distributed is plumbing here: backend "nccl" (= RCCL) on GPUs, "gloo" in the
 CPU tests.
@@ -42,17 +42,28 @@ def split_chunks(n_chunks: int, world: int):
 
 def exchange_hits(aligner, owner: int = 0, device=None) -> int:
     """After every rank ran `aligner.seed_chunks(contig, beg, end)` on its range: send the hits to `owner`, which imports
-    them (gsa_export_hits -> dist.send/recv -> gsa_import_hits).  16 + 4 bytes per hit, point to point: on one node that is
-    one xGMI link per sender (RCCL), far below its bandwidth.  Returns the number of hits the owner now holds (0 elsewhere).
-    `aligner` needs export_hits() -> (uint64 keys, uint32 vals) and import_hits(keys, vals)."""
+    them.  8 + 4 bytes per hit, point to point: on one node that is one xGMI link per sender (RCCL), far below its bandwidth.
+    On GPUs the hits never touch host memory: gsa_export_hits writes them into the send tensor (device to device), RCCL moves
+    it, gsa_import_hits reads the receive tensor in place (device pointers are what both calls accept).  On CPU (gloo tests,
+    stub aligner) the same exchange runs through numpy.  Returns the number of hits imported (0 elsewhere)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return -1
     world, rank = dist.get_world_size(), dist.get_rank()
     dev = device if device is not None else torch.device("cpu")
-    keys, vals = aligner.export_hits() if rank != owner else (np.zeros(0, np.uint64), np.zeros(0, np.uint32))
-    cnt = torch.tensor([keys.size], dtype=torch.int64, device=dev)
+    on_gpu = dev.type == "cuda" and hasattr(aligner, "hit_count")
+    if rank == owner:
+        keys = vals = None; n_mine = 0
+    elif on_gpu:
+        n_mine = aligner.hit_count()
+        keys = torch.empty(max(n_mine, 1), dtype=torch.int64, device=dev); vals = torch.empty(max(n_mine, 1), dtype=torch.int32, device=dev)
+        if n_mine:
+            aligner.export_hits(keys.data_ptr(), vals.data_ptr())       # device -> device, on the library's stream; synchronised on return
+    else:
+        k, v = aligner.export_hits(); n_mine = int(k.size)
+        keys = torch.from_numpy(k.view(np.int64)).to(dev); vals = torch.from_numpy(v.view(np.int32)).to(dev)
+    cnt = torch.tensor([n_mine], dtype=torch.int64, device=dev)
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(cnts, cnt)
     total = 0
@@ -63,11 +74,14 @@ def exchange_hits(aligner, owner: int = 0, device=None) -> int:
                 continue
             tk = torch.empty(n, dtype=torch.int64, device=dev); tv = torch.empty(n, dtype=torch.int32, device=dev)
             dist.recv(tk, src=r); dist.recv(tv, src=r)
-            aligner.import_hits(tk.cpu().numpy().view(np.uint64), tv.cpu().numpy().view(np.uint32))
+            if on_gpu:
+                torch.cuda.current_stream(dev).synchronize()            # (the receive is complete before the library's stream reads it)
+                aligner.import_hits(tk.data_ptr(), tv.data_ptr(), n)    # in place: no host copy
+            else:
+                aligner.import_hits(tk.cpu().numpy().view(np.uint64), tv.cpu().numpy().view(np.uint32))
             total += n
-    elif keys.size:
-        dist.send(torch.from_numpy(keys.view(np.int64)).to(dev), dst=owner)
-        dist.send(torch.from_numpy(vals.view(np.int32)).to(dev), dst=owner)
+    elif n_mine:
+        dist.send(keys[:n_mine], dst=owner); dist.send(vals[:n_mine], dst=owner)
     return total
 
 
@@ -92,29 +106,33 @@ def unpack_results(buf: np.ndarray, block_dt, frag_dt) -> dict:
     return out
 
 
-def gather_results(mine: dict, block_dt, frag_dt, device=None) -> dict:
-    """Every rank's finished contigs ({contig index: result dict}) on rank 0, keyed by contig index -- blocks, gap records
-    AND gapped strings, so rank 0 can emit MAF / VCF in contig order exactly as a one-GPU run does.  One all_gather of the
-    byte counts + one padded all_gather of the packed records (a direct gather, no ring: the payload is MBs)."""
+def gather_results(mine: dict, block_dt, frag_dt, device=None, dst: int = 0) -> dict:
+    """Every rank's finished contigs ({contig index: result dict}) on rank `dst`, keyed by contig index -- blocks, gap records
+    AND gapped strings, so that rank can emit MAF / VCF in contig order exactly as a one-GPU run does.  One all_gather of the
+    byte counts, then every other rank SENDS its packed records to `dst` (point to point, exact sizes): only `dst` needs them,
+    and at full-genome size a padded all_gather would hand every rank world x the largest payload (GBs).  Other ranks get {}."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return dict(mine)
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     dev = device if device is not None else torch.device("cpu")
     pay = np.concatenate([pack_result(c, r) for c, r in sorted(mine.items())]) if mine else np.zeros(0, np.uint8)
     cnt = torch.tensor([pay.size], dtype=torch.int64, device=dev)
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(cnts, cnt)
-    mx = max(1, max(int(c.item()) for c in cnts))
-    t = torch.zeros(mx, dtype=torch.uint8, device=dev)
-    if pay.size:
-        t[:pay.size] = torch.from_numpy(pay).to(dev)
-    ts = [torch.zeros_like(t) for _ in range(world)]
-    dist.all_gather(ts, t)
-    out = {}
-    for tt, c in zip(ts, cnts):
-        out.update(unpack_results(tt[: int(c.item())].cpu().numpy(), block_dt, frag_dt))
+    if rank != dst:
+        if pay.size:
+            dist.send(torch.from_numpy(pay).to(dev), dst=dst)
+        return {}
+    out = unpack_results(pay, block_dt, frag_dt)
+    for r in range(world):
+        n = int(cnts[r].item())
+        if r == dst or n == 0:
+            continue
+        t = torch.empty(n, dtype=torch.uint8, device=dev)
+        dist.recv(t, src=r)
+        out.update(unpack_results(t.cpu().numpy(), block_dt, frag_dt))
     return out
 
 

@@ -81,6 +81,8 @@ def _hostlib():
     lib.gsah_c_synth_repeats.restype = C.c_int64
     lib.gsah_c_synth_mutate.argtypes = [C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_void_p, C.c_int64]
     lib.gsah_c_synth_mutate.restype = C.c_int64
+    lib.gsah_c_synth_adversarial.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int, C.c_int64, C.c_int64]
+    lib.gsah_c_synth_adversarial.restype = C.c_int64
     return lib
 
 
@@ -96,6 +98,26 @@ def inject_repeats(seq: np.ndarray, seed: int = 11, frac: float = 0.10, fam_len:
     of the genome plus one tandem array with more than MaxSeedFreq copies.  Returns the number of family copies."""
     assert seq.flags.c_contiguous and seq.dtype == np.uint8
     return int(_hostlib().gsah_c_synth_repeats(seq.ctypes.data, seq.size, seed, frac, fam_len, copy_div, tandem_unit, tandem_copies))
+
+
+def inject_adversarial(seq: np.ndarray, seed: int = 11, frac: float = 0.25, n_fam: int = 8, max_copies: int = 100_000, n_run: int = 1_000_000) -> int:
+    """In place: repeat families with a copy-number spectrum (up to max_copies copies, 1-15 % divergent), microsatellites,
+    two runs of n_run N's (capped at 1/8 of the sequence) and soft-masked blocks -- csrc/host/synth.cpp.  Returns the copy count."""
+    assert seq.flags.c_contiguous and seq.dtype == np.uint8
+    return int(_hostlib().gsah_c_synth_adversarial(seq.ctypes.data, seq.size, seed, frac, n_fam, max_copies, min(n_run, seq.size // 9)))
+
+
+def make_adversarial_pair(total_len: int, n_contigs: int, d: float, seed: int = 11, **kw):
+    """(ref_contigs, qry_contigs) like make_pair_fast, every reference contig with the adversarial injection."""
+    base = total_len // n_contigs
+    refs, qrys = [], []
+    for i in range(n_contigs):
+        ln = base if i + 1 < n_contigs else total_len - base * (n_contigs - 1)
+        r = fast_genome(int(ln), seed * 1000 + i)
+        inject_adversarial(r, seed * 1000 + i, **kw)
+        refs.append((f"chr{i + 1}", r))
+        qrys.append((f"qry{i + 1}", fast_mutate(r, d, seed * 1000 + 500 + i)))
+    return refs, qrys
 
 
 def fast_mutate(ref: np.ndarray, d: float, seed: int) -> np.ndarray:

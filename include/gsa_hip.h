@@ -182,6 +182,11 @@ int   gsa_device_upload(int device, void *dst, const void *src, size_t bytes);
 typedef int (*gsa_result_fn)(void *user, int32_t contig, const gsa_result *res);
 #define GSA_MANY_IN_ORDER 1u   /* hand the contigs out in the order given (default: longest first) */
 #define GSA_MANY_DEVICE   2u   /* query[] are device pointers (gsa_align_contig_device); all contexts on one GPU */
+#define GSA_MANY_NO_SPLIT 4u   /* never seed one contig on several contexts (see below) */
+/* With FEWER contigs than contexts (one chromosome, two GPUs: BASELINE configs[3]) the contexts are dealt out in groups, one
+ * group per contig, sized by contig length, and a contig of at least 20 Mb (GSA_SPLIT_MIN) is seeded by chunk range on all
+ * contexts of its group -- gsa_seed_chunks ... gsa_finish_contig below, driven from the library's own threads, hits moved
+ * device to device (peer to peer between GPUs).  Results do not depend on the grouping. */
 int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n,
                    uint32_t flags, gsa_result_fn on_result, void *user);
 
@@ -196,6 +201,8 @@ int gsa_seed_chunks(gsa_ctx *ctx, const char *query, int32_t qlen, int32_t chunk
 int64_t gsa_hit_count(gsa_ctx *ctx);
 int gsa_export_hits(gsa_ctx *ctx, uint64_t *keys, uint32_t *vals);
 int gsa_import_hits(gsa_ctx *ctx, const uint64_t *keys, const uint32_t *vals, int64_t n);
+/* the hits of gsa_seed_chunks where they lie (device pointers, valid until the next call on ctx): same-node transport */
+int gsa_hit_buffers(gsa_ctx *ctx, const uint64_t **keys, const uint32_t **vals);
 int gsa_finish_contig(gsa_ctx *ctx, gsa_result *out);
 
 /* ---- stage-level entry points (what the parity tests drive) --------------

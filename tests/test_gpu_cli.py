@@ -33,6 +33,24 @@ def test_cli_golden(golden_dir, tmp_path, name, extra, maf, vcf):
         assert not os.path.exists(tmp_path / "out.vcf")                   # -no_vcf (main.cpp:280)
 
 
+def test_cli_one_contig_on_several_gpus(golden_dir, tmp_path):
+    """BASELINE configs[3] in the C++ product: ONE query sequence and several GPUs listed (-gpu 0,0,0: three contexts with an index
+    of their own each stand in for three GPUs on this one-GPU box) -> gsa_align_many seeds it by chunk range on all of them, the
+    owner imports the hits device to device and finishes; MAF and VCF byte-identical to the one-GPU run and to the reference's."""
+    qs = synth.read_fasta(os.path.join(golden_dir, "cx.qry.fa"))
+    one = tmp_path / "one.fa"
+    synth.write_fasta(str(one), [qs[0]])
+    env = dict(os.environ, GSA_SPLIT_MIN="50000")               # (the contig is 120 kb: let it split)
+    for tag, gpus in (("a", "0"), ("b", "0,0,0"), ("c", "0,0")):
+        subprocess.run([hostlib.CLI_PATH, "-i", "cx", "-q", str(one), "-o", str(tmp_path / tag), "-t", "1", "-gpu", gpus], cwd=golden_dir, env=env, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    ref_maf = open(os.path.join(golden_dir, "cx.maf"), "rb").read()
+    a = open(tmp_path / "a.maf", "rb").read()
+    assert len(a) > 1000 and ref_maf.startswith(a)             # (the golden MAF of all contigs begins with this contig's part)
+    for tag in ("b", "c"):
+        assert open(tmp_path / f"{tag}.maf", "rb").read() == a and open(tmp_path / f"{tag}.vcf", "rb").read() == open(tmp_path / "a.vcf", "rb").read(), tag
+
+
 def test_cli_dotplot_golden(golden_dir, tmp_path):
     """-dp: with a `gnuplot` on PATH (a stub that keeps what it is given -- none is installed here or where the golden was made) the CLI
     hands gnuplot the same scripts and data files as the unmodified reference CLI did (tests/golden/cx_dp.json.gz), removes its data
@@ -81,5 +99,5 @@ def test_cli_config3_and_repeat_stress_vs_live_reference(oracle_built):
     if not oracle_built.have_ref():
         pytest.skip("oracle/_ref not present")
     from conftest import ROOT
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_cli_check.py"), "c3,repeat"], capture_output=True, text=True, timeout=900, env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
-    assert r.returncode == 0 and r.stdout.count("IDENTICAL") == 4, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_cli_check.py"), "c3,repeat,adversarial"], capture_output=True, text=True, timeout=900, env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
+    assert r.returncode == 0 and r.stdout.count("IDENTICAL") == 6, r.stdout + r.stderr

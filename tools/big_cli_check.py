@@ -1,7 +1,7 @@
 """End-to-end checks on the GPU box: whole programs side by side -- our CLI (GSAlign_hip: own index builder, GPU hot path on
 several contexts, own emitters) and the unmodified reference CLI (oracle/_ref, -t 1: its block order on score ties and its
 S4/S5 race depend on the thread count) -- MAF and VCF compared byte for byte.
-    python tools/big_cli_check.py [cases: plain,c3,repeat]"""
+    python tools/big_cli_check.py [cases: plain,c3,repeat,adversarial]"""
 import os, subprocess, sys, tempfile, time
 root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
@@ -20,6 +20,9 @@ for case in cases:
     elif case == "c3":       # BASELINE configs[2]: 16 contigs with the S. cerevisiae chromosome lengths, 2 %, -sen
         refs, qrys = synth.make_pair_fast(0, 16, 0.02, seed=124, lengths=[1000 * k for k in YEAST_KB]); flags = ["-sen"]
         qrys[5] = (qrys[5][0], synth.revcomp(qrys[5][1]))
+    elif case == "adversarial":      # copy-number spectrum, microsatellites, N runs, soft-masked blocks: 12 Mb in three contigs, 2 %
+        refs, qrys = synth.make_adversarial_pair(12000000, 3, 0.02, seed=126, n_run=300000); flags = []
+        qrys[2] = (qrys[2][0], synth.revcomp(qrys[2][1]))
     else:                    # SURVEY 8(d) repeat-stress variant, 12 Mb in four contigs, 1 %
         refs, qrys = synth.make_pair_fast(12000000, 4, 0.01, seed=125, repeats=True); flags = []
     synth.write_fasta(os.path.join(d, "r.fa"), refs); synth.write_fasta(os.path.join(d, "q.fa"), qrys)

@@ -9,8 +9,8 @@ from gsalign_amd import synth, hostlib, indexio, capi
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 variants = (sys.argv[2] if len(sys.argv) > 2 else "none,family,tandem,both").split(",")
-os.environ["GSA_DEBUG"] = "1"
-tmp = tempfile.mkdtemp(prefix="seedprobe_")
+tmp = os.environ.get("GSA_PROBE_KEEP") or tempfile.mkdtemp(prefix="seedprobe_")      # (GSA_PROBE_KEEP: reuse the index between calls)
+os.makedirs(tmp, exist_ok=True)
 for v in variants:
     r = synth.fast_genome(n, 11000)
     div, prm = 0.01, {}
@@ -19,14 +19,19 @@ for v in variants:
     elif v == "both": synth.inject_repeats(r, 11000)
     elif v == "sen": div, prm = 0.02, dict(sen=1, clr=50)
     px = os.path.join(tmp, v)
-    synth.write_fasta(px + ".fa", [("chr1", r)]); t = time.time(); hostlib.build_index(px + ".fa", px); tb = time.time() - t
+    px = px + f"_{n}"
+    t = time.time()
+    if not os.path.exists(px + ".done"):
+        synth.write_fasta(px + ".fa", [("chr1", r)]); hostlib.build_index(px + ".fa", px); open(px + ".done", "w").close()
+    tb = time.time() - t
     idx = indexio.load_index(px)
     q = synth.fast_mutate(r, div, 7000)
     g = capi.Aligner(idx, **prm)
     g.set_profiling(True)
     for rep in range(2):
         g.set_query(q); g.run_to(1)
-    tm = g.timings(); c = g.counters()
+    tm = g.timings(); c = g.counters(); st = g.seed_stats()
+    print(f"   seed stats: resolver rounds max {int(st[0])}, dense chunks {int(st[1])}, wave iterations max {int(st[2])}; slowest chunk: round 1 {st[3] * 0.01:.1f} us, resolver {st[4] * 0.01:.1f} us, total {st[5] * 0.01:.1f} us")
     print(f"== {v}: n={n} index build {tb:.1f}s  seed_search {tm[0]:.3f} ms locate {tm[1]:.3f} sort {tm[2]:.3f}  hits {int(c[2])} occ_read {int(c[7])}", flush=True)
     g.set_query(q); g.run_to(8); tm = g.timings()
     print("   stages:", [round(float(x), 3) for x in tm], flush=True)
