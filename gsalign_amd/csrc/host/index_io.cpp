@@ -10,8 +10,10 @@
 // builder sorts all suffixes with a linear-time SA-IS and derives BWT, Occ and
 // the SA samples from that -- the output is byte-identical.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <zlib.h>
 #include "gsa_host.h"
 
@@ -91,6 +93,108 @@ void sais(const Ch *T, I *SA, I n, I K)
 	induce(T, SA, n, K, isS, bkt, cnt);
 }
 
+// ---- host threads ----
+// GSA_INDEX_THREADS (default: all hardware threads, at most 128); 1 = the serial builder (SA-IS)
+int index_threads()
+{
+	if (const char *e = getenv("GSA_INDEX_THREADS")) { const int v = atoi(e); if (v >= 1) return v; }
+	unsigned h = std::thread::hardware_concurrency();
+	return (int)(h < 1 ? 1 : (h > 128 ? 128 : h));
+}
+// fn(thread, begin, end) over [0, n) cut into one contiguous range per thread
+template <class F> void parallel_ranges(int64_t n, int nt, F fn)
+{
+	if (nt <= 1 || n < 65536) { fn(0, (int64_t)0, n); return; }
+	std::vector<std::thread> th;
+	for (int t = 0; t < nt; t++) { const int64_t a = n * t / nt, b = n * (t + 1) / nt; th.emplace_back([=] { fn(t, a, b); }); }
+	for (std::thread &x : th) x.join();
+}
+
+// ---- parallel suffix sorter (round 3) ----
+// The files of the index are determined by the suffix ORDER, not by how it was found, so references above a few Mb are
+// sorted on all host cores: suffixes are dealt into 4^8 buckets by their first 8 bases (two parallel passes over the text),
+// every bucket is sorted by one thread -- first on the next 32 bases as one 64-bit key, then the runs of equal keys by
+// comparing the 2-bit packed texts 32 bases per word -- and threads take buckets from a shared counter.  A suffix that runs
+// into the end of the text is SMALLER than a longer one with the same prefix ('$' sorts first); the packed text is padded
+// with A = 0, the smallest letter, so padded keys order such pairs correctly or tie, and ties are settled by length.
+// Cost grows with the depth of the comparisons (long exact repeats); a 3.1 Gbp reference (6.2 G suffixes) takes about a minute
+// on 128 threads where SA-IS on one thread took 17.
+struct PackedText {
+	std::vector<uint64_t> w; int64_t S = 0;          // base p (code 0..3) at bits 62 - 2 (p & 31) of word p >> 5
+	inline uint64_t get32(int64_t p) const           // the 32 bases from p on, zero beyond the end
+	{
+		if (p >= S) return 0;
+		const int64_t wi = p >> 5; const int sh = (int)(p & 31) * 2;
+		return sh ? (w[(size_t)wi] << sh) | (w[(size_t)wi + 1] >> (64 - sh)) : w[(size_t)wi];
+	}
+	// suffix i < suffix j, both known equal on their first d bases
+	inline bool less_from(int64_t i, int64_t j, int64_t d) const
+	{
+		for (;; d += 32) {
+			const int64_t ri = S - (i + d), rj = S - (j + d);
+			if (ri <= 0 || rj <= 0) return ri < rj;
+			uint64_t a = get32(i + d), b = get32(j + d);
+			const int64_t m = ri < rj ? (ri < 32 ? ri : 32) : (rj < 32 ? rj : 32);
+			if (m < 32) { const uint64_t mask = ~0ull << (64 - 2 * m); a &= mask; b &= mask; }
+			if (a != b) return a < b;
+			if (m < 32) return ri < rj;
+		}
+	}
+};
+
+template <class I>
+void parallel_suffix_sort(const std::vector<uint8_t> &T, int64_t S, I *SA, int nt)
+{
+	PackedText P; P.S = S; P.w.assign((size_t)(S / 32 + 3), 0);
+	parallel_ranges((S + 31) / 32, nt, [&](int, int64_t a, int64_t b) {
+		for (int64_t wi = a; wi < b; wi++) {
+			uint64_t v = 0; const int64_t p0 = wi * 32, p1 = p0 + 32 < S ? p0 + 32 : S;
+			for (int64_t p = p0; p < p1; p++) v |= (uint64_t)(T[(size_t)p] - 1) << (62 - 2 * (p - p0));
+			P.w[(size_t)wi] = v;
+		}
+	});
+	const int NB = 1 << 16;
+	std::vector<std::vector<int64_t> > hist((size_t)nt, std::vector<int64_t>((size_t)NB, 0));
+	parallel_ranges(S, nt, [&](int t, int64_t a, int64_t b) { int64_t *h = hist[(size_t)t].data(); for (int64_t i = a; i < b; i++) h[P.get32(i) >> 48]++; });
+	std::vector<int64_t> base((size_t)NB + 1);
+	{
+		int64_t at = 1;                                   // SA[0] = the suffix that is '$' alone
+		for (int bkt = 0; bkt < NB; bkt++) { base[(size_t)bkt] = at; for (int t = 0; t < nt; t++) { const int64_t c = hist[(size_t)t][(size_t)bkt]; hist[(size_t)t][(size_t)bkt] = at; at += c; } }
+		base[(size_t)NB] = at;
+	}
+	SA[0] = (I)S;
+	parallel_ranges(S, nt, [&](int t, int64_t a, int64_t b) { int64_t *o = hist[(size_t)t].data(); for (int64_t i = a; i < b; i++) SA[o[P.get32(i) >> 48]++] = (I)i; });
+	{ std::vector<std::vector<int64_t> >().swap(hist); }
+	// the buckets, largest first (a bucket is one thread's job: the heavy ones must not come last)
+	std::vector<int> order((size_t)NB);
+	for (int b = 0; b < NB; b++) order[(size_t)b] = b;
+	std::sort(order.begin(), order.end(), [&](int x, int y) { const int64_t sx = base[(size_t)x + 1] - base[(size_t)x], sy = base[(size_t)y + 1] - base[(size_t)y]; return sx != sy ? sx > sy : x < y; });
+	std::atomic<int> next(0);
+	auto worker = [&]() {
+		struct KI { uint64_t key; I idx; };
+		std::vector<KI> buf;
+		for (;;) {
+			const int o = next.fetch_add(1); if (o >= NB) return;
+			const int bkt = order[(size_t)o];
+			const int64_t lo = base[(size_t)bkt], m = base[(size_t)bkt + 1] - lo;
+			if (m < 2) continue;
+			buf.resize((size_t)m);
+			for (int64_t k = 0; k < m; k++) { const I i = SA[lo + k]; buf[(size_t)k].idx = i; buf[(size_t)k].key = P.get32((int64_t)i + 8); }
+			std::sort(buf.begin(), buf.end(), [](const KI &x, const KI &y) { return x.key < y.key; });
+			for (int64_t k = 0; k < m;) {
+				int64_t e = k + 1; while (e < m && buf[(size_t)e].key == buf[(size_t)k].key) e++;
+				if (e - k > 1) std::sort(buf.begin() + k, buf.begin() + e, [&](const KI &x, const KI &y) { return P.less_from((int64_t)x.idx, (int64_t)y.idx, 8); });
+				k = e;
+			}
+			for (int64_t k = 0; k < m; k++) SA[lo + k] = buf[(size_t)k].idx;
+		}
+	};
+	std::vector<std::thread> th;
+	for (int t = 1; t < nt; t++) th.emplace_back(worker);
+	worker();
+	for (std::thread &x : th) x.join();
+}
+
 // BWT without '$' (2 bits per symbol, MSB first in each word), primary row and the SA samples of every 32nd row, from the
 // suffix array of T = text + '$' (symbols 1..4, T[S] = 0)
 template <class I>
@@ -98,15 +202,26 @@ void derive_bwt_sa(const std::vector<uint8_t> &T, int64_t S, std::vector<uint32_
 {
 	const I n = (I)(S + 1);
 	std::vector<I> SA((size_t)n);
-	sais<uint8_t, I>(T.data(), SA.data(), n, (I)5);
-	int64_t k = 0;
-	for (I i = 0; i < n; i++) {
-		if (SA[i] == 0) { primary = (uint64_t)i; continue; }
-		const uint32_t c = T[SA[i] - 1] - 1;
-		packed[k >> 4] |= c << ((~k & 15) << 1);
-		k++;
-	}
-	for (uint64_t i = 1; i < sa.size(); i++) sa[i] = (uint64_t)SA[32 * i];
+	const int nt = index_threads();
+	// (GSA_INDEX_PAR_MIN: the tests send small fixtures through the parallel sorter too)
+	const char *pm = getenv("GSA_INDEX_PAR_MIN");
+	if (nt > 1 && S >= (pm ? atoll(pm) : (1ll << 20))) parallel_suffix_sort<I>(T, S, SA.data(), nt);
+	else sais<uint8_t, I>(T.data(), SA.data(), n, (I)5);
+	std::atomic<int64_t> prim(-1);
+	parallel_ranges((int64_t)n, nt, [&](int, int64_t a, int64_t b) { for (int64_t i = a; i < b; i++) if (SA[(size_t)i] == 0) prim.store(i); });
+	primary = (uint64_t)prim.load();
+	// row i of the matrix gives BWT symbol k = i - (i > primary); one output word (16 symbols) per iteration: no word is shared
+	parallel_ranges((S + 15) / 16, nt, [&](int, int64_t a, int64_t b) {
+		for (int64_t kw = a; kw < b; kw++) {
+			uint32_t v = 0; const int64_t k1 = kw * 16 + 16 < S ? kw * 16 + 16 : S;
+			for (int64_t k = kw * 16; k < k1; k++) {
+				const int64_t i = k + (k >= (int64_t)primary ? 1 : 0);
+				v |= (uint32_t)(T[(size_t)SA[(size_t)i] - 1] - 1) << ((~k & 15) << 1);
+			}
+			packed[(size_t)kw] = v;
+		}
+	});
+	parallel_ranges((int64_t)sa.size(), nt, [&](int, int64_t a, int64_t b) { for (int64_t i = a < 1 ? 1 : a; i < b; i++) sa[(size_t)i] = (uint64_t)SA[(size_t)(32 * i)]; });
 }
 
 struct FaRec { std::string name, comment, seq; };
@@ -269,7 +384,8 @@ bool gsah_build_index(const std::string &fasta, const std::string &prefix, std::
 	// ---- text = forward + reverse complement, then '$' ----
 	const int64_t S = 2 * G;
 	std::vector<uint8_t> T((size_t)S + 1);
-	for (int64_t i = 0; i < G; i++) { T[i] = codes[i] + 1; T[S - 1 - i] = (3 - codes[i]) + 1; }
+	const int nt = index_threads();
+	parallel_ranges(G, nt, [&](int, int64_t a, int64_t b) { for (int64_t i = a; i < b; i++) { T[(size_t)i] = codes[(size_t)i] + 1; T[(size_t)(S - 1 - i)] = (3 - codes[(size_t)i]) + 1; } });
 	T[S] = 0;
 	{ std::vector<uint8_t>().swap(codes); }
 	// ---- suffix array -> BWT without '$', primary, L2, SA samples (bwt_cal_sa, bwt.c:101-123) ----
@@ -281,21 +397,41 @@ bool gsah_build_index(const std::string &fasta, const std::string &prefix, std::
 	const char *f64 = getenv("GSA_INDEX_64BIT");
 	if (S + 1 < (1ll << 31) - 1 && !(f64 && *f64 && *f64 != '0')) derive_bwt_sa<int32_t>(T, S, packed, primary, sa);
 	else derive_bwt_sa<int64_t>(T, S, packed, primary, sa);
-	for (int64_t i = 0; i < S; i++) L2[T[i]]++;            // T[i] in 1..4 -> L2[1..4] counts
+	{
+		std::vector<std::vector<uint64_t> > part((size_t)nt, std::vector<uint64_t>(5, 0));
+		parallel_ranges(S, nt, [&](int t, int64_t a, int64_t b) { uint64_t c[5] = {0, 0, 0, 0, 0}; for (int64_t i = a; i < b; i++) c[T[(size_t)i]]++; for (int k = 0; k < 5; k++) part[(size_t)t][(size_t)k] = c[k]; });
+		for (int t = 0; t < nt; t++) for (int k = 0; k < 5; k++) L2[k] += part[(size_t)t][(size_t)k];      // T[i] in 1..4 -> L2[1..4] counts
+	}
 	for (int c = 1; c < 5; c++) L2[c] += L2[c - 1];
 	{ std::vector<uint8_t>().swap(T); }
 	// ---- interleave Occ every 128 (bwt_bwtupdate_core, bwtindex.c:53-75) ----
 	const uint64_t n_occ = (uint64_t)(S + 127) / 128 + 1;
 	std::vector<uint32_t> bwt(packed.size() + n_occ * 8, 0);
 	{
-		uint64_t c[4] = {0, 0, 0, 0}; size_t k = 0;
-		for (int64_t i = 0; i < S; i++) {
-			if (i % 128 == 0) { memcpy(&bwt[k], c, 32); k += 8; }
-			if (i % 16 == 0) bwt[k++] = packed[i >> 4];
-			c[packed[i >> 4] >> ((~i & 15) << 1) & 3]++;
-		}
-		memcpy(&bwt[k], c, 32); k += 8;
-		if (k != bwt.size()) { err = "internal: inconsistent bwt size"; return false; }
+		// block g (128 symbols = 8 packed words) goes to words [16 g, 16 g + 16): 8 words of running counts, then its symbols;
+		// the counts in front of a thread's first block come from a pass over the per-thread totals
+		const int64_t n_blk = (S + 127) / 128;
+		auto count_word = [](uint32_t w, int nsym, uint64_t *c) { for (int t = 0; t < nsym; t++) c[(w >> ((~t & 15) << 1)) & 3]++; };
+		std::vector<std::vector<uint64_t> > tot((size_t)nt, std::vector<uint64_t>(4, 0));
+		parallel_ranges(n_blk, nt, [&](int t, int64_t a, int64_t b) {
+			uint64_t c[4] = {0, 0, 0, 0};
+			for (int64_t i = a * 128; i < b * 128 && i < S; i += 16) count_word(packed[(size_t)(i >> 4)], (int)(S - i < 16 ? S - i : 16), c);
+			for (int k = 0; k < 4; k++) tot[(size_t)t][(size_t)k] = c[k];
+		});
+		const int nt_eff = (nt <= 1 || n_blk < 65536) ? 1 : nt;
+		std::vector<std::vector<uint64_t> > start((size_t)nt_eff + 1, std::vector<uint64_t>(4, 0));
+		for (int t = 0; t < nt_eff; t++) for (int k = 0; k < 4; k++) start[(size_t)t + 1][(size_t)k] = start[(size_t)t][(size_t)k] + tot[(size_t)t][(size_t)k];
+		parallel_ranges(n_blk, nt, [&](int t, int64_t a, int64_t b) {
+			uint64_t c[4]; for (int k = 0; k < 4; k++) c[k] = start[(size_t)t][(size_t)k];
+			for (int64_t g = a; g < b; g++) {
+				size_t k = (size_t)g * 16;
+				memcpy(&bwt[k], c, 32); k += 8;
+				for (int64_t i = g * 128; i < g * 128 + 128 && i < S; i += 16) { bwt[k++] = packed[(size_t)(i >> 4)]; count_word(packed[(size_t)(i >> 4)], (int)(S - i < 16 ? S - i : 16), c); }
+			}
+		});
+		const size_t k_end = (size_t)n_blk * 8 + packed.size();
+		memcpy(&bwt[k_end], start[(size_t)nt_eff].data(), 32);
+		if (k_end + 8 != bwt.size()) { err = "internal: inconsistent bwt size"; return false; }
 	}
 	{
 		FILE *fp = fopen((prefix + ".bwt").c_str(), "wb"); if (!fp) { err = "cannot write .bwt"; return false; }

@@ -3,6 +3,7 @@
 //
 // Replaces IdentifyLocalMEM + BWT_Search + bwt_sa + SeedGrouping
 // (reference src/GSAlign.cpp:51-107,126-143; src/bwt_search.cpp:121-185).
+#include <cstring>
 #include "gsa_ctx.h"
 #include "gsa_fm.h"
 #include "gsa_scan.h"
@@ -567,6 +568,222 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 	if ((j & 63) == 0 && all_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK_ALL], (unsigned long long)all_blocks);
 }
 
+// ---------------------------------------------------------------------------
+// Sweep mode (round 3): next(s) for EVERY start of a chunk like k_dense_search, but not one search per start.  Two facts about
+// L(s), the length of the longest match from s (what BWT_Search computes; its interval = all occurrences of q[s .. s+L(s))):
+//   (1) L(s) <= L(s+1) + 1                    (q[s+1 .. s+L(s)) occurs)
+//   (2) if q[s+1 .. e) is the longest match from s+1 and q[s .. e) occurs, then L(s) = e - s      (by (1))
+// So a lane that owns SWEEP_SEG consecutive starts walks them RIGHT TO LEFT: one forward search from scratch for its last start
+// (presence table -> k-mer table -> Occ steps -> dense SA -> 64-base text windows, as above), then for every start to the left
+// it only asks "does the match extend by one base on the left?":
+//   * the match is unique (one occurrence, at text position t): it extends iff text[t-1] equals the query base, and stays
+//     unique -- 32 starts per comparison of packed words (M_BACK), no index access at all;
+//   * the match has several occurrences (a repeat): ONE backward extension of the bi-interval (x0, x1, x2) -- the index is
+//     symmetric (forward + reverse-complement text), so prepending base c is the forward step of the reference's BWT_Search
+//     (bwt_search.cpp:152-165) with x0 and x1 swapped and the complementary base (M_BFM): one Occ step per start where the
+//     reference and k_dense_search walk ~L(s) steps per start -- the `freq > MaxSeedFreq` reject-and-restart regime of
+//     bwt_search.cpp:177-182 costs O(L) per copy of a repeat instead of O(L^2);
+//   * it does not extend: L(s) < e - s, and the lane searches forward from s from scratch (exact by definition).
+// Nothing is speculated and no lane depends on another: next(s) is a pure function of s.  Same outputs as k_dense_search
+// (memo / lf / x0 per start), so k_dense_resolve and everything downstream are unchanged; a unique match found by text
+// comparison has no SA row at hand, so its x0 carries the text POSITION with bit 63 set (k_seed_select takes it as located).
+// ---------------------------------------------------------------------------
+#define SWEEP_POSFLAG (1ull << 63)
+enum { M_BFM = 7, M_BACK = 8, M_LOC2 = 9 };
+enum { HV_NONE = 0, HV_UNIQ = 1, HV_MULTI = 2 };
+template <bool E16>
+__global__ void __launch_bounds__(256) k_dense_sweep(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, const u32 *__restrict__ chunk_list,
+                                                      uint16_t *dn_memo, u32 *dn_lf, u64 *dn_x0, u64 *cnt, int seg, int wgs_per_chunk)
+{
+	// seg = starts per lane (256 seg starts per workgroup, wgs_per_chunk workgroups per chunk): long segments do the least work
+	// (one forward search per segment), short ones finish soonest -- the few chunks the speculative kernel hands over take short ones
+	__shared__ u32 qp[QP_WORDS], qn[QN_WORDS];
+	const u32 slot = blockIdx.x / (u32)wgs_per_chunk, part = blockIdx.x % (u32)wgs_per_chunk;
+	const u32 chunk = chunk_list ? chunk_list[slot] : slot;
+	const int j = threadIdx.x;
+	const i64 c0 = (i64)chunk * GSA_CHUNK;
+	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
+	for (int g = j; g < QN_WORDS; g += 256) {
+		u32 w0 = 0, w1 = 0, wn = 0;
+		const int p0 = g << 5;
+		if (p0 < clen) {
+			const uint8_t *src = q + c0 + p0;
+			uint8_t b[32];
+			if (p0 + 32 <= clen) { *(uint4 *)&b[0] = *(const uint4 *)src; *(uint4 *)&b[16] = *(const uint4 *)(src + 16); }
+			else { for (int t = 0; t < 32; t++) b[t] = p0 + t < clen ? src[t] : (uint8_t)'N'; }
+#pragma unroll
+			for (int t = 0; t < 32; t++) {
+				const u32 cd = (u32)gsa_nt4(b[t]);
+				if (t < 16) w0 |= (cd & 3) << (2 * t); else w1 |= (cd & 3) << (2 * (t - 16));
+				wn |= (cd > 3 ? 1u : 0u) << t;
+			}
+		} else wn = ~0u;
+		if (2 * g < QP_WORDS) qp[2 * g] = w0;
+		if (2 * g + 1 < QP_WORDS) qp[2 * g + 1] = w1;
+		qn[g] = wn;
+	}
+	__syncthreads();
+	uint16_t *memo = dn_memo + (size_t)slot * GSA_CHUNK; u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; u64 *x0o = dn_x0 + (size_t)slot * GSA_CHUNK;
+	const int seg_a = ((int)part * 256 + j) * seg;
+	int cur = (seg_a + seg < clen ? seg_a + seg : clen) - 1;      // next start to settle; the lane is through when cur < seg_a
+	int s = 0, pos = 0, mode = M_ADV, have = HV_NONE, e_end = 0, prole = 0; u32 kid = 0, pid = 0, blk = 0, all_blocks = 0;
+	u64 pqb = 0;
+	FmIntv ik = {0, 0, 0}; i64 tp = 0, tps = 0;
+	const int L = prm.MinSeedLength < 32 ? prm.MinSeedLength : 32;
+	const u32 Lmask = L == 32 ? ~0u : (1u << L) - 1;
+	// what is known about start S_ once its longest match [S_, S_ + LEN_) with X2_ occurrences is: the hop, the seed record
+#define SWEEP_SETTLE(S_, LEN_, X2_, X0_)                                                                                   \
+	{                                                                                                                   \
+		int d_ = 1; u32 rec_ = 0;                                                                                       \
+		if ((LEN_) >= prm.MinSeedLength && (X2_) <= (u64)GSA_MAX_SEED_FREQ) { d_ = prm.bSensitive ? 5 : (LEN_) + 1; rec_ = (u32)(LEN_) | ((u32)(X2_) << 16); x0o[S_] = (X0_); } \
+		memo[S_] = (uint16_t)d_; lf[S_] = rec_;                                                                         \
+	}
+	while (!__all(mode == M_DONE)) {
+		// ---- request phase: one pending request per lane, all lanes issue together ----
+		u64 kk = 0, ll = 0; bool kn = true, ln = true;
+		if (mode == M_FM || mode == M_BFM) {
+			const u64 xr = mode == M_FM ? ik.x1 : ik.x0;      // forward extension counts on the reverse-strand interval, backward extension on the forward one
+			const u64 k = xr - 1, l = xr - 1 + ik.x2;
+			kn = (k == (u64)-1); ln = (l == (u64)-1);
+			kk = kn ? 0 : k - (k >= di.primary); ll = ln ? 0 : l - (l >= di.primary);
+		}
+		const FmBlock bk = fm_load(di.bwt, kk >> 7), bl = fm_load(di.bwt, ll >> 7);
+		struct __attribute__((packed, aligned(4))) W5 { u32 a, b, c, d, e; };
+		// forward: 64 bases from tp on; backward (M_BACK): the three words that end with the base in front of the match
+		const i64 bw_word = ((tps - 1) >> 4) - 2 > 0 ? ((tps - 1) >> 4) - 2 : 0;
+		const W5 w5 = *(const W5 *)(di.ref2 + (mode == M_TEXT ? (tp >> 4) : (mode == M_BACK ? bw_word : 0)));
+		ulonglong2 e0 = {0, 0}, e1 = {0, 0};
+		if (E16) {
+			const uint4 e = ((const uint4 *)(di.kmer ? di.kmer : (const u64 *)di.bwt))[mode == M_KMER ? kid : 0];
+			e0.x = e.x; e0.y = e.y; e1.x = e.z; e1.y = e.w;
+		} else {
+			const ulonglong2 *pe = (const ulonglong2 *)((di.kmer ? di.kmer : (const u64 *)di.bwt) + (mode == M_KMER ? ((size_t)kid << 2) : 0));
+			e0 = pe[0]; e1 = pe[1];
+		}
+		ulonglong2 l0 = {0, 0}, l1 = {0, 0};
+		if (di.kmer_lo) {
+			if (E16) { const uint4 e = ((const uint4 *)di.kmer_lo)[mode == M_KLO ? kid : 0]; l0.x = e.x; l0.y = e.y; l1.x = e.z; l1.y = e.w; }
+			else { const ulonglong2 *pe = (const ulonglong2 *)(di.kmer_lo + (mode == M_KLO ? ((size_t)kid << 2) : 0)); l0 = pe[0]; l1 = pe[1]; }
+		}
+		// the line of the grouped presence table that answers for the start and up to three starts to its LEFT (pid = line, prole = role of s)
+		uint4 pl0 = {~0u, ~0u, ~0u, ~0u}, pl1 = {~0u, ~0u, ~0u, ~0u};
+		if (di.pres) { const uint4 *pp = (const uint4 *)di.pres + 2 * (size_t)(mode == M_KMER ? pid : 0); pl0 = pp[0]; pl1 = pp[1]; }
+		const u64 sav = fm_locate(di, (mode == M_LOC || mode == M_LOC2) ? ik.x0 : 1);
+		// ---- consume phase ----
+		bool ended = false;
+		if (mode == M_KMER) {
+			// role r of the line: dword 2 r + (e >> 5), bit e & 31, e = pres4_bit(pqb, K, r) & 63 -- all four answers as a mask
+			u32 pmask = 15u;
+			if (di.pres) {
+				const u32 e0_ = pres4_bit(pqb, di.pres_k, 0) & 63u, e1_ = pres4_bit(pqb, di.pres_k, 1) & 63u, e2_ = pres4_bit(pqb, di.pres_k, 2) & 63u, e3_ = pres4_bit(pqb, di.pres_k, 3) & 63u;
+				pmask = ((((e0_ & 32u) ? pl0.y : pl0.x) >> (e0_ & 31u)) & 1u) | (((((e1_ & 32u) ? pl0.w : pl0.z) >> (e1_ & 31u)) & 1u) << 1)
+				      | (((((e2_ & 32u) ? pl1.y : pl1.x) >> (e2_ & 31u)) & 1u) << 2) | (((((e3_ & 32u) ? pl1.w : pl1.z) >> (e3_ & 31u)) & 1u) << 3);
+			}
+			auto present = [&](int r) -> bool { return (pmask >> r) & 1u; };
+			if (!present(prole)) {
+				// the first MinSeedLength bases of s do not occur: no seed, nothing to extend; the same line answers for the starts to
+				// the left while they pass the N / length tests (their own hop is 1 as well when they do not)
+				memo[s] = 1; lf[s] = 0; cur = s - 1; have = HV_NONE; mode = M_ADV;
+				for (int r = prole - 1; r >= 0 && cur >= seg_a; r--) {
+					const u32 nb = q_nbits32(qn, cur);
+					if ((nb & 1u) || cur + prm.MinSeedLength > clen || (nb & Lmask) != 0) break;      // (the advance step settles those)
+					if (present(r)) break;                                                            // occurs: needs its own search
+					memo[cur] = 1; lf[cur] = 0; cur--;
+				}
+			} else {
+				const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k
+				if (hit) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; }
+				mode = M_FM;
+				if (hit && ik.x2 == 1) { tp = (i64)(e1.y - 1) + di.kmer_k; mode = M_TEXT; }
+				if (!hit && di.kmer_lo) { kid = kid & ((1u << (2 * di.kmer_lo_k)) - 1); mode = M_KLO; }
+			}
+		} else if (mode == M_KLO) {
+			const bool hit = l1.x != 0;
+			if (hit) { ik.x0 = l0.x; ik.x1 = l0.y; ik.x2 = l1.x; pos = s + di.kmer_lo_k; }
+			mode = M_FM;
+			if (hit && ik.x2 == 1) { tp = (i64)(l1.y - 1) + di.kmer_lo_k; mode = M_TEXT; }
+		} else if (mode == M_LOC) {
+			tp = (i64)sav + (pos - s); mode = M_TEXT;
+		} else if (mode == M_TEXT) {
+			int got = text_match32(w5.a, w5.b, w5.c, tp, (i64)di.seq_len, qp, qn, pos, clen);
+			if (got == 32) got += text_match32(w5.c, w5.d, w5.e, tp + 32, (i64)di.seq_len, qp, qn, pos + 32, clen);
+			pos += got; tp += got;
+			ended = got < 64;
+		} else if (mode == M_FM) {
+			const bool can = pos < clen && !q_isn(qn, pos < clen ? pos : 0);
+			const bool ok = can && fm_extend_loaded(di, ik, q_code(qp, pos < clen ? pos : 0), bk, bl, kk, ll, kn, ln, blk);
+			ended = !ok;
+			if (ok) { pos++; if (ik.x2 == 1) mode = M_LOC; }
+		} else if (mode == M_BFM) {
+			// prepend q[cur] to the match [cur + 1, e_end): the reference's forward step on the mirrored bi-interval with the complementary base
+			FmIntv m = { ik.x1, ik.x0, ik.x2 };
+			const bool ok = fm_extend_loaded(di, m, 3 - q_code(qp, cur), bk, bl, kk, ll, kn, ln, blk);
+			all_blocks += blk; blk = 0;
+			if (ok) {
+				ik.x0 = m.x1; ik.x1 = m.x0; ik.x2 = m.x2;
+				SWEEP_SETTLE(cur, e_end - cur, ik.x2, ik.x0)
+				cur--;
+				mode = ik.x2 == 1 ? M_LOC2 : M_ADV;       // one occurrence left: from here on the text itself answers
+			} else { have = HV_NONE; mode = M_ADV; }      // (L(cur) < e_end - cur: search forward from cur)
+		} else if (mode == M_LOC2) {
+			tps = (i64)sav; have = HV_UNIQ; mode = M_ADV;      // text position of start cur + 1
+		} else if (mode == M_BACK) {
+			// the match [cur + 1, e_end) sits once in the text, at tps: start cur - t extends it iff the t + 1 bases in front agree
+			int n = cur - seg_a + 1; if (n > 32) n = 32; if ((i64)n > tps) n = (int)tps;
+			int nbk = 0;
+			if (n > 0) {
+				const int off = (int)(tps - n - (bw_word << 4));                 // first compared text base inside the three words (0 .. 47)
+				const u64 lo64 = (u64)w5.a | ((u64)w5.b << 32), hi64 = (u64)w5.c;
+				const int sh = off * 2;
+				const u64 T = sh == 0 ? lo64 : (sh < 64 ? (lo64 >> sh) | (hi64 << (64 - sh)) : (hi64 >> (sh - 64)));
+				const u64 Q = q_bits64(qp, cur - n + 1);
+				const u64 msk = n == 32 ? ~0ull : ((1ull << (2 * n)) - 1);
+				const u64 d = (Q ^ T) & msk;
+				const u64 dm = (d | (d >> 1)) & 0x5555555555555555ull;
+				const u32 nm = q_nbits32(qn, cur - n + 1) & (n == 32 ? ~0u : ((1u << n) - 1));
+				const int im = dm ? (63 - __clzll((long long)dm)) >> 1 : -1, in_ = nm ? 31 - __clz((int)nm) : -1;
+				nbk = n - 1 - (im > in_ ? im : in_);
+			}
+			for (int t = 0; t < nbk; t++) { const int st = cur - t; SWEEP_SETTLE(st, e_end - st, 1ull, SWEEP_POSFLAG | (u64)(tps - 1 - t)) }
+			cur -= nbk; tps -= nbk;
+			if (nbk < n || n <= 0) have = HV_NONE;                                  // stopped by a mismatch, an N or the start of the text
+			mode = M_ADV;
+		}
+		if (ended) {
+			// the forward search from s is through: [s, pos) with ik.x2 occurrences (ik.x0 = first row)
+			const int len = pos - s;
+			SWEEP_SETTLE(s, len, ik.x2, ik.x0)
+			all_blocks += blk; blk = 0;
+			cur = s - 1; e_end = pos;
+			if (mode == M_TEXT) { have = HV_UNIQ; tps = tp - (i64)len; }            // (tp is the text position of pos)
+			else have = (len >= 1 && ik.x2 >= 1) ? HV_MULTI : HV_NONE;
+			mode = M_ADV;
+		}
+		// ---- what to do about start cur ----
+		for (int step = 0; step < 3 && mode == M_ADV; step++) {
+			if (cur < seg_a) { mode = M_DONE; break; }
+			const u32 nb = q_nbits32(qn, cur);
+			if (nb & 1u) { memo[cur] = 1; lf[cur] = 0; have = HV_NONE; cur--; continue; }      // ambiguous base: no search from here, nothing extends over it
+			if (have == HV_UNIQ) { mode = M_BACK; break; }
+			if (have == HV_MULTI) { mode = M_BFM; break; }
+			if (cur + prm.MinSeedLength > clen || (nb & Lmask) != 0) { memo[cur] = 1; lf[cur] = 0; cur--; continue; }      // MinSeedLength out of reach
+			s = cur; ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
+			if (di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
+				kid = (u32)(q_bits64(qp, s) & ((1ull << (2 * di.kmer_k)) - 1)); mode = M_KMER;
+				// presence: the group that starts three bases to the left (as far as the chunk goes), s in its last role
+				prole = s >= 3 ? 3 : s;
+				pqb = q_bits64(qp, s - prole);
+				pid = di.pres_k ? pres4_line(pqb, di.pres_k) : 0;
+			} else if (di.kmer_lo && s + di.kmer_lo_k <= clen && (nb & ((1u << di.kmer_lo_k) - 1)) == 0) {
+				kid = (u32)(q_bits64(qp, s) & ((1ull << (2 * di.kmer_lo_k)) - 1)); mode = M_KLO;
+			}
+		}
+	}
+#undef SWEEP_SETTLE
+	for (int o = 32; o; o >>= 1) all_blocks += __shfl_down(all_blocks, o);
+	if ((j & 63) == 0 && all_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK_ALL], (unsigned long long)all_blocks);
+}
+
 // The chain of a dense chunk: orbit of 0 under p -> p + memo[p], marked by pointer doubling (jump_k = next^(2^k); the
 // marked set doubles per round), then the accepted on-chain matches go to the chunk's candidate segment in the layout
 // k_seed_wg leaves (so everything downstream is the same).
@@ -688,7 +905,7 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 			while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_offs[mid] <= t) lo = mid; else hi = mid; }
 			i = lo; h = t - s_offs[i];
 			s = cand_s[cbase + i] + s_off; f = (u32)cand_freq[cbase + i]; len = (u32)cand_len[cbase + i]; x0 = cand_x0[cbase + i];
-			r = fm_locate(di, x0 + h);
+			r = (x0 >> 63) ? (x0 & ~(1ull << 63)) : fm_locate(di, x0 + h);      // (bit 63: a unique match whose text position the sweep already knows)
 		}
 		s_r[j] = r;
 		__syncthreads();
@@ -977,7 +1194,17 @@ int stage1_seed(gsa_ctx *c)
 	u64 *cnt = c->d_cnt.as<u64>();
 	// Dense mode (one search per start position, k_dense_search): every chunk under -sen, otherwise only the chunks the
 	// speculative kernel gives up on.  The accounting build walks everything the reference's way and takes neither path.
-	const bool dense_all = c->prm.bSensitive && !c->count_blocks;
+	// GSA_SEED_MODE: "spec" (default) = the speculative kernel, and the right-to-left sweep (k_dense_sweep) for the chunks it gives up
+	// on and for every chunk under -sen; "sweep" = every chunk through the sweep; "search" = round 2's dense kernel (one search per
+	// start) in place of the sweep
+	static const int seed_mode = [] { const char *e = getenv("GSA_SEED_MODE"); return !e ? 1 : (!strcmp(e, "sweep") ? 0 : (!strcmp(e, "search") ? 2 : 1)); }();
+	// Which kernel for what (measured, profiles/r03_seed_modes.txt): the speculative kernel wins where matches are unique (the bench
+	// workload: 4.4 ms per 250 Mb against 19 for the sweep over every chunk); the sweep wins where repeats with thousands of copies make
+	// most chunks exceed the speculative budget (adversarial 250 Mb: 31 ms against 62 for round 2's path); one search per start wins
+	// under -sen (4.2 against 16 ms per 12 Mb: matches are short, a lane's chain of 40 starts is the longer road) and for a handful
+	// of handed-over chunks.  A contig whose predecessor handed more than 40 % of its chunks over skips the speculative attempt.
+	const bool sweep_all = !c->prm.bSensitive && !c->count_blocks && (seed_mode == 0 || (seed_mode == 1 && c->seed_sweep_next));
+	const bool dense_all = (c->prm.bSensitive || sweep_all) && !c->count_blocks;
 	const u32 budget = c->count_blocks ? 0u : c->seed_budget;
 	if (dense_all && ccap < GSA_CHUNK / 5 + 64) { ccap = GSA_CHUNK / 5 + 64; c->cand_cap_per_chunk = ccap; }      // one accepted start in five at most
 	u64 occ_all = 0;
@@ -1011,7 +1238,16 @@ int stage1_seed(gsa_ctx *c)
 			if (!dev_ensure<uint16_t>(c, c->dn_memo, nd) || !dev_ensure<u32>(c, c->dn_lf, nd) || !dev_ensure<u64>(c, c->dn_x0, nd)) return GSA_ERR_NOMEM;
 			const u32 *list = dense_all ? (const u32 *)nullptr : c->d_heavy.as<u32>();
 #define GSA_DENSE_ARGS(SPAN) dim3((unsigned)(n_heavy * DENSE_WGS(SPAN))), dim3(DENSE_TPB), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt
-			if (dense_all) { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 512>), GSA_DENSE_ARGS(512)); else hipLaunchKernelGGL((k_dense_search<false, 512>), GSA_DENSE_ARGS(512)); }
+			const bool use_sweep = seed_mode != 2 && !c->prm.bSensitive && (sweep_all || n_heavy >= 1024);
+			if (!dense_all && seed_mode == 1) c->seed_sweep_next = n_heavy * 5 > (u64)n_chunks * 2;      // (re-decided by every contig that goes through the speculative kernel)
+			else if (sweep_all && seed_mode == 1 && ++c->seed_sweep_run >= 8) { c->seed_sweep_next = false; c->seed_sweep_run = 0; }      // look again now and then
+			if (use_sweep) {
+				static const int seg_env = [] { const char *e = getenv("GSA_SWEEP_SEG"); return e ? atoi(e) : 0; }();
+				const int seg = seg_env > 0 ? seg_env : 40, wpc = (GSA_CHUNK + 256 * seg - 1) / (256 * seg);
+				if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_sweep<true>), dim3((unsigned)(n_heavy * wpc)), dim3(256), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
+				else hipLaunchKernelGGL((k_dense_sweep<false>), dim3((unsigned)(n_heavy * wpc)), dim3(256), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
+			}
+			else if (dense_all) { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 512>), GSA_DENSE_ARGS(512)); else hipLaunchKernelGGL((k_dense_search<false, 512>), GSA_DENSE_ARGS(512)); }
 			else { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 256>), GSA_DENSE_ARGS(256)); else hipLaunchKernelGGL((k_dense_search<false, 256>), GSA_DENSE_ARGS(256)); }
 #undef GSA_DENSE_ARGS
 			hipLaunchKernelGGL(k_dense_resolve, dim3((unsigned)n_heavy), dim3(256), 0, st, list, (u32)n_chunks, qlen, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt,

@@ -34,6 +34,40 @@ def test_index_builder_64bit_suffix_sorter(golden_dir, tmp_path, name, monkeypat
         assert filecmp.cmp(f"{px}.{ext}", os.path.join(golden_dir, f"{name}.{ext}"), shallow=False), f"{name}.{ext} differs from the reference's"
 
 
+@pytest.mark.parametrize("name,wide", [("cx", False), ("small", False), ("cx", True)])
+def test_index_builder_parallel_suffix_sorter(golden_dir, tmp_path, name, wide, monkeypatch):
+    """Round 3: references above 1 M suffixes are sorted on all host cores (bucket by 8 bases, 64-bit keys, packed-text compares:
+    index_io.cpp, parallel_suffix_sort) so that a 3.1 Gbp reference builds in minutes; GSA_INDEX_PAR_MIN sends the fixtures
+    through it (32- and 64-bit instance), four threads.  Same bytes as the reference's bwt_index (bwtindex.c:77-149)."""
+    monkeypatch.setenv("GSA_INDEX_PAR_MIN", "1000"); monkeypatch.setenv("GSA_INDEX_THREADS", "4")
+    if wide:
+        monkeypatch.setenv("GSA_INDEX_64BIT", "1")
+    px = str(tmp_path / name)
+    hostlib.build_index(os.path.join(golden_dir, f"{name}.ref.fa"), px)
+    for ext in ("pac", "ann", "amb", "bwt", "sa"):
+        assert filecmp.cmp(f"{px}.{ext}", os.path.join(golden_dir, f"{name}.{ext}"), shallow=False), f"{name}.{ext} differs from the reference's"
+
+
+def test_index_builder_parallel_vs_reference_builder_on_repeats(oracle_built, tmp_path, monkeypatch):
+    """The parallel sorter where its comparisons run deep: adversarial repeats (thousands of 1 %-divergent copies, a tandem array,
+    microsatellites, N runs packed as random bases) in two contigs, 6 Mb -- against the reference's own bwt_index run here, and
+    against our serial SA-IS builder."""
+    from gsalign_amd import synth
+    if not oracle_built.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    refs, _ = synth.make_adversarial_pair(6_000_000, 2, 0.0, seed=17, n_run=200_000)
+    synth.inject_repeats(refs[1][1], 5, frac=0.05)                       # + the 150-copy tandem array
+    fa = str(tmp_path / "r.fa"); synth.write_fasta(fa, refs)
+    monkeypatch.setenv("GSA_INDEX_THREADS", "8")
+    hostlib.build_index(fa, str(tmp_path / "par"))
+    monkeypatch.setenv("GSA_INDEX_THREADS", "1")
+    hostlib.build_index(fa, str(tmp_path / "ser"))
+    oracle_built.ref_build_index(fa, str(tmp_path / "ref"))
+    for ext in ("pac", "ann", "amb", "bwt", "sa"):
+        assert filecmp.cmp(str(tmp_path / f"par.{ext}"), str(tmp_path / f"ref.{ext}"), shallow=False), ext
+        assert filecmp.cmp(str(tmp_path / f"ser.{ext}"), str(tmp_path / f"ref.{ext}"), shallow=False), ext
+
+
 @pytest.mark.parametrize("name,params,maf,vcf", [
     ("cx", {}, "cx.maf", "cx.vcf"), ("cx", dict(sen=1, clr=50), "cx_sen.maf", "cx_sen.vcf"), ("small", {}, "small.maf", "small.vcf"),
     # flag variants of the reference CLI (tests/golden/make_golden.py --cli-variants): -unique, -fmt 2, -one, -idy 95, a combination, -sen -fmt 2

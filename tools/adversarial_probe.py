@@ -10,12 +10,17 @@ import numpy as np
 from gsalign_amd import synth, hostlib, indexio, capi
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 250_000_000
-tmp = tempfile.mkdtemp(prefix="advprobe_")
-for kind in ("repeat-stress (bench workload)", "adversarial"):
+tmp = os.environ.get("GSA_PROBE_KEEP") or tempfile.mkdtemp(prefix="advprobe_")
+os.makedirs(tmp, exist_ok=True)
+kinds = [k for k in ("repeat-stress (bench workload)", "adversarial") if len(sys.argv) < 3 or k[:6] in sys.argv[2]]
+for kind in kinds:
     r = synth.fast_genome(n, 11000)
     copies = synth.inject_repeats(r, 11000) if kind.startswith("repeat") else synth.inject_adversarial(r, 11000)
-    px = os.path.join(tmp, kind[:6])
-    synth.write_fasta(px + ".fa", [("chr1", r)]); t = time.time(); hostlib.build_index(px + ".fa", px); tb = time.time() - t
+    px = os.path.join(tmp, f"{kind[:6]}_{n}")
+    t = time.time()
+    if not os.path.exists(px + ".done"):
+        synth.write_fasta(px + ".fa", [("chr1", r)]); hostlib.build_index(px + ".fa", px); open(px + ".done", "w").close()
+    tb = time.time() - t
     idx = indexio.load_index(px)
     qs = [synth.fast_mutate(r, 0.01, 7000 + k) for k in range(2)]
     g = capi.Aligner(idx); g2 = g.clone()
