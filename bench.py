@@ -42,6 +42,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 YEAST_KB = [230, 813, 317, 1532, 577, 270, 1091, 563, 440, 746, 667, 1078, 924, 784, 1091, 948]      # S288C chromosomes I..XVI
 
+GRCH38_MB = [248, 242, 198, 190, 181, 170, 159, 145, 138, 133, 135, 133, 114, 107, 101, 90, 83, 80, 58, 64, 46, 50, 156, 57]      # chr1..22, X, Y
+
 WORKLOADS = {
     # name: genome length(s), divergence, repeat injection, aligner parameters, distinct query genomes
     "human": dict(lengths=[250_000_000], div=0.01, repeats=True, params={}, n_query=4, inflight=2,
@@ -50,6 +52,10 @@ WORKLOADS = {
                   label="E. coli-sized pair (BASELINE configs[1] stand-in): 5 Mb reference vs 2 %-diverged query, default -slen 15 -ind 25"),
     "yeast": dict(lengths=[1000 * k for k in YEAST_KB], div=0.02, repeats=False, params=dict(sen=1, clr=50), n_query=2, inflight=2,
                   label="S. cerevisiae-sized pair (BASELINE configs[2]): 16 contigs / 12 Mb vs 2 %-diverged copy, -sen"),
+    # BASELINE configs[4] on ONE GPU: the whole job of the 8-GPU configuration (the index is replicated per GPU there, so one GPU
+    # holds exactly this index).  6.2 G BWT rows: the >= 2^32-row device layout and the 64-bit suffix sorter on their real input.
+    "human_full": dict(lengths=[1_000_000 * m for m in GRCH38_MB], div=0.01, repeats=True, params=dict(alen=5000), n_query=2, inflight=2,
+                       label="full-human-sized pair (BASELINE configs[4] on one GPU): 24 contigs with GRCh38 chromosome lengths, 3.08 Gbp, repeat injection, vs 1 %-diverged copy, -alen 5000"),
 }
 
 
@@ -283,6 +289,16 @@ def summarise(name, wl, m, t_max, total_bp, world, args):
     }
 
 
+def host_mem_gb():
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemTotal"):
+                return int(ln.split()[1]) / 1e6
+    except Exception:      # noqa: BLE001
+        pass
+    return 0.0
+
+
 def physical_cores():
     """Physical cores of this host (logical CPUs / SMT siblings per core); the reference's -t."""
     n = os.cpu_count() or 1
@@ -377,7 +393,7 @@ def main():
     ap.add_argument("--genome", type=int, default=0, help="override the reference length of a one-contig workload")
     ap.add_argument("--divergence", type=float, default=-1.0)
     ap.add_argument("--inflight", type=int, default=0, help="contexts (host threads) per GPU working on different contigs (0 = the workload's own: 2, 3 for the 5 Mb one)")
-    ap.add_argument("--extra", default="ecoli,yeast", help="further workloads measured in the same run (short loops); '' = none")
+    ap.add_argument("--extra", default="ecoli,yeast,human_full", help="further workloads measured in the same run (short loops); '' = none; human_full (3.08 Gbp, ~3 min incl. its index) is skipped on hosts below 256 GB of memory")
     ap.add_argument("--hwq", type=int, default=8, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default of 4; the contexts in flight have 4 streams each)")
     ap.add_argument("--split", action="store_true", help="N > 1 only: ONE contig per step, its seed search sharded by chunk range over the ranks (strong scaling)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo: plumbing checks)")
@@ -466,7 +482,10 @@ def main():
         # process the second workload runs 10-25 % slower whatever the order (measured both ways); N = 1 only
         extras = []
         for name in [x for x in args.extra.split(",") if x and x != args.workload and world == 1]:
-            st = 200 if name == "ecoli" else 12
+            if name == "human_full" and host_mem_gb() < 256:
+                extras.append({"workload": name, "value": None, "error": f"skipped: host has {host_mem_gb():.0f} GB of memory, the 3.08 Gbp index build needs ~120"})
+                continue
+            st = 200 if name == "ecoli" else (3 if name == "human_full" else 12)
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(st), "--warmup", str(max(2, st // 5)), "--extra", "", "--no-cpu-baseline", "--hwq", str(args.hwq)]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GSA_BENCH_TMP=tmp, GSA_BENCH_KEEP="1"))

@@ -161,85 +161,115 @@ __device__ i32 write_dp_record_wg(i64 i, i32 L, const uint8_t *__restrict__ op, 
 	return total;
 }
 
-// Gapped strings and the records' (aln_len, score) contributions.  256 records per workgroup: a thread
-// settles its own record when it is a seed or a short gap (the bulk: median gap 11 bases); longer gaps
-// are queued in LDS and written by whole wavefronts.
+// Gapped strings and the per-block sums of the records' (aln_len, score) contributions.  MAT_WGS workgroups, each over one
+// contiguous range of the records in tiles of 256: a thread settles its own record when it is a seed or a short gap (the bulk:
+// median gap 11 bases); longer gaps are queued in LDS and written by whole wavefronts.  The sums stay in registers while the
+// tiles lie in one block and are added with one atomic pair when the block changes (a contig has a handful of blocks); a tile
+// that straddles a block edge adds per record.  (Round 2 stored the contributions per record and summed them in a second
+// kernel, k_block_reduce: 8 bytes written and read per record and 0.8 ms on the tail of every human-sized contig.)
 #define MAT_SERIAL 32
-__global__ void __launch_bounds__(256) k_materialize(const i32 *__restrict__ nf_ptr, const i32 *__restrict__ ftype, const i32 *__restrict__ fmism, const i32 *__restrict__ fjob,
+#define MAT_WGS 2048
+__global__ void __launch_bounds__(256) k_materialize(i32 nfb, const i32 *__restrict__ nf_ptr, const i32 *__restrict__ fragbase, const i32 *__restrict__ ftype, const i32 *__restrict__ fmism, const i32 *__restrict__ fjob,
                                                       const i32 *__restrict__ jlarge, const i32 *__restrict__ nops, const i32 *__restrict__ alen, const i64 *__restrict__ aoff, const uint8_t *__restrict__ ops,
                                                       const i64 *__restrict__ opsoff, const uint8_t *__restrict__ query, const uint8_t *__restrict__ ref,
-                                                      gsa_frag *frag, uint8_t *aln1, uint8_t *aln2, i32 *c_len, i32 *c_score)
+                                                      gsa_frag *frag, uint8_t *aln1, uint8_t *aln2, i32 *bl_len, i32 *bl_score)
 {
 	__shared__ i32 s_list[256];
 	__shared__ int s_n;
+	__shared__ i32 s_len[4], s_sc[4];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const i64 nf = nf_ptr[0];
-	if (tid == 0) s_n = 0;
-	__syncthreads();
-	{
-		const i64 i = (i64)blockIdx.x * 256 + tid;
-		if (i < nf) {
-			const i32 t = ftype[i];
-			const i32 fj = fjob[i];
-			const i32 Lr = t == FT_DP ? ((fj < 0 || jlarge[fj]) ? -1 : nops[fj]) : alen[i];       // -1: a large DP job, written after the striped kernel
-			if (t == FT_SEED) { const i32 l = frag[i].qlen; c_len[i] = l; c_score[i] = l; }
-			else if (Lr < 0) { c_len[i] = 0; c_score[i] = 0; }
-			else if (Lr > MAT_SERIAL) s_list[atomicAdd(&s_n, 1)] = tid;
-			else {
-				const gsa_frag f = frag[i];
-				const i64 o = aoff[i]; const i32 L = Lr;
-				const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos;
-				i32 score = 0;
-				if (t == FT_DEL) { for (i32 p = 0; p < L; p++) { aln1[o + p] = rs[p]; aln2[o + p] = '-'; } }
-				else if (t == FT_INS) { for (i32 p = 0; p < L; p++) { aln1[o + p] = '-'; aln2[o + p] = qs[p]; } }
-				else if (t == FT_EQ) { for (i32 p = 0; p < L; p++) { aln1[o + p] = rs[p]; aln2[o + p] = qs[p]; } score = f.qlen - fmism[i]; }
+	const i64 tiles = (nf + 255) / 256, per = (tiles + gridDim.x - 1) / gridDim.x;
+	const i64 t_beg = (i64)blockIdx.x * per, t_end = t_beg + per < tiles ? t_beg + per : tiles;
+	i32 cur = -1, l_acc = 0, sc_acc = 0;             // the block the running sums belong to (uniform); per-thread partial sums
+	auto flush = [&]() {
+		if (cur < 0) return;
+		for (int o = 32; o; o >>= 1) { l_acc += __shfl_xor(l_acc, o); sc_acc += __shfl_xor(sc_acc, o); }
+		if (lane == 0) { s_len[wv] = l_acc; s_sc[wv] = sc_acc; }
+		__syncthreads();
+		if (tid == 0) { const i32 a = s_len[0] + s_len[1] + s_len[2] + s_len[3], b = s_sc[0] + s_sc[1] + s_sc[2] + s_sc[3]; if (a) atomicAdd(&bl_len[cur], a); if (b) atomicAdd(&bl_score[cur], b); }
+		__syncthreads();
+		l_acc = 0; sc_acc = 0;
+	};
+	for (i64 tile = t_beg; tile < t_end; tile++) {
+		const i64 w0 = tile * 256, w1 = w0 + 256 < nf ? w0 + 256 : nf;
+		const i32 kf = find_block(fragbase, nfb, w0), kl = find_block(fragbase, nfb, w1 - 1);
+		const bool straddle = kf != kl;
+		if (!straddle && kf != cur) { flush(); cur = kf; }
+		// a record's contribution: into the running sums, or -- on a tile with a block edge inside -- straight to its block
+		auto add = [&](i64 i, i32 L, i32 score) {
+			if (!straddle) { l_acc += L; sc_acc += score; }
+			else { const i32 b = find_block(fragbase, nfb, i); if (L) atomicAdd(&bl_len[b], L); if (score) atomicAdd(&bl_score[b], score); }
+		};
+		if (tid == 0) s_n = 0;
+		__syncthreads();
+		{
+			const i64 i = w0 + tid;
+			if (i < nf) {
+				const i32 t = ftype[i];
+				const i32 fj = fjob[i];
+				const i32 Lr = t == FT_DP ? ((fj < 0 || jlarge[fj]) ? -1 : nops[fj]) : alen[i];       // -1: a large DP job, written after the striped kernel
+				if (t == FT_SEED) { const i32 l = frag[i].qlen; add(i, l, l); }
+				else if (Lr < 0) { }
+				else if (Lr > MAT_SERIAL) s_list[atomicAdd(&s_n, 1)] = tid;
 				else {
-					// ops are forward M/D/I; 'D' puts '-' into aln1, 'I' into aln2 (ksw2_alignment.cpp:264-272)
-					const uint8_t *op = ops + opsoff[fjob[i]];
-					i32 i1 = 0, i2 = 0;
-					for (i32 p = 0; p < L; p++) {
-						const uint8_t ch = op[p];
-						const uint8_t a1 = (ch == 'M' || ch == 'I') ? rs[i1++] : (uint8_t)'-', a2 = (ch == 'M' || ch == 'D') ? qs[i2++] : (uint8_t)'-';
-						aln1[o + p] = a1; aln2[o + p] = a2;
-						score += (gsa_nt4(a1) == gsa_nt4(a2));             // CountIdenticalPairs (:38-47)
+					const gsa_frag f = frag[i];
+					const i64 o = aoff[i]; const i32 L = Lr;
+					const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos;
+					i32 score = 0;
+					if (t == FT_DEL) { for (i32 p = 0; p < L; p++) { aln1[o + p] = rs[p]; aln2[o + p] = '-'; } }
+					else if (t == FT_INS) { for (i32 p = 0; p < L; p++) { aln1[o + p] = '-'; aln2[o + p] = qs[p]; } }
+					else if (t == FT_EQ) { for (i32 p = 0; p < L; p++) { aln1[o + p] = rs[p]; aln2[o + p] = qs[p]; } score = f.qlen - fmism[i]; }
+					else {
+						// ops are forward M/D/I; 'D' puts '-' into aln1, 'I' into aln2 (ksw2_alignment.cpp:264-272)
+						const uint8_t *op = ops + opsoff[fjob[i]];
+						i32 i1 = 0, i2 = 0;
+						for (i32 p = 0; p < L; p++) {
+							const uint8_t ch = op[p];
+							const uint8_t a1 = (ch == 'M' || ch == 'I') ? rs[i1++] : (uint8_t)'-', a2 = (ch == 'M' || ch == 'D') ? qs[i2++] : (uint8_t)'-';
+							aln1[o + p] = a1; aln2[o + p] = a2;
+							score += (gsa_nt4(a1) == gsa_nt4(a2));             // CountIdenticalPairs (:38-47)
+						}
 					}
+					add(i, L, score);
 				}
-				c_len[i] = L; c_score[i] = score;
 			}
 		}
-	}
-	__syncthreads();
-	const int nlist = s_n;
-	for (int g = wv; g < nlist; g += 4) {
-		const i64 i = (i64)blockIdx.x * 256 + s_list[g];
-		const i32 t = ftype[i];
-		const gsa_frag f = frag[i];
-		const i64 o = aoff[i]; const i32 L = t == FT_DP ? nops[fjob[i]] : alen[i];
-		const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos;
-		i32 score = 0;
-		if (t == FT_DEL) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = rs[p]; aln2[o + p] = '-'; } }
-		else if (t == FT_INS) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = '-'; aln2[o + p] = qs[p]; } }
-		else if (t == FT_EQ) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = rs[p]; aln2[o + p] = qs[p]; } score = f.qlen - fmism[i]; }
-		else {
-			const uint8_t *op = ops + opsoff[fjob[i]];
-			i32 i1 = 0, i2 = 0;                      // consumed bases of the reference / query fragment so far
-			for (i32 base = 0; base < L; base += 64) {
-				const i32 p = base + lane;
-				const uint8_t ch = p < L ? op[p] : 0;
-				const int c1 = (ch == 'M' || ch == 'I') ? 1 : 0, c2 = (ch == 'M' || ch == 'D') ? 1 : 0;
-				int s1 = c1, s2 = c2;                 // inclusive wave prefix sums
-				for (int d = 1; d < 64; d <<= 1) { int a = __shfl_up(s1, d), b = __shfl_up(s2, d); if (lane >= d) { s1 += a; s2 += b; } }
-				if (p < L) {
-					const uint8_t a1 = c1 ? rs[i1 + s1 - 1] : '-', a2 = c2 ? qs[i2 + s2 - 1] : '-';
-					aln1[o + p] = a1; aln2[o + p] = a2;
-					score += (gsa_nt4(a1) == gsa_nt4(a2));
+		__syncthreads();
+		const int nlist = s_n;
+		for (int g = wv; g < nlist; g += 4) {
+			const i64 i = w0 + s_list[g];
+			const i32 t = ftype[i];
+			const gsa_frag f = frag[i];
+			const i64 o = aoff[i]; const i32 L = t == FT_DP ? nops[fjob[i]] : alen[i];
+			const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos;
+			i32 score = 0;
+			if (t == FT_DEL) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = rs[p]; aln2[o + p] = '-'; } }
+			else if (t == FT_INS) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = '-'; aln2[o + p] = qs[p]; } }
+			else if (t == FT_EQ) { for (i32 p = lane; p < L; p += 64) { aln1[o + p] = rs[p]; aln2[o + p] = qs[p]; } score = f.qlen - fmism[i]; }
+			else {
+				const uint8_t *op = ops + opsoff[fjob[i]];
+				i32 i1 = 0, i2 = 0;                      // consumed bases of the reference / query fragment so far
+				for (i32 base = 0; base < L; base += 64) {
+					const i32 p = base + lane;
+					const uint8_t ch = p < L ? op[p] : 0;
+					const int c1 = (ch == 'M' || ch == 'I') ? 1 : 0, c2 = (ch == 'M' || ch == 'D') ? 1 : 0;
+					int s1 = c1, s2 = c2;                 // inclusive wave prefix sums
+					for (int d = 1; d < 64; d <<= 1) { int a = __shfl_up(s1, d), b = __shfl_up(s2, d); if (lane >= d) { s1 += a; s2 += b; } }
+					if (p < L) {
+						const uint8_t a1 = c1 ? rs[i1 + s1 - 1] : '-', a2 = c2 ? qs[i2 + s2 - 1] : '-';
+						aln1[o + p] = a1; aln2[o + p] = a2;
+						score += (gsa_nt4(a1) == gsa_nt4(a2));
+					}
+					i1 += __shfl(s1, 63); i2 += __shfl(s2, 63);
 				}
-				i1 += __shfl(s1, 63); i2 += __shfl(s2, 63);
+				for (int d = 32; d; d >>= 1) score += __shfl_xor(score, d);
 			}
-			for (int d = 32; d; d >>= 1) score += __shfl_xor(score, d);
+			if (lane == 0) add(i, L, score);
 		}
-		if (lane == 0) { c_len[i] = L; c_score[i] = score; }
+		__syncthreads();      // (s_list / s_n are reused by the next tile)
 	}
+	flush();
 }
 
 // The records of the large DP jobs, after the striped kernel: one workgroup per job; (record, aln_len,
@@ -262,48 +292,6 @@ __global__ void __launch_bounds__(256) k_materialize_large(i32 nlarge, const i32
 	const i32 L = nops[job];
 	const i32 sc = write_dp_record_wg(i, L, ops + opsoff[job], aoff, query, ref, frag, aln1, aln2, s_w1, s_w2, &s_sc);
 	if (threadIdx.x == 0) { patch[3 * g] = (i32)i; patch[3 * g + 1] = L; patch[3 * g + 2] = sc; }
-}
-
-// Per-block sums of the records' (aln_len, score) contributions.  BR_WGS workgroups, each over one contiguous range of the
-// records in tiles of 1 024: while the tiles lie in one block the workgroup keeps the sums in registers and adds them with one
-// atomic pair when the block changes (a contig has a handful of blocks: one atomic per tile made 4 000 workgroups queue
-// on two addresses, 0.7 ms); the few tiles that straddle a block edge add per record.
-// (Was a two-component look-back scan over all records + a difference kernel: at 4 M records the scan's tile chain took 1 ms.)
-#define BR_PER 4
-#define BR_WGS 512
-__global__ void __launch_bounds__(256) k_block_reduce(i32 nfb, const i32 *__restrict__ nf_ptr, const i32 *__restrict__ fragbase, const i32 *__restrict__ c_len, const i32 *__restrict__ c_score,
-                                                       i32 *bl_len, i32 *bl_score)
-{
-	__shared__ i32 s_len[4], s_sc[4];
-	const i64 nf = nf_ptr[0];
-	const i64 tiles = (nf + 256 * BR_PER - 1) / (256 * BR_PER), per = (tiles + gridDim.x - 1) / gridDim.x;
-	const i64 t_beg = (i64)blockIdx.x * per, t_end = t_beg + per < tiles ? t_beg + per : tiles;
-	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	i32 cur = -1, l = 0, sc = 0;                 // the block the running sums belong to (uniform); per-thread partial sums
-	auto flush = [&]() {
-		if (cur < 0) return;
-		for (int o = 32; o; o >>= 1) { l += __shfl_xor(l, o); sc += __shfl_xor(sc, o); }
-		if (lane == 0) { s_len[wv] = l; s_sc[wv] = sc; }
-		__syncthreads();
-		if (tid == 0) { atomicAdd(&bl_len[cur], s_len[0] + s_len[1] + s_len[2] + s_len[3]); atomicAdd(&bl_score[cur], s_sc[0] + s_sc[1] + s_sc[2] + s_sc[3]); }
-		__syncthreads();
-		l = 0; sc = 0;
-	};
-	for (i64 t = t_beg; t < t_end; t++) {
-		const i64 w0 = t * 256 * BR_PER, w1 = w0 + 256 * BR_PER < nf ? w0 + 256 * BR_PER : nf;
-		const i32 kf = find_block(fragbase, nfb, w0), kl = find_block(fragbase, nfb, w1 - 1);
-		if (kf == kl) {
-			if (kf != cur) { flush(); cur = kf; }
-#pragma unroll
-			for (int k = 0; k < BR_PER; k++) { const i64 i = w0 + (i64)k * 256 + tid; if (i < w1) { l += c_len[i]; sc += c_score[i]; } }
-		} else {
-			for (int k = 0; k < BR_PER; k++) {
-				const i64 i = w0 + (i64)k * 256 + tid;
-				if (i < w1) { const i32 b = find_block(fragbase, nfb, i); const i32 l1 = c_len[i], s1 = c_score[i]; if (l1) atomicAdd(&bl_len[b], l1); if (s1) atomicAdd(&bl_score[b], s1); }
-			}
-		}
-	}
-	flush();
 }
 
 i64 frags_count(gsa_ctx *c)
@@ -385,7 +373,6 @@ int stage78_extend(gsa_ctx *c)
 	if (!pin_ensure<gsa_rec>(c, c->p_frags, (size_t)nfu + 1)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipEventRecord(c->ev[19], st)); GSA_CHECK(c, hipStreamWaitEvent(sc, c->ev[19], 0));
 	ENS(uint8_t, d_ops, c->span_ub + 64);
-	ENS(i32, d_flag, nfu + 2);
 	i32 *d_blen = c->bl_alnlen.as<i32>(), *d_bscore = d_blen + nfb, *d_fragbase = d_blen + 2 * (size_t)nfb;      // (one buffer since stage 7: one copy home)
 	Ksw2Launch kl;
 	RC(run_ksw2_jobs(c, (i32)nju, c->di.ref, off1, len1, c->q_dev, off2, len2, c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->j_nops.as<i32>(), c->span_ub, &kl,
@@ -421,19 +408,17 @@ int stage78_extend(gsa_ctx *c)
 	// written straight into the pinned copy later, so nothing is left to copy behind the striped kernel
 	const bool pools_early = npatch > 0 && c->n_aln > 0;
 	const i32 *jlarge = c->d_dp_large.as<i32>() + 3 * ((size_t)nju + 1);
-	i32 *c_len = c->d_flag.as<i32>(), *c_score = c->f_score.as<i32>();
-	hipLaunchKernelGGL(k_materialize, dim3((unsigned)((nfu + 255) / 256)), dim3(256), 0, sx, mail + M_NF, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(),
-	                   jlarge, c->j_nops.as<i32>(), c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->q_dev, c->di.ref,
-	                   c->f_rec.as<gsa_frag>(), d_aln1, d_aln2, c_len, c_score);
+	{ const i64 tiles_ub = (nfu + 255) / 256;
+	  hipLaunchKernelGGL(k_materialize, dim3((unsigned)(tiles_ub < MAT_WGS ? tiles_ub : MAT_WGS)), dim3(256), 0, sx, nfb, mail + M_NF, d_fragbase, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(),
+	                     jlarge, c->j_nops.as<i32>(), c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->q_dev, c->di.ref,
+	                     c->f_rec.as<gsa_frag>(), d_aln1, d_aln2, d_blen, d_bscore); }
 	GSA_CHECK(c, hipEventRecord(c->ev[17], sx));      // the strings of everything but the large jobs are written
 	if (pools_early) {
 		GSA_CHECK(c, hipStreamWaitEvent(sc, c->ev[17], 0));
 		GSA_CHECK(c, hipMemcpyAsync((char *)c->p_tail.p + t_aln1, d_aln1, t_total - t_aln1, hipMemcpyDeviceToHost, sc));
 		GSA_CHECK(c, hipEventRecord(c->ev[23], sc));
 	}
-	// per-block sums (the large jobs' records count as zero here, the host adds them from the patch list)
-	{ const i64 tiles_ub = (nfu + 256 * BR_PER - 1) / (256 * BR_PER);
-	  hipLaunchKernelGGL(k_block_reduce, dim3((unsigned)(tiles_ub < BR_WGS ? tiles_ub : BR_WGS)), dim3(256), 0, sx, nfb, mail + M_NF, d_fragbase, c_len, c_score, d_blen, d_bscore); }
+	// (per-block sums: left by k_materialize itself; the large jobs' records count as zero there, the host adds them from the patch list)
 	if (c->profiling) dp_count_cells(c, (i32)nju, len1, len2, sx);      // (measurement: sum of m*n and m+n over the jobs, read with the final mailbox)
 	i32 *h_len = c->p_blk.as<i32>(), *h_score = h_len + nfb, *h_fragbase = h_score + nfb;
 	GSA_CHECK(c, hipMemcpyAsync(h_len, d_blen, (size_t)3 * nfb * 4, hipMemcpyDeviceToHost, sx));      // h_len | h_score | h_fragbase

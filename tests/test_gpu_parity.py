@@ -607,3 +607,23 @@ def test_full_size_result_invariants(tmp_path, total, ncontig, div, seed, repeat
         if repeats == "adversarial":
             print(f"adversarial 250 Mb: {int(g.seed_stats()[1])} of {(seq.size + 9999) // 10000} chunks took the dense search, {r['blocks'].size} blocks, coverage {cov / seq.size:.3f}")
     g.close()
+
+
+def test_config5_full_human_all_contigs():
+    """BASELINE configs[4] on one GPU (the whole job of the 8-GPU configuration; the index is replicated per GPU there): a 24-contig
+    reference with GRCh38 chromosome lengths, 3.08 Gbp / 6.2 G BWT rows -- the >= 2^32-row device layout and the 64-bit suffix sorter
+    on their real input (the index builds in ~80 s on the host's cores since round 3) -- vs a 1 %-diverged query, -alen 5000, through
+    gsa_align_many on two contexts, then EVERY contig through the result invariants (no oracle at this size).  tools/human_scale_probe.py;
+    needs a host with >= 256 GB of memory (skipped elsewhere)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    mem_gb = 0.0
+    for ln in open("/proc/meminfo"):
+        if ln.startswith("MemTotal"):
+            mem_gb = int(ln.split()[1]) / 1e6
+    if mem_gb < 256:
+        pytest.skip(f"host has {mem_gb:.0f} GB of memory")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "human_scale_probe.py")], capture_output=True, text=True, timeout=1000)
+    assert r.returncode == 0 and "HUMAN SCALE PROBE OK" in r.stdout and "all 24 contigs checked" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    print(r.stdout)
