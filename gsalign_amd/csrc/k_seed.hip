@@ -122,37 +122,48 @@ __device__ __forceinline__ void wg_exscan_hits(const i32 *hits, i32 *base, int n
 	}
 }
 
-#define LHOP_N 512
-__device__ __forceinline__ int memo_get(const uint8_t *memo, const u32 *lhop, int s)
+// next(s) - s per position of a chunk, 0 = unknown, as NIBBLES (round 3; bytes in round 2, u16 before): hops of 15 and more --
+// every accepted match, a few hundred per chunk counting the speculative walks -- keep their value in a hash table beside the
+// nibbles.  LDS per workgroup is what limits how many chunks a CU works on at once (and with them the random reads in flight):
+// 18.7 KB -> 15.7 KB = ten workgroups per CU instead of eight.  Lanes set different nibbles of one word at the same time
+// (atomic OR); a position is only ever given ONE value (next(s) is a function of s), so setting it twice is harmless.
+#ifndef SEED_MIN_WAVES
+#define SEED_MIN_WAVES 4        // waves per SIMD the register allocation must allow.  The LDS admits ten 128-lane workgroups per CU (5 per SIMD) since
+                                // the nibble memo, but 5 needs 96 VGPRs where the loop wants 119: measured 4.87 against 4.32 ms (16 dwords of scratch in the loop)
+#endif
+#define LHOP_N 1024
+#define MEMO_WORDS (GSA_CHUNK / 8)
+__device__ __forceinline__ int memo_nib(const u32 *memo, int s) { return (int)((memo[s >> 3] >> ((s & 7) << 2)) & 15u); }
+__device__ __forceinline__ void memo_one(u32 *memo, int s) { atomicOr(&memo[s >> 3], 1u << ((s & 7) << 2)); }
+__device__ __forceinline__ int memo_get(const u32 *memo, const u32 *lhop, int s)
 {
-	const int v = memo[s];
-	if (v < 255) return v;
-	for (u32 h = ((u32)s * 40503u) >> 7;; h++) { const u32 e = lhop[h & (LHOP_N - 1)]; if ((e >> 16) == (u32)s + 1) return (int)(e & 0xffffu); }
+	const int v = memo_nib(memo, s);
+	if (v < 15) return v;
+	for (u32 h = ((u32)s * 40503u) >> 6;; h++) { const u32 e = lhop[h & (LHOP_N - 1)]; if ((e >> 16) == (u32)s + 1) return (int)(e & 0xffffu); }
 }
-__device__ __forceinline__ void memo_set(uint8_t *memo, u32 *lhop, int s, int d, int *abort_flag)
+__device__ __forceinline__ void memo_set(u32 *memo, u32 *lhop, int s, int d, int *abort_flag)
 {
-	if (d < 255) { memo[s] = (uint8_t)d; return; }
+	if (d < 15) { atomicOr(&memo[s >> 3], (u32)d << ((s & 7) << 2)); return; }
 	const u32 e = ((u32)(s + 1) << 16) | (u32)d;
-	u32 h = ((u32)s * 40503u) >> 7;
+	u32 h = ((u32)s * 40503u) >> 6;
 	for (int tries = 0; tries < LHOP_N; tries++, h++) {
 		const u32 old = atomicCAS(&lhop[h & (LHOP_N - 1)], 0u, e);
-		if (old == 0 || old == e) { memo[s] = 255; return; }      // (two walks that reach the same start store the same hop: next(s) is a function of s)
+		if (old == 0 || old == e) { atomicOr(&memo[s >> 3], 15u << ((s & 7) << 2)); return; }      // (two walks that reach the same start store the same hop: next(s) is a function of s)
 	}
 	*(volatile int *)abort_flag = 1;                                // table full: the chunk is redone by the dense kernels
 }
 
 template <bool COUNT, bool E16>
-__global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
+__global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
                                                       u32 budget, u32 *heavy_list, i32 *chunk_base)
 {
 	__shared__ u32 s_ncand, s_queue, s_hits;
 	__shared__ int changed, s_abort;
 	__shared__ u32 qp[QP_WORDS], qn[QN_WORDS];
-	// next(s) - s per position, 0 = unknown, as BYTES: hops of 255 and more (a match of >= 254 bases: at most a few dozen
-	// starts of a chunk) keep their value in a small hash table beside it.  20 KB of u16 were what limited a CU to six of
-	// these workgroups; a full table (never seen) sends the chunk to the dense kernels like an exhausted budget does.
-	__shared__ uint8_t memo[GSA_CHUNK];
+	// next(s) - s per position as nibbles + a hash table for the long hops (memo_get / memo_set above); a full table (never
+	// seen) sends the chunk to the dense kernels like an exhausted budget does.
+	__shared__ u32 memo[MEMO_WORDS];
 	__shared__ u32 lhop[LHOP_N];              // (s + 1) << 16 | hop, 0 = free
 	__shared__ uint16_t mblk[COUNT ? GSA_CHUNK : 1];   // Occ blocks the search from s read (accounting build only)
 	__shared__ u32 bits[PATH_WORDS];
@@ -183,7 +194,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		if (2 * g + 1 < QP_WORDS) qp[2 * g + 1] = w1;
 		qn[g] = wn;
 	}
-	for (int p = j; p < clen; p += SEED_WG) memo[p] = 0;
+	for (int p = j; p < MEMO_WORDS; p += SEED_WG) memo[p] = 0;
 	for (int p = j; p < LHOP_N; p += SEED_WG) lhop[p] = 0;
 	for (int p = j; p < PATH_WORDS; p += SEED_WG) bits[p] = 0;
 	if (j == 0) { s_ncand = 0; s_queue = 0; s_hits = 0; s_npend = 0; s_abort = 0; }
@@ -245,17 +256,17 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 			bool ended = false;
 			if (mode == M_KMER) {
 				if (!PRES4_TEST(0)) {                  // the first MinSeedLength bases do not occur: no seed here, next start s+1
-					memo[s] = 1; s += 1; mode = M_ADV;
+					memo_one(memo, s); s += 1; mode = M_ADV;
 					// ... and the same for the starts behind it, as long as nothing else is known about them (the advance step
 					// below owns every other rule: sub-range end, memoised hop, ambiguous bases, too close to the chunk end)
 					const int L = prm.MinSeedLength < 32 ? prm.MinSeedLength : 32;
 #pragma unroll
 					for (int k2 = 0; k2 < PLOOK; k2++) {
-						if (s >= bend || memo[s]) break;
+						if (s >= bend || memo_nib(memo, s)) break;
 						const u32 nb = q_nbits32(qn, s);
 						if (s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0) break;
 						if (k2 == 0 ? PRES4_TEST(1) : k2 == 1 ? PRES4_TEST(2) : PRES4_TEST(3)) break;          // occurs: needs its table entry (next iteration)
-						memo[s] = 1; s += 1;
+						memo_one(memo, s); s += 1;
 					}
 				} else {
 					const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k, walk it base by base
@@ -306,8 +317,8 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 				if (m_) { s += m_; continue; }
 				const u32 nb = q_nbits32(qn, s);
 				const int L = prm.MinSeedLength < 32 ? prm.MinSeedLength : 32;
-				if (nb & 1u) { memo[s] = 1; if (COUNT) mblk[s] = 0; s += 1; }
-				else if (!COUNT && (s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0)) { memo[s] = 1; s += 1; }      // cannot reach MinSeedLength
+				if (nb & 1u) { memo_one(memo, s); if (COUNT) mblk[s] = 0; s += 1; }
+				else if (!COUNT && (s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0)) { memo_one(memo, s); s += 1; }      // cannot reach MinSeedLength
 				else {
 					ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
 					if (!COUNT && di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
@@ -358,7 +369,7 @@ __global__ void __launch_bounds__(SEED_WG) k_seed_wg(DevIndex di, const uint8_t 
 		for (int it = j; it < nitems; it += SEED_WG) {
 			if (!((onchain[it >> 5] >> (it & 31)) & 1u)) continue;
 			const int e = entry_of[it];
-			const bool known = ((rewalked[it >> 5] >> (it & 31)) & 1u) ? e == walked_from[it] : memo[e] != 0;
+			const bool known = ((rewalked[it >> 5] >> (it & 31)) & 1u) ? e == walked_from[it] : memo_nib(memo, e) != 0;
 			if (!known) {
 				const u32 idx = atomicAdd(&s_npend, 1u);
 				if (idx < SEED_WG) { pend_it[idx] = (uint16_t)it; walked_from[it] = (uint16_t)e; atomicOr(&rewalked[it >> 5], 1u << (it & 31)); }
