@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgsa_hip.so")
 
 EXPORTS = [
-    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many",
+    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many", "gsa_align_bundle",
     "gsa_align_contig_device", "gsa_set_query_device", "gsa_device_alloc", "gsa_device_free", "gsa_device_upload", "gsa_get_seed_stats", "gsa_hit_buffers", "gsa_seed_chunks", "gsa_hit_count", "gsa_export_hits", "gsa_import_hits", "gsa_finish_contig",
     "gsa_set_query", "gsa_rewind", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
     "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling", "gsa_bind_host_thread",
@@ -157,10 +157,11 @@ class DeviceContig:
             self.lib.gsa_device_free(self.device, C.c_void_p(self.ptr)); self.ptr = None
 
 
-def align_many(aligners, contigs, on_result=None, in_order: bool = False) -> None:
+def align_many(aligners, contigs, on_result=None, in_order: bool = False, bundle: bool = True) -> None:
     """gsa_align_many: `contigs` (uint8 arrays, or DeviceContig objects -- all of one kind) on the given contexts, one host
     thread per context inside the library.  on_result(contig_index, Result) runs on the worker threads (the Result is valid
-    during the call only).  in_order: hand the contigs out as listed (GSA_MANY_IN_ORDER) instead of longest first."""
+    during the call only).  in_order: hand the contigs out as listed (GSA_MANY_IN_ORDER) instead of longest first.
+    bundle=False: GSA_MANY_NO_BUNDLE (every contig in a pass of its own; by default short contigs share passes)."""
     lib = aligners[0].lib
     n = len(contigs)
     ctxs = (C.c_void_p * len(aligners))(*[a.ctx for a in aligners])
@@ -169,7 +170,7 @@ def align_many(aligners, contigs, on_result=None, in_order: bool = False) -> Non
     ql = (C.c_int32 * n)(*[int(c.size) for c in contigs])
     cb = RESULT_FN((lambda user, ci, res: int(on_result(ci, res.contents) or 0)) if on_result else 0)
     lib.gsa_align_many.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_uint32, RESULT_FN, C.c_void_p]
-    rc = lib.gsa_align_many(ctxs, len(aligners), qs, ql, n, (1 if in_order else 0) | (2 if on_dev else 0), cb, None)
+    rc = lib.gsa_align_many(ctxs, len(aligners), qs, ql, n, (1 if in_order else 0) | (2 if on_dev else 0) | (0 if bundle else 8), cb, None)
     if rc != 0:
         msgs = [lib.gsa_last_error(a.ctx).decode() for a in aligners]
         raise GsaError(f"gsa_align_many -> {rc}: {'; '.join(m for m in msgs if m)}")
@@ -177,6 +178,24 @@ def align_many(aligners, contigs, on_result=None, in_order: bool = False) -> Non
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
+
+
+def result_as_dump(r: dict, with_aln: bool = False) -> dict:
+    """A result dict (Aligner._result: blocks / frags / aln1 / aln2) in the shape of oracle_py._StageReader.blocks(): records
+    gathered in block order."""
+    B, F = r["blocks"], r["frags"]
+    idx = np.concatenate([np.arange(o, o + n) for o, n in zip(B["frag_off"], B["n_frag"])]) if B.size else np.zeros(0, np.int64)
+    Fo = F[idx] if idx.size else np.zeros(0, FRAG_DT)
+    out = {"b_score": B["score"].copy(), "b_aln_len": B["aln_len"].copy(), "b_bdup": B["bdup"].copy(), "b_nfrag": B["n_frag"].copy(),
+           "b_bdir": B["bdir"].copy(), "b_gpos": B["gpos"].copy(), "b_chr": B["chr"].copy(),
+           "f_bseed": Fo["bseed"].copy(), "f_qpos": Fo["qpos"].copy(), "f_qlen": Fo["qlen"].copy(), "f_rlen": Fo["rlen"].copy(),
+           "f_alnlen": Fo["aln_len"].copy(), "f_rpos": Fo["rpos"].copy()}
+    if with_aln:
+        segs1 = [r["aln1"][o:o + n] for o, n in zip(Fo["aln_off"], Fo["aln_len"]) if n]
+        segs2 = [r["aln2"][o:o + n] for o, n in zip(Fo["aln_off"], Fo["aln_len"]) if n]
+        out["aln1"] = np.concatenate(segs1) if segs1 else np.zeros(0, np.uint8)
+        out["aln2"] = np.concatenate(segs2) if segs2 else np.zeros(0, np.uint8)
+    return out
 
 
 class GsaError(RuntimeError):
@@ -358,20 +377,7 @@ class Aligner:
 
     def blocks_as_dump(self, with_aln: bool = False) -> dict:
         """Same keys/shapes as oracle_py._StageReader.blocks(): records gathered in block order."""
-        r = self.blocks()
-        B, F = r["blocks"], r["frags"]
-        idx = np.concatenate([np.arange(o, o + n) for o, n in zip(B["frag_off"], B["n_frag"])]) if B.size else np.zeros(0, np.int64)
-        Fo = F[idx] if idx.size else np.zeros(0, FRAG_DT)
-        out = {"b_score": B["score"].copy(), "b_aln_len": B["aln_len"].copy(), "b_bdup": B["bdup"].copy(), "b_nfrag": B["n_frag"].copy(),
-               "b_bdir": B["bdir"].copy(), "b_gpos": B["gpos"].copy(), "b_chr": B["chr"].copy(),
-               "f_bseed": Fo["bseed"].copy(), "f_qpos": Fo["qpos"].copy(), "f_qlen": Fo["qlen"].copy(), "f_rlen": Fo["rlen"].copy(),
-               "f_alnlen": Fo["aln_len"].copy(), "f_rpos": Fo["rpos"].copy()}
-        if with_aln:
-            segs1 = [r["aln1"][o:o + n] for o, n in zip(Fo["aln_off"], Fo["aln_len"]) if n]
-            segs2 = [r["aln2"][o:o + n] for o, n in zip(Fo["aln_off"], Fo["aln_len"]) if n]
-            out["aln1"] = np.concatenate(segs1) if segs1 else np.zeros(0, np.uint8)
-            out["aln2"] = np.concatenate(segs2) if segs2 else np.zeros(0, np.uint8)
-        return out
+        return result_as_dump(self.blocks(), with_aln)
 
     def dump_stages(self, upto: int = 8) -> dict:
         d = {}
@@ -423,6 +429,19 @@ class Aligner:
         res = np.zeros(q1.size, np.int32)
         self._ck(self.lib.gsa_gap_similarity_batch(self.ctx, C.c_int32(q1.size), _p(q1, C.c_int32), _p(q2, C.c_int32), _p(r1, C.c_int64), _p(r2, C.c_int64), _p(res, C.c_int32)))
         return res
+
+    def align_bundle(self, contigs) -> list:
+        """gsa_align_bundle: several contigs (uint8 arrays, or DeviceContig objects -- all of one kind) in ONE pass; one result dict
+        per contig, each what align_contig of that contig alone gives."""
+        n = len(contigs)
+        on_dev = n > 0 and isinstance(contigs[0], DeviceContig)
+        self._q = contigs
+        qs = (C.c_char_p * n)(*[C.cast(c.ptr if on_dev else c.ctypes.data, C.c_char_p) for c in contigs])
+        ql = (C.c_int32 * n)(*[int(c.size) for c in contigs])
+        res = (Result * n)()
+        self.lib.gsa_align_bundle.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_uint32, C.POINTER(Result)]
+        self._ck(self.lib.gsa_align_bundle(self.ctx, qs, ql, n, 2 if on_dev else 0, res))
+        return [self._result(res[k]) for k in range(n)]
 
     def align_contig_raw(self, seq: np.ndarray) -> Result:
         """gsa_align_contig without copying the result out (views into library-owned memory)."""

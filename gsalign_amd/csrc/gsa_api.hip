@@ -22,6 +22,8 @@ int gsa_fail(gsa_ctx *ctx, int code, const std::string &msg)
 int host_stage4_5_6(gsa_ctx *c, int stage);    // gsa_blocks.cpp
 int host_stage8_finish(gsa_ctx *c);            // gsa_blocks.cpp
 int build_block_view(gsa_ctx *c);              // gsa_blocks.cpp
+void bundle_split_lists(gsa_ctx *c);           // gsa_blocks.cpp  (a bundle of contigs: one AlnBlockVec per contig for stages 4-6 ...
+void bundle_join_lists(gsa_ctx *c);            // gsa_blocks.cpp   ... joined again, contig after contig, for stages 7-8)
 
 void collect_events(gsa_ctx *c)
 {
@@ -69,7 +71,7 @@ static int reset_run_state(gsa_ctx *c)
 {
 	if (c->early_in_flight) { GSA_CHECK(c, hipStreamSynchronize(c->stream_aux[0])); c->early_in_flight = false; }
 	c->n_early = 0; c->early_listed = false; c->early_consumed = false;
-	c->stage = 0; c->split = false;
+	c->stage = 0; c->split = false; c->b_lists.clear();
 	c->n_seeds = 0; c->n_groups = 0; c->n_blocks2 = 0; c->blocks.clear(); c->frags_stage = 0; c->have_host_seeds = false; c->ev_pending = 0; c->s2_host = false;
 	memset(c->counters, 0, sizeof(c->counters)); memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
 	return GSA_OK;
@@ -169,13 +171,14 @@ void gsa_destroy(gsa_ctx *c)
 		&c->fb_seedbase, &c->fb_sbeg, &c->fb_fragbase, &c->f_rec, &c->f_rec16, &c->f_type, &c->f_mism, &c->f_alnlen, &c->f_job, &c->f_score,
 		&c->d_dp_tiny, &c->d_dp_bnd, &c->d_dp_ctr, &c->d_dp_jobs, &c->d_dp_large, &c->d_tail,
 		&c->e_id, &c->e_rec, &c->e_list, &c->e_off1, &c->e_off2, &c->e_opsoff, &c->e_nops, &c->e_ops, &c->e_rev, &c->r_head, &c->f_early, &c->r_orig, &c->r_tmp_orig, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_alnoff, &c->bl_alnlen, &c->bl_score,
+		&c->d_bndtab, &c->d_bblk,
 		&c->leaf[0], &c->leaf[1], &c->leaf[2], &c->leaf[3], &c->leaf[4], &c->leaf[5], &c->leaf[6], &c->leaf[7], &c->leaf[8] };
 	// (a gsa_clone context borrows the index through `di` only: its index DevBufs are empty, a presence bitmap it built after
 	//  a parameter change is its own)
 	for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
 	if (c->h_mail) hipHostFree(c->h_mail);
-	for (DevBuf *b : { &c->p_frags, &c->p_tail, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_sj_early, &c->p_jpatch, &c->p_early }) if (b->p) hipHostFree(b->p);
+	for (DevBuf *b : { &c->p_frags, &c->p_tail, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_sj_early, &c->p_jpatch, &c->p_early, &c->p_bndtab, &c->p_bblk, &c->p_ba0 }) if (b->p) hipHostFree(b->p);
 	for (int i = 0; i < 28; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 3; i++) if (c->stream_aux[i]) hipStreamDestroy(c->stream_aux[i]);
 	if (c->stream) hipStreamDestroy(c->stream);
@@ -253,8 +256,10 @@ int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->a
 static int query_geometry(gsa_ctx *c, int32_t qlen)
 {
 	c->qlen = qlen;
+	c->bnd.n = 0; c->bnd.lmax = qlen; c->bnd.pds = 0; c->bnd.off = nullptr; c->bnd.chunk_contig = nullptr;
 	c->qbits = ceil_log2_u64((u64)qlen + 1); if (c->qbits < 1) c->qbits = 1;
-	c->pdbits = ceil_log2_u64((u64)(2 * c->G) + (u64)qlen + 2);
+	c->pd_span = 2 * c->G + (i64)qlen + 2;
+	c->pdbits = ceil_log2_u64((u64)c->pd_span);
 	if (c->qbits + c->pdbits > 64) return gsa_fail(c, GSA_ERR_LIMIT, "contig too long for the 64-bit seed key");
 	return GSA_OK;
 }
@@ -333,9 +338,9 @@ int gsa_run_to(gsa_ctx *c, int stage)
 		switch (next) {
 		case 1: rc = stage1_seed(c); break;
 		case 2: rc = stage2_chain(c); break;
-		case 3: rc = stage345_refine(c); break;                       // device part of S3..S5, host list = S3 state
+		case 3: rc = stage345_refine(c); if (rc == GSA_OK && c->bnd.n) bundle_split_lists(c); break;      // device part of S3..S5, host list = S3 state
 		case 4: case 5: case 6: rc = host_stage4_5_6(c, next); break;
-		case 7: rc = stage7_fill(c); break;
+		case 7: if (c->bnd.n) bundle_join_lists(c); rc = stage7_fill(c); break;
 		case 8: rc = stage78_extend(c); if (rc == GSA_OK) rc = host_stage8_finish(c); break;
 		}
 		if (rc == GSA_OK) { c->stage = next; c->frags_stage = (next == 8) ? 8 : 0; }
@@ -374,6 +379,98 @@ static int align_uploaded(gsa_ctx *c, gsa_result *out)
 	}
 	if (rc) return rc;
 	return gsa_get_blocks(c, out);
+}
+
+// ---- several contigs in one pass (Bundle, gsa_internal.h) ----
+// The concatenation, device-resident contigs: one workgroup per chunk copies its 10 000 bytes (or the tail of its contig and 'N's).
+struct BundleSrc { const uint8_t *p; i32 len, _pad; };
+__global__ void __launch_bounds__(256) k_bundle_gather(const i32 *__restrict__ off, const uint16_t *__restrict__ chunk_contig, const BundleSrc *__restrict__ src, uint8_t *dst)
+{
+	const i32 chunk = blockIdx.x, ci = chunk_contig[chunk];
+	const i64 g0 = (i64)chunk * GSA_CHUNK; const i32 l0 = (i32)(g0 - off[ci]);
+	const BundleSrc sc = src[ci];
+	const i32 have = sc.len - l0 < GSA_CHUNK ? sc.len - l0 : GSA_CHUNK;
+	for (i32 t = threadIdx.x; t < GSA_CHUNK; t += 256) dst[g0 + t] = t < have ? sc.p[l0 + t] : (uint8_t)'N';
+}
+
+#define GSA_BUNDLE_MAX_CONTIGS 4096
+static int set_query_bundle(gsa_ctx *c, const char *const *query, const int32_t *qlen, int32_t n, bool dev_q)
+{
+	if (n < 1 || n > GSA_BUNDLE_MAX_CONTIGS) return gsa_fail(c, GSA_ERR_ARG, "gsa_align_bundle: 1 .. 4096 contigs");
+	GSA_CHECK(c, hipSetDevice(c->device));
+	if (int rc = reset_run_state(c)) return rc;
+	c->b_off.assign((size_t)n + 1, 0); c->b_qlen.assign(qlen, qlen + n);
+	i64 tot = 0; i32 lmax = 0;
+	for (int k = 0; k < n; k++) {
+		if (qlen[k] < 0 || (qlen[k] > 0 && !query[k])) return GSA_ERR_ARG;
+		c->b_off[(size_t)k] = (i32)tot;
+		tot += ((i64)qlen[k] + GSA_CHUNK - 1) / GSA_CHUNK * GSA_CHUNK;       // every contig starts on a chunk edge, as it does alone
+		if (tot >= (1ll << 31) - 2 * GSA_CHUNK) return gsa_fail(c, GSA_ERR_LIMIT, "bundle longer than 2^31 bases");
+		if (qlen[k] > lmax) lmax = qlen[k];
+	}
+	c->b_off[(size_t)n] = (i32)tot;
+	const i64 n_chunks = tot / GSA_CHUNK;
+	// tables: off[n + 1] (i32) | chunk_contig[n_chunks] (u16) | sources (device-resident contigs)
+	const size_t o_cc = ((size_t)n + 1) * 4, o_src = (o_cc + (size_t)n_chunks * 2 + 15) & ~(size_t)15, t_bytes = o_src + (dev_q ? (size_t)n * sizeof(BundleSrc) : 0);
+	if (!pin_ensure<uint8_t>(c, c->p_bndtab, t_bytes + 16) || !dev_ensure<uint8_t>(c, c->d_bndtab, t_bytes + 16)) return GSA_ERR_NOMEM;
+	uint8_t *ht = c->p_bndtab.as<uint8_t>();
+	memcpy(ht, c->b_off.data(), o_cc);
+	{ uint16_t *cc = (uint16_t *)(ht + o_cc); for (int k = 0; k < n; k++) for (i64 ch = c->b_off[(size_t)k] / GSA_CHUNK; ch < c->b_off[(size_t)k + 1] / GSA_CHUNK; ch++) cc[ch] = (uint16_t)k; }
+	if (dev_q) { BundleSrc *bs = (BundleSrc *)(ht + o_src); for (int k = 0; k < n; k++) { bs[k].p = (const uint8_t *)query[k]; bs[k].len = qlen[k]; bs[k]._pad = 0; } }
+	if (!dev_ensure<uint8_t>(c, c->d_query, (size_t)tot + 64)) return GSA_ERR_NOMEM;
+	GSA_CHECK(c, hipMemcpyAsync(c->d_bndtab.p, ht, t_bytes, hipMemcpyHostToDevice, c->stream));
+	const uint8_t *dt = c->d_bndtab.as<uint8_t>();
+	if (tot > 0) {
+		if (dev_q) hipLaunchKernelGGL(k_bundle_gather, dim3((unsigned)n_chunks), dim3(256), 0, c->stream, (const i32 *)dt, (const uint16_t *)(dt + o_cc), (const BundleSrc *)(dt + o_src), c->d_query.as<uint8_t>());
+		else {
+			GSA_CHECK(c, hipMemsetAsync(c->d_query.p, 'N', (size_t)tot, c->stream));
+			for (int k = 0; k < n; k++) if (qlen[k] > 0) GSA_CHECK(c, hipMemcpyAsync(c->d_query.as<uint8_t>() + c->b_off[(size_t)k], query[k], (size_t)qlen[k], hipMemcpyHostToDevice, c->stream));
+		}
+		GSA_CHECK(c, hipGetLastError());
+	}
+	c->q_dev = c->d_query.as<uint8_t>();
+	c->qlen = (i32)tot;
+	c->bnd.n = n; c->bnd.lmax = lmax; c->bnd.off = (const i32 *)dt; c->bnd.chunk_contig = (const uint16_t *)(dt + o_cc);
+	c->bnd.pds = (2 * c->G + (i64)lmax + (i64)c->prm.MaxIndelSize + 64 + 31) & ~31ll;      // (a PosDiff of contig k: rPos - qLocal + lmax in (0, 2G + lmax])
+	c->qbits = ceil_log2_u64((u64)tot + 1); if (c->qbits < 1) c->qbits = 1;
+	c->pd_span = (i64)n * c->bnd.pds + 2;
+	c->pdbits = ceil_log2_u64((u64)c->pd_span);
+	if (c->qbits + c->pdbits > 64) return gsa_fail(c, GSA_ERR_LIMIT, "bundle too long for the 64-bit seed key");
+	return GSA_OK;
+}
+
+// the result of contig k of the bundle this context just aligned (valid until the next call on the context)
+static void bundle_result(gsa_ctx *c, int k, const std::vector<i64> &a0, size_t blk_at, gsa_result *out)
+{
+	out->n_blocks = c->b_nblk[(size_t)k]; out->blocks = c->h_blocks.data() + blk_at;
+	out->n_frags = c->b_frag0[(size_t)k + 1] - c->b_frag0[(size_t)k]; out->recs = c->p_frags.as<gsa_rec>() + c->b_frag0[(size_t)k];
+	out->n_aln = a0[(size_t)k + 1] - a0[(size_t)k]; out->aln1 = c->h_taln1 + a0[(size_t)k]; out->aln2 = c->h_taln2 + a0[(size_t)k];
+}
+
+int gsa_align_bundle(gsa_ctx *c, const char *const *query, const int32_t *qlen, int32_t n, uint32_t flags, gsa_result *out)
+{
+	if (!c || !query || !qlen || !out || (flags & ~(uint32_t)GSA_MANY_DEVICE)) return GSA_ERR_ARG;
+	int rc = set_query_bundle(c, query, qlen, n, (flags & GSA_MANY_DEVICE) != 0); if (rc) return rc;
+	c->dp_timeout = false;
+	rc = gsa_run_to(c, 8);
+	if (rc == GSA_ERR_STATE && c->dp_timeout && !c->dp_safe) {      // (the safety net of gsa_align_contig; the concatenation stays where it is)
+		c->dp_timeout = false; c->dp_safe = true;
+		{ const Bundle keep = c->bnd; rc = reset_run_state(c); c->bnd = keep; }
+		if (rc == GSA_OK) rc = gsa_run_to(c, 8);
+		c->dp_safe = false;
+	}
+	if (rc) return rc;
+	const size_t nfb = c->b_blk0.empty() ? 0 : (size_t)c->b_blk0[(size_t)n];
+	if (nfb == 0 || c->n_frags == 0) {
+		for (int k = 0; k < n; k++) { out[k].n_blocks = 0; out[k].n_frags = 0; out[k].n_aln = 0; out[k].blocks = nullptr; out[k].recs = nullptr; out[k].aln1 = out[k].aln2 = nullptr; }
+		return GSA_OK;
+	}
+	// string-pool offset of every contig: k_bundle_rebase left it for the contigs that have records
+	std::vector<i64> a0((size_t)n + 1, c->n_aln);
+	for (int k = n - 1; k >= 0; k--) a0[(size_t)k] = c->b_blk0[(size_t)k] < c->b_blk0[(size_t)k + 1] ? c->p_ba0.as<i64>()[k] : a0[(size_t)k + 1];
+	size_t at = 0;
+	for (int k = 0; k < n; k++) { bundle_result(c, k, a0, at, &out[k]); at += (size_t)c->b_nblk[(size_t)k]; }
+	return GSA_OK;
 }
 
 // ---- one contig seeded by several GPUs ----
@@ -466,7 +563,7 @@ static int align_split(gsa_ctx *const *grp, int n_grp, const char *query, int32_
 
 int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n, uint32_t flags, gsa_result_fn on_result, void *user)
 {
-	if (flags & ~(uint32_t)(GSA_MANY_IN_ORDER | GSA_MANY_DEVICE | GSA_MANY_NO_SPLIT)) return GSA_ERR_ARG;
+	if (flags & ~(uint32_t)(GSA_MANY_IN_ORDER | GSA_MANY_DEVICE | GSA_MANY_NO_SPLIT | GSA_MANY_NO_BUNDLE)) return GSA_ERR_ARG;
 	if (!ctx || n_ctx <= 0 || n < 0 || (n > 0 && (!query || !qlen))) return GSA_ERR_ARG;
 	for (int k = 0; k < n_ctx; k++) if (!ctx[k]) return GSA_ERR_ARG;
 	const bool dev_q = (flags & GSA_MANY_DEVICE) != 0;
@@ -503,21 +600,62 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 		for (std::thread &t : th) t.join();
 		return err.load();
 	}
-	std::atomic<int32_t> next(0);
-	auto loop = [&](gsa_ctx *c) {
-		for (;;) {
-			const int32_t i = next.fetch_add(1);
-			if (i >= n || err.load() != GSA_OK) return;
+	// Short contigs travel in BUNDLES: a contig of a few Mb is ~60 GPU operations whatever its size, and with several contexts in
+	// flight the operations of one stretch the other's (profiles/r03_timeline_multi_*.txt), so n short contigs are concatenated and
+	// go through the stages as ONE pass (set_query_bundle / gsa_align_bundle; results per contig, identical to the ones they get
+	// alone).  A unit of work = a long contig, or a bundle of consecutive short ones in hand-out order.  Bundle size: large enough
+	// to amortise the operations, small enough that every context gets about three units (GSA_BUNDLE_CAP bases at most, default
+	// 32 Mb; contigs above GSA_BUNDLE_CONTIG, default 16 Mb, stay alone; GSA_BUNDLE_CONTIG=0 or GSA_MANY_NO_BUNDLE: no bundles).
+	static const int64_t bundle_contig = [] { const char *e = getenv("GSA_BUNDLE_CONTIG"); return e ? (int64_t)atoll(e) : 16000000ll; }();
+	static const int64_t bundle_cap = [] { const char *e = getenv("GSA_BUNDLE_CAP"); return e ? (int64_t)atoll(e) : 32000000ll; }();
+	std::vector<std::vector<int32_t> > units;
+	{
+		bool may = !(flags & GSA_MANY_NO_BUNDLE) && bundle_contig > 0;
+		for (int k = 0; k < n_ctx; k++) if (ctx[k]->profiling || ctx[k]->count_blocks) may = false;      // (per-contig counters and stage timers)
+		int64_t small_total = 0; int32_t n_small = 0;
+		for (int32_t i = 0; i < n; i++) if ((int64_t)qlen[i] <= bundle_contig) { small_total += qlen[i]; n_small++; }
+		if (n_small < 2) may = false;
+		int64_t target = small_total / (3 * (int64_t)n_ctx); if (target > bundle_cap) target = bundle_cap;
+		int64_t cur = 0;
+		for (int32_t i = 0; i < n; i++) {
 			const int32_t ci = order[(size_t)i];
-			gsa_result res;
-			int rc = dev_q ? gsa_align_contig_device(c, query[ci], qlen[ci], &res) : gsa_align_contig(c, query[ci], qlen[ci], &res);
-			if (rc == GSA_OK && on_result) rc = on_result(user, ci, &res);
+			const bool small = may && (int64_t)qlen[ci] <= bundle_contig;
+			if (!small) { units.push_back(std::vector<int32_t>(1, ci)); cur = 0; continue; }
+			const int64_t padded = ((int64_t)qlen[ci] + GSA_CHUNK - 1) / GSA_CHUNK * GSA_CHUNK;
+			if (cur > 0 && (cur + padded > target || units.back().size() >= GSA_BUNDLE_MAX_CONTIGS)) cur = 0;
+			if (cur == 0) units.push_back(std::vector<int32_t>());
+			units.back().push_back(ci); cur += padded > 0 ? padded : 1;
+		}
+	}
+	const int32_t n_units = (int32_t)units.size();
+	std::atomic<int32_t> next(0);
+	auto one = [&](gsa_ctx *c, int32_t ci) {
+		gsa_result res;
+		int rc = dev_q ? gsa_align_contig_device(c, query[ci], qlen[ci], &res) : gsa_align_contig(c, query[ci], qlen[ci], &res);
+		if (rc == GSA_OK && on_result) rc = on_result(user, ci, &res);
+		return rc;
+	};
+	auto loop = [&](gsa_ctx *c) {
+		std::vector<const char *> bq; std::vector<int32_t> bl; std::vector<gsa_result> br;
+		for (;;) {
+			const int32_t u = next.fetch_add(1);
+			if (u >= n_units || err.load() != GSA_OK) return;
+			const std::vector<int32_t> &un = units[(size_t)u];
+			int rc = GSA_OK;
+			if (un.size() == 1) rc = one(c, un[0]);
+			else {
+				bq.clear(); bl.clear(); br.resize(un.size());
+				for (int32_t ci : un) { bq.push_back(query[ci]); bl.push_back(qlen[ci]); }
+				rc = gsa_align_bundle(c, bq.data(), bl.data(), (int32_t)un.size(), dev_q ? GSA_MANY_DEVICE : 0u, br.data());
+				if (rc == GSA_OK) { for (size_t k = 0; k < un.size() && rc == GSA_OK && on_result; k++) rc = on_result(user, un[k], &br[k]); }
+				else if (rc == GSA_ERR_LIMIT) { rc = GSA_OK; for (size_t k = 0; k < un.size() && rc == GSA_OK; k++) rc = one(c, un[k]); }      // (a capacity of the joint pass: one by one)
+			}
 			if (rc != GSA_OK) { int ok = GSA_OK; err.compare_exchange_strong(ok, rc); return; }
 		}
 	};
 	std::vector<std::thread> th;
 	// (thread placement is the caller's: gsa_bind_host_thread; the threads started here inherit the caller's affinity)
-	for (int k = 1; k < n_ctx && k < n; k++) th.emplace_back(loop, ctx[k]);
+	for (int k = 1; k < n_ctx && k < n_units; k++) th.emplace_back(loop, ctx[k]);
 	loop(ctx[0]);
 	for (std::thread &t : th) t.join();
 	return err.load();

@@ -119,7 +119,40 @@ void remove_redundant(gsa_ctx *c, int type, const std::vector<i64> &chr_score)
 
 } // namespace
 
+// ---- a bundle of contigs (Bundle, gsa_internal.h): the reference keeps ONE AlnBlockVec per query sequence and clears it between
+// sequences (GSAlign.cpp:483-490), and its std::sort calls see that sequence's blocks only -- so the list logic runs per contig,
+// on that contig's blocks in the order the device left them (S2 order: groups ascend with the contig's PosDiff stride).
+static inline int contig_of_q(const gsa_ctx *c, i32 q)
+{
+	const i32 *o = c->b_off.data() + 1;            // contig k = [b_off[k], b_off[k + 1]); empty contigs share their start with the next one
+	return (int)(std::upper_bound(o, o + c->bnd.n, q) - o);
+}
+void bundle_split_lists(gsa_ctx *c)
+{
+	c->b_lists.assign((size_t)c->bnd.n, std::vector<HostBlock>());
+	for (const HostBlock &hb : c->blocks) c->b_lists[(size_t)contig_of_q(c, c->h_leaf[hb.leaf_beg].q_first)].push_back(hb);
+	c->blocks.clear();
+}
+void bundle_join_lists(gsa_ctx *c)
+{
+	c->blocks.clear(); c->b_blk0.assign((size_t)c->bnd.n + 1, 0);
+	for (int k = 0; k < c->bnd.n; k++) {
+		c->b_blk0[(size_t)k] = (i32)c->blocks.size();
+		c->blocks.insert(c->blocks.end(), c->b_lists[(size_t)k].begin(), c->b_lists[(size_t)k].end());
+	}
+	c->b_blk0[(size_t)c->bnd.n] = (i32)c->blocks.size();
+	c->b_lists.clear();
+}
+
+static int host_stage4_5_6_one(gsa_ctx *c, int stage);
 int host_stage4_5_6(gsa_ctx *c, int stage)
+{
+	if (!c->bnd.n) return host_stage4_5_6_one(c, stage);
+	for (std::vector<HostBlock> &L : c->b_lists) { c->blocks.swap(L); host_stage4_5_6_one(c, stage); c->blocks.swap(L); }
+	return GSA_OK;
+}
+
+static int host_stage4_5_6_one(gsa_ctx *c, int stage)
 {
 	auto t0 = std::chrono::steady_clock::now();
 	if (stage == 4) split_blocks(c, 4);
@@ -198,16 +231,25 @@ int host_stage8_finish(gsa_ctx *c)
 		}
 	}
 	struct ByScoreE { bool operator()(const Ext &a, const Ext &b) const { return a.b.score > b.b.score; } };
-	std::sort(E.begin(), E.end(), ByScoreE());
-	size_t n = E.size(); while (n > 0 && E[n - 1].b.score == 0) n--;
-	E.resize(n);
-	B.resize(n);
-	c->h_blocks.resize(n);
-	for (size_t k = 0; k < n; k++) {
-		B[k] = E[k].b;
-		gsa_block &o = c->h_blocks[k];
-		o.score = B[k].score; o.aln_len = B[k].aln_len; o.bdup = B[k].bdup; o.n_frag = E[k].n_frag; o.frag_off = E[k].frag_off;
-		o.bdir = B[k].bdir; o.gpos = B[k].gpos; o.chr = B[k].chr; o._pad = 0;
+	// final RemoveBadAlnBlocks (GSAlign.cpp:540) -- per query sequence: a bundle sorts every contig's segment of the list by itself
+	// and hands out record offsets relative to the contig's first record
+	const int nseg = c->bnd.n ? c->bnd.n : 1;
+	if (c->bnd.n) { c->b_nblk.assign((size_t)nseg, 0); c->b_frag0.assign((size_t)nseg + 1, c->n_frags); }
+	B.clear(); c->h_blocks.clear();
+	for (int sgi = 0; sgi < nseg; sgi++) {
+		const size_t sb = c->bnd.n ? (size_t)c->b_blk0[(size_t)sgi] : 0, se = c->bnd.n ? (size_t)c->b_blk0[(size_t)sgi + 1] : nfb;
+		const i64 f0 = c->bnd.n ? (sb < nfb ? (i64)fragbase[sb] : c->n_frags) : 0;
+		if (c->bnd.n) c->b_frag0[(size_t)sgi] = f0;
+		std::sort(E.begin() + sb, E.begin() + se, ByScoreE());
+		size_t m = se; while (m > sb && E[m - 1].b.score == 0) m--;
+		for (size_t k = sb; k < m; k++) {
+			B.push_back(E[k].b);
+			gsa_block o;
+			o.score = E[k].b.score; o.aln_len = E[k].b.aln_len; o.bdup = E[k].b.bdup; o.n_frag = E[k].n_frag; o.frag_off = E[k].frag_off - f0;
+			o.bdir = E[k].b.bdir; o.gpos = E[k].b.gpos; o.chr = E[k].b.chr; o._pad = 0;
+			c->h_blocks.push_back(o);
+		}
+		if (c->bnd.n) c->b_nblk[(size_t)sgi] = (i32)(m - sb);
 	}
 	c->kernel_ms[7] += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	c->result_pinned = true;

@@ -60,6 +60,16 @@ struct gsa_ctx {
 	const uint8_t *q_dev = nullptr;                // the contig on the device: d_query (uploaded by gsa_set_query) or the caller's buffer (gsa_set_query_device)
 	bool split = false; i64 rng_beg = 0, rng_end = 0;     // gsa_seed_chunks: stage 1 on a chunk range only, the hits of other ranges are imported
 	int qbits = 1, pdbits = 1;
+	i64 pd_span = 0;                               // number of PosDiff key values: 2G + qlen + 2, a bundle: contigs x stride
+
+	// ---- a bundle of contigs in one pass (Bundle, gsa_internal.h; gsa_align_bundle in gsa_api.hip) ----
+	Bundle bnd = { 0, 0, 0, nullptr, nullptr };
+	std::vector<i32> b_off, b_qlen;               // start of contig k in the concatenation [n + 1], its length
+	DevBuf d_bndtab, p_bndtab;                     // off[n + 1] | chunk_contig[chunks] | (device-resident contigs: source pointers) -- device / pinned staging
+	std::vector<std::vector<HostBlock> > b_lists;  // the AlnBlockVec of every contig while the list logic runs (stages 3-6)
+	std::vector<i32> b_blk0;                       // first block of contig k in the joined final list [n + 1]
+	DevBuf d_bblk, p_bblk, p_ba0;                          // contig of every final block | first block per contig (device); string-pool offset of every contig (pinned, written by k_bundle_rebase)
+	std::vector<i32> b_nblk; std::vector<i64> b_frag0;      // blocks that survive the identity filter, and the first record, per contig
 
 	// scratch for rocPRIM
 	DevBuf tmp;

@@ -48,6 +48,26 @@ struct DevIndex {
 	i32 pres_k;             //   for four consecutive start positions (layout: pres4_* in k_seed.hip); rebuilt by gsa_set_params
 };
 
+// ---- several query contigs in ONE pass (gsa_align_many bundles short contigs) --------------
+// The reference clears all state per query sequence (GSAlign.cpp:483-490), so contigs are independent; a contig of a few Mb is
+// ~60 GPU operations whatever its size, and operations -- not bytes -- bound such contigs.  A bundle is the concatenation of n
+// contigs, each padded with 'N' to a chunk edge (GSA_CHUNK: chunk grids restart per contig, matches stop at N exactly as they stop
+// at the end of a sequence), searched / chained / extended as one virtual contig of length off[n]: query positions are positions
+// in the concatenation, reference positions stay what they are.  Two places must know the contig of a seed: (1) the PosDiff key
+// that forms the seed groups gets a per-contig stride (groups never span contigs), (2) integer means over PosDiff values truncate
+// toward zero, so they are taken over the TRUE PosDiff rPos - (q - off[contig]).  n = 0: a single contig.
+struct Bundle {
+	i32 n;                          // contigs in the bundle (0: not a bundle)
+	i32 lmax;                       // PosDiff shift: key = rPos - qLocal + lmax + contig * pds  (single contig: its length)
+	i64 pds;                        // PosDiff key stride per contig: 2G + lmax + MaxIndelSize + slack, a multiple of 32
+	const i32 *off;                 // [n + 1] start of contig c in the concatenation (multiples of GSA_CHUNK)
+	const uint16_t *chunk_contig;   // contig of every chunk of the concatenation
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ i32 bundle_contig(const Bundle &b, i32 q) { return b.n ? (i32)b.chunk_contig[q / GSA_CHUNK] : 0; }
+__device__ __forceinline__ i32 bundle_off(const Bundle &b, i32 q) { return b.n ? b.off[b.chunk_contig[q / GSA_CHUNK]] : 0; }
+#endif
+
 struct DevBuf {
 	void *p = nullptr; size_t cap = 0;
 	template <class T> T *as() const { return (T *)p; }

@@ -86,15 +86,17 @@ __global__ void k_pd_heads(i64 n, const u64 *__restrict__ key, int gshift, i32 *
 	if (i == 0 || (i32)(key[i - 1] >> gshift) != g) g_beg[g] = (i32)i;
 	if (i == n - 1) g_beg[g + 1] = (i32)n;
 }
-__global__ void k_pd_gather(i64 n, const u64 *__restrict__ key, const u32 *__restrict__ perm, const u64 *__restrict__ hkey, const u32 *__restrict__ hval, int gshift, int qbits, i32 qlen,
+__global__ void k_pd_gather(i64 n, const u64 *__restrict__ key, const u32 *__restrict__ perm, const u64 *__restrict__ hkey, const u32 *__restrict__ hval, int gshift, int qbits, Bundle bnd,
                             const i32 *__restrict__ g_beg, i32 *a_q, i32 *a_len, i64 *a_r, i32 *a_gb, i32 *a_ge, u32 *bm)
 {
 	GID(n);
 	const u32 src = perm[i];
 	const u64 k = hkey[src];
-	const i32 q = (i32)(k & ((1ull << qbits) - 1)); const i64 pd = (i64)(k >> qbits) - qlen;
+	const i32 q = (i32)(k & ((1ull << qbits) - 1)); const i64 pdk = (i64)(k >> qbits);
+	i64 pd = pdk - bnd.lmax;                        // rPos - q  (a bundle: q is the position in the concatenation, see Bundle)
+	if (bnd.n) { const i32 ci = bnd.chunk_contig[q / GSA_CHUNK]; pd -= (i64)bnd.off[ci] + (i64)ci * bnd.pds; }
 	a_q[i] = q; a_len[i] = (i32)(hval[src] & 0xffffu); a_r[i] = pd + q;
-	bm[(pd + qlen) >> 5] = 0;                       // (the bitmap is done with: wiped for the next contig by the hits that set it)
+	bm[pdk >> 5] = 0;                               // (the bitmap is done with: wiped for the next contig by the hits that set it)
 	const i32 g = (i32)(key[i] >> gshift);
 	a_gb[i] = g_beg[g]; a_ge[i] = g_beg[g + 1];
 }
@@ -335,7 +337,7 @@ __global__ void k_window_mode(i64 cap, const Bucket *__restrict__ tab, unsigned 
 // (the seeds of a window are neighbours: their contributions are summed along the wavefront first, one pair of atomics
 //  per window and wavefront instead of one per seed)
 __global__ void k_window_avg(i64 na, const i32 *__restrict__ slot_of, const Bucket *__restrict__ tab, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r,
-                             const unsigned long long *__restrict__ wbest, const i32 *__restrict__ ws, const i32 *__restrict__ wsEx, unsigned long long *wsum, i32 *wn)
+                             const unsigned long long *__restrict__ wbest, const i32 *__restrict__ ws, const i32 *__restrict__ wsEx, unsigned long long *wsum, i32 *wn, Bundle bnd)
 {
 	const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
 	const int lane = threadIdx.x & 63;
@@ -345,7 +347,7 @@ __global__ void k_window_avg(i64 na, const i32 *__restrict__ slot_of, const Buck
 		const i32 sl = slot_of[i];
 		if (sl >= 0) {
 			const i64 kk = (i64)(u32)tab[sl].key, mode = (i64)(0xFFFFFFFFu - (u32)wbest[w]);      // (shifted buckets: only their difference is used)
-			if (d_llabs(kk - mode) < 3) { vs = (unsigned long long)(a_r[i] - a_q[i]); vn = 1; }     // surviving bucket (:256)
+			if (d_llabs(kk - mode) < 3) { vs = (unsigned long long)(a_r[i] - a_q[i] + bundle_off(bnd, a_q[i])); vn = 1; }     // surviving bucket (:256); the TRUE PosDiff: the mean truncates toward zero
 		}
 	}
 	for (int d = 1; d < 64; d <<= 1) {
@@ -358,7 +360,7 @@ __global__ void k_window_avg(i64 na, const i32 *__restrict__ slot_of, const Buck
 
 __global__ void k_outlier_kill(i64 na, const i32 *__restrict__ slot_of, const Bucket *__restrict__ tab, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r,
                                const unsigned long long *__restrict__ wbest, const unsigned long long *__restrict__ wsum, const i32 *__restrict__ wn,
-                               i64 G, i32 max_indel, i32 *alive)
+                               i64 G, i32 max_indel, i32 *alive, Bundle bnd)
 {
 	GID(na);
 	const i32 sl = slot_of[i];
@@ -367,7 +369,7 @@ __global__ void k_outlier_kill(i64 na, const i32 *__restrict__ slot_of, const Bu
 	const i64 kk = (i64)(u32)k, mode = (i64)(0xFFFFFFFFu - (u32)wbest[w]);
 	const i32 cnt = d_llabs(kk - mode) < 3 ? (i32)(tab[sl].cnt + 1u) : 0;       // counts are read after zeroing (App. B #23)
 	const i64 avg = wn[w] > 0 ? (i64)wsum[w] / wn[w] : G;                      // C division: truncation toward zero
-	const i64 pd = a_r[i] - a_q[i];
+	const i64 pd = a_r[i] - a_q[i] + bundle_off(bnd, a_q[i]);
 	if (d_llabs(avg - pd) > max_indel && cnt < 3) alive[i] = 0;               // GSAlign.cpp:290, Min_PD_Freq = 3
 }
 
@@ -380,7 +382,7 @@ struct OpAliveUnique {      // ranks of the alive unique seeds
 };
 
 __global__ void k_multihit(i64 na, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge,
-                           const i32 *__restrict__ auEx, const i32 *__restrict__ aulist, i64 G, i32 max_indel, i32 *alive)
+                           const i32 *__restrict__ auEx, const i32 *__restrict__ aulist, i64 G, i32 max_indel, i32 *alive, Bundle bnd)
 {
 	GID(na);
 	const i32 gb = a_gb[i], ge = a_ge[i], q = a_q[i];
@@ -389,9 +391,11 @@ __global__ void k_multihit(i64 na, const i32 *__restrict__ a_q, const i64 *__res
 	i64 s1 = 0, s2 = 0; i32 n1 = 0, n2 = 0;
 	for (i32 k = auEx[i] - 1; k >= auEx[gb] && n1 < 5; k--) { const i32 s = aulist[k]; s1 += a_r[s] - a_q[s]; n1++; }
 	for (i32 k = auEx[j]; k < auEx[ge] && n2 < 5; k++) { const i32 s = aulist[k]; s2 += a_r[s] - a_q[s]; n2++; }
-	const i64 avg = (n1 > 0 || n2 > 0) ? (s1 + s2) / (n1 + n2) : (a_r[i] - q);
+	// (a bundle: a group lies in one contig; the mean is taken over TRUE PosDiff values -- C division truncates toward zero)
+	const i64 o = bundle_off(bnd, q);
+	const i64 avg = (n1 > 0 || n2 > 0) ? (s1 + s2 + o * (n1 + n2)) / (n1 + n2) : (a_r[i] - q + o);
 	i32 idx = -1; i64 md = G;
-	for (i32 k = (i32)i; k < j; k++) { const i64 d = d_llabs((a_r[k] - q) - avg); if (d < max_indel && d < md) { md = d; idx = k; } }
+	for (i32 k = (i32)i; k < j; k++) { const i64 d = d_llabs((a_r[k] - q + o) - avg); if (d < max_indel && d < md) { md = d; idx = k; } }
 	for (i32 k = (i32)i; k < j; k++) if (k != idx) alive[k] = 0;
 }
 
@@ -631,7 +635,7 @@ int stage2_chain(gsa_ctx *c)
 		LAUNCH(k_pd_keys, n, n, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->d_pdbm.as<u32>(), c->d_gpre.as<i32>(), c->prm.MaxIndelSize, c->qbits, c->d_key_c.as<u64>(), c->d_val_c.as<u32>());
 		RC(prim_sort_pairs_u64_u32(c, c->d_key_c.as<u64>(), c->d_key_b.as<u64>(), c->d_val_c.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + 7 + gbits));
 		LAUNCH(k_pd_heads, n, n, c->d_key_b.as<u64>(), c->qbits + 7, c->g_beg.as<i32>());
-		LAUNCH(k_pd_gather, n, n, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->qbits + 7, c->qbits, c->qlen, c->g_beg.as<i32>(),
+		LAUNCH(k_pd_gather, n, n, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->qbits + 7, c->qbits, c->bnd, c->g_beg.as<i32>(),
 		       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), c->d_pdbm.as<u32>());
 		c->pdbm_dirty = false;
 	} else {
@@ -675,13 +679,13 @@ int stage2_chain(gsa_ctx *c)
 	                         c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>() }; RC((lb_launch<1>(c, na, op))); }
 	LAUNCH(k_window_mode, cap, cap, c->d_btab.as<Bucket>(), c->w_best.as<unsigned long long>());
 	LAUNCH(k_window_avg, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(), c->w_best.as<unsigned long long>(), ws, wsEx,
-	       c->w_sum.as<unsigned long long>(), c->w_n.as<i32>());
+	       c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->bnd);
 	LAUNCH(k_outlier_kill, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(),
-	       c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->G, c->prm.MaxIndelSize, alive);
+	       c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->G, c->prm.MaxIndelSize, alive, c->bnd);
 	// D. multi-hit positions
 	i32 *auEx = c->a_aurank.as<i32>(), *aulist = c->a_aulist.as<i32>();
 	{ OpAliveUnique op = { na, uniq, alive, auEx, aulist }; RC((lb_launch<1>(c, na, op))); }
-	LAUNCH(k_multihit, na, na, c->a_q.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), auEx, aulist, c->G, c->prm.MaxIndelSize, alive);
+	LAUNCH(k_multihit, na, na, c->a_q.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), auEx, aulist, c->G, c->prm.MaxIndelSize, alive, c->bnd);
 	// E. compaction #1, noise stencil + compaction #2 (counts stay in the mailbox)
 	ENS(i32, b_q, na); ENS(i32, b_len, na); ENS(i64, b_r, na); ENS(i32, b_gb, na);
 	{ OpCompactAlive op = { alive, c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(),

@@ -294,6 +294,22 @@ __global__ void __launch_bounds__(256) k_materialize_large(i32 nlarge, const i32
 	if (threadIdx.x == 0) { patch[3 * g] = (i32)i; patch[3 * g + 1] = L; patch[3 * g + 2] = sc; }
 }
 
+// A bundle of contigs (Bundle, gsa_internal.h): the records as they travel carry query positions and string offsets relative to
+// THEIR contig (what gsa_align_contig of that contig alone returns); the device works on positions in the concatenation and on
+// one string pool.  One thread per record, on the records' way out; the pool offset of every contig goes to pinned memory.
+__global__ void __launch_bounds__(256) k_bundle_rebase(i64 ub, const i32 *__restrict__ nf_ptr, i32 nfb, const i32 *__restrict__ fragbase, const i32 *__restrict__ bcontig, const i32 *__restrict__ blk0,
+                                                        const i32 *__restrict__ off, const i64 *__restrict__ aoff, gsa_rec *rec16, i64 *h_a0)
+{
+	GID(ub);
+	if (i >= nf_ptr[0]) return;
+	const i32 k = find_block(fragbase, nfb, i), ci = bcontig[k];
+	const i64 f0 = fragbase[blk0[ci]], a0 = aoff[f0];
+	gsa_rec r = rec16[i];
+	if (r.seed.qpos >= 0) r.seed.qpos -= off[ci]; else r.gap.aln_off -= (u32)a0;
+	rec16[i] = r;
+	if (i == f0) h_a0[ci] = a0;
+}
+
 i64 frags_count(gsa_ctx *c)
 {
 	if (c->n_frags < 0) {
@@ -332,6 +348,16 @@ int stage7_fill(gsa_ctx *c)
 	//  contigs in flight are bound by exactly that)
 	ENS(i32, fb_seedbase, 2 * (size_t)nfb + 2); ENS(i32, bl_alnlen, 3 * (size_t)nfb + 3);
 	GSA_CHECK(c, hipMemcpyAsync(c->fb_seedbase.p, seedbase, (size_t)(2 * nfb + 1) * 4, hipMemcpyHostToDevice, st));
+	if (c->bnd.n) {
+		// contig of every final block | first block of every contig: what k_bundle_rebase needs on the records' way out
+		const size_t nt = (size_t)nfb + (size_t)c->bnd.n + 1;
+		if (!pin_ensure<i32>(c, c->p_bblk, nt) || !pin_ensure<i64>(c, c->p_ba0, (size_t)c->bnd.n + 1)) return GSA_ERR_NOMEM;
+		ENS(i32, d_bblk, nt);
+		i32 *t = c->p_bblk.as<i32>();
+		for (int k = 0; k < c->bnd.n; k++) for (i32 b = c->b_blk0[(size_t)k]; b < c->b_blk0[(size_t)k + 1]; b++) t[b] = k;
+		for (int k = 0; k <= c->bnd.n; k++) t[(size_t)nfb + (size_t)k] = c->b_blk0[(size_t)k] < nfb ? c->b_blk0[(size_t)k] : nfb - 1;
+		GSA_CHECK(c, hipMemcpyAsync(c->d_bblk.p, t, nt * 4, hipMemcpyHostToDevice, st));
+	}
 	i32 *d_sbeg = c->fb_seedbase.as<i32>() + nfb + 1, *d_fragbase = c->bl_alnlen.as<i32>() + 2 * (size_t)nfb;      // bl_alnlen[nfb] | bl_score[nfb] | fragbase[nfb + 1]
 	const i64 nfu = c->nf_ub;
 	ENS(gsa_frag, f_rec, nfu + 1); ENS(i32, f_type, nfu + 1); ENS(i32, f_mism, nfu + 1); ENS(i32, f_score, nfu + 1); ENS(i32, f_job, nfu + 1); ENS(i32, f_alnlen, nfu + 1);
@@ -381,6 +407,9 @@ int stage78_extend(gsa_ctx *c)
 	// The records leave only now, behind the host's look at the size classes: a 166 MB copy (a 250 Mb contig) in flight keeps
 	// the link busy for 3 ms, and the few bytes the classification pass stores into pinned memory for that look queued
 	// behind it -- the small-DP kernels started 3 ms late.  (Since round 3 the records travel as 16-byte gsa_rec: 66 MB.)
+	if (c->bnd.n)
+		hipLaunchKernelGGL(k_bundle_rebase, dim3(grid_for((size_t)nfu, TPB)), dim3(TPB), 0, sc, nfu, mail + M_NF, nfb, d_fragbase, c->d_bblk.as<i32>(), c->d_bblk.as<i32>() + nfb,
+		                   c->bnd.off, c->d_alnoff.as<i64>(), c->f_rec16.as<gsa_rec>(), c->p_ba0.as<i64>());
 	GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec16.p, (size_t)nfu * sizeof(gsa_rec), hipMemcpyDeviceToHost, sc));
 	const i32 *hm = c->p_dp.as<i32>();
 	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN]; c->n_large = kl.nlarge;

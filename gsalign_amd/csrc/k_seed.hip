@@ -871,10 +871,11 @@ __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ c
 #define SEL_HASH 256
 __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, const u32 *__restrict__ cand_cnt, const i32 *__restrict__ cand_s, const i32 *__restrict__ cand_len,
                                                       const u64 *__restrict__ cand_x0, const i32 *__restrict__ cand_freq, const u32 *__restrict__ onpath,
-                                                      const i32 *__restrict__ hit_base, i32 qlen, i32 s_off, int qbits, u64 *key, u32 *val, u32 *pdbm)
+                                                      const i32 *__restrict__ hit_base, Bundle bnd, i32 s_off, int qbits, u64 *key, u32 *val, u32 *pdbm)
 {
-	// (qlen = length of the whole contig, s_off = contig position of the first chunk searched: not 0 when only a chunk range
-	//  of the contig was seeded on this GPU, gsa_seed_chunks)
+	// (bnd.lmax = length of the whole contig, s_off = contig position of the first chunk searched: not 0 when only a chunk range
+	//  of the contig was seeded on this GPU, gsa_seed_chunks.  A bundle of contigs: the key's PosDiff is the true one of the
+	//  chunk's contig plus that contig's stride, see Bundle)
 	extern __shared__ u32 s_offs[];                    // exclusive prefix of the hit counts of the chunk's candidates (0 for off-chain ones), [nc + 1]
 	__shared__ unsigned long long s_w[SEL_HASH]; __shared__ u32 s_b[SEL_HASH];
 	__shared__ u32 s_wsum[4], s_run;
@@ -906,6 +907,8 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 	if (j == 0) s_offs[nc] = total;
 	__syncthreads();
 	const u64 base = (u64)hit_base[chunk];
+	i64 pd_base = bnd.lmax;                              // key = rPos - qPos + pd_base
+	if (bnd.n) { const i32 ci = bnd.chunk_contig[chunk]; pd_base += (i64)bnd.off[ci] + (i64)ci * bnd.pds; }
 	__shared__ unsigned long long s_r[256];                  // located positions of the 256 hits in flight: a hit ranks itself among its siblings from here
 	for (u32 t0 = 0; t0 < total; t0 += 256) {
 		const u32 t = t0 + j;
@@ -921,7 +924,7 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 		s_r[j] = r;
 		__syncthreads();
 		if (t < total) {
-		const i64 pd = (i64)r - s + qlen;
+		const i64 pd = (i64)r - s + pd_base;
 		u32 rank = 0;
 		if (f > 1) {
 			const u32 first = t - h;                            // hit index of sibling 0
@@ -986,18 +989,19 @@ __global__ void __launch_bounds__(256) k_count_lf(DevIndex di, u32 cand_cap, con
 // sorted keys -> SoA seeds + group ids (SeedGrouping, a6): one fused pass (gsa_scan.h); a new group
 // starts where PosDiff jumps by more than MaxIndelSize
 struct OpDecodeGroup {
-	i64 n; const u64 *key; const u32 *val; i32 qlen; int qbits; i32 max_indel;
+	i64 n; const u64 *key; const u32 *val; Bundle bnd; int qbits; i32 max_indel;
 	i32 *s_q, *s_len; i64 *s_r; i32 *s_gid, *g_beg, *mail;
 	__device__ i32 value(i64 i, int) const
 	{
 		if (i == 0) return 1;
-		const i64 pd = (i64)(key[i] >> qbits) - qlen, pd0 = (i64)(key[i - 1] >> qbits) - qlen;
+		const i64 pd = (i64)(key[i] >> qbits), pd0 = (i64)(key[i - 1] >> qbits);      // (a bundle: the stride between contigs exceeds max_indel)
 		return (pd - pd0 > max_indel) ? 1 : 0;
 	}
 	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
 	{
 		const u64 k = key[i];
-		const i32 qp = (i32)(k & ((1ull << qbits) - 1)); const i64 pd = (i64)(k >> qbits) - qlen;
+		const i32 qp = (i32)(k & ((1ull << qbits) - 1)); i64 pd = (i64)(k >> qbits) - bnd.lmax;
+		if (bnd.n) { const i32 ci = bnd.chunk_contig[qp / GSA_CHUNK]; pd -= (i64)bnd.off[ci] + (i64)ci * bnd.pds; }      // rPos - qp
 		s_q[i] = qp; s_len[i] = (i32)(val[i] & 0xffffu); s_r[i] = pd + qp;
 		const i32 g = ex[0] + v[0] - 1;
 		s_gid[i] = g;
@@ -1169,7 +1173,7 @@ template <class T> static T *dev_grow_keep(gsa_ctx *c, DevBuf &b, size_t n, size
 // Groups without the PosDiff sort: decide whether the bitmap of occupied PosDiff values is kept for this contig and clear it
 static int prepare_pd_bitmap(gsa_ctx *c, i64 n_hits)
 {
-	const u64 pd_words = (((u64)(2 * c->G) + (u64)c->qlen + 2) >> 5) + 2;
+	const u64 pd_words = ((u64)c->pd_span >> 5) + 2;
 	// (a chunk range: the hit count of the whole contig is not known here; the bitmap is kept whenever MaxIndelSize allows it)
 	c->pd_path = (n_hits > 0 || c->split) && c->prm.MaxIndelSize >= 0 && c->prm.MaxIndelSize <= 31 && (c->split || pd_words <= 64ull * (u64)n_hits + 65536) && !getenv("GSA_NO_PDBITMAP");
 	c->seed_view_ready = false;
@@ -1284,7 +1288,7 @@ int stage1_seed(gsa_ctx *c)
 	if (n_hits > 0) {
 		if (!dev_ensure<u64>(c, c->d_key_a, hcap) || !dev_ensure<u32>(c, c->d_val_a, hcap)) return GSA_ERR_NOMEM;
 		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), (ccap + 2) * sizeof(u32), st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
-		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), qlen_full, s_off, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr);
+		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), c->bnd, s_off, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr);
 	}
 	if (c->profiling) hipEventRecord(c->ev[2], st);
 	u64 lf_steps = 0;
@@ -1316,7 +1320,6 @@ int seed_view_sort(gsa_ctx *c)
 {
 	if (c->seed_view_ready || c->n_seeds == 0) return GSA_OK;
 	hipStream_t st = c->stream;
-	const i32 qlen = c->qlen;
 	const size_t n = (size_t)c->n_seeds, hcap = n + 64;
 	if (!dev_ensure<u64>(c, c->d_key_b, hcap) || !dev_ensure<u32>(c, c->d_val_b, hcap)) return GSA_ERR_NOMEM;
 	int rc = prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), n, 0, c->qbits + c->pdbits);
@@ -1324,7 +1327,7 @@ int seed_view_sort(gsa_ctx *c)
 	if (!dev_ensure<i32>(c, c->s_q, n) || !dev_ensure<i32>(c, c->s_len, n) || !dev_ensure<i64>(c, c->s_r, n) || !dev_ensure<i32>(c, c->s_gid, n) ||
 	    !dev_ensure<i32>(c, c->d_flag, n + 1) || !dev_ensure<i32>(c, c->d_scan, n + 1) || !dev_ensure<i32>(c, c->g_beg, n + 1)) return GSA_ERR_NOMEM;
 	{
-		OpDecodeGroup op = { (i64)n, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), qlen, c->qbits, c->prm.MaxIndelSize,
+		OpDecodeGroup op = { (i64)n, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), c->bnd, c->qbits, c->prm.MaxIndelSize,
 		                     c->s_q.as<i32>(), c->s_len.as<i32>(), c->s_r.as<i64>(), c->s_gid.as<i32>(), c->g_beg.as<i32>(), c->d_mail.as<i32>() };
 		rc = lb_launch<1>(c, (i64)n, op);
 		if (rc) return rc;

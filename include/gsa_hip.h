@@ -183,12 +183,22 @@ typedef int (*gsa_result_fn)(void *user, int32_t contig, const gsa_result *res);
 #define GSA_MANY_IN_ORDER 1u   /* hand the contigs out in the order given (default: longest first) */
 #define GSA_MANY_DEVICE   2u   /* query[] are device pointers (gsa_align_contig_device); all contexts on one GPU */
 #define GSA_MANY_NO_SPLIT 4u   /* never seed one contig on several contexts (see below) */
+#define GSA_MANY_NO_BUNDLE 8u  /* never align several short contigs in one pass (see gsa_align_bundle) */
 /* With FEWER contigs than contexts (one chromosome, two GPUs: BASELINE configs[3]) the contexts are dealt out in groups, one
  * group per contig, sized by contig length, and a contig of at least 20 Mb (GSA_SPLIT_MIN) is seeded by chunk range on all
  * contexts of its group -- gsa_seed_chunks ... gsa_finish_contig below, driven from the library's own threads, hits moved
  * device to device (peer to peer between GPUs).  Results do not depend on the grouping. */
 int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n,
                    uint32_t flags, gsa_result_fn on_result, void *user);
+
+/* Several contigs in ONE pass.  The reference clears all per-sequence state between query sequences (GSAlign.cpp:483-490), so
+ * contigs are independent; a short contig costs the GPU ~60 operations whatever its size, so short contigs are concatenated
+ * (each padded with N to a 10 000-bp chunk edge: IdentifyLocalMEM's chunk grid restarts per sequence, GSAlign.cpp:61-94) and go
+ * through all stages together; seed groups never span contigs, AlnBlockVec is kept per contig.  out[k] is EXACTLY what
+ * gsa_align_contig(query[k]) returns -- positions, record and string offsets relative to contig k -- and stays valid until the
+ * next call on ctx.  n <= 4096, total length < 2^31.  flags: GSA_MANY_DEVICE (query[] are device pointers on ctx's GPU).
+ * gsa_align_many bundles contigs of at most 16 Mb by itself (GSA_BUNDLE_CONTIG; bundles of at most GSA_BUNDLE_CAP = 32 Mb). */
+int gsa_align_bundle(gsa_ctx *ctx, const char *const *query, const int32_t *qlen, int32_t n, uint32_t flags, gsa_result *out);
 
 /* ---- one long contig on several GPUs ---------------------------------------
  * IdentifyLocalMEM hands 10 000-bp chunks of the contig to whichever thread is free (GSAlign.cpp:61-94) and seeds never
