@@ -603,11 +603,13 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 	// Short contigs travel in BUNDLES: a contig of a few Mb is ~60 GPU operations whatever its size, and with several contexts in
 	// flight the operations of one stretch the other's (profiles/r03_timeline_multi_*.txt), so n short contigs are concatenated and
 	// go through the stages as ONE pass (set_query_bundle / gsa_align_bundle; results per contig, identical to the ones they get
-	// alone).  A unit of work = a long contig, or a bundle of consecutive short ones in hand-out order.  Bundle size: large enough
-	// to amortise the operations, small enough that every context gets about three units (GSA_BUNDLE_CAP bases at most, default
-	// 32 Mb; contigs above GSA_BUNDLE_CONTIG, default 16 Mb, stay alone; GSA_BUNDLE_CONTIG=0 or GSA_MANY_NO_BUNDLE: no bundles).
+	// alone).  A unit of work = a long contig, or a bundle of consecutive short ones in hand-out order.  Bundle size: measured on
+	// 5 Mb contigs, larger is better all the way (6 / 11 / 16 / 21 / 31 / 60 Mb per bundle: 5.3 / 7.6 / 9.7 / 10.8 / 13.9 / 16.0 Gbp/s on
+	// one context, profiles/r03_bundle_sweep.txt), so the short contigs are dealt into as few bundles as GSA_BUNDLE_CAP (default
+	// 64 Mb) allows, rounded up to a multiple of the context count (one equal share per context).  Contigs above
+	// GSA_BUNDLE_CONTIG (default 16 Mb) stay alone; GSA_BUNDLE_CONTIG=0 or GSA_MANY_NO_BUNDLE: no bundles.
 	static const int64_t bundle_contig = [] { const char *e = getenv("GSA_BUNDLE_CONTIG"); return e ? (int64_t)atoll(e) : 16000000ll; }();
-	static const int64_t bundle_cap = [] { const char *e = getenv("GSA_BUNDLE_CAP"); return e ? (int64_t)atoll(e) : 32000000ll; }();
+	static const int64_t bundle_cap = [] { const char *e = getenv("GSA_BUNDLE_CAP"); return e ? (int64_t)atoll(e) : 64000000ll; }();
 	std::vector<std::vector<int32_t> > units;
 	{
 		bool may = !(flags & GSA_MANY_NO_BUNDLE) && bundle_contig > 0;
@@ -615,14 +617,18 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 		int64_t small_total = 0; int32_t n_small = 0;
 		for (int32_t i = 0; i < n; i++) if ((int64_t)qlen[i] <= bundle_contig) { small_total += qlen[i]; n_small++; }
 		if (n_small < 2) may = false;
-		int64_t target = small_total / (3 * (int64_t)n_ctx); if (target > bundle_cap) target = bundle_cap;
+		static const int64_t bundle_target = [] { const char *e = getenv("GSA_BUNDLE_TARGET"); return e ? (int64_t)atoll(e) : 0ll; }();      // (experiments: a fixed bundle size)
+		int64_t n_bundles = (small_total + bundle_cap - 1) / (bundle_cap > 0 ? bundle_cap : 1); if (n_bundles < 1) n_bundles = 1;
+		n_bundles = (n_bundles + n_ctx - 1) / n_ctx * n_ctx;
+		int64_t target = small_total / n_bundles + 1;
+		if (bundle_target > 0) target = bundle_target;
 		int64_t cur = 0;
 		for (int32_t i = 0; i < n; i++) {
 			const int32_t ci = order[(size_t)i];
 			const bool small = may && (int64_t)qlen[ci] <= bundle_contig;
 			if (!small) { units.push_back(std::vector<int32_t>(1, ci)); cur = 0; continue; }
 			const int64_t padded = ((int64_t)qlen[ci] + GSA_CHUNK - 1) / GSA_CHUNK * GSA_CHUNK;
-			if (cur > 0 && (cur + padded > target || units.back().size() >= GSA_BUNDLE_MAX_CONTIGS)) cur = 0;
+			if (cur > 0 && (cur + padded / 2 > target || cur + padded > bundle_cap + bundle_cap / 8 || units.back().size() >= GSA_BUNDLE_MAX_CONTIGS)) cur = 0;      // (to the nearest contig)
 			if (cur == 0) units.push_back(std::vector<int32_t>());
 			units.back().push_back(ci); cur += padded > 0 ? padded : 1;
 		}

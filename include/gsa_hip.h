@@ -197,7 +197,7 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
  * through all stages together; seed groups never span contigs, AlnBlockVec is kept per contig.  out[k] is EXACTLY what
  * gsa_align_contig(query[k]) returns -- positions, record and string offsets relative to contig k -- and stays valid until the
  * next call on ctx.  n <= 4096, total length < 2^31.  flags: GSA_MANY_DEVICE (query[] are device pointers on ctx's GPU).
- * gsa_align_many bundles contigs of at most 16 Mb by itself (GSA_BUNDLE_CONTIG; bundles of at most GSA_BUNDLE_CAP = 32 Mb). */
+ * gsa_align_many bundles contigs of at most 16 Mb by itself (GSA_BUNDLE_CONTIG; bundles of about GSA_BUNDLE_CAP = 64 Mb at most). */
 int gsa_align_bundle(gsa_ctx *ctx, const char *const *query, const int32_t *qlen, int32_t n, uint32_t flags, gsa_result *out);
 
 /* ---- one long contig on several GPUs ---------------------------------------

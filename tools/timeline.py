@@ -22,7 +22,11 @@ def main(path, verbose=False):
             ops.append((r[0], r[1], f"<copy {r[2] if sz else ''}>"))
     ops.sort()
     # last step = ops after the last k_seed_wg launch
-    idx = [i for i, o in enumerate(ops) if "k_seed_wg" in o[2]]
+    idx = [i for i, o in enumerate(ops) if "k_seed_wgILb0" in o[2] or "k_dense_searchILb" in o[2] or ("k_dense_sweep" in o[2])]      # (not the accounting build k_seed_wg<true, .>)
+    if idx:      # a pass may launch the speculative kernel AND a dense one: the step starts at the first seed launch behind the last k_seed_select in front of it
+        sel = [i for i, o in enumerate(ops) if "k_seed_select" in o[2] and i < idx[-1]]
+        first = [i for i in idx if not sel or i > sel[-1]]
+        idx = [first[0]] if first else idx
     if not idx:
         print("no seed kernel found"); return
     step = ops[idx[-1]:]
