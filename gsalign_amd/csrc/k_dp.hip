@@ -761,6 +761,21 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	std::vector<LgJob> large((const LgJob *)(h + MAIL_N), (const LgJob *)(h + MAIL_N) + nlarge);
 	hipEvent_t ev_fork = c->ev[10], ev_j2 = c->ev[12];
 	// the many small jobs run on a second stream, concurrently with the striped ones
+	static const int dp_order = [] { const char *e = getenv("GSA_DP_ORDER"); return e ? atoi(e) : 0; }();      // experiment: 1 = tiny, small, then the stripes, one after the other on the caller's stream
+	if (nsmall + ntiny > 0 && dp_order == 1) {
+		if (ntiny > 0) {
+			const unsigned nb = (unsigned)((ntiny + 4 * TINY_WAVES - 1) / (4 * TINY_WAVES));
+			hipLaunchKernelGGL(k_dp_tiny, dim3(nb), dim3(64 * TINY_WAVES), 0, st, ntiny, d_order_tiny, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag);
+		}
+		if (nsmall > 0) {
+			const unsigned nb = (unsigned)((nsmall + SMALL_WAVES - 1) / SMALL_WAVES);
+			hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, st, nsmall, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag);
+		}
+		GSA_CHECK(c, hipGetLastError());
+		GSA_CHECK(c, hipEventRecord(ev_j2, st));
+		GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], ev_j2, 0));
+		out->small_in_flight = true;
+	} else
 	if (nsmall + ntiny > 0) {
 		GSA_CHECK(c, hipEventRecord(ev_fork, st));
 		GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], ev_fork, 0));
