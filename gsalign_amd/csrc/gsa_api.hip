@@ -171,7 +171,7 @@ void gsa_destroy(gsa_ctx *c)
 		&c->fb_seedbase, &c->fb_sbeg, &c->fb_fragbase, &c->f_rec, &c->f_rec16, &c->f_type, &c->f_mism, &c->f_alnlen, &c->f_job, &c->f_score,
 		&c->d_dp_tiny, &c->d_dp_bnd, &c->d_dp_ctr, &c->d_dp_jobs, &c->d_dp_large, &c->d_tail,
 		&c->e_id, &c->e_rec, &c->e_list, &c->e_off1, &c->e_off2, &c->e_opsoff, &c->e_nops, &c->e_ops, &c->e_rev, &c->r_head, &c->f_early, &c->r_orig, &c->r_tmp_orig, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_alnoff, &c->bl_alnlen, &c->bl_score,
-		&c->d_bndtab, &c->d_bblk,
+		&c->d_bndtab, &c->d_bblk, &c->d_dp_arena,
 		&c->leaf[0], &c->leaf[1], &c->leaf[2], &c->leaf[3], &c->leaf[4], &c->leaf[5], &c->leaf[6], &c->leaf[7], &c->leaf[8] };
 	// (a gsa_clone context borrows the index through `di` only: its index DevBufs are empty, a presence bitmap it built after
 	//  a parameter change is its own)

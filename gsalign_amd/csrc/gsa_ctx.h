@@ -142,6 +142,7 @@ struct gsa_ctx {
 	DevBuf f_type, f_mism, f_alnlen, f_job, f_score;
 	DevBuf j_frag, j_opsoff, j_nops, d_ops, j_cells;
 	DevBuf d_dp_tiny;                              // order array of the four-per-wavefront DP kernel
+	DevBuf d_dp_arena;                             // k_dp_lane: direction nibbles of the alignments in flight (per-wave regions)
 	DevBuf d_dp_bnd, d_dp_ctr, d_dp_jobs, d_dp_large;   // striped DP: boundary granules, tickets, job descriptors, (job,m,n) of the large jobs
 	// large DP gaps are known once the leaf table exists: they are launched there (stream_aux[0]) and run under stages 6-7
 	DevBuf e_id, e_rec, e_list, e_off1, e_off2, e_opsoff, e_nops, e_ops, e_rev, r_head, f_early, r_orig, r_tmp_orig, p_early;
@@ -166,7 +167,7 @@ template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 	size_t bytes = (n ? n : 1) * sizeof(T);
 	if (bytes <= b.cap) return (T *)b.p;
 	if (b.p) { hipStreamSynchronize(c->stream); hipFree(b.p); b.p = nullptr; b.cap = 0; }
-	size_t want = bytes + bytes / 4 + 256;
+	size_t want = bytes + bytes / 2 + 256;      // (half again: a context that meets a somewhat larger contig or bundle than it has seen does not stop to reallocate)
 	if (hipMalloc(&b.p, want) != hipSuccess) { gsa_fail(c, GSA_ERR_NOMEM, "hipMalloc"); return nullptr; }
 	b.cap = want;
 	return (T *)b.p;

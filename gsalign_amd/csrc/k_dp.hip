@@ -168,6 +168,146 @@ __global__ void __launch_bounds__(64 * TINY_WAVES) k_dp_tiny(i32 n_jobs, const i
 }
 
 // ---------------------------------------------------------------------------
+// k_dp_lane (round 3): ONE LANE PER ALIGNMENT for everything below the striped kernel (n <= 64, m + n - 1 <= 128: 360 000 jobs and
+// 104 M cells of a human-sized contig -- 7 % of the cells, but k_dp_small / k_dp_tiny spent 4.7 VALU instructions per cell on them,
+// ten times the striped kernel: a systolic wave has 23 of 64 lanes busy on the median job, moves three values by DPP per step and
+// walks back on one lane).  A lane needs no neighbour: cell (i, j) takes x, v from the cell on its left (registers) and u, y from
+// the cell above (one 16-bit LDS entry per column, with the query base's code), row by row -- the same recurrence in another
+// order (dp_cell is order-free: gsa_dp.h), so every lane is busy on every instruction.  What has to be managed is balance: a
+// wavefront runs as long as its largest job.  A workgroup takes a tile of 512 jobs, counting-sorts it by cells (128 logarithmic
+// bins in LDS) and its four waves draw batches of 64 size-neighbours, largest first.  Direction nibbles go to a per-wave arena in
+// global memory (L2-resident: eight cells per dword, dword k of lane l at [k][l] -- coalesced), the traceback automaton reads them
+// back, the reversed op string is staged in the LDS of the (dead) column entries.
+// ---------------------------------------------------------------------------
+#define LANE_TILE 512
+#define LANE_BINS 128
+#define LANE_KMAX 576           // direction dwords of one job at most: m * ceil(n / 8) with n <= 64, m + n - 1 <= 128 (n = 57, m = 72)
+#define LANE_WGS 1024           // persistent workgroups (four per CU: 38 KB of LDS each)
+#define LANE_LDS_WAVE 8448      // 64 columns x 64 lanes x 2 bytes (forward)  |  (128 + 2) op bytes x 64 lanes (traceback)
+__device__ __forceinline__ u32 lane_bin(u32 cells)      // floor(8 log2 cells): 1 <= cells < 8192 -> 0 .. 103
+{
+	const int msb = 31 - __clz((int)cells);
+	const u32 frac = msb >= 3 ? (cells >> (msb - 3)) & 7u : (cells << (3 - msb)) & 7u;
+	return ((u32)msb << 3) | frac;
+}
+
+__global__ void __launch_bounds__(256) k_dp_lane(i32 n_tiny, const i32 *__restrict__ order_tiny, i32 n_small, const i32 *__restrict__ order_small,
+                                                  const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1, const i32 *__restrict__ len1,
+                                                  const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2, const i32 *__restrict__ len2,
+                                                  uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, const i32 *__restrict__ jfrag, gsa_frag *frag, u32 *arena_all)
+{
+	__shared__ u32 s_hist[LANE_BINS];
+	__shared__ i32 s_sorted[LANE_TILE];
+	__shared__ int s_next;
+	__shared__ __attribute__((aligned(16))) uint8_t s_work[4][LANE_LDS_WAVE];
+	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const i64 n_all = (i64)n_tiny + n_small;
+	u32 *arena = arena_all + ((size_t)blockIdx.x * 4 + w) * 64 * LANE_KMAX + lane;      // dword k of my job: arena[k * 64]
+	uint16_t *col = (uint16_t *)s_work[w] + lane;                                         // column i of my job: col[i * 64]
+	uint8_t *revb = s_work[w] + lane;                                                     // reversed op k of my job: revb[k * 64]
+	for (i64 t0 = (i64)blockIdx.x * LANE_TILE; t0 < n_all; t0 += (i64)gridDim.x * LANE_TILE) {
+		// ---- the tile's jobs, largest first (counting sort by cells) ----
+		if (tid < LANE_BINS) s_hist[tid] = 0;
+		if (tid == 0) s_next = 0;
+		__syncthreads();
+		i32 jb[LANE_TILE / 256]; u32 key[LANE_TILE / 256], rk[LANE_TILE / 256];
+#pragma unroll
+		for (int k = 0; k < LANE_TILE / 256; k++) {
+			const i64 idx = t0 + k * 256 + tid;
+			jb[k] = -1; key[k] = 0; rk[k] = 0;
+			if (idx < n_all) {
+				const i32 job = idx < n_tiny ? order_tiny[idx] : order_small[idx - n_tiny];
+				jb[k] = job; key[k] = lane_bin((u32)len1[job] * (u32)len2[job]); rk[k] = atomicAdd(&s_hist[key[k]], 1u);
+			}
+		}
+		__syncthreads();
+		if (tid < 64) {      // exclusive prefix over the bins in descending order (two bins per lane)
+			const u32 a = s_hist[LANE_BINS - 1 - 2 * lane], b = s_hist[LANE_BINS - 2 - 2 * lane];
+			u32 inc = a + b;
+			for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+			const u32 ex = inc - (a + b);
+			s_hist[LANE_BINS - 1 - 2 * lane] = ex; s_hist[LANE_BINS - 2 - 2 * lane] = ex + a;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int k = 0; k < LANE_TILE / 256; k++) if (jb[k] >= 0) s_sorted[s_hist[key[k]] + rk[k]] = jb[k];
+		__syncthreads();
+		const int nt = (int)(n_all - t0 < LANE_TILE ? n_all - t0 : LANE_TILE), nb = (nt + 63) >> 6;
+		for (;;) {
+			int b = 0;
+			if (lane == 0) b = atomicAdd(&s_next, 1);
+			b = __builtin_amdgcn_readfirstlane(b);
+			if (b >= nb) break;
+			const int p = b * 64 + lane;
+			const bool have = p < nt;
+			const i32 job = have ? s_sorted[p] : 0;
+			const int m = have ? len1[job] : 0, n = have ? len2[job] : 0;
+			const uint8_t *s1 = pool1 + off1[job], *s2 = pool2 + off2[job];
+			const int nw = (n + 7) >> 3;
+			// column entries: u (5 bits) | y << 5 (5 bits) | code of the query base << 10; before row 0: u = 2 (0 in column 0), y = 0
+			int nmax = n;
+			for (int o = 32; o; o >>= 1) { const int t = __shfl_xor(nmax, o); nmax = t > nmax ? t : nmax; }
+			for (int i = 0; i < nmax; i++) if (i < n) col[i * 64] = (uint16_t)((i ? 2 : 0) | (gsa_nt4(s2[i]) << 10));
+			// ---- forward: row j = reference base, column i = query base; x, v of the left neighbour in registers ----
+			bool act = have && m > 0 && n > 0;
+			int i = 0, j = 0, x = 0, v = 0, kk = 0;
+			u32 acc = 0;
+			int b_ = act ? gsa_nt4(s1[0]) : 4, b_next = (act && m > 1) ? gsa_nt4(s1[1]) : 4;
+			u32 e = act ? col[0] : 0;
+			while (__any(act)) {
+				if (act) {
+					const int inext = i + 1 < n ? i + 1 : 0;
+					const u32 e_next = col[inext * 64];      // (the entry above the next cell: independent of this one unless n == 1)
+					const int u = (int)(e & 31u), y = (int)((e >> 5) & 31u), a_ = (int)(e >> 10);
+					int un, vn, xn, yn;
+					const int d = dp_cell(x, v, u, y, a_, b_, un, vn, xn, yn);
+					const u32 en = (u32)un | ((u32)yn << 5) | ((u32)a_ << 10);
+					col[i * 64] = (uint16_t)en;
+					x = xn; v = vn;
+					acc |= (u32)((d & 3) | ((d & 0x18) >> 1)) << ((i & 7) << 2);
+					e = n == 1 ? en : e_next;
+					i = i + 1;
+					if ((i & 7) == 0 || i == n) { arena[(size_t)kk * 64] = acc; acc = 0; kk++; }
+					if (i == n) {
+						i = 0; j++; x = 0; v = 2;      // (left boundary of row j > 0: x = 0, v = 2; ksw2_alignment.cpp:157-164)
+						b_ = b_next;
+						if (j >= m) act = false; else b_next = j + 1 < m ? gsa_nt4(s1[j + 1]) : 4;
+					}
+				}
+			}
+			// ---- traceback (ksw_backtrack automaton, gsa_dp.h), one lane per job; the reversed ops go where the column entries were ----
+			int ti = n - 1, tj = m - 1, state = 0, k = 0;
+			bool tb = have && ti >= 0 && tj >= 0;
+			while (__any(tb)) {
+				if (tb) {
+					const u32 wd = arena[(size_t)(tj * nw + (ti >> 3)) * 64];
+					const u32 nbv = (wd >> ((ti & 7) << 2)) & 15u;
+					const u32 tmp = (nbv & 3u) | ((nbv & 0xCu) << 1);
+					int ns = state;
+					if (ns != 0 && !((tmp >> (ns + 2)) & 1)) ns = 0;
+					if (ns == 0) ns = (int)(tmp & 7);
+					state = ns;
+					const int isM = ns == 0 ? 1 : 0, isD = (ns == 1 || ns == 3) ? 1 : 0;
+					revb[k * 64] = (uint8_t)(isM ? 'M' : (isD ? 'D' : 'I'));
+					k++;
+					ti -= isM | isD; tj -= isM | (1 - isD);
+					tb = ti >= 0 && tj >= 0;
+				}
+			}
+			if (have) {
+				for (; ti >= 0; --ti) { revb[k * 64] = 'D'; k++; }
+				for (; tj >= 0; --tj) { revb[k * 64] = 'I'; k++; }
+				uint8_t *op = ops + ops_off[job];
+				for (int q = 0; q < k; q++) op[q] = revb[(k - 1 - q) * 64];
+				ops_len[job] = k;
+				if (frag) frag[jfrag[job]].aln_len = k;      // (the job's record is final with this)
+			}
+		}
+		__syncthreads();      // (the next tile reuses the bins and the sorted list)
+	}
+}
+
+// ---------------------------------------------------------------------------
 // k_dp_stripe: every alignment that does not fit the small kernel.  The n target
 // columns are cut into stripes of 64; ONE WAVEFRONT PER PAIR OF STRIPES, the pairs of a
 // job on whatever CUs the dispatcher picks (four pairs per workgroup), so a 1.5k x 1.5k
@@ -577,7 +717,9 @@ struct OpClassify {
 		if (j >= mail[M_NJOB]) return 0;
 		const i32 m = len1[j], n = len2[j];
 		if (c == 0) return dp_is_large(m, n) ? 1 : 0;
-		return (n <= 16 && m + n - 1 <= TINY_ROWS) ? 1 : 0;            // four of these share a wavefront
+		if (dp_is_large(m, n)) return 0;
+		if (lane_cells > 0) return m * n <= lane_cells ? 1 : 0;         // one lane each (k_dp_lane); the rest of the class: one wavefront each (k_dp_small)
+		return (n <= 16 && m + n - 1 <= TINY_ROWS) ? 1 : 0;            // (GSA_DP_LANE=0) four of these share a wavefront
 	}
 	__device__ void emit(i64 j, const i32 *v, const i32 *ex) const
 	{
@@ -591,7 +733,7 @@ struct OpClassify {
 	}
 	__device__ void done(const i32 *t) const { lb_pub(&mail[M_NLARGE], t[0]); lb_pub(&mail[M_NTINY], t[1]); }
 	// the last tile puts the mailbox and the head of the large-job list into pinned memory (the host launches from there)
-	i32 *h_out; i32 h_cap;
+	i32 *h_out; i32 h_cap; i32 lane_cells;
 	__device__ void finish(int tid) const
 	{
 		if (tid < MAIL_N) h_out[tid] = __hip_atomic_load(&mail[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -743,7 +885,11 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	if (!mail_clean) GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR, 0, 8 * sizeof(i32), st));                    // M_DPERR, M_NLARGE, M_DPERR2, -, M_CELLS (2 x u64): one aligned fill (28 bytes at an odd offset were three)
 	i32 *h = c->p_dp.as<i32>();
 	const size_t first_lg = (size_t)std::min<i64>(n_ub, LG_CHUNK);
-	{ OpClassify op = { len1, len2, d_order, d_order_tiny, d_lg, d_jlarge, mail, h, (i32)first_lg }; int rc = lb_launch<2>(c, n_ub, op); if (rc) return rc; }
+	// Size classes below the striped kernel: alignments of at most GSA_DP_LANE cells (default 512; swept 256 .. 8192: profiles/r03_dp_lane_sweep.txt) go one per LANE (k_dp_lane: every lane busy
+	// on every instruction; a lane walks its cells one after the other, so the largest job of a launch is its latency floor --
+	// 35 instructions per cell), the larger ones one per wavefront (k_dp_small).  GSA_DP_LANE=0: round 2's tiny / small split.
+	static const int dp_lane = [] { const char *e = getenv("GSA_DP_LANE"); return e ? atoi(e) : 512; }();
+	{ OpClassify op = { len1, len2, d_order, d_order_tiny, d_lg, d_jlarge, mail, h, (i32)first_lg, dp_lane }; int rc = lb_launch<2>(c, n_ub, op); if (rc) return rc; }
 	GSA_CHECK(c, hipStreamSynchronize(st));
 	if (h[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
 	if (h[M_DPERR]) return gsa_fail(c, GSA_ERR_ARG, "DP job with an empty side");
@@ -762,7 +908,26 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	hipEvent_t ev_fork = c->ev[10], ev_j2 = c->ev[12];
 	// the many small jobs run on a second stream, concurrently with the striped ones
 	static const int dp_order = [] { const char *e = getenv("GSA_DP_ORDER"); return e ? atoi(e) : 0; }();      // experiment: 1 = tiny, small, then the stripes, one after the other on the caller's stream
-	if (nsmall + ntiny > 0 && dp_order == 1) {
+	if (nsmall + ntiny > 0 && dp_lane > 0) {
+		GSA_CHECK(c, hipEventRecord(ev_fork, st));
+		GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], ev_fork, 0));
+		if (ntiny > 0) {
+			const i64 tiles = ((i64)ntiny + LANE_TILE - 1) / LANE_TILE;
+			const unsigned nwg = (unsigned)(tiles < LANE_WGS ? tiles : LANE_WGS);
+			u32 *arena = dev_ensure<u32>(c, c->d_dp_arena, (size_t)nwg * 4 * 64 * LANE_KMAX);
+			if (!arena) return GSA_ERR_NOMEM;
+			hipLaunchKernelGGL(k_dp_lane, dim3(nwg), dim3(256), 0, c->stream_aux[1], ntiny, d_order_tiny, 0, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag, arena);
+		}
+		if (nsmall > 0) {
+			hipStream_t s2 = ntiny > 0 ? st : c->stream_aux[1];
+			const unsigned nb = (unsigned)((nsmall + SMALL_WAVES - 1) / SMALL_WAVES);
+			hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, s2, nsmall, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag);
+			if (ntiny > 0) { GSA_CHECK(c, hipEventRecord(c->ev[18], s2)); GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], c->ev[18], 0)); }
+		}
+		GSA_CHECK(c, hipGetLastError());
+		GSA_CHECK(c, hipEventRecord(ev_j2, c->stream_aux[1]));
+		out->small_in_flight = true;
+	} else if (nsmall + ntiny > 0 && dp_order == 1) {
 		if (ntiny > 0) {
 			const unsigned nb = (unsigned)((ntiny + 4 * TINY_WAVES - 1) / (4 * TINY_WAVES));
 			hipLaunchKernelGGL(k_dp_tiny, dim3(nb), dim3(64 * TINY_WAVES), 0, st, ntiny, d_order_tiny, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag);

@@ -1253,7 +1253,8 @@ int stage1_seed(gsa_ctx *c)
 			if (!dev_ensure<uint16_t>(c, c->dn_memo, nd) || !dev_ensure<u32>(c, c->dn_lf, nd) || !dev_ensure<u64>(c, c->dn_x0, nd)) return GSA_ERR_NOMEM;
 			const u32 *list = dense_all ? (const u32 *)nullptr : c->d_heavy.as<u32>();
 #define GSA_DENSE_ARGS(SPAN) dim3((unsigned)(n_heavy * DENSE_WGS(SPAN))), dim3(DENSE_TPB), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt
-			const bool use_sweep = seed_mode != 2 && !c->prm.bSensitive && (sweep_all || n_heavy >= 1024);
+			static const u64 sweep_min = [] { const char *e = getenv("GSA_SWEEP_MIN"); return e ? (u64)atoll(e) : 1024ull; }();      // (experiments)
+			const bool use_sweep = seed_mode != 2 && !c->prm.bSensitive && (sweep_all || n_heavy >= sweep_min);
 			if (!dense_all && seed_mode == 1) c->seed_sweep_next = n_heavy * 5 > (u64)n_chunks * 2;      // (re-decided by every contig that goes through the speculative kernel)
 			else if (sweep_all && seed_mode == 1 && ++c->seed_sweep_run >= 8) { c->seed_sweep_next = false; c->seed_sweep_run = 0; }      // look again now and then
 			if (use_sweep) {

@@ -74,6 +74,27 @@ def test_ksw2_leaf_operator_edge_shapes(oracle_built, cx_index, seed):
         a.close()
 
 
+@pytest.mark.parametrize("lane", ["512", "64", "8192", "0"])
+def test_ksw2_leaf_operator_small_classes(oracle_built, golden_dir, lane):
+    """The classes below the striped kernel: 3000 pairs over every corner of n <= 64, m + n - 1 <= 128 (tools/dp_fuzz.py,
+    make_small_pairs) against the oracle's ksw2 (ksw2_alignment.cpp:74-95) -- one alignment per lane up to GSA_DP_LANE cells
+    (k_dp_lane; default 512), one per wavefront above (k_dp_small); 64 and 8192 move the border to both ends of the domain, 0 is
+    round 2's split (four per wavefront / one per wavefront).  Twice: the second call reuses the arena and the sorted tiles."""
+    import json
+    import subprocess
+    import sys
+    # (the switch is read once per process: a child process per setting)
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import dp_fuzz; from gsalign_amd import capi, indexio; from oracle import oracle_py\n"
+            "idx = indexio.load_index(%r); a = capi.Aligner(idx); s1, s2 = dp_fuzz.make_small_pairs(3000, 5); bad = []\n"
+            "for rep in range(2):\n"
+            "    ops = a.ksw2_batch(s1, s2)\n"
+            "    bad += [(rep, i, len(s1[i]), len(s2[i])) for i in range(len(s1)) if capi.apply_ops(s1[i], s2[i], ops[i]) != oracle_py.oracle_ksw2(s1[i], s2[i])]\n"
+            "a.close(); print(json.dumps(bad[:10]))\n") % (os.path.dirname(os.path.dirname(GOLDEN)), os.path.join(os.path.dirname(os.path.dirname(GOLDEN)), "tools"), os.path.join(golden_dir, "cx"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, GSA_DP_LANE=lane), timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1]) == [], (lane, r.stdout[-500:])
+
+
 def test_gap_similarity_leaf_operator_golden(gpu, cx_queries):
     rows = np.load(os.path.join(GOLDEN, "gapsim.npz"))["rows"]
     for ci in np.unique(rows[:, 0]):

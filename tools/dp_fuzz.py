@@ -48,6 +48,45 @@ def make_pairs(npairs, seed):
     return s1, s2
 
 
+def make_small_pairs(npairs, seed):
+    """Pairs of the classes below the striped kernel (n <= 64 query bases, m + n - 1 <= 128): every corner of that domain -- one
+    row, one column, 64 columns, 128 rows, products around the lane kernel's cell limit (512) and around its 8-cell direction
+    words -- with substitutions, indels, unrelated and identical pairs and N bases."""
+    rng = np.random.default_rng(seed)
+    s1, s2 = [], []
+    ns = [1, 2, 3, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 32, 33, 40, 48, 56, 57, 63, 64]
+    for i in range(npairs):
+        kind = i % 6
+        n = int(ns[rng.integers(len(ns))]) if kind < 4 else int(rng.integers(1, 65))
+        mmax = 129 - n
+        if kind == 0: m = 1 + int(rng.integers(0, min(mmax, 4)))
+        elif kind == 1: m = mmax - int(rng.integers(0, min(mmax, 3)))
+        elif kind == 2: m = min(mmax, max(1, (512 + int(rng.integers(-2, 3)) * n) // n))       # m * n around 512
+        elif kind == 3: m = min(mmax, max(1, n + int(rng.integers(-6, 7))))
+        else: m = 1 + int(rng.integers(0, mmax))
+        a = rng.integers(0, 4, m).astype(np.uint8)
+        mode = int(rng.integers(0, 6))
+        if mode == 0: b = rng.integers(0, 4, n).astype(np.uint8)
+        else:
+            out = []; j = 0; d = (0.02, 0.08, 0.2, 0.4, 0.0)[mode - 1]
+            while j < m and len(out) < n:
+                r = rng.random()
+                if r < d * 0.6: out.append((int(a[j]) + 1 + int(rng.integers(0, 3))) & 3); j += 1
+                elif r < d * 0.8: out.extend(rng.integers(0, 4, int(rng.integers(1, 6))).tolist())
+                elif r < d: j += int(rng.integers(1, 6))
+                else: out.append(int(a[j])); j += 1
+            out = out[:n]
+            while len(out) < n: out.append(int(rng.integers(0, 4)))
+            b = np.array(out, dtype=np.uint8)
+        A = np.frombuffer(b"ACGT", dtype=np.uint8)[a].copy(); B = np.frombuffer(b"ACGT", dtype=np.uint8)[b].copy()
+        if i % 7 == 0:
+            A[rng.integers(0, m, max(1, m // 10))] = ord("N")
+            B[rng.integers(0, n, max(1, n // 10))] = ord("N")
+        if i % 13 == 0: A = np.frombuffer(bytes(A).lower(), np.uint8).copy()
+        s1.append(A.tobytes()); s2.append(B.tobytes())
+    return s1, s2
+
+
 def make_large_pairs(npairs, seed):
     """Few long pairs around the LDS limit of the four-wave layout (reference side 3968) up to the 5000-base gap limit."""
     rng = np.random.default_rng(seed)
