@@ -244,34 +244,52 @@ __global__ void __launch_bounds__(256) k_dp_lane(i32 n_tiny, const i32 *__restri
 			const int m = have ? len1[job] : 0, n = have ? len2[job] : 0;
 			const uint8_t *s1 = pool1 + off1[job], *s2 = pool2 + off2[job];
 			const int nw = (n + 7) >> 3;
-			// column entries: u (5 bits) | y << 5 (5 bits) | code of the query base << 10; before row 0: u = 2 (0 in column 0), y = 0
+			// column entries: u (5 bits) | y << 5 (5 bits) | 4 * code of the query base << 10; before row 0: u = 2 (0 in column 0), y = 0
 			int nmax = n;
 			for (int o = 32; o; o >>= 1) { const int t = __shfl_xor(nmax, o); nmax = t > nmax ? t : nmax; }
-			for (int i = 0; i < nmax; i++) if (i < n) col[i * 64] = (uint16_t)((i ? 2 : 0) | (gsa_nt4(s2[i]) << 10));
-			// ---- forward: row j = reference base, column i = query base; x, v of the left neighbour in registers ----
+			for (int i = 0; i < nmax; i++) if (i < n) col[i * 64] = (uint16_t)((i ? 2 : 0) | (gsa_nt4(s2[i]) << 12));
+			// ---- forward: row j = reference base, columns in GROUPS OF EIGHT (one direction dword; its eight entries are read together,
+			//      the cells follow one another through x, v in registers, the loop control is paid once per group) ----
 			bool act = have && m > 0 && n > 0;
-			int i = 0, j = 0, x = 0, v = 0, kk = 0;
-			u32 acc = 0;
-			int b_ = act ? gsa_nt4(s1[0]) : 4, b_next = (act && m > 1) ? gsa_nt4(s1[1]) : 4;
-			u32 e = act ? col[0] : 0;
+			int g = 0, j = 0, x = 0, v = 0, kk = 0;
+			// z = score + q + e of (query code a, row base b) as a nibble table over a: 7 match, 5 mismatch, 6 when either is N
+			auto row_table = [](int b) -> u32 { return b == 4 ? 0x66666u : 0x65555u + (2u << (4 * b)); };
+			u32 tbl = row_table(act ? gsa_nt4(s1[0]) : 4);
+			uint8_t raw_next = (act && m > 1) ? s1[1] : (uint8_t)'N';      // (the next row's base: loaded a row ahead, decoded when the row starts)
 			while (__any(act)) {
 				if (act) {
-					const int inext = i + 1 < n ? i + 1 : 0;
-					const u32 e_next = col[inext * 64];      // (the entry above the next cell: independent of this one unless n == 1)
-					const int u = (int)(e & 31u), y = (int)((e >> 5) & 31u), a_ = (int)(e >> 10);
-					int un, vn, xn, yn;
-					const int d = dp_cell(x, v, u, y, a_, b_, un, vn, xn, yn);
-					const u32 en = (u32)un | ((u32)yn << 5) | ((u32)a_ << 10);
-					col[i * 64] = (uint16_t)en;
-					x = xn; v = vn;
-					acc |= (u32)((d & 3) | ((d & 0x18) >> 1)) << ((i & 7) << 2);
-					e = n == 1 ? en : e_next;
-					i = i + 1;
-					if ((i & 7) == 0 || i == n) { arena[(size_t)kk * 64] = acc; acc = 0; kk++; }
-					if (i == n) {
-						i = 0; j++; x = 0; v = 2;      // (left boundary of row j > 0: x = 0, v = 2; ksw2_alignment.cpp:157-164)
-						b_ = b_next;
-						if (j >= m) act = false; else b_next = j + 1 < m ? gsa_nt4(s1[j + 1]) : 4;
+					uint16_t *cg = col + g * 8 * 64;
+					u32 e[8];
+#pragma unroll
+					for (int k = 0; k < 8; k++) e[k] = cg[k * 64];
+					u32 acc = 0;
+					const int left = n - g * 8;                            // valid columns of this group (>= 1; 8 or more: all)
+#pragma unroll
+					for (int k = 0; k < 8; k++) {
+						if (k < left) {
+							const int u = (int)(e[k] & 31u), y = (int)((e[k] >> 5) & 31u);
+							const u32 c4 = e[k] >> 10;
+							int z = (int)((tbl >> c4) & 15u);
+							int a = x + v, b = y + u;
+							int d = a > z ? 1 : 0; z = z > a ? z : a;
+							if (b > z) d = 2;
+							z = z > b ? z : b;
+							z = z < 7 ? z : 7;
+							const int un = z - v, vn = z - u;
+							z -= 2; a -= z; b -= z;
+							if (a > 0) d |= 0x08; else a = 0;
+							if (b > 0) d |= 0x10; else b = 0;
+							cg[k * 64] = (uint16_t)((u32)un | ((u32)b << 5) | (c4 << 10));
+							x = a; v = vn;
+							acc |= (u32)((d & 3) | ((d & 0x18) >> 1)) << (4 * k);
+						}
+					}
+					arena[(size_t)kk * 64] = acc; kk++;
+					g++;
+					if (g == nw) {
+						g = 0; j++; x = 0; v = 2;      // (left boundary of row j > 0: x = 0, v = 2; ksw2_alignment.cpp:157-164)
+						if (j >= m) act = false;
+						else { tbl = row_table(gsa_nt4(raw_next)); raw_next = j + 1 < m ? s1[j + 1] : (uint8_t)'N'; }
 					}
 				}
 			}

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "ksw2 or drop_in or degenerate or stages_vs_golden" 2>&1 | tail -2
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "ksw2 or drop_in or degenerate or stages_vs_golden" 2>&1 | tail -6
 for l in ${LANES:-0 256 512 1024 2048 8192}; do for cfg in "human 1" "human 3" "ecoli 2"; do set -- $cfg
   v=$(GSA_DP_LANE=$l python bench.py --workload $1 --inflight $2 --steps 24 --warmup 6 --extra "" --no-cpu-baseline 2>/dev/null | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("%.3f Gbp/s %.3f ms/step pcie %.3f  extend alone %.2f" % (d["value"], d["ms_per_step"], d["pcie_inclusive"]["value"], d["stage_ms_one_context_alone"]["extend"]))')
   echo "GSA_DP_LANE=$l $1 inflight $2: $v"
