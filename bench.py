@@ -46,7 +46,7 @@ GRCH38_MB = [248, 242, 198, 190, 181, 170, 159, 145, 138, 133, 135, 133, 114, 10
 
 WORKLOADS = {
     # name: genome length(s), divergence, repeat injection, aligner parameters, distinct query genomes
-    "human": dict(lengths=[250_000_000], div=0.01, repeats=True, params={}, n_query=4, inflight=3,
+    "human": dict(lengths=[250_000_000], div=0.01, repeats=True, params={}, n_query=4, inflight=4,
                   label="human-chr1-sized pair (BASELINE configs[3] on one GPU): 250 Mb reference with repeat injection (300-bp family over 10 %, 150-copy tandem) vs 1 %-diverged query, defaults"),
     "ecoli": dict(lengths=[5_000_000], div=0.02, repeats=False, params={}, n_query=4, inflight=2,
                   label="E. coli-sized pair (BASELINE configs[1] stand-in): 5 Mb reference vs 2 %-diverged query, default -slen 15 -ind 25"),

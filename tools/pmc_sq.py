@@ -16,11 +16,11 @@ cols = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INS
 print(f"# rocprofv3 --pmc SQ counters, bench.py --workload {W} --inflight 1, per launch (mean); two passes of 8 counters")
 print(f"{'kernel':44s} {'launches':>8s} " + " ".join(f"{c[3:][:13]:>13s}" for c in cols))
 rows = sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))
-for k, d in rows[:16]:
+for k, d in rows[:32]:
     ln = max(n[k].values())
     print(f"{k:44s} {ln:8d} " + " ".join(f"{d.get(c, 0) / max(1, n[k].get(c, 1)):13.3g}" for c in cols))
 print("# derived: VALU issue share = ACTIVE_INST_VALU / WAVE_CYCLES ; waiting share = WAIT_ANY / WAVE_CYCLES ; LDS conflict share = LDS_BANK_CONFLICT / LDS_IDX_ACTIVE")
-for k, d in rows[:16]:
+for k, d in rows[:32]:
     wc = d.get("SQ_WAVE_CYCLES", 0) / max(1, n[k].get("SQ_WAVE_CYCLES", 1))
     if wc <= 0: continue
     g = lambda c: d.get(c, 0) / max(1, n[k].get(c, 1))

@@ -12,7 +12,7 @@ D = os.path.join(ROOT, "gpurun_out", f"pmc_{W}")
 GROUPS = {      # key in the json -> predicate on the (mangled) kernel name
     "k_seed_wg": lambda k: ("k_seed_wg" in k and "Lb1ELb0" not in k and "<true" not in k) or "k_dense_search" in k or "k_dense_resolve" in k,
     "k_dp_stripe": lambda k: "k_dp_stripe" in k,
-    "k_dp_small": lambda k: "k_dp_small" in k or "k_dp_tiny" in k,
+    "k_dp_small": lambda k: "k_dp_small" in k or "k_dp_tiny" in k or "k_dp_lane" in k,
     "k_seed_select": lambda k: "k_seed_select" in k,
     "k_materialize": lambda k: "k_materialize" in k,
     "copies": lambda k: "copyBuffer" in k or "fillBuffer" in k,

@@ -10,3 +10,5 @@ for w in human ecoli yeast; do
   rm -rf gpurun_out/prof_$w
 done
 bash tools/pmc_top.sh human > gpurun_out/pmc_top.log 2>&1
+bash tools/pmc_sq.sh human > gpurun_out/pmc_sq.log 2>&1
+# then, back in the container: python tools/pmc_top.py human ; python tools/pmc_sq.py human > profiles/r03_sq_human.txt
