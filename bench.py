@@ -54,7 +54,7 @@ WORKLOADS = {
                   label="S. cerevisiae-sized pair (BASELINE configs[2]): 16 contigs / 12 Mb vs 2 %-diverged copy, -sen"),
     # BASELINE configs[4] on ONE GPU: the whole job of the 8-GPU configuration (the index is replicated per GPU there, so one GPU
     # holds exactly this index).  6.2 G BWT rows: the >= 2^32-row device layout and the 64-bit suffix sorter on their real input.
-    "human_full": dict(lengths=[1_000_000 * m for m in GRCH38_MB], div=0.01, repeats=True, params=dict(alen=5000), n_query=2, inflight=2,
+    "human_full": dict(lengths=[1_000_000 * m for m in GRCH38_MB], div=0.01, repeats=True, params=dict(alen=5000), n_query=2, inflight=4,
                        label="full-human-sized pair (BASELINE configs[4] on one GPU): 24 contigs with GRCh38 chromosome lengths, 3.08 Gbp, repeat injection, vs 1 %-diverged copy, -alen 5000"),
 }
 

@@ -617,6 +617,16 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 		int64_t small_total = 0; int32_t n_small = 0;
 		for (int32_t i = 0; i < n; i++) if ((int64_t)qlen[i] <= bundle_contig) { small_total += qlen[i]; n_small++; }
 		if (n_small < 2) may = false;
+		// the 64-bit seed key holds (contig x stride + PosDiff, position in the bundle): against a large reference (stride ~ 2G) only
+		// so many contigs fit one bundle -- 32 against a human genome
+		size_t max_contigs = GSA_BUNDLE_MAX_CONTIGS;
+		{
+			const int qb = ceil_log2_u64((u64)(bundle_cap + bundle_cap / 8 + bundle_contig) + 1);
+			const u64 stride = (u64)(2 * ctx[0]->G) + (u64)bundle_contig + (u64)ctx[0]->prm.MaxIndelSize + 96;
+			const u64 fit = qb < 62 ? (1ull << (63 - qb)) / stride : 0;
+			if (fit < max_contigs) max_contigs = (size_t)fit;
+			if (max_contigs < 2) may = false;
+		}
 		static const int64_t bundle_target = [] { const char *e = getenv("GSA_BUNDLE_TARGET"); return e ? (int64_t)atoll(e) : 0ll; }();      // (experiments: a fixed bundle size)
 		int64_t n_bundles = (small_total + bundle_cap - 1) / (bundle_cap > 0 ? bundle_cap : 1); if (n_bundles < 1) n_bundles = 1;
 		n_bundles = (n_bundles + n_ctx - 1) / n_ctx * n_ctx;
@@ -628,7 +638,7 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 			const bool small = may && (int64_t)qlen[ci] <= bundle_contig;
 			if (!small) { units.push_back(std::vector<int32_t>(1, ci)); cur = 0; continue; }
 			const int64_t padded = ((int64_t)qlen[ci] + GSA_CHUNK - 1) / GSA_CHUNK * GSA_CHUNK;
-			if (cur > 0 && (cur + padded / 2 > target || cur + padded > bundle_cap + bundle_cap / 8 || units.back().size() >= GSA_BUNDLE_MAX_CONTIGS)) cur = 0;      // (to the nearest contig)
+			if (cur > 0 && (cur + padded / 2 > target || cur + padded > bundle_cap + bundle_cap / 8 || units.back().size() >= max_contigs)) cur = 0;      // (to the nearest contig)
 			if (cur == 0) units.push_back(std::vector<int32_t>());
 			units.back().push_back(ci); cur += padded > 0 ? padded : 1;
 		}

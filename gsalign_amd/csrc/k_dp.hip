@@ -926,9 +926,11 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	hipEvent_t ev_fork = c->ev[10], ev_j2 = c->ev[12];
 	// the many small jobs run on a second stream, concurrently with the striped ones
 	static const int dp_order = [] { const char *e = getenv("GSA_DP_ORDER"); return e ? atoi(e) : 0; }();      // experiment: 1 = tiny, small, then the stripes, one after the other on the caller's stream
+	static const int dp_after_early = [] { const char *e = getenv("GSA_DP_AFTER_EARLY"); return e ? atoi(e) : 0; }();      // experiment: the small classes wait for the early striped launch
 	if (nsmall + ntiny > 0 && dp_lane > 0) {
 		GSA_CHECK(c, hipEventRecord(ev_fork, st));
 		GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], ev_fork, 0));
+		if (dp_after_early && c->early_in_flight) GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], c->ev[14], 0));
 		if (ntiny > 0) {
 			const i64 tiles = ((i64)ntiny + LANE_TILE - 1) / LANE_TILE;
 			const unsigned nwg = (unsigned)(tiles < LANE_WGS ? tiles : LANE_WGS);

@@ -47,6 +47,19 @@ try:
         #  the same shape against the oracle)
         assert cov > (0.45 if ci == 20 else 0.9) * qs[ci].size
     print(f"all {len(qs)} contigs checked, total coverage {tot_cov / total:.3f}")
+    # short contigs against the human-sized index, bundled (the PosDiff stride of a bundle is ~ 2G = 6.2 G here: the seed key's width
+    # and the PosDiff-sort path at their real size): pieces of five query chromosomes, one reverse-complemented, in one pass == one by one
+    import numpy as np
+    pieces = [np.ascontiguousarray(qs[ci][o:o + ln]) for ci, o, ln in ((0, 1000000, 2000000), (7, 5000000, 1500000), (20, 300000, 999999), (22, 0, 3000001), (12, 40000000, 10000))]
+    bun = g0.align_bundle(pieces)
+    for k, pc in enumerate(pieces):
+        alone = g0.align_contig(pc)
+        for key in ("blocks", "frags"):
+            assert np.array_equal(bun[k][key], alone[key]), (k, key)
+        da, db = capi.result_as_dump(bun[k], with_aln=True), capi.result_as_dump(alone, with_aln=True)
+        assert np.array_equal(da["aln1"], db["aln1"]) and np.array_equal(da["aln2"], db["aln2"]), (k, "strings")
+        assert int(alone["blocks"]["aln_len"].sum()) > 0.5 * pc.size or k == 2, k      # (piece 2 lies on the reverse-complemented contig 20)
+    print(f"bundle of {len(pieces)} short contigs against the {idx.G / 1e9:.2f} Gbp index == one by one")
     g1.close(); g0.close()
     print("HUMAN SCALE PROBE OK")
 finally:
