@@ -11,11 +11,14 @@
 enum { CNT_OCCBLK = 0, CNT_DONE = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 4, CNT_DPJOBS = 5, CNT_DPMN = 6, CNT_CAND = 8, CNT_OVERFLOW = 9, CNT_OCCBLK_ALL = 10, CNT_HEAVY = 12 };
 
 #ifndef SEED_WG
-#define SEED_WG 128             // lanes per chunk: one per sub-range (256 lanes with 128 sub-ranges left two of four waves idle: 0.157 -> 0.139 ms)
+#define SEED_WG 64              // lanes per chunk: ONE WAVE (round 3, late: 128 lanes = two waves per chunk spent 27 % more VALU wave-instructions on the same
+                                // searches -- a wave iterates as long as its slowest lane, and the tail of a chunk, a few lanes deep in the Occ walk of
+                                // a repeat copy, kept both waves turning; profiles/r03_seed_shape_sweep.txt.  256 lanes before that: 0.157 -> 0.139 ms)
 #endif
 #ifndef NSUB
-#define NSUB 128               // speculative sub-ranges per chunk (work items of the workgroup; swept 64 .. 512 on the bench: with 64-base
-                               // text windows and four presence bits per round trip fewer, longer walks win -- 384 was best before them)
+#define NSUB 96                // speculative sub-ranges per chunk (work items of the workgroup, drawn from an LDS queue: 64 lanes take the first 64, a lane
+                               // that is through early takes one of the other 32).  Swept 64 .. 512 on the bench: with 64-base text windows and four
+                               // presence bits per round trip fewer, longer walks win -- 384 was best before them, 128 with two waves per chunk)
 #endif
 #ifndef ADV_STEPS
 #define ADV_STEPS 4             // advance steps (hops over memoised / ambiguous positions, opening a search) per round trip
@@ -93,20 +96,21 @@ __device__ __forceinline__ u32 pres4_bit(u64 qb, int K, int i)      // 0 .. 255:
 // ---------------------------------------------------------------------------
 // Exclusive prefix of the per-chunk hit counts (n1 = chunks + 1 entries, the last one is 0), by the workgroup that is through
 // LAST in a seed kernel: the counts were stored with agent-scope atomics and are read the same way (the other workgroups ran on
-// other XCDs), eight loads in flight per lane.  Was a rocPRIM scan behind the kernel: two more GPU operations per contig.
+// other XCDs), 8 or 16 loads in flight per lane.  Was a rocPRIM scan behind the kernel: two more GPU operations per contig.
 template <int TPB>
 __device__ __forceinline__ void wg_exscan_hits(const i32 *hits, i32 *base, int n1)
 {
+	constexpr int V = TPB <= 64 ? 16 : 8;             // loads in flight per lane
 	__shared__ i32 s_ws[TPB / 64], s_run;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	if (tid == 0) s_run = 0;
 	__syncthreads();
-	for (int b0 = 0; b0 < n1; b0 += TPB * 8) {
-		i32 v[8], tsum = 0;
+	for (int b0 = 0; b0 < n1; b0 += TPB * V) {
+		i32 v[V], tsum = 0;
 #pragma unroll
-		for (int k = 0; k < 8; k++) { const int idx = b0 + tid * 8 + k; v[k] = idx < n1 ? __hip_atomic_load(&hits[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; }
+		for (int k = 0; k < V; k++) { const int idx = b0 + tid * V + k; v[k] = idx < n1 ? __hip_atomic_load(&hits[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; }
 #pragma unroll
-		for (int k = 0; k < 8; k++) tsum += v[k];
+		for (int k = 0; k < V; k++) tsum += v[k];
 		i32 inc = tsum;
 		for (int o = 1; o < 64; o <<= 1) { const i32 t = __shfl_up(inc, o); if (lane >= o) inc += t; }
 		if (lane == 63) s_ws[wv] = inc;
@@ -115,7 +119,7 @@ __device__ __forceinline__ void wg_exscan_hits(const i32 *hits, i32 *base, int n
 		for (int w = 0; w < TPB / 64; w++) { const i32 x = s_ws[w]; if (w < wv) wo += x; tot += x; }
 		i32 e = s_run + wo + inc - tsum;
 #pragma unroll
-		for (int k = 0; k < 8; k++) { const int idx = b0 + tid * 8 + k; if (idx < n1) base[idx] = e; e += v[k]; }
+		for (int k = 0; k < V; k++) { const int idx = b0 + tid * V + k; if (idx < n1) base[idx] = e; e += v[k]; }
 		__syncthreads();
 		if (tid == 0) s_run += tot;
 		__syncthreads();
@@ -204,6 +208,9 @@ __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg
 	const int nitems = (clen + S - 1) / S;
 	for (int it = j; it < nitems; it += SEED_WG) entry_of[it] = (uint16_t)(it * S);
 	u32 all_blocks = 0, rounds = 0, iters = 0;
+#ifdef SEED_STATS
+	u32 st_it = 0, st_fm_any = 0, st_fm_only = 0, st_act = 0, st_fm = 0;
+#endif
 	unsigned long long t_begin = wall_clock64(), t_round0 = 0, t_resolve = 0;
 	u32 dirty = 0;                                      // rounds >= 2: this lane has one sub-range (fb_item) to walk for real
 	int fb_item = 0;
@@ -224,6 +231,10 @@ __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg
 			// here and searched from EVERY position in parallel by the dense kernels below.
 			if (!COUNT && budget && iters > budget) *(volatile int *)&s_abort = 1;
 			if (*(volatile int *)&s_abort) break;
+#ifdef SEED_STATS      // (experiments: what the wave-iterations are spent on -- sums over all waves instead of the maxima / timers)
+			{ const u64 bf = __ballot(mode == M_FM), ba = __ballot(mode != M_DONE);
+			  st_it++; st_fm_any += bf != 0; st_fm_only += bf != 0 && bf == ba; st_act += __popcll(ba); st_fm += __popcll(bf); }
+#endif
 			// ---- request phase (convergent) ----
 			u64 kk = 0, ll = 0; bool kn = true, ln = true;
 			if (mode == M_FM) {
@@ -403,8 +414,15 @@ __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg
 	if ((j & 63) == 0) {
 		if (alg_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK], (unsigned long long)alg_blocks);
 		if (all_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK_ALL], (unsigned long long)all_blocks);
+#ifndef SEED_STATS
 		atomicMax((unsigned long long *)&cnt[13], (unsigned long long)iters);
+#endif
 	}
+#ifdef SEED_STATS
+	if ((j & 63) == 0) { atomicAdd((unsigned long long *)&cnt[11], (unsigned long long)st_it); atomicAdd((unsigned long long *)&cnt[13], (unsigned long long)st_fm_any); atomicAdd((unsigned long long *)&cnt[14], (unsigned long long)st_fm_only);
+	                     atomicAdd((unsigned long long *)&cnt[15], (unsigned long long)st_act); atomicAdd((unsigned long long *)&cnt[7], (unsigned long long)st_fm); }
+	if (false)
+#endif
 	if (j == 0) { atomicMax((unsigned long long *)&cnt[11], (unsigned long long)rounds); atomicMax((unsigned long long *)&cnt[14], t_round0); atomicMax((unsigned long long *)&cnt[15], t_resolve); atomicMax((unsigned long long *)&cnt[7], wall_clock64() - t_begin); }
 	__syncthreads();
 	if (!heavy) for (int p = j; p < PATH_WORDS; p += SEED_WG) onpath[(size_t)chunk * PATH_WORDS + p] = bits[p];

@@ -31,6 +31,9 @@ for v in variants:
     for rep in range(2):
         g.set_query(q); g.run_to(1)
     tm = g.timings(); c = g.counters(); st = g.seed_stats()
+    if os.environ.get("SEED_STATS"):      # (library built with -DSEED_STATS: sums over the waves of the LAST launch instead of maxima / timers)
+        it, fm_any, fm_only, act, fm = (int(st[0]), int(st[2]), int(st[3]), int(st[4]), int(st[5]))
+        print(f"   SEED_STATS: wave-iterations {it}, with an FM lane {fm_any} ({fm_any / max(1, it):.2f}), FM lanes only {fm_only} ({fm_only / max(1, it):.2f}), lanes active per iteration {act / max(1, it):.1f}, FM lanes per iteration {fm / max(1, it):.2f}")
     print(f"   seed stats: resolver rounds max {int(st[0])}, dense chunks {int(st[1])}, wave iterations max {int(st[2])}; slowest chunk: round 1 {st[3] * 0.01:.1f} us, resolver {st[4] * 0.01:.1f} us, total {st[5] * 0.01:.1f} us")
     print(f"== {v}: n={n} index build {tb:.1f}s  seed_search {tm[0]:.3f} ms locate {tm[1]:.3f} sort {tm[2]:.3f}  hits {int(c[2])} occ_read {int(c[7])}", flush=True)
     g.set_query(q); g.run_to(8); tm = g.timings()

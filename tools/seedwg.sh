@@ -9,6 +9,6 @@ mkdir -p gpurun_out; : > gpurun_out/seedwg.txt
 for x in "$@"; do
   rm -f gsalign_amd/csrc/build/k_seed.o; make -C gsalign_amd/csrc -j32 lib EXTRA="$x" > /tmp/mk.log 2>&1 || tail -5 /tmp/mk.log
   echo "=== $x" >> gpurun_out/seedwg.txt
-  python tools/seed_probe.py $N $V 2>&1 | grep -E "^==|seed stats|Error|error" >> gpurun_out/seedwg.txt
+  python tools/seed_probe.py $N $V 2>&1 | grep -E "^==|seed stats|SEED_STATS|Error|error" >> gpurun_out/seedwg.txt
 done
 cat gpurun_out/seedwg.txt
