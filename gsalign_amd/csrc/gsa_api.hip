@@ -119,10 +119,10 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	(void)hipSetDeviceFlags(hipDeviceScheduleSpin);      // host waits spin instead of sleeping: the pipeline has ~20 short count read-backs per contig
 	(void)hipGetLastError();
 	if (int rcp = ctx_private_init(c)) { g_create_error = c->err; gsa_destroy(c); return rcp; }
-	const size_t bwt_bytes = ((idx->bwt_words + 15) / 16) * 64;          // whole 64-byte blocks
-	CK(hipMalloc(&c->d_bwt.p, bwt_bytes + 64)); c->d_bwt.cap = bwt_bytes + 64;
-	CK(hipMemset(c->d_bwt.p, 0, bwt_bytes + 64));
-	CK(hipMemcpy(c->d_bwt.p, idx->bwt, idx->bwt_words * 4, hipMemcpyHostToDevice));
+	const size_t bwt_bytes = ((idx->bwt_words + 15) / 16) * 64;          // whole 64-byte blocks of the reference's layout (regrouped below: build_occ)
+	CK(hipMalloc(&c->d_bwt_ref.p, bwt_bytes + 64)); c->d_bwt_ref.cap = bwt_bytes + 64;      // (freed once regrouped)
+	CK(hipMemset(c->d_bwt_ref.p, 0, bwt_bytes + 64));
+	CK(hipMemcpy(c->d_bwt_ref.p, idx->bwt, idx->bwt_words * 4, hipMemcpyHostToDevice));
 	CK(hipMalloc(&c->d_sa.p, idx->n_sa * 8)); c->d_sa.cap = idx->n_sa * 8;
 	CK(hipMemcpy(c->d_sa.p, idx->sa, idx->n_sa * 8, hipMemcpyHostToDevice));
 	CK(hipMalloc(&c->d_ref.p, (size_t)2 * idx->G + 64)); c->d_ref.cap = (size_t)2 * idx->G + 64;
@@ -145,9 +145,14 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 #undef CK
 	c->di.primary = idx->primary; for (int i = 0; i < 5; i++) c->di.L2[i] = idx->L2[i]; c->di.L2[0] = 0;
 	c->di.seq_len = idx->L2[4];
-	c->di.bwt = c->d_bwt.as<uint4>(); c->di.sa = c->d_sa.as<u64>(); c->di.ref = c->d_ref.as<uint8_t>(); c->di.G = idx->G;
+	c->di.bwt = nullptr; c->di.occ_base = nullptr; c->di.occ_shift = 0; c->di.sa = c->d_sa.as<u64>(); c->di.ref = c->d_ref.as<uint8_t>(); c->di.G = idx->G;
 	c->di.chr_end = c->d_chr_end.as<i64>(); c->di.chr_of_end = c->d_chr_of_end.as<i32>(); c->di.n_ends = (i32)c->h_chr_end.size();
 	c->di.sa32 = nullptr; c->di.sa64 = nullptr; c->di.kmer = nullptr; c->di.kmer_k = 0; c->di.kmer_lo = nullptr; c->di.kmer_lo_k = 0; c->di.kmer_e16 = 0; c->di.ref2 = nullptr; c->di.pres = nullptr; c->di.pres_k = 0;
+	{
+		const int rco = build_occ(c, c->d_bwt_ref.p, bwt_bytes / 64);
+		hipFree(c->d_bwt_ref.p); c->d_bwt_ref.p = nullptr; c->d_bwt_ref.cap = 0;
+		if (rco) { g_create_error = c->err; gsa_destroy(c); return rco; }
+	}
 	if (int rcd = build_dense_sa(c, idx->n_sa)) { g_create_error = c->err; gsa_destroy(c); return rcd; }
 	gsa_params dp; gsa_default_params(&dp);
 	int rc = gsa_set_params(c, prm ? prm : &dp);
@@ -162,7 +167,7 @@ void gsa_destroy(gsa_ctx *c)
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
 	if (c->lender) c->lender->n_borrowers.fetch_sub(1);      // (`parent` outlives its clones: gsa_hip.h)
-	DevBuf *bufs[] = { &c->d_bwt, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->d_query, &c->tmp, &c->d_cnt, &c->d_mail, &c->d_lb_status[0], &c->d_lb_status[1],
+	DevBuf *bufs[] = { &c->d_bwt, &c->d_bwt_ref, &c->d_occ_base, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->d_query, &c->tmp, &c->d_cnt, &c->d_mail, &c->d_lb_status[0], &c->d_lb_status[1],
 		&c->d_sa_dense, &c->d_kmer, &c->d_kmer_lo, &c->d_pres, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_heavy, &c->dn_memo, &c->dn_lf, &c->dn_x0, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
 		&c->d_flag, &c->d_scan, &c->g_beg, &c->w_j0, &c->w_j1, &c->w_on, &c->d_pdbm, &c->d_gpre, &c->d_key_c, &c->d_val_c, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
 		&c->a_next, &c->a_brk, &c->a_aurank, &c->a_aulist, &c->a_runinfo, &c->w_best, &c->w_sum, &c->w_n, &c->d_btab, &c->d_flag2, &c->d_scan2, &c->d_i64a,
@@ -181,6 +186,8 @@ void gsa_destroy(gsa_ctx *c)
 	for (DevBuf *b : { &c->p_frags, &c->p_tail, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_sj_early, &c->p_jpatch, &c->p_early, &c->p_bndtab, &c->p_bblk, &c->p_ba0 }) if (b->p) hipHostFree(b->p);
 	for (int i = 0; i < 28; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 3; i++) if (c->stream_aux[i]) hipStreamDestroy(c->stream_aux[i]);
+	if (c->stream_seed) hipStreamDestroy(c->stream_seed);
+	if (c->ev_seed_fork) hipEventDestroy(c->ev_seed_fork);
 	if (c->stream) hipStreamDestroy(c->stream);
 	delete c;
 }

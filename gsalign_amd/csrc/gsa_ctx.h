@@ -33,6 +33,8 @@ struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf ra
 struct gsa_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
+	hipStream_t stream_seed = nullptr;      // (experiment, GSA_SEED_CUS: the seed-search kernels on a stream restricted to part of the CUs)
+	hipEvent_t ev_seed_fork = nullptr;
 	hipStream_t stream_aux[3] = {nullptr, nullptr, nullptr};   // [0] early striped DP, [1] tiny DP + strings + sums, [2] records to the host (four streams in all: one per hardware queue)
 	std::string err;
 	Params prm;
@@ -51,7 +53,7 @@ struct gsa_ctx {
 	u64 counters[8];
 
 	// index (device)
-	DevBuf d_bwt, d_sa, d_ref, d_chr_end, d_chr_of_end;
+	DevBuf d_bwt, d_bwt_ref, d_occ_base, d_sa, d_ref, d_chr_end, d_chr_of_end;
 	std::vector<i64> h_chr_end, h_chr_fwd; std::vector<i32> h_chr_of_end, h_chr_len;
 	i64 G = 0;
 
@@ -186,6 +188,7 @@ template <class T> static inline T *pin_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 
 // stage drivers (one per translation unit)
 int build_dense_sa(gsa_ctx *c, u64 n_sa);   // k_seed.hip
+int build_occ(gsa_ctx *c, const void *ref_layout, u64 n_blocks128);   // k_seed.hip: the device's Occ blocks from the reference's layout
 int build_presence(gsa_ctx *c);             // k_seed.hip  (after MinSeedLength changed)
 int stage1_seed(gsa_ctx *c);          // k_seed.hip
 int stage1_import_hits(gsa_ctx *c, const u64 *keys, const u32 *vals, i64 n);   // k_seed.hip

@@ -4,7 +4,7 @@
 //   bwt_occ4 / bwt_2occ4   reference src/bwt_search.cpp:69-119
 //   bwt_occ / bwt_invPsi   :45-67,121-127
 //   BWT_Search             :141-185
-// One Occ query = one 64-byte block (4 x global_load_dwordx4 issued together),
+// One Occ query = one 32-byte block of 64 rows (2 x global_load_dwordx4, one sector of HBM: the layout below),
 // then three 64-bit popcounts per 32 symbols instead of the reference's byte
 // table; the count is a pure function of (block, row) so results are identical.
 // Everything is written with selects instead of runtime-indexed arrays so that
@@ -24,16 +24,27 @@ __device__ __forceinline__ int gsa_nt4(uint8_t c)
 	return ok ? (int)code : 4;
 }
 
-struct FmBlock { uint4 c0, c1, w0, w1; };
+// Occ blocks on the device (round 3, late): 64 rows per 32-BYTE block -- ONE 32-byte sector of HBM answers an Occ query, where
+// the reference's interleaved block (128 rows: four 64-bit counts + 128 symbols = 64 bytes, bwt_search.cpp:69-119) costs two.
+// Random 32-byte sectors, not bytes, are what the seed kernels are bound by (40-48 G sectors/s on an MI355X whatever the
+// occupancy: tools/rand_probe.hip), and most of theirs are the two Occ blocks per step of the walks inside repeat copies.
+//   c = counts of A, C, G, T in front of the block as u32, relative to the block's SUPER-block (2^occ_shift blocks; its 64-bit
+//       base counts in di.occ_base, a table of a few entries; no table = no base: texts below 2^32 rows),
+//   w = 64 symbols in the reference's bit order (first symbol in the top bits of w.x; w.x, w.y = the first 32).
+// Built from the uploaded reference layout by k_occ_relayout (k_seed.hip); the counts are the reference's numbers regrouped, so
+// every Occ value -- and the number of 128-row blocks the reference would have touched (row arithmetic) -- is unchanged.
+struct FmBlock { uint4 c, w; u64 ba, bc, bg, bt; };
 
-__device__ __forceinline__ FmBlock fm_load(const uint4 *__restrict__ bwt, u64 blk)
+__device__ __forceinline__ FmBlock fm_load(const DevIndex &di, u64 blk)
 {
-	const uint4 *p = bwt + (blk << 2);
-	FmBlock b; b.c0 = p[0]; b.c1 = p[1]; b.w0 = p[2]; b.w1 = p[3];
+	const uint4 *p = di.bwt + (blk << 1);
+	FmBlock b; b.c = p[0]; b.w = p[1];
+	b.ba = b.bc = b.bg = b.bt = 0;
+	if (di.occ_base) { const ulonglong2 *sb = (const ulonglong2 *)(di.occ_base + ((blk >> di.occ_shift) << 2)); const ulonglong2 s0 = sb[0], s1 = sb[1]; b.ba = s0.x; b.bc = s0.y; b.bg = s1.x; b.bt = s1.y; }
 	return b;
 }
 
-// counts of C,G,T among the first n (1..128) symbols of the block; A follows from n
+// counts of C,G,T among the first n (1..64) symbols of the block; A follows from n
 __device__ __forceinline__ void fm_count(const FmBlock &b, int n, u32 &c1, u32 &c2, u32 &c3)
 {
 	const u64 M = 0x5555555555555555ull;
@@ -43,7 +54,7 @@ __device__ __forceinline__ void fm_count(const FmBlock &b, int n, u32 &c1, u32 &
 		const u64 m = nj == 0 ? 0ull : (M & ~((nj == 32) ? 0ull : ((1ull << (64 - 2 * nj)) - 1))); \
 		const u64 lo = W & M, hi = (W >> 1) & M; \
 		c3 += __popcll(hi & lo & m); c2 += __popcll(hi & ~lo & m); c1 += __popcll(~hi & lo & m); }
-	GSA_CNT(0, b.w0.x, b.w0.y) GSA_CNT(1, b.w0.z, b.w0.w) GSA_CNT(2, b.w1.x, b.w1.y) GSA_CNT(3, b.w1.z, b.w1.w)
+	GSA_CNT(0, b.w.x, b.w.y) GSA_CNT(1, b.w.z, b.w.w)
 #undef GSA_CNT
 }
 
@@ -51,30 +62,30 @@ struct Occ4 { u64 a, c, g, t; };
 
 __device__ __forceinline__ u64 occ_sel(const Occ4 &o, int i) { return i == 0 ? o.a : (i == 1 ? o.c : (i == 2 ? o.g : o.t)); }
 
-// Occ(c, k) for all four c at a row inside one loaded block (n = symbols up to the row, inclusive)
+// Occ(c, k) for all four c at a row inside one loaded block (n = symbols up to the row, inclusive: 1..64)
 __device__ __forceinline__ Occ4 fm_occ4_in(const FmBlock &b, int n)
 {
 	u32 c1, c2, c3; fm_count(b, n, c1, c2, c3);
 	Occ4 o;
-	o.a = (((u64)b.c0.y << 32) | b.c0.x) + (u32)(n - c1 - c2 - c3);
-	o.c = (((u64)b.c0.w << 32) | b.c0.z) + c1;
-	o.g = (((u64)b.c1.y << 32) | b.c1.x) + c2;
-	o.t = (((u64)b.c1.w << 32) | b.c1.z) + c3;
+	o.a = b.ba + b.c.x + (u32)(n - c1 - c2 - c3);
+	o.c = b.bc + b.c.y + c1;
+	o.g = b.bg + b.c.z + c2;
+	o.t = b.bt + b.c.w + c3;
 	return o;
 }
 
-// bwt_2occ4(k, l): returns the number of 64-byte blocks the reference touches.
+// bwt_2occ4(k, l): returns the number of 64-byte blocks THE REFERENCE touches (its blocks hold 128 rows).
 // Branch-free on the memory side: both blocks are requested back to back (the second
 // request is an L1 hit when the rows share a block) and waited for once.
 __device__ __forceinline__ int fm_2occ4(const DevIndex &di, u64 k, u64 l, Occ4 &ck, Occ4 &cl)
 {
 	const bool kn = (k == (u64)-1), ln = (l == (u64)-1);
 	const u64 kk = kn ? 0 : k - (k >= di.primary), ll = ln ? 0 : l - (l >= di.primary);
-	const FmBlock bk = fm_load(di.bwt, kk >> 7);
-	const FmBlock bl = fm_load(di.bwt, ll >> 7);
+	const FmBlock bk = fm_load(di, kk >> 6);
+	const FmBlock bl = fm_load(di, ll >> 6);
 	const Occ4 z = {0, 0, 0, 0};
-	ck = fm_occ4_in(bk, (int)(kk & 127) + 1);
-	cl = fm_occ4_in(bl, (int)(ll & 127) + 1);
+	ck = fm_occ4_in(bk, (int)(kk & 63) + 1);
+	cl = fm_occ4_in(bl, (int)(ll & 63) + 1);
 	if (kn) ck = z;
 	if (ln) cl = z;
 	if (!kn && !ln && (kk >> 7) == (ll >> 7)) return 1;
@@ -113,7 +124,7 @@ __device__ __forceinline__ bool fm_extend(const DevIndex &di, FmIntv &ik, int nt
 __device__ __forceinline__ bool fm_extend_loaded(const DevIndex &di, FmIntv &ik, int nt, const FmBlock &bk, const FmBlock &bl, u64 kk, u64 ll, bool kn, bool ln, u32 &blocks)
 {
 	const Occ4 z = {0, 0, 0, 0};
-	Occ4 tk = fm_occ4_in(bk, (int)(kk & 127) + 1), tl = fm_occ4_in(bl, (int)(ll & 127) + 1);
+	Occ4 tk = fm_occ4_in(bk, (int)(kk & 63) + 1), tl = fm_occ4_in(bl, (int)(ll & 63) + 1);
 	if (kn) tk = z;
 	if (ln) tl = z;
 	blocks += (!kn && !ln && (kk >> 7) == (ll >> 7)) ? 1 : ((kn ? 0 : 1) + (ln ? 0 : 1));
@@ -193,10 +204,9 @@ __device__ __forceinline__ u64 fm_lf(const DevIndex &di, u64 k)
 {
 	if (k == di.primary) return 0;
 	const u64 x = k - (k > di.primary);
-	const FmBlock b = fm_load(di.bwt, x >> 7);
-	const int s = (int)(x & 127);
-	const u32 w = s < 64 ? (s < 32 ? (s < 16 ? b.w0.x : b.w0.y) : (s < 48 ? b.w0.z : b.w0.w))
-	                     : (s < 96 ? (s < 80 ? b.w1.x : b.w1.y) : (s < 112 ? b.w1.z : b.w1.w));
+	const FmBlock b = fm_load(di, x >> 6);
+	const int s = (int)(x & 63);
+	const u32 w = s < 32 ? (s < 16 ? b.w.x : b.w.y) : (s < 48 ? b.w.z : b.w.w);
 	const int sym = (w >> ((~s & 15) << 1)) & 3;
 	const Occ4 o = fm_occ4_in(b, s + 1);
 	return l2_sel(di, sym) + occ_sel(o, sym);

@@ -28,7 +28,9 @@ typedef int32_t i32;
 // each, MSB first inside each u32.
 struct DevIndex {
 	u64 primary, L2[5], seq_len;
-	const uint4 *bwt;       // 4 x uint4 per block
+	const uint4 *bwt;       // Occ blocks, 2 x uint4 per 64 rows: four u32 counts + 64 symbols (FmBlock, gsa_fm.h; built at gsa_create from the reference's layout)
+	const u64 *occ_base;    // 64-bit base counts (A, C, G, T) per super-block of 2^occ_shift blocks; null when all counts fit 32 bits
+	i32 occ_shift;
 	const u64 *sa;          // sa[i] = SA of row 32 i ; sa[0] = -1   (the on-disk sampling)
 	const u32 *sa32;        // dense SA, one entry per row, built on the device at gsa_create
 	const u64 *sa64;        //   (32-bit entries when 2G < 2^32, else 64-bit); row 0 is the -1 sentinel

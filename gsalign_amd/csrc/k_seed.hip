@@ -132,8 +132,9 @@ __device__ __forceinline__ void wg_exscan_hits(const i32 *hits, i32 *base, int n
 // 18.7 KB -> 15.7 KB = ten workgroups per CU instead of eight.  Lanes set different nibbles of one word at the same time
 // (atomic OR); a position is only ever given ONE value (next(s) is a function of s), so setting it twice is harmless.
 #ifndef SEED_MIN_WAVES
-#define SEED_MIN_WAVES 4        // waves per SIMD the register allocation must allow.  The LDS admits ten 128-lane workgroups per CU (5 per SIMD) since
-                                // the nibble memo, but 5 needs 96 VGPRs where the loop wants 119: measured 4.87 against 4.32 ms (16 dwords of scratch in the loop)
+#define SEED_MIN_WAVES 3        // waves per SIMD the register allocation must allow: the LDS admits ten one-wave workgroups per CU (2.5 per SIMD), the loop wants
+                                // ~120 VGPRs.  (Two waves per chunk: 4; 5 needed 96 VGPRs -- 16 dwords of scratch in the loop, 4.87 against 4.32 ms.  The
+                                // kernel's time does not depend on its occupancy between 5 and 10 chunks per CU: profiles/r03_seed_shape_sweep.txt)
 #endif
 #define LHOP_N 1024
 #define MEMO_WORDS (GSA_CHUNK / 8)
@@ -242,13 +243,21 @@ __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg
 				kn = (k == (u64)-1); ln = (l == (u64)-1);
 				kk = kn ? 0 : k - (k >= di.primary); ll = ln ? 0 : l - (l >= di.primary);
 			}
-			const FmBlock bk = fm_load(di.bwt, kk >> 7), bl = fm_load(di.bwt, ll >> 7);
+#ifdef SEED_SKIP_IDLE      // (experiment: a kind of request no lane of the wave makes is not issued at all -- the other form reads entry 0 of the table)
+#define ANY_IN(M) __any(mode == (M))
+#else
+#define ANY_IN(M) true
+#endif
+			FmBlock bk = {{0, 0, 0, 0}, {0, 0, 0, 0}, 0, 0, 0, 0}, bl = bk;
+			if (ANY_IN(M_FM)) { bk = fm_load(di, kk >> 6); bl = fm_load(di, ll >> 6); }
 			struct __attribute__((packed, aligned(4))) W5 { u32 a, b, c, d, e; };
-			const W5 w5 = *(const W5 *)(di.ref2 + (mode == M_TEXT ? (tp >> 4) : 0));      // 20 bytes of packed text: a 64-base window
+			W5 w5 = {0, 0, 0, 0, 0};
+			if (ANY_IN(M_TEXT)) w5 = *(const W5 *)(di.ref2 + (mode == M_TEXT ? (tp >> 4) : 0));      // 20 bytes of packed text: a 64-base window
 			const u32 r0 = w5.a, r1 = w5.b, r2 = w5.c, r3 = w5.d, r4 = w5.e;
 			// one k-mer table entry: 16 bytes (one load) when the text is below 2^32, else 32
 			ulonglong2 e0 = {0, 0}, e1 = {0, 0};
-			if (E16) {
+			if (!ANY_IN(M_KMER)) {}
+			else if (E16) {
 				const uint4 e = ((const uint4 *)(di.kmer ? di.kmer : (const u64 *)di.bwt))[mode == M_KMER ? kid : 0];
 				e0.x = e.x; e0.y = e.y; e1.x = e.z; e1.y = e.w;
 			} else {
@@ -259,10 +268,12 @@ __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg
 			// so walks cross the 14 bases in front of a mismatch start by start -- four of those per memory round trip, and since
 			// round 3 all four from ONE 32-byte line (pres4_*)
 			uint4 pl0 = {~0u, ~0u, ~0u, ~0u}, pl1 = {~0u, ~0u, ~0u, ~0u};
-			if (di.pres) { const uint4 *pp = (const uint4 *)di.pres + 2 * (size_t)(mode == M_KMER ? pid : 0); pl0 = pp[0]; pl1 = pp[1]; }
+			if (di.pres && ANY_IN(M_KMER)) { const uint4 *pp = (const uint4 *)di.pres + 2 * (size_t)(mode == M_KMER ? pid : 0); pl0 = pp[0]; pl1 = pp[1]; }
 			// (bit 64 i + e of the line: dword 2 i + (e >> 5); e_i packed in pext, 6 bits each)
 #define PRES4_TEST(I) ((((((pext >> (6 * (I))) & 32u) ? ((I) == 0 ? pl0.y : (I) == 1 ? pl0.w : (I) == 2 ? pl1.y : pl1.w) : ((I) == 0 ? pl0.x : (I) == 1 ? pl0.z : (I) == 2 ? pl1.x : pl1.z)) >> ((pext >> (6 * (I))) & 31u)) & 1u) != 0)
-			const u64 sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
+			u64 sav = 0;
+			if (ANY_IN(M_LOC)) sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
+#undef ANY_IN
 			// ---- consume phase: straight-line, one predicated block per mode ----
 			bool ended = false;
 			if (mode == M_KMER) {
@@ -519,7 +530,7 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 			kn = (k == (u64)-1); ln = (l == (u64)-1);
 			kk = kn ? 0 : k - (k >= di.primary); ll = ln ? 0 : l - (l >= di.primary);
 		}
-		const FmBlock bk = fm_load(di.bwt, kk >> 7), bl = fm_load(di.bwt, ll >> 7);
+		const FmBlock bk = fm_load(di, kk >> 6), bl = fm_load(di, ll >> 6);
 		struct __attribute__((packed, aligned(4))) W5 { u32 a, b, c, d, e; };
 		const W5 w5 = *(const W5 *)(di.ref2 + (mode == M_TEXT ? (tp >> 4) : 0));
 		ulonglong2 e0 = {0, 0}, e1 = {0, 0};
@@ -676,7 +687,7 @@ __global__ void __launch_bounds__(256) k_dense_sweep(DevIndex di, const uint8_t 
 			kn = (k == (u64)-1); ln = (l == (u64)-1);
 			kk = kn ? 0 : k - (k >= di.primary); ll = ln ? 0 : l - (l >= di.primary);
 		}
-		const FmBlock bk = fm_load(di.bwt, kk >> 7), bl = fm_load(di.bwt, ll >> 7);
+		const FmBlock bk = fm_load(di, kk >> 6), bl = fm_load(di, ll >> 6);
 		struct __attribute__((packed, aligned(4))) W5 { u32 a, b, c, d, e; };
 		// forward: 64 bases from tp on; backward (M_BACK): the three words that end with the base in front of the match
 		const i64 bw_word = ((tps - 1) >> 4) - 2 > 0 ? ((tps - 1) >> 4) - 2 : 0;
@@ -1125,6 +1136,64 @@ int build_presence(gsa_ctx *c)
 	return GSA_OK;
 }
 
+// ---- Occ blocks: the reference's interleaved layout (128 rows per 64-byte block: four u64 counts + 128 symbols,
+// bwt_search.cpp:69-119) regrouped into 64 rows per 32-byte block (FmBlock, gsa_fm.h) ----
+__global__ void __launch_bounds__(256) k_occ_base(const uint4 *__restrict__ src, u64 n_super, int shift, u64 *base)
+{
+	const u64 sb = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (sb >= n_super) return;
+	const uint4 *p = src + (((sb << shift) >> 1) << 2);              // (a super-block starts on an even block: a header of the reference)
+	const uint4 c0 = p[0], c1 = p[1];
+	base[4 * sb] = ((u64)c0.y << 32) | c0.x; base[4 * sb + 1] = ((u64)c0.w << 32) | c0.z; base[4 * sb + 2] = ((u64)c1.y << 32) | c1.x; base[4 * sb + 3] = ((u64)c1.w << 32) | c1.z;
+}
+__global__ void __launch_bounds__(256) k_occ_relayout(const uint4 *__restrict__ src, u64 n_blocks, const u64 *__restrict__ base, int shift, uint4 *dst)
+{
+	const u64 b = (u64)blockIdx.x * 256 + threadIdx.x;
+	if (b >= n_blocks) return;
+	const uint4 *p = src + ((b >> 1) << 2);
+	const uint4 c0 = p[0], c1 = p[1], w = p[2 + (b & 1)];
+	u64 ca = ((u64)c0.y << 32) | c0.x, cc = ((u64)c0.w << 32) | c0.z, cg = ((u64)c1.y << 32) | c1.x, ct = ((u64)c1.w << 32) | c1.z;
+	if (b & 1) {                                                      // the second half of a reference block: its header + its first 64 symbols
+		const uint4 w0 = p[2];
+		const u64 M = 0x5555555555555555ull;
+		u32 n1 = 0, n2 = 0, n3 = 0;
+		for (int J = 0; J < 2; J++) {
+			const u64 W = J ? (((u64)w0.z << 32) | w0.w) : (((u64)w0.x << 32) | w0.y);
+			const u64 lo = W & M, hi = (W >> 1) & M;
+			n3 += __popcll(hi & lo); n2 += __popcll(hi & ~lo & M); n1 += __popcll(~hi & lo & M);
+		}
+		ca += 64 - n1 - n2 - n3; cc += n1; cg += n2; ct += n3;
+	}
+	if (base) { const u64 *sb = base + ((b >> shift) << 2); ca -= sb[0]; cc -= sb[1]; cg -= sb[2]; ct -= sb[3]; }
+	dst[2 * b] = make_uint4((u32)ca, (u32)cc, (u32)cg, (u32)ct);
+	dst[2 * b + 1] = w;
+}
+
+// `ref_layout` = the index file's bwt words on the device, whole 64-byte blocks, zero-padded
+int build_occ(gsa_ctx *c, const void *ref_layout, u64 n_blocks128)
+{
+	const u64 n_blocks = 2 * n_blocks128;
+	const bool wide = c->force_wide || c->di.seq_len >= 0xFFFFFF00ull;
+	// super-blocks of 2^31 rows where the counts need them; the forced-wide layout of the test-suite uses 2^16 rows so that small
+	// texts have several super-blocks and their relative counts really are relative
+	const int shift = c->di.seq_len >= 0xFFFFFF00ull ? 25 : 10;
+	if (!dev_ensure<uint4>(c, c->d_bwt, 2 * n_blocks + 4)) return GSA_ERR_NOMEM;
+	GSA_CHECK(c, hipMemsetAsync(c->d_bwt.p, 0, (2 * n_blocks + 4) * sizeof(uint4), c->stream));
+	u64 *base = nullptr;
+	if (wide) {
+		const u64 n_super = (n_blocks >> shift) + 1;
+		if (!dev_ensure<u64>(c, c->d_occ_base, 4 * n_super)) return GSA_ERR_NOMEM;
+		base = c->d_occ_base.as<u64>();
+		hipLaunchKernelGGL(k_occ_base, dim3(grid_for(n_super, 256)), dim3(256), 0, c->stream, (const uint4 *)ref_layout, n_super, shift, base);
+		GSA_CHECK(c, hipGetLastError());
+	}
+	hipLaunchKernelGGL(k_occ_relayout, dim3(grid_for(n_blocks, 256)), dim3(256), 0, c->stream, (const uint4 *)ref_layout, n_blocks, (const u64 *)base, shift, c->d_bwt.as<uint4>());
+	GSA_CHECK(c, hipGetLastError());
+	GSA_CHECK(c, hipStreamSynchronize(c->stream));
+	c->di.bwt = c->d_bwt.as<uint4>(); c->di.occ_base = base; c->di.occ_shift = shift;
+	return GSA_OK;
+}
+
 int build_dense_sa(gsa_ctx *c, u64 n_sa)
 {
 	{
@@ -1208,9 +1277,38 @@ static int prepare_pd_bitmap(gsa_ctx *c, i64 n_hits)
 // independently (GSAlign.cpp:61-94: a thread takes 10 000-bp chunks off a counter; seeds never cross a chunk edge), so a
 // long contig can be seeded by several GPUs and the hits sent to the GPU that chains it.  The
 // kernels see the range as a contig of its own (pointer + length); only the select kernel needs the absolute position.
+// At most GSA_SEED_SLOTS contexts of one GPU inside their seed-search kernels at a time (0 = no limit).  Contexts that are
+// handed contigs of one size start together and stay in step -- four speculative kernels compete for the one resource that bounds
+// them (random 32-byte sectors of HBM), then four chaining stages, which are chains of short dependent passes, leave the chip
+// idle together (kernel timeline: profiles/r03_timeline_multi_human.txt).  With a gate in front of the seed kernels the contexts
+// fall out of step: one searches while the others chain and extend.
+#include <mutex>
+#include <condition_variable>
+static std::mutex g_seed_mu; static std::condition_variable g_seed_cv; static int g_seed_busy[64];
+struct SeedGate {
+	int dev, slots; bool held;
+	SeedGate(int d, int n) : dev(d & 63), slots(n), held(false) { if (slots > 0) { std::unique_lock<std::mutex> lk(g_seed_mu); g_seed_cv.wait(lk, [&] { return g_seed_busy[dev] < slots; }); g_seed_busy[dev]++; held = true; } }
+	void release() { if (held) { { std::lock_guard<std::mutex> lk(g_seed_mu); g_seed_busy[dev]--; } g_seed_cv.notify_all(); held = false; } }
+	~SeedGate() { release(); }
+};
+
 int stage1_seed(gsa_ctx *c)
 {
+	// GSA_SEED_CUS=n (experiment): the seed-search kernels run on a stream that may only use n of the CUs, spread evenly
+	static const int seed_cus = [] { const char *e = getenv("GSA_SEED_CUS"); return e ? atoi(e) : 0; }();
+	if (seed_cus > 0 && !c->stream_seed) {
+		hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device));
+		const int ncu = pr.multiProcessorCount;
+		std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+		for (int i = 0; i < ncu; i++) if ((long long)(i + 1) * seed_cus / ncu != (long long)i * seed_cus / ncu) mask[(size_t)i >> 5] |= 1u << (i & 31);
+		GSA_CHECK(c, hipExtStreamCreateWithCUMask(&c->stream_seed, (uint32_t)mask.size(), mask.data()));
+		GSA_CHECK(c, hipEventCreateWithFlags(&c->ev_seed_fork, hipEventDisableTiming));
+	}
 	hipStream_t st = c->stream;
+	if (c->stream_seed) {      // (everything in front of the search on the main stream -- the contig's upload -- first; the host waits for the search itself)
+		GSA_CHECK(c, hipEventRecord(c->ev_seed_fork, c->stream)); GSA_CHECK(c, hipStreamWaitEvent(c->stream_seed, c->ev_seed_fork, 0));
+		st = c->stream_seed;
+	}
 	const bool split = c->split;
 	const i64 all_chunks = ((i64)c->qlen + GSA_CHUNK - 1) / GSA_CHUNK;
 	const i64 cb = split ? c->rng_beg : 0, ce = split ? (c->rng_end < all_chunks ? c->rng_end : all_chunks) : all_chunks;
@@ -1241,6 +1339,8 @@ int stage1_seed(gsa_ctx *c)
 	const u32 budget = c->count_blocks ? 0u : c->seed_budget;
 	if (dense_all && ccap < GSA_CHUNK / 5 + 64) { ccap = GSA_CHUNK / 5 + 64; c->cand_cap_per_chunk = ccap; }      // one accepted start in five at most
 	u64 occ_all = 0;
+	static const int seed_slots = [] { const char *e = getenv("GSA_SEED_SLOTS"); return e ? atoi(e) : 0; }();
+	SeedGate gate(c->device, (c->profiling || c->count_blocks) ? 0 : seed_slots);
 	for (int attempt = 0;; attempt++) {
 		if (attempt == 8) return gsa_fail(c, GSA_ERR_LIMIT, "seed buffers keep overflowing");
 		const size_t ctot = ccap * (size_t)n_chunks;
@@ -1299,6 +1399,8 @@ int stage1_seed(gsa_ctx *c)
 		n_hits = (i64)hits;
 		break;
 	}
+	gate.release();
+	st = c->stream;      // (the host has waited for the search kernels: what follows is ordered behind them)
 	const size_t hcap = (size_t)n_hits + 64;
 	// Groups: a new group starts where the sorted PosDiff values jump by more than MaxIndelSize.  With a bitmap of the
 	// occupied PosDiff values that needs no sort: group id = number of group starts at or below a hit's PosDiff (a scan
