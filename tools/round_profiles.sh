@@ -2,10 +2,10 @@
 # Round-end measurements on the GPU box: default bench line, rocprofv3 kernel-trace summaries of the three workloads, PMC passes.
 #   gpurun -- 'bash tools/round_profiles.sh'   ->  gpurun_out/{bench_default.json, kernels_<w>.txt, pmc_human/*.csv}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 tail -c 600 gpurun_out/bench_default.json
 for w in human ecoli yeast; do
-  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$w -o p -- python bench.py --workload $w --steps 20 --warmup 5 --extra "" --no-cpu-baseline > gpurun_out/prof_$w.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$w -o p -- python bench.py --workload $w --steps 20 --warmup 5 --extra "" --no-cpu-baseline > gpurun_out/prof_$w.log 2>&1
   python tools/rocprof_summary.py gpurun_out/prof_$w/p_results.db > gpurun_out/kernels_$w.txt
   rm -rf gpurun_out/prof_$w
 done
