@@ -44,11 +44,12 @@ static void run(const uint4 *tab, uint64_t bytes, int wg, int rounds, int chain,
 	       bytes / 1e9, BYTES, wg, chain, reads / ms / 1e6, reads * BYTES / ms / 1e6, ms);
 }
 
-int main()
+int main(int argc, char **argv)
 {
 	uint32_t *sink; hipMalloc(&sink, 64);
-	const uint64_t sizes[] = {64ull << 20, 512ull << 20, 4ull << 30, 17ull << 30, 48ull << 30};
+	const uint64_t sizes[] = {64ull << 20, 512ull << 20, 4ull << 30, 17ull << 30, 48ull << 30};      // (argv[1] = one size in MB)
 	for (uint64_t bytes : sizes) {
+		if (argc > 1 && bytes != ((uint64_t)atoll(argv[1]) << 20)) continue;
 		uint4 *tab = nullptr;
 		if (hipMalloc(&tab, bytes) != hipSuccess) { printf("  (no %llu MB)\n", (unsigned long long)(bytes >> 20)); continue; }
 		hipMemset(tab, 0, bytes);
@@ -59,6 +60,8 @@ int main()
 		}
 		run<16>(tab, bytes, 4096, 8, 8, sink);
 		run<64>(tab, bytes, 4096, 8, 8, sink);
+		// few lanes in flight (the seed kernel holds ~2 500 waves x 15 active lanes = 150 workgroups' worth): latency-bound rates
+		for (int wg : {40, 150, 300, 600}) { run<16>(tab, bytes, wg, 64, 8, sink); run<32>(tab, bytes, wg, 64, 8, sink); }
 		hipFree(tab);
 	}
 	return 0;
