@@ -44,18 +44,19 @@ __device__ __forceinline__ FmBlock fm_load(const DevIndex &di, u64 blk)
 	return b;
 }
 
-// counts of C,G,T among the first n (1..64) symbols of the block; A follows from n
+// counts of C,G,T among the first n (1..64) symbols of the block; A follows from n.  The first symbol sits in the top bits of
+// a word, so "the first k symbols" are moved to the bottom by ONE shift and the symbols shifted in are code 0 = A, which is not
+// counted: no mask.  Three popcounts per word (both bits, low bits, high bits): C = low - both, G = high - both, T = both.
 __device__ __forceinline__ void fm_count(const FmBlock &b, int n, u32 &c1, u32 &c2, u32 &c3)
 {
 	const u64 M = 0x5555555555555555ull;
-	c1 = c2 = c3 = 0;
-#define GSA_CNT(J, HI, LO) { int nj = n - 32 * (J); nj = nj < 0 ? 0 : (nj > 32 ? 32 : nj); \
-		const u64 W = ((u64)(HI) << 32) | (LO); \
-		const u64 m = nj == 0 ? 0ull : (M & ~((nj == 32) ? 0ull : ((1ull << (64 - 2 * nj)) - 1))); \
-		const u64 lo = W & M, hi = (W >> 1) & M; \
-		c3 += __popcll(hi & lo & m); c2 += __popcll(hi & ~lo & m); c1 += __popcll(~hi & lo & m); }
-	GSA_CNT(0, b.w.x, b.w.y) GSA_CNT(1, b.w.z, b.w.w)
-#undef GSA_CNT
+	const int n0 = n < 32 ? n : 32, n1 = n - 32;                      // symbols taken from word 0 (1..32) and word 1 (<= 0: none)
+	const u64 w0 = (((u64)b.w.x << 32) | b.w.y) >> (64 - 2 * n0);
+	const u64 w1 = n1 > 0 ? (((u64)b.w.z << 32) | b.w.w) >> (64 - 2 * n1) : 0ull;
+	const u64 lo0 = w0 & M, hi0 = (w0 >> 1) & M, lo1 = w1 & M, hi1 = (w1 >> 1) & M;
+	c3 = (u32)(__popcll(hi0 & lo0) + __popcll(hi1 & lo1));
+	c1 = (u32)(__popcll(lo0) + __popcll(lo1)) - c3;
+	c2 = (u32)(__popcll(hi0) + __popcll(hi1)) - c3;
 }
 
 struct Occ4 { u64 a, c, g, t; };

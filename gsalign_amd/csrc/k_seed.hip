@@ -4,6 +4,9 @@
 // Replaces IdentifyLocalMEM + BWT_Search + bwt_sa + SeedGrouping
 // (reference src/GSAlign.cpp:51-107,126-143; src/bwt_search.cpp:121-185).
 #include <cstring>
+#include <mutex>
+#include <condition_variable>
+#include <vector>
 #include "gsa_ctx.h"
 #include "gsa_fm.h"
 #include "gsa_scan.h"
@@ -293,6 +296,7 @@ __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg
 				} else {
 					const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k, walk it base by base
 					if (hit) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; }
+					else ik = fm_init(di, q_code(qp, s));      // (pos = s + 1 since the search was opened)
 					mode = M_FM;
 					if (hit && ik.x2 == 1) { tp = (i64)(e1.y - 1) + di.kmer_k; mode = M_TEXT; }      // unique: straight to the text comparison
 				}
@@ -342,8 +346,14 @@ __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg
 				if (nb & 1u) { memo_one(memo, s); if (COUNT) mblk[s] = 0; s += 1; }
 				else if (!COUNT && (s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0)) { memo_one(memo, s); s += 1; }      // cannot reach MinSeedLength
 				else {
-					ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
-					if (!COUNT && di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
+					pos = s + 1; blk = 0; mode = M_FM;
+					// (the interval of the first base -- fm_init: three 5-way selects of 64-bit numbers -- only where the walk really starts
+					//  at the first base: next to the chunk end / an N, or behind a k-mer entry that says "absent")
+#ifdef SEED_EAGER_INIT      // (A/B switch: the interval of the first base computed for every search that is opened, as until late round 3)
+					ik = fm_init(di, q_code(qp, s));
+#endif
+					if (COUNT || !(di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0)) ik = fm_init(di, q_code(qp, s));
+					else {
 						const u64 qb = q_bits64(qp, s);
 						kid = (u32)(qb & ((1ull << (2 * di.kmer_k)) - 1)); mode = M_KMER;
 						// the line of the presence table that answers for s .. s+3, and the four positions inside it
@@ -1282,8 +1292,6 @@ static int prepare_pd_bitmap(gsa_ctx *c, i64 n_hits)
 // them (random 32-byte sectors of HBM), then four chaining stages, which are chains of short dependent passes, leave the chip
 // idle together (kernel timeline: profiles/r03_timeline_multi_human.txt).  With a gate in front of the seed kernels the contexts
 // fall out of step: one searches while the others chain and extend.
-#include <mutex>
-#include <condition_variable>
 static std::mutex g_seed_mu; static std::condition_variable g_seed_cv; static int g_seed_busy[64];
 struct SeedGate {
 	int dev, slots; bool held;
