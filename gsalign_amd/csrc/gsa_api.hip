@@ -46,7 +46,7 @@ static int ctx_private_init(gsa_ctx *c)
 	GSA_CHECK(c, hipStreamCreate(&c->stream));
 	for (int i = 0; i < 3; i++) GSA_CHECK(c, hipStreamCreate(&c->stream_aux[i]));
 	for (int i = 0; i < 28; i++) GSA_CHECK(c, hipEventCreate(&c->ev[i]));
-	GSA_CHECK(c, hipMalloc(&c->d_cnt.p, 16 * sizeof(u64))); c->d_cnt.cap = 16 * sizeof(u64); GSA_CHECK(c, hipMemset(c->d_cnt.p, 0, 16 * sizeof(u64)));
+	GSA_CHECK(c, hipMalloc(&c->d_cnt.p, 32 * sizeof(u64))); c->d_cnt.cap = 32 * sizeof(u64); GSA_CHECK(c, hipMemset(c->d_cnt.p, 0, 32 * sizeof(u64)));      // (16 counters + the seed kernel's ticket counter)
 	GSA_CHECK(c, hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(u64)));
 	GSA_CHECK(c, hipMalloc(&c->d_mail.p, MAIL_N * sizeof(i32))); c->d_mail.cap = MAIL_N * sizeof(i32);
 	GSA_CHECK(c, hipMemset(c->d_mail.p, 0, MAIL_N * sizeof(i32)));

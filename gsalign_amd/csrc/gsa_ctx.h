@@ -35,6 +35,8 @@ struct gsa_ctx {
 	hipStream_t stream = nullptr;
 	hipStream_t stream_seed = nullptr;      // (experiment, GSA_SEED_CUS: the seed-search kernels on a stream restricted to part of the CUs)
 	hipEvent_t ev_seed_fork = nullptr;
+	u64 seed_ticket = 0;                    // value of the seed kernel's ticket counter (d_cnt[16]) before the next launch
+	int n_cus = 0;
 	hipStream_t stream_aux[3] = {nullptr, nullptr, nullptr};   // [0] early striped DP, [1] tiny DP + strings + sums, [2] records to the host (four streams in all: one per hardware queue)
 	std::string err;
 	Params prm;

@@ -162,9 +162,9 @@ __device__ __forceinline__ void memo_set(u32 *memo, u32 *lhop, int s, int d, int
 }
 
 template <bool COUNT, bool E16>
-__global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
+__device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__restrict__ q, i32 qlen, const Params &prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
-                                                      u32 budget, u32 *heavy_list, i32 *chunk_base)
+                                                      u32 budget, u32 *heavy_list, i32 *chunk_base, const int chunk, const u32 n_chunks)
 {
 	__shared__ u32 s_ncand, s_queue, s_hits;
 	__shared__ int changed, s_abort;
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg
 	__shared__ uint16_t pend_it[SEED_WG];                       // sub-ranges to walk for real in this pass
 	__shared__ uint16_t jmp[2][NSUB], walked_from[NSUB];        // pointer-jumping buffers; entry of the last real walk of a re-walked sub-range
 	__shared__ u32 rewalked[NSUB / 32], onchain[NSUB / 32], s_npend;
-	const int chunk = blockIdx.x, j = threadIdx.x;
+	const int j = threadIdx.x;
 	const i64 c0 = (i64)chunk * GSA_CHUNK;
 	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
 	// stage the chunk: 32 bases per lane per pass -> two code words + one N word (16-byte global loads)
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg
 		if (j == 0) {
 			const u32 hslot = (u32)atomicAdd((unsigned long long *)&cnt[CNT_HEAVY], 1ull);
 			heavy_list[hslot] = (u32)chunk;
-			s_ncand = 0; cand_cnt[chunk] = 0; lb_pub(&chunk_hits[chunk], 0); if (chunk == 0) lb_pub(&chunk_hits[gridDim.x], 0);
+			s_ncand = 0; cand_cnt[chunk] = 0; lb_pub(&chunk_hits[chunk], 0); if (chunk == 0) lb_pub(&chunk_hits[n_chunks], 0);
 		}
 		__syncthreads();
 	}
@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg
 		if ((j & 63) == 0 && h) atomicAdd(&s_hits, h);
 		__syncthreads();
 		if (j == 0) {
-			cand_cnt[chunk] = nc; lb_pub(&chunk_hits[chunk], (i32)s_hits); if (chunk == 0) lb_pub(&chunk_hits[gridDim.x], 0); atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand);
+			cand_cnt[chunk] = nc; lb_pub(&chunk_hits[chunk], (i32)s_hits); if (chunk == 0) lb_pub(&chunk_hits[n_chunks], 0); atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand);
 			if (s_hits) atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)s_hits);      // the contig's total: all the host needs to go on
 		}
 	}
@@ -467,14 +467,38 @@ __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg
 	__syncthreads();
 	if (j == 0) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (counters are device atomics; an agent-scope fence is an L2 write-back per workgroup here)
-		s_last = atomicAdd((unsigned long long *)&cnt[CNT_DONE], 1ull) == (unsigned long long)gridDim.x - 1 ? 1 : 0;
+		s_last = atomicAdd((unsigned long long *)&cnt[CNT_DONE], 1ull) == (unsigned long long)n_chunks - 1 ? 1 : 0;
 	}
 	__syncthreads();
 	if (s_last && j < 16) {
 		hcnt[j] = j == CNT_DONE ? 0 : __hip_atomic_load(&cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		cnt[j] = 0;
 	}
-	if (s_last) wg_exscan_hits<SEED_WG>(chunk_hits, chunk_base, (int)gridDim.x + 1);
+	if (s_last) wg_exscan_hits<SEED_WG>(chunk_hits, chunk_base, (int)n_chunks + 1);
+}
+
+
+// The kernel: workgroups DRAW their chunks from a ticket counter (cnt[SEED_TICKET], never reset: the host passes the value it has
+// at launch, and a launch of g workgroups over n chunks leaves it n + g higher -- every workgroup's last draw is the one that fails).
+// With g = n every workgroup takes one chunk, as a plain grid would; with fewer the launch is PERSISTENT and holds at most g
+// workgroups' worth of LDS and wave slots whatever the contig's size (GSA_SEED_PERSIST = workgroups per CU; the kernel's own time does
+// not depend on how many chunks a CU works on between 5 and 12, DESIGN section 4 (vi), and what it leaves free the kernels of other
+// contexts can take).
+#define SEED_TICKET 16
+template <bool COUNT, bool E16>
+__global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
+                                                      i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
+                                                      u32 budget, u32 *heavy_list, i32 *chunk_base, u64 tk_base, u32 n_chunks)
+{
+	__shared__ u32 s_tk;
+	for (;;) {
+		__syncthreads();
+		if (threadIdx.x == 0) s_tk = (u32)(atomicAdd((unsigned long long *)&cnt[SEED_TICKET], 1ull) - tk_base);
+		__syncthreads();
+		const u32 chunk = s_tk;
+		if (chunk >= n_chunks) return;
+		seed_chunk<COUNT, E16>(di, q, qlen, prm, cnt, cand_s, cand_len, cand_x0, cand_freq, cand_cap, cand_cnt, onpath, chunk_hits, hcnt, budget, heavy_list, chunk_base, (int)chunk, n_chunks);
+	}
 }
 
 
@@ -1361,9 +1385,17 @@ int stage1_seed(gsa_ctx *c)
 		if (!dense_all) {
 #define GSA_SEED_ARGS c->di, d_q, qlen, c->prm, cnt, c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, \
 			c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>(), c->h_cnt, budget, c->d_heavy.as<u32>(), c->d_chunk_base.as<i32>()
-			if (c->count_blocks) hipLaunchKernelGGL((k_seed_wg<true, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, GSA_SEED_ARGS);
-			else if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, GSA_SEED_ARGS);
-			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3((unsigned)n_chunks), dim3(SEED_WG), 0, st, GSA_SEED_ARGS);
+			// (persistent launch: GSA_SEED_PERSIST workgroups per CU -- default 10, what the LDS admits -- draw the chunks from the ticket counter;
+			//  0 = one workgroup per chunk.  Measured on a 250 Mb contig: the kernel alone 3.40 -> 3.20 ms at 10 or 16 per CU, 3.6 / 4.2 / 4.8 / 5.7 /
+			//  7.1 / 9.9 ms at 8 / 6 / 5 / 4 / 3 / 2 (the dispatcher fills CUs one after the other, so fewer workgroups mean fewer CUs, not thinner
+			//  ones); four contexts' throughput within +- 2 % of each other from 4 per CU upwards: tools/persist.sh)
+			static const int persist = [] { const char *e = getenv("GSA_SEED_PERSIST"); return e ? atoi(e) : 10; }();
+			unsigned grid = (unsigned)n_chunks;
+			if (persist > 0 && !c->count_blocks) { if (c->n_cus <= 0) { hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device)); c->n_cus = pr.multiProcessorCount; } const i64 cap = (i64)persist * c->n_cus; if (cap < n_chunks) grid = (unsigned)cap; }
+			const u64 tk_base = c->seed_ticket; c->seed_ticket += (u64)n_chunks + grid;
+			if (c->count_blocks) hipLaunchKernelGGL((k_seed_wg<true, false>), dim3(grid), dim3(SEED_WG), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
+			else if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3(grid), dim3(SEED_WG), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
+			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3(grid), dim3(SEED_WG), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
 #undef GSA_SEED_ARGS
 			if (c->profiling || c->prof_seed) hipEventRecord(c->ev[1], st);
 			// (the counters are in pinned memory when the seed kernel is done; the host waits for that, not for the scan of the
