@@ -398,8 +398,8 @@ def dry_main(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=80)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="human", choices=sorted(WORKLOADS))
     ap.add_argument("--genome", type=int, default=0, help="override the reference length of a one-contig workload")
     ap.add_argument("--divergence", type=float, default=-1.0)
