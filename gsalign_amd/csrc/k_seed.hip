@@ -272,8 +272,9 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 			// round 3 all four from ONE 32-byte line (pres4_*)
 			uint4 pl0 = {~0u, ~0u, ~0u, ~0u}, pl1 = {~0u, ~0u, ~0u, ~0u};
 			if (di.pres && ANY_IN(M_KMER)) { const uint4 *pp = (const uint4 *)di.pres + 2 * (size_t)(mode == M_KMER ? pid : 0); pl0 = pp[0]; pl1 = pp[1]; }
-			// (bit 64 i + e of the line: dword 2 i + (e >> 5); e_i packed in pext, 6 bits each)
-#define PRES4_TEST(I) ((((((pext >> (6 * (I))) & 32u) ? ((I) == 0 ? pl0.y : (I) == 1 ? pl0.w : (I) == 2 ? pl1.y : pl1.w) : ((I) == 0 ? pl0.x : (I) == 1 ? pl0.z : (I) == 2 ? pl1.x : pl1.z)) >> ((pext >> (6 * (I))) & 31u)) & 1u) != 0)
+			// (bit 64 i + e_i of the line: dword 2 i + (e_i >> 5).  e_i = pres4_bit(.., i) & 63 = the three bases outside the core = bits 2 i .. 2 i + 5 of
+			//  the 12-bit number pext = q[s .. s+3) | q[s+K .. s+K+3) << 6: one number per open search instead of four packed ones)
+#define PRES4_TEST(I) ((((((pext >> (2 * (I))) & 32u) ? ((I) == 0 ? pl0.y : (I) == 1 ? pl0.w : (I) == 2 ? pl1.y : pl1.w) : ((I) == 0 ? pl0.x : (I) == 1 ? pl0.z : (I) == 2 ? pl1.x : pl1.z)) >> ((pext >> (2 * (I))) & 31u)) & 1u) != 0)
 			u64 sav = 0;
 			if (ANY_IN(M_LOC)) sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
 #undef ANY_IN
@@ -358,7 +359,7 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 						kid = (u32)(qb & ((1ull << (2 * di.kmer_k)) - 1)); mode = M_KMER;
 						// the line of the presence table that answers for s .. s+3, and the four positions inside it
 						pid = di.pres_k ? pres4_line(qb, di.pres_k) : 0;
-						pext = di.pres_k ? ((pres4_bit(qb, di.pres_k, 0) & 63u) | ((pres4_bit(qb, di.pres_k, 1) & 63u) << 6) | ((pres4_bit(qb, di.pres_k, 2) & 63u) << 12) | ((pres4_bit(qb, di.pres_k, 3) & 63u) << 18)) : 0;
+						pext = di.pres_k ? (((u32)qb & 63u) | (((u32)(qb >> (2 * di.pres_k)) & 63u) << 6)) : 0;
 					}
 				}
 			}
