@@ -161,6 +161,41 @@ __device__ __forceinline__ void memo_set(u32 *memo, u32 *lhop, int s, int d, int
 	*(volatile int *)abort_flag = 1;                                // table full: the chunk is redone by the dense kernels
 }
 
+// Four ASCII bases (one dword, first base in the low byte) -> their nt4 codes packed LSB first in bits 0-7 (an ambiguous base: code 0,
+// as gsa_nt4's 4 & 3) | the "ambiguous" flags of the four in bits 8-11.  gsa_nt4 (nst_nt4_table, bntseq.c:40-57) byte by byte costs
+// ~17 VALU instructions per base; staging a 10 000-base chunk that way was a tenth of the seed kernel's instructions.  Here: fold the
+// case, code = ((b >> 1) & 3) ^ (its own high bit) -- a 0, c 1, g 3 ^ 1 = 2, t 2 ^ 1 = 3 -- look the letter that code stands for up with
+// one v_perm and compare: anything that is not that letter is ambiguous.  ~5 instructions per base.
+__device__ __forceinline__ u32 nt4_quad(u32 w)
+{
+	const u32 l = w | 0x20202020u;
+	const u32 x = (l >> 1) & 0x03030303u;
+	u32 code = x ^ ((x >> 1) & 0x01010101u);
+	const u32 want = __builtin_amdgcn_perm(0u, 0x74676361u, code);               // bytes 'a' 'c' 'g' 't' selected by the four codes
+	const u32 diff = l ^ want;
+	const u32 bad = ((diff | ((diff & 0x7f7f7f7fu) + 0x7f7f7f7fu)) >> 7) & 0x01010101u;      // 1 per byte that is not the letter of its code
+	code &= ~(bad * 3u);
+	return ((code * 0x01041040u) >> 24) | (((bad * 0x01020408u) >> 24) & 15u) << 8;
+}
+
+// 32 bases from `src` (position p0 of a chunk of clen bases; behind the chunk: N) -> two words of 2-bit codes + the word of their N flags
+__device__ __forceinline__ void stage32(const uint8_t *src, int p0, int clen, u32 &w0, u32 &w1, u32 &wn)
+{
+	u32 d[8];
+	if (p0 + 32 <= clen) { const uint4 a = *(const uint4 *)src, b = *(const uint4 *)(src + 16); d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w; }
+	else {
+#pragma unroll
+		for (int t = 0; t < 8; t++) { d[t] = 0; for (int k = 0; k < 4; k++) d[t] |= (u32)(p0 + 4 * t + k < clen ? src[4 * t + k] : (uint8_t)'N') << (8 * k); }
+	}
+	w0 = w1 = wn = 0;
+#pragma unroll
+	for (int t = 0; t < 8; t++) {
+		const u32 r = nt4_quad(d[t]);
+		if (t < 4) w0 |= (r & 0xffu) << (8 * t); else w1 |= (r & 0xffu) << (8 * (t - 4));
+		wn |= (r >> 8) << (4 * t);
+	}
+}
+
 template <bool COUNT, bool E16>
 __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__restrict__ q, i32 qlen, const Params &prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
@@ -187,16 +222,7 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 		u32 w0 = 0, w1 = 0, wn = 0;
 		const int p0 = g << 5;
 		if (p0 < clen) {
-			const uint8_t *src = q + c0 + p0;
-			uint8_t b[32];
-			if (p0 + 32 <= clen) { *(uint4 *)&b[0] = *(const uint4 *)src; *(uint4 *)&b[16] = *(const uint4 *)(src + 16); }
-			else { for (int t = 0; t < 32; t++) b[t] = p0 + t < clen ? src[t] : (uint8_t)'N'; }
-#pragma unroll
-			for (int t = 0; t < 32; t++) {
-				const u32 cd = (u32)gsa_nt4(b[t]);
-				if (t < 16) w0 |= (cd & 3) << (2 * t); else w1 |= (cd & 3) << (2 * (t - 16));
-				wn |= (cd > 3 ? 1u : 0u) << t;
-			}
+			stage32(q + c0 + p0, p0, clen, w0, w1, wn);
 		}
 		if (2 * g < QP_WORDS) qp[2 * g] = w0;
 		if (2 * g + 1 < QP_WORDS) qp[2 * g + 1] = w1;
@@ -536,16 +562,7 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 		u32 w0 = 0, w1 = 0, wn = 0;
 		const int p0 = g << 5;
 		if (p0 < clen) {
-			const uint8_t *src = q + c0 + p0;
-			uint8_t b[32];
-			if (p0 + 32 <= clen) { *(uint4 *)&b[0] = *(const uint4 *)src; *(uint4 *)&b[16] = *(const uint4 *)(src + 16); }
-			else { for (int t = 0; t < 32; t++) b[t] = p0 + t < clen ? src[t] : (uint8_t)'N'; }
-#pragma unroll
-			for (int t = 0; t < 32; t++) {
-				const u32 cd = (u32)gsa_nt4(b[t]);
-				if (t < 16) w0 |= (cd & 3) << (2 * t); else w1 |= (cd & 3) << (2 * (t - 16));
-				wn |= (cd > 3 ? 1u : 0u) << t;
-			}
+			stage32(q + c0 + p0, p0, clen, w0, w1, wn);
 		}
 		if (2 * g < QP_WORDS) qp[2 * g] = w0;
 		if (2 * g + 1 < QP_WORDS) qp[2 * g + 1] = w1;
@@ -682,16 +699,7 @@ __global__ void __launch_bounds__(256) k_dense_sweep(DevIndex di, const uint8_t 
 		u32 w0 = 0, w1 = 0, wn = 0;
 		const int p0 = g << 5;
 		if (p0 < clen) {
-			const uint8_t *src = q + c0 + p0;
-			uint8_t b[32];
-			if (p0 + 32 <= clen) { *(uint4 *)&b[0] = *(const uint4 *)src; *(uint4 *)&b[16] = *(const uint4 *)(src + 16); }
-			else { for (int t = 0; t < 32; t++) b[t] = p0 + t < clen ? src[t] : (uint8_t)'N'; }
-#pragma unroll
-			for (int t = 0; t < 32; t++) {
-				const u32 cd = (u32)gsa_nt4(b[t]);
-				if (t < 16) w0 |= (cd & 3) << (2 * t); else w1 |= (cd & 3) << (2 * (t - 16));
-				wn |= (cd > 3 ? 1u : 0u) << t;
-			}
+			stage32(q + c0 + p0, p0, clen, w0, w1, wn);
 		} else wn = ~0u;
 		if (2 * g < QP_WORDS) qp[2 * g] = w0;
 		if (2 * g + 1 < QP_WORDS) qp[2 * g + 1] = w1;
