@@ -114,6 +114,8 @@ def load_library() -> C.CDLL:
     lib.gsa_device_upload.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.gsa_align_contig_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(Result)]
     lib.gsa_set_query_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.gsa_prefetch_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
+    lib.gsa_cancel_prefetch.argtypes = [C.c_void_p]
     lib.gsa_last_error.restype = C.c_char_p
     lib.gsa_last_error.argtypes = [C.c_void_p]
     lib.gsa_seed_count.restype = C.c_int64
@@ -157,11 +159,13 @@ class DeviceContig:
             self.lib.gsa_device_free(self.device, C.c_void_p(self.ptr)); self.ptr = None
 
 
-def align_many(aligners, contigs, on_result=None, in_order: bool = False, bundle: bool = True) -> None:
+def align_many(aligners, contigs, on_result=None, in_order: bool = False, bundle: bool = True, prefetch: bool = True) -> None:
     """gsa_align_many: `contigs` (uint8 arrays, or DeviceContig objects -- all of one kind) on the given contexts, one host
     thread per context inside the library.  on_result(contig_index, Result) runs on the worker threads (the Result is valid
     during the call only).  in_order: hand the contigs out as listed (GSA_MANY_IN_ORDER) instead of longest first.
-    bundle=False: GSA_MANY_NO_BUNDLE (every contig in a pass of its own; by default short contigs share passes)."""
+    bundle=False: GSA_MANY_NO_BUNDLE (every contig in a pass of its own; by default short contigs share passes).
+    prefetch=False: GSA_MANY_NO_PREFETCH (a contig is uploaded when its turn comes; by default a context uploads its next contig
+    while it aligns the current one)."""
     lib = aligners[0].lib
     n = len(contigs)
     ctxs = (C.c_void_p * len(aligners))(*[a.ctx for a in aligners])
@@ -170,7 +174,7 @@ def align_many(aligners, contigs, on_result=None, in_order: bool = False, bundle
     ql = (C.c_int32 * n)(*[int(c.size) for c in contigs])
     cb = RESULT_FN((lambda user, ci, res: int(on_result(ci, res.contents) or 0)) if on_result else 0)
     lib.gsa_align_many.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_int32, C.c_uint32, RESULT_FN, C.c_void_p]
-    rc = lib.gsa_align_many(ctxs, len(aligners), qs, ql, n, (1 if in_order else 0) | (2 if on_dev else 0) | (0 if bundle else 8), cb, None)
+    rc = lib.gsa_align_many(ctxs, len(aligners), qs, ql, n, (1 if in_order else 0) | (2 if on_dev else 0) | (0 if bundle else 8) | (0 if prefetch else 16), cb, None)
     if rc != 0:
         msgs = [lib.gsa_last_error(a.ctx).decode() for a in aligners]
         raise GsaError(f"gsa_align_many -> {rc}: {'; '.join(m for m in msgs if m)}")
@@ -254,6 +258,13 @@ class Aligner:
         d = DeviceContig(self.lib, device, seq)
         self._devbufs.append(d)
         return d
+
+    def prefetch_contig(self, seq: np.ndarray):
+        """gsa_prefetch_contig: start the upload of the NEXT contig; the following align_contig(seq) -- same buffer -- finds it on the device."""
+        self._ck(self.lib.gsa_prefetch_contig(self.ctx, seq.ctypes.data_as(C.c_char_p), C.c_int32(seq.size)))
+
+    def cancel_prefetch(self):
+        self._ck(self.lib.gsa_cancel_prefetch(self.ctx))
 
     def align_contig_device(self, d: DeviceContig) -> dict:
         res = Result()

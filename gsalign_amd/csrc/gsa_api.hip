@@ -40,11 +40,66 @@ void collect_events(gsa_ctx *c)
 	(void)hipGetLastError();
 }
 
+void Uploader::run()
+{
+	(void)hipSetDevice(device);
+	for (;;) {
+		Job j;
+		{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return stop || !q.empty(); }); if (q.empty()) return; j = std::move(q.front()); q.pop_front(); if (n_demand > 0) n_demand--; }
+		const auto t0 = std::chrono::steady_clock::now();
+		for (const Piece &p : j.pieces) if (p.n) { (void)hipMemcpyAsync(p.dst, p.src, p.n, hipMemcpyHostToDevice, st); bytes += p.n; }
+		(void)hipStreamSynchronize(st); (void)hipGetLastError();
+		const auto t1 = std::chrono::steady_clock::now();
+		{ std::lock_guard<std::mutex> g(mu); copy_ms += std::chrono::duration<double, std::milli>(t1 - t0).count(); wait_ms += std::chrono::duration<double, std::milli>(t0 - j.t_push).count(); jobs++; }
+		j.busy->fetch_sub(1, std::memory_order_release);
+	}
+}
+
+static int uploader_start(gsa_ctx *c)
+{
+	Uploader *u = new Uploader(); u->device = c->device;
+	if (hipStreamCreateWithFlags(&u->st, hipStreamNonBlocking) != hipSuccess) { delete u; return gsa_fail(c, GSA_ERR_HIP, "hipStreamCreate (upload stream)"); }
+	u->th = std::thread([u] { u->run(); });
+	c->up = u; c->own_up = true;
+	return GSA_OK;
+}
+
+static void uploader_stop(gsa_ctx *c)
+{
+	if (!c->up || !c->own_up) { c->up = nullptr; return; }
+	Uploader *u = c->up;
+	{ std::lock_guard<std::mutex> g(u->mu); u->stop = true; }
+	u->cv.notify_all();
+	if (u->th.joinable()) u->th.join();
+#ifdef GSA_EXPERIMENTS
+	if (getenv("GSA_UP_STATS") && u->jobs) fprintf(stderr, "[uploader] %lld jobs, %.1f MB each, %.2f ms in the queue, %.2f ms copying (%.1f GB/s)\n", (long long)u->jobs, u->bytes / 1e6 / u->jobs, u->wait_ms / u->jobs, u->copy_ms / u->jobs, u->bytes / 1e6 / u->copy_ms);
+#endif
+	if (u->st) hipStreamDestroy(u->st);
+	delete u; c->up = nullptr;
+}
+
+static inline void slot_wait(QuerySlot &s) { while (s.busy.load(std::memory_order_acquire) > 0) std::this_thread::yield(); }
+// A context needs this slot NOW: its upload, if it has not started, goes to the front of the queue (uploads somebody waits for before
+// uploads of contigs whose turn comes later: at the start of a run every context has two contigs in the queue and the GPU has nothing)
+static void slot_demand(gsa_ctx *c, QuerySlot &s)
+{
+	if (s.busy.load(std::memory_order_acquire) > 0 && c->up) {
+		Uploader *u = c->up;
+		std::lock_guard<std::mutex> g(u->mu);
+		for (size_t k = u->n_demand; k < u->q.size(); k++) if (u->q[k].busy == &s.busy) {
+			Uploader::Job j = std::move(u->q[k]); u->q.erase(u->q.begin() + (long)k); u->q.insert(u->q.begin() + (long)u->n_demand, std::move(j)); u->n_demand++;
+			break;
+		}
+	}
+	slot_wait(s);
+}
+
 // what every context owns, shared index or not: streams, events, counters, mailbox
-static int ctx_private_init(gsa_ctx *c)
+static int ctx_private_init(gsa_ctx *c, gsa_ctx *share = nullptr)
 {
 	GSA_CHECK(c, hipStreamCreate(&c->stream));
 	for (int i = 0; i < 3; i++) GSA_CHECK(c, hipStreamCreate(&c->stream_aux[i]));
+	if (share) { c->up = share->up; c->own_up = false; } else if (int rc = uploader_start(c)) return rc;      // (Uploader, gsa_ctx.h)
 	for (int i = 0; i < 28; i++) GSA_CHECK(c, hipEventCreate(&c->ev[i]));
 	GSA_CHECK(c, hipMalloc(&c->d_cnt.p, 32 * sizeof(u64))); c->d_cnt.cap = 32 * sizeof(u64); GSA_CHECK(c, hipMemset(c->d_cnt.p, 0, 32 * sizeof(u64)));      // (16 counters + the seed kernel's ticket counter)
 	GSA_CHECK(c, hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(u64)));
@@ -166,8 +221,10 @@ void gsa_destroy(gsa_ctx *c)
 	if (!c) return;
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
+	for (int i = 0; i < 2; i++) slot_wait(c->qs[i]);
+	uploader_stop(c);
 	if (c->lender) c->lender->n_borrowers.fetch_sub(1);      // (`parent` outlives its clones: gsa_hip.h)
-	DevBuf *bufs[] = { &c->d_bwt, &c->d_bwt_ref, &c->d_occ_base, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->d_query, &c->tmp, &c->d_cnt, &c->d_mail, &c->d_lb_status[0], &c->d_lb_status[1],
+	DevBuf *bufs[] = { &c->d_bwt, &c->d_bwt_ref, &c->d_occ_base, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->qs[0].d_query, &c->qs[1].d_query, &c->qs[0].d_bndtab, &c->qs[1].d_bndtab, &c->tmp, &c->d_cnt, &c->d_mail, &c->d_lb_status[0], &c->d_lb_status[1],
 		&c->d_sa_dense, &c->d_kmer, &c->d_kmer_lo, &c->d_pres, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_heavy, &c->dn_memo, &c->dn_lf, &c->dn_x0, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
 		&c->d_flag, &c->d_scan, &c->g_beg, &c->w_j0, &c->w_j1, &c->w_on, &c->d_pdbm, &c->d_gpre, &c->d_key_c, &c->d_val_c, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
 		&c->a_next, &c->a_brk, &c->a_aurank, &c->a_aulist, &c->a_runinfo, &c->w_best, &c->w_sum, &c->w_n, &c->d_btab, &c->d_flag2, &c->d_scan2, &c->d_i64a,
@@ -176,14 +233,14 @@ void gsa_destroy(gsa_ctx *c)
 		&c->fb_seedbase, &c->fb_sbeg, &c->fb_fragbase, &c->f_rec, &c->f_rec16, &c->f_type, &c->f_mism, &c->f_alnlen, &c->f_job, &c->f_score,
 		&c->d_dp_tiny, &c->d_dp_bnd, &c->d_dp_ctr, &c->d_dp_jobs, &c->d_dp_large, &c->d_tail,
 		&c->e_id, &c->e_rec, &c->e_list, &c->e_off1, &c->e_off2, &c->e_opsoff, &c->e_nops, &c->e_ops, &c->e_rev, &c->r_head, &c->f_early, &c->r_orig, &c->r_tmp_orig, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_alnoff, &c->bl_alnlen, &c->bl_score,
-		&c->d_bndtab, &c->d_bblk, &c->d_dp_arena,
+		&c->d_bblk, &c->d_dp_arena,
 		&c->leaf[0], &c->leaf[1], &c->leaf[2], &c->leaf[3], &c->leaf[4], &c->leaf[5], &c->leaf[6], &c->leaf[7], &c->leaf[8] };
 	// (a gsa_clone context borrows the index through `di` only: its index DevBufs are empty, a presence bitmap it built after
 	//  a parameter change is its own)
 	for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
 	if (c->h_cnt) hipHostFree(c->h_cnt);
 	if (c->h_mail) hipHostFree(c->h_mail);
-	for (DevBuf *b : { &c->p_frags, &c->p_tail, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_sj_early, &c->p_jpatch, &c->p_early, &c->p_bndtab, &c->p_bblk, &c->p_ba0 }) if (b->p) hipHostFree(b->p);
+	for (DevBuf *b : { &c->p_frags, &c->p_tail, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_sj_early, &c->p_jpatch, &c->p_early, &c->qs[0].p_bndtab, &c->qs[1].p_bndtab, &c->p_bblk, &c->p_ba0 }) if (b->p) hipHostFree(b->p);
 	for (int i = 0; i < 28; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	for (int i = 0; i < 3; i++) if (c->stream_aux[i]) hipStreamDestroy(c->stream_aux[i]);
 	if (c->stream_seed) hipStreamDestroy(c->stream_seed);
@@ -204,7 +261,7 @@ int gsa_clone(gsa_ctx *parent, gsa_ctx **out)
 	c->device = parent->device; c->force_wide = parent->force_wide;
 	c->index_owner = parent->index_owner ? parent->index_owner : parent; c->seed_budget = parent->seed_budget;
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
-	if (int rc = ctx_private_init(c)) { g_create_error = c->err; gsa_destroy(c); return rc; }
+	if (int rc = ctx_private_init(c, c->index_owner)) { g_create_error = c->err; gsa_destroy(c); return rc; }
 	c->di = parent->di; c->G = parent->G;
 	c->lender = parent; parent->n_borrowers.fetch_add(1);
 	c->h_chr_end = parent->h_chr_end; c->h_chr_fwd = parent->h_chr_fwd; c->h_chr_of_end = parent->h_chr_of_end; c->h_chr_len = parent->h_chr_len;
@@ -258,7 +315,15 @@ void *gsa_host_alloc(size_t bytes)
 }
 void gsa_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
-int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->acc_seed_ms = 0.0; c->profiling = (enable & 1) != 0; c->count_blocks = (enable & 2) != 0; c->prof_seed = (enable & 4) != 0; return GSA_OK; }
+int gsa_get_wall_sums(gsa_ctx *c, double ms[10], int64_t *n)
+{
+	if (!c || !ms || !n) return GSA_ERR_ARG;
+	memcpy(ms, c->wall_ms, sizeof(c->wall_ms)); *n = c->wall_n;
+	if (c->up && c->own_up) { std::lock_guard<std::mutex> g(c->up->mu); ms[9] = c->up->jobs ? c->up->copy_ms / (double)c->up->jobs * (double)c->wall_n : 0.0; }      // (x n: the caller divides by n)
+	return GSA_OK;
+}
+
+int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->acc_seed_ms = 0.0; memset(c->wall_ms, 0, sizeof(c->wall_ms)); c->wall_n = 0; if (c->up && c->own_up) { std::lock_guard<std::mutex> g(c->up->mu); c->up->copy_ms = c->up->wait_ms = c->up->bytes = 0; c->up->jobs = 0; } c->profiling = (enable & 1) != 0; c->count_blocks = (enable & 2) != 0; c->prof_seed = (enable & 4) != 0; return GSA_OK; }
 
 static int query_geometry(gsa_ctx *c, int32_t qlen)
 {
@@ -271,16 +336,154 @@ static int query_geometry(gsa_ctx *c, int32_t qlen)
 	return GSA_OK;
 }
 
+#define GSA_BUNDLE_MAX_CONTIGS 4096
+// ---- query slots (QuerySlot, gsa_ctx.h) ----
+// a slot's buffer grows: nothing may still read or write it (the stages of the contig it held are over -- the API is synchronous --
+// but an upload may be on its way)
+static void *slot_ensure_bytes(gsa_ctx *c, DevBuf &b, size_t bytes, bool pinned)
+{
+	if (bytes && bytes <= b.cap) return b.p;
+	return pinned ? (void *)pin_ensure<uint8_t>(c, b, bytes) : (void *)dev_ensure<uint8_t>(c, b, bytes);
+}
+
+// The concatenation of a bundle: every contig starts on a chunk edge, as it does alone.
+static int slot_layout(gsa_ctx *c, QuerySlot &s, const char *const *query, const int32_t *qlen, int32_t n)
+{
+	s.b_off.assign((size_t)n + 1, 0); s.b_qlen.assign(qlen, qlen + n); s.src.assign(query, query + n);
+	i64 tot = 0; i32 lmax = 0;
+	for (int k = 0; k < n; k++) {
+		if (qlen[k] < 0 || (qlen[k] > 0 && !query[k])) return GSA_ERR_ARG;
+		s.b_off[(size_t)k] = (i32)tot;
+		tot += ((i64)qlen[k] + GSA_CHUNK - 1) / GSA_CHUNK * GSA_CHUNK;
+		if (tot >= (1ll << 31) - 2 * GSA_CHUNK) return gsa_fail(c, GSA_ERR_LIMIT, "bundle longer than 2^31 bases");
+		if (qlen[k] > lmax) lmax = qlen[k];
+	}
+	s.b_off[(size_t)n] = (i32)tot; s.tot = tot; s.lmax = lmax; s.n = n;
+	return GSA_OK;
+}
+
+// the tail of every contig of a bundle up to its chunk edge reads 'N' (a match stops there exactly as it stops at the end of a sequence)
+__global__ void __launch_bounds__(256) k_bundle_pad(const i32 *__restrict__ off, const i32 *__restrict__ len, uint8_t *dst)
+{
+	const i32 k = blockIdx.x; const i64 b = (i64)off[k] + len[k], e = off[k + 1];
+	for (i64 t = b + threadIdx.x; t < e; t += 256) dst[t] = (uint8_t)'N';
+}
+
+// Hands the Uploader the copies that fill slot `s` from host memory: one contig (n = 0, query[0] / qlen[0]) or the concatenation of a
+// bundle + its tables (the 'N' tails are written by slot_finish on the main stream: nothing but copies on the upload stream).
+static int slot_upload(gsa_ctx *c, QuerySlot &s, const char *const *query, const int32_t *qlen, int32_t n)
+{
+	slot_wait(s);      // (a cancelled upload into this slot may still be on its way)
+	Uploader::Job job; job.busy = &s.busy;
+	if (n == 0) {
+		s.n = 0; s.tot = qlen[0]; s.lmax = qlen[0]; s.src.assign(1, query[0]); s.b_qlen.assign(1, qlen[0]); s.b_off.clear();
+		if (!slot_ensure_bytes(c, s.d_query, (size_t)qlen[0] + 64, false)) return GSA_ERR_NOMEM;
+		size_t nb = (size_t)qlen[0];
+#ifdef GSA_EXPERIMENTS
+		{ static const long long cap = [] { const char *e = getenv("GSA_X_UPBYTES"); return e ? atoll(e) : -1ll; }(); if (cap >= 0 && (size_t)cap < nb) nb = (size_t)cap; }      // (timing experiment: the API pattern without the bytes)
+#endif
+		// (a buffer from gsa_host_alloc is pinned: one DMA transfer; pageable memory is staged by the runtime)
+		if (nb > 0) { job.pieces.push_back({ s.d_query.p, query[0], nb }); c->up->push(std::move(job)); }
+		return GSA_OK;
+	}
+	if (int rc = slot_layout(c, s, query, qlen, n)) return rc;
+	const i64 n_chunks = s.tot / GSA_CHUNK;
+	// tables: off[n + 1] (i32) | chunk_contig[n_chunks] (u16) | len[n] (i32)
+	s.o_cc = ((size_t)n + 1) * 4; s.o_src = (s.o_cc + (size_t)n_chunks * 2 + 15) & ~(size_t)15;
+	const size_t t_bytes = s.o_src + (size_t)n * 4;
+	if (!slot_ensure_bytes(c, s.p_bndtab, t_bytes + 16, true) || !slot_ensure_bytes(c, s.d_bndtab, t_bytes + 16, false) || !slot_ensure_bytes(c, s.d_query, (size_t)s.tot + 64, false)) return GSA_ERR_NOMEM;
+	uint8_t *ht = s.p_bndtab.as<uint8_t>();
+	memcpy(ht, s.b_off.data(), s.o_cc);
+	{ uint16_t *cc = (uint16_t *)(ht + s.o_cc); for (int k = 0; k < n; k++) for (i64 ch = s.b_off[(size_t)k] / GSA_CHUNK; ch < s.b_off[(size_t)k + 1] / GSA_CHUNK; ch++) cc[ch] = (uint16_t)k; }
+	memcpy(ht + s.o_src, qlen, (size_t)n * 4);
+	job.pieces.push_back({ s.d_bndtab.p, ht, t_bytes });
+	for (int k = 0; k < n; k++) if (qlen[k] > 0) job.pieces.push_back({ s.d_query.as<uint8_t>() + s.b_off[(size_t)k], query[k], (size_t)qlen[k] });
+	c->up->push(std::move(job));
+	return GSA_OK;
+}
+
+// The host waits for the slot's upload (long over when the contig was prefetched a contig ago), then the main stream pads a bundle's contigs.
+static int slot_finish(gsa_ctx *c, QuerySlot &s)
+{
+	slot_demand(c, s);
+	if (s.n > 0 && s.tot > 0) {
+		const uint8_t *dt = s.d_bndtab.as<uint8_t>();
+		hipLaunchKernelGGL(k_bundle_pad, dim3((unsigned)s.n), dim3(256), 0, c->stream, (const i32 *)dt, (const i32 *)(dt + s.o_src), s.d_query.as<uint8_t>());
+		GSA_CHECK(c, hipGetLastError());
+	}
+	return GSA_OK;
+}
+
+static bool slot_holds(const QuerySlot &s, const char *const *query, const int32_t *qlen, int32_t n)
+{
+	if (!s.pending || s.n != n) return false;
+	const int32_t m = n ? n : 1;
+	if ((int32_t)s.src.size() != m || (int32_t)s.b_qlen.size() != m) return false;
+	for (int32_t k = 0; k < m; k++) if (s.src[(size_t)k] != query[k] || s.b_qlen[(size_t)k] != qlen[k]) return false;
+	return true;
+}
+
+// The slot the stages will read: the one a prefetch filled with exactly these buffers (the main stream waits for its upload), else a
+// free one, filled on the main stream.
+static int slot_acquire(gsa_ctx *c, const char *const *query, const int32_t *qlen, int32_t n, int *which)
+{
+	for (int i = 0; i < 2; i++) if (slot_holds(c->qs[i], query, qlen, n)) {
+		c->qs[i].pending = false; *which = i;
+		return slot_finish(c, c->qs[i]);
+	}
+	int i = (c->q_cur == 1 && !c->qs[1].pending) ? 1 : 0;
+	if (c->qs[i].pending) i ^= 1;
+	if (c->qs[i].pending) return gsa_fail(c, GSA_ERR_STATE, "both query slots hold prefetched contigs: align them (or gsa_cancel_prefetch) first");
+	*which = i;
+	if (int rc = slot_upload(c, c->qs[i], query, qlen, n)) return rc;
+	return slot_finish(c, c->qs[i]);
+}
+
+static int prefetch(gsa_ctx *c, const char *const *query, const int32_t *qlen, int32_t n)
+{
+	GSA_CHECK(c, hipSetDevice(c->device));
+	// (the same buffer may wait twice -- a caller that aligns one buffer again and again -- so a waiting copy of it is no reason to skip this one)
+	// not the slot of the contig that was aligned last while the other one is free (gsa_rewind stays possible); a pending slot never
+	int i = c->q_cur == 0 ? 1 : 0;
+	if (c->qs[i].pending) i ^= 1;
+	if (c->qs[i].pending) return gsa_fail(c, GSA_ERR_STATE, "gsa_prefetch: two contigs are waiting already");
+	if (i == c->q_cur) c->q_cur = -2;
+	int rc = slot_upload(c, c->qs[i], query, qlen, n);
+	if (rc == GSA_OK) c->qs[i].pending = true;
+	return rc;
+}
+
+int gsa_prefetch_contig(gsa_ctx *c, const char *query, int32_t qlen)
+{
+	if (!c || !query || qlen < 0) return GSA_ERR_ARG;
+	return prefetch(c, &query, &qlen, 0);
+}
+
+int gsa_prefetch_bundle(gsa_ctx *c, const char *const *query, const int32_t *qlen, int32_t n)
+{
+	if (!c || !query || !qlen) return GSA_ERR_ARG;
+	if (n < 1 || n > GSA_BUNDLE_MAX_CONTIGS) return gsa_fail(c, GSA_ERR_ARG, "gsa_prefetch_bundle: 1 .. 4096 contigs");
+	return prefetch(c, query, qlen, n);
+}
+
+int gsa_cancel_prefetch(gsa_ctx *c)
+{
+	if (!c) return GSA_ERR_ARG;
+	if (!c->qs[0].pending && !c->qs[1].pending) return GSA_OK;
+	c->qs[0].pending = c->qs[1].pending = false;      // (the copies run to their end; slot_upload waits for them before it reuses the slot)
+	return GSA_OK;
+}
+
 int gsa_set_query(gsa_ctx *c, const char *query, int32_t qlen)
 {
 	if (!c || !query || qlen < 0) return GSA_ERR_ARG;
 	GSA_CHECK(c, hipSetDevice(c->device));
 	if (int rc = reset_run_state(c)) return rc;
-	if (!dev_ensure<uint8_t>(c, c->d_query, (size_t)qlen + 64)) return GSA_ERR_NOMEM;
-	// (a buffer from gsa_host_alloc is pinned: the copy is one DMA transfer the seed kernel queues behind; pageable memory is
-	// staged by the runtime)
-	GSA_CHECK(c, hipMemcpyAsync(c->d_query.p, query, (size_t)qlen, hipMemcpyHostToDevice, c->stream));
-	c->q_dev = c->d_query.as<uint8_t>();
+	int w = 0;
+	const auto t0 = std::chrono::steady_clock::now();
+	if (int rc = slot_acquire(c, &query, &qlen, 0, &w)) return rc;
+	c->wall_ms[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	c->q_cur = w; c->q_dev = c->qs[w].d_query.as<uint8_t>();
 	return query_geometry(c, qlen);
 }
 
@@ -294,7 +497,7 @@ int gsa_set_query_device(gsa_ctx *c, const char *d_query, int32_t qlen)
 	hipPointerAttribute_t at;
 	if (hipPointerGetAttributes(&at, d_query) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != c->device) { (void)hipGetLastError(); return gsa_fail(c, GSA_ERR_ARG, "gsa_set_query_device: not a device buffer of this context's GPU"); }
 	if (int rc = reset_run_state(c)) return rc;
-	c->q_dev = (const uint8_t *)d_query;
+	c->q_dev = (const uint8_t *)d_query; c->q_cur = -1;
 	return query_geometry(c, qlen);
 }
 
@@ -328,6 +531,7 @@ int gsa_rewind(gsa_ctx *c)
 {
 	if (!c) return GSA_ERR_ARG;
 	if (c->qlen <= 0) return gsa_fail(c, GSA_ERR_STATE, "gsa_set_query first");
+	if (c->q_cur == -2) return gsa_fail(c, GSA_ERR_STATE, "gsa_rewind: the contig's device copy was overwritten by a prefetch");
 	GSA_CHECK(c, hipSetDevice(c->device));
 	return reset_run_state(c);
 }
@@ -340,6 +544,7 @@ int gsa_run_to(gsa_ctx *c, int stage)
 	if (c->split) return gsa_fail(c, GSA_ERR_STATE, "gsa_run_to: a split contig is finished with gsa_finish_contig");
 	GSA_CHECK(c, hipSetDevice(c->device));
 	int rc = GSA_OK;
+	auto t_prev = std::chrono::steady_clock::now();
 	while (c->stage < stage && rc == GSA_OK) {
 		const int next = c->stage + 1;
 		switch (next) {
@@ -351,7 +556,9 @@ int gsa_run_to(gsa_ctx *c, int stage)
 		case 8: rc = stage78_extend(c); if (rc == GSA_OK) rc = host_stage8_finish(c); break;
 		}
 		if (rc == GSA_OK) { c->stage = next; c->frags_stage = (next == 8) ? 8 : 0; }
+		{ const auto t_now = std::chrono::steady_clock::now(); c->wall_ms[next] += std::chrono::duration<double, std::milli>(t_now - t_prev).count(); t_prev = t_now; }
 	}
+	if (stage == 8) c->wall_n++;
 	// stages 1-2 leave work in flight (no count read-backs); the call returns with the stream idle
 	if (rc == GSA_OK) { GSA_CHECK(c, hipStreamSynchronize(c->stream)); collect_events(c); }
 	if (c->early_in_flight && (rc != GSA_OK || !c->early_consumed)) GSA_CHECK(c, hipStreamSynchronize(c->stream_aux[0]));      // a stage view (or an error) must not leave the early DP launch running
@@ -400,46 +607,48 @@ __global__ void __launch_bounds__(256) k_bundle_gather(const i32 *__restrict__ o
 	for (i32 t = threadIdx.x; t < GSA_CHUNK; t += 256) dst[g0 + t] = t < have ? sc.p[l0 + t] : (uint8_t)'N';
 }
 
-#define GSA_BUNDLE_MAX_CONTIGS 4096
 static int set_query_bundle(gsa_ctx *c, const char *const *query, const int32_t *qlen, int32_t n, bool dev_q)
 {
 	if (n < 1 || n > GSA_BUNDLE_MAX_CONTIGS) return gsa_fail(c, GSA_ERR_ARG, "gsa_align_bundle: 1 .. 4096 contigs");
 	GSA_CHECK(c, hipSetDevice(c->device));
 	if (int rc = reset_run_state(c)) return rc;
-	c->b_off.assign((size_t)n + 1, 0); c->b_qlen.assign(qlen, qlen + n);
-	i64 tot = 0; i32 lmax = 0;
-	for (int k = 0; k < n; k++) {
-		if (qlen[k] < 0 || (qlen[k] > 0 && !query[k])) return GSA_ERR_ARG;
-		c->b_off[(size_t)k] = (i32)tot;
-		tot += ((i64)qlen[k] + GSA_CHUNK - 1) / GSA_CHUNK * GSA_CHUNK;       // every contig starts on a chunk edge, as it does alone
-		if (tot >= (1ll << 31) - 2 * GSA_CHUNK) return gsa_fail(c, GSA_ERR_LIMIT, "bundle longer than 2^31 bases");
-		if (qlen[k] > lmax) lmax = qlen[k];
-	}
-	c->b_off[(size_t)n] = (i32)tot;
-	const i64 n_chunks = tot / GSA_CHUNK;
-	// tables: off[n + 1] (i32) | chunk_contig[n_chunks] (u16) | sources (device-resident contigs)
-	const size_t o_cc = ((size_t)n + 1) * 4, o_src = (o_cc + (size_t)n_chunks * 2 + 15) & ~(size_t)15, t_bytes = o_src + (dev_q ? (size_t)n * sizeof(BundleSrc) : 0);
-	if (!pin_ensure<uint8_t>(c, c->p_bndtab, t_bytes + 16) || !dev_ensure<uint8_t>(c, c->d_bndtab, t_bytes + 16)) return GSA_ERR_NOMEM;
-	uint8_t *ht = c->p_bndtab.as<uint8_t>();
-	memcpy(ht, c->b_off.data(), o_cc);
-	{ uint16_t *cc = (uint16_t *)(ht + o_cc); for (int k = 0; k < n; k++) for (i64 ch = c->b_off[(size_t)k] / GSA_CHUNK; ch < c->b_off[(size_t)k + 1] / GSA_CHUNK; ch++) cc[ch] = (uint16_t)k; }
-	if (dev_q) { BundleSrc *bs = (BundleSrc *)(ht + o_src); for (int k = 0; k < n; k++) { bs[k].p = (const uint8_t *)query[k]; bs[k].len = qlen[k]; bs[k]._pad = 0; } }
-	if (!dev_ensure<uint8_t>(c, c->d_query, (size_t)tot + 64)) return GSA_ERR_NOMEM;
-	GSA_CHECK(c, hipMemcpyAsync(c->d_bndtab.p, ht, t_bytes, hipMemcpyHostToDevice, c->stream));
-	const uint8_t *dt = c->d_bndtab.as<uint8_t>();
-	if (tot > 0) {
-		if (dev_q) hipLaunchKernelGGL(k_bundle_gather, dim3((unsigned)n_chunks), dim3(256), 0, c->stream, (const i32 *)dt, (const uint16_t *)(dt + o_cc), (const BundleSrc *)(dt + o_src), c->d_query.as<uint8_t>());
-		else {
-			GSA_CHECK(c, hipMemsetAsync(c->d_query.p, 'N', (size_t)tot, c->stream));
-			for (int k = 0; k < n; k++) if (qlen[k] > 0) GSA_CHECK(c, hipMemcpyAsync(c->d_query.as<uint8_t>() + c->b_off[(size_t)k], query[k], (size_t)qlen[k], hipMemcpyHostToDevice, c->stream));
+	int w = 0;
+	if (!dev_q) { if (int rc = slot_acquire(c, query, qlen, n, &w)) return rc; }
+	else {
+		// device-resident contigs: gathered into a free slot by one kernel (a workgroup per chunk), sources in the slot's table
+		w = (c->q_cur == 1 && !c->qs[1].pending) ? 1 : 0;
+		if (c->qs[w].pending) w ^= 1;
+		if (c->qs[w].pending) return gsa_fail(c, GSA_ERR_STATE, "both query slots hold prefetched contigs");
+		QuerySlot &s = c->qs[w];
+		slot_wait(s);
+		for (int k = 0; k < n; k++) if (qlen[k] > 0) {      // (what gsa_set_query_device checks: a host pointer here would be a GPU fault, not an error code)
+			hipPointerAttribute_t at;
+			if (!query[k] || hipPointerGetAttributes(&at, query[k]) != hipSuccess || at.type != hipMemoryTypeDevice || at.device != c->device) { (void)hipGetLastError(); return gsa_fail(c, GSA_ERR_ARG, "gsa_align_bundle (GSA_MANY_DEVICE): not a device buffer of this context's GPU"); }
 		}
-		GSA_CHECK(c, hipGetLastError());
+		if (int rc = slot_layout(c, s, query, qlen, n)) return rc;
+		const i64 n_chunks = s.tot / GSA_CHUNK;
+		s.o_cc = ((size_t)n + 1) * 4; s.o_src = (s.o_cc + (size_t)n_chunks * 2 + 15) & ~(size_t)15;
+		const size_t t_bytes = s.o_src + (size_t)n * sizeof(BundleSrc);
+		if (!slot_ensure_bytes(c, s.p_bndtab, t_bytes + 16, true) || !slot_ensure_bytes(c, s.d_bndtab, t_bytes + 16, false) || !slot_ensure_bytes(c, s.d_query, (size_t)s.tot + 64, false)) return GSA_ERR_NOMEM;
+		uint8_t *ht = s.p_bndtab.as<uint8_t>();
+		memcpy(ht, s.b_off.data(), s.o_cc);
+		{ uint16_t *cc = (uint16_t *)(ht + s.o_cc); for (int k = 0; k < n; k++) for (i64 ch = s.b_off[(size_t)k] / GSA_CHUNK; ch < s.b_off[(size_t)k + 1] / GSA_CHUNK; ch++) cc[ch] = (uint16_t)k; }
+		{ BundleSrc *bs = (BundleSrc *)(ht + s.o_src); for (int k = 0; k < n; k++) { bs[k].p = (const uint8_t *)query[k]; bs[k].len = qlen[k]; bs[k]._pad = 0; } }
+		GSA_CHECK(c, hipMemcpyAsync(s.d_bndtab.p, ht, t_bytes, hipMemcpyHostToDevice, c->stream));
+		const uint8_t *dt = s.d_bndtab.as<uint8_t>();
+		if (s.tot > 0) {
+			hipLaunchKernelGGL(k_bundle_gather, dim3((unsigned)n_chunks), dim3(256), 0, c->stream, (const i32 *)dt, (const uint16_t *)(dt + s.o_cc), (const BundleSrc *)(dt + s.o_src), s.d_query.as<uint8_t>());
+			GSA_CHECK(c, hipGetLastError());
+		}
 	}
-	c->q_dev = c->d_query.as<uint8_t>();
-	c->qlen = (i32)tot;
-	c->bnd.n = n; c->bnd.lmax = lmax; c->bnd.off = (const i32 *)dt; c->bnd.chunk_contig = (const uint16_t *)(dt + o_cc);
-	c->bnd.pds = (2 * c->G + (i64)lmax + (i64)c->prm.MaxIndelSize + 64 + 31) & ~31ll;      // (a PosDiff of contig k: rPos - qLocal + lmax in (0, 2G + lmax])
-	c->qbits = ceil_log2_u64((u64)tot + 1); if (c->qbits < 1) c->qbits = 1;
+	const QuerySlot &s = c->qs[w];
+	c->q_cur = w; c->b_off = s.b_off; c->b_qlen = s.b_qlen;
+	const uint8_t *dt = s.d_bndtab.as<uint8_t>();
+	c->q_dev = s.d_query.as<uint8_t>();
+	c->qlen = (i32)s.tot;
+	c->bnd.n = n; c->bnd.lmax = s.lmax; c->bnd.off = (const i32 *)dt; c->bnd.chunk_contig = (const uint16_t *)(dt + s.o_cc);
+	c->bnd.pds = (2 * c->G + (i64)s.lmax + (i64)c->prm.MaxIndelSize + 64 + 31) & ~31ll;      // (a PosDiff of contig k: rPos - qLocal + lmax in (0, 2G + lmax])
+	c->qbits = ceil_log2_u64((u64)s.tot + 1); if (c->qbits < 1) c->qbits = 1;
 	c->pd_span = (i64)n * c->bnd.pds + 2;
 	c->pdbits = ceil_log2_u64((u64)c->pd_span);
 	if (c->qbits + c->pdbits > 64) return gsa_fail(c, GSA_ERR_LIMIT, "bundle too long for the 64-bit seed key");
@@ -570,7 +779,7 @@ static int align_split(gsa_ctx *const *grp, int n_grp, const char *query, int32_
 
 int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n, uint32_t flags, gsa_result_fn on_result, void *user)
 {
-	if (flags & ~(uint32_t)(GSA_MANY_IN_ORDER | GSA_MANY_DEVICE | GSA_MANY_NO_SPLIT | GSA_MANY_NO_BUNDLE)) return GSA_ERR_ARG;
+	if (flags & ~(uint32_t)(GSA_MANY_IN_ORDER | GSA_MANY_DEVICE | GSA_MANY_NO_SPLIT | GSA_MANY_NO_BUNDLE | GSA_MANY_NO_PREFETCH)) return GSA_ERR_ARG;
 	if (!ctx || n_ctx <= 0 || n < 0 || (n > 0 && (!query || !qlen))) return GSA_ERR_ARG;
 	for (int k = 0; k < n_ctx; k++) if (!ctx[k]) return GSA_ERR_ARG;
 	const bool dev_q = (flags & GSA_MANY_DEVICE) != 0;
@@ -658,11 +867,26 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 		if (rc == GSA_OK && on_result) rc = on_result(user, ci, &res);
 		return rc;
 	};
+	// A context works on unit u while unit u + 1 -- claimed one ahead -- is uploaded into its other query slot (gsa_prefetch_contig /
+	// gsa_prefetch_bundle): the reference reads a sequence from host memory when its turn comes (GSAlign.cpp:483-490); here the H2D
+	// copy of a chromosome (4.8 ms per 250 Mb) would otherwise sit in front of every contig's seed search.
+	const bool pre = !dev_q && !(flags & GSA_MANY_NO_PREFETCH);
 	auto loop = [&](gsa_ctx *c) {
-		std::vector<const char *> bq; std::vector<int32_t> bl; std::vector<gsa_result> br;
+		std::vector<const char *> bq, pq; std::vector<int32_t> bl, pl; std::vector<gsa_result> br;
+		auto fetch = [&](int32_t u) {
+			if (!pre || u >= n_units) return;
+			const std::vector<int32_t> &un = units[(size_t)u];
+			if (un.size() == 1) (void)gsa_prefetch_contig(c, query[un[0]], qlen[un[0]]);
+			else { pq.clear(); pl.clear(); for (int32_t ci : un) { pq.push_back(query[ci]); pl.push_back(qlen[ci]); } (void)gsa_prefetch_bundle(c, pq.data(), pl.data(), (int32_t)un.size()); }
+			// (a prefetch that fails -- memory -- leaves nothing pending: the contig is uploaded when its turn comes)
+		};
+		(void)gsa_cancel_prefetch(c);
+		int32_t u = next.fetch_add(1);
+		fetch(u);
 		for (;;) {
-			const int32_t u = next.fetch_add(1);
-			if (u >= n_units || err.load() != GSA_OK) return;
+			if (u >= n_units || err.load() != GSA_OK) { (void)gsa_cancel_prefetch(c); return; }
+			const int32_t u_next = next.fetch_add(1);
+			fetch(u_next);
 			const std::vector<int32_t> &un = units[(size_t)u];
 			int rc = GSA_OK;
 			if (un.size() == 1) rc = one(c, un[0]);
@@ -673,7 +897,8 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 				if (rc == GSA_OK) { for (size_t k = 0; k < un.size() && rc == GSA_OK && on_result; k++) rc = on_result(user, un[k], &br[k]); }
 				else if (rc == GSA_ERR_LIMIT) { rc = GSA_OK; for (size_t k = 0; k < un.size() && rc == GSA_OK; k++) rc = one(c, un[k]); }      // (a capacity of the joint pass: one by one)
 			}
-			if (rc != GSA_OK) { int ok = GSA_OK; err.compare_exchange_strong(ok, rc); return; }
+			if (rc != GSA_OK) { int ok = GSA_OK; err.compare_exchange_strong(ok, rc); (void)gsa_cancel_prefetch(c); return; }
+			u = u_next;
 		}
 	};
 	std::vector<std::thread> th;

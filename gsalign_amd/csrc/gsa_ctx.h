@@ -2,6 +2,11 @@
 #ifndef GSA_CTX_H
 #define GSA_CTX_H
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include "gsa_internal.h"
 
 // A leaf = a maximal run of seeds of one S2 block that neither S4 (large gaps)
@@ -30,8 +35,42 @@ struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf ra
 	i32 aln_len, bdir, gpos, chr;
 };
 
+// A query slot: the device copy of a contig, or of a bundle's concatenation with its tables.  A context has two: while the contig
+// of one slot goes through the stages, the next one is uploaded into the other on `stream_up` (gsa_prefetch_contig /
+// gsa_prefetch_bundle; gsa_align_many does it by itself), so the H2D copy of a contig -- 4.8 ms for 250 Mb at 52 GB/s, the reference
+// reads QueryChrVec[i].seq from host memory every iteration (GSAlign.cpp:483-490) -- hides behind its predecessor's stages.
+struct QuerySlot {
+	DevBuf d_query;                                // contig / concatenation
+	DevBuf d_bndtab, p_bndtab;                     // bundle tables: off[n + 1] | chunk_contig[chunks] | (device-resident contigs: source pointers) -- device / pinned staging
+	std::vector<i32> b_off, b_qlen;                // start of contig k in the concatenation [n + 1], its length
+	std::vector<const char *> src;                 // the host buffers this slot was filled from (the identity of a prefetch)
+	i32 n = 0;                                     // 0: one contig, > 0: a bundle of n
+	i32 lmax = 0; i64 tot = 0; size_t o_cc = 0, o_src = 0;
+	bool pending = false;                          // uploaded (or on its way) and not yet adopted by gsa_set_query / set_query_bundle
+	std::atomic<int> busy{0};                      // uploads of this slot the Uploader has not finished yet
+};
+
+// Uploads of query sequences, ONE AT A TIME per device index, in the order they were asked for (a thread + a copy stream; the contexts
+// that share an index -- gsa_clone -- share it).  Why not a copy stream per context: copies that run side by side share the link, so
+// every one of them takes as long as all of them together; four contexts that each prefetch their next contig then all get it late, at
+// the same moment, and stay in lockstep (measured: the host waited 5 ms per contig for an upload issued a whole contig earlier, and the
+// upload-inclusive rate was 27.5 Gbp/s against 31.5 with resident contigs).  First come first served, a 250 MB contig lands 4.4 ms after
+// its turn and the contexts stagger.  Nothing but DMA copies runs on the stream and only host threads wait for them: a GPU-side wait
+// (an event behind the copy, a kernel queued behind it) is a barrier packet that blocks a shared hardware queue for milliseconds.
+struct Uploader {
+	struct Piece { void *dst; const void *src; size_t n; };
+	struct Job { std::vector<Piece> pieces; std::atomic<int> *busy; std::chrono::steady_clock::time_point t_push; };
+	double copy_ms = 0, wait_ms = 0, bytes = 0; long long jobs = 0;      // (statistics, uploader thread only)
+	int device = 0; hipStream_t st = nullptr;
+	std::thread th; std::mutex mu; std::condition_variable cv; std::deque<Job> q; bool stop = false;
+	size_t n_demand = 0;                           // the first n_demand jobs of q are uploads a context is waiting for (slot_demand), in the order they asked
+	void run();
+	void push(Job &&j) { j.busy->fetch_add(1); j.t_push = std::chrono::steady_clock::now(); { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(j)); } cv.notify_one(); }
+};
+
 struct gsa_ctx {
 	int device = 0;
+	Uploader *up = nullptr; bool own_up = false;
 	hipStream_t stream = nullptr;
 	hipStream_t stream_seed = nullptr;      // (experiment, GSA_SEED_CUS: the seed-search kernels on a stream restricted to part of the CUs)
 	hipEvent_t ev_seed_fork = nullptr;
@@ -51,6 +90,7 @@ struct gsa_ctx {
 	u64 dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	hipEvent_t ev[28];
 	float kernel_ms[8];
+	double wall_ms[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; int64_t wall_n = 0;      // host wall clock spent in [0] the query set-up (upload / wait for the prefetch) and [s] stage s of gsa_run_to, summed over contigs since gsa_set_profiling (gsa_get_wall_sums)
 	double acc_seed_ms = 0.0;                      // seed-search kernel time summed over the contigs since gsa_set_profiling (flag bit 2), see gsa_get_timings
 	u64 counters[8];
 
@@ -60,7 +100,8 @@ struct gsa_ctx {
 	i64 G = 0;
 
 	// query
-	DevBuf d_query; i32 qlen = 0; int stage = 0;
+	QuerySlot qs[2]; int q_cur = -1;               // q_cur: slot of the current contig; -1: the caller's device buffer / none; -2: overwritten by a prefetch (no gsa_rewind)
+	i32 qlen = 0; int stage = 0;
 	const uint8_t *q_dev = nullptr;                // the contig on the device: d_query (uploaded by gsa_set_query) or the caller's buffer (gsa_set_query_device)
 	bool split = false; i64 rng_beg = 0, rng_end = 0;     // gsa_seed_chunks: stage 1 on a chunk range only, the hits of other ranges are imported
 	int qbits = 1, pdbits = 1;
@@ -68,8 +109,7 @@ struct gsa_ctx {
 
 	// ---- a bundle of contigs in one pass (Bundle, gsa_internal.h; gsa_align_bundle in gsa_api.hip) ----
 	Bundle bnd = { 0, 0, 0, nullptr, nullptr };
-	std::vector<i32> b_off, b_qlen;               // start of contig k in the concatenation [n + 1], its length
-	DevBuf d_bndtab, p_bndtab;                     // off[n + 1] | chunk_contig[chunks] | (device-resident contigs: source pointers) -- device / pinned staging
+	std::vector<i32> b_off, b_qlen;               // start of contig k in the concatenation [n + 1], its length (copied from the slot that holds the bundle)
 	std::vector<std::vector<HostBlock> > b_lists;  // the AlnBlockVec of every contig while the list logic runs (stages 3-6)
 	std::vector<i32> b_blk0;                       // first block of contig k in the joined final list [n + 1]
 	DevBuf d_bblk, p_bblk, p_ba0;                          // contig of every final block | first block per contig (device); string-pool offset of every contig (pinned, written by k_bundle_rebase)
@@ -166,11 +206,21 @@ struct gsa_ctx {
 	DevBuf p_frags, p_blk; bool result_pinned = false;
 };
 
+// A buffer is about to be freed: nothing of this context may still use it -- not only the main stream: the early striped DP launch runs on
+// stream_aux[0] beside stages 3-7 and shares direction / boundary / ticket buffers with the late launch, strings and record copies run on
+// stream_aux[1] / [2].  (Until round 4 only the main stream was waited for: a late launch that outgrew a shared buffer while the early one
+// was still running freed it under the kernel -- a rare "memory access fault", seen once in a four-context run.)
+static inline void ctx_quiesce(gsa_ctx *c)
+{
+	hipStreamSynchronize(c->stream);
+	for (int i = 0; i < 3; i++) if (c->stream_aux[i]) hipStreamSynchronize(c->stream_aux[i]);
+}
+
 template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 {
 	size_t bytes = (n ? n : 1) * sizeof(T);
 	if (bytes <= b.cap) return (T *)b.p;
-	if (b.p) { hipStreamSynchronize(c->stream); hipFree(b.p); b.p = nullptr; b.cap = 0; }
+	if (b.p) { ctx_quiesce(c); hipFree(b.p); b.p = nullptr; b.cap = 0; }
 	size_t want = bytes + bytes / 2 + 256;      // (half again: a context that meets a somewhat larger contig or bundle than it has seen does not stop to reallocate)
 	if (hipMalloc(&b.p, want) != hipSuccess) { gsa_fail(c, GSA_ERR_NOMEM, "hipMalloc"); return nullptr; }
 	b.cap = want;
@@ -181,7 +231,7 @@ template <class T> static inline T *pin_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 {
 	size_t bytes = (n ? n : 1) * sizeof(T);
 	if (bytes <= b.cap) return (T *)b.p;
-	if (b.p) { hipStreamSynchronize(c->stream); hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+	if (b.p) { ctx_quiesce(c); hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
 	size_t want = bytes + bytes / 4 + 4096;
 	if (hipHostMalloc(&b.p, want) != hipSuccess) { gsa_fail(c, GSA_ERR_NOMEM, "hipHostMalloc"); return nullptr; }
 	b.cap = want;

@@ -9,7 +9,7 @@
 static int ensure_tmp(gsa_ctx *c, size_t bytes)
 {
 	if (bytes <= c->tmp.cap) return GSA_OK;
-	if (c->tmp.p) { hipStreamSynchronize(c->stream); hipFree(c->tmp.p); c->tmp.p = nullptr; c->tmp.cap = 0; }
+	if (c->tmp.p) { ctx_quiesce(c); hipFree(c->tmp.p); c->tmp.p = nullptr; c->tmp.cap = 0; }
 	size_t want = bytes + bytes / 4 + 4096;
 	if (hipMalloc(&c->tmp.p, want) != hipSuccess) return gsa_fail(c, GSA_ERR_NOMEM, "hipMalloc(prim temp)");
 	c->tmp.cap = want;

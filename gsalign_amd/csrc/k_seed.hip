@@ -1295,7 +1295,7 @@ template <class T> static T *dev_grow_keep(gsa_ctx *c, DevBuf &b, size_t n, size
 	DevBuf nb;
 	if (!dev_ensure<T>(c, nb, n + n / 2)) return nullptr;
 	if (keep && b.p) { if (hipMemcpyAsync(nb.p, b.p, keep * sizeof(T), hipMemcpyDeviceToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { hipFree(nb.p); gsa_fail(c, GSA_ERR_HIP, "hipMemcpyAsync"); return nullptr; } }
-	if (b.p) { hipStreamSynchronize(c->stream); hipFree(b.p); }
+	if (b.p) { ctx_quiesce(c); hipFree(b.p); }
 	b = nb;
 	return (T *)b.p;
 }

@@ -136,6 +136,105 @@ def gather_results(mine: dict, block_dt, frag_dt, device=None, dst: int = 0) -> 
     return out
 
 
+class ResultStage:
+    """Finished contigs of this rank, staged for the gather to rank 0 ("grouped send/recv of block records + op
+    bytes to rank 0, which writes MAF/VCF in contig order").  A worker thread hands over a finished contig as host-memory pieces
+    (block records, 16-byte gap/seed records, the two gapped-string pools -- library-owned pinned memory, valid during the
+    on_result callback only); put() copies them behind a 40-byte header into ONE tensor on `device` -- on a GPU through
+    `upload(dst_ptr, src_ptr, nbytes)` (gsa_device_upload: pinned -> device DMA, no Python-side copy), on CPU (gloo tests) by
+    memmove -- so that the gather is device to device over xGMI and nothing is packed or copied in Python."""
+
+    HDR = 40
+
+    def __init__(self, device, upload=None):
+        import threading
+        self.dev, self.upload, self.steps, self.lock = device, upload, {}, threading.Lock()
+
+    def put(self, step: int, contig: int, pieces) -> None:
+        import ctypes
+        import torch
+        sizes = [int(n) for _, n in pieces]
+        assert len(sizes) == 4
+        pad = [(n + 7) & ~7 for n in sizes]
+        t = torch.empty(self.HDR + sum(pad), dtype=torch.uint8, device=self.dev)
+        hdr = np.array([contig] + sizes, np.int64)
+        on_gpu = self.upload is not None and self.dev.type == "cuda"
+        off = self.HDR
+        if on_gpu:
+            self.upload(t.data_ptr(), hdr.ctypes.data, self.HDR)
+        else:
+            ctypes.memmove(t.data_ptr(), hdr.ctypes.data, self.HDR)
+        for (addr, n), pn in zip(pieces, pad):
+            if n:
+                if on_gpu:
+                    self.upload(t.data_ptr() + off, addr, n)
+                else:
+                    ctypes.memmove(t.data_ptr() + off, addr, n)
+            off += pn
+        with self.lock:
+            self.steps.setdefault(step, []).append((contig, t))
+
+    def take(self, step: int):
+        with self.lock:
+            return sorted(self.steps.pop(step, []), key=lambda x: x[0])
+
+
+def parse_staged(buf: np.ndarray, block_dt, rec_dt) -> tuple:
+    """(contig, result dict) from the bytes of one staged contig (views, no copies)."""
+    contig, nb, nf, n1, n2 = (int(x) for x in buf[:40].view(np.int64))
+    p = 40
+    blocks = buf[p:p + nb].view(block_dt); p += (nb + 7) & ~7
+    recs = buf[p:p + nf].view(rec_dt); p += (nf + 7) & ~7
+    a1 = buf[p:p + n1]; p += (n1 + 7) & ~7
+    a2 = buf[p:p + n2]
+    return contig, dict(blocks=blocks, recs=recs, aln1=a1, aln2=a2)
+
+
+def gather_staged(staged, max_items: int, device=None, dst: int = 0, host_pool=None):
+    """One step's staged contigs of every rank -> rank `dst`, as host byte arrays (one per contig, in contig order).  One all_gather
+    of the per-contig byte counts (max_items slots per rank), then batched point-to-point sends / receives of exact sizes
+    (device to device: RCCL over xGMI), then -- on `dst` -- one D2H copy per contig into `host_pool` (a pinned uint8 tensor that
+    grows as needed; pass the returned pool back in).  Other ranks return ([], host_pool)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [], host_pool
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else torch.device("cpu")
+    assert len(staged) <= max_items
+    cnt = torch.zeros(max_items, dtype=torch.int64)
+    for i, (_, t) in enumerate(staged):
+        cnt[i] = t.numel()
+    cnt = cnt.to(dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    if rank != dst:
+        ops = [dist.P2POp(dist.isend, t, dst) for _, t in staged]
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        return [], host_pool
+    recv, ops = [], []
+    for r in range(world):
+        if r == dst:
+            continue
+        for n in (int(x) for x in cnts[r].tolist()):
+            if n > 0:
+                t = torch.empty(n, dtype=torch.uint8, device=dev)
+                recv.append(t); ops.append(dist.P2POp(dist.irecv, t, r))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    total = sum(t.numel() for t in recv)
+    if dev.type == "cuda":
+        if host_pool is None or host_pool.numel() < total:
+            host_pool = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+        out, off = [], 0
+        for t in recv:
+            h = host_pool[off:off + t.numel()]; h.copy_(t, non_blocking=True); out.append(h); off += t.numel()
+        torch.cuda.current_stream(dev).synchronize()
+        return [h.numpy() for h in out], host_pool
+    return [t.numpy() for t in recv], host_pool
+
+
 def gather_block_records(records: np.ndarray, contig_ids: np.ndarray, device=None):
     """Gather per-rank block records to every rank (rank 0 uses them), ordered by
     (contig id, original position).  records: uint8 [n, 40] (gsa_block bytes);

@@ -168,6 +168,17 @@ int gsa_align_contig(gsa_ctx *ctx, const char *query, int32_t qlen, gsa_result *
  * as above, valid and unmodified until the call returns.  gsa_device_alloc / gsa_device_upload / gsa_device_free are the
  * plain-C way to such a buffer for hosts that do not link a HIP runtime themselves. */
 int gsa_align_contig_device(gsa_ctx *ctx, const char *d_query, int32_t qlen, gsa_result *out);
+/* Upload of the NEXT contig while the current one is aligned.  The reference reads QueryChrVec[i].seq from host memory when the
+ * loop reaches it (GSAlign.cpp:483-490, loader main.cpp:82-114); a GPU has to copy it first -- 4.8 ms per 250 Mb -- and that copy
+ * hides behind the stages of the contig in front of it: a context has two device buffers for query sequences, gsa_prefetch_contig
+ * (or _bundle) starts the copy of `query` into the one the next gsa_align_contig / gsa_align_bundle will not use and returns at
+ * once; the following gsa_align_contig(ctx, query, qlen) -- same pointer, same length -- finds the contig on the device.  Call
+ * order: gsa_prefetch_contig(next); gsa_align_contig(current); ...  `query` must stay valid and unmodified until it has been
+ * aligned (or gsa_cancel_prefetch returned).  At most two contigs wait at a time (GSA_ERR_STATE beyond that).  After a prefetch
+ * gsa_rewind may report GSA_ERR_STATE (the previous contig's device copy is gone).  gsa_align_many does all this by itself. */
+int gsa_prefetch_contig(gsa_ctx *ctx, const char *query, int32_t qlen);
+int gsa_prefetch_bundle(gsa_ctx *ctx, const char *const *query, const int32_t *qlen, int32_t n);
+int gsa_cancel_prefetch(gsa_ctx *ctx);
 void *gsa_device_alloc(int device, size_t bytes);
 void  gsa_device_free(int device, void *p);
 int   gsa_device_upload(int device, void *dst, const void *src, size_t bytes);
@@ -184,6 +195,7 @@ typedef int (*gsa_result_fn)(void *user, int32_t contig, const gsa_result *res);
 #define GSA_MANY_DEVICE   2u   /* query[] are device pointers (gsa_align_contig_device); all contexts on one GPU */
 #define GSA_MANY_NO_SPLIT 4u   /* never seed one contig on several contexts (see below) */
 #define GSA_MANY_NO_BUNDLE 8u  /* never align several short contigs in one pass (see gsa_align_bundle) */
+#define GSA_MANY_NO_PREFETCH 16u /* upload every contig when its turn comes (default: a context uploads its next contig while it aligns the current one) */
 /* With FEWER contigs than contexts (one chromosome, two GPUs: BASELINE configs[3]) the contexts are dealt out in groups, one
  * group per contig, sized by contig length, and a contig of at least 20 Mb (GSA_SPLIT_MIN) is seeded by chunk range on all
  * contexts of its group -- gsa_seed_chunks ... gsa_finish_contig below, driven from the library's own threads, hits moved
@@ -276,6 +288,12 @@ int gsa_gap_similarity_batch(gsa_ctx *ctx, int32_t n, const int32_t *q1, const i
  * [5] DP + string materialisation [6] total device time [7] host list logic. */
 int gsa_get_counters(gsa_ctx *ctx, uint64_t counters[8]);
 int gsa_get_timings(gsa_ctx *ctx, float kernel_ms[8]);
+/* Host wall clock the calling thread spent inside the library per phase, summed over the contigs aligned since the last
+ * gsa_set_profiling: ms[0] query set-up (upload, or the wait for a prefetched one), ms[s] stage s = 1..8 of gsa_run_to (a stage ends
+ * where the host has to look at a count: ms[1] seed search incl. its read-back ... ms[8] DP + strings + the results' D2H);
+ * *n = contigs; on the context that owns the index, ms[9] / *n = mean duration of one query upload (the Uploader's copies, one at a time).
+ * Always on (nine clock reads per contig). */
+int gsa_get_wall_sums(gsa_ctx *ctx, double ms[10], int64_t *n);
 /* flags: bit 0 = per-stage hipEvent timing; bit 1 = run the ACCOUNTING build of the seed kernel,
  * which also records, per search, how many Occ blocks the reference's walk reads, so that counters[0]
  * is exact (same seeds either way; the default build leaves counters[0] = 0); bit 2 = time the seed

@@ -1,6 +1,7 @@
 """bench.py --gpus N must really become N ranks (round-1 finding: the flag was parsed and ignored).  CPU check with the
 --dry stub: `python bench.py --gpus 2 --dry` re-executes itself under torch.distributed.run, rank 0 prints one JSON line
-with n_gpus = 2, and the result gather has seen the contigs of both ranks."""
+with n_gpus = 2, and the staged result gather (shard.ResultStage / gather_staged: ONE genome's contigs dealt to the ranks by LPT,
+every finished contig to rank 0, checked byte for byte inside the run) has left all contigs of the genome on rank 0."""
 import json
 import os
 import subprocess
@@ -20,8 +21,8 @@ def run(*args):
 
 def test_gpus_2_relaunches_as_two_ranks():
     d = run("--gpus", "2", "--dry", "--steps", "3", "--warmup", "1")
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["config"]["gathered_contigs"] == 8
-    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["value"] > 0
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["config"]["contigs_on_rank0_after_gather"] == 5 and d["config"]["world_size"] == 2
+    assert d["scaling"] == "strong" and d["higher_is_better"] is True and d["value"] > 0
 
 
 def test_gpus_1_runs_in_process():

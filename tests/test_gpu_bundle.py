@@ -133,3 +133,66 @@ def test_align_many_bundles_short_contigs(oracle_built, tmp_path, monkeypatch):
     for g in ctxs[1:]:
         g.close()
     g0.close()
+
+
+def test_prefetch_hides_upload_same_bytes(oracle_built, tmp_path, monkeypatch):
+    """Round 4: a context uploads its NEXT contig (or bundle) into its second query slot while it aligns the current one
+    (gsa_prefetch_contig / gsa_prefetch_bundle; gsa_align_many does it by itself).  (1) gsa_align_many with and without the prefetch
+    (GSA_MANY_NO_PREFETCH), two contexts, bundles and single contigs mixed: the same bytes per contig.  (2) the calls by hand on one
+    context -- prefetch(next); align(current) -- against plain gsa_align_contig and the oracle; state rules: a third waiting contig is
+    refused, gsa_rewind after a prefetch took the previous contig's slot is refused, gsa_cancel_prefetch frees the slots."""
+    monkeypatch.setenv("GSA_BUNDLE_CONTIG", "1000000")
+    lens = [150000 + 41000 * k for k in range(9)] + [2500000, 1800000, 9999, 0, 1200000]
+    refs, qrys = synth.make_pair_fast(0, len(lens), 0.02, seed=81, lengths=lens)
+    idx = _build(tmp_path, refs)
+    g0 = capi.Aligner(idx); ctxs = [g0, g0.clone()]
+    seqs = [g0.pinned_copy(q) for _, q in qrys]
+
+    def run(prefetch):
+        out = {}
+
+        def on_result(ci, res):
+            out[ci] = g0._result(res)
+            return 0
+        capi.align_many(ctxs, seqs, on_result, prefetch=prefetch)
+        return out
+    a, b = run(True), run(False)
+    assert sorted(a) == sorted(b) == list(range(len(seqs)))
+    for ci in a:
+        _same_result(a[ci], b[ci], f"contig {ci}")
+    # (2) by hand
+    g = ctxs[1]
+    order = [9, 0, 10, 13, 3]
+    plain = {ci: g.align_contig(seqs[ci]) for ci in order}
+    g.prefetch_contig(seqs[order[0]])
+    got = {}
+    for k, ci in enumerate(order):
+        if k + 1 < len(order):
+            g.prefetch_contig(seqs[order[k + 1]])
+        got[ci] = g.align_contig(seqs[ci])
+    for ci in order:
+        _same_result(got[ci], plain[ci], f"prefetched contig {ci}")
+    o = oracle_built.Oracle(idx)
+    for ci in (9, 3):
+        o.set_query(np.array(seqs[ci])); o.run_to(8); want = o.blocks(with_aln=True)
+        d = capi.result_as_dump(got[ci], with_aln=True)
+        for key, v in want.items():
+            assert np.array_equal(d[key], v), (ci, key)
+    o.close()
+    # state rules
+    g.align_contig(seqs[0])
+    g.prefetch_contig(seqs[1]); g.prefetch_contig(seqs[2])
+    with pytest.raises(capi.GsaError):
+        g.prefetch_contig(seqs[3])                  # two contigs wait already
+    with pytest.raises(capi.GsaError):
+        g.rewind()                                  # the second prefetch took contig 0's slot
+    g.cancel_prefetch()
+    r = g.align_contig(seqs[3]); g.rewind(); g.run_to(8)
+    _same_result(g.blocks(), r, "rewind after cancel")
+    # a prefetched contig nobody aligns does not get in the way of other contigs
+    g.prefetch_contig(seqs[10])
+    _same_result(g.align_contig(seqs[9]), plain[9], "other contig while one waits")
+    _same_result(g.align_contig(seqs[10]), plain[10], "the waiting contig, later")
+    for x in ctxs[1:]:
+        x.close()
+    g0.close()
