@@ -52,7 +52,7 @@ GRCH38_MB = [248, 242, 198, 190, 181, 170, 159, 145, 138, 133, 135, 133, 114, 10
 
 WORKLOADS = {
     # name: genome length(s), divergence, repeat injection, aligner parameters, distinct query genomes
-    "human": dict(lengths=[250_000_000], div=0.01, repeats=True, params={}, n_query=4, inflight=4, steps=80,
+    "human": dict(lengths=[250_000_000], div=0.01, repeats=True, params={}, n_query=4, inflight=4, steps=160,
                   label="human-chr1-sized pair (BASELINE configs[3] on one GPU): 250 Mb reference with repeat injection (300-bp family over 10 %, 150-copy tandem) vs 1 %-diverged query, defaults"),
     "ecoli": dict(lengths=[5_000_000], div=0.02, repeats=False, params={}, n_query=4, inflight=2, steps=200,
                   label="E. coli-sized pair (BASELINE configs[1] stand-in): 5 Mb reference vs 2 %-diverged query, default -slen 15 -ind 25"),
@@ -216,8 +216,9 @@ def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup, d
     # (priming, untimed: the timed call's own shape once -- gsa_align_many sizes its bundles of short contigs by the work it is
     #  handed, and a context that meets a larger pass than it has seen grows its device buffers: hipMalloc inside a timed step)
     bundle_main = not single_short       # configs[1] is ONE 5 Mb contig: a real run cannot bundle it with anything -- `value` = every contig in a pass of its own
+    short = min(c.size for gq in genomes for c in gq) <= 16_000_000          # (contigs short enough to be bundled: the shape of the passes depends on how many are queued)
     if max(len(gq) for gq in genomes) > 1 or single_short:
-        timed_run(min(steps, 2 * len(pinned)) if not single_short else steps, pinned, bundle=bundle_main)
+        timed_run(steps if short else min(steps, 2 * len(pinned)), pinned, bundle=bundle_main)
     timed_run(warmup, pinned, bundle=bundle_main)
     # timed region: the dominant kernel (seed search) is timed live, two hipEvents per contig on the library's stream; the
     # library sums them per context (gsa_get_timings, kernel_ms[6])
@@ -252,7 +253,7 @@ def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup, d
         v = v.cpu().numpy(); alg = dict(zip(alg.keys(), (float(x) for x in v[:len(alg)]))); cnt = v[len(alg):]
     return dict(px=px, refs=refs, genomes=genomes, t_total=t_total, bp=bp_job * steps, bp_per_step=bp_job, steps=steps, alg=alg, cnt=cnt, tm=tm,
                 occ_read=occ_read, seed_live_ms=seed_live_ms, side=side, n_blocks=n_blocks, n_frags=n_frags, n_aln=n_aln, contigs_per_step=len(genomes[0]),
-                contigs_this_rank=per_step, inflight=inflight, lat_ms=lat_ms, lat_bp=lat_bp, single_short=single_short, gathered=gathered, bundle_main=bundle_main)
+                contigs_this_rank=per_step, inflight=inflight, lat_ms=lat_ms, lat_bp=lat_bp, single_short=single_short, short=short, gathered=gathered, bundle_main=bundle_main)
 
 
 def measure_split(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup, dev):
@@ -335,7 +336,8 @@ def summarise(name, wl, m, t_max, total_bp, world, args):
     out = {
         "value": total_bp / t_max / 1e9, "ms_per_step": ms_step,
         "config": {"workload": wl["label"] + f"; {len(m['genomes'])} distinct query genomes rotating; step = every contig of one genome: H2D of the contig from pinned host memory (hidden behind the previous contig: gsa_prefetch_contig) + S1..S7 + D2H of records and strings"
-                   + ("" if m["bundle_main"] else "; every contig in a pass of its own (GSA_MANY_NO_BUNDLE: one genome = one short contig, nothing to bundle it with)"),
+                   + ("" if m["bundle_main"] else "; every contig in a pass of its own (GSA_MANY_NO_BUNDLE: one genome = one short contig, nothing to bundle it with)")
+                   + ("; the K genomes are queued at once and gsa_align_many lets short contigs of consecutive genomes share passes (bundles of <= 64 Mb)" if m["bundle_main"] and m["short"] else ""),
                    "query_bp_per_step": int(m["bp_per_step"]), "contigs_per_step": m["contigs_per_step"], "inflight_contexts_per_gpu": m["inflight"],
                    "parallelism": (f"contig-shard x{world} (LPT, shard.assign_contigs), index replicated, results gathered on rank 0 over RCCL inside the timed region" if world > 1 else "one GPU"),
                    "aligner_params": wl["params"]},
@@ -426,6 +428,10 @@ def dry_main(args):
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr); sys.exit(2)
+    if args.steps <= 0:
+        args.steps = 3
+    if args.warmup < 0:
+        args.warmup = 1
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.default_rng(100)                       # ONE genome, the same on every rank
@@ -479,14 +485,14 @@ def dry_main(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=0, help="0 = the workload's own (human_full: 10 genomes = 240 contigs)")
+    ap.add_argument("--warmup", type=int, default=-1, help="-1 = steps / 8, at least 2")
     ap.add_argument("--workload", default="human_full", choices=sorted(WORKLOADS))
     ap.add_argument("--genome", type=int, default=0, help="override the reference length of a one-contig workload")
     ap.add_argument("--divergence", type=float, default=-1.0)
     ap.add_argument("--inflight", type=int, default=0, help="contexts (host threads) per GPU working on different contigs (0 = the workload's own)")
     ap.add_argument("--extra", default="human,ecoli,yeast,adversarial", help="further workloads measured in the same run (a process each, loops of their own); '' = none")
-    ap.add_argument("--hwq", type=int, default=8, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default of 4; the contexts in flight have 5 streams each)")
+    ap.add_argument("--hwq", type=int, default=16, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default of 4; the contexts in flight have 5 streams each)")
     ap.add_argument("--split", action="store_true", help="N > 1 only: ONE contig per step, its seed search sharded by chunk range over the ranks (BASELINE configs[3])")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo: plumbing checks)")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing check on a one-GPU box: every rank uses GPU 0 (with --backend gloo)")
@@ -550,6 +556,10 @@ def main():
         fallback = f"host has {host_mem_gb():.0f} GB of memory, the 3.08 Gbp index build needs ~120: fell back to --workload human (BASELINE configs[3] on one GPU)"
         name = "human"
     wl = dict(WORKLOADS[name])
+    if args.steps <= 0:
+        args.steps = wl["steps"]
+    if args.warmup < 0:
+        args.warmup = max(2, args.steps // 8)
     if args.fasta_ref:
         wl["label"] = f"real genomes: {os.path.basename(args.fasta_ref)} vs {os.path.basename(args.fasta_query)}"; wl["n_query"] = 1
     if args.genome > 0 and len(wl["lengths"]) == 1:
@@ -585,7 +595,7 @@ def main():
         extras = []
         for xn in [x for x in args.extra.split(",") if x and x != name and world == 1 and not args.fasta_ref]:
             st = WORKLOADS[xn]["steps"]
-            cmd = [sys.executable, os.path.abspath(__file__), "--workload", xn, "--steps", str(st), "--warmup", str(max(2, st // 8)), "--extra", "", "--no-cpu-baseline", "--hwq", str(args.hwq)]
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", xn, "--extra", "", "--no-cpu-baseline", "--hwq", str(args.hwq)]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GSA_BENCH_TMP=tmp, GSA_BENCH_KEEP="1"))
                 d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
