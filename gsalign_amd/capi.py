@@ -20,7 +20,7 @@ EXPORTS = [
     "gsa_align_contig_device", "gsa_set_query_device", "gsa_device_alloc", "gsa_device_free", "gsa_device_upload", "gsa_get_seed_stats", "gsa_hit_buffers", "gsa_seed_chunks", "gsa_hit_count", "gsa_export_hits", "gsa_import_hits", "gsa_finish_contig",
     "gsa_set_query", "gsa_rewind", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
     "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling", "gsa_bind_host_thread",
-    "gsa_prefetch_contig", "gsa_prefetch_bundle", "gsa_cancel_prefetch", "gsa_get_wall_sums",
+    "gsa_prefetch_contig", "gsa_prefetch_bundle", "gsa_cancel_prefetch", "gsa_get_wall_sums", "gsa_set_option",
 ]
 
 
@@ -117,6 +117,7 @@ def load_library() -> C.CDLL:
     lib.gsa_set_query_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.gsa_prefetch_contig.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     lib.gsa_cancel_prefetch.argtypes = [C.c_void_p]
+    lib.gsa_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.gsa_last_error.restype = C.c_char_p
     lib.gsa_last_error.argtypes = [C.c_void_p]
     lib.gsa_seed_count.restype = C.c_int64
@@ -210,7 +211,22 @@ class GsaError(RuntimeError):
 class Aligner:
     """One gsa_ctx on one GPU."""
 
-    def __init__(self, idx, device: int = 0, wide: bool = False, _clone_of=None, **params):
+    # gsa_set_option names a test / tool may also give through the environment (GSA_<NAME>): the LIBRARY reads no environment variable,
+    # this Python layer does and passes the values on
+    ENV_OPTIONS = ("split_min", "bundle_contig", "bundle_cap", "seed_budget", "dp_lane", "seed_mode", "pd_bitmap", "dp_safe", "dp_fake_timeout")
+
+    def _options_from_env(self):
+        for name in self.ENV_OPTIONS:
+            v = os.environ.get("GSA_" + name.upper())
+            if v is not None and v != "":
+                self.set_option(name, {"sweep": 0, "spec": 1, "search": 2}.get(v, v) if name == "seed_mode" else v)
+        if os.environ.get("GSA_NO_PDBITMAP"):
+            self.set_option("pd_bitmap", 0)
+
+    def set_option(self, name: str, value) -> None:
+        self._ck(self.lib.gsa_set_option(self.ctx, name.encode(), C.c_int64(int(value))))
+
+    def __init__(self, idx, device: int = 0, wide: bool = False, kmer_k: int = 0, _clone_of=None, **params):
         self.lib = load_library()
         self.idx = idx
         self._pinned = []
@@ -221,6 +237,7 @@ class Aligner:
             if rc != 0:
                 raise GsaError(f"gsa_clone -> {rc}: {self.lib.gsa_last_error(None).decode()}")
             self._parent = _clone_of        # keeps the index owner alive
+            self._options_from_env()
             return
         self._ref = np.ascontiguousarray(idx.ref)
         v = IndexView()
@@ -234,10 +251,15 @@ class Aligner:
         v.chr_len = _p(idx.chr_len, C.c_int32); v.n_chr = len(idx.chr_len)
         self.ctx = C.c_void_p()
         p = self._params(**params)
-        # wide=True: GSA_CREATE_WIDE, the >= 2^32-row device layout on any index; plain gsa_create otherwise (it honours GSA_FORCE_WIDE)
-        rc = self.lib.gsa_create_opts(device, C.byref(v), C.byref(p), 1, C.byref(self.ctx)) if wide else self.lib.gsa_create(device, C.byref(v), C.byref(p), C.byref(self.ctx))
+        # wide=True (or GSA_FORCE_WIDE=1 in the environment of the test run): GSA_CREATE_WIDE, the >= 2^32-row device layout on any index;
+        # kmer_k (or GSA_KMER_K): GSA_CREATE_KMER_K
+        wide = wide or os.environ.get("GSA_FORCE_WIDE", "0") not in ("", "0")
+        kmer_k = kmer_k or int(os.environ.get("GSA_KMER_K", "0") or 0)
+        flags = (1 if wide else 0) | ((kmer_k & 15) << 8)
+        rc = self.lib.gsa_create_opts(device, C.byref(v), C.byref(p), flags, C.byref(self.ctx))
         if rc != 0:
             raise GsaError(f"gsa_create -> {rc}: {self.lib.gsa_last_error(None).decode()}")
+        self._options_from_env()
 
     def clone(self) -> "Aligner":
         """A further context on the same GPU sharing this one's device index (gsa_clone)."""

@@ -151,8 +151,7 @@ int gsa_set_params(gsa_ctx *c, const gsa_params *p)
 
 int gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa_ctx **out)
 {
-	const char *w = getenv("GSA_FORCE_WIDE");        // whole runs (CLI, test-suite) under the >= 2^32-row layout
-	return gsa_create_opts(device, idx, prm, (w && *w && *w != '0') ? GSA_CREATE_WIDE : 0u, out);
+	return gsa_create_opts(device, idx, prm, 0u, out);
 }
 
 int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm, uint32_t flags, gsa_ctx **out)
@@ -162,12 +161,9 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gsa_fail(nullptr, GSA_ERR_HIP, "no HIP device available (libgsa_hip.so has no CPU path)");
 	if (device < 0 || device >= ndev) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create: bad device ordinal");
-	if (flags & ~(uint32_t)GSA_CREATE_WIDE) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create_opts: unknown flag");
+	if (flags & ~(uint32_t)(GSA_CREATE_WIDE | GSA_CREATE_KMER_K(15))) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create_opts: unknown flag");
 	gsa_ctx *c = new gsa_ctx();
-	c->device = device; c->force_wide = (flags & GSA_CREATE_WIDE) != 0;
-	if (const char *b = getenv("GSA_SEED_BUDGET")) c->seed_budget = (u32)atoi(b);
-	if (const char *b = getenv("GSA_DP_SAFE")) c->dp_safe = atoi(b) != 0;      // (test hook: always take the one-job-per-launch path of the striped DP)
-	if (const char *b = getenv("GSA_DP_FAKE_TIMEOUT")) c->dp_fake_timeout = atoi(b);      // (test hook: the retry after a hand-off time-out)
+	c->device = device; c->force_wide = (flags & GSA_CREATE_WIDE) != 0; c->opt.kmer_k = (int)((flags >> 8) & 15u);
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gsa_fail(nullptr, GSA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); gsa_destroy(c); return GSA_ERR_HIP; } } while (0)
 	CK(hipSetDevice(device));
@@ -259,7 +255,7 @@ int gsa_clone(gsa_ctx *parent, gsa_ctx **out)
 	if (hipSetDevice(parent->device) != hipSuccess) return gsa_fail(nullptr, GSA_ERR_HIP, "hipSetDevice");
 	gsa_ctx *c = new gsa_ctx();
 	c->device = parent->device; c->force_wide = parent->force_wide;
-	c->index_owner = parent->index_owner ? parent->index_owner : parent; c->seed_budget = parent->seed_budget;
+	c->index_owner = parent->index_owner ? parent->index_owner : parent; c->seed_budget = parent->seed_budget; c->opt = parent->opt;
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
 	if (int rc = ctx_private_init(c, c->index_owner)) { g_create_error = c->err; gsa_destroy(c); return rc; }
 	c->di = parent->di; c->G = parent->G;
@@ -297,8 +293,6 @@ static bool device_local_cpus(int device, cpu_set_t *set)
 }
 int gsa_bind_host_thread(int device)
 {
-	static const bool off = getenv("GSA_NO_BIND") != nullptr;
-	if (off) return GSA_OK;
 	cpu_set_t set;
 	if (!device_local_cpus(device, &set)) return GSA_OK;      // (no topology information: leave the thread where it is)
 	(void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
@@ -314,6 +308,23 @@ void *gsa_host_alloc(size_t bytes)
 	return p;
 }
 void gsa_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
+int gsa_set_option(gsa_ctx *c, const char *name, int64_t value)
+{
+	if (!c || !name) return GSA_ERR_ARG;
+	const std::string k(name);
+	if (k == "split_min") c->opt.split_min = value;
+	else if (k == "bundle_contig") c->opt.bundle_contig = value;
+	else if (k == "bundle_cap") c->opt.bundle_cap = value > 0 ? value : 1;
+	else if (k == "seed_budget") c->seed_budget = (u32)value;
+	else if (k == "dp_lane") c->opt.dp_lane = (int)value;
+	else if (k == "seed_mode") { if (value < 0 || value > 2) return gsa_fail(c, GSA_ERR_ARG, "seed_mode: 0 sweep, 1 speculative, 2 search"); c->opt.seed_mode = (int)value; }
+	else if (k == "pd_bitmap") c->opt.pd_bitmap = value != 0;
+	else if (k == "dp_safe") c->dp_safe = value != 0;                    // (test hook)
+	else if (k == "dp_fake_timeout") c->dp_fake_timeout = (int)value;    // (test hook)
+	else return gsa_fail(c, GSA_ERR_ARG, "gsa_set_option: unknown option " + k);
+	return GSA_OK;
+}
 
 int gsa_get_wall_sums(gsa_ctx *c, double ms[10], int64_t *n)
 {
@@ -539,6 +550,7 @@ int gsa_rewind(gsa_ctx *c)
 int gsa_run_to(gsa_ctx *c, int stage)
 {
 	if (!c || stage < 0 || stage > 8) return GSA_ERR_ARG;
+	if (c->bnd.n && stage < 8 && !c->bundle_call) return gsa_fail(c, GSA_ERR_STATE, "gsa_run_to: the context holds a bundle (gsa_align_bundle runs it); gsa_set_query first");
 	// (between gsa_seed_chunks and gsa_finish_contig the context holds the hits of a chunk range only: stage 1 here would seed
 	//  that range again and call the result a contig)
 	if (c->split) return gsa_fail(c, GSA_ERR_STATE, "gsa_run_to: a split contig is finished with gsa_finish_contig");
@@ -668,6 +680,8 @@ int gsa_align_bundle(gsa_ctx *c, const char *const *query, const int32_t *qlen, 
 	if (!c || !query || !qlen || !out || (flags & ~(uint32_t)GSA_MANY_DEVICE)) return GSA_ERR_ARG;
 	int rc = set_query_bundle(c, query, qlen, n, (flags & GSA_MANY_DEVICE) != 0); if (rc) return rc;
 	c->dp_timeout = false;
+	c->bundle_call = true;
+	struct Clear { gsa_ctx *c; ~Clear() { c->bundle_call = false; } } clear_{ c };
 	rc = gsa_run_to(c, 8);
 	if (rc == GSA_ERR_STATE && c->dp_timeout && !c->dp_safe) {      // (the safety net of gsa_align_contig; the concatenation stays where it is)
 		c->dp_timeout = false; c->dp_safe = true;
@@ -794,8 +808,9 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 	// dealt out in GROUPS, one per contig, sized by contig length, and every group seeds its contig by chunk range (align_split).
 	// Only contigs of at least GSA_SPLIT_MIN bases (default 20 Mb: below that the seed search is a fraction of a millisecond and
 	// a second upload of the contig costs more than it saves) get more than one context.
-	static const int64_t split_min = [] { const char *e = getenv("GSA_SPLIT_MIN"); return e ? (int64_t)atoll(e) : 20000000ll; }();
-	if (n < n_ctx && !dev_q && !(flags & GSA_MANY_NO_SPLIT) && (int64_t)qlen[order[0]] >= split_min) {
+	const int64_t split_min = ctx[0]->opt.split_min;
+	int64_t longest = 0; for (int32_t i = 0; i < n; i++) if (qlen[i] > longest) longest = qlen[i];      // (in hand-out order the first contig need not be the longest)
+	if (n < n_ctx && !dev_q && !(flags & GSA_MANY_NO_SPLIT) && longest >= split_min) {
 		std::vector<int> gsz((size_t)n, 1);
 		for (int left = n_ctx - n; left > 0; left--) {       // the next context goes where a context has the most bases to itself
 			int best = -1; double load = 0;
@@ -824,8 +839,7 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 	// one context, profiles/r03_bundle_sweep.txt), so the short contigs are dealt into as few bundles as GSA_BUNDLE_CAP (default
 	// 64 Mb) allows, rounded up to a multiple of the context count (one equal share per context).  Contigs above
 	// GSA_BUNDLE_CONTIG (default 16 Mb) stay alone; GSA_BUNDLE_CONTIG=0 or GSA_MANY_NO_BUNDLE: no bundles.
-	static const int64_t bundle_contig = [] { const char *e = getenv("GSA_BUNDLE_CONTIG"); return e ? (int64_t)atoll(e) : 16000000ll; }();
-	static const int64_t bundle_cap = [] { const char *e = getenv("GSA_BUNDLE_CAP"); return e ? (int64_t)atoll(e) : 64000000ll; }();
+	const int64_t bundle_contig = ctx[0]->opt.bundle_contig, bundle_cap = ctx[0]->opt.bundle_cap;
 	std::vector<std::vector<int32_t> > units;
 	{
 		bool may = !(flags & GSA_MANY_NO_BUNDLE) && bundle_contig > 0;
@@ -843,7 +857,11 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
 			if (fit < max_contigs) max_contigs = (size_t)fit;
 			if (max_contigs < 2) may = false;
 		}
-		static const int64_t bundle_target = [] { const char *e = getenv("GSA_BUNDLE_TARGET"); return e ? (int64_t)atoll(e) : 0ll; }();      // (experiments: a fixed bundle size)
+#ifdef GSA_EXPERIMENTS
+		static const int64_t bundle_target = [] { const char *e = getenv("GSA_BUNDLE_TARGET"); return e ? (int64_t)atoll(e) : 0ll; }();      // (a fixed bundle size)
+#else
+		const int64_t bundle_target = 0;
+#endif
 		int64_t n_bundles = (small_total + bundle_cap - 1) / (bundle_cap > 0 ? bundle_cap : 1); if (n_bundles < 1) n_bundles = 1;
 		n_bundles = (n_bundles + n_ctx - 1) / n_ctx * n_ctx;
 		int64_t target = small_total / n_bundles + 1;
@@ -953,6 +971,7 @@ int gsa_get_blocks(gsa_ctx *c, gsa_result *out)
 {
 	if (!c || !out) return GSA_ERR_ARG;
 	if (c->stage < 2) return gsa_fail(c, GSA_ERR_STATE, "run stage 2 first");
+	if (c->bnd.n && c->stage < 8) return gsa_fail(c, GSA_ERR_STATE, "gsa_get_blocks: the context holds a bundle -- only its finished result (gsa_align_bundle's out[]) is defined per contig");
 	if (c->frags_stage != c->stage) { int rc = build_block_view(c); if (rc) return rc; }
 	out->n_blocks = (int32_t)c->h_blocks.size(); out->blocks = c->h_blocks.data();
 	if (c->result_pinned && c->stage == 8) {

@@ -148,8 +148,9 @@ static int host_stage4_5_6_one(gsa_ctx *c, int stage);
 int host_stage4_5_6(gsa_ctx *c, int stage)
 {
 	if (!c->bnd.n) return host_stage4_5_6_one(c, stage);
-	for (std::vector<HostBlock> &L : c->b_lists) { c->blocks.swap(L); host_stage4_5_6_one(c, stage); c->blocks.swap(L); }
-	return GSA_OK;
+	int rc = GSA_OK;
+	for (std::vector<HostBlock> &L : c->b_lists) { c->blocks.swap(L); const int r1 = host_stage4_5_6_one(c, stage); c->blocks.swap(L); if (r1 != GSA_OK && rc == GSA_OK) rc = r1; }
+	return rc;
 }
 
 static int host_stage4_5_6_one(gsa_ctx *c, int stage)

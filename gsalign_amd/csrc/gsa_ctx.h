@@ -68,8 +68,21 @@ struct Uploader {
 	void push(Job &&j) { j.busy->fetch_add(1); j.t_push = std::chrono::steady_clock::now(); { std::lock_guard<std::mutex> g(mu); q.push_back(std::move(j)); } cv.notify_one(); }
 };
 
+// What gsa_set_option sets (include/gsa_hip.h); a clone starts with its parent's values.  The library reads NO environment variable
+// (experiment switches exist only in builds with -DGSA_EXPERIMENTS).
+struct Options {
+	int64_t split_min = 20000000;      // gsa_align_many: a contig of at least this many bases may be seeded by chunk range on several contexts
+	int64_t bundle_contig = 16000000;  // ... contigs up to this length travel in bundles (0: never)
+	int64_t bundle_cap = 64000000;     // ... of about this many bases at most
+	int dp_lane = 512;                 // alignments of at most this many cells go one per lane (k_dp_lane); 0: round 2's tiny / small split
+	int seed_mode = 1;                 // 0 sweep: every chunk through k_dense_sweep; 1: the speculative kernel + dense kernels for what it gives up on; 2: round 2's k_dense_search in place of the sweep
+	int pd_bitmap = 1;                 // 0: groups by the PosDiff sort although MaxIndelSize <= 31 would allow the bitmap scan
+	int kmer_k = 0;                    // gsa_create_opts (GSA_CREATE_KMER_K): length of the jump table's k-mers (0: by text length and free memory)
+};
+
 struct gsa_ctx {
 	int device = 0;
+	Options opt;
 	Uploader *up = nullptr; bool own_up = false;
 	hipStream_t stream = nullptr;
 	hipStream_t stream_seed = nullptr;      // (experiment, GSA_SEED_CUS: the seed-search kernels on a stream restricted to part of the CUs)
@@ -108,7 +121,7 @@ struct gsa_ctx {
 	i64 pd_span = 0;                               // number of PosDiff key values: 2G + qlen + 2, a bundle: contigs x stride
 
 	// ---- a bundle of contigs in one pass (Bundle, gsa_internal.h; gsa_align_bundle in gsa_api.hip) ----
-	Bundle bnd = { 0, 0, 0, nullptr, nullptr };
+	Bundle bnd = { 0, 0, 0, nullptr, nullptr }; bool bundle_call = false;
 	std::vector<i32> b_off, b_qlen;               // start of contig k in the concatenation [n + 1], its length (copied from the slot that holds the bundle)
 	std::vector<std::vector<HostBlock> > b_lists;  // the AlnBlockVec of every contig while the list logic runs (stages 3-6)
 	std::vector<i32> b_blk0;                       // first block of contig k in the joined final list [n + 1]

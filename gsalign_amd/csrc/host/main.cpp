@@ -127,7 +127,14 @@ int main(int argc, char *argv[])
 	const size_t want_ctx = std::min(std::max(qs.size(), gpus.size()), gpus.size() * (size_t)n_ctx_per_gpu);
 	for (size_t g = 0; g < gpus.size() && ctxs.size() < std::max<size_t>(want_ctx, 1); g++) {
 		gsa_ctx *owner = NULL;
-		if (gsa_create(gpus[g], &view, &prm, &owner) != GSA_OK) { fprintf(stderr, "GPU initialisation failed (device %d): %s\n", gpus[g], gsa_last_error(NULL)); return 2; }
+		// (the HOST PROGRAM honours a few environment variables and hands them to the library as options -- the library itself reads none:
+		//  GSA_FORCE_WIDE=1: the >= 2^32-row device layout on any index; GSA_SPLIT_MIN / GSA_BUNDLE_CONTIG / GSA_BUNDLE_CAP: gsa_align_many's policy)
+		const char *fw = getenv("GSA_FORCE_WIDE");
+		if (gsa_create_opts(gpus[g], &view, &prm, (fw && *fw && *fw != '0') ? GSA_CREATE_WIDE : 0u, &owner) != GSA_OK) { fprintf(stderr, "GPU initialisation failed (device %d): %s\n", gpus[g], gsa_last_error(NULL)); return 2; }
+		for (const char *nm : { "split_min", "bundle_contig", "bundle_cap" }) {
+			std::string ev = std::string("GSA_") + nm; for (char &ch : ev) ch = (char)toupper((unsigned char)ch);
+			if (const char *v = getenv(ev.c_str())) (void)gsa_set_option(owner, nm, atoll(v));
+		}
 		ctxs.push_back(owner);
 	}
 	for (int k = 1; k < n_ctx_per_gpu; k++)

@@ -641,7 +641,9 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	// the load: the tile is then fetched the plain way.
 	// (a tile = DP_TILE_ROWS / 8 blocks of eight diagonals = 5 KB; block-aligned)
 	constexpr int TB_BLKS = DP_TILE_ROWS / 8, TB_VEC = TB_BLKS * 16 / 64;
-	uint4 pf[TB_VEC];
+	static_assert(TB_VEC == 5, "the prefetched tile is five named registers (an array was kept in scratch: 96 bytes per lane)");
+	uint4 pf0 = {0, 0, 0, 0}, pf1 = pf0, pf2 = pf0, pf3 = pf0, pf4 = pf0;
+#define PF_EACH(X) X(0, pf0) X(1, pf1) X(2, pf2) X(3, pf3) X(4, pf4)
 	int pf_sp = -1, pf_lo = 0, pf_hi = -1;
 	const int rl_max = m - 1 + 63;                                      // last local diagonal of a stripe
 	const u32 *tile32 = (const u32 *)tile;
@@ -655,8 +657,9 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 		if (sp == pf_sp && rl_hi <= pf_hi && rl_hi - pf_lo >= 64) {
 			rl_lo = pf_lo;
 			DPT(nrun += 1 << 16;)
-#pragma unroll
-			for (int q2 = 0; q2 < TB_VEC; q2++) dst[q2 * 64 + lane] = pf[q2];
+#define PF_PUT(Q, R) dst[(Q) * 64 + lane] = R;
+			PF_EACH(PF_PUT)
+#undef PF_PUT
 		} else {
 			const int b_hi = rl_hi >> 3, b_lo = b_hi - (TB_BLKS - 1) > 0 ? b_hi - (TB_BLKS - 1) : 0;
 			rl_lo = b_lo << 3;
@@ -673,8 +676,9 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 				const int pb_hi = hi >> 3, pb_lo = pb_hi - (TB_BLKS - 1) > 0 ? pb_hi - (TB_BLKS - 1) : 0;
 				const uint4 *src = (const uint4 *)(dir + (size_t)(sp - 1) * pitch + ((size_t)pb_lo << 8));
 				const int nvec = (pb_hi - pb_lo + 1) * 16;
-#pragma unroll
-				for (int q2 = 0; q2 < TB_VEC; q2++) { const int id = q2 * 64 + lane; pf[q2] = src[id < nvec ? id : 0]; }
+#define PF_GET(Q, R) { const int id = (Q) * 64 + lane; R = src[id < nvec ? id : 0]; }
+				PF_EACH(PF_GET)
+#undef PF_GET
 				pf_sp = sp - 1; pf_lo = pb_lo << 3; pf_hi = (pb_hi << 3) + 7 < rl_max ? (pb_hi << 3) + 7 : rl_max;
 			}
 		}
@@ -906,7 +910,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	// Size classes below the striped kernel: alignments of at most GSA_DP_LANE cells (default 512; swept 256 .. 8192: profiles/r03_dp_lane_sweep.txt) go one per LANE (k_dp_lane: every lane busy
 	// on every instruction; a lane walks its cells one after the other, so the largest job of a launch is its latency floor --
 	// 35 instructions per cell), the larger ones one per wavefront (k_dp_small).  GSA_DP_LANE=0: round 2's tiny / small split.
-	static const int dp_lane = [] { const char *e = getenv("GSA_DP_LANE"); return e ? atoi(e) : 512; }();
+	const int dp_lane = c->opt.dp_lane;
 	{ OpClassify op = { len1, len2, d_order, d_order_tiny, d_lg, d_jlarge, mail, h, (i32)first_lg, dp_lane }; int rc = lb_launch<2>(c, n_ub, op); if (rc) return rc; }
 	GSA_CHECK(c, hipStreamSynchronize(st));
 	if (h[M_LBERR]) return gsa_fail(c, GSA_ERR_STATE, "internal: look-back scan timed out");
@@ -925,8 +929,12 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	std::vector<LgJob> large((const LgJob *)(h + MAIL_N), (const LgJob *)(h + MAIL_N) + nlarge);
 	hipEvent_t ev_fork = c->ev[10], ev_j2 = c->ev[12];
 	// the many small jobs run on a second stream, concurrently with the striped ones
-	static const int dp_order = [] { const char *e = getenv("GSA_DP_ORDER"); return e ? atoi(e) : 0; }();      // experiment: 1 = tiny, small, then the stripes, one after the other on the caller's stream
-	static const int dp_after_early = [] { const char *e = getenv("GSA_DP_AFTER_EARLY"); return e ? atoi(e) : 0; }();      // experiment: the small classes wait for the early striped launch
+#ifdef GSA_EXPERIMENTS
+	static const int dp_order = [] { const char *e = getenv("GSA_DP_ORDER"); return e ? atoi(e) : 0; }();      // 1 = tiny, small, then the stripes, one after the other on the caller's stream
+	static const int dp_after_early = [] { const char *e = getenv("GSA_DP_AFTER_EARLY"); return e ? atoi(e) : 0; }();      // the small classes wait for the early striped launch
+#else
+	const int dp_order = 0, dp_after_early = 0;
+#endif
 	if (nsmall + ntiny > 0 && dp_lane > 0) {
 		GSA_CHECK(c, hipEventRecord(ev_fork, st));
 		GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], ev_fork, 0));

@@ -439,7 +439,7 @@ int stage78_extend(gsa_ctx *c)
 	const i32 *jlarge = c->d_dp_large.as<i32>() + 3 * ((size_t)nju + 1);
 	// (a gap's room in the pools is what it can need AT MOST; the bytes no record ends up owning are zero, not whatever the buffer held:
 	//  results are byte-identical from call to call pool slack included -- tools/stress_consistency.py compares whole pools)
-	if (c->n_aln > 0 && !getenv("GSA_NO_POOL_CLEAR")) GSA_CHECK(c, hipMemsetAsync(d_aln1, 0, t_total - t_aln1, sx));
+	if (c->n_aln > 0) GSA_CHECK(c, hipMemsetAsync(d_aln1, 0, t_total - t_aln1, sx));
 	{ const i64 tiles_ub = (nfu + 255) / 256;
 	  hipLaunchKernelGGL(k_materialize, dim3((unsigned)(tiles_ub < MAT_WGS ? tiles_ub : MAT_WGS)), dim3(256), 0, sx, nfb, mail + M_NF, d_fragbase, c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_job.as<i32>(),
 	                     jlarge, c->j_nops.as<i32>(), c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), c->d_ops.as<uint8_t>(), c->j_opsoff.as<i64>(), c->q_dev, c->di.ref,

@@ -196,53 +196,74 @@ __device__ __forceinline__ void stage32(const uint8_t *src, int p0, int clen, u3
 	}
 }
 
-template <bool COUNT, bool E16>
+// NCH chunks per wave (round 4).  What the wave-iterations of ONE chunk hold on repeat-bearing text: 68 iterations with 14.6 of 64 lanes
+// active (-DSEED_STATS) -- the body is over after ~25 iterations, the rest is a handful of lanes deep in the Occ walks of repeat copies --
+// and every iteration costs the wave its ~650 instructions whatever the number of lanes in it: with 2.5 waves per SIMD issuing in 40 % of
+// their cycles each, the SIMDs' issue ports were the kernel's limit (r03_sq_human.txt), not the memory system (8.4 G requests/s against
+// the 19 - 48 G/s tools/rand_probe.hip reaches).  So a wave now owns TWO neighbouring chunks: 2 x 96 sub-ranges in one queue, the tails of
+// the two chunks overlap in time, and the pair takes ~1.2x the iterations of one chunk -- 0.6x the instructions per chunk.  Everything a
+// chunk owns in LDS exists per chunk ([NCH][...]; ~30 KB per pair: five pairs per CU = the same ten chunks in flight); an item is a
+// (chunk, sub-range) pair, v = ch * NSUB + sub-range; the chains of the two chunks never touch (a match stops at its chunk's end and
+// IdentifyLocalMEM restarts at every chunk, GSAlign.cpp:61-94), so the resolver works on both at once: two roots, exits past a chunk's
+// end terminate.  The accounting build (COUNT) keeps one chunk per wave (its per-start Occ-block array is 20 KB per chunk).
+template <bool COUNT, bool E16, int NCH>
 __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__restrict__ q, i32 qlen, const Params &prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
-                                                      u32 budget, u32 *heavy_list, i32 *chunk_base, const int chunk, const u32 n_chunks)
+                                                      u32 budget, u32 *heavy_list, i32 *chunk_base, const int chunk0, const u32 n_chunks)
 {
-	__shared__ u32 s_ncand, s_queue, s_hits;
+	constexpr int NV = NCH * NSUB;                     // virtual items
+	__shared__ u32 s_ncand[NCH], s_queue, s_hits[NCH];
 	__shared__ int changed, s_abort;
-	__shared__ u32 qp[QP_WORDS], qn[QN_WORDS];
+	__shared__ u32 qp[NCH][QP_WORDS], qn[NCH][QN_WORDS];
 	// next(s) - s per position as nibbles + a hash table for the long hops (memo_get / memo_set above); a full table (never
 	// seen) sends the chunk to the dense kernels like an exhausted budget does.
-	__shared__ u32 memo[MEMO_WORDS];
-	__shared__ u32 lhop[LHOP_N];              // (s + 1) << 16 | hop, 0 = free
-	__shared__ uint16_t mblk[COUNT ? GSA_CHUNK : 1];   // Occ blocks the search from s read (accounting build only)
-	__shared__ u32 bits[PATH_WORDS];
-	__shared__ uint16_t entry_of[NSUB], exit_of[NSUB];
-	__shared__ uint16_t pend_it[SEED_WG];                       // sub-ranges to walk for real in this pass
-	__shared__ uint16_t jmp[2][NSUB], walked_from[NSUB];        // pointer-jumping buffers; entry of the last real walk of a re-walked sub-range
-	__shared__ u32 rewalked[NSUB / 32], onchain[NSUB / 32], s_npend;
+	__shared__ u32 memo[NCH][MEMO_WORDS];
+	__shared__ u32 lhop[NCH][LHOP_N];         // (s + 1) << 16 | hop, 0 = free
+	__shared__ uint16_t mblk[COUNT ? GSA_CHUNK : 1];   // Occ blocks the search from s read (accounting build only: NCH = 1)
+	__shared__ u32 bits[NCH][PATH_WORDS];
+	__shared__ uint16_t entry_of[NV], exit_of[NV];
+	__shared__ uint16_t pend_it[SEED_WG];                       // items to walk for real in this pass
+	__shared__ uint16_t jmp[2][NV], walked_from[NV];            // pointer-jumping buffers; entry of the last real walk of a re-walked sub-range
+	__shared__ u32 rewalked[(NV + 31) / 32], onchain[(NV + 31) / 32], s_npend;
+	static_assert(!COUNT || NCH == 1, "the accounting build walks one chunk per wave");
 	const int j = threadIdx.x;
-	const i64 c0 = (i64)chunk * GSA_CHUNK;
-	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
-	// stage the chunk: 32 bases per lane per pass -> two code words + one N word (16-byte global loads)
-	for (int g = j; g < QN_WORDS; g += SEED_WG) {
-		u32 w0 = 0, w1 = 0, wn = 0;
-		const int p0 = g << 5;
-		if (p0 < clen) {
-			stage32(q + c0 + p0, p0, clen, w0, w1, wn);
-		}
-		if (2 * g < QP_WORDS) qp[2 * g] = w0;
-		if (2 * g + 1 < QP_WORDS) qp[2 * g + 1] = w1;
-		qn[g] = wn;
+	const int nch = (u32)chunk0 + NCH <= n_chunks ? NCH : (int)(n_chunks - (u32)chunk0);      // chunks of this pair that exist (the last pair of an odd contig: one)
+	i64 c0[NCH]; int clen[NCH], S[NCH], nitems[NCH]; size_t cbase[NCH];
+#pragma unroll
+	for (int ch = 0; ch < NCH; ch++) {
+		c0[ch] = (i64)(chunk0 + ch) * GSA_CHUNK;
+		clen[ch] = ch < nch ? (int)((i64)qlen - c0[ch] < GSA_CHUNK ? (i64)qlen - c0[ch] : GSA_CHUNK) : 0;
+		S[ch] = (clen[ch] + NSUB - 1) / NSUB; if (S[ch] < 1) S[ch] = 1;       // sub-range length
+		nitems[ch] = (clen[ch] + S[ch] - 1) / S[ch];
+		cbase[ch] = (size_t)(chunk0 + ch) * cand_cap;                          // this chunk's private candidate segment
 	}
-	for (int p = j; p < MEMO_WORDS; p += SEED_WG) memo[p] = 0;
-	for (int p = j; p < LHOP_N; p += SEED_WG) lhop[p] = 0;
-	for (int p = j; p < PATH_WORDS; p += SEED_WG) bits[p] = 0;
-	if (j == 0) { s_ncand = 0; s_queue = 0; s_hits = 0; s_npend = 0; s_abort = 0; }
-	if (j < NSUB / 32) rewalked[j] = 0;
-	const size_t cbase = (size_t)chunk * cand_cap;      // this chunk's private candidate segment
-	const int S = (clen + NSUB - 1) / NSUB;             // sub-range length (>= 1)
-	const int nitems = (clen + S - 1) / S;
-	for (int it = j; it < nitems; it += SEED_WG) entry_of[it] = (uint16_t)(it * S);
+	const int nitems_all = NCH == 1 ? nitems[0] : nitems[0] + nitems[NCH - 1];
+#define CH_SEL(ARR, CH) (NCH == 1 ? ARR[0] : ((CH) ? ARR[NCH - 1] : ARR[0]))
+	// stage the chunks: 32 bases per lane per pass -> two code words + one N word (16-byte global loads)
+#pragma unroll
+	for (int ch = 0; ch < NCH; ch++) {
+		for (int g = j; g < QN_WORDS; g += SEED_WG) {
+			u32 w0 = 0, w1 = 0, wn = 0;
+			const int p0 = g << 5;
+			if (p0 < clen[ch]) stage32(q + c0[ch] + p0, p0, clen[ch], w0, w1, wn);
+			if (2 * g < QP_WORDS) qp[ch][2 * g] = w0;
+			if (2 * g + 1 < QP_WORDS) qp[ch][2 * g + 1] = w1;
+			qn[ch][g] = wn;
+		}
+		for (int p = j; p < MEMO_WORDS; p += SEED_WG) memo[ch][p] = 0;
+		for (int p = j; p < LHOP_N; p += SEED_WG) lhop[ch][p] = 0;
+		for (int p = j; p < PATH_WORDS; p += SEED_WG) bits[ch][p] = 0;
+		for (int it = j; it < nitems[ch]; it += SEED_WG) entry_of[ch * NSUB + it] = (uint16_t)(it * S[ch]);
+		if (j == 0) { s_ncand[ch] = 0; s_hits[ch] = 0; }
+	}
+	if (j == 0) { s_queue = 0; s_npend = 0; s_abort = 0; }
+	if (j < (NV + 31) / 32) rewalked[j] = 0;
 	u32 all_blocks = 0, rounds = 0, iters = 0;
 #ifdef SEED_STATS
 	u32 st_it = 0, st_fm_any = 0, st_fm_only = 0, st_act = 0, st_fm = 0;
 #endif
 	unsigned long long t_begin = wall_clock64(), t_round0 = 0, t_resolve = 0;
-	u32 dirty = 0;                                      // rounds >= 2: this lane has one sub-range (fb_item) to walk for real
+	u32 dirty = 0;                                      // rounds >= 2: this lane has one item (fb_item) to walk for real
 	int fb_item = 0;
 	__syncthreads();
 	for (;;) {
@@ -252,13 +273,15 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 		// different searches, or in different phases of a search, never serialise on each other's
 		// memory latency.
 		int item = -1, s = 0, bend = 0, pos = 0, mode = M_ADV; u32 kid = 0, pid = 0, pext = 0;
+		int lclen = 0;                                        // length of the chunk my item belongs to
+		const u32 *qp_l = qp[0], *qn_l = qn[0]; u32 *memo_l = memo[0], *lhop_l = lhop[0];      // ... and that chunk's arrays
 		FmIntv ik = {0, 0, 0}; u32 blk = 0; i64 tp = 0;
 		bool need_item = true;
 		while (!__all(mode == M_DONE)) {
 			iters++;
 			// A chunk whose walks exceed the budget (a tandem array with more than MaxSeedFreq copies: every start is searched for
 			// ~100 bases, rejected and followed by start+1 -- thousands of dependent searches on a handful of lanes) is given up
-			// here and searched from EVERY position in parallel by the dense kernels below.
+			// here and searched from EVERY position in parallel by the dense kernels below (with its partner).
 			if (!COUNT && budget && iters > budget) *(volatile int *)&s_abort = 1;
 			if (*(volatile int *)&s_abort) break;
 #ifdef SEED_STATS      // (experiments: what the wave-iterations are spent on -- sums over all waves instead of the maxima / timers)
@@ -308,35 +331,35 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 			bool ended = false;
 			if (mode == M_KMER) {
 				if (!PRES4_TEST(0)) {                  // the first MinSeedLength bases do not occur: no seed here, next start s+1
-					memo_one(memo, s); s += 1; mode = M_ADV;
+					memo_one(memo_l, s); s += 1; mode = M_ADV;
 					// ... and the same for the starts behind it, as long as nothing else is known about them (the advance step
 					// below owns every other rule: sub-range end, memoised hop, ambiguous bases, too close to the chunk end)
 					const int L = prm.MinSeedLength < 32 ? prm.MinSeedLength : 32;
 #pragma unroll
 					for (int k2 = 0; k2 < PLOOK; k2++) {
-						if (s >= bend || memo_nib(memo, s)) break;
-						const u32 nb = q_nbits32(qn, s);
-						if (s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0) break;
+						if (s >= bend || memo_nib(memo_l, s)) break;
+						const u32 nb = q_nbits32(qn_l, s);
+						if (s + prm.MinSeedLength > lclen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0) break;
 						if (k2 == 0 ? PRES4_TEST(1) : k2 == 1 ? PRES4_TEST(2) : PRES4_TEST(3)) break;          // occurs: needs its table entry (next iteration)
-						memo_one(memo, s); s += 1;
+						memo_one(memo_l, s); s += 1;
 					}
 				} else {
 					const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k, walk it base by base
 					if (hit) { ik.x0 = e0.x; ik.x1 = e0.y; ik.x2 = e1.x; pos = s + di.kmer_k; }
-					else ik = fm_init(di, q_code(qp, s));      // (pos = s + 1 since the search was opened)
+					else ik = fm_init(di, q_code(qp_l, s));      // (pos = s + 1 since the search was opened)
 					mode = M_FM;
 					if (hit && ik.x2 == 1) { tp = (i64)(e1.y - 1) + di.kmer_k; mode = M_TEXT; }      // unique: straight to the text comparison
 				}
 			} else if (mode == M_LOC) {
 				tp = (i64)sav + (pos - s); mode = M_TEXT;
 			} else if (mode == M_TEXT) {
-				int got = text_match32(r0, r1, r2, tp, (i64)di.seq_len, qp, qn, pos, clen);
-				if (got == 32) got += text_match32(r2, r3, r4, tp + 32, (i64)di.seq_len, qp, qn, pos + 32, clen);
+				int got = text_match32(r0, r1, r2, tp, (i64)di.seq_len, qp_l, qn_l, pos, lclen);
+				if (got == 32) got += text_match32(r2, r3, r4, tp + 32, (i64)di.seq_len, qp_l, qn_l, pos + 32, lclen);
 				pos += got; tp += got;
 				ended = got < 64;
 			} else if (mode == M_FM) {
-				const bool can = pos < clen && !q_isn(qn, pos < clen ? pos : 0);
-				const bool ok = can && fm_extend_loaded(di, ik, q_code(qp, pos < clen ? pos : 0), bk, bl, kk, ll, kn, ln, blk);
+				const bool can = pos < lclen && !q_isn(qn_l, pos < lclen ? pos : 0);
+				const bool ok = can && fm_extend_loaded(di, ik, q_code(qp_l, pos < lclen ? pos : 0), bk, bl, kk, ll, kn, ln, blk);
 				ended = !ok;
 				if (ok) { pos++; if (!COUNT && ik.x2 == 1) mode = M_LOC; }
 			}
@@ -344,12 +367,14 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 				const int len = pos - s;
 				int d = 1;
 				if (len >= prm.MinSeedLength && ik.x2 <= GSA_MAX_SEED_FREQ) {
-					const u32 slot = atomicAdd(&s_ncand, 1u);                 // LDS counter: no global round trip in the loop
-					if (slot < cand_cap) { cand_s[cbase + slot] = (i32)(c0 + s); cand_len[cbase + slot] = len; cand_x0[cbase + slot] = ik.x0; cand_freq[cbase + slot] = (i32)ik.x2; }
+					const int ch = NCH == 1 ? 0 : (item >= NSUB ? NCH - 1 : 0);
+					const u32 slot = atomicAdd(&s_ncand[ch], 1u);                 // LDS counter: no global round trip in the loop
+					const size_t cb = CH_SEL(cbase, ch);
+					if (slot < cand_cap) { cand_s[cb + slot] = (i32)(CH_SEL(c0, ch) + s); cand_len[cb + slot] = len; cand_x0[cb + slot] = ik.x0; cand_freq[cb + slot] = (i32)ik.x2; }
 					else cnt[CNT_OVERFLOW] = 1;
 					d = prm.bSensitive ? 5 : len + 1;
 				}
-				memo_set(memo, lhop, s, d, &s_abort); if (COUNT) mblk[s] = (uint16_t)blk;
+				memo_set(memo_l, lhop_l, s, d, &s_abort); if (COUNT) mblk[s] = (uint16_t)blk;
 				all_blocks += blk;
 				s += d; mode = M_ADV;
 			}
@@ -358,30 +383,43 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 			// (a few steps per iteration: hops over memoised / ambiguous positions cost no memory access)
 			for (int step = 0; step < ADV_STEPS && mode == M_ADV; step++) {
 				if (need_item) {
-					if (rounds == 0) { const u32 it_ = atomicAdd(&s_queue, 1u); item = it_ < (u32)nitems ? (int)it_ : -1; }
+					if (rounds == 0) {
+						// (the queue hands the two chunks' sub-ranges out alternately, so that both chunks' long walks start early)
+						const u32 it_ = atomicAdd(&s_queue, 1u);
+						if (NCH == 1) item = it_ < (u32)nitems[0] ? (int)it_ : -1;
+						else {
+							const u32 both = 2u * (u32)(nitems[0] < nitems[NCH - 1] ? nitems[0] : nitems[NCH - 1]);
+							if (it_ < both) item = (int)(it_ >> 1) + ((it_ & 1u) ? NSUB : 0);
+							else if (it_ < (u32)nitems_all) { const int r = (int)(it_ - both) + (int)(both >> 1); item = nitems[0] > nitems[NCH - 1] ? r : NSUB + r; }
+							else item = -1;
+						}
+					}
 					else if (dirty) { dirty = 0; item = fb_item; }
 					else item = -1;
 					need_item = false;
 					if (item < 0) { mode = M_DONE; break; }
-					s = entry_of[item]; bend = (item + 1) * S < clen ? (item + 1) * S : clen;
+					const int ch = NCH == 1 ? 0 : (item >= NSUB ? NCH - 1 : 0), li = item - ch * NSUB;
+					lclen = CH_SEL(clen, ch); qp_l = qp[ch]; qn_l = qn[ch]; memo_l = memo[ch]; lhop_l = lhop[ch];
+					const int S_l = CH_SEL(S, ch);
+					s = entry_of[item]; bend = (li + 1) * S_l < lclen ? (li + 1) * S_l : lclen;
 				}
 				if (s >= bend) { exit_of[item] = (uint16_t)s; need_item = true; continue; }
-				const int m_ = memo_get(memo, lhop, s);
+				const int m_ = memo_get(memo_l, lhop_l, s);
 				if (m_) { s += m_; continue; }
-				const u32 nb = q_nbits32(qn, s);
+				const u32 nb = q_nbits32(qn_l, s);
 				const int L = prm.MinSeedLength < 32 ? prm.MinSeedLength : 32;
-				if (nb & 1u) { memo_one(memo, s); if (COUNT) mblk[s] = 0; s += 1; }
-				else if (!COUNT && (s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0)) { memo_one(memo, s); s += 1; }      // cannot reach MinSeedLength
+				if (nb & 1u) { memo_one(memo_l, s); if (COUNT) mblk[s] = 0; s += 1; }
+				else if (!COUNT && (s + prm.MinSeedLength > lclen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0)) { memo_one(memo_l, s); s += 1; }      // cannot reach MinSeedLength
 				else {
 					pos = s + 1; blk = 0; mode = M_FM;
 					// (the interval of the first base -- fm_init: three 5-way selects of 64-bit numbers -- only where the walk really starts
 					//  at the first base: next to the chunk end / an N, or behind a k-mer entry that says "absent")
 #ifdef SEED_EAGER_INIT      // (A/B switch: the interval of the first base computed for every search that is opened, as until late round 3)
-					ik = fm_init(di, q_code(qp, s));
+					ik = fm_init(di, q_code(qp_l, s));
 #endif
-					if (COUNT || !(di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0)) ik = fm_init(di, q_code(qp, s));
+					if (COUNT || !(di.kmer_k > 1 && s + di.kmer_k <= lclen && (nb & ((1u << di.kmer_k) - 1)) == 0)) ik = fm_init(di, q_code(qp_l, s));
 					else {
-						const u64 qb = q_bits64(qp, s);
+						const u64 qb = q_bits64(qp_l, s);
 						kid = (u32)(qb & ((1ull << (2 * di.kmer_k)) - 1)); mode = M_KMER;
 						// the line of the presence table that answers for s .. s+3, and the four positions inside it
 						pid = di.pres_k ? pres4_line(qb, di.pres_k) : 0;
@@ -404,34 +442,43 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 		// entry the speculation never visited (a random >= MinSeedLength match made the speculative walk
 		// jump over it) needs a real walk: such sub-ranges are collected, ASSUMED to keep their exit, walked
 		// in parallel (one lane each) in another pass of the loop above, and the chain is resolved again.
-		for (int it = j; it < nitems; it += SEED_WG) { const int X = exit_of[it]; jmp[0][it] = (uint16_t)(X >= clen ? 0xffff : X / S); }
-		if (j < NSUB / 32) onchain[j] = j == 0 ? 1u : 0u;
+		// (v = ch * NSUB + sub-range: the chains of the chunks of a pair are resolved together, one root each)
+#define V_LIVE(V) ((V) < NSUB ? (V) < nitems[0] : (NCH > 1 && (V) - NSUB < nitems[NCH - 1]))
+		for (int v = j; v < NV; v += SEED_WG) if (V_LIVE(v)) {
+			const int ch = v >= NSUB ? NCH - 1 : 0;
+			const int X = exit_of[v]; jmp[0][v] = (uint16_t)(X >= CH_SEL(clen, ch) ? 0xffff : ch * NSUB + X / CH_SEL(S, ch));
+		}
+		if (j < (NV + 31) / 32) onchain[j] = 0;
 		if (j == 0) s_npend = 0;
 		__syncthreads();
+		if (j == 0) { onchain[0] = 1u; if (NCH > 1 && nitems[NCH - 1] > 0) atomicOr(&onchain[NSUB >> 5], 1u << (NSUB & 31)); }
+		__syncthreads();
 		int cur = 0;
-		for (int span = 1; span < nitems; span <<= 1) {
-			for (int it = j; it < nitems; it += SEED_WG) {
-				const int t = jmp[cur][it];
+		const int nmax = NCH == 1 ? nitems[0] : (nitems[0] > nitems[NCH - 1] ? nitems[0] : nitems[NCH - 1]);
+		for (int span = 1; span < nmax; span <<= 1) {
+			for (int v = j; v < NV; v += SEED_WG) if (V_LIVE(v)) {
+				const int t = jmp[cur][v];
 				if (t != 0xffff) {
-					if ((onchain[it >> 5] >> (it & 31)) & 1u) atomicOr(&onchain[t >> 5], 1u << (t & 31));
-					jmp[cur ^ 1][it] = jmp[cur][t];
-				} else jmp[cur ^ 1][it] = 0xffff;
+					if ((onchain[v >> 5] >> (v & 31)) & 1u) atomicOr(&onchain[t >> 5], 1u << (t & 31));
+					jmp[cur ^ 1][v] = jmp[cur][t];
+				} else jmp[cur ^ 1][v] = 0xffff;
 			}
 			__syncthreads();
 			cur ^= 1;
 		}
-		for (int it = j; it < nitems; it += SEED_WG) entry_of[it] = (uint16_t)(it ? clen : 0);      // off-chain: nothing to mark
+		for (int v = j; v < NV; v += SEED_WG) if (V_LIVE(v)) { const int ch = v >= NSUB ? NCH - 1 : 0; entry_of[v] = (uint16_t)((v - ch * NSUB) ? CH_SEL(clen, ch) : 0); }      // off-chain: nothing to mark
 		__syncthreads();
-		for (int it = j; it < nitems; it += SEED_WG)
-			if ((onchain[it >> 5] >> (it & 31)) & 1u) { const int X = exit_of[it]; if (X < clen) entry_of[X / S] = (uint16_t)X; }
+		for (int v = j; v < NV; v += SEED_WG) if (V_LIVE(v))
+			if ((onchain[v >> 5] >> (v & 31)) & 1u) { const int ch = v >= NSUB ? NCH - 1 : 0; const int X = exit_of[v]; if (X < CH_SEL(clen, ch)) entry_of[ch * NSUB + X / CH_SEL(S, ch)] = (uint16_t)X; }
 		__syncthreads();
-		for (int it = j; it < nitems; it += SEED_WG) {
-			if (!((onchain[it >> 5] >> (it & 31)) & 1u)) continue;
-			const int e = entry_of[it];
-			const bool known = ((rewalked[it >> 5] >> (it & 31)) & 1u) ? e == walked_from[it] : memo_nib(memo, e) != 0;
+		for (int v = j; v < NV; v += SEED_WG) if (V_LIVE(v)) {
+			if (!((onchain[v >> 5] >> (v & 31)) & 1u)) continue;
+			const int ch = v >= NSUB ? NCH - 1 : 0;
+			const int e = entry_of[v];
+			const bool known = ((rewalked[v >> 5] >> (v & 31)) & 1u) ? e == walked_from[v] : memo_nib(memo[ch], e) != 0;
 			if (!known) {
 				const u32 idx = atomicAdd(&s_npend, 1u);
-				if (idx < SEED_WG) { pend_it[idx] = (uint16_t)it; walked_from[it] = (uint16_t)e; atomicOr(&rewalked[it >> 5], 1u << (it & 31)); }
+				if (idx < SEED_WG) { pend_it[idx] = (uint16_t)v; walked_from[v] = (uint16_t)e; atomicOr(&rewalked[v >> 5], 1u << (v & 31)); }
 			}
 		}
 		__syncthreads();
@@ -445,19 +492,21 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 	}
 	const bool heavy = s_abort != 0;
 	if (heavy) {
-		if (j == 0) {
+		if (j == 0) for (int ch = 0; ch < nch; ch++) {
 			const u32 hslot = (u32)atomicAdd((unsigned long long *)&cnt[CNT_HEAVY], 1ull);
-			heavy_list[hslot] = (u32)chunk;
-			s_ncand = 0; cand_cnt[chunk] = 0; lb_pub(&chunk_hits[chunk], 0); if (chunk == 0) lb_pub(&chunk_hits[n_chunks], 0);
+			heavy_list[hslot] = (u32)(chunk0 + ch);
+			s_ncand[ch] = 0; cand_cnt[chunk0 + ch] = 0; lb_pub(&chunk_hits[chunk0 + ch], 0); if (chunk0 + ch == 0) lb_pub(&chunk_hits[n_chunks], 0);
 		}
 		__syncthreads();
 	}
 	// mark the true path and count the Occ blocks the reference's walk reads
 	u32 alg_blocks = 0;
-	if (!heavy) for (int it = j; it < nitems; it += SEED_WG) {
-		const int bend = (it + 1) * S < clen ? (it + 1) * S : clen;
-		for (int s = entry_of[it]; s < bend;) { atomicOr(&bits[s >> 5], 1u << (s & 31)); if (COUNT) alg_blocks += mblk[s]; s += memo_get(memo, lhop, s); }
+	if (!heavy) for (int v = j; v < NV; v += SEED_WG) if (V_LIVE(v)) {
+		const int ch = v >= NSUB ? NCH - 1 : 0, li = v - ch * NSUB;
+		const int bend = (li + 1) * CH_SEL(S, ch) < CH_SEL(clen, ch) ? (li + 1) * CH_SEL(S, ch) : CH_SEL(clen, ch);
+		for (int s = entry_of[v]; s < bend;) { atomicOr(&bits[ch][s >> 5], 1u << (s & 31)); if (COUNT) alg_blocks += mblk[s]; s += memo_get(memo[ch], lhop[ch], s); }
 	}
+#undef V_LIVE
 	for (int o = 32; o; o >>= 1) { alg_blocks += __shfl_down(alg_blocks, o); all_blocks += __shfl_down(all_blocks, o); }
 	if ((j & 63) == 0) {
 		if (alg_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK], (unsigned long long)alg_blocks);
@@ -473,20 +522,25 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 #endif
 	if (j == 0) { atomicMax((unsigned long long *)&cnt[11], (unsigned long long)rounds); atomicMax((unsigned long long *)&cnt[14], t_round0); atomicMax((unsigned long long *)&cnt[15], t_resolve); atomicMax((unsigned long long *)&cnt[7], wall_clock64() - t_begin); }
 	__syncthreads();
-	if (!heavy) for (int p = j; p < PATH_WORDS; p += SEED_WG) onpath[(size_t)chunk * PATH_WORDS + p] = bits[p];
-	// how many located hits will this chunk contribute (so that the select kernel needs no global atomic)
+	// per chunk: the on-path bits, and how many located hits it will contribute (so that the select kernel needs no global atomic)
 	if (!heavy) {
-		const u32 nc = s_ncand < cand_cap ? s_ncand : cand_cap;
-		u32 h = 0;
-		for (u32 i = j; i < nc; i += SEED_WG) { const i32 p = cand_s[cbase + i] - (i32)c0; if ((bits[p >> 5] >> (p & 31)) & 1u) h += (u32)cand_freq[cbase + i]; }
-		for (int o = 32; o; o >>= 1) h += __shfl_down(h, o);
-		if ((j & 63) == 0 && h) atomicAdd(&s_hits, h);
+#pragma unroll
+		for (int ch = 0; ch < NCH; ch++) if (ch < nch) {
+			for (int p = j; p < PATH_WORDS; p += SEED_WG) onpath[(size_t)(chunk0 + ch) * PATH_WORDS + p] = bits[ch][p];
+			const u32 nc = s_ncand[ch] < cand_cap ? s_ncand[ch] : cand_cap;
+			u32 h = 0;
+			for (u32 i = j; i < nc; i += SEED_WG) { const i32 p = cand_s[cbase[ch] + i] - (i32)c0[ch]; if ((bits[ch][p >> 5] >> (p & 31)) & 1u) h += (u32)cand_freq[cbase[ch] + i]; }
+			for (int o = 32; o; o >>= 1) h += __shfl_down(h, o);
+			if ((j & 63) == 0 && h) atomicAdd(&s_hits[ch], h);
+		}
 		__syncthreads();
-		if (j == 0) {
-			cand_cnt[chunk] = nc; lb_pub(&chunk_hits[chunk], (i32)s_hits); if (chunk == 0) lb_pub(&chunk_hits[n_chunks], 0); atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand);
-			if (s_hits) atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)s_hits);      // the contig's total: all the host needs to go on
+		if (j == 0) for (int ch = 0; ch < nch; ch++) {
+			const u32 nc = s_ncand[ch] < cand_cap ? s_ncand[ch] : cand_cap;
+			cand_cnt[chunk0 + ch] = nc; lb_pub(&chunk_hits[chunk0 + ch], (i32)s_hits[ch]); if (chunk0 + ch == 0) lb_pub(&chunk_hits[n_chunks], 0); atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand[ch]);
+			if (s_hits[ch]) atomicAdd((unsigned long long *)&cnt[CNT_HITS], (unsigned long long)s_hits[ch]);      // the contig's total: all the host needs to go on
 		}
 	}
+#undef CH_SEL
 	// the workgroup that is through last puts the counters into pinned memory (the host waits for this kernel, nothing
 	// else) and leaves them at zero for the next contig
 	__shared__ int s_last;
@@ -494,7 +548,7 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 	__syncthreads();
 	if (j == 0) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (counters are device atomics; an agent-scope fence is an L2 write-back per workgroup here)
-		s_last = atomicAdd((unsigned long long *)&cnt[CNT_DONE], 1ull) == (unsigned long long)n_chunks - 1 ? 1 : 0;
+		s_last = atomicAdd((unsigned long long *)&cnt[CNT_DONE], (unsigned long long)nch) == (unsigned long long)n_chunks - (unsigned long long)nch ? 1 : 0;
 	}
 	__syncthreads();
 	if (s_last && j < 16) {
@@ -505,26 +559,26 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 }
 
 
-// The kernel: workgroups DRAW their chunks from a ticket counter (cnt[SEED_TICKET], never reset: the host passes the value it has
-// at launch, and a launch of g workgroups over n chunks leaves it n + g higher -- every workgroup's last draw is the one that fails).
-// With g = n every workgroup takes one chunk, as a plain grid would; with fewer the launch is PERSISTENT and holds at most g
-// workgroups' worth of LDS and wave slots whatever the contig's size (GSA_SEED_PERSIST = workgroups per CU; the kernel's own time does
-// not depend on how many chunks a CU works on between 5 and 12, DESIGN section 4 (vi), and what it leaves free the kernels of other
-// contexts can take).
+// The kernel: workgroups DRAW their chunk pairs from a ticket counter (cnt[SEED_TICKET], never reset: the host passes the value it has
+// at launch, and a launch of g workgroups over n units leaves it n + g higher -- every workgroup's last draw is the one that fails).
+// With g = n every workgroup takes one unit, as a plain grid would; with fewer the launch is PERSISTENT and holds at most g
+// workgroups' worth of LDS and wave slots whatever the contig's size (what it leaves free the kernels of other contexts can take).
 #define SEED_TICKET 16
+#define SEED_NCH 2              // chunks per wave of the production kernel (the accounting build: 1)
 template <bool COUNT, bool E16>
 __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
                                                       u32 budget, u32 *heavy_list, i32 *chunk_base, u64 tk_base, u32 n_chunks)
 {
+	constexpr int NCH = COUNT ? 1 : SEED_NCH;
 	__shared__ u32 s_tk;
 	for (;;) {
 		__syncthreads();
 		if (threadIdx.x == 0) s_tk = (u32)(atomicAdd((unsigned long long *)&cnt[SEED_TICKET], 1ull) - tk_base);
 		__syncthreads();
-		const u32 chunk = s_tk;
-		if (chunk >= n_chunks) return;
-		seed_chunk<COUNT, E16>(di, q, qlen, prm, cnt, cand_s, cand_len, cand_x0, cand_freq, cand_cap, cand_cnt, onpath, chunk_hits, hcnt, budget, heavy_list, chunk_base, (int)chunk, n_chunks);
+		const u32 unit = s_tk;
+		if ((u64)unit * NCH >= n_chunks) return;
+		seed_chunk<COUNT, E16, NCH>(di, q, qlen, prm, cnt, cand_s, cand_len, cand_x0, cand_freq, cand_cap, cand_cnt, onpath, chunk_hits, hcnt, budget, heavy_list, chunk_base, (int)(unit * NCH), n_chunks);
 	}
 }
 
@@ -1265,7 +1319,7 @@ int build_dense_sa(gsa_ctx *c, u64 n_sa)
 			if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 8ull << 30; }
 			const size_t esz = (c->di.seq_len < 0xFFFFFFF0ull && !c->force_wide) ? 16 : 32;
 			while (k > 2 && ((size_t)esz << (2 * k)) > fr / 4) k--;
-			if (const char *ek = getenv("GSA_KMER_K")) { const int kk = atoi(ek); if (kk >= 2 && kk <= 15 && ((size_t)esz << (2 * kk)) <= fr / 2) k = kk; }      // (tests: a long table on a short text)
+			if (c->opt.kmer_k) { const int kk = c->opt.kmer_k; if (kk >= 2 && kk <= 15 && ((size_t)esz << (2 * kk)) <= fr / 2) k = kk; }      // (GSA_CREATE_KMER_K; tests: a long table on a short text)
 		}
 		if (k >= 2) {
 			const size_t n = (size_t)1 << (2 * k);
@@ -1305,7 +1359,7 @@ static int prepare_pd_bitmap(gsa_ctx *c, i64 n_hits)
 {
 	const u64 pd_words = ((u64)c->pd_span >> 5) + 2;
 	// (a chunk range: the hit count of the whole contig is not known here; the bitmap is kept whenever MaxIndelSize allows it)
-	c->pd_path = (n_hits > 0 || c->split) && c->prm.MaxIndelSize >= 0 && c->prm.MaxIndelSize <= 31 && (c->split || pd_words <= 64ull * (u64)n_hits + 65536) && !getenv("GSA_NO_PDBITMAP");
+	c->pd_path = (n_hits > 0 || c->split) && c->prm.MaxIndelSize >= 0 && c->prm.MaxIndelSize <= 31 && (c->split || pd_words <= 64ull * (u64)n_hits + 65536) && c->opt.pd_bitmap;
 	c->seed_view_ready = false;
 	if (c->pd_path) {
 		const size_t cap0 = c->d_pdbm.cap;
@@ -1336,7 +1390,11 @@ struct SeedGate {
 int stage1_seed(gsa_ctx *c)
 {
 	// GSA_SEED_CUS=n (experiment): the seed-search kernels run on a stream that may only use n of the CUs, spread evenly
+#ifdef GSA_EXPERIMENTS
 	static const int seed_cus = [] { const char *e = getenv("GSA_SEED_CUS"); return e ? atoi(e) : 0; }();
+#else
+	const int seed_cus = 0;
+#endif
 	if (seed_cus > 0 && !c->stream_seed) {
 		hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device));
 		const int ncu = pr.multiProcessorCount;
@@ -1369,7 +1427,7 @@ int stage1_seed(gsa_ctx *c)
 	// GSA_SEED_MODE: "spec" (default) = the speculative kernel, and the right-to-left sweep (k_dense_sweep) for the chunks it gives up
 	// on and for every chunk under -sen; "sweep" = every chunk through the sweep; "search" = round 2's dense kernel (one search per
 	// start) in place of the sweep
-	static const int seed_mode = [] { const char *e = getenv("GSA_SEED_MODE"); return !e ? 1 : (!strcmp(e, "sweep") ? 0 : (!strcmp(e, "search") ? 2 : 1)); }();
+	const int seed_mode = c->opt.seed_mode;
 	// Which kernel for what (measured, profiles/r03_seed_modes.txt): the speculative kernel wins where matches are unique (the bench
 	// workload: 4.4 ms per 250 Mb against 19 for the sweep over every chunk); the sweep wins where repeats with thousands of copies make
 	// most chunks exceed the speculative budget (adversarial 250 Mb: 31 ms against 62 for round 2's path); one search per start wins
@@ -1380,7 +1438,11 @@ int stage1_seed(gsa_ctx *c)
 	const u32 budget = c->count_blocks ? 0u : c->seed_budget;
 	if (dense_all && ccap < GSA_CHUNK / 5 + 64) { ccap = GSA_CHUNK / 5 + 64; c->cand_cap_per_chunk = ccap; }      // one accepted start in five at most
 	u64 occ_all = 0;
+#ifdef GSA_EXPERIMENTS
 	static const int seed_slots = [] { const char *e = getenv("GSA_SEED_SLOTS"); return e ? atoi(e) : 0; }();
+#else
+	const int seed_slots = 0;
+#endif
 	SeedGate gate(c->device, (c->profiling || c->count_blocks) ? 0 : seed_slots);
 	for (int attempt = 0;; attempt++) {
 		if (attempt == 8) return gsa_fail(c, GSA_ERR_LIMIT, "seed buffers keep overflowing");
@@ -1398,10 +1460,15 @@ int stage1_seed(gsa_ctx *c)
 			//  0 = one workgroup per chunk.  Measured on a 250 Mb contig: the kernel alone 3.40 -> 3.20 ms at 10 or 16 per CU, 3.6 / 4.2 / 4.8 / 5.7 /
 			//  7.1 / 9.9 ms at 8 / 6 / 5 / 4 / 3 / 2 (the dispatcher fills CUs one after the other, so fewer workgroups mean fewer CUs, not thinner
 			//  ones); four contexts' throughput within +- 2 % of each other from 4 per CU upwards: tools/persist.sh)
-			static const int persist = [] { const char *e = getenv("GSA_SEED_PERSIST"); return e ? atoi(e) : 10; }();
-			unsigned grid = (unsigned)n_chunks;
-			if (persist > 0 && !c->count_blocks) { if (c->n_cus <= 0) { hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device)); c->n_cus = pr.multiProcessorCount; } const i64 cap = (i64)persist * c->n_cus; if (cap < n_chunks) grid = (unsigned)cap; }
-			const u64 tk_base = c->seed_ticket; c->seed_ticket += (u64)n_chunks + grid;
+#ifdef GSA_EXPERIMENTS
+			static const int persist = [] { const char *e = getenv("GSA_SEED_PERSIST"); return e ? atoi(e) : 10 / SEED_NCH; }();
+#else
+			const int persist = 10 / SEED_NCH;      // (what the LDS admits: ~30 KB per pair of chunks)
+#endif
+			const i64 n_units = c->count_blocks ? n_chunks : (n_chunks + SEED_NCH - 1) / SEED_NCH;      // (a wave of the production kernel owns SEED_NCH chunks)
+			unsigned grid = (unsigned)n_units;
+			if (persist > 0 && !c->count_blocks) { if (c->n_cus <= 0) { hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device)); c->n_cus = pr.multiProcessorCount; } const i64 cap = (i64)persist * c->n_cus; if (cap < n_units) grid = (unsigned)cap; }
+			const u64 tk_base = c->seed_ticket; c->seed_ticket += (u64)n_units + grid;
 			if (c->count_blocks) hipLaunchKernelGGL((k_seed_wg<true, false>), dim3(grid), dim3(SEED_WG), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
 			else if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3(grid), dim3(SEED_WG), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
 			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3(grid), dim3(SEED_WG), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
@@ -1420,12 +1487,20 @@ int stage1_seed(gsa_ctx *c)
 			if (!dev_ensure<uint16_t>(c, c->dn_memo, nd) || !dev_ensure<u32>(c, c->dn_lf, nd) || !dev_ensure<u64>(c, c->dn_x0, nd)) return GSA_ERR_NOMEM;
 			const u32 *list = dense_all ? (const u32 *)nullptr : c->d_heavy.as<u32>();
 #define GSA_DENSE_ARGS(SPAN) dim3((unsigned)(n_heavy * DENSE_WGS(SPAN))), dim3(DENSE_TPB), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt
-			static const u64 sweep_min = [] { const char *e = getenv("GSA_SWEEP_MIN"); return e ? (u64)atoll(e) : 1024ull; }();      // (experiments)
+#ifdef GSA_EXPERIMENTS
+			static const u64 sweep_min = [] { const char *e = getenv("GSA_SWEEP_MIN"); return e ? (u64)atoll(e) : 1024ull; }();
+#else
+			const u64 sweep_min = 1024;
+#endif
 			const bool use_sweep = seed_mode != 2 && !c->prm.bSensitive && (sweep_all || n_heavy >= sweep_min);
 			if (!dense_all && seed_mode == 1) c->seed_sweep_next = n_heavy * 5 > (u64)n_chunks * 2;      // (re-decided by every contig that goes through the speculative kernel)
 			else if (sweep_all && seed_mode == 1 && ++c->seed_sweep_run >= 8) { c->seed_sweep_next = false; c->seed_sweep_run = 0; }      // look again now and then
 			if (use_sweep) {
+#ifdef GSA_EXPERIMENTS
 				static const int seg_env = [] { const char *e = getenv("GSA_SWEEP_SEG"); return e ? atoi(e) : 0; }();
+#else
+				const int seg_env = 0;
+#endif
 				const int seg = seg_env > 0 ? seg_env : 40, wpc = (GSA_CHUNK + 256 * seg - 1) / (256 * seg);
 				if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_sweep<true>), dim3((unsigned)(n_heavy * wpc)), dim3(256), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
 				else hipLaunchKernelGGL((k_dense_sweep<false>), dim3((unsigned)(n_heavy * wpc)), dim3(256), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);

@@ -131,10 +131,24 @@ typedef struct {
 int  gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gsa_ctx **out);
 /* gsa_create with layout options.  GSA_CREATE_WIDE: the device layout of a text with >= 2^32 BWT rows (64-bit dense SA,
  * 32-byte k-mer entries) whatever the text length -- what a full human index (bwt_t::seq_len = 6.2 G, structure.h:28-38)
- * gets by itself; on a small index it lets the tests drive that code path.  gsa_create honours the environment variable
- * GSA_FORCE_WIDE=1 the same way. */
+ * gets by itself; on a small index it lets the tests drive that code path. */
 #define GSA_CREATE_WIDE 1u
+/* GSA_CREATE_KMER_K(k), 2 <= k <= 15: the jump table that replaces the first k steps of BWT_Search (bwt_search.cpp:152-165) is built for
+ * k-mers of this length if it fits (default: by text length and free device memory; tests: a long table on a short text). */
+#define GSA_CREATE_KMER_K(k) (((uint32_t)(k) & 15u) << 8)
 int  gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm, uint32_t flags, gsa_ctx **out);
+/* Tunables that are not aligner parameters (the library reads no environment variable).  A clone starts with its parent's values;
+ * gsa_align_many takes its policy from ctx[0].
+ *   "split_min"      bases; gsa_align_many seeds a contig of at least this length on several contexts when contexts would idle (20 000 000)
+ *   "bundle_contig"  bases; contigs up to this length share passes (16 000 000; 0 = never)      "bundle_cap"  bases per bundle, about (64 000 000)
+ *   "seed_budget"    wave-iterations a 10 000-bp chunk may take in the speculative seed kernel before the dense kernels redo it (256)
+ *   "dp_lane"        cells; gap alignments up to this size run one per lane (512; 0 = one per wavefront / quarter wavefront)
+ *   "seed_mode"      1 = speculative kernel + dense kernels for the chunks it gives up on (default), 0 = every chunk through the
+ *                    right-to-left sweep, 2 = one search per start instead of the sweep
+ *   "pd_bitmap"      0 = seed groups by the PosDiff sort (SeedGrouping as written, GSAlign.cpp:126-143) even where the bitmap scan applies
+ *   "dp_safe", "dp_fake_timeout"   test hooks: one striped DP job per launch; the next n contigs report a stripe hand-off time-out once
+ * Unknown names: GSA_ERR_ARG. */
+int  gsa_set_option(gsa_ctx *ctx, const char *name, int64_t value);
 /* A further context on the same GPU that borrows `parent`'s device-resident index (read-only) and owns everything else.
  * The reference runs -t N threads inside one contig (GSAlign.cpp:477-526); contigs are independent (all per-contig state
  * is cleared at GSAlign.cpp:490), so a host drives N contexts from N threads on N contigs instead and the GPU overlaps

@@ -32,6 +32,8 @@ DEFAULT_PARAMS = dict(slen=15, ind=25, clr=200, alen=200, idy=70, sen=0, one=0) 
 def build(ref: bool = True) -> None:
     """make the oracle (and, when /root/reference is present, oracle/_ref)."""
     subprocess.run(["make", "-C", HERE, "oracle"] + (["ref"] if ref else []), check=True, stdout=subprocess.DEVNULL)
+    if ref and os.path.exists(os.path.join(ROOT, "gsalign_amd", "lib", "libgsa_hip.so")):
+        subprocess.run(["make", "-C", HERE, "ref_hip"], check=True, stdout=subprocess.DEVNULL)      # INTEGRATION.md section 2, compiled (needs the product library)
 
 
 def have_ref() -> bool:

@@ -101,3 +101,19 @@ def test_cli_config3_and_repeat_stress_vs_live_reference(oracle_built):
     from conftest import ROOT
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "big_cli_check.py"), "c3,repeat,adversarial"], capture_output=True, text=True, timeout=900, env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
     assert r.returncode == 0 and r.stdout.count("IDENTICAL") == 6, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("name,extra,maf,vcf", [("cx", [], "cx.maf", "cx.vcf"), ("cx", ["-sen"], "cx_sen.maf", "cx_sen.vcf"), ("cx", ["-fmt", "2", "-idy", "70"], "cx_fmt2.aln", "cx_fmt2.vcf"),
+                                                ("cx", ["-one", "-ind", "40", "-clr", "300", "-alen", "1000", "-unique"], "cx_combo.maf", "cx_combo.vcf"), ("small", [], "small.maf", "small.vcf")])
+def test_reference_program_with_the_drop_in(oracle_built, golden_dir, tmp_path, name, extra, maf, vcf):
+    """INTEGRATION.md section 2 as a compiled artefact (oracle/_ref/GSAlign_ref_hip, oracle/Makefile `ref_hip`): the REFERENCE'S OWN program
+    -- its main(), argument parsing, FASTA and index loaders, MAF / ALN / VCF emitters, built from /root/reference in place -- with the
+    eight pthread stages of GenomeComparison() (GSAlign.cpp:483-540) replaced by one gsa_align_contig call per query sequence
+    (oracle/ref_hip_dropin.cpp).  Its output bytes == the unmodified reference's (the committed goldens)."""
+    exe = os.path.join(os.path.dirname(oracle_built.REF_GSALIGN), "GSAlign_ref_hip")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/GSAlign_ref_hip not built (no /root/reference at build time)")
+    subprocess.run([exe, "-i", name, "-q", f"{name}.qry.fa", "-o", str(tmp_path / "out"), "-t", "1", *extra], cwd=golden_dir, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    kind = maf.rsplit(".", 1)[1]
+    assert open(tmp_path / f"out.{kind}", "rb").read() == open(os.path.join(golden_dir, maf), "rb").read()
+    assert open(tmp_path / "out.vcf", "rb").read() == open(os.path.join(golden_dir, vcf), "rb").read()
