@@ -100,9 +100,10 @@ def build_library() -> None:
 
 
 def load_library() -> C.CDLL:
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
-    lib = C.CDLL(LIB_PATH)
+    path = os.environ.get("GSA_LIB_PATH") or LIB_PATH          # (GSA_LIB_PATH: an experiment variant of the library, tools only)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)")
+    lib = C.CDLL(path)
     lib.gsa_create.argtypes = [C.c_int, C.POINTER(IndexView), C.POINTER(Params), C.POINTER(C.c_void_p)]
     lib.gsa_create_opts.argtypes = [C.c_int, C.POINTER(IndexView), C.POINTER(Params), C.c_uint32, C.POINTER(C.c_void_p)]
     lib.gsa_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]

@@ -196,16 +196,19 @@ __device__ __forceinline__ void stage32(const uint8_t *src, int p0, int clen, u3
 	}
 }
 
-// NCH chunks per wave (round 4).  What the wave-iterations of ONE chunk hold on repeat-bearing text: 68 iterations with 14.6 of 64 lanes
-// active (-DSEED_STATS) -- the body is over after ~25 iterations, the rest is a handful of lanes deep in the Occ walks of repeat copies --
-// and every iteration costs the wave its ~650 instructions whatever the number of lanes in it: with 2.5 waves per SIMD issuing in 40 % of
-// their cycles each, the SIMDs' issue ports were the kernel's limit (r03_sq_human.txt), not the memory system (8.4 G requests/s against
-// the 19 - 48 G/s tools/rand_probe.hip reaches).  So a wave now owns TWO neighbouring chunks: 2 x 96 sub-ranges in one queue, the tails of
-// the two chunks overlap in time, and the pair takes ~1.2x the iterations of one chunk -- 0.6x the instructions per chunk.  Everything a
-// chunk owns in LDS exists per chunk ([NCH][...]; ~30 KB per pair: five pairs per CU = the same ten chunks in flight); an item is a
-// (chunk, sub-range) pair, v = ch * NSUB + sub-range; the chains of the two chunks never touch (a match stops at its chunk's end and
-// IdentifyLocalMEM restarts at every chunk, GSAlign.cpp:61-94), so the resolver works on both at once: two roots, exits past a chunk's
-// end terminate.  The accounting build (COUNT) keeps one chunk per wave (its per-start Occ-block array is 20 KB per chunk).
+// NCH chunks per wave (round 4; the round-3 verdict's "fill the lanes": a wave that owns TWO chunk states).  What the wave-iterations of
+// ONE chunk hold on repeat-bearing text: 75 iterations with 14.7 of 64 lanes active (-DSEED_STATS) -- the body is over after ~25
+// iterations, the rest is a handful of lanes deep in the Occ walks of repeat copies.  With NCH = 2 a wave owns two neighbouring chunks:
+// 2 x 96 sub-ranges in one queue, the tails of the two chunks overlap in time.  Everything a chunk owns in LDS exists per chunk
+// ([NCH][...]; 30 KB per pair: five pairs per CU = the same ten chunks in flight); an item is a (chunk, sub-range) pair, v = ch * NSUB +
+// sub-range; the chains of the two chunks never touch (a match stops at its chunk's end and IdentifyLocalMEM restarts at every chunk,
+// GSAlign.cpp:61-94), so the resolver works on both at once: two roots, exits past a chunk's end terminate.  Parity green (stage-1
+// goldens, both layouts, 48 cases).  MEASURED (profiles/r04_seed_nch.txt, 250 Mb bench workload, kernel alone): wave-iterations 1.87 M ->
+// 1.23 M (-34 %), active lanes 14.7 -> 21.1 -- and the kernel 3.02 -> 3.79 ms, four contexts 30.3 -> 28.2 Gbp/s.  A wave-iteration takes
+// ~4 us on the full chip whatever the number of waves per SIMD (1.25 or 2.5): it is a dependent random read over 20 GB of tables (a TLB
+// walk each), not instruction issue, so what counts is requests in flight = waves x active lanes, and half the waves with 1.4x the lanes
+// is fewer.  PRODUCTION STAYS AT NCH = 1 (SEED_NCH); the pair form is kept for the day the LDS per chunk halves (then ten PAIRS fit a CU).
+// The accounting build (COUNT) keeps one chunk per wave in any case (its per-start Occ-block array is 20 KB per chunk).
 template <bool COUNT, bool E16, int NCH>
 __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__restrict__ q, i32 qlen, const Params &prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
@@ -564,7 +567,9 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 // With g = n every workgroup takes one unit, as a plain grid would; with fewer the launch is PERSISTENT and holds at most g
 // workgroups' worth of LDS and wave slots whatever the contig's size (what it leaves free the kernels of other contexts can take).
 #define SEED_TICKET 16
-#define SEED_NCH 2              // chunks per wave of the production kernel (the accounting build: 1)
+#ifndef SEED_NCH
+#define SEED_NCH 1              // chunks per wave of the production kernel (2: measured slower, see seed_chunk; the accounting build: always 1)
+#endif
 template <bool COUNT, bool E16>
 __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
