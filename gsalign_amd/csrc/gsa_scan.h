@@ -12,15 +12,19 @@
 // ever waits for tiles that are already running.
 #ifndef GSA_SCAN_H
 #define GSA_SCAN_H
+#include <algorithm>
 #include "gsa_ctx.h"
 
 #define LB_TPB 256
+#ifndef LB_GRID_PER_CU
+#define LB_GRID_PER_CU 2    // workgroups per CU of a fused pass (persistent: tiles are drawn from the ticket counter)
+#endif
 #define LB_ITEMS 4          // elements per thread (default; passes with heavy per-element work use 1)
 
 struct LbArgs {
 	unsigned long long *status[2];   // tile status words, one array per scanned component
 	u32 *ticket;                     // never reset: tile = ticket - base
-	u32 base, epoch;
+	u32 base, epoch; i32 n_tiles;
 	i32 *err;                        // set when a spin runs into its bound (a bug, not a state)
 	u32 *finished;                   // tiles that are through (only Ops with a finish() hook count; the last one resets it)
 };
@@ -75,55 +79,71 @@ template <int NV, class Op, int ITEMS>
 __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 {
 	constexpr int LB_TILE = LB_TPB * ITEMS;
-	__shared__ i32 s_tile, s_bcast[2], s_wsum[2][LB_TPB / 64];
+	__shared__ i32 s_tile, s_bcast[2], s_wsum[NV][ITEMS][LB_TPB / 64];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	// PERSISTENT since round 4: the grid is at most LB_GRID_PER_CU workgroups per CU and every workgroup draws tile after tile.  A full
+	// grid put ~2000 tiles on the chip at once, none of which had its inclusive prefix yet, so a tile walked back through up to 30 windows
+	// of 64 aggregates -- a dependent agent-scope load each -- before it met one (58 us mean tile lifetime in OpDpJobs: r03_sq_human.txt,
+	// 2.2 x 10^9 wave-cycles per contig, more than the striped DP).  With a few hundred tiles in flight, all of them consecutive, the
+	// predecessors of a tile are mostly through and the first window answers.
+	for (;;) {
+	__syncthreads();
 	if (tid == 0) s_tile = (i32)(atomicAdd(lb.ticket, 1u) - lb.base);
 	__syncthreads();
 	const int tile = s_tile;
-	const i64 i0 = (i64)tile * LB_TILE + (i64)tid * ITEMS;
-	i32 v[NV][ITEMS], tsum[NV];
-#pragma unroll
-	for (int c = 0; c < NV; c++) tsum[c] = 0;
+	if (tile >= lb.n_tiles) break;
+	// STRIPED since round 4: item k of thread t is element tile * LB_TILE + k * LB_TPB + t, so the 64 lanes of a wave read 64 consecutive
+	// elements of every array an Op touches (with consecutive items per thread a wave's load touched 64 lines at 16 items per thread and ran
+	// at the address unit's pace: chain 2.0 -> 2.6 ms when tried).  The tile is then ITEMS rows of LB_TPB elements: a row is scanned across
+	// the workgroup (wave scan + wave totals through LDS, one barrier for all rows), rows follow each other.
+	const i64 i0 = (i64)tile * LB_TILE + tid;
+	i32 v[NV][ITEMS], inc[NV][ITEMS];
 #pragma unroll
 	for (int k = 0; k < ITEMS; k++) {
-		const i64 i = i0 + k;
+		const i64 i = i0 + (i64)k * LB_TPB;
 #pragma unroll
-		for (int c = 0; c < NV; c++) { v[c][k] = i < n ? op.value(i, c) : 0; tsum[c] += v[c][k]; }
+		for (int c = 0; c < NV; c++) v[c][k] = i < n ? op.value(i, c) : 0;
 	}
-	// thread totals -> exclusive offsets inside the tile
-	i32 toff[NV], agg[NV];
 #pragma unroll
-	for (int c = 0; c < NV; c++) {
-		i32 inc = tsum[c];
-		for (int o = 1; o < 64; o <<= 1) { const i32 t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-		if (lane == 63) s_wsum[c][wv] = inc;
-		toff[c] = inc - tsum[c];
-	}
+	for (int c = 0; c < NV; c++)
+#pragma unroll
+		for (int k = 0; k < ITEMS; k++) {
+			i32 x = v[c][k];
+			for (int o = 1; o < 64; o <<= 1) { const i32 t = __shfl_up(x, o); if (lane >= o) x += t; }
+			inc[c][k] = x;
+			if (lane == 63) s_wsum[c][k][wv] = x;
+		}
 	__syncthreads();
+	i32 agg[NV];
 #pragma unroll
 	for (int c = 0; c < NV; c++) {
-		i32 wo = 0, tot = 0;
+		i32 run = 0;                      // elements of the rows in front of row k
 #pragma unroll
-		for (int w = 0; w < LB_TPB / 64; w++) { const i32 s = s_wsum[c][w]; if (w < wv) wo += s; tot += s; }
-		toff[c] += wo; agg[c] = tot;
+		for (int k = 0; k < ITEMS; k++) {
+			i32 wo = 0, tot = 0;
+#pragma unroll
+			for (int w = 0; w < LB_TPB / 64; w++) { const i32 sw = s_wsum[c][k][w]; if (w < wv) wo += sw; tot += sw; }
+			inc[c][k] += run + wo - v[c][k];      // exclusive prefix of my element inside the tile
+			run += tot;
+		}
+		agg[c] = run;
 	}
 	i32 pre[NV];
 #pragma unroll
 	for (int c = 0; c < NV; c++) pre[c] = lb_tile_prefix(lb, c, tile, agg[c], s_bcast);
-#pragma unroll
-	for (int c = 0; c < NV; c++) toff[c] += pre[c];
 	i32 vv[NV], ee[NV];
 #pragma unroll
 	for (int k = 0; k < ITEMS; k++) {
-		const i64 i = i0 + k;
+		const i64 i = i0 + (i64)k * LB_TPB;
 #pragma unroll
-		for (int c = 0; c < NV; c++) { vv[c] = v[c][k]; ee[c] = toff[c]; toff[c] += v[c][k]; }
+		for (int c = 0; c < NV; c++) { vv[c] = v[c][k]; ee[c] = pre[c] + inc[c][k]; }
 		if (i < n) {
 			op.emit(i, vv, ee);
 			if (i == n - 1) { i32 tt[NV]; for (int c = 0; c < NV; c++) tt[c] = ee[c] + vv[c]; op.done(tt); }
 		}
 	}
 	if (n == 0 && tile == 0 && tid == 0) { i32 tt[NV]; for (int c = 0; c < NV; c++) tt[c] = 0; op.done(tt); }
+	}
 	// Ops with a finish(tid) hook: the workgroup that is through LAST runs it (all 256 threads) -- everything every tile
 	// emitted is visible to it.  Used to put counts and list heads into pinned memory for the host without another launch.
 	if constexpr (lb_has_finish<Op>::value) {
@@ -166,9 +186,12 @@ static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op, hipStream_t stream 
 	LbArgs lb;
 	lb.status[0] = c->d_lb_status[0].as<unsigned long long>(); lb.status[1] = c->d_lb_status[1].as<unsigned long long>();
 	lb.ticket = c->d_mail.as<u32>() + M_TICKET; lb.base = c->lb_base; lb.epoch = c->lb_epoch; lb.err = c->d_mail.as<i32>() + M_LBERR; lb.finished = c->d_mail.as<u32>() + M_LBDONE;
-	hipLaunchKernelGGL((k_lb_pass<NV, Op, ITEMS>), dim3((unsigned)tiles), dim3(LB_TPB), 0, stream, n, op, lb);
+	lb.n_tiles = (i32)tiles;
+	if (c->n_cus <= 0) { hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device)); c->n_cus = pr.multiProcessorCount; }
+	const size_t grid = std::min<size_t>(tiles, (size_t)LB_GRID_PER_CU * (size_t)c->n_cus);
+	hipLaunchKernelGGL((k_lb_pass<NV, Op, ITEMS>), dim3((unsigned)grid), dim3(LB_TPB), 0, stream, n, op, lb);
 	GSA_CHECK(c, hipGetLastError());
-	c->lb_base += (u32)tiles;
+	c->lb_base += (u32)(tiles + grid);      // (every workgroup's last draw is the one that fails)
 	return GSA_OK;
 }
 
