@@ -648,3 +648,37 @@ def test_config5_full_human_all_contigs():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "human_scale_probe.py")], capture_output=True, text=True, timeout=1000)
     assert r.returncode == 0 and "HUMAN SCALE PROBE OK" in r.stdout and "all 24 contigs checked" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     print(r.stdout)
+
+
+def test_align_many_over_two_devices(oracle_built, tmp_path):
+    """The day a box has two GPUs: gsa_align_many with one context on each (gsa_create per device: the index replicated) --
+    contigs dealt over both, and ONE long contig seeded by chunk range on both with the hits moved peer to peer (hipMemcpyPeerAsync,
+    gsa_import_hits) -- against the oracle.  Skipped on one-GPU boxes (every box this round): nothing here has run on two devices yet."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (hipGetDeviceCount() >= 2)")
+    refs, qrys = synth.make_pair_fast(2400000, 4, 0.02, seed=91)
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx)
+    want = []
+    for name, seq in qrys:
+        o.set_query(seq); o.run_to(8); want.append(o.blocks(with_aln=True))
+    o.close()
+    ctxs = [capi.Aligner(idx, device=0), capi.Aligner(idx, device=1)]
+    ctxs[0].set_option("split_min", 200000)
+    got = {}
+
+    def on_result(ci, res):
+        got[ci] = capi.result_as_dump(ctxs[0]._result(res), with_aln=True)
+        return 0
+    capi.align_many(ctxs, [q for _, q in qrys], on_result)                       # four contigs on two devices
+    assert sorted(got) == list(range(len(qrys)))
+    for ci, d in got.items():
+        for key, v in want[ci].items():
+            assert np.array_equal(d[key], v), (ci, key)
+    got.clear()
+    capi.align_many(ctxs, [qrys[0][1]], on_result)                               # one contig: seeded on both, hits peer to peer
+    for key, v in want[0].items():
+        assert np.array_equal(got[0][key], v), ("split", key)
+    for g in ctxs:
+        g.close()

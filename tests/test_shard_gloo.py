@@ -83,6 +83,24 @@ if rank == 0:
     for ci, c in enumerate(contigs):
         w = g.align(ci, c)
         for k in w: assert np.array_equal(allr[ci][k], w[k]), (ci, k)
+# (1b) the bench's gather (round 4): finished contigs staged as one tensor each (shard.ResultStage), point-to-point to rank 0 in exact sizes
+stage = shard.ResultStage(torch.device("cpu"))
+assign = shard.assign_contigs([c.size for c in contigs], world)
+for ci in assign[rank]:
+    w = g.align(ci, contigs[ci]); R = np.zeros(3 + ci, capi.REC_DT); R["w0"] = np.arange(3 + ci) * 7 + ci; R["w3"] = 11 * ci
+    B, a1, a2 = np.ascontiguousarray(w["blocks"]), w["aln1"], w["aln2"]
+    if rank != 0:
+        stage.put(7, ci, [(B.ctypes.data, B.nbytes), (R.ctypes.data, R.nbytes), (a1.ctypes.data, a1.nbytes), (a2.ctypes.data, a2.nbytes)])
+got, _ = shard.gather_staged(stage.take(7), max(len(x) for x in assign), device=torch.device("cpu"))
+if rank == 0:
+    seen = dict(shard.parse_staged(b, capi.BLOCK_DT, capi.REC_DT) for b in got)
+    assert sorted(seen) == sorted(ci for r in range(1, world) for ci in assign[r])
+    for ci, r in seen.items():
+        w = g.align(ci, contigs[ci])
+        R = np.zeros(3 + ci, capi.REC_DT); R["w0"] = np.arange(3 + ci) * 7 + ci; R["w3"] = 11 * ci
+        assert np.array_equal(r["blocks"], w["blocks"]) and np.array_equal(r["recs"], R) and np.array_equal(r["aln1"], w["aln1"]) and np.array_equal(r["aln2"], w["aln2"]), ci
+else:
+    assert got == []
 # (2) one contig seeded by chunk range on every rank, hits sent to the owner
 n_chunks = 23
 rngs = shard.split_chunks(n_chunks, world)

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 
 template <int BYTES>
 __global__ void __launch_bounds__(256) k_rand(const uint4 *__restrict__ tab, uint64_t lines, int rounds, int chain, uint32_t *sink)
@@ -17,10 +18,11 @@ __global__ void __launch_bounds__(256) k_rand(const uint4 *__restrict__ tab, uin
 		uint64_t a = x;
 		for (int c = 0; c < chain; c++) {
 			a ^= a >> 29; a *= 0xBF58476D1CE4E5B9ull; a ^= a >> 32;
-			const uint4 *p = tab + (a % lines) * 4;           // a 64-byte line
+			const uint4 *p = BYTES > 64 ? tab + (a % (lines / 2)) * 8 : tab + (a % lines) * 4;           // a 64-byte line (128-byte aligned pair for BYTES = 128)
 			uint4 v = p[0];
 			if (BYTES >= 32) { const uint4 w = p[1]; v.x ^= w.x; v.y ^= w.y; }
 			if (BYTES >= 64) { const uint4 w = p[2], z = p[3]; v.x ^= w.x ^ z.x; v.y ^= w.y ^ z.y; }
+			if (BYTES >= 128) { const uint4 w = p[4], z = p[5], w2 = p[6], z2 = p[7]; v.x ^= w.x ^ z.x ^ w2.x ^ z2.x; v.y ^= w.y ^ z.y ^ w2.y ^ z2.y; }
 			acc += v.x ^ v.y ^ v.z ^ v.w;
 			a += v.x;                                         // (the table holds zeros: the dependency is real, the address is not disturbed)
 		}
@@ -47,6 +49,22 @@ static void run(const uint4 *tab, uint64_t bytes, int wg, int rounds, int chain,
 int main(int argc, char **argv)
 {
 	uint32_t *sink; hipMalloc(&sink, 64);
+	if (argc > 1 && !strcmp(argv[1], "cal")) {
+		// calibration of the TCC_EA0_RDREQ counters (round 4): reads of KNOWN number and width on a table far beyond the caches, one launch
+		// per width, so that `rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum` (tools/pmc_cal.sh) tells how many requests, of which
+		// kind, a 16 / 32 / 64 / 128-byte random read costs: wg x 256 lanes x rounds reads per launch
+		const uint64_t bytes = 18ull << 30; uint4 *tab = nullptr;
+		if (hipMalloc(&tab, bytes) != hipSuccess) { printf("no memory\n"); return 1; }
+		hipMemset(tab, 0, bytes); hipDeviceSynchronize();
+		const int wg = 4096, rounds = 16;
+		printf("calibration: %llu reads per launch\n", (unsigned long long)wg * 256 * rounds);
+		hipLaunchKernelGGL(k_rand<16>, dim3(wg), dim3(256), 0, 0, tab, bytes / 64, rounds, 1, sink);
+		hipLaunchKernelGGL(k_rand<32>, dim3(wg), dim3(256), 0, 0, tab, bytes / 64, rounds, 1, sink);
+		hipLaunchKernelGGL(k_rand<64>, dim3(wg), dim3(256), 0, 0, tab, bytes / 64, rounds, 1, sink);
+		hipLaunchKernelGGL(k_rand<128>, dim3(wg), dim3(256), 0, 0, tab, bytes / 64, rounds, 1, sink);
+		hipDeviceSynchronize();
+		return 0;
+	}
 	const uint64_t sizes[] = {64ull << 20, 512ull << 20, 4ull << 30, 17ull << 30, 48ull << 30};      // (argv[1] = one size in MB)
 	for (uint64_t bytes : sizes) {
 		if (argc > 1 && bytes != ((uint64_t)atoll(argv[1]) << 20)) continue;
