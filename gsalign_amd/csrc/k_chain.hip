@@ -60,14 +60,56 @@ __device__ __forceinline__ u32 pd_starts(const u32 *__restrict__ bm, i64 w, int 
 	if (cov < max_indel) sm |= sm << (max_indel - cov);
 	return (u32)((m & ~sm) >> 32);
 }
-struct OpPdScan {
-	const u32 *bm; int max_indel; i32 *gpre, *mail; i64 nw;
-	__device__ i32 value(i64 w, int) const { return __popc(pd_starts(bm, w, max_indel)); }
-	__device__ void emit(i64 w, const i32 *, const i32 *ex) const { gpre[w] = ex[0]; }
+// Round 4: the scan runs over the COARSE bitmap (one bit per block of 32 bitmap words = 1024 PosDiff values, set together with the bitmap
+// by k_seed_select) and only looks into the blocks that hold a hit: against a human reference the bitmap is 776 MB per contig of which a few
+// hundred thousand cache lines are occupied -- the word-by-word scan read all of it and wrote as much again (group starts below each WORD),
+// which is why such contigs used to fall back to the PosDiff sort.  gpre[blk] = group starts below block blk, written for occupied blocks.
+// group starts in the 32 words of block blk as 32 counts: the block is ONE 128-byte line, fetched with eight 16-byte loads at once (a loop
+// of pd_starts() over the words is 64 dependent-looking loads: 4.2 instead of 1.9 ms of chaining on a 250 Mb contig when first tried)
+__device__ __forceinline__ u32 pd_starts_pair(u32 cur, u32 prev, int max_indel)
+{
+	const u64 m = ((u64)cur << 32) | prev;
+	if (max_indel <= 0) return cur;
+	u64 sm = m << 1; int cov = 1;
+	while (2 * cov <= max_indel) { sm |= sm << cov; cov *= 2; }
+	if (cov < max_indel) sm |= sm << (max_indel - cov);
+	return (u32)((m & ~sm) >> 32);
+}
+__device__ __forceinline__ void pd_block_load(const u32 *__restrict__ bm, i64 blk, u32 (&w)[33])
+{
+	const uint4 *p = (const uint4 *)(bm + (blk << 5));
+	w[0] = blk > 0 ? bm[(blk << 5) - 1] : 0u;
+#pragma unroll
+	for (int k = 0; k < 8; k++) { const uint4 q = p[k]; w[1 + 4 * k] = q.x; w[2 + 4 * k] = q.y; w[3 + 4 * k] = q.z; w[4 + 4 * k] = q.w; }
+}
+struct OpPdScan {      // over the BLOCKS (32 bitmap words each); a block without a hit costs a look at its coarse bit
+	const u32 *bm, *cb; int max_indel; i32 *gpre; uint16_t *gword; i32 *mail; i64 nw;
+	__device__ i32 value(i64 blk, int) const
+	{
+		if (!((cb[blk >> 5] >> (blk & 31)) & 1u)) return 0;
+		u32 w[33]; pd_block_load(bm, blk, w);
+		i32 n = 0;
+#pragma unroll
+		for (int k = 0; k < 32; k++) n += __popc(pd_starts_pair(w[k + 1], w[k], max_indel));
+		return n;
+	}
+	__device__ void emit(i64 blk, const i32 *, const i32 *ex) const
+	{
+		if (!((cb[blk >> 5] >> (blk & 31)) & 1u)) return;
+		u32 w[33]; pd_block_load(bm, blk, w);
+		gpre[blk] = ex[0];
+		// group starts below each word of the block, inside the block (what a hit in that word adds to gpre[blk]): 32 x u16 = one 64-byte row
+		u32 in = 0, pk[16];
+#pragma unroll
+		for (int k = 0; k < 32; k++) { if (k & 1) pk[k >> 1] |= in << 16; else pk[k >> 1] = in; in += (u32)__popc(pd_starts_pair(w[k + 1], w[k], max_indel)); }
+		uint4 *o = (uint4 *)(gword + (blk << 5));
+#pragma unroll
+		for (int k = 0; k < 4; k++) o[k] = make_uint4(pk[4 * k], pk[4 * k + 1], pk[4 * k + 2], pk[4 * k + 3]);
+	}
 	__device__ void done(const i32 *t) const { mail[M_NG] = t[0]; }
 };
 // key = (group, qPos, rank among the hits of the same start); val = index of the hit
-__global__ void k_pd_keys(i64 n, const u64 *__restrict__ hkey, const u32 *__restrict__ hval, const u32 *__restrict__ bm, const i32 *__restrict__ gpre, int max_indel, int qbits,
+__global__ void k_pd_keys(i64 n, const u64 *__restrict__ hkey, const u32 *__restrict__ hval, const u32 *__restrict__ bm, const i32 *__restrict__ gpre, const uint16_t *__restrict__ gword, int max_indel, int qbits,
                           u64 *key, u32 *val)
 {
 	GID(n);
@@ -75,7 +117,7 @@ __global__ void k_pd_keys(i64 n, const u64 *__restrict__ hkey, const u32 *__rest
 	const i64 pd = (i64)(k >> qbits); const u32 q = (u32)(k & ((1ull << qbits) - 1));
 	const i64 w = pd >> 5; const int b = (int)(pd & 31);
 	const u32 st = pd_starts(bm, w, max_indel);
-	const i32 gid = gpre[w] + __popc(st & (b == 31 ? ~0u : ((2u << b) - 1))) - 1;
+	const i32 gid = gpre[w >> 5] + (i32)gword[w] + __popc(st & (b == 31 ? ~0u : ((2u << b) - 1))) - 1;      // (starts below my block | in the words of my block below mine | in my word up to my bit)
 	key[i] = ((u64)(u32)gid << (qbits + 7)) | ((u64)q << 7) | (hval[i] >> 16);
 	val[i] = (u32)i;
 }
@@ -87,7 +129,7 @@ __global__ void k_pd_heads(i64 n, const u64 *__restrict__ key, int gshift, i32 *
 	if (i == n - 1) g_beg[g + 1] = (i32)n;
 }
 __global__ void k_pd_gather(i64 n, const u64 *__restrict__ key, const u32 *__restrict__ perm, const u64 *__restrict__ hkey, const u32 *__restrict__ hval, int gshift, int qbits, Bundle bnd,
-                            const i32 *__restrict__ g_beg, i32 *a_q, i32 *a_len, i64 *a_r, i32 *a_gb, i32 *a_ge, u32 *bm)
+                            const i32 *__restrict__ g_beg, i32 *a_q, i32 *a_len, i64 *a_r, i32 *a_gb, i32 *a_ge, u32 *bm, u32 *cb)
 {
 	GID(n);
 	const u32 src = perm[i];
@@ -96,7 +138,7 @@ __global__ void k_pd_gather(i64 n, const u64 *__restrict__ key, const u32 *__res
 	i64 pd = pdk - bnd.lmax;                        // rPos - q  (a bundle: q is the position in the concatenation, see Bundle)
 	if (bnd.n) { const i32 ci = bnd.chunk_contig[q / GSA_CHUNK]; pd -= (i64)bnd.off[ci] + (i64)ci * bnd.pds; }
 	a_q[i] = q; a_len[i] = (i32)(hval[src] & 0xffffu); a_r[i] = pd + q;
-	bm[pdk >> 5] = 0;                               // (the bitmap is done with: wiped for the next contig by the hits that set it)
+	bm[pdk >> 5] = 0; cb[pdk >> 15] = 0;            // (the bitmaps are done with: wiped for the next contig by the hits that set them)
 	const i32 g = (i32)(key[i] >> gshift);
 	a_gb[i] = g_beg[g]; a_ge[i] = g_beg[g + 1];
 }
@@ -629,14 +671,15 @@ int stage2_chain(gsa_ctx *c)
 	if (c->pd_path && c->qbits + 7 + gbits <= 64) {
 		// group ids from the PosDiff bitmap, then ONE sort by (group, qPos, rank) straight from the located hits
 		const i64 nw = c->pd_words;
-		ENS(i32, d_gpre, nw + 2); ENS(u64, d_key_c, n); ENS(u32, d_val_c, n); ENS(u64, d_key_b, n); ENS(u32, d_val_b, n); ENS(i32, g_beg, n + 2);
+		const i64 nblk = (nw + 31) >> 5;      // blocks of 32 bitmap words (one coarse bit each)
+		ENS(i32, d_gpre, ((nw + 31) >> 5) + 2); ENS(uint16_t, d_gword, nw + 64); ENS(u64, d_key_c, n); ENS(u32, d_val_c, n); ENS(u64, d_key_b, n); ENS(u32, d_val_b, n); ENS(i32, g_beg, n + 2);
 		i32 *mail_ = c->d_mail.as<i32>();
-		{ OpPdScan op = { c->d_pdbm.as<u32>(), c->prm.MaxIndelSize, c->d_gpre.as<i32>(), mail_, nw }; RC((lb_launch<1, 16>(c, nw, op))); }      // (16 bitmap words per thread: a popcount each -- the pass is the 94 MB read of a 250 Mb contig's bitmap, not 23 000 tiles of look-back)
-		LAUNCH(k_pd_keys, n, n, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->d_pdbm.as<u32>(), c->d_gpre.as<i32>(), c->prm.MaxIndelSize, c->qbits, c->d_key_c.as<u64>(), c->d_val_c.as<u32>());
+		{ OpPdScan op = { c->d_pdbm.as<u32>(), c->d_pdcb.as<u32>(), c->prm.MaxIndelSize, c->d_gpre.as<i32>(), c->d_gword.as<uint16_t>(), mail_, nw }; RC((lb_launch<1, 4>(c, nblk, op))); }      // (16 bitmap words per thread: a popcount each -- the pass is the 94 MB read of a 250 Mb contig's bitmap, not 23 000 tiles of look-back)
+		LAUNCH(k_pd_keys, n, n, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->d_pdbm.as<u32>(), c->d_gpre.as<i32>(), c->d_gword.as<uint16_t>(), c->prm.MaxIndelSize, c->qbits, c->d_key_c.as<u64>(), c->d_val_c.as<u32>());
 		RC(prim_sort_pairs_u64_u32(c, c->d_key_c.as<u64>(), c->d_key_b.as<u64>(), c->d_val_c.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + 7 + gbits));
 		LAUNCH(k_pd_heads, n, n, c->d_key_b.as<u64>(), c->qbits + 7, c->g_beg.as<i32>());
 		LAUNCH(k_pd_gather, n, n, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->qbits + 7, c->qbits, c->bnd, c->g_beg.as<i32>(),
-		       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), c->d_pdbm.as<u32>());
+		       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), c->d_pdbm.as<u32>(), c->d_pdcb.as<u32>());
 		c->pdbm_dirty = false;
 	} else {
 		RC(seed_view_sort(c));

@@ -139,24 +139,31 @@ __device__ __forceinline__ void wg_exscan_hits(const i32 *hits, i32 *base, int n
                                 // ~120 VGPRs.  (Two waves per chunk: 4; 5 needed 96 VGPRs -- 16 dwords of scratch in the loop, 4.87 against 4.32 ms.  The
                                 // kernel's time does not depend on its occupancy between 5 and 10 chunks per CU: profiles/r03_seed_shape_sweep.txt)
 #endif
+#ifndef LHOP_N
 #define LHOP_N 1024
-#define MEMO_WORDS (GSA_CHUNK / 8)
-__device__ __forceinline__ int memo_nib(const u32 *memo, int s) { return (int)((memo[s >> 3] >> ((s & 7) << 2)) & 15u); }
-__device__ __forceinline__ void memo_one(u32 *memo, int s) { atomicOr(&memo[s >> 3], 1u << ((s & 7) << 2)); }
+#endif
+// Round 4: two bits per position.  next(s) - s only ever takes three kinds of value -- 1 (no seed from s), 5 (an accepted match under -sen:
+// GSAlign.cpp:88-91) and len + 1 >= MinSeedLength + 1 (an accepted match) -- so the codes are 0 unknown, 1 -> +1, 2 -> +5, 3 -> the hop sits in the
+// hash table; anything else (hops of 2-4, 6-...: the accounting build, MinSeedLength below 5) goes to the table as well.  5 KB -> 2.5 KB per chunk:
+// LDS x time is what the seed kernel costs the chip (a CU's LDS holds its chunks and nothing else's meanwhile), see DESIGN section 4.
+#define MEMO_WORDS (GSA_CHUNK / 16)
+__device__ __forceinline__ int memo_nib(const u32 *memo, int s) { return (int)((memo[s >> 4] >> ((s & 15) << 1)) & 3u); }      // the code: 0 = unknown
+__device__ __forceinline__ void memo_one(u32 *memo, int s) { atomicOr(&memo[s >> 4], 1u << ((s & 15) << 1)); }
 __device__ __forceinline__ int memo_get(const u32 *memo, const u32 *lhop, int s)
 {
 	const int v = memo_nib(memo, s);
-	if (v < 15) return v;
+	if (v < 2) return v;
+	if (v == 2) return 5;
 	for (u32 h = ((u32)s * 40503u) >> 6;; h++) { const u32 e = lhop[h & (LHOP_N - 1)]; if ((e >> 16) == (u32)s + 1) return (int)(e & 0xffffu); }
 }
 __device__ __forceinline__ void memo_set(u32 *memo, u32 *lhop, int s, int d, int *abort_flag)
 {
-	if (d < 15) { atomicOr(&memo[s >> 3], (u32)d << ((s & 7) << 2)); return; }
+	if (d == 1 || d == 5) { atomicOr(&memo[s >> 4], (d == 1 ? 1u : 2u) << ((s & 15) << 1)); return; }
 	const u32 e = ((u32)(s + 1) << 16) | (u32)d;
 	u32 h = ((u32)s * 40503u) >> 6;
 	for (int tries = 0; tries < LHOP_N; tries++, h++) {
 		const u32 old = atomicCAS(&lhop[h & (LHOP_N - 1)], 0u, e);
-		if (old == 0 || old == e) { atomicOr(&memo[s >> 3], 15u << ((s & 7) << 2)); return; }      // (two walks that reach the same start store the same hop: next(s) is a function of s)
+		if (old == 0 || old == e) { atomicOr(&memo[s >> 4], 3u << ((s & 15) << 1)); return; }      // (two walks that reach the same start store the same hop: next(s) is a function of s)
 	}
 	*(volatile int *)abort_flag = 1;                                // table full: the chunk is redone by the dense kernels
 }
@@ -567,6 +574,9 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 // With g = n every workgroup takes one unit, as a plain grid would; with fewer the launch is PERSISTENT and holds at most g
 // workgroups' worth of LDS and wave slots whatever the contig's size (what it leaves free the kernels of other contexts can take).
 #define SEED_TICKET 16
+#ifndef SEED_PERSIST
+#define SEED_PERSIST 12        // workgroups per CU of the persistent launch: what the LDS admits (12.8 KB per chunk since the memo is two bits per position)
+#endif
 #ifndef SEED_NCH
 #define SEED_NCH 1              // chunks per wave of the production kernel (2: measured slower, see seed_chunk; the accounting build: always 1)
 #endif
@@ -1000,9 +1010,17 @@ __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ c
 // hits of its start by position: the tie-break of the (group, qPos) order, which the reference gets from a stable sort
 // of the PosDiff order (the f rows of one start are re-read by f lanes: L1/L2 hits on the dense SA).
 #define SEL_HASH 256
+// the coarse bitmap beside the PosDiff bitmap: bit (w >> 5) for bitmap word w (k_chain.hip, OpPdScan)
+__device__ __forceinline__ void pd_coarse_set(u32 *pdcb, unsigned long long w)
+{
+	const unsigned long long blk = w >> 5; const u32 bit = 1u << (blk & 31);
+	// (looked at first: the main diagonal of a whole contig sits in one block, and an unconditional atomic per workgroup queues on that word
+	//  -- locate + order of a 250 Mb contig 0.31 -> 0.67 ms when tried; a kernel of its own with a thread per hit: 1.4 ms, the looks queue too)
+	if (!(__hip_atomic_load(&pdcb[blk >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(&pdcb[blk >> 5], bit);
+}
 __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, const u32 *__restrict__ cand_cnt, const i32 *__restrict__ cand_s, const i32 *__restrict__ cand_len,
                                                       const u64 *__restrict__ cand_x0, const i32 *__restrict__ cand_freq, const u32 *__restrict__ onpath,
-                                                      const i32 *__restrict__ hit_base, Bundle bnd, i32 s_off, int qbits, u64 *key, u32 *val, u32 *pdbm)
+                                                      const i32 *__restrict__ hit_base, Bundle bnd, i32 s_off, int qbits, u64 *key, u32 *val, u32 *pdbm, u32 *pdcb)
 {
 	// (bnd.lmax = length of the whole contig, s_off = contig position of the first chunk searched: not 0 when only a chunk range
 	//  of the contig was seeded on this GPU, gsa_seed_chunks.  A bundle of contigs: the key's PosDiff is the true one of the
@@ -1078,24 +1096,24 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 				const unsigned long long prev = atomicCAS(&s_w[hh], ~0ull, w);
 				if (prev == ~0ull || prev == w) { atomicOr(&s_b[hh], bit); break; }
 			}
-			if (tries == 4) atomicOr(&pdbm[w], bit);
+			if (tries == 4) { atomicOr(&pdbm[w], bit); pd_coarse_set(pdcb, w); }
 		}
 		}
 		__syncthreads();
 	}
 	if (pdbm) {
 		__syncthreads();
-		for (int t = j; t < SEL_HASH; t += 256) if (s_w[t] != ~0ull) atomicOr(&pdbm[s_w[t]], s_b[t]);
+		for (int t = j; t < SEL_HASH; t += 256) if (s_w[t] != ~0ull) { atomicOr(&pdbm[s_w[t]], s_b[t]); pd_coarse_set(pdcb, s_w[t]); }
 	}
 }
 
 // PosDiff bitmap bits of hits that arrived from another GPU (gsa_import_hits)
-__global__ void __launch_bounds__(256) k_pd_from_keys(i64 n, const u64 *__restrict__ key, int qbits, u32 *pdbm)
+__global__ void __launch_bounds__(256) k_pd_from_keys(i64 n, const u64 *__restrict__ key, int qbits, u32 *pdbm, u32 *pdcb)
 {
 	const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const u64 pd = key[i] >> qbits;
-	atomicOr(&pdbm[pd >> 5], 1u << (pd & 31));
+	atomicOr(&pdbm[pd >> 5], 1u << (pd & 31)); pd_coarse_set(pdcb, (unsigned long long)(pd >> 5));
 }
 
 // Accounting build only: the LF steps bwt_sa would walk for every located hit (the row is sampled every 32 ROWS, so the
@@ -1364,12 +1382,16 @@ static int prepare_pd_bitmap(gsa_ctx *c, i64 n_hits)
 {
 	const u64 pd_words = ((u64)c->pd_span >> 5) + 2;
 	// (a chunk range: the hit count of the whole contig is not known here; the bitmap is kept whenever MaxIndelSize allows it)
-	c->pd_path = (n_hits > 0 || c->split) && c->prm.MaxIndelSize >= 0 && c->prm.MaxIndelSize <= 31 && (c->split || pd_words <= 64ull * (u64)n_hits + 65536) && c->opt.pd_bitmap;
+	// (since the scan only visits occupied blocks -- OpPdScan, round 4 -- the bitmap pays whatever the hit count: a human reference is 776 MB per
+	//  contig; beyond 2 GB -- bundles against a large reference -- only with enough hits to justify the memory)
+	c->pd_path = (n_hits > 0 || c->split) && c->prm.MaxIndelSize >= 0 && c->prm.MaxIndelSize <= 31 && (c->split || pd_words <= (512ull << 20) || pd_words <= 64ull * (u64)n_hits + 65536) && c->opt.pd_bitmap;
 	c->seed_view_ready = false;
 	if (c->pd_path) {
 		const size_t cap0 = c->d_pdbm.cap;
-		if (!dev_ensure<u32>(c, c->d_pdbm, (size_t)pd_words + 2)) return GSA_ERR_NOMEM;
+		const size_t ccap0 = c->d_pdcb.cap;
+		if (!dev_ensure<u32>(c, c->d_pdbm, (size_t)pd_words + 66) || !dev_ensure<u32>(c, c->d_pdcb, (size_t)(pd_words >> 10) + 4)) return GSA_ERR_NOMEM;
 		if (c->d_pdbm.cap != cap0 || c->pdbm_dirty) GSA_CHECK(c, hipMemsetAsync(c->d_pdbm.p, 0, c->d_pdbm.cap, c->stream));
+		if (c->d_pdcb.cap != ccap0 || c->pdbm_dirty) GSA_CHECK(c, hipMemsetAsync(c->d_pdcb.p, 0, c->d_pdcb.cap, c->stream));
 		c->pdbm_dirty = true; c->pd_words = (i64)pd_words;
 	}
 	return GSA_OK;
@@ -1466,9 +1488,9 @@ int stage1_seed(gsa_ctx *c)
 			//  7.1 / 9.9 ms at 8 / 6 / 5 / 4 / 3 / 2 (the dispatcher fills CUs one after the other, so fewer workgroups mean fewer CUs, not thinner
 			//  ones); four contexts' throughput within +- 2 % of each other from 4 per CU upwards: tools/persist.sh)
 #ifdef GSA_EXPERIMENTS
-			static const int persist = [] { const char *e = getenv("GSA_SEED_PERSIST"); return e ? atoi(e) : 10 / SEED_NCH; }();
+			static const int persist = [] { const char *e = getenv("GSA_SEED_PERSIST"); return e ? atoi(e) : SEED_PERSIST / SEED_NCH; }();
 #else
-			const int persist = 10 / SEED_NCH;      // (what the LDS admits: ~30 KB per pair of chunks)
+			const int persist = SEED_PERSIST / SEED_NCH;      // (what the LDS admits)
 #endif
 			const i64 n_units = c->count_blocks ? n_chunks : (n_chunks + SEED_NCH - 1) / SEED_NCH;      // (a wave of the production kernel owns SEED_NCH chunks)
 			unsigned grid = (unsigned)n_units;
@@ -1538,7 +1560,7 @@ int stage1_seed(gsa_ctx *c)
 	if (n_hits > 0) {
 		if (!dev_ensure<u64>(c, c->d_key_a, hcap) || !dev_ensure<u32>(c, c->d_val_a, hcap)) return GSA_ERR_NOMEM;
 		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), (ccap + 2) * sizeof(u32), st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
-		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), c->bnd, s_off, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr);
+		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), c->bnd, s_off, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr, c->d_pdcb.as<u32>());
 	}
 	if (c->profiling) hipEventRecord(c->ev[2], st);
 	u64 lf_steps = 0;
@@ -1609,7 +1631,7 @@ int stage1_import_hits(gsa_ctx *c, const u64 *keys, const u32 *vals, i64 n)
 		GSA_CHECK(c, hipMemcpyAsync(c->d_key_a.as<u64>() + have, keys, (size_t)n * 8, hipMemcpyDefault, c->stream));
 		GSA_CHECK(c, hipMemcpyAsync(c->d_val_a.as<u32>() + have, vals, (size_t)n * 4, hipMemcpyDefault, c->stream));
 	}
-	if (c->pd_path) hipLaunchKernelGGL(k_pd_from_keys, dim3(grid_for((size_t)n, 256)), dim3(256), 0, c->stream, n, c->d_key_a.as<u64>() + have, c->qbits, c->d_pdbm.as<u32>());
+	if (c->pd_path) hipLaunchKernelGGL(k_pd_from_keys, dim3(grid_for((size_t)n, 256)), dim3(256), 0, c->stream, n, c->d_key_a.as<u64>() + have, c->qbits, c->d_pdbm.as<u32>(), c->d_pdcb.as<u32>());
 	GSA_CHECK(c, hipGetLastError());
 	GSA_CHECK(c, hipStreamSynchronize(c->stream));      // (the caller's buffers are free again)
 	c->n_seeds += n;
@@ -1630,8 +1652,8 @@ int stage1_finish_split(gsa_ctx *c)
 int stage1_restore_pdbm(gsa_ctx *c)
 {
 	if (!c->pd_path || c->n_seeds == 0) return GSA_OK;
-	if (c->pdbm_dirty) { GSA_CHECK(c, hipMemsetAsync(c->d_pdbm.p, 0, c->d_pdbm.cap, c->stream)); }
-	hipLaunchKernelGGL(k_pd_from_keys, dim3(grid_for((size_t)c->n_seeds, 256)), dim3(256), 0, c->stream, c->n_seeds, c->d_key_a.as<u64>(), c->qbits, c->d_pdbm.as<u32>());
+	if (c->pdbm_dirty) { GSA_CHECK(c, hipMemsetAsync(c->d_pdbm.p, 0, c->d_pdbm.cap, c->stream)); GSA_CHECK(c, hipMemsetAsync(c->d_pdcb.p, 0, c->d_pdcb.cap, c->stream)); }
+	hipLaunchKernelGGL(k_pd_from_keys, dim3(grid_for((size_t)c->n_seeds, 256)), dim3(256), 0, c->stream, c->n_seeds, c->d_key_a.as<u64>(), c->qbits, c->d_pdbm.as<u32>(), c->d_pdcb.as<u32>());
 	GSA_CHECK(c, hipGetLastError());
 	c->pdbm_dirty = true;
 	return GSA_OK;

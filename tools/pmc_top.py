@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/pmc_<workload>/*.csv (tools/pmc_top.sh) -> profiles/r03_pmc_<workload>.json: HBM traffic per step of the
+"""gpurun_out/pmc_<workload>/*.csv (tools/pmc_top.sh) -> profiles/r04_pmc_<workload>.json: HBM traffic per step of the
 top kernels and of the whole step, from separate rocprofv3 --pmc passes.  Reads: from the request counters
 (TCC_EA0_RDREQ: requests that are not 32-byte ones are 128 bytes wide on gfx950 -- the same correction as
 "FETCH_SIZE x 2" in MI355X_MICROARCH.md, HBM section); writes: WRITE_SIZE (KB) as is (uncalibrated there)."""
@@ -37,6 +37,9 @@ def load(fn):
     for r in csv.DictReader(open(p)):
         k, c = r["Kernel_Name"], r["Counter_Name"]
         per[k][c] += float(r["Counter_Value"])
+        if "Launches" in r:            # (reduced on the GPU box: tools/pmc_reduce.py)
+            launches[k] = max(launches[k], int(r["Launches"]))
+            continue
         key = (r.get("Dispatch_Id"), k)
         if key not in seen:
             seen.add(key); launches[k] += 1
@@ -56,13 +59,13 @@ def main():
     # runs with the production seed kernel = launches of k_seed_wg<false,*>
     sel = sum(v for k, v in launches.items() if "k_seed_select" in k)
     prod = sum(v for k, v in launches.items() if "k_seed_wg" in k and "Lb1ELb0" not in k and "<true" not in k) or sum(v for k, v in launches.items() if "k_dense_resolve" in k)
-    contigs_per_step = {"human": 1, "ecoli": 1, "yeast": 16}[W]
+    contigs_per_step = {"human": 1, "ecoli": 1, "yeast": 16, "human_full": 24, "adversarial": 1}[W]
     def bytes_of(d):
         rd, rd32 = d.get("TCC_EA0_RDREQ_sum", 0.0), d.get("TCC_EA0_RDREQ_32B_sum", 0.0)
         rb = (rd - rd32) * 128.0 + rd32 * 32.0 if rd else d.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
         return rb, d.get("WRITE_SIZE", 0.0) * 1024.0
     out = {"_what": f"HBM traffic per step of bench.py --workload {W} from rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only beside it), inflight 1",
-           "_method": "reads = (TCC_EA0_RDREQ - RDREQ_32B) x 128 B + RDREQ_32B x 32 B (gfx950: FETCH_SIZE tallies 128-byte requests at 64 B, MI355X_MICROARCH.md HBM section); writes = WRITE_SIZE KB x 1024 (uncalibrated); "
+           "_method": "reads = (TCC_EA0_RDREQ - RDREQ_32B) x 128 B + RDREQ_32B x 32 B (gfx950: FETCH_SIZE tallies 128-byte requests at 64 B, MI355X_MICROARCH.md HBM section; CALIBRATED in round 4 -- profiles/r04_pmc_calibration.txt: a random read of 16, 32, 64 or 128 bytes costs exactly one RDREQ, none of the 32-byte kind, and FETCH_SIZE counts it as 64 B: every L2 miss fetches one 128-byte line); writes = WRITE_SIZE KB x 1024 (uncalibrated); "
                       "Infinity-Cache hits are counted, so this is L2-miss traffic, an upper bound of HBM bytes; per step = total over the run / hot-path runs x contigs per step "
                       "(seed kernels: / runs with the production seed kernel)",
            "commit": commit(), "workload": W, "hot_path_runs": sel, "production_seed_runs": prod, "kernels": {}}
@@ -83,7 +86,7 @@ def main():
                                     "traffic_bytes_per_step": (rb + wb) / runs * contigs_per_step}
     if sel:
         out["traffic_bytes_per_step"] = (tot_r + tot_w) / sel * contigs_per_step
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"r03_pmc_{W}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"r04_pmc_{W}.json"), "w"), indent=1)
     print(json.dumps(out, indent=1)[:3000])
 
 

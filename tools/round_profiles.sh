@@ -1,14 +1,17 @@
 #!/bin/bash
-# Round-end measurements on the GPU box: default bench line, rocprofv3 kernel-trace summaries of the three workloads, PMC passes.
-#   gpurun -- 'bash tools/round_profiles.sh'   ->  gpurun_out/{bench_default.json, kernels_<w>.txt, pmc_human/*.csv}
+# Round-end measurements on the GPU box: default bench line, rocprofv3 kernel-trace summaries of the workloads, one-context timelines, PMC passes.
+#   gpurun -- 'bash tools/round_profiles.sh'   ->  gpurun_out/{bench_default.json, kernels_<w>.txt, tl1_<w>.txt, pmc_<w>/*.csv, pmc_sq_human/*.csv}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
-timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-tail -c 600 gpurun_out/bench_default.json
-for w in human ecoli yeast; do
-  timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$w -o p -- python bench.py --workload $w --steps 20 --warmup 5 --extra "" --no-cpu-baseline > gpurun_out/prof_$w.log 2>&1
+export GSA_BENCH_TMP=/tmp/gsa_round GSA_BENCH_KEEP=1; mkdir -p $GSA_BENCH_TMP gpurun_out
+timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+tail -c 400 gpurun_out/bench_default.json; echo
+for w in ${KW:-human_full human ecoli yeast adversarial}; do
+  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$w -o p -- python bench.py --workload $w --extra "" --no-cpu-baseline --no-side-legs > gpurun_out/prof_$w.log 2>&1
   python tools/rocprof_summary.py gpurun_out/prof_$w/p_results.db > gpurun_out/kernels_$w.txt
   rm -rf gpurun_out/prof_$w
 done
+WL="human ecoli yeast" STEPS=8 bash tools/tl1.sh
+STEPS=1 bash tools/pmc_top.sh human_full > gpurun_out/pmc_top_full.log 2>&1
 bash tools/pmc_top.sh human > gpurun_out/pmc_top.log 2>&1
 bash tools/pmc_sq.sh human > gpurun_out/pmc_sq.log 2>&1
-# then, back in the container: python tools/pmc_top.py human ; python tools/pmc_sq.py human > profiles/r03_sq_human.txt
+# then, back in the container: python tools/pmc_top.py human_full; python tools/pmc_top.py human ; python tools/pmc_sq.py human > profiles/r04_sq_human.txt
