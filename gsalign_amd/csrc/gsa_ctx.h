@@ -158,7 +158,6 @@ struct gsa_ctx {
 	i32 n_groups = 0;
 	bool pd_path = false, seed_view_ready = false, pdbm_dirty = true; i64 pd_words = 0;      // groups from the PosDiff bitmap (no PosDiff sort on the hot path)
 	DevBuf w_j0, w_j1, w_on;                      // window chain of large contigs: leave(), its double, orbit flags
-	DevBuf d_gword;                                // group starts below each bitmap word inside its block (u16; written for occupied blocks)
 	DevBuf d_pdcb;                                 // coarse bitmap: one bit per block of 32 words of d_pdbm (the blocks that hold a hit)
 	DevBuf d_pdbm, d_gpre, d_key_c, d_val_c;      // bitmap of occupied PosDiff values, group starts below each word, (group, qPos, rank) keys
 	DevBuf g_beg;                                  // group start indices (n_groups+1)

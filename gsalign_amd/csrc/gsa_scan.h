@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 
 // host side: one fused pass on the context's stream
 template <int NV, int ITEMS = LB_ITEMS, class Op>
-static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op, hipStream_t stream = nullptr)
+static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op, hipStream_t stream = nullptr, int grid_per_cu = LB_GRID_PER_CU)
 {
 	if (!stream) stream = c->stream;      // (only one stream may run fused passes at a time: they share the status words)
 	constexpr i64 LB_TILE = (i64)LB_TPB * ITEMS;
@@ -188,7 +188,7 @@ static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op, hipStream_t stream 
 	lb.ticket = c->d_mail.as<u32>() + M_TICKET; lb.base = c->lb_base; lb.epoch = c->lb_epoch; lb.err = c->d_mail.as<i32>() + M_LBERR; lb.finished = c->d_mail.as<u32>() + M_LBDONE;
 	lb.n_tiles = (i32)tiles;
 	if (c->n_cus <= 0) { hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device)); c->n_cus = pr.multiProcessorCount; }
-	const size_t grid = std::min<size_t>(tiles, (size_t)LB_GRID_PER_CU * (size_t)c->n_cus);
+	const size_t grid = std::min<size_t>(tiles, (size_t)grid_per_cu * (size_t)c->n_cus);
 	hipLaunchKernelGGL((k_lb_pass<NV, Op, ITEMS>), dim3((unsigned)grid), dim3(LB_TPB), 0, stream, n, op, lb);
 	GSA_CHECK(c, hipGetLastError());
 	c->lb_base += (u32)(tiles + grid);      // (every workgroup's last draw is the one that fails)

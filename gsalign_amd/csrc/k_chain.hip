@@ -83,7 +83,7 @@ __device__ __forceinline__ void pd_block_load(const u32 *__restrict__ bm, i64 bl
 	for (int k = 0; k < 8; k++) { const uint4 q = p[k]; w[1 + 4 * k] = q.x; w[2 + 4 * k] = q.y; w[3 + 4 * k] = q.z; w[4 + 4 * k] = q.w; }
 }
 struct OpPdScan {      // over the BLOCKS (32 bitmap words each); a block without a hit costs a look at its coarse bit
-	const u32 *bm, *cb; int max_indel; i32 *gpre; uint16_t *gword; i32 *mail; i64 nw;
+	const u32 *bm, *cb; int max_indel; i32 *gpre, *mail; i64 nw;
 	__device__ i32 value(i64 blk, int) const
 	{
 		if (!((cb[blk >> 5] >> (blk & 31)) & 1u)) return 0;
@@ -93,31 +93,24 @@ struct OpPdScan {      // over the BLOCKS (32 bitmap words each); a block withou
 		for (int k = 0; k < 32; k++) n += __popc(pd_starts_pair(w[k + 1], w[k], max_indel));
 		return n;
 	}
-	__device__ void emit(i64 blk, const i32 *, const i32 *ex) const
-	{
-		if (!((cb[blk >> 5] >> (blk & 31)) & 1u)) return;
-		u32 w[33]; pd_block_load(bm, blk, w);
-		gpre[blk] = ex[0];
-		// group starts below each word of the block, inside the block (what a hit in that word adds to gpre[blk]): 32 x u16 = one 64-byte row
-		u32 in = 0, pk[16];
-#pragma unroll
-		for (int k = 0; k < 32; k++) { if (k & 1) pk[k >> 1] |= in << 16; else pk[k >> 1] = in; in += (u32)__popc(pd_starts_pair(w[k + 1], w[k], max_indel)); }
-		uint4 *o = (uint4 *)(gword + (blk << 5));
-#pragma unroll
-		for (int k = 0; k < 4; k++) o[k] = make_uint4(pk[4 * k], pk[4 * k + 1], pk[4 * k + 2], pk[4 * k + 3]);
-	}
+	__device__ void emit(i64 blk, const i32 *v, const i32 *ex) const { if (v[0] || ((cb[blk >> 5] >> (blk & 31)) & 1u)) gpre[blk] = ex[0]; }
 	__device__ void done(const i32 *t) const { mail[M_NG] = t[0]; }
 };
 // key = (group, qPos, rank among the hits of the same start); val = index of the hit
-__global__ void k_pd_keys(i64 n, const u64 *__restrict__ hkey, const u32 *__restrict__ hval, const u32 *__restrict__ bm, const i32 *__restrict__ gpre, const uint16_t *__restrict__ gword, int max_indel, int qbits,
+__global__ void k_pd_keys(i64 n, const u64 *__restrict__ hkey, const u32 *__restrict__ hval, const u32 *__restrict__ bm, const i32 *__restrict__ gpre, int max_indel, int qbits,
                           u64 *key, u32 *val)
 {
 	GID(n);
 	const u64 k = hkey[i];
 	const i64 pd = (i64)(k >> qbits); const u32 q = (u32)(k & ((1ull << qbits) - 1));
 	const i64 w = pd >> 5; const int b = (int)(pd & 31);
-	const u32 st = pd_starts(bm, w, max_indel);
-	const i32 gid = gpre[w >> 5] + (i32)gword[w] + __popc(st & (b == 31 ? ~0u : ((2u << b) - 1))) - 1;      // (starts below my block | in the words of my block below mine | in my word up to my bit)
+	// group id = starts below my block (OpPdScan) + in the words of my block below mine + in my word up to my bit: the block is one 128-byte line
+	u32 wd[33]; pd_block_load(bm, w >> 5, wd);
+	const int wi = (int)(w & 31);
+	i32 below = 0; u32 st = 0;
+#pragma unroll
+	for (int k = 0; k < 32; k++) { const u32 sk = pd_starts_pair(wd[k + 1], wd[k], max_indel); below += k < wi ? __popc(sk) : 0; st = k == wi ? sk : st; }
+	const i32 gid = gpre[w >> 5] + below + __popc(st & (b == 31 ? ~0u : ((2u << b) - 1))) - 1;
 	key[i] = ((u64)(u32)gid << (qbits + 7)) | ((u64)q << 7) | (hval[i] >> 16);
 	val[i] = (u32)i;
 }
@@ -672,10 +665,10 @@ int stage2_chain(gsa_ctx *c)
 		// group ids from the PosDiff bitmap, then ONE sort by (group, qPos, rank) straight from the located hits
 		const i64 nw = c->pd_words;
 		const i64 nblk = (nw + 31) >> 5;      // blocks of 32 bitmap words (one coarse bit each)
-		ENS(i32, d_gpre, ((nw + 31) >> 5) + 2); ENS(uint16_t, d_gword, nw + 64); ENS(u64, d_key_c, n); ENS(u32, d_val_c, n); ENS(u64, d_key_b, n); ENS(u32, d_val_b, n); ENS(i32, g_beg, n + 2);
+		ENS(i32, d_gpre, ((nw + 31) >> 5) + 2); ENS(u64, d_key_c, n); ENS(u32, d_val_c, n); ENS(u64, d_key_b, n); ENS(u32, d_val_b, n); ENS(i32, g_beg, n + 2);
 		i32 *mail_ = c->d_mail.as<i32>();
-		{ OpPdScan op = { c->d_pdbm.as<u32>(), c->d_pdcb.as<u32>(), c->prm.MaxIndelSize, c->d_gpre.as<i32>(), c->d_gword.as<uint16_t>(), mail_, nw }; RC((lb_launch<1, 4>(c, nblk, op))); }      // (16 bitmap words per thread: a popcount each -- the pass is the 94 MB read of a 250 Mb contig's bitmap, not 23 000 tiles of look-back)
-		LAUNCH(k_pd_keys, n, n, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->d_pdbm.as<u32>(), c->d_gpre.as<i32>(), c->d_gword.as<uint16_t>(), c->prm.MaxIndelSize, c->qbits, c->d_key_c.as<u64>(), c->d_val_c.as<u32>());
+		{ OpPdScan op = { c->d_pdbm.as<u32>(), c->d_pdcb.as<u32>(), c->prm.MaxIndelSize, c->d_gpre.as<i32>(), mail_, nw }; RC((lb_launch<1, 4>(c, nblk, op, nullptr, 8))); }      // (eight workgroups per CU: a block costs two dependent looks and nothing else)      // (16 bitmap words per thread: a popcount each -- the pass is the 94 MB read of a 250 Mb contig's bitmap, not 23 000 tiles of look-back)
+		LAUNCH(k_pd_keys, n, n, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->d_pdbm.as<u32>(), c->d_gpre.as<i32>(), c->prm.MaxIndelSize, c->qbits, c->d_key_c.as<u64>(), c->d_val_c.as<u32>());
 		RC(prim_sort_pairs_u64_u32(c, c->d_key_c.as<u64>(), c->d_key_b.as<u64>(), c->d_val_c.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + 7 + gbits));
 		LAUNCH(k_pd_heads, n, n, c->d_key_b.as<u64>(), c->qbits + 7, c->g_beg.as<i32>());
 		LAUNCH(k_pd_gather, n, n, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->qbits + 7, c->qbits, c->bnd, c->g_beg.as<i32>(),

@@ -395,11 +395,29 @@ struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; }
 
 // packed 16-bit arithmetic on the two halves of a register, spelled out: the compiler rewrites min(x, 1) and friends into
 // per-half compares and selects (five instructions for one)
+// Round 4: the packed instructions come from vector builtins (the compiler knows what they are: no `s_nop` behind every one of them, as there was
+// behind each inline-asm statement -- 475 in the kernel).  What made round 2 spell them as inline asm -- `min(x, 1)` on packed shorts is rewritten into
+// per-half compares and selects -- is avoided by keeping the constants opaque (DP_OPAQUE: a register the optimiser cannot see through).
+#ifdef DP_PK_ASM
 #define PK2(NAME, INS) __device__ __forceinline__ u32 NAME(u32 a, u32 b) { u32 d; asm(INS " %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 PK2(pk_add, "v_pk_add_u16") PK2(pk_sub, "v_pk_sub_u16") PK2(pk_max, "v_pk_max_u16") PK2(pk_min, "v_pk_min_u16")
 __device__ __forceinline__ u32 pk_sub_sat(u32 a, u32 b) { u32 d; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }      // max(a - b, 0)
 __device__ __forceinline__ u32 pk_mad(u32 a, u32 b, u32 c) { u32 d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ u32 pk_shl(u32 a, u32 sh) { u32 d; asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(d) : "v"(sh), "v"(a)); return d; }
+#define DP_OPAQUE(X)
+#else
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+#define V2(X) __builtin_bit_cast(v2u16, (u32)(X))
+#define U1(X) __builtin_bit_cast(u32, (v2u16)(X))
+__device__ __forceinline__ u32 pk_add(u32 a, u32 b) { return U1(V2(a) + V2(b)); }
+__device__ __forceinline__ u32 pk_sub(u32 a, u32 b) { return U1(V2(a) - V2(b)); }
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b) { return U1(__builtin_elementwise_max(V2(a), V2(b))); }
+__device__ __forceinline__ u32 pk_min(u32 a, u32 b) { return U1(__builtin_elementwise_min(V2(a), V2(b))); }
+__device__ __forceinline__ u32 pk_sub_sat(u32 a, u32 b) { return U1(__builtin_elementwise_sub_sat(V2(a), V2(b))); }      // max(a - b, 0)
+__device__ __forceinline__ u32 pk_mad(u32 a, u32 b, u32 c) { return U1(V2(a) * V2(b) + V2(c)); }
+__device__ __forceinline__ u32 pk_shl(u32 a, u32 sh) { return U1(V2(a) << V2(sh)); }
+#define DP_OPAQUE(X) asm volatile("" : "+v"(X))
+#endif
 
 template <int WPB>
 __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ blk2job, const StripeJob *__restrict__ sjobs, const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1,
@@ -488,7 +506,8 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	u32 hb = 0;                                         // lanes 0-7: stripe B's boundary column (x | v << 8 of its lane 63), the eight rows of the current block
 	const u32 selx = lane ? 0x0c060c04u : 0x0c040c00u, selv = lane ? 0x0c070c05u : 0x0c050c01u;      // x, v of (lane - 1 | boundary, A's lane 63) from (rotated pairs, boundary row)
 	u32 acc = 0, r0 = 0;                   // direction nibbles of the last four steps (per half, oldest on top); those of the four before
-	const u32 c1 = 0x00010001u, c2 = 0x00020002u, c4 = 0x00040004u, c7 = 0x00070007u, c16 = 0x00100010u;
+	u32 c1 = 0x00010001u, c2 = 0x00020002u, c4 = 0x00040004u, c7 = 0x00070007u, c16 = 0x00100010u;
+	DP_OPAQUE(c1); DP_OPAQUE(c2); DP_OPAQUE(c4); DP_OPAQUE(c7); DP_OPAQUE(c16);
 	// one step; K2 is the position inside the 16-step block (a literal in the unrolled body).  GUARD = 1: the first 128 steps (lanes
 	// that have not reached row 0 yet are put back to the initial state after every step) and the last blocks (stripe A's
 	// direction blocks have an end).  Nothing masks the cells a lane computes outside the matrix -- rows >= m, columns >= n:
