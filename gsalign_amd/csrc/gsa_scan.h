@@ -86,7 +86,8 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 	// of 64 aggregates -- a dependent agent-scope load each -- before it met one (58 us mean tile lifetime in OpDpJobs: r03_sq_human.txt,
 	// 2.2 x 10^9 wave-cycles per contig, more than the striped DP).  With a few hundred tiles in flight, all of them consecutive, the
 	// predecessors of a tile are mostly through and the first window answers.
-	for (;;) {
+	for (bool first = true;; first = false) {
+	if (!first && (i32)gridDim.x >= lb.n_tiles) break;      // (a launch with a workgroup per tile: one draw each, no failing second one -- a round trip per pass on small contigs)
 	__syncthreads();
 	if (tid == 0) s_tile = (i32)(atomicAdd(lb.ticket, 1u) - lb.base);
 	__syncthreads();
@@ -191,7 +192,7 @@ static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op, hipStream_t stream 
 	const size_t grid = std::min<size_t>(tiles, (size_t)grid_per_cu * (size_t)c->n_cus);
 	hipLaunchKernelGGL((k_lb_pass<NV, Op, ITEMS>), dim3((unsigned)grid), dim3(LB_TPB), 0, stream, n, op, lb);
 	GSA_CHECK(c, hipGetLastError());
-	c->lb_base += (u32)(tiles + grid);      // (every workgroup's last draw is the one that fails)
+	c->lb_base += (u32)(tiles + (grid < tiles ? grid : 0));      // (persistent: every workgroup's last draw is the one that fails)
 	return GSA_OK;
 }
 

@@ -667,7 +667,9 @@ int stage2_chain(gsa_ctx *c)
 		const i64 nblk = (nw + 31) >> 5;      // blocks of 32 bitmap words (one coarse bit each)
 		ENS(i32, d_gpre, ((nw + 31) >> 5) + 2); ENS(u64, d_key_c, n); ENS(u32, d_val_c, n); ENS(u64, d_key_b, n); ENS(u32, d_val_b, n); ENS(i32, g_beg, n + 2);
 		i32 *mail_ = c->d_mail.as<i32>();
-		{ OpPdScan op = { c->d_pdbm.as<u32>(), c->d_pdcb.as<u32>(), c->prm.MaxIndelSize, c->d_gpre.as<i32>(), mail_, nw }; RC((lb_launch<1, 4>(c, nblk, op, nullptr, 8))); }      // (eight workgroups per CU: a block costs two dependent looks and nothing else)      // (16 bitmap words per thread: a popcount each -- the pass is the 94 MB read of a 250 Mb contig's bitmap, not 23 000 tiles of look-back)
+		{ OpPdScan op = { c->d_pdbm.as<u32>(), c->d_pdcb.as<u32>(), c->prm.MaxIndelSize, c->d_gpre.as<i32>(), mail_, nw };
+		  if (nblk <= (1 << 20)) RC((lb_launch<1, 1>(c, nblk, op, nullptr, 8))); else RC((lb_launch<1, 4>(c, nblk, op, nullptr, 8))); }      // (a small bitmap: a block per thread -- four in a row are four times two dependent looks)
+		{}      // (eight workgroups per CU: a block costs two dependent looks and nothing else)      // (16 bitmap words per thread: a popcount each -- the pass is the 94 MB read of a 250 Mb contig's bitmap, not 23 000 tiles of look-back)
 		LAUNCH(k_pd_keys, n, n, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->d_pdbm.as<u32>(), c->d_gpre.as<i32>(), c->prm.MaxIndelSize, c->qbits, c->d_key_c.as<u64>(), c->d_val_c.as<u32>());
 		RC(prim_sort_pairs_u64_u32(c, c->d_key_c.as<u64>(), c->d_key_b.as<u64>(), c->d_val_c.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + 7 + gbits));
 		LAUNCH(k_pd_heads, n, n, c->d_key_b.as<u64>(), c->qbits + 7, c->g_beg.as<i32>());
