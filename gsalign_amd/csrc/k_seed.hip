@@ -32,7 +32,12 @@ enum { CNT_OCCBLK = 0, CNT_DONE = 1, CNT_HITS = 2, CNT_SEEDS = 3, CNT_DPCELLS = 
 #define PATH_WORDS 320          // 10240 on-path bits per chunk
 #define QP_WORDS (GSA_CHUNK / 16 + 4)
 #define QN_WORDS (GSA_CHUNK / 32 + 4)
-enum { M_DONE = 0, M_FM = 1, M_TEXT = 2, M_KMER = 3, M_LOC = 4, M_ADV = 5, M_KLO = 6 };
+enum { M_DONE = 0, M_FM = 1, M_TEXT = 2, M_KMER = 3, M_LOC = 4, M_ADV = 5, M_KLO = 6, M_MLOC = 7, M_MTEXT = 8 };
+#ifndef SEED_MULTI
+#define SEED_MULTI 1            // intervals of at most this many rows (<= 4) are finished by text comparison of all their rows (seed_chunk, round 4); 1 = off.
+#endif                          // MEASURED at 4 (parity green, 50 cases): 28 more VGPRs (168 + spills), seed stage of a 250 Mb contig 3.03 -> 3.27 ms, of the
+                                // full human set 55.2 -> 54.0 ms: the Occ steps that weigh are the walks through repeat copies with thousands of rows, not the
+                                // last two steps of a chance interval.  Off in production; kept behind this switch.
 
 // ---- 2-bit packed sequences: base p sits at bits (2*(p&15)) of word p>>4 (LSB first) ----
 __device__ __forceinline__ int q_code(const u32 *qp, int p) { return (qp[p >> 4] >> ((p & 15) << 1)) & 3; }
@@ -286,6 +291,14 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 		int lclen = 0;                                        // length of the chunk my item belongs to
 		const u32 *qp_l = qp[0], *qn_l = qn[0]; u32 *memo_l = memo[0], *lhop_l = lhop[0];      // ... and that chunk's arrays
 		FmIntv ik = {0, 0, 0}; u32 blk = 0; i64 tp = 0;
+		// Round 4: an interval of 2 .. SEED_MULTI rows is finished WITHOUT further Occ steps.  Its rows are suffix-array rows x0 .. x0 + x2 - 1,
+		// sorted by suffix; extending the match by base c keeps the rows whose text continues with c -- a contiguous run, and the reference's
+		// new x0 is the old one plus the rows in front of that run (bwt_search.cpp:159-165: ok[3] = A first, then C, G, T; the row whose suffix
+		// ends is the `primary` adjustment).  So: read the rows' text positions from the dense SA (one round trip), compare every row's text with
+		// the query 64 bases per round trip, and the match ends where the longest row ends: len = the longest common prefix, the final
+		// interval = the rows that reach it.  Against a human-sized index most 15-mers that occur have 2-8 rows by chance (6.2 G rows over 4^15
+		// k-mers) and took 2-3 Occ steps + a locate to get to the text comparison.
+		i64 mp[4] = {0, 0, 0, 0}; u32 malive = 0;          // text positions of the rows at `pos`; the rows still matching (bit i: row x0 + i)
 		bool need_item = true;
 		while (!__all(mode == M_DONE)) {
 			iters++;
@@ -314,7 +327,7 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 			if (ANY_IN(M_FM)) { bk = fm_load(di, kk >> 6); bl = fm_load(di, ll >> 6); }
 			struct __attribute__((packed, aligned(4))) W5 { u32 a, b, c, d, e; };
 			W5 w5 = {0, 0, 0, 0, 0};
-			if (ANY_IN(M_TEXT)) w5 = *(const W5 *)(di.ref2 + (mode == M_TEXT ? (tp >> 4) : 0));      // 20 bytes of packed text: a 64-base window
+			if (ANY_IN(M_TEXT)) w5 = *(const W5 *)(di.ref2 + (mode == M_TEXT ? (tp >> 4) : ((mode == M_MTEXT && (malive & 1u)) ? (mp[0] >> 4) : 0)));      // 20 bytes of packed text: a 64-base window
 			const u32 r0 = w5.a, r1 = w5.b, r2 = w5.c, r3 = w5.d, r4 = w5.e;
 			// one k-mer table entry: 16 bytes (one load) when the text is below 2^32, else 32
 			ulonglong2 e0 = {0, 0}, e1 = {0, 0};
@@ -335,8 +348,21 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 			//  the 12-bit number pext = q[s .. s+3) | q[s+K .. s+K+3) << 6: one number per open search instead of four packed ones)
 #define PRES4_TEST(I) ((((((pext >> (2 * (I))) & 32u) ? ((I) == 0 ? pl0.y : (I) == 1 ? pl0.w : (I) == 2 ? pl1.y : pl1.w) : ((I) == 0 ? pl0.x : (I) == 1 ? pl0.z : (I) == 2 ? pl1.x : pl1.z)) >> ((pext >> (2 * (I))) & 31u)) & 1u) != 0)
 			u64 sav = 0;
-			if (ANY_IN(M_LOC)) sav = fm_locate(di, mode == M_LOC ? ik.x0 : 1);
+			if (ANY_IN(M_LOC)) sav = fm_locate(di, (mode == M_LOC || mode == M_MLOC) ? ik.x0 : 1);
 #undef ANY_IN
+			u64 sav1 = 0, sav2 = 0, sav3 = 0; W5 w5b = {0, 0, 0, 0, 0}, w5c = w5b, w5d = w5b;
+			if (!COUNT && SEED_MULTI > 1) {
+				if (__any(mode == M_MLOC)) {      // (rare enough per wave-iteration that the loads are only issued when somebody needs them)
+					const int nr = mode == M_MLOC ? (int)ik.x2 : 0;
+					sav1 = fm_locate(di, nr > 1 ? ik.x0 + 1 : 1); sav2 = fm_locate(di, nr > 2 ? ik.x0 + 2 : 1); sav3 = fm_locate(di, nr > 3 ? ik.x0 + 3 : 1);
+				}
+				if (__any(mode == M_MTEXT)) {
+					const bool mt = mode == M_MTEXT;
+					w5b = *(const W5 *)(di.ref2 + ((mt && (malive & 2u)) ? (mp[1] >> 4) : 0));
+					w5c = *(const W5 *)(di.ref2 + ((mt && (malive & 4u)) ? (mp[2] >> 4) : 0));
+					w5d = *(const W5 *)(di.ref2 + ((mt && (malive & 8u)) ? (mp[3] >> 4) : 0));
+				}
+			}
 			// ---- consume phase: straight-line, one predicated block per mode ----
 			bool ended = false;
 			if (mode == M_KMER) {
@@ -359,9 +385,32 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 					else ik = fm_init(di, q_code(qp_l, s));      // (pos = s + 1 since the search was opened)
 					mode = M_FM;
 					if (hit && ik.x2 == 1) { tp = (i64)(e1.y - 1) + di.kmer_k; mode = M_TEXT; }      // unique: straight to the text comparison
+					else if (!COUNT && SEED_MULTI > 1 && hit && ik.x2 <= SEED_MULTI) mode = M_MLOC;      // a few rows: their text positions, then the text
 				}
 			} else if (mode == M_LOC) {
 				tp = (i64)sav + (pos - s); mode = M_TEXT;
+			} else if (!COUNT && SEED_MULTI > 1 && mode == M_MLOC) {
+				mp[0] = (i64)sav + (pos - s); mp[1] = (i64)sav1 + (pos - s); mp[2] = (i64)sav2 + (pos - s); mp[3] = (i64)sav3 + (pos - s);
+				malive = (1u << (int)ik.x2) - 1u; mode = M_MTEXT;
+			} else if (!COUNT && SEED_MULTI > 1 && mode == M_MTEXT) {
+				int g0 = -1, g1 = -1, g2 = -1, g3 = -1;
+#define MT_ROW(G, W, P) { int got = text_match32(W.a, W.b, W.c, P, (i64)di.seq_len, qp_l, qn_l, pos, lclen); if (got == 32) got += text_match32(W.c, W.d, W.e, P + 32, (i64)di.seq_len, qp_l, qn_l, pos + 32, lclen); G = got; }
+				if (malive & 1u) MT_ROW(g0, w5, mp[0])
+				if (malive & 2u) MT_ROW(g1, w5b, mp[1])
+				if (malive & 4u) MT_ROW(g2, w5c, mp[2])
+				if (malive & 8u) MT_ROW(g3, w5d, mp[3])
+#undef MT_ROW
+				int m = g0 > g1 ? g0 : g1; m = m > g2 ? m : g2; m = m > g3 ? m : g3;
+				const u32 na = (g0 == m ? 1u : 0u) | (g1 == m ? 2u : 0u) | (g2 == m ? 4u : 0u) | (g3 == m ? 8u : 0u);      // (rows not alive hold -1 < m)
+				pos += m; mp[0] += m; mp[1] += m; mp[2] += m; mp[3] += m;
+				if (m < 64 || __popc(na) == 1) {
+					// the rows that reach the longest match are the final interval (contiguous: the rows are sorted by suffix)
+					const int first = __ffs((int)na) - 1;
+					ik.x0 += (u64)first; ik.x2 = (u64)__popc(na);
+					if (m == 64) { tp = first == 0 ? mp[0] : first == 1 ? mp[1] : first == 2 ? mp[2] : mp[3]; mode = M_TEXT; }      // one row left and still matching: the unique-interval path
+					else ended = true;
+				} else malive = na;
+				if (mode == M_MTEXT && !ended && malive != na) malive = na;
 			} else if (mode == M_TEXT) {
 				int got = text_match32(r0, r1, r2, tp, (i64)di.seq_len, qp_l, qn_l, pos, lclen);
 				if (got == 32) got += text_match32(r2, r3, r4, tp + 32, (i64)di.seq_len, qp_l, qn_l, pos + 32, lclen);
@@ -371,7 +420,7 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 				const bool can = pos < lclen && !q_isn(qn_l, pos < lclen ? pos : 0);
 				const bool ok = can && fm_extend_loaded(di, ik, q_code(qp_l, pos < lclen ? pos : 0), bk, bl, kk, ll, kn, ln, blk);
 				ended = !ok;
-				if (ok) { pos++; if (!COUNT && ik.x2 == 1) mode = M_LOC; }
+				if (ok) { pos++; if (!COUNT && ik.x2 == 1) mode = M_LOC; else if (!COUNT && SEED_MULTI > 1 && ik.x2 <= SEED_MULTI) mode = M_MLOC; }
 			}
 			if (ended) {
 				const int len = pos - s;
