@@ -152,7 +152,7 @@ struct gsa_ctx {
 	u32 seed_budget = 256;                         // wave-iterations a chunk may take in the speculative kernel before it goes to the dense path (GSA_SEED_BUDGET)
 	DevBuf d_chunk_hits, d_chunk_base;             // located hits per chunk and their exclusive prefix   // memoised matches of the search kernel + on-path bits
 	DevBuf d_key_a, d_key_b, d_val_a, d_val_b;     // sort ping-pong
-	i64 n_seeds = 0;
+	i64 n_seeds = 0; bool hits_sorted = false;     // the hits in d_key_a / d_val_a are in (qPos, rank) order (k_seed_select over the whole contig; not after an import)
 	DevBuf s_q, s_len, s_r, s_gid;                 // seeds in (PosDiff,qPos) order + group id
 	DevBuf d_flag, d_scan;                         // generic i32 flag / scan arrays (n+1)
 	i32 n_groups = 0;

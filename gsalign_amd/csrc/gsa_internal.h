@@ -86,9 +86,7 @@ int gsa_fail(gsa_ctx *ctx, int code, const std::string &msg);
 
 // ---- rocPRIM-backed primitives (gsa_prim.hip) --------------------------------
 // All asynchronous on `stream`; `tmp` is a reusable scratch buffer that grows.
-int prim_sort_pairs_u64_u32(gsa_ctx *, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n, int begin_bit, int end_bit);
-int prim_exscan_i32(gsa_ctx *, const i32 *in, i32 *out, size_t n);        // out[i] = sum in[0..i)
-int prim_exscan_i32_i64(gsa_ctx *, const i32 *in, i64 *out, size_t n);
+int gsa_sort_pairs_u64_u32(gsa_ctx *, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n, int begin_bit, int end_bit);      // gsa_sort.hip: stable LSD radix sort, kin / vin untouched
 
 static inline int ceil_log2_u64(u64 v) { int b = 0; while ((1ull << b) < v && b < 63) b++; return b; }
 static inline unsigned grid_for(size_t n, unsigned block) { size_t g = (n + block - 1) / block; return (unsigned)(g ? g : 1); }

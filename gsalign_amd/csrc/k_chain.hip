@@ -671,7 +671,9 @@ int stage2_chain(gsa_ctx *c)
 		  if (nblk <= (1 << 20)) RC((lb_launch<1, 1>(c, nblk, op, nullptr, 8))); else RC((lb_launch<1, 4>(c, nblk, op, nullptr, 8))); }      // (a small bitmap: a block per thread -- four in a row are four times two dependent looks)
 		{}      // (eight workgroups per CU: a block costs two dependent looks and nothing else)      // (16 bitmap words per thread: a popcount each -- the pass is the 94 MB read of a 250 Mb contig's bitmap, not 23 000 tiles of look-back)
 		LAUNCH(k_pd_keys, n, n, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->d_pdbm.as<u32>(), c->d_gpre.as<i32>(), c->prm.MaxIndelSize, c->qbits, c->d_key_c.as<u64>(), c->d_val_c.as<u32>());
-		RC(prim_sort_pairs_u64_u32(c, c->d_key_c.as<u64>(), c->d_key_b.as<u64>(), c->d_val_c.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + 7 + gbits));
+		// (hits straight from k_seed_select are in (qPos, rank) order already: the stable sort only has to order the group ids -- three passes for 22 bits.
+		//  Hits that arrived from other GPUs' chunk ranges sit behind each other in arrival order: the whole key)
+		RC(gsa_sort_pairs_u64_u32(c, c->d_key_c.as<u64>(), c->d_key_b.as<u64>(), c->d_val_c.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, c->hits_sorted ? c->qbits + 7 : 0, c->qbits + 7 + gbits));
 		LAUNCH(k_pd_heads, n, n, c->d_key_b.as<u64>(), c->qbits + 7, c->g_beg.as<i32>());
 		LAUNCH(k_pd_gather, n, n, c->d_key_b.as<u64>(), c->d_val_b.as<u32>(), c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->qbits + 7, c->qbits, c->bnd, c->g_beg.as<i32>(),
 		       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), c->d_pdbm.as<u32>(), c->d_pdcb.as<u32>());
@@ -680,7 +682,7 @@ int stage2_chain(gsa_ctx *c)
 		RC(seed_view_sort(c));
 		ENS(u64, d_key_a, n); ENS(u64, d_key_b, n); ENS(u32, d_val_a, n); ENS(u32, d_val_b, n);
 		LAUNCH(k_group_keys, n, n, c->s_q.as<i32>(), c->s_gid.as<i32>(), c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>());
-		RC(prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + gbits));
+		RC(gsa_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), (size_t)na, 0, c->qbits + gbits));
 		LAUNCH(k_gather_active, na, na, c->d_val_b.as<u32>(), c->s_q.as<i32>(), c->s_len.as<i32>(), c->s_r.as<i64>(), c->s_gid.as<i32>(), c->g_beg.as<i32>(),
 		       c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>());
 	}

@@ -1074,35 +1074,66 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 	// (bnd.lmax = length of the whole contig, s_off = contig position of the first chunk searched: not 0 when only a chunk range
 	//  of the contig was seeded on this GPU, gsa_seed_chunks.  A bundle of contigs: the key's PosDiff is the true one of the
 	//  chunk's contig plus that contig's stride, see Bundle)
-	extern __shared__ u32 s_offs[];                    // exclusive prefix of the hit counts of the chunk's candidates (0 for off-chain ones), [nc + 1]
+	// Round 4: the hits leave this kernel in (qPos, rank) order -- chunk after chunk (the launch order), inside a chunk by the start position
+	// of their candidate (the on-chain starts are marked in a bitmap over the chunk's positions: a candidate's place is the number of marked
+	// starts below its own), inside a start by the rank of the hit.  Stage 2 then needs ONE stable sort by the group id alone (three 8-bit passes
+	// instead of eight over the whole 57-bit key).  Off-chain candidates take no part.
+	extern __shared__ u32 s_offs[];                    // [nc + 1] exclusive prefix of the hit counts of the on-chain candidates in start order | [nc] their candidate numbers
+	u32 *s_ord = s_offs + cand_cap + 2;
 	__shared__ unsigned long long s_w[SEL_HASH]; __shared__ u32 s_b[SEL_HASH];
-	__shared__ u32 s_wsum[4], s_run;
+	__shared__ u32 s_wsum[4], s_run, s_sb[GSA_CHUNK / 32 + 2], s_sbpre[GSA_CHUNK / 32 + 2];
 	const u32 chunk = blockIdx.x, nc = cand_cnt[chunk];
 	const size_t cbase = (size_t)chunk * cand_cap;
 	const int j = threadIdx.x, lane = j & 63, wv = j >> 6;
 	for (int t = j; t < SEL_HASH; t += 256) { s_w[t] = ~0ull; s_b[t] = 0; }
+	for (int t = j; t < GSA_CHUNK / 32 + 2; t += 256) s_sb[t] = 0;
 	if (j == 0) s_run = 0;
 	__syncthreads();
-	for (u32 i0 = 0; i0 < nc; i0 += 256) {
-		const u32 i = i0 + j;
-		u32 f = 0;
-		if (i < nc) {
-			const i32 p = cand_s[cbase + i] - (i32)chunk * GSA_CHUNK;
-			if ((onpath[(size_t)chunk * PATH_WORDS + (p >> 5)] >> (p & 31)) & 1u) f = (u32)cand_freq[cbase + i];
-		}
-		u32 inc = f;
+	for (u32 i = j; i < nc; i += 256) {
+		const i32 p = cand_s[cbase + i] - (i32)chunk * GSA_CHUNK;
+		if ((onpath[(size_t)chunk * PATH_WORDS + (p >> 5)] >> (p & 31)) & 1u) atomicOr(&s_sb[p >> 5], 1u << (p & 31));
+	}
+	__syncthreads();
+	if (wv == 0) {      // marked starts below each word: 313 words, five per lane
+		constexpr int WPL = (GSA_CHUNK / 32 + 2 + 63) / 64;
+		u32 c5 = 0;
+		for (int k = 0; k < WPL; k++) { const int w = lane * WPL + k; if (w < GSA_CHUNK / 32 + 2) c5 += (u32)__popc(s_sb[w]); }
+		u32 inc = c5;
 		for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+		u32 run = inc - c5;
+		for (int k = 0; k < WPL; k++) { const int w = lane * WPL + k; if (w < GSA_CHUNK / 32 + 2) { s_sbpre[w] = run; run += (u32)__popc(s_sb[w]); } }
+		if (lane == 63) s_run = inc;      // on-chain candidates of the chunk
+	}
+	__syncthreads();
+	const u32 n_on = s_run;
+	for (u32 i = j; i < nc; i += 256) {
+		const i32 p = cand_s[cbase + i] - (i32)chunk * GSA_CHUNK;
+		if ((s_sb[p >> 5] >> (p & 31)) & 1u) {
+			if ((onpath[(size_t)chunk * PATH_WORDS + (p >> 5)] >> (p & 31)) & 1u) {
+				const u32 o = s_sbpre[p >> 5] + (u32)__popc(s_sb[p >> 5] & ((1u << (p & 31)) - 1u));
+				s_ord[o] = i;
+			}
+		}
+	}
+	__syncthreads();
+	if (j == 0) s_run = 0;
+	__syncthreads();
+	for (u32 i0 = 0; i0 < n_on; i0 += 256) {
+		const u32 o = i0 + j;
+		const u32 f = o < n_on ? (u32)cand_freq[cbase + s_ord[o]] : 0u;
+		u32 inc = f;
+		for (int oo = 1; oo < 64; oo <<= 1) { const u32 t = __shfl_up(inc, oo); if (lane >= oo) inc += t; }
 		if (lane == 63) s_wsum[wv] = inc;
 		__syncthreads();
 		u32 wo = 0; for (int w = 0; w < wv; w++) wo += s_wsum[w];
 		const u32 run = s_run;
-		if (i < nc) s_offs[i] = run + wo + inc - f;
+		if (o < n_on) s_offs[o] = run + wo + inc - f;
 		__syncthreads();
 		if (j == 255) s_run = run + wo + inc;
 		__syncthreads();
 	}
 	const u32 total = s_run;
-	if (j == 0) s_offs[nc] = total;
+	if (j == 0) s_offs[n_on] = total;
 	__syncthreads();
 	const u64 base = (u64)hit_base[chunk];
 	i64 pd_base = bnd.lmax;                              // key = rPos - qPos + pd_base
@@ -1113,9 +1144,9 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 		u32 i = 0, h = 0, f = 0, len = 0; i32 s = 0; u64 x0 = 0, r = 0;
 		if (t < total) {
 			// the candidate whose range holds hit t: the last i with s_offs[i] <= t (empty ranges share their start with the next one)
-			u32 lo = 0, hi = nc;
+			u32 lo = 0, hi = n_on;
 			while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_offs[mid] <= t) lo = mid; else hi = mid; }
-			i = lo; h = t - s_offs[i];
+			i = s_ord[lo]; h = t - s_offs[lo];
 			s = cand_s[cbase + i] + s_off; f = (u32)cand_freq[cbase + i]; len = (u32)cand_len[cbase + i]; x0 = cand_x0[cbase + i];
 			r = (x0 >> 63) ? (x0 & ~(1ull << 63)) : fm_locate(di, x0 + h);      // (bit 63: a unique match whose text position the sweep already knows)
 		}
@@ -1132,8 +1163,9 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 				rank += r2 < r ? 1u : 0u;
 			}
 		}
-		key[base + t] = ((u64)pd << qbits) | (u32)s;
-		val[base + t] = len | (rank << 16);
+		const u64 at = base + (t - h) + rank;                 // (the hits of a start in rank order: distinct text positions, so the ranks are a permutation)
+		key[at] = ((u64)pd << qbits) | (u32)s;
+		val[at] = len | (rank << 16);
 		// occupied PosDiff values: groups without sorting by PosDiff (k_chain.hip).  Collected per workgroup in LDS, one
 		// global OR per touched word at the end: a chunk's hits sit in two or three words and the whole contig's main
 		// diagonal in one cache line -- an atomic (or even a look) per hit queues 75 k operations on that line.  Hits of
@@ -1608,7 +1640,7 @@ int stage1_seed(gsa_ctx *c)
 	if (int rcp = prepare_pd_bitmap(c, n_hits)) return rcp;
 	if (n_hits > 0) {
 		if (!dev_ensure<u64>(c, c->d_key_a, hcap) || !dev_ensure<u32>(c, c->d_val_a, hcap)) return GSA_ERR_NOMEM;
-		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), (ccap + 2) * sizeof(u32), st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
+		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), 2 * (ccap + 2) * sizeof(u32), st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
 		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), c->bnd, s_off, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr, c->d_pdcb.as<u32>());
 	}
 	if (c->profiling) hipEventRecord(c->ev[2], st);
@@ -1623,7 +1655,7 @@ int stage1_seed(gsa_ctx *c)
 		lf_steps = c->h_cnt[CNT_DONE];
 	}
 	c->counters[1] = lf_steps; c->counters[2] = (u64)n_hits; c->counters[3] = (u64)n_hits; c->counters[7] = occ_all;
-	c->n_seeds = n_hits;
+	c->n_seeds = n_hits; c->hits_sorted = !split;
 	if (split) return GSA_OK;                 // (the tail of stage 1 runs in gsa_finish_contig, on the hits of all ranges)
 	if (n_hits == 0) { if (c->profiling) { GSA_CHECK(c, hipStreamSynchronize(st)); float ms; hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->kernel_ms[0] = ms; } return GSA_OK; }
 	if (n_hits >= (1ll << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");
@@ -1643,7 +1675,7 @@ int seed_view_sort(gsa_ctx *c)
 	hipStream_t st = c->stream;
 	const size_t n = (size_t)c->n_seeds, hcap = n + 64;
 	if (!dev_ensure<u64>(c, c->d_key_b, hcap) || !dev_ensure<u32>(c, c->d_val_b, hcap)) return GSA_ERR_NOMEM;
-	int rc = prim_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), n, 0, c->qbits + c->pdbits);
+	int rc = gsa_sort_pairs_u64_u32(c, c->d_key_a.as<u64>(), c->d_key_b.as<u64>(), c->d_val_a.as<u32>(), c->d_val_b.as<u32>(), n, 0, c->qbits + c->pdbits);
 	if (rc) return rc;
 	if (!dev_ensure<i32>(c, c->s_q, n) || !dev_ensure<i32>(c, c->s_len, n) || !dev_ensure<i64>(c, c->s_r, n) || !dev_ensure<i32>(c, c->s_gid, n) ||
 	    !dev_ensure<i32>(c, c->d_flag, n + 1) || !dev_ensure<i32>(c, c->d_scan, n + 1) || !dev_ensure<i32>(c, c->g_beg, n + 1)) return GSA_ERR_NOMEM;
