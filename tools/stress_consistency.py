@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Flake hunt (GPU box): the same contigs aligned over and over on three contexts at once must give byte-identical results
+"""Flake hunt (GPU box): the same contigs aligned over and over on four contexts at once (uploads prefetched since round 4) must give byte-identical results
 every time (blocks, records, both string pools) -- the synchronisation of the striped DP, the fused passes and the seed
 kernels runs without agent-scope fences, so a missing ordering would show up here as a rare difference.
 usage: stress_consistency.py [workload=human] [genome_len] [rounds=12]"""
@@ -15,9 +15,11 @@ wl = dict(bench.WORKLOADS[name])
 if len(sys.argv) > 2 and int(sys.argv[2]) > 0: wl["lengths"] = [int(sys.argv[2])]
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 tmp = tempfile.mkdtemp(prefix="stress_")
-px, idx, refs = bench.build_reference(tmp, name, wl, 0, 1)
-contigs = [c for gq in bench.make_queries(wl, refs, 0) for c in gq]
-g0 = capi.Aligner(idx, **wl["params"]); ctxs = [g0, g0.clone(), g0.clone()]
+import types
+args = types.SimpleNamespace(fasta_ref="", fasta_query="")
+px, idx, refs = bench.build_reference(tmp, name, wl, 0, 1, args)
+contigs = [c for gq in bench.make_queries(wl, refs, args) for c in gq]
+g0 = capi.Aligner(idx, **wl["params"]); ctxs = [g0, g0.clone(), g0.clone(), g0.clone()]
 pinned = [g0.pinned_copy(c) for c in contigs]
 sums = {}; lock = threading.Lock(); bad = []
 
@@ -34,6 +36,6 @@ def on_result(ci, res):
     return 0
 
 capi.align_many(ctxs, pinned * rounds, on_result)
-print(f"{name}: {len(contigs)} contigs x {rounds} rounds on 3 contexts: {len(bad)} differences", sums if len(sums) < 6 else len(sums))
+print(f"{name}: {len(contigs)} contigs x {rounds} rounds on 4 contexts: {len(bad)} differences", sums if len(sums) < 6 else len(sums))
 for b in bad[:5]: print("  DIFF", b)
 sys.exit(1 if bad else 0)
