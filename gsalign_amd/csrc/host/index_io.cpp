@@ -121,6 +121,10 @@ template <class F> void parallel_ranges(int64_t n, int nt, F fn)
 // on 128 threads where SA-IS on one thread took 17.
 struct PackedText {
 	std::vector<uint64_t> w; int64_t S = 0;          // base p (code 0..3) at bits 62 - 2 (p & 31) of word p >> 5
+	// Round 4 (ADVICE): a comparison that runs deeper than `depth_limit` bases gives the sorter up -- exact repeats of megabase length (identical
+	// haplotigs, a duplicated chromosome) make the comparisons of a bucket cost copies x L^2 / 32 word compares, hours where SA-IS is linear --
+	// and the caller falls back to SA-IS for the whole text.
+	int64_t depth_limit = 1ll << 22; std::atomic<bool> *give_up = nullptr;
 	inline uint64_t get32(int64_t p) const           // the 32 bases from p on, zero beyond the end
 	{
 		if (p >= S) return 0;
@@ -131,6 +135,7 @@ struct PackedText {
 	inline bool less_from(int64_t i, int64_t j, int64_t d) const
 	{
 		for (;; d += 32) {
+			if (d > depth_limit) { if (give_up) give_up->store(true, std::memory_order_relaxed); return i < j; }      // (the order no longer matters: the result is thrown away)
 			const int64_t ri = S - (i + d), rj = S - (j + d);
 			if (ri <= 0 || rj <= 0) return ri < rj;
 			uint64_t a = get32(i + d), b = get32(j + d);
@@ -143,9 +148,11 @@ struct PackedText {
 };
 
 template <class I>
-void parallel_suffix_sort(const std::vector<uint8_t> &T, int64_t S, I *SA, int nt)
+bool parallel_suffix_sort(const std::vector<uint8_t> &T, int64_t S, I *SA, int nt)
 {
 	PackedText P; P.S = S; P.w.assign((size_t)(S / 32 + 3), 0);
+	std::atomic<bool> give_up(false); P.give_up = &give_up;
+	if (const char *e = getenv("GSA_INDEX_DEPTH")) { const long long v = atoll(e); if (v >= 64) P.depth_limit = v; }      // (tests: force the fallback)
 	parallel_ranges((S + 31) / 32, nt, [&](int, int64_t a, int64_t b) {
 		for (int64_t wi = a; wi < b; wi++) {
 			uint64_t v = 0; const int64_t p0 = wi * 32, p1 = p0 + 32 < S ? p0 + 32 : S;
@@ -174,7 +181,7 @@ void parallel_suffix_sort(const std::vector<uint8_t> &T, int64_t S, I *SA, int n
 		struct KI { uint64_t key; I idx; };
 		std::vector<KI> buf;
 		for (;;) {
-			const int o = next.fetch_add(1); if (o >= NB) return;
+			const int o = next.fetch_add(1); if (o >= NB || give_up.load(std::memory_order_relaxed)) return;
 			const int bkt = order[(size_t)o];
 			const int64_t lo = base[(size_t)bkt], m = base[(size_t)bkt + 1] - lo;
 			if (m < 2) continue;
@@ -193,6 +200,7 @@ void parallel_suffix_sort(const std::vector<uint8_t> &T, int64_t S, I *SA, int n
 	for (int t = 1; t < nt; t++) th.emplace_back(worker);
 	worker();
 	for (std::thread &x : th) x.join();
+	return !give_up.load();
 }
 
 // BWT without '$' (2 bits per symbol, MSB first in each word), primary row and the SA samples of every 32nd row, from the
@@ -205,8 +213,9 @@ void derive_bwt_sa(const std::vector<uint8_t> &T, int64_t S, std::vector<uint32_
 	const int nt = index_threads();
 	// (GSA_INDEX_PAR_MIN: the tests send small fixtures through the parallel sorter too)
 	const char *pm = getenv("GSA_INDEX_PAR_MIN");
-	if (nt > 1 && S >= (pm ? atoll(pm) : (1ll << 20))) parallel_suffix_sort<I>(T, S, SA.data(), nt);
-	else sais<uint8_t, I>(T.data(), SA.data(), n, (I)5);
+	bool sorted = false;
+	if (nt > 1 && S >= (pm ? atoll(pm) : (1ll << 20))) sorted = parallel_suffix_sort<I>(T, S, SA.data(), nt);
+	if (!sorted) sais<uint8_t, I>(T.data(), SA.data(), n, (I)5);      // (small texts, one thread, or comparisons that ran too deep: linear time whatever the repeats)
 	std::atomic<int64_t> prim(-1);
 	parallel_ranges((int64_t)n, nt, [&](int, int64_t a, int64_t b) { for (int64_t i = a; i < b; i++) if (SA[(size_t)i] == 0) prim.store(i); });
 	primary = (uint64_t)prim.load();

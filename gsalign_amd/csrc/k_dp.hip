@@ -194,7 +194,7 @@ __device__ __forceinline__ u32 lane_bin(u32 cells)      // floor(8 log2 cells): 
 __global__ void __launch_bounds__(256) k_dp_lane(i32 n_tiny, const i32 *__restrict__ order_tiny, i32 n_small, const i32 *__restrict__ order_small,
                                                   const uint8_t *__restrict__ pool1, const i64 *__restrict__ off1, const i32 *__restrict__ len1,
                                                   const uint8_t *__restrict__ pool2, const i64 *__restrict__ off2, const i32 *__restrict__ len2,
-                                                  uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, const i32 *__restrict__ jfrag, gsa_frag *frag, u32 *arena_all)
+                                                  uint8_t *ops, const i64 *__restrict__ ops_off, i32 *ops_len, const i32 *__restrict__ jfrag, gsa_frag *frag, u32 *arena_all, u32 kstride)
 {
 	__shared__ u32 s_hist[LANE_BINS];
 	__shared__ i32 s_sorted[LANE_TILE];
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) k_dp_lane(i32 n_tiny, const i32 *__restri
 	__shared__ __attribute__((aligned(16))) uint8_t s_work[4][LANE_LDS_WAVE];
 	const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const i64 n_all = (i64)n_tiny + n_small;
-	u32 *arena = arena_all + ((size_t)blockIdx.x * 4 + w) * 64 * LANE_KMAX + lane;      // dword k of my job: arena[k * 64]
+	u32 *arena = arena_all + ((size_t)blockIdx.x * 4 + w) * 64 * kstride + lane;      // dword k of my job: arena[k * 64]; kstride = the most dwords a job of this launch's class can need
 	uint16_t *col = (uint16_t *)s_work[w] + lane;                                         // column i of my job: col[i * 64]
 	uint8_t *revb = s_work[w] + lane;                                                     // reversed op k of my job: revb[k * 64]
 	for (i64 t0 = (i64)blockIdx.x * LANE_TILE; t0 < n_all; t0 += (i64)gridDim.x * LANE_TILE) {
@@ -961,9 +961,14 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 		if (ntiny > 0) {
 			const i64 tiles = ((i64)ntiny + LANE_TILE - 1) / LANE_TILE;
 			const unsigned nwg = (unsigned)(tiles < LANE_WGS ? tiles : LANE_WGS);
-			u32 *arena = dev_ensure<u32>(c, c->d_dp_arena, (size_t)nwg * 4 * 64 * LANE_KMAX);
+			// direction dwords of one job at most: m * ceil(n / 8) over the shapes of the class (n <= 64, m + n - 1 <= 128, m * n <= dp_lane cells): 128 for
+			// the default 512 cells, LANE_KMAX = 576 without a cell limit -- the arena was always sized for the latter: 604 MB per context instead of 134
+			u32 kstride = 1;
+			for (int nn = 1; nn <= 64; nn++) { int mm = 128 - nn + 1; if (dp_lane > 0 && dp_lane / nn < mm) mm = dp_lane / nn; if (mm < 1) continue; const u32 kd = (u32)mm * (u32)((nn + 7) / 8); if (kd > kstride) kstride = kd; }
+			if (kstride > LANE_KMAX) kstride = LANE_KMAX;
+			u32 *arena = dev_ensure<u32>(c, c->d_dp_arena, (size_t)nwg * 4 * 64 * kstride);
 			if (!arena) return GSA_ERR_NOMEM;
-			hipLaunchKernelGGL(k_dp_lane, dim3(nwg), dim3(256), 0, c->stream_aux[1], ntiny, d_order_tiny, 0, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag, arena);
+			hipLaunchKernelGGL(k_dp_lane, dim3(nwg), dim3(256), 0, c->stream_aux[1], ntiny, d_order_tiny, 0, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag, arena, kstride);
 		}
 		if (nsmall > 0) {
 			hipStream_t s2 = ntiny > 0 ? st : c->stream_aux[1];

@@ -117,3 +117,23 @@ def test_dotplot_golden(oracle_built, golden_dir, tmp_path, monkeypatch):
     assert scripts == gold["scripts"]
     assert data == gold["data"]
 
+
+
+def test_index_builder_gives_up_on_deep_repeats(oracle_built, tmp_path, monkeypatch):
+    """Round 4 (ADVICE): a reference with long EXACT duplicates -- here a 400 kb contig twice, and a 150 kb piece of it a third time -- makes the parallel
+    sorter's packed-text comparisons run as deep as the copies are long; beyond its depth limit (GSA_INDEX_DEPTH, 4 M bases by default; 20 000 here) it
+    gives up and the whole text goes through SA-IS: same files as the reference's own bwt_index either way."""
+    from gsalign_amd import synth
+    if not oracle_built.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    a = synth.fast_genome(400_000, 31)
+    refs = [("c1", a), ("c2", a.copy()), ("c3", synth.fast_genome(100_000, 32)), ("c4", a[120_000:270_000].copy())]
+    fa = str(tmp_path / "d.fa"); synth.write_fasta(fa, refs)
+    oracle_built.ref_build_index(fa, str(tmp_path / "ref"))
+    monkeypatch.setenv("GSA_INDEX_PAR_MIN", "1000"); monkeypatch.setenv("GSA_INDEX_THREADS", "4")
+    for tag, depth in (("deep", None), ("fallback", "20000")):
+        if depth:
+            monkeypatch.setenv("GSA_INDEX_DEPTH", depth)
+        hostlib.build_index(fa, str(tmp_path / tag))
+        for ext in ("pac", "ann", "amb", "bwt", "sa"):
+            assert filecmp.cmp(str(tmp_path / f"{tag}.{ext}"), str(tmp_path / f"ref.{ext}"), shallow=False), (tag, ext)
