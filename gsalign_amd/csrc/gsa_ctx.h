@@ -77,6 +77,7 @@ struct Options {
 	int dp_lane = 512;                 // alignments of at most this many cells go one per lane (k_dp_lane); 0: round 2's tiny / small split
 	int seed_mode = 1;                 // 0 sweep: every chunk through k_dense_sweep; 1: the speculative kernel + dense kernels for what it gives up on; 2: round 2's k_dense_search in place of the sweep
 	int pd_bitmap = 1;                 // 0: groups by the PosDiff sort although MaxIndelSize <= 31 would allow the bitmap scan
+	int walk_coop = 0;                 // 1: the window walk's pointer-doubling rounds as one cooperative launch (measured slower, alone and under load); 0: a launch per round
 	int kmer_k = 0;                    // gsa_create_opts (GSA_CREATE_KMER_K): length of the jump table's k-mers (0: by text length and free memory)
 };
 
@@ -157,6 +158,7 @@ struct gsa_ctx {
 	DevBuf d_flag, d_scan;                         // generic i32 flag / scan arrays (n+1)
 	i32 n_groups = 0;
 	bool pd_path = false, seed_view_ready = false, pdbm_dirty = true; i64 pd_words = 0;      // groups from the PosDiff bitmap (no PosDiff sort on the hot path)
+	DevBuf d_wbar; u32 wbar_cnt = 0, wbar_gen = 0;  // k_walkg_ladder's barrier words (arrivals, generation: never reset) and what the host knows they hold
 	DevBuf w_j0, w_j1, w_on;                      // window chain of large contigs: leave(), its double, orbit flags
 	DevBuf d_pdcb;                                 // coarse bitmap: one bit per block of 32 words of d_pdbm (the blocks that hold a hit)
 	DevBuf d_pdbm, d_gpre, d_key_c, d_val_c;      // bitmap of occupied PosDiff values, group starts below each word, (group, qPos, rank) keys

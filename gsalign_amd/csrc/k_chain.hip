@@ -634,6 +634,43 @@ __global__ void k_walkg_double(i64 na, const i32 *__restrict__ candEx, const i32
 	const i32 j = Jin[k];
 	if (j < nC) { if (on[k]) on[j] = 1; Jout[k] = Jin[j]; } else Jout[k] = nC;
 }
+// The doubling rounds as ONE launch (round 4; one kernel per round until then: 13-14 launches per 250 Mb contig, and with four contexts in flight
+// every one of those tiny launches waited ~80 us for its turn: profiles/r04_kernels_human_full.txt).  A grid of WALKG_COOP workgroups per CU -- all
+// resident: no LDS, 256 threads -- strides over the candidates, and a counter barrier separates the rounds.  What one round writes and the next one reads
+// goes through agent-scope atomic accesses (coherent across the XCDs' L2s by themselves, like the look-back words), and every wave's stores are
+// complete (vmcnt) before its workgroup arrives at the barrier, so no fence is needed.  The barrier words are never reset: the host passes the arrival
+// count and the generation they have at launch.  MEASURED SLOWER than the launches it replaces, alone (chaining of a 250 Mb contig 1.58 -> 1.73-1.82 ms:
+// a round is a barrier plus dependent agent-scope loads on 65-130 k threads instead of one thread per candidate) and with four contexts (full human 26.9 ->
+// 25.8 Gbp/s, 250 Mb contigs 33.7 -> 32.8): a kernel boundary is the cheapest grid barrier this part has.  Off by default (gsa_set_option "walk_coop").
+#define WALKG_COOP 2
+__device__ __forceinline__ i32 wg_ald(const i32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wg_ast(i32 *p, i32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void __launch_bounds__(256) k_walkg_ladder(i64 na, const i32 *__restrict__ candEx, i32 *J0, i32 *J1, i32 *on, int rounds, u32 *bar, u32 cnt0, u32 gen0, i32 *err)
+{
+	const i32 nC = candEx[na];
+	const i32 G = (i32)(gridDim.x * 256), gtid = (i32)(blockIdx.x * 256 + threadIdx.x);
+	for (int r = 0; r < rounds; r++) {
+		const i32 *Jin = (r & 1) ? J1 : J0; i32 *Jout = (r & 1) ? J0 : J1;
+		for (i32 k = gtid; k < nC; k += G) {
+			const i32 j = wg_ald(&Jin[k]);
+			if (j < nC) { if (wg_ald(&on[k])) wg_ast(&on[j], 1); wg_ast(&Jout[k], wg_ald(&Jin[j])); } else wg_ast(&Jout[k], nC);
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const u32 t = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (t == cnt0 + gridDim.x * (u32)(r + 1) - 1u) __hip_atomic_store(&bar[1], gen0 + (u32)r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			else {
+				u32 spins = 0;
+				while ((i32)(__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (gen0 + (u32)r + 1u)) < 0) {
+					if (++spins > (1u << 24)) { *err = 1; break; }
+					__builtin_amdgcn_s_sleep(2);
+				}
+			}
+		}
+		__syncthreads();
+	}
+}
 __global__ void k_walkg_mark(i64 na, i32 nt, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, const i32 *__restrict__ nextk, const i32 *__restrict__ on, i32 *ws)
 {
 	const i32 t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -704,7 +741,17 @@ int stage2_chain(gsa_ctx *c)
 		i32 *J0 = c->w_j0.as<i32>(), *J1 = c->w_j1.as<i32>(), *on = c->w_on.as<i32>();
 		const i32 *nextk = c->d_flag2.as<i32>();
 		LAUNCH(k_walkg_leave, nt, na, nt, candEx, nextk, J0, on);
-		for (i32 span = 1; span < nt; span <<= 1) { LAUNCH(k_walkg_double, na, na, candEx, J0, J1, on); std::swap(J0, J1); }
+		if (!c->opt.walk_coop) { for (i32 span = 1; span < nt; span <<= 1) { LAUNCH(k_walkg_double, na, na, candEx, J0, J1, on); std::swap(J0, J1); } }
+		else {
+			int rounds = 0; for (i32 span = 1; span < nt; span <<= 1) rounds++;
+			if (!c->d_wbar.p) { ENS(u32, d_wbar, 4); GSA_CHECK(c, hipMemsetAsync(c->d_wbar.p, 0, 16, st)); c->wbar_cnt = c->wbar_gen = 0; }
+			if (c->n_cus <= 0) { hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device)); c->n_cus = pr.multiProcessorCount; }
+			const unsigned grid = (unsigned)c->n_cus * WALKG_COOP;
+			if (rounds > 0) {
+				hipLaunchKernelGGL(k_walkg_ladder, dim3(grid), dim3(256), 0, st, na, candEx, J0, J1, on, rounds, c->d_wbar.as<u32>(), c->wbar_cnt, c->wbar_gen, c->d_mail.as<i32>() + M_LBERR);
+				c->wbar_cnt += grid * (u32)rounds; c->wbar_gen += (u32)rounds;
+			}
+		}
 		LAUNCH(k_walkg_mark, nt, na, nt, candEx, clist, nextk, on, ws);
 	}
 	// C. outliers
