@@ -801,19 +801,29 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 #define SWEEP_POSFLAG (1ull << 63)
 enum { M_BFM = 7, M_BACK = 8, M_LOC2 = 9 };
 enum { HV_NONE = 0, HV_UNIQ = 1, HV_MULTI = 2 };
-template <bool E16>
-__global__ void __launch_bounds__(256) k_dense_sweep(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, const u32 *__restrict__ chunk_list,
+#ifdef SWEEP_NOSTORE      // (timing experiment: results are wrong)
+#define SWEEP_ST(...)
+#else
+#define SWEEP_ST(...) __VA_ARGS__
+#endif
+#ifndef SWEEP_MIN_WAVES
+#define SWEEP_MIN_WAVES 4      // waves per SIMD the register allocation must allow (4: ~104 VGPRs, no scratch)
+#endif
+template <bool E16, int TPB>
+__global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, const u32 *__restrict__ chunk_list,
                                                       uint16_t *dn_memo, u32 *dn_lf, u64 *dn_x0, u64 *cnt, int seg, int wgs_per_chunk)
 {
-	// seg = starts per lane (256 seg starts per workgroup, wgs_per_chunk workgroups per chunk): long segments do the least work
-	// (one forward search per segment), short ones finish soonest -- the few chunks the speculative kernel hands over take short ones
+	// seg = starts per lane (TPB x seg starts per workgroup, wgs_per_chunk workgroups per chunk): long segments do the least work
+	// (one forward search per segment), short ones finish soonest.  Round 4: ONE WAVE per chunk with 160 starts per lane (TPB = 64) where
+	// round 3 ran four waves with 40: inside a high-copy repeat a segment costs ~150 Occ steps for its first (forward) search and one
+	// backward step per start, so 40 starts cost a lane 190 dependent steps and 160 cost it 310 -- a quarter of the lanes, 2.5x fewer steps
 	__shared__ u32 qp[QP_WORDS], qn[QN_WORDS];
 	const u32 slot = blockIdx.x / (u32)wgs_per_chunk, part = blockIdx.x % (u32)wgs_per_chunk;
 	const u32 chunk = chunk_list ? chunk_list[slot] : slot;
 	const int j = threadIdx.x;
 	const i64 c0 = (i64)chunk * GSA_CHUNK;
 	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
-	for (int g = j; g < QN_WORDS; g += 256) {
+	for (int g = j; g < QN_WORDS; g += TPB) {
 		u32 w0 = 0, w1 = 0, wn = 0;
 		const int p0 = g << 5;
 		if (p0 < clen) {
@@ -825,7 +835,7 @@ __global__ void __launch_bounds__(256) k_dense_sweep(DevIndex di, const uint8_t 
 	}
 	__syncthreads();
 	uint16_t *memo = dn_memo + (size_t)slot * GSA_CHUNK; u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; u64 *x0o = dn_x0 + (size_t)slot * GSA_CHUNK;
-	const int seg_a = ((int)part * 256 + j) * seg;
+	const int seg_a = ((int)part * TPB + j) * seg;
 	int cur = (seg_a + seg < clen ? seg_a + seg : clen) - 1;      // next start to settle; the lane is through when cur < seg_a
 	int s = 0, pos = 0, mode = M_ADV, have = HV_NONE, e_end = 0, prole = 0; u32 kid = 0, pid = 0, blk = 0, all_blocks = 0;
 	u64 pqb = 0;
@@ -836,8 +846,8 @@ __global__ void __launch_bounds__(256) k_dense_sweep(DevIndex di, const uint8_t 
 #define SWEEP_SETTLE(S_, LEN_, X2_, X0_)                                                                                   \
 	{                                                                                                                   \
 		int d_ = 1; u32 rec_ = 0;                                                                                       \
-		if ((LEN_) >= prm.MinSeedLength && (X2_) <= (u64)GSA_MAX_SEED_FREQ) { d_ = prm.bSensitive ? 5 : (LEN_) + 1; rec_ = (u32)(LEN_) | ((u32)(X2_) << 16); x0o[S_] = (X0_); } \
-		memo[S_] = (uint16_t)d_; lf[S_] = rec_;                                                                         \
+		if ((LEN_) >= prm.MinSeedLength && (X2_) <= (u64)GSA_MAX_SEED_FREQ) { d_ = prm.bSensitive ? 5 : (LEN_) + 1; rec_ = (u32)(LEN_) | ((u32)(X2_) << 16); SWEEP_ST(x0o[S_] = (X0_);) } \
+		SWEEP_ST(memo[S_] = (uint16_t)d_; lf[S_] = rec_;)                                                                         \
 	}
 	while (!__all(mode == M_DONE)) {
 		// ---- request phase: one pending request per lane, all lanes issue together ----
@@ -884,12 +894,12 @@ __global__ void __launch_bounds__(256) k_dense_sweep(DevIndex di, const uint8_t 
 			if (!present(prole)) {
 				// the first MinSeedLength bases of s do not occur: no seed, nothing to extend; the same line answers for the starts to
 				// the left while they pass the N / length tests (their own hop is 1 as well when they do not)
-				memo[s] = 1; lf[s] = 0; cur = s - 1; have = HV_NONE; mode = M_ADV;
+				SWEEP_ST(memo[s] = 1; lf[s] = 0;) cur = s - 1; have = HV_NONE; mode = M_ADV;
 				for (int r = prole - 1; r >= 0 && cur >= seg_a; r--) {
 					const u32 nb = q_nbits32(qn, cur);
 					if ((nb & 1u) || cur + prm.MinSeedLength > clen || (nb & Lmask) != 0) break;      // (the advance step settles those)
 					if (present(r)) break;                                                            // occurs: needs its own search
-					memo[cur] = 1; lf[cur] = 0; cur--;
+					SWEEP_ST(memo[cur] = 1; lf[cur] = 0;) cur--;
 				}
 			} else {
 				const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k
@@ -964,10 +974,10 @@ __global__ void __launch_bounds__(256) k_dense_sweep(DevIndex di, const uint8_t 
 		for (int step = 0; step < 3 && mode == M_ADV; step++) {
 			if (cur < seg_a) { mode = M_DONE; break; }
 			const u32 nb = q_nbits32(qn, cur);
-			if (nb & 1u) { memo[cur] = 1; lf[cur] = 0; have = HV_NONE; cur--; continue; }      // ambiguous base: no search from here, nothing extends over it
+			if (nb & 1u) { SWEEP_ST(memo[cur] = 1; lf[cur] = 0;) have = HV_NONE; cur--; continue; }      // ambiguous base: no search from here, nothing extends over it
 			if (have == HV_UNIQ) { mode = M_BACK; break; }
 			if (have == HV_MULTI) { mode = M_BFM; break; }
-			if (cur + prm.MinSeedLength > clen || (nb & Lmask) != 0) { memo[cur] = 1; lf[cur] = 0; cur--; continue; }      // MinSeedLength out of reach
+			if (cur + prm.MinSeedLength > clen || (nb & Lmask) != 0) { SWEEP_ST(memo[cur] = 1; lf[cur] = 0;) cur--; continue; }      // MinSeedLength out of reach
 			s = cur; ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
 			if (di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
 				kid = (u32)(q_bits64(qp, s) & ((1ull << (2 * di.kmer_k)) - 1)); mode = M_KMER;
@@ -1609,9 +1619,9 @@ int stage1_seed(gsa_ctx *c)
 #else
 				const int seg_env = 0;
 #endif
-				const int seg = seg_env > 0 ? seg_env : 40, wpc = (GSA_CHUNK + 256 * seg - 1) / (256 * seg);
-				if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_sweep<true>), dim3((unsigned)(n_heavy * wpc)), dim3(256), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
-				else hipLaunchKernelGGL((k_dense_sweep<false>), dim3((unsigned)(n_heavy * wpc)), dim3(256), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
+				const int seg = seg_env > 0 ? seg_env : 160, wpc = (GSA_CHUNK + 64 * seg - 1) / (64 * seg);
+				if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_sweep<true, 64>), dim3((unsigned)(n_heavy * wpc)), dim3(64), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
+				else hipLaunchKernelGGL((k_dense_sweep<false, 64>), dim3((unsigned)(n_heavy * wpc)), dim3(64), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
 			}
 			else if (dense_all) { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 512>), GSA_DENSE_ARGS(512)); else hipLaunchKernelGGL((k_dense_search<false, 512>), GSA_DENSE_ARGS(512)); }
 			else { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 256>), GSA_DENSE_ARGS(256)); else hipLaunchKernelGGL((k_dense_search<false, 256>), GSA_DENSE_ARGS(256)); }
