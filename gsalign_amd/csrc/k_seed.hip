@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg
 #define DENSE_WGS(SPAN) ((GSA_CHUNK + (SPAN) - 1) / (SPAN))
 template <bool E16, int DENSE_SPAN>
 __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, const u32 *__restrict__ chunk_list,
-                                                              uint16_t *dn_memo, u32 *dn_lf, u64 *dn_x0, u64 *cnt)
+                                                              u32 *dn_lf, u64 *dn_x0, u64 *cnt)
 {
 	__shared__ u32 qp[QP_WORDS], qn[QN_WORDS];
 	const u32 slot = blockIdx.x / DENSE_WGS(DENSE_SPAN), part = blockIdx.x % DENSE_WGS(DENSE_SPAN);
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 		qn[g] = wn;
 	}
 	__syncthreads();
-	uint16_t *memo = dn_memo + (size_t)slot * GSA_CHUNK; u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; u64 *x0o = dn_x0 + (size_t)slot * GSA_CHUNK;
+	u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; u64 *x0o = dn_x0 + (size_t)slot * GSA_CHUNK;
 	int nextp = span0 + j;                                  // this lane's starts: nextp, nextp + DENSE_TPB
 	int s = 0, pos = 0, mode = M_ADV; u32 kid = 0, pid = 0, pext = 0, blk = 0, all_blocks = 0;
 	FmIntv ik = {0, 0, 0}; i64 tp = 0;
@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 			const int len = pos - s;
 			int d = 1; u32 rec = 0;
 			if (len >= prm.MinSeedLength && ik.x2 <= GSA_MAX_SEED_FREQ) { d = prm.bSensitive ? 5 : len + 1; rec = (u32)len | ((u32)ik.x2 << 16); x0o[s] = ik.x0; }
-			memo[s] = (uint16_t)d; lf[s] = rec;
+			lf[s] = rec;      // (the hop follows from the record: k_dense_resolve)
 			all_blocks += blk;
 			mode = M_ADV;
 		}
@@ -763,7 +763,7 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 			if (nextp >= span1) { mode = M_DONE; break; }
 			s = nextp; nextp += DENSE_TPB;
 			const u32 nb = q_nbits32(qn, s);
-			if ((nb & 1u) || s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0) { memo[s] = 1; lf[s] = 0; continue; }      // ambiguous start, or MinSeedLength out of reach
+			if ((nb & 1u) || s + prm.MinSeedLength > clen || (nb & (L == 32 ? ~0u : (1u << L) - 1)) != 0) { lf[s] = 0; continue; }      // ambiguous start, or MinSeedLength out of reach
 			ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
 			if (di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
 				const u64 qb = q_bits64(qp, s);
@@ -795,7 +795,7 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 //     bwt_search.cpp:177-182 costs O(L) per copy of a repeat instead of O(L^2);
 //   * it does not extend: L(s) < e - s, and the lane searches forward from s from scratch (exact by definition).
 // Nothing is speculated and no lane depends on another: next(s) is a pure function of s.  Same outputs as k_dense_search
-// (memo / lf / x0 per start), so k_dense_resolve and everything downstream are unchanged; a unique match found by text
+// (lf / x0 per start), so k_dense_resolve and everything downstream are unchanged; a unique match found by text
 // comparison has no SA row at hand, so its x0 carries the text POSITION with bit 63 set (k_seed_select takes it as located).
 // ---------------------------------------------------------------------------
 #define SWEEP_POSFLAG (1ull << 63)
@@ -811,7 +811,7 @@ enum { HV_NONE = 0, HV_UNIQ = 1, HV_MULTI = 2 };
 #endif
 template <bool E16, int TPB>
 __global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, const u32 *__restrict__ chunk_list,
-                                                      uint16_t *dn_memo, u32 *dn_lf, u64 *dn_x0, u64 *cnt, int seg, int wgs_per_chunk)
+                                                      u32 *dn_lf, u64 *dn_x0, u64 *cnt, int seg, int wgs_per_chunk)
 {
 	// seg = starts per lane (TPB x seg starts per workgroup, wgs_per_chunk workgroups per chunk): long segments do the least work
 	// (one forward search per segment), short ones finish soonest.  Round 4: ONE WAVE per chunk with 160 starts per lane (TPB = 64) where
@@ -834,7 +834,7 @@ __global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex d
 		qn[g] = wn;
 	}
 	__syncthreads();
-	uint16_t *memo = dn_memo + (size_t)slot * GSA_CHUNK; u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; u64 *x0o = dn_x0 + (size_t)slot * GSA_CHUNK;
+	u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; u64 *x0o = dn_x0 + (size_t)slot * GSA_CHUNK;
 	const int seg_a = ((int)part * TPB + j) * seg;
 	int cur = (seg_a + seg < clen ? seg_a + seg : clen) - 1;      // next start to settle; the lane is through when cur < seg_a
 	int s = 0, pos = 0, mode = M_ADV, have = HV_NONE, e_end = 0, prole = 0; u32 kid = 0, pid = 0, blk = 0, all_blocks = 0;
@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex d
 	{                                                                                                                   \
 		int d_ = 1; u32 rec_ = 0;                                                                                       \
 		if ((LEN_) >= prm.MinSeedLength && (X2_) <= (u64)GSA_MAX_SEED_FREQ) { d_ = prm.bSensitive ? 5 : (LEN_) + 1; rec_ = (u32)(LEN_) | ((u32)(X2_) << 16); SWEEP_ST(x0o[S_] = (X0_);) } \
-		SWEEP_ST(memo[S_] = (uint16_t)d_; lf[S_] = rec_;)                                                                         \
+		SWEEP_ST(lf[S_] = rec_;)                                                                         \
 	}
 	while (!__all(mode == M_DONE)) {
 		// ---- request phase: one pending request per lane, all lanes issue together ----
@@ -894,12 +894,12 @@ __global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex d
 			if (!present(prole)) {
 				// the first MinSeedLength bases of s do not occur: no seed, nothing to extend; the same line answers for the starts to
 				// the left while they pass the N / length tests (their own hop is 1 as well when they do not)
-				SWEEP_ST(memo[s] = 1; lf[s] = 0;) cur = s - 1; have = HV_NONE; mode = M_ADV;
+				SWEEP_ST(lf[s] = 0;) cur = s - 1; have = HV_NONE; mode = M_ADV;
 				for (int r = prole - 1; r >= 0 && cur >= seg_a; r--) {
 					const u32 nb = q_nbits32(qn, cur);
 					if ((nb & 1u) || cur + prm.MinSeedLength > clen || (nb & Lmask) != 0) break;      // (the advance step settles those)
 					if (present(r)) break;                                                            // occurs: needs its own search
-					SWEEP_ST(memo[cur] = 1; lf[cur] = 0;) cur--;
+					SWEEP_ST(lf[cur] = 0;) cur--;
 				}
 			} else {
 				const bool hit = e1.x != 0;         // absent k-mer: the match is shorter than k
@@ -955,7 +955,26 @@ __global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex d
 				const int im = dm ? (63 - __clzll((long long)dm)) >> 1 : -1, in_ = nm ? 31 - __clz((int)nm) : -1;
 				nbk = n - 1 - (im > in_ ? im : in_);
 			}
-			for (int t = 0; t < nbk; t++) { const int st = cur - t; SWEEP_SETTLE(st, e_end - st, 1ull, SWEEP_POSFLAG | (u64)(tps - 1 - t)) }
+			// the nbk starts [cur - nbk + 1, cur] are settled at once: start a + i matches [a + i, e_end) once, at text position tps - nbk + i.
+			// Four starts per store (dword-aligned 16-byte stores: the records of a run are consecutive) -- a lane in unique sequence
+			// settles 32 starts per iteration, and one scalar store per array and start was most of what the kernel asked of the L2
+			{
+				const int a = cur - nbk + 1;
+				struct __attribute__((packed, aligned(4))) R4 { u32 v[4]; };
+				struct __attribute__((packed, aligned(8))) X4 { u64 v[4]; };
+				int i = 0;
+				for (; i + 4 <= nbk; i += 4) {
+					R4 r; X4 x;
+#pragma unroll
+					for (int e = 0; e < 4; e++) {
+						const int len_ = e_end - (a + i + e);
+						r.v[e] = len_ >= prm.MinSeedLength ? (u32)len_ | (1u << 16) : 0u;      // (SWEEP_SETTLE with one occurrence; -sen does not come here)
+						x.v[e] = SWEEP_POSFLAG | (u64)(tps - nbk + i + e);
+					}
+					SWEEP_ST(*(R4 *)(lf + a + i) = r; *(X4 *)(x0o + a + i) = x;)
+				}
+				for (; i < nbk; i++) { const int st = a + i; SWEEP_SETTLE(st, e_end - st, 1ull, SWEEP_POSFLAG | (u64)(tps - nbk + i)) }
+			}
 			cur -= nbk; tps -= nbk;
 			if (nbk < n || n <= 0) have = HV_NONE;                                  // stopped by a mismatch, an N or the start of the text
 			mode = M_ADV;
@@ -974,10 +993,10 @@ __global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex d
 		for (int step = 0; step < 3 && mode == M_ADV; step++) {
 			if (cur < seg_a) { mode = M_DONE; break; }
 			const u32 nb = q_nbits32(qn, cur);
-			if (nb & 1u) { SWEEP_ST(memo[cur] = 1; lf[cur] = 0;) have = HV_NONE; cur--; continue; }      // ambiguous base: no search from here, nothing extends over it
+			if (nb & 1u) { SWEEP_ST(lf[cur] = 0;) have = HV_NONE; cur--; continue; }      // ambiguous base: no search from here, nothing extends over it
 			if (have == HV_UNIQ) { mode = M_BACK; break; }
 			if (have == HV_MULTI) { mode = M_BFM; break; }
-			if (cur + prm.MinSeedLength > clen || (nb & Lmask) != 0) { SWEEP_ST(memo[cur] = 1; lf[cur] = 0;) cur--; continue; }      // MinSeedLength out of reach
+			if (cur + prm.MinSeedLength > clen || (nb & Lmask) != 0) { SWEEP_ST(lf[cur] = 0;) cur--; continue; }      // MinSeedLength out of reach
 			s = cur; ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
 			if (di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
 				kid = (u32)(q_bits64(qp, s) & ((1ull << (2 * di.kmer_k)) - 1)); mode = M_KMER;
@@ -995,10 +1014,10 @@ __global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex d
 	if ((j & 63) == 0 && all_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK_ALL], (unsigned long long)all_blocks);
 }
 
-// The chain of a dense chunk: orbit of 0 under p -> p + memo[p], marked by pointer doubling (jump_k = next^(2^k); the
+// The chain of a dense chunk: orbit of 0 under p -> next(p) (from the start's record), marked by pointer doubling (jump_k = next^(2^k); the
 // marked set doubles per round), then the accepted on-chain matches go to the chunk's candidate segment in the layout
 // k_seed_wg leaves (so everything downstream is the same).
-__global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ chunk_list, u32 n_total_chunks, i32 qlen, const uint16_t *__restrict__ dn_memo, const u32 *__restrict__ dn_lf,
+__global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ chunk_list, u32 n_total_chunks, i32 qlen, int sen, const u32 *__restrict__ dn_lf,
                                                         const u64 *__restrict__ dn_x0, u64 *cnt, i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt,
                                                         u32 *onpath, i32 *chunk_hits, u64 *hcnt, i32 *chunk_base)
 {
@@ -1010,8 +1029,9 @@ __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ c
 	const int j = threadIdx.x;
 	const i64 c0 = (i64)chunk * GSA_CHUNK;
 	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
-	const uint16_t *memo = dn_memo + (size_t)slot * GSA_CHUNK;
-	for (int p = j; p < clen; p += 256) { const int t = p + memo[p]; jmp[0][p] = (uint16_t)(t < clen ? t : 0xffff); }
+	const u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; const u64 *x0 = dn_x0 + (size_t)slot * GSA_CHUNK;
+	// next(p): behind an accepted match (five bases on with -sen), else the next base -- the record says which (GSAlign.cpp:61-94)
+	for (int p = j; p < clen; p += 256) { const u32 rec = lf[p]; const int t = p + (rec ? (sen ? 5 : (int)(rec & 0xffffu) + 1) : 1); jmp[0][p] = (uint16_t)(t < clen ? t : 0xffff); }
 	for (int w = j; w < PATH_WORDS; w += 256) bits[w] = w == 0 ? 1u : 0u;
 	if (j == 0) { s_n = 0; s_hits = 0; }
 	__syncthreads();
@@ -1028,7 +1048,6 @@ __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ c
 		cur ^= 1;
 	}
 	const size_t cbase = (size_t)chunk * cand_cap;
-	const u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; const u64 *x0 = dn_x0 + (size_t)slot * GSA_CHUNK;
 	u32 h = 0;
 	for (int p = j; p < clen; p += 256) {
 		if (!((bits[p >> 5] >> (p & 31)) & 1u)) continue;
@@ -1602,9 +1621,9 @@ int stage1_seed(gsa_ctx *c)
 		}
 		if (n_heavy > 0) {
 			const size_t nd = (size_t)n_heavy * GSA_CHUNK;
-			if (!dev_ensure<uint16_t>(c, c->dn_memo, nd) || !dev_ensure<u32>(c, c->dn_lf, nd) || !dev_ensure<u64>(c, c->dn_x0, nd)) return GSA_ERR_NOMEM;
+			if (!dev_ensure<u32>(c, c->dn_lf, nd) || !dev_ensure<u64>(c, c->dn_x0, nd)) return GSA_ERR_NOMEM;
 			const u32 *list = dense_all ? (const u32 *)nullptr : c->d_heavy.as<u32>();
-#define GSA_DENSE_ARGS(SPAN) dim3((unsigned)(n_heavy * DENSE_WGS(SPAN))), dim3(DENSE_TPB), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt
+#define GSA_DENSE_ARGS(SPAN) dim3((unsigned)(n_heavy * DENSE_WGS(SPAN))), dim3(DENSE_TPB), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt
 #ifdef GSA_EXPERIMENTS
 			static const u64 sweep_min = [] { const char *e = getenv("GSA_SWEEP_MIN"); return e ? (u64)atoll(e) : 1024ull; }();
 #else
@@ -1620,13 +1639,13 @@ int stage1_seed(gsa_ctx *c)
 				const int seg_env = 0;
 #endif
 				const int seg = seg_env > 0 ? seg_env : 160, wpc = (GSA_CHUNK + 64 * seg - 1) / (64 * seg);
-				if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_sweep<true, 64>), dim3((unsigned)(n_heavy * wpc)), dim3(64), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
-				else hipLaunchKernelGGL((k_dense_sweep<false, 64>), dim3((unsigned)(n_heavy * wpc)), dim3(64), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
+				if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_sweep<true, 64>), dim3((unsigned)(n_heavy * wpc)), dim3(64), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
+				else hipLaunchKernelGGL((k_dense_sweep<false, 64>), dim3((unsigned)(n_heavy * wpc)), dim3(64), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
 			}
 			else if (dense_all) { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 512>), GSA_DENSE_ARGS(512)); else hipLaunchKernelGGL((k_dense_search<false, 512>), GSA_DENSE_ARGS(512)); }
 			else { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 256>), GSA_DENSE_ARGS(256)); else hipLaunchKernelGGL((k_dense_search<false, 256>), GSA_DENSE_ARGS(256)); }
 #undef GSA_DENSE_ARGS
-			hipLaunchKernelGGL(k_dense_resolve, dim3((unsigned)n_heavy), dim3(256), 0, st, list, (u32)n_chunks, qlen, c->dn_memo.as<uint16_t>(), c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt,
+			hipLaunchKernelGGL(k_dense_resolve, dim3((unsigned)n_heavy), dim3(256), 0, st, list, (u32)n_chunks, qlen, (int)c->prm.bSensitive, c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt,
 			                   c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(),
 			                   c->d_chunk_hits.as<i32>(), c->h_cnt, c->d_chunk_base.as<i32>());
 			GSA_CHECK(c, hipGetLastError());
