@@ -752,8 +752,8 @@ __global__ void __launch_bounds__(DENSE_TPB) k_dense_search(DevIndex di, const u
 		}
 		if (ended) {
 			const int len = pos - s;
-			int d = 1; u32 rec = 0;
-			if (len >= prm.MinSeedLength && ik.x2 <= GSA_MAX_SEED_FREQ) { d = prm.bSensitive ? 5 : len + 1; rec = (u32)len | ((u32)ik.x2 << 16); x0o[s] = ik.x0; }
+			u32 rec = 0;
+			if (len >= prm.MinSeedLength && ik.x2 <= GSA_MAX_SEED_FREQ) { rec = (u32)len | ((u32)ik.x2 << 16); x0o[s] = ik.x0; }
 			lf[s] = rec;      // (the hop follows from the record: k_dense_resolve)
 			all_blocks += blk;
 			mode = M_ADV;
@@ -806,47 +806,62 @@ enum { HV_NONE = 0, HV_UNIQ = 1, HV_MULTI = 2 };
 #else
 #define SWEEP_ST(...) __VA_ARGS__
 #endif
-#ifndef SWEEP_MIN_WAVES
-#define SWEEP_MIN_WAVES 4      // waves per SIMD the register allocation must allow (4: ~104 VGPRs, no scratch)
+#ifndef SWEEP_NCH
+#define SWEEP_NCH 4            // chunks per workgroup (3.75 KB of LDS each)
 #endif
-template <bool E16, int TPB>
-__global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, const u32 *__restrict__ chunk_list,
-                                                      u32 *dn_lf, u64 *dn_x0, u64 *cnt, int seg, int wgs_per_chunk)
+#ifndef SWEEP_TPB
+#define SWEEP_TPB 128
+#endif
+template <bool E16, int NCH, int TPB>
+__global__ void __launch_bounds__(TPB) k_dense_sweep(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, const u32 *__restrict__ chunk_list, u32 n_slots,
+                                                     u32 *dn_lf, u64 *dn_x0, u64 *cnt, int seg)
 {
-	// seg = starts per lane (TPB x seg starts per workgroup, wgs_per_chunk workgroups per chunk): long segments do the least work
-	// (one forward search per segment), short ones finish soonest.  Round 4: ONE WAVE per chunk with 160 starts per lane (TPB = 64) where
-	// round 3 ran four waves with 40: inside a high-copy repeat a segment costs ~150 Occ steps for its first (forward) search and one
-	// backward step per start, so 40 starts cost a lane 190 dependent steps and 160 cost it 310 -- a quarter of the lanes, 2.5x fewer steps
-	__shared__ u32 qp[QP_WORDS], qn[QN_WORDS];
-	const u32 slot = blockIdx.x / (u32)wgs_per_chunk, part = blockIdx.x % (u32)wgs_per_chunk;
-	const u32 chunk = chunk_list ? chunk_list[slot] : slot;
+	// seg = starts per segment; long segments do the least work (one forward search per segment), short ones finish soonest.
+	// Round 3 ran four waves per chunk with 40 starts per lane; round 4 first ONE wave per chunk with 160: inside a high-copy repeat a
+	// segment costs ~150 Occ steps for its first (forward) search and one backward step per start, so 40 starts cost a lane 190
+	// dependent steps and 160 cost it 310 -- a quarter of the forward searches.  But a lane in unique sequence is through with its
+	// 160 starts after ~14 steps, and three lanes in four waited for the wave's repeat lanes while the kernel is bound by the
+	// instructions its waves issue (tools/r4_adv_pmc.sh: 6.0 G VALU wave-instructions per 250 Mb, 318 iterations per wave).  So now
+	// ONE WAVE takes NCH chunks and its lanes DRAW the segments (63 per chunk) from a counter in LDS: a lane that is through
+	// takes the next one, whichever chunk it belongs to -- every lane carries its chunk (query words in LDS, record arrays) along.
+	__shared__ u32 qp[NCH][QP_WORDS], qn[NCH][QN_WORDS];
+	__shared__ u32 s_next;
 	const int j = threadIdx.x;
-	const i64 c0 = (i64)chunk * GSA_CHUNK;
-	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
-	for (int g = j; g < QN_WORDS; g += TPB) {
-		u32 w0 = 0, w1 = 0, wn = 0;
-		const int p0 = g << 5;
-		if (p0 < clen) {
-			stage32(q + c0 + p0, p0, clen, w0, w1, wn);
-		} else wn = ~0u;
-		if (2 * g < QP_WORDS) qp[2 * g] = w0;
-		if (2 * g + 1 < QP_WORDS) qp[2 * g + 1] = w1;
-		qn[g] = wn;
+	const u32 slot0 = blockIdx.x * (u32)NCH;
+	const int nch = (int)(n_slots - slot0 < (u32)NCH ? n_slots - slot0 : (u32)NCH);
+	const int spc = (GSA_CHUNK + seg - 1) / seg;                  // segments per chunk
+	const u32 n_seg = (u32)(nch * spc);
+	for (int ch = 0; ch < nch; ch++) {
+		const u32 chunk = chunk_list ? chunk_list[slot0 + ch] : slot0 + ch;
+		const i64 c0 = (i64)chunk * GSA_CHUNK;
+		const int cl = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
+		for (int g = j; g < QN_WORDS; g += TPB) {
+			u32 w0 = 0, w1 = 0, wn = 0;
+			const int p0 = g << 5;
+			if (p0 < cl) {
+				stage32(q + c0 + p0, p0, cl, w0, w1, wn);
+			} else wn = ~0u;
+			if (2 * g < QP_WORDS) qp[ch][2 * g] = w0;
+			if (2 * g + 1 < QP_WORDS) qp[ch][2 * g + 1] = w1;
+			qn[ch][g] = wn;
+		}
 	}
+	if (j == 0) s_next = 0;
 	__syncthreads();
-	u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; u64 *x0o = dn_x0 + (size_t)slot * GSA_CHUNK;
-	const int seg_a = ((int)part * TPB + j) * seg;
-	int cur = (seg_a + seg < clen ? seg_a + seg : clen) - 1;      // next start to settle; the lane is through when cur < seg_a
+	// the lane's segment: chunk-relative starts [seg_a, cur] of the chunk whose words are qp_l / qn_l and whose records are lf / x0o
+	const u32 *qp_l = qp[0], *qn_l = qn[0]; u32 *lf = dn_lf; u64 *x0o = dn_x0; int clen = 0;
+	int seg_a = 0;
+	int cur = -1;                                              // next start to settle; the lane draws a segment when cur < seg_a
 	int s = 0, pos = 0, mode = M_ADV, have = HV_NONE, e_end = 0, prole = 0; u32 kid = 0, pid = 0, blk = 0, all_blocks = 0;
 	u64 pqb = 0;
 	FmIntv ik = {0, 0, 0}; i64 tp = 0, tps = 0;
 	const int L = prm.MinSeedLength < 32 ? prm.MinSeedLength : 32;
 	const u32 Lmask = L == 32 ? ~0u : (1u << L) - 1;
-	// what is known about start S_ once its longest match [S_, S_ + LEN_) with X2_ occurrences is: the hop, the seed record
+	// what is known about start S_ once its longest match [S_, S_ + LEN_) with X2_ occurrences is: the seed record (the hop follows from it)
 #define SWEEP_SETTLE(S_, LEN_, X2_, X0_)                                                                                   \
 	{                                                                                                                   \
-		int d_ = 1; u32 rec_ = 0;                                                                                       \
-		if ((LEN_) >= prm.MinSeedLength && (X2_) <= (u64)GSA_MAX_SEED_FREQ) { d_ = prm.bSensitive ? 5 : (LEN_) + 1; rec_ = (u32)(LEN_) | ((u32)(X2_) << 16); SWEEP_ST(x0o[S_] = (X0_);) } \
+		u32 rec_ = 0;                                                                                       \
+		if ((LEN_) >= prm.MinSeedLength && (X2_) <= (u64)GSA_MAX_SEED_FREQ) { rec_ = (u32)(LEN_) | ((u32)(X2_) << 16); SWEEP_ST(x0o[S_] = (X0_);) } \
 		SWEEP_ST(lf[S_] = rec_;)                                                                         \
 	}
 	while (!__all(mode == M_DONE)) {
@@ -896,7 +911,7 @@ __global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex d
 				// the left while they pass the N / length tests (their own hop is 1 as well when they do not)
 				SWEEP_ST(lf[s] = 0;) cur = s - 1; have = HV_NONE; mode = M_ADV;
 				for (int r = prole - 1; r >= 0 && cur >= seg_a; r--) {
-					const u32 nb = q_nbits32(qn, cur);
+					const u32 nb = q_nbits32(qn_l, cur);
 					if ((nb & 1u) || cur + prm.MinSeedLength > clen || (nb & Lmask) != 0) break;      // (the advance step settles those)
 					if (present(r)) break;                                                            // occurs: needs its own search
 					SWEEP_ST(lf[cur] = 0;) cur--;
@@ -916,19 +931,19 @@ __global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex d
 		} else if (mode == M_LOC) {
 			tp = (i64)sav + (pos - s); mode = M_TEXT;
 		} else if (mode == M_TEXT) {
-			int got = text_match32(w5.a, w5.b, w5.c, tp, (i64)di.seq_len, qp, qn, pos, clen);
-			if (got == 32) got += text_match32(w5.c, w5.d, w5.e, tp + 32, (i64)di.seq_len, qp, qn, pos + 32, clen);
+			int got = text_match32(w5.a, w5.b, w5.c, tp, (i64)di.seq_len, qp_l, qn_l, pos, clen);
+			if (got == 32) got += text_match32(w5.c, w5.d, w5.e, tp + 32, (i64)di.seq_len, qp_l, qn_l, pos + 32, clen);
 			pos += got; tp += got;
 			ended = got < 64;
 		} else if (mode == M_FM) {
-			const bool can = pos < clen && !q_isn(qn, pos < clen ? pos : 0);
-			const bool ok = can && fm_extend_loaded(di, ik, q_code(qp, pos < clen ? pos : 0), bk, bl, kk, ll, kn, ln, blk);
+			const bool can = pos < clen && !q_isn(qn_l, pos < clen ? pos : 0);
+			const bool ok = can && fm_extend_loaded(di, ik, q_code(qp_l, pos < clen ? pos : 0), bk, bl, kk, ll, kn, ln, blk);
 			ended = !ok;
 			if (ok) { pos++; if (ik.x2 == 1) mode = M_LOC; }
 		} else if (mode == M_BFM) {
 			// prepend q[cur] to the match [cur + 1, e_end): the reference's forward step on the mirrored bi-interval with the complementary base
 			FmIntv m = { ik.x1, ik.x0, ik.x2 };
-			const bool ok = fm_extend_loaded(di, m, 3 - q_code(qp, cur), bk, bl, kk, ll, kn, ln, blk);
+			const bool ok = fm_extend_loaded(di, m, 3 - q_code(qp_l, cur), bk, bl, kk, ll, kn, ln, blk);
 			all_blocks += blk; blk = 0;
 			if (ok) {
 				ik.x0 = m.x1; ik.x1 = m.x0; ik.x2 = m.x2;
@@ -947,11 +962,11 @@ __global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex d
 				const u64 lo64 = (u64)w5.a | ((u64)w5.b << 32), hi64 = (u64)w5.c;
 				const int sh = off * 2;
 				const u64 T = sh == 0 ? lo64 : (sh < 64 ? (lo64 >> sh) | (hi64 << (64 - sh)) : (hi64 >> (sh - 64)));
-				const u64 Q = q_bits64(qp, cur - n + 1);
+				const u64 Q = q_bits64(qp_l, cur - n + 1);
 				const u64 msk = n == 32 ? ~0ull : ((1ull << (2 * n)) - 1);
 				const u64 d = (Q ^ T) & msk;
 				const u64 dm = (d | (d >> 1)) & 0x5555555555555555ull;
-				const u32 nm = q_nbits32(qn, cur - n + 1) & (n == 32 ? ~0u : ((1u << n) - 1));
+				const u32 nm = q_nbits32(qn_l, cur - n + 1) & (n == 32 ? ~0u : ((1u << n) - 1));
 				const int im = dm ? (63 - __clzll((long long)dm)) >> 1 : -1, in_ = nm ? 31 - __clz((int)nm) : -1;
 				nbk = n - 1 - (im > in_ ? im : in_);
 			}
@@ -991,21 +1006,32 @@ __global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex d
 		}
 		// ---- what to do about start cur ----
 		for (int step = 0; step < 3 && mode == M_ADV; step++) {
-			if (cur < seg_a) { mode = M_DONE; break; }
-			const u32 nb = q_nbits32(qn, cur);
+			if (cur < seg_a) {
+				// through with the segment: the next one of the wave's chunks (LDS counter; M_DONE when they are all handed out)
+				const u32 id = atomicAdd(&s_next, 1u);
+				if (id >= n_seg) { mode = M_DONE; break; }
+				const int ch = (int)id / spc, sg = (int)id - ch * spc;
+				const u32 chunk = chunk_list ? chunk_list[slot0 + ch] : slot0 + ch;
+				const i64 c0 = (i64)chunk * GSA_CHUNK;
+				clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
+				qp_l = qp[ch]; qn_l = qn[ch]; lf = dn_lf + (size_t)(slot0 + ch) * GSA_CHUNK; x0o = dn_x0 + (size_t)(slot0 + ch) * GSA_CHUNK;
+				seg_a = sg * seg; cur = (seg_a + seg < clen ? seg_a + seg : clen) - 1; have = HV_NONE;
+				continue;
+			}
+			const u32 nb = q_nbits32(qn_l, cur);
 			if (nb & 1u) { SWEEP_ST(lf[cur] = 0;) have = HV_NONE; cur--; continue; }      // ambiguous base: no search from here, nothing extends over it
 			if (have == HV_UNIQ) { mode = M_BACK; break; }
 			if (have == HV_MULTI) { mode = M_BFM; break; }
 			if (cur + prm.MinSeedLength > clen || (nb & Lmask) != 0) { SWEEP_ST(lf[cur] = 0;) cur--; continue; }      // MinSeedLength out of reach
-			s = cur; ik = fm_init(di, q_code(qp, s)); pos = s + 1; blk = 0; mode = M_FM;
+			s = cur; ik = fm_init(di, q_code(qp_l, s)); pos = s + 1; blk = 0; mode = M_FM;
 			if (di.kmer_k > 1 && s + di.kmer_k <= clen && (nb & ((1u << di.kmer_k) - 1)) == 0) {
-				kid = (u32)(q_bits64(qp, s) & ((1ull << (2 * di.kmer_k)) - 1)); mode = M_KMER;
+				kid = (u32)(q_bits64(qp_l, s) & ((1ull << (2 * di.kmer_k)) - 1)); mode = M_KMER;
 				// presence: the group that starts three bases to the left (as far as the chunk goes), s in its last role
 				prole = s >= 3 ? 3 : s;
-				pqb = q_bits64(qp, s - prole);
+				pqb = q_bits64(qp_l, s - prole);
 				pid = di.pres_k ? pres4_line(pqb, di.pres_k) : 0;
 			} else if (di.kmer_lo && s + di.kmer_lo_k <= clen && (nb & ((1u << di.kmer_lo_k) - 1)) == 0) {
-				kid = (u32)(q_bits64(qp, s) & ((1ull << (2 * di.kmer_lo_k)) - 1)); mode = M_KLO;
+				kid = (u32)(q_bits64(qp_l, s) & ((1ull << (2 * di.kmer_lo_k)) - 1)); mode = M_KLO;
 			}
 		}
 	}
@@ -1014,14 +1040,24 @@ __global__ void __launch_bounds__(TPB, SWEEP_MIN_WAVES) k_dense_sweep(DevIndex d
 	if ((j & 63) == 0 && all_blocks) atomicAdd((unsigned long long *)&cnt[CNT_OCCBLK_ALL], (unsigned long long)all_blocks);
 }
 
-// The chain of a dense chunk: orbit of 0 under p -> next(p) (from the start's record), marked by pointer doubling (jump_k = next^(2^k); the
-// marked set doubles per round), then the accepted on-chain matches go to the chunk's candidate segment in the layout
-// k_seed_wg leaves (so everything downstream is the same).
+// The chain of a dense chunk: orbit of 0 under p -> next(p) (from the start's record), then the accepted on-chain matches go to
+// the chunk's candidate segment in the layout k_seed_wg leaves (so everything downstream is the same).  Round 3 marked the orbit by
+// pointer doubling over all 10 000 positions (14 rounds: 2.8 ms per 250 Mb of dense chunks, a fifth of their seed stage).  next() only
+// moves forward, so the chunk is cut into 256 blocks of 40 positions, one per thread:
+//   1. every thread resolves its block from right to left: ex[p] = where the path through p LEAVES the block (40 dependent LDS reads);
+//   2. one thread follows 0 -> ex[0] -> ex[ex[0]] ... (at most one step per block) and notes where the path enters each block;
+//   3. every thread whose block the path enters walks it inside the block and marks the positions.
+#define RS_B 40                 // positions per thread
+#define RS_XS 42                // block stride of ex[] (u16; 21 dwords: odd, so the threads' blocks fall into different banks)
+#define RS_HS 44                // block stride of hopb[] (u8; 11 dwords)
+static_assert(256 * RS_B >= GSA_CHUNK, "one block per thread");
 __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ chunk_list, u32 n_total_chunks, i32 qlen, int sen, const u32 *__restrict__ dn_lf,
                                                         const u64 *__restrict__ dn_x0, u64 *cnt, i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt,
                                                         u32 *onpath, i32 *chunk_hits, u64 *hcnt, i32 *chunk_base)
 {
-	__shared__ uint16_t jmp[2][GSA_CHUNK];
+	__shared__ uint16_t ex[256 * RS_XS];        // first position outside p's block on the path through p (0xffff: outside the chunk)
+	__shared__ uint8_t hopb[256 * RS_HS];       // next(p) - p where that stays inside p's block, else 0
+	__shared__ uint16_t s_entry[256];           // where the path from 0 enters the block (0xffff: it jumps over it)
 	__shared__ u32 bits[PATH_WORDS];
 	__shared__ u32 s_n, s_hits;
 	__shared__ int s_last;
@@ -1031,22 +1067,33 @@ __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ c
 	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
 	const u32 *lf = dn_lf + (size_t)slot * GSA_CHUNK; const u64 *x0 = dn_x0 + (size_t)slot * GSA_CHUNK;
 	// next(p): behind an accepted match (five bases on with -sen), else the next base -- the record says which (GSAlign.cpp:61-94)
-	for (int p = j; p < clen; p += 256) { const u32 rec = lf[p]; const int t = p + (rec ? (sen ? 5 : (int)(rec & 0xffffu) + 1) : 1); jmp[0][p] = (uint16_t)(t < clen ? t : 0xffff); }
-	for (int w = j; w < PATH_WORDS; w += 256) bits[w] = w == 0 ? 1u : 0u;
+	for (int p = j; p < clen; p += 256) {
+		const u32 rec = lf[p];
+		const int hop = rec ? (sen ? 5 : (int)(rec & 0xffffu) + 1) : 1, t = p + hop;
+		const int b = p / RS_B, i = p - b * RS_B, bend = (b + 1) * RS_B < clen ? (b + 1) * RS_B : clen;
+		ex[b * RS_XS + i] = (uint16_t)(t < clen ? t : 0xffff);
+		hopb[b * RS_HS + i] = (uint8_t)(t < bend ? hop : 0);
+	}
+	for (int w = j; w < PATH_WORDS; w += 256) bits[w] = 0u;
+	s_entry[j] = 0xffff;
 	if (j == 0) { s_n = 0; s_hits = 0; }
 	__syncthreads();
-	int cur = 0;
-	for (int span = 1; span < clen; span <<= 1) {
-		for (int p = j; p < clen; p += 256) {
-			const int t = jmp[cur][p];
-			if (t != 0xffff) {
-				if ((bits[p >> 5] >> (p & 31)) & 1u) atomicOr(&bits[t >> 5], 1u << (t & 31));
-				jmp[cur ^ 1][p] = jmp[cur][t];
-			} else jmp[cur ^ 1][p] = 0xffff;
-		}
-		__syncthreads();
-		cur ^= 1;
+	{
+		const int n = clen - j * RS_B < RS_B ? clen - j * RS_B : RS_B;      // (<= 0: the chunk ends in front of this block)
+		for (int i = n - 1; i >= 0; i--) { const int h = hopb[j * RS_HS + i]; if (h) ex[j * RS_XS + i] = ex[j * RS_XS + i + h]; }
 	}
+	__syncthreads();
+	if (j == 0) for (int e = 0; e != 0xffff;) { const int b = e / RS_B; s_entry[b] = (uint16_t)e; e = ex[b * RS_XS + (e - b * RS_B)]; }
+	__syncthreads();
+	if (s_entry[j] != 0xffff)
+		for (int i = (int)s_entry[j] - j * RS_B;;) {
+			const int p = j * RS_B + i;
+			atomicOr(&bits[p >> 5], 1u << (p & 31));
+			const int h = hopb[j * RS_HS + i];
+			if (!h) break;
+			i += h;
+		}
+	__syncthreads();
 	const size_t cbase = (size_t)chunk * cand_cap;
 	u32 h = 0;
 	for (int p = j; p < clen; p += 256) {
@@ -1638,9 +1685,10 @@ int stage1_seed(gsa_ctx *c)
 #else
 				const int seg_env = 0;
 #endif
-				const int seg = seg_env > 0 ? seg_env : 160, wpc = (GSA_CHUNK + 64 * seg - 1) / (64 * seg);
-				if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_sweep<true, 64>), dim3((unsigned)(n_heavy * wpc)), dim3(64), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
-				else hipLaunchKernelGGL((k_dense_sweep<false, 64>), dim3((unsigned)(n_heavy * wpc)), dim3(64), 0, st, c->di, d_q, qlen, c->prm, list, c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg, wpc);
+				const int seg = seg_env > 0 ? seg_env : 160;
+				const unsigned n_wg = (unsigned)((n_heavy + SWEEP_NCH - 1) / SWEEP_NCH);
+				if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_sweep<true, SWEEP_NCH, SWEEP_TPB>), dim3(n_wg), dim3(SWEEP_TPB), 0, st, c->di, d_q, qlen, c->prm, list, (u32)n_heavy, c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg);
+				else hipLaunchKernelGGL((k_dense_sweep<false, SWEEP_NCH, SWEEP_TPB>), dim3(n_wg), dim3(SWEEP_TPB), 0, st, c->di, d_q, qlen, c->prm, list, (u32)n_heavy, c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg);
 			}
 			else if (dense_all) { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 512>), GSA_DENSE_ARGS(512)); else hipLaunchKernelGGL((k_dense_search<false, 512>), GSA_DENSE_ARGS(512)); }
 			else { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 256>), GSA_DENSE_ARGS(256)); else hipLaunchKernelGGL((k_dense_search<false, 256>), GSA_DENSE_ARGS(256)); }
