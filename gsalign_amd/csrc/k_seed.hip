@@ -935,22 +935,28 @@ __global__ void __launch_bounds__(TPB) k_dense_sweep(DevIndex di, const uint8_t 
 			if (got == 32) got += text_match32(w5.c, w5.d, w5.e, tp + 32, (i64)di.seq_len, qp_l, qn_l, pos + 32, clen);
 			pos += got; tp += got;
 			ended = got < 64;
-		} else if (mode == M_FM) {
-			const bool can = pos < clen && !q_isn(qn_l, pos < clen ? pos : 0);
-			const bool ok = can && fm_extend_loaded(di, ik, q_code(qp_l, pos < clen ? pos : 0), bk, bl, kk, ll, kn, ln, blk);
-			ended = !ok;
-			if (ok) { pos++; if (ik.x2 == 1) mode = M_LOC; }
-		} else if (mode == M_BFM) {
-			// prepend q[cur] to the match [cur + 1, e_end): the reference's forward step on the mirrored bi-interval with the complementary base
-			FmIntv m = { ik.x1, ik.x0, ik.x2 };
-			const bool ok = fm_extend_loaded(di, m, 3 - q_code(qp_l, cur), bk, bl, kk, ll, kn, ln, blk);
-			all_blocks += blk; blk = 0;
-			if (ok) {
-				ik.x0 = m.x1; ik.x1 = m.x0; ik.x2 = m.x2;
-				SWEEP_SETTLE(cur, e_end - cur, ik.x2, ik.x0)
-				cur--;
-				mode = ik.x2 == 1 ? M_LOC2 : M_ADV;       // one occurrence left: from here on the text itself answers
-			} else { have = HV_NONE; mode = M_ADV; }      // (L(cur) < e_end - cur: search forward from cur)
+		} else if (mode == M_FM || mode == M_BFM) {
+			// one Occ step for both directions (a wave has lanes in either most of the time: the step is the heaviest block of the loop).
+			// Forward: append q[pos] to [s, pos).  Backward: prepend q[cur] to the match [cur + 1, e_end) -- the reference's forward step
+			// on the mirrored bi-interval with the complementary base
+			const bool bw = mode == M_BFM;
+			const int qi = bw ? cur : (pos < clen ? pos : 0);
+			const bool can = bw || (pos < clen && !q_isn(qn_l, qi));
+			const int code = q_code(qp_l, qi);
+			FmIntv m = { bw ? ik.x1 : ik.x0, bw ? ik.x0 : ik.x1, ik.x2 };
+			const bool ok = can && fm_extend_loaded(di, m, bw ? 3 - code : code, bk, bl, kk, ll, kn, ln, blk);
+			if (ok) { ik.x0 = bw ? m.x1 : m.x0; ik.x1 = bw ? m.x0 : m.x1; ik.x2 = m.x2; }
+			if (!bw) {
+				ended = !ok;
+				if (ok) { pos++; if (ik.x2 == 1) mode = M_LOC; }
+			} else {
+				all_blocks += blk; blk = 0;
+				if (ok) {
+					SWEEP_SETTLE(cur, e_end - cur, ik.x2, ik.x0)
+					cur--;
+					mode = ik.x2 == 1 ? M_LOC2 : M_ADV;       // one occurrence left: from here on the text itself answers
+				} else { have = HV_NONE; mode = M_ADV; }      // (L(cur) < e_end - cur: search forward from cur)
+			}
 		} else if (mode == M_LOC2) {
 			tps = (i64)sav; have = HV_UNIQ; mode = M_ADV;      // text position of start cur + 1
 		} else if (mode == M_BACK) {
