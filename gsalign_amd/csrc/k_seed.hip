@@ -1151,7 +1151,7 @@ __device__ __forceinline__ void pd_coarse_set(u32 *pdcb, unsigned long long w)
 }
 __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, const u32 *__restrict__ cand_cnt, const i32 *__restrict__ cand_s, const i32 *__restrict__ cand_len,
                                                       const u64 *__restrict__ cand_x0, const i32 *__restrict__ cand_freq, const u32 *__restrict__ onpath,
-                                                      const i32 *__restrict__ hit_base, Bundle bnd, i32 s_off, int qbits, u64 *key, u32 *val, u32 *pdbm, u32 *pdcb)
+                                                      const i32 *__restrict__ hit_base, Bundle bnd, i32 s_off, int qbits, u64 *key, u32 *val, u32 *pdbm, u32 *pdcb, u32 lds_cand)
 {
 	// (bnd.lmax = length of the whole contig, s_off = contig position of the first chunk searched: not 0 when only a chunk range
 	//  of the contig was seeded on this GPU, gsa_seed_chunks.  A bundle of contigs: the key's PosDiff is the true one of the
@@ -1161,7 +1161,7 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 	// starts below its own), inside a start by the rank of the hit.  Stage 2 then needs ONE stable sort by the group id alone (three 8-bit passes
 	// instead of eight over the whole 57-bit key).  Off-chain candidates take no part.
 	extern __shared__ u32 s_offs[];                    // [nc + 1] exclusive prefix of the hit counts of the on-chain candidates in start order | [nc] their candidate numbers
-	u32 *s_ord = s_offs + cand_cap + 2;
+	u32 *s_ord = s_offs + lds_cand + 2;                // (lds_cand: the most candidates any chunk of THIS contig holds -- not the capacity of the segments)
 	__shared__ unsigned long long s_w[SEL_HASH]; __shared__ u32 s_b[SEL_HASH];
 	__shared__ u32 s_wsum[4], s_run, s_sb[GSA_CHUNK / 32 + 2], s_sbpre[GSA_CHUNK / 32 + 2];
 	const u32 chunk = blockIdx.x, nc = cand_cnt[chunk];
@@ -1634,6 +1634,7 @@ int stage1_seed(gsa_ctx *c)
 	const int seed_slots = 0;
 #endif
 	SeedGate gate(c->device, (c->profiling || c->count_blocks) ? 0 : seed_slots);
+	u64 contig_maxcand = 0;      // most candidates in one chunk of this contig
 	for (int attempt = 0;; attempt++) {
 		if (attempt == 8) return gsa_fail(c, GSA_ERR_LIMIT, "seed buffers keep overflowing");
 		const size_t ctot = ccap * (size_t)n_chunks;
@@ -1682,19 +1683,24 @@ int stage1_seed(gsa_ctx *c)
 #else
 			const u64 sweep_min = 1024;
 #endif
-			const bool use_sweep = seed_mode != 2 && !c->prm.bSensitive && (sweep_all || n_heavy >= sweep_min);
+			const bool use_sweep = seed_mode != 2 && ((seed_mode == 0 && dense_all) || n_heavy >= sweep_min);      // (-sen: every chunk is dense -- a bundle's worth of them is swept, a short contig's few are searched start by start: one round trip chain of ~5 per start beats a segment's chain of 60-250 when the chip is empty)
 			if (!dense_all && seed_mode == 1) c->seed_sweep_next = n_heavy * 5 > (u64)n_chunks * 2;      // (re-decided by every contig that goes through the speculative kernel)
 			else if (sweep_all && seed_mode == 1 && ++c->seed_sweep_run >= 8) { c->seed_sweep_next = false; c->seed_sweep_run = 0; }      // look again now and then
 			if (use_sweep) {
 #ifdef GSA_EXPERIMENTS
 				static const int seg_env = [] { const char *e = getenv("GSA_SWEEP_SEG"); return e ? atoi(e) : 0; }();
+				static const int shape_env = [] { const char *e = getenv("GSA_SWEEP_SHAPE"); return e ? atoi(e) : -1; }();
 #else
-				const int seg_env = 0;
+				const int seg_env = 0, shape_env = -1;
 #endif
-				const int seg = seg_env > 0 ? seg_env : 160;
-				const unsigned n_wg = (unsigned)((n_heavy + SWEEP_NCH - 1) / SWEEP_NCH);
-				if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_sweep<true, SWEEP_NCH, SWEEP_TPB>), dim3(n_wg), dim3(SWEEP_TPB), 0, st, c->di, d_q, qlen, c->prm, list, (u32)n_heavy, c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg);
-				else hipLaunchKernelGGL((k_dense_sweep<false, SWEEP_NCH, SWEEP_TPB>), dim3(n_wg), dim3(SWEEP_TPB), 0, st, c->di, d_q, qlen, c->prm, list, (u32)n_heavy, c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg);
+				// few dense chunks (a bundle of short contigs): one chunk per workgroup of four waves and 40 starts per segment, so that the
+				// chip has waves to run; many: four chunks per workgroup of two waves, 160 starts per segment
+				const bool small = shape_env >= 0 ? shape_env == 1 : n_heavy < 8192;
+				const int seg = seg_env > 0 ? seg_env : (small ? 40 : 160);
+#define GSA_SWEEP_ARGS(NCH_, TPB_) dim3((unsigned)((n_heavy + (NCH_) - 1) / (NCH_))), dim3(TPB_), 0, st, c->di, d_q, qlen, c->prm, list, (u32)n_heavy, c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg
+				if (small) { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_sweep<true, 1, 256>), GSA_SWEEP_ARGS(1, 256)); else hipLaunchKernelGGL((k_dense_sweep<false, 1, 256>), GSA_SWEEP_ARGS(1, 256)); }
+				else { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_sweep<true, SWEEP_NCH, SWEEP_TPB>), GSA_SWEEP_ARGS(SWEEP_NCH, SWEEP_TPB)); else hipLaunchKernelGGL((k_dense_sweep<false, SWEEP_NCH, SWEEP_TPB>), GSA_SWEEP_ARGS(SWEEP_NCH, SWEEP_TPB)); }
+#undef GSA_SWEEP_ARGS
 			}
 			else if (dense_all) { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 512>), GSA_DENSE_ARGS(512)); else hipLaunchKernelGGL((k_dense_search<false, 512>), GSA_DENSE_ARGS(512)); }
 			else { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_search<true, 256>), GSA_DENSE_ARGS(256)); else hipLaunchKernelGGL((k_dense_search<false, 256>), GSA_DENSE_ARGS(256)); }
@@ -1711,7 +1717,7 @@ int stage1_seed(gsa_ctx *c)
 		}
 		if (hits >= (1ull << 31) - 2) return gsa_fail(c, GSA_ERR_LIMIT, "more than 2^31 seeds in one contig");
 		if (maxcand > ccap) { ccap = (size_t)maxcand + 256; c->cand_cap_per_chunk = ccap; continue; }
-		n_hits = (i64)hits;
+		n_hits = (i64)hits; contig_maxcand = maxcand;
 		break;
 	}
 	gate.release();
@@ -1723,8 +1729,11 @@ int stage1_seed(gsa_ctx *c)
 	if (int rcp = prepare_pd_bitmap(c, n_hits)) return rcp;
 	if (n_hits > 0) {
 		if (!dev_ensure<u64>(c, c->d_key_a, hcap) || !dev_ensure<u32>(c, c->d_val_a, hcap)) return GSA_ERR_NOMEM;
-		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), 2 * (ccap + 2) * sizeof(u32), st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
-		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), c->bnd, s_off, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr, c->d_pdcb.as<u32>());
+		// (LDS by the contig's own maximum: the segments' capacity only grows -- one contig with a crowded chunk, or the counting pass of the
+		//  bench, and every later launch would run one workgroup per CU)
+		const size_t sel_cand = contig_maxcand < ccap ? (((size_t)contig_maxcand + 64) & ~(size_t)63) : ccap;
+		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), 2 * (sel_cand + 2) * sizeof(u32), st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
+		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), c->bnd, s_off, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr, c->d_pdcb.as<u32>(), (u32)sel_cand);
 	}
 	if (c->profiling) hipEventRecord(c->ev[2], st);
 	u64 lf_steps = 0;
