@@ -64,7 +64,7 @@ WORKLOADS = {
                        label="full-human-sized pair (BASELINE configs[4]): 24 contigs with GRCh38 chromosome lengths, 3.08 Gbp, repeat injection, vs 1 %-diverged copy, -alen 5000"),
     # not a BASELINE config: the repeat regime of real (T2T) sequence -- csrc/host/synth.cpp: eight families with a copy-number spectrum up
     # to 10^5 copies at 1-15 % divergence over 25 % of the sequence, microsatellites, two Mb-long N runs, soft-masked blocks
-    "adversarial": dict(lengths=[250_000_000], div=0.01, repeats="adversarial", params={}, n_query=2, inflight=4, steps=16,
+    "adversarial": dict(lengths=[250_000_000], div=0.01, repeats="adversarial", params={}, n_query=2, inflight=4, steps=32,
                         label="adversarial repeats (not a BASELINE config): 250 Mb reference, 25 % in eight repeat families up to 10^5 copies at 1-15 % divergence, microsatellites, N runs, soft-masked blocks, vs 1 %-diverged query"),
 }
 
@@ -494,6 +494,7 @@ def main():
     ap.add_argument("--extra", default="human,ecoli,yeast,adversarial", help="further workloads measured in the same run (a process each, loops of their own); '' = none")
     ap.add_argument("--hwq", type=int, default=16, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default of 4; the contexts in flight have 5 streams each)")
     ap.add_argument("--split", action="store_true", help="N > 1 only: ONE contig per step, its seed search sharded by chunk range over the ranks (BASELINE configs[3])")
+    ap.add_argument("--no-torch", action="store_true", help="experiment (N = 1): keep torch out of the process, so that the library runs on the system's HIP runtime")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the N > 1 run (nccl = RCCL; gloo: plumbing checks)")
     ap.add_argument("--same-gpu", action="store_true", help="plumbing check on a one-GPU box: every rank uses GPU 0 (with --backend gloo)")
     ap.add_argument("--dry", action="store_true", help="no GPU: stub aligner + gloo, checks the launcher and the rank plumbing")
@@ -509,20 +510,27 @@ def main():
     if args.hwq > 0:
         os.environ["GPU_MAX_HW_QUEUES"] = str(args.hwq)      # (the runtime's default is 4 hardware queues per process; `inflight` contexts x 5 streams share them)
 
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr); sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py needs a GPU: libgsa_hip.so has no CPU path", file=sys.stderr); sys.exit(2)
     if bool(args.fasta_ref) != bool(args.fasta_query):
         print("bench.py: --fasta-ref and --fasta-query go together", file=sys.stderr); sys.exit(2)
-    if args.same_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    torch.zeros(1, device=dev)                                  # (the runtime's helper threads exist after the first use of the device)
+    no_torch = args.no_torch and world == 1
+    if no_torch:
+        # experiment: N = 1 without torch in the process -- libgsa_hip.so then runs on the system's HIP runtime (its D2H copies go through the
+        # SDMA engines; under the runtime bundled with torch they are shader blits, profiles/r04_blit_probe.txt).  Every library call the
+        # timed region makes is synchronous, so the clock needs no device-wide synchronisation of its own
+        torch = dist = dev = None
+    else:
+        import torch
+        import torch.distributed as dist
+        if not torch.cuda.is_available():
+            print("bench.py needs a GPU: libgsa_hip.so has no CPU path", file=sys.stderr); sys.exit(2)
+        if args.same_gpu:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        torch.zeros(1, device=dev)                                  # (the runtime's helper threads exist after the first use of the device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         if args.backend == "nccl":
@@ -540,11 +548,14 @@ def main():
         dist.barrier()
 
     def sync():
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
 
     def whole_job(m):
+        if torch is None:
+            return float(m["t_total"]), float(m["bp"])
         tt = torch.tensor([m["t_total"]], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -596,6 +607,8 @@ def main():
         for xn in [x for x in args.extra.split(",") if x and x != name and world == 1 and not args.fasta_ref]:
             st = WORKLOADS[xn]["steps"]
             cmd = [sys.executable, os.path.abspath(__file__), "--workload", xn, "--extra", "", "--no-cpu-baseline", "--hwq", str(args.hwq)]
+            if args.no_torch:
+                cmd.append("--no-torch")
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GSA_BENCH_TMP=tmp, GSA_BENCH_KEEP="1"))
                 d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

@@ -149,7 +149,7 @@ struct gsa_ctx {
 	DevBuf d_cand_s, d_cand_len, d_cand_x0, d_cand_freq, d_onpath, d_cand_cnt;
 	size_t cand_cap_per_chunk = 1536;
 	DevBuf d_heavy, dn_lf, dn_x0;               // chunks the speculative seed kernel gave up on; next(s) / accepted match per start of the dense chunks
-	bool seed_sweep_next = false; int seed_sweep_run = 0;   // the previous contig handed most chunks to the sweep: the next one starts there (k_seed.hip, stage1_seed)
+	bool seed_sweep_next = false, seed_sweep_probe = false; int seed_sweep_run = 0, seed_sweep_period = 8;   // the previous contig handed most chunks to the sweep: the next one starts there (k_seed.hip, stage1_seed)
 	u32 seed_budget = 256;                         // wave-iterations a chunk may take in the speculative kernel before it goes to the dense path (GSA_SEED_BUDGET)
 	DevBuf d_chunk_hits, d_chunk_base;             // located hits per chunk and their exclusive prefix   // memoised matches of the search kernel + on-path bits
 	DevBuf d_key_a, d_key_b, d_val_a, d_val_b;     // sort ping-pong

@@ -217,20 +217,34 @@ __global__ void __launch_bounds__(256) k_materialize(i32 nfb, const i32 *__restr
 					const i64 o = aoff[i]; const i32 L = Lr;
 					const uint8_t *qs = query + f.qpos, *rs = ref + f.rpos;
 					i32 score = 0;
-					if (t == FT_DEL) { for (i32 p = 0; p < L; p++) { aln1[o + p] = rs[p]; aln2[o + p] = '-'; } }
-					else if (t == FT_INS) { for (i32 p = 0; p < L; p++) { aln1[o + p] = '-'; aln2[o + p] = qs[p]; } }
-					else if (t == FT_EQ) { for (i32 p = 0; p < L; p++) { aln1[o + p] = rs[p]; aln2[o + p] = qs[p]; } score = f.qlen - fmism[i]; }
-					else {
+					// All the loads of a record first, then its stores: the string pools are byte pointers like the sources, so a store in
+					// between holds every later load back until it is through -- 32 dependent round trips per record where two will do.
+					uint8_t a1[MAT_SERIAL], a2[MAT_SERIAL];
+					if (t == FT_DP) {
 						// ops are forward M/D/I; 'D' puts '-' into aln1, 'I' into aln2 (ksw2_alignment.cpp:264-272)
-						const uint8_t *op = ops + opsoff[fjob[i]];
+						const uint8_t *op = ops + opsoff[fj];
+						uint8_t ch[MAT_SERIAL];
+#pragma unroll
+						for (i32 p = 0; p < MAT_SERIAL; p++) ch[p] = p < L ? op[p] : (uint8_t)0;
 						i32 i1 = 0, i2 = 0;
-						for (i32 p = 0; p < L; p++) {
-							const uint8_t ch = op[p];
-							const uint8_t a1 = (ch == 'M' || ch == 'I') ? rs[i1++] : (uint8_t)'-', a2 = (ch == 'M' || ch == 'D') ? qs[i2++] : (uint8_t)'-';
-							aln1[o + p] = a1; aln2[o + p] = a2;
-							score += (gsa_nt4(a1) == gsa_nt4(a2));             // CountIdenticalPairs (:38-47)
+#pragma unroll
+						for (i32 p = 0; p < MAT_SERIAL; p++) {
+							const bool c1 = ch[p] == 'M' || ch[p] == 'I', c2 = ch[p] == 'M' || ch[p] == 'D';
+							a1[p] = c1 ? rs[i1] : (uint8_t)'-'; a2[p] = c2 ? qs[i2] : (uint8_t)'-';
+							i1 += c1; i2 += c2;
 						}
+#pragma unroll
+						for (i32 p = 0; p < MAT_SERIAL; p++) if (p < L) score += (gsa_nt4(a1[p]) == gsa_nt4(a2[p]));             // CountIdenticalPairs (:38-47)
+					} else {
+#pragma unroll
+						for (i32 p = 0; p < MAT_SERIAL; p++) {
+							a1[p] = (t != FT_INS && p < L) ? rs[p] : (uint8_t)'-';
+							a2[p] = (t != FT_DEL && p < L) ? qs[p] : (uint8_t)'-';
+						}
+						if (t == FT_EQ) score = f.qlen - fmism[i];
 					}
+#pragma unroll
+					for (i32 p = 0; p < MAT_SERIAL; p++) if (p < L) { aln1[o + p] = a1[p]; aln2[o + p] = a2[p]; }
 					add(i, L, score);
 				}
 			}

@@ -1672,6 +1672,13 @@ int stage1_seed(gsa_ctx *c)
 			hits = c->h_cnt[CNT_HITS]; maxcand = c->h_cnt[CNT_CAND]; n_heavy = c->h_cnt[CNT_HEAVY]; occ_all = c->h_cnt[CNT_OCCBLK_ALL];
 			c->dbg[0] = c->h_cnt[11]; c->dbg[1] = n_heavy; c->dbg[2] = c->h_cnt[13]; c->dbg[3] = c->h_cnt[14]; c->dbg[4] = c->h_cnt[15]; c->dbg[5] = c->h_cnt[7];
 			c->counters[0] = c->h_cnt[CNT_OCCBLK];
+			if (seed_mode == 1) {
+				// re-decided by every contig that goes through the speculative kernel.  A look that only confirms the sweep doubles the distance to
+				// the next one (8, 16, 32, 64 contigs: the speculative attempt costs a repeat-rich 250 Mb contig 4.9 ms on top of its 12)
+				c->seed_sweep_next = n_heavy * 5 > (u64)n_chunks * 2;
+				c->seed_sweep_period = (c->seed_sweep_next && c->seed_sweep_probe) ? (c->seed_sweep_period < 64 ? c->seed_sweep_period * 2 : 64) : 8;
+				c->seed_sweep_probe = false;
+			}
 		}
 		if (n_heavy > 0) {
 			const size_t nd = (size_t)n_heavy * GSA_CHUNK;
@@ -1684,8 +1691,7 @@ int stage1_seed(gsa_ctx *c)
 			const u64 sweep_min = 1024;
 #endif
 			const bool use_sweep = seed_mode != 2 && ((seed_mode == 0 && dense_all) || n_heavy >= sweep_min);      // (-sen: every chunk is dense -- a bundle's worth of them is swept, a short contig's few are searched start by start: one round trip chain of ~5 per start beats a segment's chain of 60-250 when the chip is empty)
-			if (!dense_all && seed_mode == 1) c->seed_sweep_next = n_heavy * 5 > (u64)n_chunks * 2;      // (re-decided by every contig that goes through the speculative kernel)
-			else if (sweep_all && seed_mode == 1 && ++c->seed_sweep_run >= 8) { c->seed_sweep_next = false; c->seed_sweep_run = 0; }      // look again now and then
+			if (sweep_all && seed_mode == 1 && ++c->seed_sweep_run >= c->seed_sweep_period) { c->seed_sweep_next = false; c->seed_sweep_probe = true; c->seed_sweep_run = 0; }      // look again now and then
 			if (use_sweep) {
 #ifdef GSA_EXPERIMENTS
 				static const int seg_env = [] { const char *e = getenv("GSA_SWEEP_SEG"); return e ? atoi(e) : 0; }();
