@@ -10,8 +10,9 @@ for w in ${KW:-human_full human ecoli yeast adversarial}; do
   python tools/rocprof_summary.py gpurun_out/prof_$w/p_results.db > gpurun_out/kernels_$w.txt
   rm -rf gpurun_out/prof_$w
 done
-WL="human ecoli yeast" STEPS=8 bash tools/tl1.sh
+WL="human ecoli yeast adversarial" STEPS=8 bash tools/tl1.sh
 STEPS=1 bash tools/pmc_top.sh human_full > gpurun_out/pmc_top_full.log 2>&1
 bash tools/pmc_top.sh human > gpurun_out/pmc_top.log 2>&1
 bash tools/pmc_sq.sh human > gpurun_out/pmc_sq.log 2>&1
-# then, back in the container: python tools/pmc_top.py human_full; python tools/pmc_top.py human ; python tools/pmc_sq.py human > profiles/r04_sq_human.txt
+bash tools/r4_adv_pmc.sh > gpurun_out/pmc_adv.log 2>&1
+# then, back in the container: python tools/pmc_top.py human_full; python tools/pmc_top.py human ; python tools/pmc_sq.py human > profiles/r04_sq_human.txt ; python tools/pmc_adv.py > profiles/r04_pmc_adversarial.txt
