@@ -321,6 +321,7 @@ int gsa_set_option(gsa_ctx *c, const char *name, int64_t value)
 	else if (k == "seed_mode") { if (value < 0 || value > 2) return gsa_fail(c, GSA_ERR_ARG, "seed_mode: 0 sweep, 1 speculative, 2 search"); c->opt.seed_mode = (int)value; }
 	else if (k == "pd_bitmap") c->opt.pd_bitmap = value != 0;
 	else if (k == "walk_coop") c->opt.walk_coop = value != 0;
+	else if (k == "sweep_shape") { if (value < -1 || value > 1) return gsa_fail(c, GSA_ERR_ARG, "sweep_shape: -1, 0 or 1"); c->opt.sweep_shape = (int)value; }
 	else if (k == "dp_safe") c->dp_safe = value != 0;                    // (test hook)
 	else if (k == "dp_fake_timeout") c->dp_fake_timeout = (int)value;    // (test hook)
 	else return gsa_fail(c, GSA_ERR_ARG, "gsa_set_option: unknown option " + k);

@@ -77,6 +77,7 @@ struct Options {
 	int dp_lane = 512;                 // alignments of at most this many cells go one per lane (k_dp_lane); 0: round 2's tiny / small split
 	int seed_mode = 1;                 // 0 sweep: every chunk through k_dense_sweep; 1: the speculative kernel + dense kernels for what it gives up on; 2: round 2's k_dense_search in place of the sweep
 	int pd_bitmap = 1;                 // 0: groups by the PosDiff sort although MaxIndelSize <= 31 would allow the bitmap scan
+	int sweep_shape = -1;              // k_dense_sweep's launch shape: -1 by the number of dense chunks, 0 = four chunks per two-wave workgroup / 160-start segments, 1 = one chunk per four-wave workgroup / 40-start segments
 	int walk_coop = 0;                 // 1: the window walk's pointer-doubling rounds as one cooperative launch (measured slower, alone and under load); 0: a launch per round
 	int kmer_k = 0;                    // gsa_create_opts (GSA_CREATE_KMER_K): length of the jump table's k-mers (0: by text length and free memory)
 };

@@ -1695,10 +1695,10 @@ int stage1_seed(gsa_ctx *c)
 			if (use_sweep) {
 #ifdef GSA_EXPERIMENTS
 				static const int seg_env = [] { const char *e = getenv("GSA_SWEEP_SEG"); return e ? atoi(e) : 0; }();
-				static const int shape_env = [] { const char *e = getenv("GSA_SWEEP_SHAPE"); return e ? atoi(e) : -1; }();
 #else
-				const int seg_env = 0, shape_env = -1;
+				const int seg_env = 0;
 #endif
+				const int shape_env = c->opt.sweep_shape;
 				// few dense chunks (a bundle of short contigs): one chunk per workgroup of four waves and 40 starts per segment, so that the
 				// chip has waves to run; many: four chunks per workgroup of two waves, 160 starts per segment
 				const bool small = shape_env >= 0 ? shape_env == 1 : n_heavy < 8192;

@@ -146,6 +146,8 @@ int  gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *pr
  *   "seed_mode"      1 = speculative kernel + dense kernels for the chunks it gives up on (default), 0 = every chunk through the
  *                    right-to-left sweep, 2 = one search per start instead of the sweep
  *   "pd_bitmap"      0 = seed groups by the PosDiff sort (SeedGrouping as written, GSAlign.cpp:126-143) even where the bitmap scan applies
+ *   "sweep_shape"    launch shape of the repeat-regime seed kernel (k_dense_sweep): -1 (default) by the number of dense chunks, 0 = four chunks per
+ *                    workgroup and 160-start segments (many chunks), 1 = one chunk per workgroup and 40-start segments (few).  Results do not depend on it
  *   "walk_coop"      1 = the pointer-doubling rounds of the window walk (chaining, contigs above 100 000 seeds) as ONE cooperative launch instead of a
  *                    launch per round (default 0: measured slower)
  *   "dp_safe", "dp_fake_timeout"   test hooks: one striped DP job per launch; the next n contigs report a stripe hand-off time-out once

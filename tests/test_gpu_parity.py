@@ -280,6 +280,25 @@ def test_adversarial_repeats_vs_oracle(oracle_built, tmp_path, total, ncontig, d
     o.close(); g.close()
 
 
+@pytest.mark.parametrize("shape,params", [(0, {}), (1, {}), (0, dict(sen=1, clr=50)), (1, dict(sen=1, clr=50, wide=True))])
+def test_sweep_launch_shapes_vs_oracle(oracle_built, tmp_path, shape, params):
+    """k_dense_sweep's two launch shapes (round 4: four chunks per workgroup with the 160-start segments drawn by the lanes from an LDS counter;
+    one chunk per four-wave workgroup with 40-start segments), each forced onto EVERY chunk of an adversarial pair (`seed_mode` 0, `sweep_shape`),
+    with and without -sen: the shape is chosen by the number of dense chunks otherwise, and inputs of test size would only ever see one of them.
+    Every block, record and gapped string vs the oracle; regime: bwt_search.cpp:177-182, GSAlign.cpp:75-91."""
+    params = dict(params); wide = params.pop("wide", False)
+    refs, qrys = synth.make_adversarial_pair(3000000, 2, 0.01, seed=74 + shape, n_run=100000)
+    qrys[1] = (qrys[1][0], synth.revcomp(qrys[1][1]))
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx, params); g = capi.Aligner(idx, wide=wide, **params)
+    g.set_option("seed_mode", 0); g.set_option("sweep_shape", shape)
+    _same_as_oracle(o, g, qrys)
+    assert int(g.seed_stats()[1]) == sum((q.size + 9999) // 10000 for _, q in qrys[-1:])      # every chunk of the last contig went the dense way
+    c = g.counters()
+    assert int(c[2]) > 0 and int(c[2]) == int(o.counters()[2])
+    o.close(); g.close()
+
+
 @pytest.mark.parametrize("k,wide", [(15, False), (15, True)])
 def test_long_kmer_table(oracle_built, tmp_path, monkeypatch, k, wide):
     """Human-chromosome-sized texts get a k-mer jump table of k = 15 (16 GiB; 32 with wide entries) -- the table length follows
