@@ -19,7 +19,11 @@
 #ifndef LB_GRID_PER_CU
 #define LB_GRID_PER_CU 2    // workgroups per CU of a fused pass (persistent: tiles are drawn from the ticket counter)
 #endif
-#define LB_ITEMS 4          // elements per thread (default; passes with heavy per-element work use 1)
+#ifndef LB_ITEMS
+#define LB_ITEMS 8          // elements per thread (default).  Round 4 (late): 4 -> 8 once the passes read an element's inputs in front of the scan (Item): a tile's fixed
+                            // cost -- ticket, barriers, look-back -- is what a pass pays; 2 / 4 / 8 / 12 / 16 per thread: 3.06 / 2.29 / 1.86 / 1.81 / 3.49 ms for the
+                            // 21 passes of a 250 Mb contig (16 spills); the hash-table pass stays at 4, the record pass takes 12
+#endif
 
 struct LbArgs {
 	unsigned long long *status[2];   // tile status words, one array per scanned component
@@ -31,42 +35,93 @@ struct LbArgs {
 #include <type_traits>
 template <class T, class = void> struct lb_has_finish : std::false_type {};
 template <class T> struct lb_has_finish<T, std::void_t<decltype(&T::finish)>> : std::true_type {};
+// Ops with an Item: `Item load(i)` reads everything value() and emit() need about element i ONCE, in front of the scan -- the loads of a
+// thread's ITEMS elements are independent and go out together -- and `value(item, i, c)` / `emit(item, i, v, ex)` work from the registers.
+// Without it emit() re-reads its inputs behind the look-back (atomics: nothing loaded earlier may be kept) and, its pointers being plain,
+// behind each of its own stores: ~10 dependent L2 round trips per element, ITEMS times in a row (OpDpJobs: 64 us per tile, 98 % of its
+// wave-cycles waiting -- profiles/r04_sq_human.txt).
+template <class T, class = void> struct lb_has_item : std::false_type {};
+template <class T> struct lb_has_item<T, std::void_t<typename T::Item>> : std::true_type {};
+template <class T, bool = lb_has_item<T>::value> struct lb_item_of { struct type {}; };
+template <class T> struct lb_item_of<T, true> { using type = typename T::Item; };
 
 __device__ __forceinline__ unsigned long long lb_pack(u32 epoch, u32 flag, u32 val) { return ((unsigned long long)(epoch & 0x3fffffffu) << 34) | ((unsigned long long)flag << 32) | val; }
 
-// exclusive prefix of tile `tile` for one component; agg = the tile's total (same in all threads).
-// Must be called by every thread of the workgroup.
-__device__ __forceinline__ i32 lb_tile_prefix(const LbArgs &lb, int comp, int tile, i32 agg, i32 *s_bcast)
+// exclusive prefixes of tile `tile` for all NV components at once; agg[c] = the tile's totals (same in all threads).
+// Must be called by every thread of the workgroup.  Wave 0 walks back through the predecessors' status words, 64 per window.
+// Round 4 (late): (a) the components are looked up TOGETHER -- their loads are in flight at the same time; one after the other a
+// two-component pass paid the walk twice; (b) a window is settled as soon as every tile between this one and the NEAREST
+// predecessor that knows its inclusive prefix has published its total: the tiles further back than that one do not matter, and
+// waiting for all 64 of a window meant waiting for the slowest of 64 workgroups.
+template <int NV>
+__device__ __forceinline__ void lb_tile_prefix(const LbArgs &lb, int tile, const i32 (&agg)[NV], i32 (&pre)[NV], i32 *s_bcast)
 {
-	unsigned long long *st = lb.status[comp];
 	const int tid = threadIdx.x, lane = tid & 63;
 	const u32 ep = lb.epoch & 0x3fffffffu;
 	if (tile == 0) {
-		if (tid == 0) { __hip_atomic_store(&st[0], lb_pack(ep, 2, (u32)agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_bcast[comp] = 0; }
+		if (tid == 0) {
+#pragma unroll
+			for (int c = 0; c < NV; c++) { __hip_atomic_store(&lb.status[c][0], lb_pack(ep, 2, (u32)agg[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_bcast[c] = 0; }
+		}
 	} else if (tid < 64) {
-		if (lane == 0) __hip_atomic_store(&st[tile], lb_pack(ep, 1, (u32)agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		i32 excl = 0;
+		if (lane == 0) {
+#pragma unroll
+			for (int c = 0; c < NV; c++) __hip_atomic_store(&lb.status[c][tile], lb_pack(ep, 1, (u32)agg[c]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		i32 excl[NV]; bool fin[NV];                                   // (fin: wave-uniform)
+#pragma unroll
+		for (int c = 0; c < NV; c++) { excl[c] = 0; fin[c] = false; }
 		for (int base = tile - 1;; base -= 64) {
 			const int idx = base - lane;
-			unsigned long long w = lb_pack(ep, 2, 0);                    // tiles before tile 0: prefix 0
+			unsigned long long w[NV];
+			int first[NV];
 			u32 spins = 0;
 			for (;;) {
-				if (idx >= 0) w = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (!__any((u32)(w >> 34) != ep || ((w >> 32) & 3) == 0)) break;
-				if (++spins > (1u << 22)) { if (lane == 0) *lb.err = 1; w = lb_pack(ep, 2, 0); break; }
+				bool settled = true;
+#pragma unroll
+				for (int c = 0; c < NV; c++) {
+					w[c] = lb_pack(ep, 2, 0);                            // tiles before tile 0: prefix 0
+					first[c] = 0;
+					if (fin[c]) continue;
+					if (idx >= 0) w[c] = __hip_atomic_load(&lb.status[c][idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+#pragma unroll
+				for (int c = 0; c < NV; c++) {
+					if (fin[c]) continue;
+					const bool rdy = (u32)(w[c] >> 34) == ep && ((w[c] >> 32) & 3) != 0;
+					const unsigned long long p2 = __ballot(rdy && ((w[c] >> 32) & 3) == 2), nr = __ballot(!rdy);
+					first[c] = p2 ? __ffsll((long long)p2) - 1 : 64;     // nearest predecessor that already knows its inclusive prefix
+					const unsigned long long need = first[c] >= 63 ? ~0ull : ((2ull << first[c]) - 1ull);      // lanes 0 .. first
+					if (nr & need) settled = false;
+				}
+				if (settled) break;
+				if (++spins > (1u << 22)) {
+					if (lane == 0) *lb.err = 1;
+#pragma unroll
+					for (int c = 0; c < NV; c++) { w[c] = lb_pack(ep, 2, 0); first[c] = 0; }
+					break;
+				}
 				__builtin_amdgcn_s_sleep(1);
 			}
-			const unsigned long long pm = __ballot(((w >> 32) & 3) == 2);
-			const int first = pm ? __ffsll((long long)pm) - 1 : 64;      // nearest predecessor that already knows its inclusive prefix
-			i32 v = lane <= first ? (i32)(u32)w : 0;
-			for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-			excl += v;
-			if (pm) break;
+			bool all_fin = true;
+#pragma unroll
+			for (int c = 0; c < NV; c++) {
+				if (fin[c]) continue;
+				i32 v = lane <= first[c] ? (i32)(u32)w[c] : 0;
+				for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+				excl[c] += v;
+				if (first[c] < 64) fin[c] = true; else all_fin = false;
+			}
+			if (all_fin) break;
 		}
-		if (lane == 0) { __hip_atomic_store(&st[tile], lb_pack(ep, 2, (u32)(excl + agg)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_bcast[comp] = excl; }
+		if (lane == 0) {
+#pragma unroll
+			for (int c = 0; c < NV; c++) { __hip_atomic_store(&lb.status[c][tile], lb_pack(ep, 2, (u32)(excl[c] + agg[c])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_bcast[c] = excl[c]; }
+		}
 	}
 	__syncthreads();
-	return s_bcast[comp];
+#pragma unroll
+	for (int c = 0; c < NV; c++) pre[c] = s_bcast[c];
 }
 
 // a store that the finish() hook of a pass (run by whichever workgroup is through last, possibly on another XCD) will read
@@ -99,11 +154,19 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 	// the workgroup (wave scan + wave totals through LDS, one barrier for all rows), rows follow each other.
 	const i64 i0 = (i64)tile * LB_TILE + tid;
 	i32 v[NV][ITEMS], inc[NV][ITEMS];
+	typename lb_item_of<Op>::type item[ITEMS];
+	if constexpr (lb_has_item<Op>::value) {
+#pragma unroll
+		for (int k = 0; k < ITEMS; k++) { const i64 i = i0 + (i64)k * LB_TPB; if (i < n) item[k] = op.load(i); }
+	}
 #pragma unroll
 	for (int k = 0; k < ITEMS; k++) {
 		const i64 i = i0 + (i64)k * LB_TPB;
 #pragma unroll
-		for (int c = 0; c < NV; c++) v[c][k] = i < n ? op.value(i, c) : 0;
+		for (int c = 0; c < NV; c++) {
+			if constexpr (lb_has_item<Op>::value) v[c][k] = i < n ? op.value(item[k], i, c) : 0;
+			else v[c][k] = i < n ? op.value(i, c) : 0;
+		}
 	}
 #pragma unroll
 	for (int c = 0; c < NV; c++)
@@ -130,8 +193,7 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 		agg[c] = run;
 	}
 	i32 pre[NV];
-#pragma unroll
-	for (int c = 0; c < NV; c++) pre[c] = lb_tile_prefix(lb, c, tile, agg[c], s_bcast);
+	lb_tile_prefix<NV>(lb, tile, agg, pre, s_bcast);
 	i32 vv[NV], ee[NV];
 #pragma unroll
 	for (int k = 0; k < ITEMS; k++) {
@@ -139,7 +201,8 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 #pragma unroll
 		for (int c = 0; c < NV; c++) { vv[c] = v[c][k]; ee[c] = pre[c] + inc[c][k]; }
 		if (i < n) {
-			op.emit(i, vv, ee);
+			if constexpr (lb_has_item<Op>::value) op.emit(item[k], i, vv, ee);
+			else op.emit(i, vv, ee);
 			if (i == n - 1) { i32 tt[NV]; for (int c = 0; c < NV; c++) tt[c] = ee[c] + vv[c]; op.done(tt); }
 		}
 	}

@@ -165,14 +165,18 @@ struct OpUniqBrk {
 struct OpCand {
 	i64 na; const i32 *a_gb, *a_ge, *cuEx, *brk;
 	i32 *candf, *candEx, *clist, *ws;
-	__device__ i32 value(i64 i, int) const
+	struct Item { i32 cand, head; };
+	__device__ Item load(i64 i) const
 	{
 		const i32 gb = a_gb[i], ge = a_ge[i];
-		return (cuEx[ge] - cuEx[gb] >= GSA_WIN_SEEDS && (i == gb || brk[i])) ? 1 : 0;
+		Item it; it.head = i == gb ? 1 : 0;
+		it.cand = (cuEx[ge] - cuEx[gb] >= GSA_WIN_SEEDS && (i == gb || brk[i])) ? 1 : 0;
+		return it;
 	}
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	__device__ i32 value(const Item &it, i64, int) const { return it.cand; }
+	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const
 	{
-		candf[i] = v[0]; candEx[i] = ex[0]; ws[i] = i == a_gb[i] ? 1 : 0;
+		candf[i] = v[0]; candEx[i] = ex[0]; ws[i] = it.head;
 		if (v[0]) clist[ex[0]] = (i32)i;
 	}
 	__device__ void done(const i32 *t) const { candEx[na] = t[0]; candf[na] = 0; ws[na] = 0; }
@@ -335,15 +339,17 @@ __device__ __forceinline__ u32 bkt_hash(unsigned long long k, int capbits) { ret
 struct OpWindowBuckets {
 	i64 na; const i32 *a_q; const i64 *a_r; const i32 *uniq, *ws; i64 bmin; int capbits;
 	i32 *wsEx, *slot_of; Bucket *tab; unsigned long long *wbest, *wsum; i32 *wn;
-	__device__ i32 value(i64 i, int) const { return ws[i]; }
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	struct Item { i32 ws, uniq; i64 pd; };
+	__device__ Item load(i64 i) const { Item it; it.ws = ws[i]; it.uniq = uniq[i]; it.pd = a_r[i] - a_q[i]; return it; }
+	__device__ i32 value(const Item &it, i64, int) const { return it.ws; }
+	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const
 	{
 		wsEx[i] = ex[0];
 		wbest[i] = 0; wsum[i] = 0; wn[i] = 0;
 		i32 slot = -1;
-		if (uniq[i]) {
+		if (it.uniq) {
 			const u32 w = (u32)(ex[0] + v[0] - 1);
-			const u32 b = (u32)(((a_r[i] - a_q[i]) >> 4) - bmin);              // bucket, shifted to be non-negative
+			const u32 b = (u32)((it.pd >> 4) - bmin);              // bucket, shifted to be non-negative
 			const unsigned long long key = ((unsigned long long)w << 32) | b;
 			const u32 mask = (1u << capbits) - 1;
 			u32 h = bkt_hash(key, capbits);
@@ -440,12 +446,19 @@ __global__ void k_multihit(i64 na, const i32 *__restrict__ a_q, const i64 *__res
 struct OpCompactAlive {
 	const i32 *alive, *a_q, *a_len; const i64 *a_r; const i32 *a_gb;
 	i32 *b_q, *b_len; i64 *b_r; i32 *b_g, *mail;
-	__device__ i32 value(i64 i, int) const { return alive[i] ? 1 : 0; }
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	struct Item { i32 alive, q, len, g; i64 r; };
+	__device__ Item load(i64 i) const
+	{
+		Item it; it.alive = alive[i] ? 1 : 0; it.q = it.len = it.g = 0; it.r = 0;
+		if (it.alive) { it.q = a_q[i]; it.len = a_len[i]; it.r = a_r[i]; it.g = a_gb[i]; }
+		return it;
+	}
+	__device__ i32 value(const Item &it, i64, int) const { return it.alive; }
+	__device__ void emit(const Item &it, i64, const i32 *v, const i32 *ex) const
 	{
 		if (!v[0]) return;
 		const i32 p = ex[0];
-		b_q[p] = a_q[i]; b_len[p] = a_len[i]; b_r[p] = a_r[i]; b_g[p] = a_gb[i];
+		b_q[p] = it.q; b_len[p] = it.len; b_r[p] = it.r; b_g[p] = it.g;
 	}
 	__device__ void done(const i32 *t) const { mail[M_NB] = t[0]; }
 };
@@ -454,21 +467,25 @@ struct OpCompactAlive {
 struct OpNoise {
 	const i32 *b_q, *b_len; const i64 *b_r; const i32 *b_g;
 	i32 *c_q, *c_len; i64 *c_r; i32 *c_g, *mail;
-	__device__ i32 value(i64 i, int) const
+	struct Item { i32 keep, q, len, g; i64 r; };
+	__device__ Item load(i64 i) const
 	{
+		Item it; it.keep = 0; it.q = it.len = it.g = 0; it.r = 0;
 		const i64 nb = mail[M_NB];
-		if (i >= nb) return 0;
-		if (i > 0 && i + 1 < nb && b_g[i - 1] == b_g[i] && b_g[i + 1] == b_g[i]) {
-			const i64 pd = b_r[i] - b_q[i], p0 = b_r[i - 1] - b_q[i - 1], p1 = b_r[i + 1] - b_q[i + 1];
-			if (d_llabs(pd - p0) > 5 && d_llabs(pd - p1) > 5) return 0;
+		if (i >= nb) return it;
+		it.keep = 1; it.q = b_q[i]; it.len = b_len[i]; it.r = b_r[i]; it.g = b_g[i];
+		if (i > 0 && i + 1 < nb && b_g[i - 1] == it.g && b_g[i + 1] == it.g) {
+			const i64 pd = it.r - it.q, p0 = b_r[i - 1] - b_q[i - 1], p1 = b_r[i + 1] - b_q[i + 1];
+			if (d_llabs(pd - p0) > 5 && d_llabs(pd - p1) > 5) it.keep = 0;
 		}
-		return 1;
+		return it;
 	}
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	__device__ i32 value(const Item &it, i64, int) const { return it.keep; }
+	__device__ void emit(const Item &it, i64, const i32 *v, const i32 *ex) const
 	{
 		if (!v[0]) return;
 		const i32 p = ex[0];
-		c_q[p] = b_q[i]; c_len[p] = b_len[i]; c_r[p] = b_r[i]; c_g[p] = b_g[i];
+		c_q[p] = it.q; c_len[p] = it.len; c_r[p] = it.r; c_g[p] = it.g;
 	}
 	__device__ void done(const i32 *t) const { mail[M_NC] = t[0]; }
 };
@@ -495,21 +512,24 @@ struct OpBlockFilter {
 	i64 na; const i32 *bstart, *c_q, *c_len; const u32 *ps; Params prm;
 	i32 *bkeep, *bkeepEx, *blk_beg, *blk_end, *blk_score, *mail;
 	__device__ void span(i64 b, i32 &s, i32 &e) const { const i32 nAll = mail[M_NBRAW]; s = bstart[b]; e = (b + 1 < nAll) ? bstart[b + 1] : mail[M_NC]; }
-	__device__ i32 value(i64 b, int) const
+	struct Item { i32 keep, s, e, score; };
+	__device__ Item load(i64 b) const
 	{
-		if (b >= mail[M_NBRAW]) return 0;
-		i32 s, e; span(b, s, e);
-		const i32 score = (i32)(ps[e] - ps[s]);
-		const i32 region = c_q[e - 1] + c_len[e - 1] - c_q[s];
-		const bool drop = score < prm.MinAlnBlockScore || region < prm.MinAlnLength || (score < 1000 && (double)score < region * 0.05);
-		return drop ? 0 : 1;
+		Item it; it.keep = 0; it.s = it.e = it.score = 0;
+		if (b >= mail[M_NBRAW]) return it;
+		span(b, it.s, it.e);
+		it.score = (i32)(ps[it.e] - ps[it.s]);
+		const i32 region = c_q[it.e - 1] + c_len[it.e - 1] - c_q[it.s];
+		const bool drop = it.score < prm.MinAlnBlockScore || region < prm.MinAlnLength || (it.score < 1000 && (double)it.score < region * 0.05);
+		it.keep = drop ? 0 : 1;
+		return it;
 	}
-	__device__ void emit(i64 b, const i32 *v, const i32 *ex) const
+	__device__ i32 value(const Item &it, i64, int) const { return it.keep; }
+	__device__ void emit(const Item &it, i64 b, const i32 *v, const i32 *ex) const
 	{
 		bkeep[b] = v[0]; bkeepEx[b] = ex[0];
 		if (!v[0]) return;
-		i32 s, e; span(b, s, e);
-		blk_beg[ex[0]] = s; blk_end[ex[0]] = e; blk_score[ex[0]] = (i32)(ps[e] - ps[s]);
+		blk_beg[ex[0]] = it.s; blk_end[ex[0]] = it.e; blk_score[ex[0]] = it.score;
 	}
 	__device__ void done(const i32 *t) const { mail[M_NBLK] = t[0]; }
 };
@@ -542,25 +562,25 @@ struct OpEarlyGaps {
 		i32 mism;
 		return classify_gap(query, ref, qp, rp, qg, rg, mism) == FT_DP;
 	}
-	// (component 0 is asked first and leaves its verdict in e_id[s], so the mismatch loop of a gap runs once)
-	__device__ i32 value(i64 s, int c) const
+	// (everything a seed's verdict needs is read once, in front of the scan: Item)
+	struct Item { i32 in, bid, g, qp, qg, rg; i64 rp; };      // in: s < the live seed count; g: a large DP gap follows s; qg / rg: its two lengths as the job list takes them
+	__device__ Item load(i64 s) const
 	{
-		if (c == 1) { if (!e_id[s]) return 0; const i32 qp = q[s] + len[s]; const i64 rp = r[s] + len[s]; return (q[s + 1] - qp) + (i32)(r[s + 1] - rp); }
+		Item it; it.in = 0; it.bid = -1; it.g = 0; it.qp = it.qg = it.rg = 0; it.rp = 0;
+		if (s < mail[M_NC]) { it.in = 1; it.bid = bid_of(s); }
 		i32 qp, qg, rg; i64 rp;
-		const bool g = gap(s, qp, rp, qg, rg);
-		e_id[s] = g ? 1 : 0;
-		return g ? 1 : 0;
+		if (gap(s, qp, rp, qg, rg)) { it.g = 1; it.qp = qp; it.rp = rp; it.qg = q[s + 1] - qp; it.rg = (i32)(r[s + 1] - rp); }
+		return it;
 	}
-	__device__ void emit(i64 s, const i32 *v, const i32 *ex) const
+	__device__ i32 value(const Item &it, i64, int c) const { return c == 1 ? (it.g ? it.qg + it.rg : 0) : it.g; }
+	__device__ void emit(const Item &it, i64 s, const i32 *v, const i32 *ex) const
 	{
-		if (s < mail[M_NC]) bid[s] = bid_of(s);
+		if (it.in) bid[s] = it.bid;
 		e_id[s] = v[0] ? ex[0] : -1;
 		if (!v[0]) return;
-		const i32 qp = q[s] + len[s]; const i64 rp = r[s] + len[s];
-		const i32 qg = q[s + 1] - qp, rg = (i32)(r[s + 1] - rp);
 		const i32 e = ex[0];
-		lb_pub(&e_list[3 * e], e); lb_pub(&e_list[3 * e + 1], rg); lb_pub(&e_list[3 * e + 2], qg);      // (finish() reads the list)
-		off1[e] = rp; off2[e] = qp; opsoff[e] = ex[1]; e_rec[e] = -1;
+		lb_pub(&e_list[3 * e], e); lb_pub(&e_list[3 * e + 1], it.rg); lb_pub(&e_list[3 * e + 2], it.qg);      // (finish() reads the list)
+		off1[e] = it.rp; off2[e] = it.qp; opsoff[e] = ex[1]; e_rec[e] = -1;
 	}
 	__device__ void done(const i32 *t) const { lb_pub(&mail[M_NEARLY], t[0]); lb_pub(&mail[M_EOPS], t[1]); lb_pub(&mail[M_DPERR3], 0); }
 	// the last tile puts the two counts and the head of the list into pinned memory: the host launches from there
@@ -763,7 +783,7 @@ int stage2_chain(gsa_ctx *c)
 	GSA_CHECK(c, hipMemsetAsync(c->d_btab.p, 0xff, (size_t)cap * sizeof(Bucket), st));
 	i32 *slot_of = c->a_runinfo.as<i32>();
 	{ OpWindowBuckets op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, bmin, capbits, wsEx, slot_of, c->d_btab.as<Bucket>(),
-	                         c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>() }; RC((lb_launch<1>(c, na, op))); }
+	                         c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>() }; RC((lb_launch<1, 4>(c, na, op))); }
 	LAUNCH(k_window_mode, cap, cap, c->d_btab.as<Bucket>(), c->w_best.as<unsigned long long>());
 	LAUNCH(k_window_avg, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(), c->w_best.as<unsigned long long>(), ws, wsEx,
 	       c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->bnd);

@@ -753,19 +753,21 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 // as (job, m, n) triples and packs the others into the small kernel's order array.
 struct OpClassify {
 	const i32 *len1, *len2; i32 *order, *order_tiny, *lg, *jlarge, *mail;
-	__device__ i32 value(i64 j, int c) const
+	struct Item { i32 in, m, n; };
+	__device__ Item load(i64 j) const { Item it; it.in = j < mail[M_NJOB] ? 1 : 0; it.m = it.in ? len1[j] : 0; it.n = it.in ? len2[j] : 0; return it; }
+	__device__ i32 value(const Item &it, i64, int c) const
 	{
-		if (j >= mail[M_NJOB]) return 0;
-		const i32 m = len1[j], n = len2[j];
+		if (!it.in) return 0;
+		const i32 m = it.m, n = it.n;
 		if (c == 0) return dp_is_large(m, n) ? 1 : 0;
 		if (dp_is_large(m, n)) return 0;
 		if (lane_cells > 0) return m * n <= lane_cells ? 1 : 0;         // one lane each (k_dp_lane); the rest of the class: one wavefront each (k_dp_small)
 		return (n <= 16 && m + n - 1 <= TINY_ROWS) ? 1 : 0;            // (GSA_DP_LANE=0) four of these share a wavefront
 	}
-	__device__ void emit(i64 j, const i32 *v, const i32 *ex) const
+	__device__ void emit(const Item &it, i64 j, const i32 *v, const i32 *ex) const
 	{
-		if (j >= mail[M_NJOB]) return;
-		const i32 m = len1[j], n = len2[j];
+		if (!it.in) return;
+		const i32 m = it.m, n = it.n;
 		if (m <= 0 || n <= 0) lb_pub(&mail[M_DPERR], 2);
 		jlarge[j] = v[0];
 		if (v[0]) { i32 *e = lg + 3 * (size_t)ex[0]; lb_pub(&e[0], (i32)j); lb_pub(&e[1], m); lb_pub(&e[2], n); }      // (finish() reads the list)

@@ -41,21 +41,30 @@ struct OpSlots {
 			if (qg > 0 || rg > 0) n = 2;
 		}
 	}
-	__device__ i32 value(i64 i, int) const { i32 k, s, n; slot(i, k, s, n); return n; }
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	struct Item { i32 k, first, n, q, len, qn, early; i64 r, rn; };      // first: the slot opens block k; n = 2: a gap record follows; qn / rn: the next seed's start; early: its early DP job
+	__device__ Item load(i64 i) const
 	{
-		i32 k, s, n; slot(i, k, s, n);
-		const i32 p = ex[0];
-		if (i == seedbase[k]) { fragbase[k] = p; fragbase[k - 2 * (i64)nfb] = 0; fragbase[k - (i64)nfb] = 0; }      // (+ the block's aln_len / score sums start at 0: bl_alnlen[nfb] | bl_score[nfb] | fragbase[] is one buffer)
-		gsa_frag f; f.bseed = 1; f.qpos = q[s]; f.qlen = len[s]; f.rlen = len[s]; f.rpos = r[s]; f.aln_off = 0; f.aln_len = 0; f._pad = 0;
+		Item it; i32 s;
+		slot(i, it.k, s, it.n);
+		it.first = i == seedbase[it.k] ? 1 : 0;
+		it.q = q[s]; it.len = len[s]; it.r = r[s]; it.qn = 0; it.rn = 0; it.early = -1;
+		if (it.n == 2) { it.qn = q[s + 1]; it.rn = r[s + 1]; it.early = e_id[r_orig[s]]; }
+		return it;
+	}
+	__device__ i32 value(const Item &it, i64, int) const { return it.n; }
+	__device__ void emit(const Item &it, i64, const i32 *v, const i32 *ex) const
+	{
+		const i32 k = it.k, p = ex[0];
+		if (it.first) { fragbase[k] = p; fragbase[k - 2 * (i64)nfb] = 0; fragbase[k - (i64)nfb] = 0; }      // (+ the block's aln_len / score sums start at 0: bl_alnlen[nfb] | bl_score[nfb] | fragbase[] is one buffer)
+		gsa_frag f; f.bseed = 1; f.qpos = it.q; f.qlen = it.len; f.rlen = it.len; f.rpos = it.r; f.aln_off = 0; f.aln_len = 0; f._pad = 0;
 		frag[p] = f; ftype[p] = FT_SEED; fmism[p] = 0; fearly[p] = -1;
 		if (v[0] == 2) {
-			i32 qg = q[s + 1] - (q[s] + len[s]); if (qg < 0) qg = 0;
-			i64 rg64 = r[s + 1] - (r[s] + len[s]); i32 rg = rg64 < 0 ? 0 : (i32)rg64;
-			gsa_frag g; g.bseed = 0; g.qpos = q[s] + len[s]; g.rpos = r[s] + len[s]; g.qlen = qg; g.rlen = rg; g.aln_off = 0; g.aln_len = 0; g._pad = 0;
+			i32 qg = it.qn - (it.q + it.len); if (qg < 0) qg = 0;
+			i64 rg64 = it.rn - (it.r + it.len); i32 rg = rg64 < 0 ? 0 : (i32)rg64;
+			gsa_frag g; g.bseed = 0; g.qpos = it.q + it.len; g.rpos = it.r + it.len; g.qlen = qg; g.rlen = rg; g.aln_off = 0; g.aln_len = 0; g._pad = 0;
 			// (class, mismatch count and the link to an early DP launch: k_gap_class, one thread per record)
 			frag[p + 1] = g; ftype[p + 1] = FT_DP; fmism[p + 1] = 0;
-			fearly[p + 1] = e_id[r_orig[s]];
+			fearly[p + 1] = it.early;
 		}
 	}
 	__device__ void done(const i32 *t) const { mail[M_NF] = t[0]; }
@@ -85,32 +94,40 @@ __global__ void k_gap_class(i64 ub, const i32 *__restrict__ mail, const gsa_frag
 struct OpDpJobs {
 	const i32 *ftype, *fearly; gsa_frag *frag; gsa_rec *rec16;
 	i32 *jfrag; i64 *off1; i32 *len1; i64 *off2; i32 *len2; i64 *opsoff; i32 *fjob, *alen; i64 *aoff; i32 *mail;
-	__device__ i32 value(i64 i, int c) const
+	struct Item { gsa_frag f; i32 t, early; };      // t = -1: behind the last record
+	__device__ Item load(i64 i) const
 	{
-		if (i >= mail[M_NF]) return 0;
-		const i32 t = ftype[i];
-		if (c == 0) return (t == FT_DP && fearly[i] < 0) ? 1 : 0;      // (early jobs are already running)
-		if (t == FT_DEL) return frag[i].rlen;
-		if (t == FT_INS || t == FT_EQ) return frag[i].qlen;
-		if (t == FT_DP) return frag[i].rlen + frag[i].qlen;
+		Item it; it.t = -1; it.early = -1;
+		if (i >= mail[M_NF]) return it;
+		it.t = ftype[i]; it.f = frag[i]; it.early = fearly[i];
+		return it;
+	}
+	__device__ i32 value(const Item &it, i64, int c) const
+	{
+		if (it.t < 0) return 0;
+		if (c == 0) return (it.t == FT_DP && it.early < 0) ? 1 : 0;      // (early jobs are already running)
+		if (it.t == FT_DEL) return it.f.rlen;
+		if (it.t == FT_INS || it.t == FT_EQ) return it.f.qlen;
+		if (it.t == FT_DP) return it.f.rlen + it.f.qlen;
 		return 0;
 	}
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const
 	{
-		if (i >= mail[M_NF]) return;
+		if (it.t < 0) return;
 		alen[i] = v[1]; aoff[i] = ex[1];                      // (alen of a DP gap: replaced by the op count)
 		// the record's own string fields: final here for everything but a DP gap (its length comes from the DP kernel
 		// of its size class, or from the host's patch list for the striped ones), so the records can leave early
-		if (ftype[i] != FT_SEED) { frag[i].aln_off = ex[1]; frag[i].aln_len = ftype[i] == FT_DP ? 0 : v[1]; }
+		const i32 al = it.t == FT_DP ? 0 : v[1];
+		if (it.t != FT_SEED) { frag[i].aln_off = ex[1]; frag[i].aln_len = al; }
 		{	// the 16-byte record that travels (gsa_rec, gsa_hip.h): a seed as it is, a gap without its positions
-			const gsa_frag f = frag[i]; gsa_rec r;
-			if (ftype[i] == FT_SEED) { r.seed.qpos = f.qpos; r.seed.len = f.qlen; r.seed.rpos = f.rpos; }
-			else { r.gap.nqlen = -1 - f.qlen; r.gap.rlen = f.rlen; r.gap.aln_len = ftype[i] == FT_DP ? 0 : v[1]; r.gap.aln_off = (u32)ex[1]; }
+			gsa_rec r;
+			if (it.t == FT_SEED) { r.seed.qpos = it.f.qpos; r.seed.len = it.f.qlen; r.seed.rpos = it.f.rpos; }
+			else { r.gap.nqlen = -1 - it.f.qlen; r.gap.rlen = it.f.rlen; r.gap.aln_len = al; r.gap.aln_off = (u32)ex[1]; }
 			rec16[i] = r;
 		}
-		if (!v[0]) { fjob[i] = (ftype[i] == FT_DP) ? -2 - fearly[i] : -1; return; }      // <= -2: early job -2 - fjob
+		if (!v[0]) { fjob[i] = (it.t == FT_DP) ? -2 - it.early : -1; return; }      // <= -2: early job -2 - fjob
 		const i32 j = ex[0];
-		jfrag[j] = (i32)i; off1[j] = frag[i].rpos; len1[j] = frag[i].rlen; off2[j] = frag[i].qpos; len2[j] = frag[i].qlen; opsoff[j] = ex[1];
+		jfrag[j] = (i32)i; off1[j] = it.f.rpos; len1[j] = it.f.rlen; off2[j] = it.f.qpos; len2[j] = it.f.qlen; opsoff[j] = ex[1];
 		fjob[i] = j;
 	}
 	__device__ void done(const i32 *t) const
@@ -406,7 +423,7 @@ int stage78_extend(gsa_ctx *c)
 	ENS(i64, d_alnoff, nfu + 2);
 	ENS(gsa_rec, f_rec16, nfu + 1);
 	{ OpDpJobs op = { c->f_type.as<i32>(), c->f_early.as<i32>(), c->f_rec.as<gsa_frag>(), c->f_rec16.as<gsa_rec>(), c->j_frag.as<i32>(), off1, len1, off2, len2, c->j_opsoff.as<i64>(), c->f_job.as<i32>(),
-	                  c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), mail }; RC((lb_launch<2>(c, nfu, op))); }
+	                  c->f_alnlen.as<i32>(), c->d_alnoff.as<i64>(), mail }; RC((lb_launch<2, 12>(c, nfu, op))); }
 	// the records are final here except for the string length of a DP gap: they leave now (all nf_ub of them: the count is
 	// still on the device), on a third stream; the DP gaps' lengths follow as a short list the host patches in
 	hipStream_t sc = c->stream_aux[2];

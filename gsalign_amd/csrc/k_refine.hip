@@ -27,12 +27,19 @@
 struct OpTakeInBlock {      // seeds that belong to a kept S2 block
 	const i32 *c_q, *c_len; const i64 *c_r; const i32 *c_bid;
 	i32 *r_q, *r_len; i64 *r_r; i32 *r_bid, *r_orig, *mail;      // r_orig: index in the stage-2 seed arrays (links stage-2's early DP launches to the final gaps)
-	__device__ i32 value(i64 i, int) const { return (i < mail[M_NC] && c_bid[i] >= 0) ? 1 : 0; }
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	struct Item { i32 q, len, bid; i64 r; };      // (bid < 0: not taken)
+	__device__ Item load(i64 i) const
+	{
+		Item it; it.bid = -1; it.q = it.len = 0; it.r = 0;
+		if (i < mail[M_NC]) { it.bid = c_bid[i]; it.q = c_q[i]; it.len = c_len[i]; it.r = c_r[i]; }
+		return it;
+	}
+	__device__ i32 value(const Item &it, i64, int) const { return it.bid >= 0 ? 1 : 0; }
+	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const
 	{
 		if (!v[0]) return;
 		const i32 p = ex[0];
-		r_q[p] = c_q[i]; r_len[p] = c_len[i]; r_r[p] = c_r[i]; r_bid[p] = c_bid[i]; r_orig[p] = (i32)i;
+		r_q[p] = it.q; r_len[p] = it.len; r_r[p] = it.r; r_bid[p] = it.bid; r_orig[p] = (i32)i;
 	}
 	__device__ void done(const i32 *t) const { mail[M_NR] = t[0]; for (int k = 0; k < 32; k++) mail[M_ANY + k] = 0; }      // (+ the "a seed died" flags of the overlap rounds: no fill operation in front of them)
 };
@@ -42,27 +49,35 @@ struct OpTakeInBlock {      // seeds that belong to a kept S2 block
 struct OpOverlapPass {
 	const i32 *q, *len; const i64 *r; const i32 *bid, *orig;
 	i32 *oq, *olen; i64 *orr; i32 *obid, *oorig, *mail; int nin, nout, anyslot;
-	__device__ i32 trim(i64 i, i32 &l) const
+	struct Item { i32 in, keep, l, q, bid, orig; i64 r; };      // in: i < the live count; keep / l: the pass's verdict and the trimmed length
+	__device__ Item load(i64 i) const
 	{
+		Item it; it.in = 0; it.keep = 0; it.l = it.q = it.bid = it.orig = 0; it.r = 0;
 		const i64 n = mail[nin];
-		l = len[i];
-		if (i + 1 < n && bid[i + 1] == bid[i]) {
-			const i64 ri = r[i], rj = r[i + 1]; const i32 qi = q[i], qj = q[i + 1];
-			if (rj <= ri) return 0;
-			i32 ov = (i32)(ri + l - rj);
-			if (ov > 0) { l -= ov; if (l <= 0) return 0; }
-			ov = qi + l - qj; if (ov > 0) { l -= ov; if (l <= 0) return 0; }
+		if (i >= n) return it;
+		it.in = 1; it.keep = 1;
+		i32 l = len[i];
+		const i64 ri = r[i]; const i32 qi = q[i], bi = bid[i];
+		it.q = qi; it.r = ri; it.bid = bi; it.orig = orig[i];
+		if (i + 1 < n && bid[i + 1] == bi) {
+			const i64 rj = r[i + 1]; const i32 qj = q[i + 1];
+			if (rj <= ri) it.keep = 0;
+			else {
+				i32 ov = (i32)(ri + l - rj);
+				if (ov > 0) { l -= ov; if (l <= 0) it.keep = 0; }
+				if (it.keep) { ov = qi + l - qj; if (ov > 0) { l -= ov; if (l <= 0) it.keep = 0; } }
+			}
 		}
-		return 1;
+		it.l = l;
+		return it;
 	}
-	__device__ i32 value(i64 i, int) const { if (i >= mail[nin]) return 0; i32 l; return trim(i, l); }
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	__device__ i32 value(const Item &it, i64, int) const { return it.in ? it.keep : 0; }
+	__device__ void emit(const Item &it, i64, const i32 *v, const i32 *ex) const
 	{
-		if (i >= mail[nin]) return;
+		if (!it.in) return;
 		if (!v[0]) { mail[anyslot] = 1; return; }
-		i32 l; trim(i, l);
 		const i32 p = ex[0];
-		oq[p] = q[i]; olen[p] = l; orr[p] = r[i]; obid[p] = bid[i]; oorig[p] = orig[i];
+		oq[p] = it.q; olen[p] = it.l; orr[p] = it.r; obid[p] = it.bid; oorig[p] = it.orig;
 	}
 	__device__ void done(const i32 *t) const { mail[nout] = t[0]; }
 };
@@ -72,25 +87,28 @@ struct OpOverlapPass {
 struct OpGapCuts {
 	int nin; const i32 *q, *len; const i64 *r; const i32 *bid;
 	i32 *cut4, *jq1, *jq2; i64 *jr1, *jr2; i32 *jseed, *mail;
-	__device__ void gaps(i64 i, i32 &cut, i32 &jb) const
+	struct Item { i32 cut, jb, q1, q2; i64 r1, r2; };
+	__device__ Item load(i64 i) const
 	{
-		cut = 0; jb = 0;
+		Item it; it.cut = 0; it.jb = 0; it.q1 = it.q2 = 0; it.r1 = it.r2 = 0;
 		if (i < mail[nin] && i > 0 && bid[i - 1] == bid[i]) {
-			const i32 qGap = q[i] - q[i - 1] - len[i - 1];
-			const i32 rGap = (i32)(r[i] - r[i - 1] - len[i - 1]);
+			const i32 l0 = len[i - 1];
+			it.q1 = q[i - 1] + l0; it.q2 = q[i]; it.r1 = r[i - 1] + l0; it.r2 = r[i];
+			const i32 qGap = it.q2 - it.q1;
+			const i32 rGap = (i32)(it.r2 - it.r1);
 			if (qGap > GSA_GAP_CHECK || rGap > GSA_GAP_CHECK) {
-				if (qGap > GSA_MAX_SEED_GAP || rGap > GSA_MAX_SEED_GAP) cut = 1; else jb = 1;
+				if (qGap > GSA_MAX_SEED_GAP || rGap > GSA_MAX_SEED_GAP) it.cut = 1; else it.jb = 1;
 			}
 		}
+		return it;
 	}
-	__device__ i32 value(i64 i, int) const { i32 c, j; gaps(i, c, j); return j; }
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	__device__ i32 value(const Item &it, i64, int) const { return it.jb; }
+	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const
 	{
-		i32 c, j; gaps(i, c, j);
-		cut4[i] = c;
+		cut4[i] = it.cut;
 		if (!v[0]) return;
 		const i32 p = ex[0];
-		jq1[p] = q[i - 1] + len[i - 1]; jq2[p] = q[i]; jr1[p] = r[i - 1] + len[i - 1]; jr2[p] = r[i]; jseed[p] = (i32)i;
+		jq1[p] = it.q1; jq2[p] = it.q2; jr1[p] = it.r1; jr2[p] = it.r2; jseed[p] = (i32)i;
 	}
 	__device__ void done(const i32 *t) const { mail[M_NJ] = t[0]; }
 };
@@ -115,13 +133,20 @@ struct OpChrCuts {
 			}
 		}
 	}
-	__device__ i32 value(i64 i, int c) const { if (i >= *d_n) return 0; if (c == 1) return len[i]; i32 c5, h; cuts(i, c5, h); return h; }
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	struct Item { i32 in, c5, h, len; };
+	__device__ Item load(i64 i) const
+	{
+		Item it; it.in = 0; it.c5 = 0; it.h = 0; it.len = 0;
+		if (i >= *d_n) return it;
+		it.in = 1; it.len = len[i]; cuts(i, it.c5, it.h);
+		return it;
+	}
+	__device__ i32 value(const Item &it, i64, int c) const { return c == 1 ? it.len : it.h; }
+	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const
 	{
 		ps[i] = (u32)ex[1];                                    // (behind the last seed: the total)
-		if (i >= *d_n) { head[i] = 1; return; }
-		i32 c5, h; cuts(i, c5, h);
-		cut5[i] = c5; head[i] = v[0];
+		if (!it.in) { head[i] = 1; return; }
+		cut5[i] = it.c5; head[i] = v[0];
 		if (v[0]) lstart[ex[0]] = (i32)i;
 	}
 	__device__ void done(const i32 *t) const { mail[M_NL] = t[0]; ps[ub] = (u32)t[1]; head[ub] = 1; }
