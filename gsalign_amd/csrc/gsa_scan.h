@@ -234,6 +234,10 @@ template <int NV, int ITEMS = LB_ITEMS, class Op>
 static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op, hipStream_t stream = nullptr, int grid_per_cu = LB_GRID_PER_CU)
 {
 	if (!stream) stream = c->stream;      // (only one stream may run fused passes at a time: they share the status words)
+	if (c->n_cus <= 0) { hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device)); c->n_cus = pr.multiProcessorCount; }
+	// a short input (a bacterial contig's 75 000 seeds) keeps tiles of four elements per thread: while every tile finds a workgroup of its own,
+	// smaller tiles are more of them at work
+	if constexpr (ITEMS > 4) { if (n <= (i64)LB_TPB * 4 * grid_per_cu * c->n_cus) return lb_launch<NV, 4>(c, n, op, stream, grid_per_cu); }
 	constexpr i64 LB_TILE = (i64)LB_TPB * ITEMS;
 	const size_t tiles = n > 0 ? (size_t)((n + LB_TILE - 1) / LB_TILE) : 1;
 	for (int k = 0; k < 2; k++) {
@@ -251,7 +255,6 @@ static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op, hipStream_t stream 
 	lb.status[0] = c->d_lb_status[0].as<unsigned long long>(); lb.status[1] = c->d_lb_status[1].as<unsigned long long>();
 	lb.ticket = c->d_mail.as<u32>() + M_TICKET; lb.base = c->lb_base; lb.epoch = c->lb_epoch; lb.err = c->d_mail.as<i32>() + M_LBERR; lb.finished = c->d_mail.as<u32>() + M_LBDONE;
 	lb.n_tiles = (i32)tiles;
-	if (c->n_cus <= 0) { hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device)); c->n_cus = pr.multiProcessorCount; }
 	const size_t grid = std::min<size_t>(tiles, (size_t)grid_per_cu * (size_t)c->n_cus);
 	hipLaunchKernelGGL((k_lb_pass<NV, Op, ITEMS>), dim3((unsigned)grid), dim3(LB_TPB), 0, stream, n, op, lb);
 	GSA_CHECK(c, hipGetLastError());
