@@ -32,8 +32,11 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 	const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const i32 slot = blockIdx.x * SMALL_WAVES + w;
 	if (slot >= n_jobs) return;
-	const i32 job = order[slot];
-	const int m = len1[job], n = len2[job];
+	// (the job and its two lengths are the same in all lanes: said so, they live in scalar registers, the loop over the anti-diagonals is
+	//  uniform and the reference base that enters at lane 0 is READ from its lane (v_readlane) instead of fetched through the LDS crossbar
+	//  (ds_bpermute): that fetch sat in front of every diagonal's dependent chain)
+	const i32 job = __builtin_amdgcn_readfirstlane(order[slot]);
+	const int m = __builtin_amdgcn_readfirstlane(len1[job]), n = __builtin_amdgcn_readfirstlane(len2[job]);
 	const uint8_t *s1 = pool1 + off1[job], *s2 = pool2 + off2[job];
 	uint8_t *dir = s_dir[w], *rev = s_rev[w];
 	const int cq = lane < n ? gsa_nt4(s2[lane]) : 4;
@@ -42,7 +45,7 @@ __global__ void __launch_bounds__(64 * SMALL_WAVES) k_dp_small(i32 n_jobs, const
 	int u = lane ? 2 : 0, v = 0, x = 0, y = 0, wref = 4, dacc = 0;
 	const int nr = m + n - 1;
 	for (int r = 0; r < nr; r++) {
-		const int inb = r < m ? (r < 64 ? __shfl(c1a, r) : __shfl(c1b, r - 64)) : 4;      // s1[r] broadcast
+		const int inb = r < m ? (r < 64 ? __builtin_amdgcn_readlane(c1a, r) : __builtin_amdgcn_readlane(c1b, r - 64)) : 4;      // s1[r] broadcast
 		wref = wave_shr1(wref, inb);
 		const int xt1 = wave_shr1(x, 0), vt1 = wave_shr1(v, r ? 2 : 0);                     // (r-1,t-1); boundary for t = 0 (:157-164)
 		const int jj = r - lane;
