@@ -1701,7 +1701,7 @@ int stage1_seed(gsa_ctx *c)
 				const int shape_env = c->opt.sweep_shape;
 				// few dense chunks (a bundle of short contigs): one chunk per workgroup of four waves and 40 starts per segment, so that the
 				// chip has waves to run; many: four chunks per workgroup of two waves, 160 starts per segment
-				const bool small = shape_env >= 0 ? shape_env == 1 : n_heavy < 8192;
+				const bool small = shape_env >= 0 ? shape_env == 1 : n_heavy < 4096;      // (a 60 Mb -sen bundle, 6 000 chunks: 3.9 ms with four chunks per workgroup, 4.8 with one)
 				const int seg = seg_env > 0 ? seg_env : (small ? 40 : 160);
 #define GSA_SWEEP_ARGS(NCH_, TPB_) dim3((unsigned)((n_heavy + (NCH_) - 1) / (NCH_))), dim3(TPB_), 0, st, c->di, d_q, qlen, c->prm, list, (u32)n_heavy, c->dn_lf.as<u32>(), c->dn_x0.as<u64>(), cnt, seg
 				if (small) { if (c->di.kmer_e16) hipLaunchKernelGGL((k_dense_sweep<true, 1, 256>), GSA_SWEEP_ARGS(1, 256)); else hipLaunchKernelGGL((k_dense_sweep<false, 1, 256>), GSA_SWEEP_ARGS(1, 256)); }
