@@ -98,7 +98,7 @@ static void slot_demand(gsa_ctx *c, QuerySlot &s)
 static int ctx_private_init(gsa_ctx *c, gsa_ctx *share = nullptr)
 {
 	GSA_CHECK(c, hipStreamCreate(&c->stream));
-	for (int i = 0; i < 3; i++) GSA_CHECK(c, hipStreamCreate(&c->stream_aux[i]));
+	for (int i = 0; i < 4; i++) GSA_CHECK(c, hipStreamCreate(&c->stream_aux[i]));
 	if (share) { c->up = share->up; c->own_up = false; } else if (int rc = uploader_start(c)) return rc;      // (Uploader, gsa_ctx.h)
 	for (int i = 0; i < 28; i++) GSA_CHECK(c, hipEventCreate(&c->ev[i]));
 	GSA_CHECK(c, hipMalloc(&c->d_cnt.p, 32 * sizeof(u64))); c->d_cnt.cap = 32 * sizeof(u64); GSA_CHECK(c, hipMemset(c->d_cnt.p, 0, 32 * sizeof(u64)));      // (16 counters + the seed kernel's ticket counter)
@@ -238,7 +238,7 @@ void gsa_destroy(gsa_ctx *c)
 	if (c->h_mail) hipHostFree(c->h_mail);
 	for (DevBuf *b : { &c->p_frags, &c->p_tail, &c->p_leaf, &c->p_blk, &c->p_dp, &c->p_sj, &c->p_sj_early, &c->p_jpatch, &c->p_early, &c->qs[0].p_bndtab, &c->qs[1].p_bndtab, &c->p_bblk, &c->p_ba0 }) if (b->p) hipHostFree(b->p);
 	for (int i = 0; i < 28; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
-	for (int i = 0; i < 3; i++) if (c->stream_aux[i]) hipStreamDestroy(c->stream_aux[i]);
+	for (int i = 0; i < 4; i++) if (c->stream_aux[i]) hipStreamDestroy(c->stream_aux[i]);
 	if (c->stream_seed) hipStreamDestroy(c->stream_seed);
 	if (c->ev_seed_fork) hipEventDestroy(c->ev_seed_fork);
 	if (c->stream) hipStreamDestroy(c->stream);
@@ -321,6 +321,7 @@ int gsa_set_option(gsa_ctx *c, const char *name, int64_t value)
 	else if (k == "seed_mode") { if (value < 0 || value > 2) return gsa_fail(c, GSA_ERR_ARG, "seed_mode: 0 sweep, 1 speculative, 2 search"); c->opt.seed_mode = (int)value; }
 	else if (k == "pd_bitmap") c->opt.pd_bitmap = value != 0;
 	else if (k == "walk_coop") c->opt.walk_coop = value != 0;
+	else if (k == "dp_side") c->opt.dp_side = value != 0;
 	else if (k == "sweep_shape") { if (value < -1 || value > 1) return gsa_fail(c, GSA_ERR_ARG, "sweep_shape: -1, 0 or 1"); c->opt.sweep_shape = (int)value; }
 	else if (k == "dp_safe") c->dp_safe = value != 0;                    // (test hook)
 	else if (k == "dp_fake_timeout") c->dp_fake_timeout = (int)value;    // (test hook)

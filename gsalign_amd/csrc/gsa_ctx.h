@@ -78,6 +78,7 @@ struct Options {
 	int seed_mode = 1;                 // 0 sweep: every chunk through k_dense_sweep; 1: the speculative kernel + dense kernels for what it gives up on; 2: round 2's k_dense_search in place of the sweep
 	int pd_bitmap = 1;                 // 0: groups by the PosDiff sort although MaxIndelSize <= 31 would allow the bitmap scan
 	int sweep_shape = -1;              // k_dense_sweep's launch shape: -1 by the number of dense chunks, 0 = four chunks per two-wave workgroup / 160-start segments, 1 = one chunk per four-wave workgroup / 40-start segments
+	int dp_side = 0;                   // 1: the striped DP's lower size class on a stream of its own, beside the upper class (0: behind it)
 	int walk_coop = 0;                 // 1: the window walk's pointer-doubling rounds as one cooperative launch (measured slower, alone and under load); 0: a launch per round
 	int kmer_k = 0;                    // gsa_create_opts (GSA_CREATE_KMER_K): length of the jump table's k-mers (0: by text length and free memory)
 };
@@ -91,7 +92,7 @@ struct gsa_ctx {
 	hipEvent_t ev_seed_fork = nullptr;
 	u64 seed_ticket = 0;                    // value of the seed kernel's ticket counter (d_cnt[16]) before the next launch
 	int n_cus = 0;
-	hipStream_t stream_aux[3] = {nullptr, nullptr, nullptr};   // [0] early striped DP, [1] tiny DP + strings + sums, [2] records to the host (four streams in all: one per hardware queue)
+	hipStream_t stream_aux[4] = {nullptr, nullptr, nullptr, nullptr};   // [3]: the striped DP's lower size class beside its upper one (option dp_side); [0] early striped DP, [1] tiny DP + strings + sums, [2] records to the host (four streams in all: one per hardware queue)
 	std::string err;
 	Params prm;
 	DevIndex di;
@@ -230,7 +231,7 @@ struct gsa_ctx {
 static inline void ctx_quiesce(gsa_ctx *c)
 {
 	hipStreamSynchronize(c->stream);
-	for (int i = 0; i < 3; i++) if (c->stream_aux[i]) hipStreamSynchronize(c->stream_aux[i]);
+	for (int i = 0; i < 4; i++) if (c->stream_aux[i]) hipStreamSynchronize(c->stream_aux[i]);
 }
 
 template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n)

@@ -890,12 +890,19 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		if (c->d_dp_ctr.cap != ctr_cap0 || c->dp_dirty) { GSA_CHECK(c, hipMemsetAsync(ctr, 0, c->d_dp_ctr.cap, st)); GSA_CHECK(c, hipMemsetAsync(mail + err_slot, 0, 4, st)); c->dp_dirty = false; }
 		// (the two classes back to back on one stream.  Side by side on two streams -- the few long jobs at raised priority --
 		//  was measured at 250 Mb: same step time, the refinement passes beside them starve instead: the chip is busy either way)
+		// (option dp_side: the lower class on a stream of its own -- it then starts with the upper one instead of behind it; the classes share
+		//  nothing but the error word: tickets per class, direction / boundary bytes per job)
+		const bool side = c->opt.dp_side && c->stream_aux[3] && seg[2].nblocks > 0 && (seg[0].nblocks > 0 || seg[1].nblocks > 0);
+		if (side) { GSA_CHECK(c, hipEventRecord(c->ev[24], st)); GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[3], c->ev[24], 0)); }
+		hipStream_t st_main = st;
 		for (int si = 0; si < 3; si++) {
 			const Seg &sg = seg[si];
 			if (sg.nblocks == 0) continue;
+			hipStream_t st = (side && si == 2) ? c->stream_aux[3] : st_main;
 			if (sg.wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)sg.nblocks), dim3(256), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
 			else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)sg.nblocks), dim3(64), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
 		}
+		if (side) { GSA_CHECK(c, hipEventRecord(c->ev[25], c->stream_aux[3])); GSA_CHECK(c, hipStreamWaitEvent(st, c->ev[25], 0)); }
 		GSA_CHECK(c, hipGetLastError());
 		DPT(GSA_CHECK(c, hipStreamSynchronize(st)); if (cnt == 1) { u32 hh[6]; hipMemcpy(hh, ctr + sj[0].ctr + 40, 24, hipMemcpyDeviceToHost); fprintf(stderr, "[dp] %d x %d: fwd0 %.1f us  fwdlast %.1f us  traceback %.1f us (tiles %u runs %u)  total %.1f us\n", sj[0].m, sj[0].n, hh[0] * 0.01, hh[1] * 0.01, hh[2] * 0.01, hh[3], hh[4], hh[5] * 0.01); })
 		if (last < large.size()) {

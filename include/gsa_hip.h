@@ -148,6 +148,8 @@ int  gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *pr
  *   "pd_bitmap"      0 = seed groups by the PosDiff sort (SeedGrouping as written, GSAlign.cpp:126-143) even where the bitmap scan applies
  *   "sweep_shape"    launch shape of the repeat-regime seed kernel (k_dense_sweep): -1 (default) by the number of dense chunks, 0 = four chunks per
  *                    workgroup and 160-start segments (many chunks), 1 = one chunk per workgroup and 40-start segments (few).  Results do not depend on it
+ *   "dp_side"        1 = the striped DP launches its lower size class on a stream of its own, beside the upper class, instead of behind it (measured: the DP
+ *                    span of a 250 Mb contig 4.9 -> 1.9 ms, but the refinement passes beside it starve: contig latency 13.7 -> 14.3 ms, throughput -4 % / +4 %); default 0
  *   "walk_coop"      1 = the pointer-doubling rounds of the window walk (chaining, contigs above 100 000 seeds) as ONE cooperative launch instead of a
  *                    launch per round (default 0: measured slower)
  *   "dp_safe", "dp_fake_timeout"   test hooks: one striped DP job per launch; the next n contigs report a stripe hand-off time-out once
