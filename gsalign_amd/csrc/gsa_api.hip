@@ -97,8 +97,19 @@ static void slot_demand(gsa_ctx *c, QuerySlot &s)
 // what every context owns, shared index or not: streams, events, counters, mailbox
 static int ctx_private_init(gsa_ctx *c, gsa_ctx *share = nullptr)
 {
+#ifdef GSA_EXPERIMENTS
+	// experiment (GSA_STREAM_PRIO=1): the main stream (seed kernels, fused passes) above the DP streams in the dispatcher's eyes
+	static const int prio = [] { const char *e = getenv("GSA_STREAM_PRIO"); return e ? atoi(e) : 0; }();
+	if (prio) {
+		int lo = 0, hi = 0; GSA_CHECK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));      // (lo = least, hi = greatest priority: numerically lo >= hi)
+		GSA_CHECK(c, hipStreamCreateWithPriority(&c->stream, hipStreamDefault, hi));
+		for (int i = 0; i < 4; i++) GSA_CHECK(c, hipStreamCreateWithPriority(&c->stream_aux[i], hipStreamDefault, (i == 0 || i == 3 || (prio > 1 && i == 1)) ? lo : hi));
+	} else
+#endif
+	{
 	GSA_CHECK(c, hipStreamCreate(&c->stream));
 	for (int i = 0; i < 4; i++) GSA_CHECK(c, hipStreamCreate(&c->stream_aux[i]));
+	}
 	if (share) { c->up = share->up; c->own_up = false; } else if (int rc = uploader_start(c)) return rc;      // (Uploader, gsa_ctx.h)
 	for (int i = 0; i < 28; i++) GSA_CHECK(c, hipEventCreate(&c->ev[i]));
 	GSA_CHECK(c, hipMalloc(&c->d_cnt.p, 32 * sizeof(u64))); c->d_cnt.cap = 32 * sizeof(u64); GSA_CHECK(c, hipMemset(c->d_cnt.p, 0, 32 * sizeof(u64)));      // (16 counters + the seed kernel's ticket counter)
