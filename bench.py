@@ -244,6 +244,14 @@ def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup, d
             # many 5 Mb genomes queued at once: gsa_align_many aligns ~12 of them per pass (bundles) -- batch throughput, NOT one E. coli run
             timed_run(steps, pinned, bundle=True)
             sync(); t0 = time.perf_counter(); timed_run(steps, pinned, bundle=True); sync(); side["t_bundled"] = time.perf_counter() - t0
+    parity_gpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        # the GPU's answer for the sample the CPU baseline is about to time (first cpu_sample / 4 bases of the longest contig of genome 0 against
+        # the FULL index): cpu_baseline() compares the reference's stage-8 result with it -- parity at the scale the headline is quoted on
+        q0 = max(genomes[0], key=lambda c: c.size)
+        n1 = int(min(q0.size, max(1000, args.cpu_sample // 4)))
+        g0.align_contig(np.ascontiguousarray(q0[:n1]))
+        parity_gpu = (n1, g0.blocks_as_dump(with_aln=True))
     run.close()
     alg = {"occ_blocks": 64.0 * cnt[0], "lf_steps": 64.0 * cnt[1], "sa_reads": 8.0 * cnt[2], "query": float(np.mean([sum(c.size for c in gq) for gq in pinned])), "seeds": 16.0 * cnt[3],
            "dp_cells": cnt[4], "dp_fragments": cnt[6]}
@@ -253,7 +261,8 @@ def measure(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup, d
         v = v.cpu().numpy(); alg = dict(zip(alg.keys(), (float(x) for x in v[:len(alg)]))); cnt = v[len(alg):]
     return dict(px=px, refs=refs, genomes=genomes, t_total=t_total, bp=bp_job * steps, bp_per_step=bp_job, steps=steps, alg=alg, cnt=cnt, tm=tm,
                 occ_read=occ_read, seed_live_ms=seed_live_ms, side=side, n_blocks=n_blocks, n_frags=n_frags, n_aln=n_aln, contigs_per_step=len(genomes[0]),
-                contigs_this_rank=per_step, inflight=inflight, lat_ms=lat_ms, lat_bp=lat_bp, single_short=single_short, short=short, gathered=gathered, bundle_main=bundle_main)
+                contigs_this_rank=per_step, inflight=inflight, lat_ms=lat_ms, lat_bp=lat_bp, single_short=single_short, short=short, gathered=gathered, bundle_main=bundle_main,
+                parity_gpu=parity_gpu)
 
 
 def measure_split(name, wl, args, tmp, rank, world, local_rank, sync, steps, warmup, dev):
@@ -285,12 +294,12 @@ def measure_split(name, wl, args, tmp, rank, world, local_rank, sync, steps, war
     return dict(t_total=t_total, bp=bp_per_step * steps, bp_per_step=bp_per_step, steps=steps)
 
 
-PMC_FILE = "profiles/r04_pmc_{name}.json"
+PMC_FILE = "profiles/r05_pmc_{name}.json"
 
 
 def pmc_traffic(name):
     """PMC traffic per step of the top kernels.  NOT measured in this run: rocprofv3 --pmc needs passes of its own (one counter
-    set per pass, tools/pmc_top.sh -> tools/pmc_top.py -> profiles/r04_pmc_<workload>.json, which names the commit it was taken
+    set per pass, tools/pmc_top.sh -> tools/pmc_top.py -> profiles/r05_pmc_<workload>.json, which names the commit it was taken
     at); the JSON line says where the number comes from (`traffic_source`)."""
     try:
         return json.load(open(os.path.join(ROOT, PMC_FILE.format(name=name))))
@@ -312,14 +321,25 @@ def summarise(name, wl, m, t_max, total_bp, world, args):
     # reference's bwt_sa does for every hit (the `lf_steps` term of the whole-path formula) is work it does not do, so that
     # term is not its algorithmic traffic
     loc_alg = m["alg"]["sa_reads"] + m["alg"]["seeds"]
-    for kname, ms, ab, key in (("k_seed_wg + k_dense_search (seed search, S1): mean launch duration over the TIMED steps, hipEvents, contexts in flight beside each other" + (" [rank 0's shard]" if world > 1 else ""), m["seed_live_ms"] if m["seed_live_ms"] > 0 else float(tm[0]), seed_alg / world, "k_seed_wg"),
-                               ("k_dp_stripe + k_dp_small/lane + k_materialize (extend stage, S7): stage timer, one context alone, untimed pass" + (" [rank 0's shard]" if world > 1 else ""), float(tm[5]), dp_alg / world, "k_dp_stripe"),
-                               ("k_seed_select + sort + group (locate/order, S1 tail; algorithmic bytes = dense-SA reads + seed records, the reference's LF walk is replaced, not performed): stage timer, one context alone, untimed pass" + (" [rank 0's shard]" if world > 1 else ""), float(tm[1] + tm[2]), loc_alg / world, "k_seed_select")):
+    # ONE timer kind for every entry: the hipEvent stage timers of ONE context ALONE (untimed pass in front of the timed region), so an entry is
+    # the time its kernels need with the chip to themselves and entries add up to (about) a contig's latency -- never to more than the step.
+    # The seed kernels are also timed LIVE in the timed region (two events per contig, summed over the contexts in flight): those durations
+    # overlap each other and the other contexts' kernels, i.e. they are occupancy, not work -- reported as `live_sum_ms_per_step` beside the
+    # entry, with no fraction derived from it.
+    chain_alg = 2.0 * m["alg"]["seeds"]          # chain + refine read the located seeds and write the refined ones: 16 B each way per seed
+    for kname, ms, ab, key, live in (("k_seed_wg + dense kernels (seed search, S1)" + (" [rank 0's shard]" if world > 1 else ""), float(tm[0]), seed_alg / world, "k_seed_wg", m["seed_live_ms"] if m["seed_live_ms"] > 0 else None),
+                                     ("k_seed_select + sort + group (locate/order, S1 tail; algorithmic bytes = dense-SA reads + seed records, the reference's LF walk is replaced, not performed)" + (" [rank 0's shard]" if world > 1 else ""), float(tm[1] + tm[2]), loc_alg / world, "k_seed_select", None),
+                                     ("fused look-back passes + window walk + gap similarity (chain + refine, S2-S5; algorithmic bytes = 16 B per seed read + 16 B written)" + (" [rank 0's shard]" if world > 1 else ""), float(tm[3] + tm[4]), chain_alg / world, "chain_refine", None),
+                                     ("k_dp_stripe + k_dp_small/lane + k_materialize (extend stage, S6-S7)" + (" [rank 0's shard]" if world > 1 else ""), float(tm[5]), dp_alg / world, "k_dp_stripe", None)):
         a = ab / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         tr = None
         if pmc and key in pmc.get("kernels", {}):
             tr = float(pmc["kernels"][key]["traffic_bytes_per_step"])
-        ent = {"kernel": kname, "ms_per_step": ms, "algorithmic_bytes_per_step": ab, "achieved": a, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": tr}
+        ent = {"kernel": kname, "timer": "hipEvent stage timer, one context alone, untimed pass", "ms_per_step": ms, "algorithmic_bytes_per_step": ab, "achieved": a, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": tr,
+               "physical_frac": (tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (tr is not None and ms > 0) else None}
+        if live is not None:
+            ent["live_sum_ms_per_step"] = live
+            ent["live_sum_note"] = "sum over the contexts in flight of this kernel's hipEvent durations inside the TIMED steps: overlapping launches (occupancy), not comparable with ms_per_step of the step"
         if a > HBM_PEAK_GBS:
             # more "algorithmic" bytes per second than HBM can move: the kernel does not read them (small reference: nearly every
             # search is settled by the k-mer table and one text comparison instead of the Occ walk the formula counts, see
@@ -343,6 +363,8 @@ def summarise(name, wl, m, t_max, total_bp, world, args):
                    "aligner_params": wl["params"]},
         "roofline": {"bound": "hbm", "kernel": "whole hot path S1-S7 incl. query H2D (SURVEY 8(d) formula: 64 N_occblk + 64 N_lf + 8 N_sa + L_query + 16 N_seed + N_dpcells + sum(m+n))",
                      "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world), "traffic": traffic, "traffic_source": traffic_source,
+                     "physical_frac": (traffic / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)) if traffic is not None else None,
+                     "physical_frac_note": "PMC traffic per step / measured step time / peak: what HBM actually moves; `frac` divides the SURVEY 8(d) formula's bytes (the reference's Occ and LF walks, most of which this path does not perform) by the same time",
                      "algorithmic_bytes_per_step": alg_total, "terms": m["alg"], "bytes_per_query_base": alg_total / m["bp_per_step"]},
         "kernels": kern,
         "stage_ms_one_context_alone": {"seed_search": float(tm[0]), "locate": float(tm[1]), "sort_group": float(tm[2]), "chain": float(tm[3]), "refine": float(tm[4]),
@@ -388,32 +410,54 @@ def physical_cores():
         return n
 
 
-def cpu_baseline(px, qry, tmp, budget_bp):
+def parity_compare(want, parity_gpu, n1):
+    """The CPU side's stage-8 result of the sample against the GPU's (blocks, records, both gapped-string pools): (verdict, detail)."""
+    if parity_gpu is None:
+        return "not compared", "no GPU result of the sample"
+    if parity_gpu[0] != n1:
+        return "not compared", f"sample lengths differ ({parity_gpu[0]} vs {n1})"
+    got = parity_gpu[1]
+    for k in sorted(want):
+        if k not in got or got[k].shape != want[k].shape or not np.array_equal(got[k], want[k]):
+            return "DIFFERENT", f"{k}: GPU {got[k].shape if k in got else None} vs CPU {want[k].shape}"
+    return "identical", f"{int(want['b_score'].size)} blocks, {int(want['f_qpos'].size)} records, {int(want['aln1'].size)} string bytes per side"
+
+
+def cpu_baseline(px, qry, tmp, budget_bp, params=None, parity_gpu=None):
     """The real reference (oracle/_ref) on this host, on a bounded sample of the same workload (the first budget_bp bases of
-    one query contig against the FULL index): (a) its hot path S1-S7 at one thread through libgsref; (b) the unmodified CLI
-    with all cores, whole program, and the same with a 1 kb query -- the difference is its hot path + output at N threads."""
+    one query contig against the FULL index): (a) its hot path S1-S7 at one thread through libgsref -- whose stage-8 result is KEPT and
+    compared with the GPU's result for the same bases (`parity_sample`); (b) the unmodified CLI with all cores, whole program, and the
+    same with a 1 kb query -- the difference is its hot path + output at N threads."""
     from gsalign_amd import synth
     from oracle import oracle_py as op
     sample = qry[:budget_bp]
+    params = dict(params or {})
     qfa = os.path.join(tmp, "cpu_q.fa"); tiny = os.path.join(tmp, "cpu_tiny.fa")
     synth.write_fasta(qfa, [("q", sample)]); synth.write_fasta(tiny, [("t", sample[:1000])])
     cores = os.cpu_count() or 1
+    n1 = int(min(sample.size, max(1000, budget_bp // 4)))     # (one thread gets a quarter of the sample: ~5 s of hot path)
     if not op.have_ref():
         from gsalign_amd import indexio
-        o = op.Oracle(indexio.load_index(px))
-        o.set_query(sample); t = time.time(); o.run_to(8); dt = time.time() - t; o.close()
-        return {"value": sample.size / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port", "sample": f"first {sample.size} bp of one query contig, oracle restatement S1-S7, 1 thread, {dt:.2f} s"}
+        o = op.Oracle(indexio.load_index(px), params)
+        o.set_query(sample[:n1]); t = time.time(); o.run_to(8); dt = time.time() - t
+        verdict, detail = parity_compare(o.blocks(with_aln=True), parity_gpu, n1); o.close()
+        return {"value": n1 / dt / 1e9, "unit": "Gbp/s", "cores": 1, "kind": "port", "sample": f"first {n1} bp of one query contig, oracle restatement S1-S7, 1 thread, {dt:.2f} s",
+                "parity_sample": verdict, "parity_detail": detail + f"; oracle restatement vs gsa_align_contig, first {n1} bp against the full index"}
+    dump = os.path.join(tmp, "cpu_parity.npz")
     code = ("import sys,time;sys.path.insert(0,%r);import numpy as np;from oracle import oracle_py as op;from gsalign_amd import synth;"
-            "r=op.RefLib(%r);q=synth.read_fasta(%r)[0][1][:%d];r.set_query(q);t=time.time();r.run_to(8);print(time.time()-t)" % (ROOT, px, qfa, max(1000, budget_bp // 4)))
-    n1 = min(sample.size, max(1000, budget_bp // 4))          # (one thread gets a quarter of the sample: ~5 s of hot path)
+            "r=op.RefLib(%r,%r);q=synth.read_fasta(%r)[0][1][:%d];r.set_query(q);t=time.time();r.run_to(8);print(time.time()-t);np.savez(%r,**r.blocks(with_aln=True))" % (ROOT, px, params, qfa, n1, dump))
     t1 = float(subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True).stdout.strip().splitlines()[-1])
+    with np.load(dump) as z:
+        verdict, detail = parity_compare({k: z[k] for k in z.files}, parity_gpu, n1)
+    os.remove(dump)
     nthr = physical_cores()                        # SURVEY 8(d): the reference's pthread path on all physical cores of this host
     t = time.time(); op.ref_run_cli(px, qfa, os.path.join(tmp, "cpu_out"), threads=nthr); tn = time.time() - t
     t = time.time(); op.ref_run_cli(px, tiny, os.path.join(tmp, "cpu_out0"), threads=nthr); t0 = time.time() - t
     v1 = n1 / t1 / 1e9
     thot = max(tn - t0, 1e-3); vn = sample.size / thot / 1e9
     best_cores, best = (1, v1) if v1 >= vn else (nthr, vn)
-    return {"value": best, "unit": "Gbp/s", "cores": best_cores, "kind": "reference",
+    return {"value": best, "unit": "Gbp/s", "cores": best_cores, "kind": "reference", "parity_sample": verdict,
+            "parity_detail": detail + f"; the real reference's stage-8 result (libgsref, -t 1) vs gsa_align_contig, first {n1} bp of the longest contig of query genome 0 against the full index, parameters {params}",
             "sample": f"one query contig vs the full index; reference hot path S1-S7 at -t 1 (libgsref) on its first {n1} bp: {t1:.2f} s = {v1:.5f} Gbp/s; "
                       f"unmodified reference CLI -t {nthr} on its first {sample.size} bp: {tn:.2f} s whole program, {t0:.2f} s with a 1 kb query (index load + unpack) -> {thot:.2f} s for hot path + output = {vn:.5f} Gbp/s; "
                       f"host has {cores} logical cores"}
@@ -621,10 +665,15 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             try:
                 q0 = max(m["genomes"][0], key=lambda c: c.size)
-                out["cpu_baseline"] = cpu_baseline(m["px"], q0, tmp, args.cpu_sample)
+                out["cpu_baseline"] = cpu_baseline(m["px"], q0, tmp, args.cpu_sample, params=wl["params"], parity_gpu=m["parity_gpu"])
             except Exception as e:   # never lose the GPU line to a baseline hiccup      # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+        if out.get("cpu_baseline", {}).get("parity_sample") == "DIFFERENT":      # a fast result that differs from the reference's is not a result
+            print("bench.py: the GPU's result for the CPU baseline's sample differs from the reference's: " + out["cpu_baseline"]["parity_detail"], file=sys.stderr)
+            if world > 1:
+                dist.barrier(); dist.destroy_process_group()
+            sys.exit(3)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 

@@ -47,8 +47,13 @@ void Uploader::run()
 		Job j;
 		{ std::unique_lock<std::mutex> g(mu); cv.wait(g, [&] { return stop || !q.empty(); }); if (q.empty()) return; j = std::move(q.front()); q.pop_front(); if (n_demand > 0) n_demand--; }
 		const auto t0 = std::chrono::steady_clock::now();
-		for (const Piece &p : j.pieces) if (p.n) { (void)hipMemcpyAsync(p.dst, p.src, p.n, hipMemcpyHostToDevice, st); bytes += p.n; }
-		(void)hipStreamSynchronize(st); (void)hipGetLastError();
+		// a failed copy (a host pointer the runtime cannot read, a device fault) must not look like an upload: the slot keeps the first error
+		// and the align call that adopts the slot fails with GSA_ERR_HIP (slot_finish)
+		hipError_t e_first = hipSuccess;
+		for (const Piece &p : j.pieces) if (p.n) { const hipError_t e = hipMemcpyAsync(p.dst, p.src, p.n, hipMemcpyHostToDevice, st); if (e != hipSuccess && e_first == hipSuccess) e_first = e; bytes += p.n; }
+		{ const hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess && e_first == hipSuccess) e_first = e; }
+		(void)hipGetLastError();
+		if (e_first != hipSuccess && j.err) { int none = 0; j.err->compare_exchange_strong(none, (int)e_first); }
 		const auto t1 = std::chrono::steady_clock::now();
 		{ std::lock_guard<std::mutex> g(mu); copy_ms += std::chrono::duration<double, std::milli>(t1 - t0).count(); wait_ms += std::chrono::duration<double, std::milli>(t0 - j.t_push).count(); jobs++; }
 		j.busy->fetch_sub(1, std::memory_order_release);
@@ -173,6 +178,7 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gsa_fail(nullptr, GSA_ERR_HIP, "no HIP device available (libgsa_hip.so has no CPU path)");
 	if (device < 0 || device >= ndev) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create: bad device ordinal");
 	if (flags & ~(uint32_t)(GSA_CREATE_WIDE | GSA_CREATE_KMER_K(15))) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create_opts: unknown flag");
+	{ const uint32_t kk = (flags >> 8) & 15u; if (kk == 1) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create_opts: GSA_CREATE_KMER_K takes 2 .. 15 (0: chosen by text length and free memory)"); }
 	gsa_ctx *c = new gsa_ctx();
 	c->device = device; c->force_wide = (flags & GSA_CREATE_WIDE) != 0; c->opt.kmer_k = (int)((flags >> 8) & 15u);
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
@@ -324,18 +330,20 @@ int gsa_set_option(gsa_ctx *c, const char *name, int64_t value)
 {
 	if (!c || !name) return GSA_ERR_ARG;
 	const std::string k(name);
-	if (k == "split_min") c->opt.split_min = value;
-	else if (k == "bundle_contig") c->opt.bundle_contig = value;
-	else if (k == "bundle_cap") c->opt.bundle_cap = value > 0 ? value : 1;
-	else if (k == "seed_budget") c->seed_budget = (u32)value;
-	else if (k == "dp_lane") c->opt.dp_lane = (int)value;
+	auto in = [&](int64_t lo, int64_t hi) { return value >= lo && value <= hi; };
+	const int64_t BIG = (int64_t)1 << 40;
+	if (k == "split_min") { if (!in(0, BIG)) return gsa_fail(c, GSA_ERR_ARG, "split_min: 0 .. 2^40 bases"); c->opt.split_min = value; }
+	else if (k == "bundle_contig") { if (!in(0, BIG)) return gsa_fail(c, GSA_ERR_ARG, "bundle_contig: 0 (no bundles) .. 2^40 bases"); c->opt.bundle_contig = value; }
+	else if (k == "bundle_cap") { if (!in(1, BIG)) return gsa_fail(c, GSA_ERR_ARG, "bundle_cap: 1 .. 2^40 bases"); c->opt.bundle_cap = value; }
+	else if (k == "seed_budget") { if (!in(1, 0xffffffffll)) return gsa_fail(c, GSA_ERR_ARG, "seed_budget: 1 .. 2^32 - 1 wave-iterations"); c->seed_budget = (u32)value; }
+	else if (k == "dp_lane") { if (!in(0, 1 << 20)) return gsa_fail(c, GSA_ERR_ARG, "dp_lane: 0 (round 2's tiny / small split) .. 2^20 cells"); c->opt.dp_lane = (int)value; }
 	else if (k == "seed_mode") { if (value < 0 || value > 2) return gsa_fail(c, GSA_ERR_ARG, "seed_mode: 0 sweep, 1 speculative, 2 search"); c->opt.seed_mode = (int)value; }
 	else if (k == "pd_bitmap") c->opt.pd_bitmap = value != 0;
 	else if (k == "walk_coop") c->opt.walk_coop = value != 0;
 	else if (k == "dp_side") c->opt.dp_side = value != 0;
 	else if (k == "sweep_shape") { if (value < -1 || value > 1) return gsa_fail(c, GSA_ERR_ARG, "sweep_shape: -1, 0 or 1"); c->opt.sweep_shape = (int)value; }
 	else if (k == "dp_safe") c->dp_safe = value != 0;                    // (test hook)
-	else if (k == "dp_fake_timeout") c->dp_fake_timeout = (int)value;    // (test hook)
+	else if (k == "dp_fake_timeout") { if (!in(0, 1 << 20)) return gsa_fail(c, GSA_ERR_ARG, "dp_fake_timeout: >= 0"); c->dp_fake_timeout = (int)value; }    // (test hook)
 	else return gsa_fail(c, GSA_ERR_ARG, "gsa_set_option: unknown option " + k);
 	return GSA_OK;
 }
@@ -399,7 +407,8 @@ __global__ void __launch_bounds__(256) k_bundle_pad(const i32 *__restrict__ off,
 static int slot_upload(gsa_ctx *c, QuerySlot &s, const char *const *query, const int32_t *qlen, int32_t n)
 {
 	slot_wait(s);      // (a cancelled upload into this slot may still be on its way)
-	Uploader::Job job; job.busy = &s.busy;
+	s.up_err.store(0);      // (... and whatever became of it no longer matters)
+	Uploader::Job job; job.busy = &s.busy; job.err = &s.up_err;
 	if (n == 0) {
 		s.n = 0; s.tot = qlen[0]; s.lmax = qlen[0]; s.src.assign(1, query[0]); s.b_qlen.assign(1, qlen[0]); s.b_off.clear();
 		if (!slot_ensure_bytes(c, s.d_query, (size_t)qlen[0] + 64, false)) return GSA_ERR_NOMEM;
@@ -431,6 +440,7 @@ static int slot_upload(gsa_ctx *c, QuerySlot &s, const char *const *query, const
 static int slot_finish(gsa_ctx *c, QuerySlot &s)
 {
 	slot_demand(c, s);
+	if (const int e = s.up_err.exchange(0)) return gsa_fail(c, GSA_ERR_HIP, std::string("query upload (hipMemcpyAsync H2D): ") + hipGetErrorString((hipError_t)e));
 	if (s.n > 0 && s.tot > 0) {
 		const uint8_t *dt = s.d_bndtab.as<uint8_t>();
 		hipLaunchKernelGGL(k_bundle_pad, dim3((unsigned)s.n), dim3(256), 0, c->stream, (const i32 *)dt, (const i32 *)(dt + s.o_src), s.d_query.as<uint8_t>());
@@ -472,6 +482,9 @@ static int prefetch(gsa_ctx *c, const char *const *query, const int32_t *qlen, i
 	int i = c->q_cur == 0 ? 1 : 0;
 	if (c->qs[i].pending) i ^= 1;
 	if (c->qs[i].pending) return gsa_fail(c, GSA_ERR_STATE, "gsa_prefetch: two contigs are waiting already");
+	// the only free slot holds the contig whose stages are under way (stage views: gsa_set_query + gsa_run_to(k < 8)): the later stages still
+	// read its bases there -- overwriting, or growing and so freeing, that buffer would hand them another contig or freed memory
+	if (i == c->q_cur && c->stage > 0 && c->stage < 8) return gsa_fail(c, GSA_ERR_STATE, "gsa_prefetch: the free query slot holds the contig whose stages are still running (finish it with gsa_run_to(8) or gsa_set_query first)");
 	if (i == c->q_cur) c->q_cur = -2;
 	int rc = slot_upload(c, c->qs[i], query, qlen, n);
 	if (rc == GSA_OK) c->qs[i].pending = true;

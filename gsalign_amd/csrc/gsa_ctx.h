@@ -48,6 +48,7 @@ struct QuerySlot {
 	i32 lmax = 0; i64 tot = 0; size_t o_cc = 0, o_src = 0;
 	bool pending = false;                          // uploaded (or on its way) and not yet adopted by gsa_set_query / set_query_bundle
 	std::atomic<int> busy{0};                      // uploads of this slot the Uploader has not finished yet
+	std::atomic<int> up_err{0};                    // first hipError_t of an upload into this slot (the Uploader thread sets it, slot_finish turns it into GSA_ERR_HIP)
 };
 
 // Uploads of query sequences, ONE AT A TIME per device index, in the order they were asked for (a thread + a copy stream; the contexts
@@ -59,7 +60,7 @@ struct QuerySlot {
 // (an event behind the copy, a kernel queued behind it) is a barrier packet that blocks a shared hardware queue for milliseconds.
 struct Uploader {
 	struct Piece { void *dst; const void *src; size_t n; };
-	struct Job { std::vector<Piece> pieces; std::atomic<int> *busy; std::chrono::steady_clock::time_point t_push; };
+	struct Job { std::vector<Piece> pieces; std::atomic<int> *busy; std::atomic<int> *err; std::chrono::steady_clock::time_point t_push; };
 	double copy_ms = 0, wait_ms = 0, bytes = 0; long long jobs = 0;      // (statistics, uploader thread only)
 	int device = 0; hipStream_t st = nullptr;
 	std::thread th; std::mutex mu; std::condition_variable cv; std::deque<Job> q; bool stop = false;

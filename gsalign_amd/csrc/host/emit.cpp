@@ -6,11 +6,22 @@
 //   OutputMAF / OutputAlignment / SelfComplementarySeq   src/tools.cpp:3-44,149-286
 //   VariantIdentification / OutputSequenceVariants       src/SeqVariant.cpp:6-143
 #include <algorithm>
+#include <array>
+#include <atomic>
 #include <cstring>
 #include <fstream>
+#include <memory>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "gsa_host.h"
+#include "par.h"
 
 namespace {
+
+// blocks / lists / files below this size are handled by the calling thread alone.  GSA_HOST_PAR_MIN (read at every call: the CPU tests switch it)
+// forces the parallel forms on the small goldens
+size_t par_min_bytes() { const char *e = getenv("GSA_HOST_PAR_MIN"); return e ? (size_t)atoll(e) : (size_t)1 << 20; }
 
 inline int nt4(unsigned char c)
 {
@@ -27,11 +38,15 @@ inline char rev_map(char c)
 	}
 }
 
-void self_complement(std::string &s, int len)          // SelfComplementarySeq (tools.cpp:33-44)
+// TrimChromosomeName (main.cpp:35-47): '|' -> '-', cut at space # : = tab
+std::string trim_name(const char *p, size_t n)
 {
-	int i, j;
-	for (j = len - 1, i = 0; i < j; i++, j--) { char a = s[i], b = s[j]; s[i] = rev_map(b); s[j] = rev_map(a); }
-	if (i == j) s[i] = rev_map(s[i]);
+	std::string name(p, n); size_t i;
+	for (i = 0; i < name.size(); i++) {
+		if (name[i] == '|') name[i] = '-';
+		else if (name[i] == ' ' || name[i] == '#' || name[i] == ':' || name[i] == '=' || name[i] == '\t') break;
+	}
+	return name.substr(0, i);
 }
 
 int count_gaps(const std::string &s, int i, int stop) { int n = 0; for (; i < stop; i++) if (s[i] == '-') n++; return n; }
@@ -57,69 +72,231 @@ int extension(const HostIndex &ix, const gsa_block &b, const gsa_frag &last)
 
 } // namespace
 
-void ContigResult::assign(const gsa_result &r)
+// what a GPU worker thread does inside gsa_align_many's callback: the result is valid during the call only, so its bytes are copied -- and
+// nothing else; the FragPair_t-shaped view is made later, off that thread (expand)
+void ContigResult::assign_raw(const gsa_result &r)
 {
 	blocks.assign(r.blocks, r.blocks + r.n_blocks);
-	frags.resize((size_t)r.n_frags);                      // FragPair_t-shaped copies of the 16-byte records
-	gsa_expand_frags(r.recs, r.n_frags, frags.data());
+	recs.assign(r.recs, r.recs + r.n_frags); frags.clear();
 	aln1.assign(r.aln1, (size_t)r.n_aln); aln2.assign(r.aln2, (size_t)r.n_aln);
 }
 
+void ContigResult::expand()
+{
+	if (!frags.empty() || recs.empty()) return;
+	frags.resize(recs.size());
+	// a gap record takes its position from the seed record in front of it (gsa_expand_frags): ranges may start anywhere, the expander
+	// only looks one record back
+	gsa_frag *F = frags.data(); const gsa_rec *R = recs.data();
+	par_ranges(recs.size(), (size_t)1 << 16, [&](size_t b, size_t e) {
+		for (size_t i = b; i < e; i++) gsa_rec_expand(R, (int64_t)i, F + i);      // (a gap record reads the seed record in front of it: any range start is fine)
+	});
+	std::vector<gsa_rec>().swap(recs);
+}
+
+void ContigResult::assign(const gsa_result &r) { assign_raw(r); expand(); }
+
+// LoadQueryFile (main.cpp:82-114) line by line -- getline on '\n', empty lines skipped, a line that starts with '>' opens a sequence
+// (TrimChromosomeName), every other line loses ONE trailing '\r', must be all isalpha (CheckQuerySeq) and is appended -- but on the whole
+// file at once: the file is read in slices by the pool's threads, cut into segments at line starts, every segment validates and counts
+// its lines (pass 1), the sequences get their sizes, every segment copies its lines to where they belong (pass 2).  3 GB of FASTA: the
+// reference's getline loop takes ~10 s, this takes the time of two passes over the page cache.
 bool gsah_load_query(const std::string &path, std::vector<QueryContig> &out, std::string &err)
 {
-	std::ifstream file(path.c_str());
-	if (!file.is_open()) { err = "cannot open " + path; return false; }
-	std::string str; bool first = true;
-	while (std::getline(file, str)) {
-		if (first) { first = false; if (str.empty() || str[0] != '>') { err = "not a FASTA file: " + path; return false; } }
-		if (str.empty()) continue;
-		if (str[0] == '>') {
-			// TrimChromosomeName (main.cpp:35-47): '|' -> '-', cut at space # : = tab
-			std::string name = str.substr(1); size_t i;
-			for (i = 0; i < name.size(); i++) {
-				if (name[i] == '|') name[i] = '-';
-				else if (name[i] == ' ' || name[i] == '#' || name[i] == ':' || name[i] == '=' || name[i] == '\t') break;
+	const int fd = open(path.c_str(), O_RDONLY);
+	if (fd < 0) { err = "cannot open " + path; return false; }
+	struct stat st;
+	if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+		// not a regular file (a pipe): the serial reader
+		close(fd);
+		std::ifstream file(path.c_str());
+		if (!file.is_open()) { err = "cannot open " + path; return false; }
+		std::string str; bool first = true;
+		while (std::getline(file, str)) {
+			if (first) { first = false; if (str.empty() || str[0] != '>') { err = "not a FASTA file: " + path; return false; } }
+			if (str.empty()) continue;
+			if (str[0] == '>') { QueryContig qc; qc.name = trim_name(str.data() + 1, str.size() - 1); out.push_back(qc); }
+			else {
+				if (str[str.size() - 1] == '\r') str.resize(str.size() - 1);
+				for (size_t i = 0; i < str.size(); i++) if (!isalpha((unsigned char)str[i])) { err = "The query sequence contains non-alphabet characters!"; return false; }
+				if (out.empty()) { err = "sequence before the first header"; return false; }
+				out.back().seq.append(str);
 			}
-			QueryContig qc; qc.name = name.substr(0, i); out.push_back(qc);
-		} else {
-			if (!str.empty() && str[str.size() - 1] == '\r') str.resize(str.size() - 1);          // CheckQuerySeq (main.cpp:66-80)
-			for (size_t i = 0; i < str.size(); i++) if (!isalpha((unsigned char)str[i])) { err = "The query sequence contains non-alphabet characters!"; return false; }
-			if (out.empty()) { err = "sequence before the first header"; return false; }
-			out.back().seq.append(str);
+		}
+		if (out.empty()) { err = "no sequence in " + path; return false; }
+		return true;
+	}
+	const size_t n = (size_t)st.st_size;
+	if (n == 0) { close(fd); err = "not a FASTA file: " + path; return false; }
+	std::unique_ptr<char[]> buf(new char[n]);
+	std::atomic<bool> io_ok(true);
+	par_ranges(n, (size_t)8 << 20, [&](size_t b, size_t e) {
+		while (b < e) { const ssize_t r = pread(fd, buf.get() + b, e - b, (off_t)b); if (r <= 0) { io_ok = false; return; } b += (size_t)r; }
+	});
+	close(fd);
+	if (!io_ok) { err = "cannot read " + path; return false; }
+	const char *d = buf.get();
+	if (d[0] != '>') { err = "not a FASTA file: " + path; return false; }      // (the first line is empty or no header: CheckInputFile, main.cpp:49-64)
+	// segments: [seg[k], seg[k + 1]) each starting at a line start
+	const size_t want = std::min<size_t>((size_t)HostPool::global().threads() * 4, n / std::max<size_t>(par_min_bytes(), 1) + 1);
+	std::vector<size_t> seg(1, 0);
+	for (size_t k = 1; k < want; k++) {
+		size_t p = n * k / want; if (p <= seg.back()) continue;
+		const char *nl = (const char *)memchr(d + p, '\n', n - p);
+		if (!nl) break;
+		p = (size_t)(nl - d) + 1;
+		if (p > seg.back() && p < n) seg.push_back(p);
+	}
+	seg.push_back(n);
+	const size_t S = seg.size() - 1;
+	struct Piece { size_t hdr_off, hdr_len; size_t bases; };         // a header line (hdr_len = 0 for the headless first piece of a segment) and the bases that follow it in the segment
+	std::vector<std::vector<Piece> > pieces(S);
+	std::atomic<bool> bad(false);
+	static const struct AlphaTab { bool ok[256]; AlphaTab() { for (int c = 0; c < 256; c++) ok[c] = isalpha(c) != 0; } } alpha;
+	// calls line(ptr, len) for every line of the segment (without its '\n')
+	auto each_line = [&](size_t k, auto &&line) {
+		size_t p = seg[k]; const size_t e = seg[k + 1];
+		while (p < e) {
+			const char *nl = (const char *)memchr(d + p, '\n', e - p);
+			const size_t le = nl ? (size_t)(nl - d) : e;
+			line(p, le - p);
+			p = le + 1;
+		}
+	};
+	HostPool::global().run(S, [&](size_t k) {
+		std::vector<Piece> &pc = pieces[k];
+		pc.push_back(Piece{ 0, 0, 0 });
+		each_line(k, [&](size_t p, size_t len) {
+			if (len == 0) return;
+			if (d[p] == '>') { pc.push_back(Piece{ p, len, 0 }); return; }
+			if (d[p + len - 1] == '\r') len--;
+			bool ok = true;
+			for (size_t i = 0; i < len; i++) ok &= alpha.ok[(unsigned char)d[p + i]];
+			if (!ok) bad = true;
+			pc.back().bases += len;
+		});
+	});
+	if (bad) { err = "The query sequence contains non-alphabet characters!"; return false; }
+	// sequences and the place of every piece in them
+	const size_t base = out.size();                  // (a caller may hand in a vector that already holds contigs)
+	std::vector<std::vector<size_t> > dst(S), cidx(S);
+	std::vector<size_t> total;
+	for (size_t k = 0; k < S; k++) {
+		dst[k].assign(pieces[k].size(), 0); cidx[k].assign(pieces[k].size(), 0);
+		for (size_t j = 0; j < pieces[k].size(); j++) {
+			const Piece &pc = pieces[k][j];
+			if (pc.hdr_len) { QueryContig qc; qc.name = trim_name(d + pc.hdr_off + 1, pc.hdr_len - 1); out.push_back(qc); total.push_back(0); }
+			if (total.empty()) { if (pc.bases) { err = "sequence before the first header"; return false; } continue; }
+			cidx[k][j] = total.size() - 1; dst[k][j] = total.back(); total.back() += pc.bases;
 		}
 	}
-	if (out.empty()) { err = "no sequence in " + path; return false; }
+	if (total.empty()) { err = "no sequence in " + path; return false; }
+	HostPool::global().run(total.size(), [&](size_t c) { out[base + c].seq.resize(total[c]); });
+	HostPool::global().run(S, [&](size_t k) {
+		size_t j = 0;
+		char *w = pieces[k][0].bases ? &out[base + cidx[k][0]].seq[0] + dst[k][0] : nullptr;
+		each_line(k, [&](size_t p, size_t len) {
+			if (len == 0) return;
+			if (d[p] == '>') { j++; w = pieces[k][j].bases ? &out[base + cidx[k][j]].seq[0] + dst[k][j] : nullptr; return; }
+			if (d[p + len - 1] == '\r') len--;
+			if (len) { memcpy(w, d + p, len); w += len; }
+		});
+	});
 	return true;
+}
+
+// One block of OutputMAF (tools.cpp:164-216) as bytes.  The two text lines are filled piece by piece -- a seed prints the QUERY text on both
+// lines, a gap its two gapped strings -- by the pool's threads, each piece at the offset the serial concatenation gives it; trimming
+// (iExtension), the '-' counts, the reverse-complement of a reverse-strand block (SelfComplementarySeq: in place, pairs (i, L-1-i) are
+// independent) and the NUL quirk (an unknown byte maps to '\0' and "%s" stops there) are the serial code's.
+void Emitter::maf_block(const QueryContig &q, ContigResult &r, gsa_block &b, OutBuf &small, const std::function<void(OutBuf &&)> &sink, const std::function<OutBuf(size_t)> &take) const
+{
+	gsa_frag *F = r.frags.data() + b.frag_off;
+	const size_t nf = (size_t)b.n_frag;
+	std::vector<size_t> off(nf + 1); off[0] = 0;
+	for (size_t k = 0; k < nf; k++) off[k + 1] = off[k] + (size_t)(F[k].bseed ? F[k].qlen : F[k].aln_len);
+	const size_t total = off[nf];
+	gsa_frag &last = F[nf - 1];
+	const int ext = extension(*idx, b, last);
+	if (ext > 0) { b.aln_len -= ext; b.score -= ext; last.rlen -= ext; last.qlen -= ext; }
+	const size_t L = (size_t)(b.aln_len > 0 ? b.aln_len : 0);
+	const bool big = 2 * L >= par_min_bytes();
+	OutBuf t1 = big ? take(L + 1) : OutBuf(L + 1), t2 = big ? take(L + 1) : OutBuf(L + 1);
+	const size_t fillable = total < L ? total : L;
+	auto fill = [&](size_t pb, size_t pe) {      // text positions [pb, pe)
+		size_t k = (size_t)(std::upper_bound(off.begin(), off.end(), pb) - off.begin()) - 1;
+		for (size_t p = pb; p < pe; k++) {
+			const size_t o = p - off[k], n = std::min(off[k + 1], pe) - p;
+			if (F[k].bseed) { memcpy(t1.p + p, q.seq.data() + F[k].qpos + o, n); memcpy(t2.p + p, q.seq.data() + F[k].qpos + o, n); }
+			else { memcpy(t1.p + p, r.aln1.data() + F[k].aln_off + o, n); memcpy(t2.p + p, r.aln2.data() + F[k].aln_off + o, n); }
+			p += n;
+		}
+	};
+	std::atomic<long long> g1(0), g2(0);
+	auto gaps = [&](size_t pb, size_t pe) { long long a = 0, c = 0; for (size_t i = pb; i < pe; i++) { a += t1.p[i] == '-'; c += t2.p[i] == '-'; } g1 += a; g2 += c; };
+	auto revpair = [&](char *s, size_t ib, size_t ie) { for (size_t i = ib; i < ie; i++) { const size_t j = L - 1 - i; const char a = s[i], c = s[j]; s[i] = rev_map(c); s[j] = rev_map(a); } };
+	if (big) {
+		par_ranges(fillable, (size_t)1 << 18, fill);
+		if (L > fillable) { memset(t1.p + fillable, 0, L - fillable); memset(t2.p + fillable, 0, L - fillable); }      // (std::string::resize pads with NULs)
+		par_ranges(L, (size_t)1 << 18, gaps);
+		if (!b.bdir) {
+			par_ranges(L / 2, (size_t)1 << 18, [&](size_t ib, size_t ie) { revpair(t1.p, ib, ie); revpair(t2.p, ib, ie); });
+			if (L & 1) { t1.p[L / 2] = rev_map(t1.p[L / 2]); t2.p[L / 2] = rev_map(t2.p[L / 2]); }
+		}
+	} else {
+		if (fillable) fill(0, fillable);
+		if (L > fillable) { memset(t1.p + fillable, 0, L - fillable); memset(t2.p + fillable, 0, L - fillable); }
+		gaps(0, L);
+		if (!b.bdir) { revpair(t1.p, 0, L / 2); revpair(t2.p, 0, L / 2); if (L & 1) { t1.p[L / 2] = rev_map(t1.p[L / 2]); t2.p[L / 2] = rev_map(t2.p[L / 2]); } }
+	}
+	// "%s": the line ends at the first NUL
+	const size_t n1 = (size_t)((const char *)memchr(t1.p, 0, L) ? (const char *)memchr(t1.p, 0, L) - t1.p : (ptrdiff_t)L);
+	const size_t n2 = (size_t)((const char *)memchr(t2.p, 0, L) ? (const char *)memchr(t2.p, 0, L) - t2.p : (ptrdiff_t)L);
+	const std::string &rname = idx->chr_name[b.chr];
+	std::string qname = q.name;
+	if (qname.size() <= rname.size()) qname.append(rname.size() - qname.size(), ' ');           // only the query name is printed padded (App. B #18)
+	const int clen = idx->chr_len[b.chr]; const unsigned qlen = (unsigned)q.seq.size();
+	std::vector<char> h1(rname.size() + 128), h2(qname.size() + 128);
+	int l1, l2;
+	if (b.bdir) {
+		l1 = snprintf(h1.data(), h1.size(), "a score=%d\ns ref.%s %d %d + %d ", b.bdup ? 1 : b.score, rname.c_str(), b.gpos - 1, b.aln_len - (int)g1.load(), clen);
+		l2 = snprintf(h2.data(), h2.size(), "\ns qry.%s %d %d + %d ", qname.c_str(), F[0].qpos, b.aln_len - (int)g2.load(), qlen);
+	} else {
+		const int64_t rpos = last.rpos + last.rlen - 1;
+		int d, c, g; idx->coordinate(rpos, &d, &c, &g);
+		l1 = snprintf(h1.data(), h1.size(), "a score=%d\ns ref.%s %d %d + %d ", b.bdup ? 1 : b.score, rname.c_str(), g - 1, b.aln_len - (int)g1.load(), clen);
+		l2 = snprintf(h2.data(), h2.size(), "\ns qry.%s %d %d - %d ", qname.c_str(), qlen - (last.qpos + last.qlen), b.aln_len - (int)g2.load(), qlen);
+	}
+	if (!big) {
+		small.append(h1.data(), (size_t)l1); small.append(t1.p, n1); small.append(h2.data(), (size_t)l2); small.append(t2.p, n2); small.append("\n\n", 2);
+		if (small.n >= ((size_t)4 << 20)) { OutBuf out = std::move(small); small = OutBuf(); sink(std::move(out)); }
+		return;
+	}
+	small.append(h1.data(), (size_t)l1);
+	{ OutBuf out = std::move(small); small = OutBuf(); sink(std::move(out)); }
+	t1.n = n1; sink(std::move(t1));
+	small.append(h2.data(), (size_t)l2);
+	{ OutBuf out = std::move(small); small = OutBuf(); sink(std::move(out)); }
+	t2.n = n2; sink(std::move(t2));
+	small.append("\n\n", 2);
+}
+
+void Emitter::maf_text(bool first, const QueryContig &q, ContigResult &r, const std::function<void(OutBuf &&)> &sink, const std::function<OutBuf(size_t)> &take) const
+{
+	r.expand();
+	OutBuf small;
+	if (first) small.append("##maf version=1\n", 16);
+	for (size_t bi = 0; bi < r.blocks.size(); bi++) {
+		gsa_block &b = r.blocks[bi];
+		if (!allow_dup && b.bdup) continue;
+		maf_block(q, r, b, small, sink, take);
+	}
+	if (small.n) sink(std::move(small));
 }
 
 void Emitter::maf(FILE *fp, bool first, const QueryContig &q, ContigResult &r) const
 {
-	if (first) fprintf(fp, "##maf version=1\n");
-	std::string t1, t2;
-	for (size_t bi = 0; bi < r.blocks.size(); bi++) {
-		gsa_block &b = r.blocks[bi];
-		if (!allow_dup && b.bdup) continue;
-		block_text(q, r, b, t1, t2);
-		gsa_frag &last = r.frags[b.frag_off + b.n_frag - 1];
-		const int ext = extension(*idx, b, last);
-		if (ext > 0) { b.aln_len -= ext; b.score -= ext; last.rlen -= ext; last.qlen -= ext; }
-		t1.resize(b.aln_len); t2.resize(b.aln_len);
-		const std::string &rname = idx->chr_name[b.chr];
-		std::string qname = q.name;
-		if (qname.size() <= rname.size()) qname.append(rname.size() - qname.size(), ' ');           // only the query name is printed padded (App. B #18)
-		const int clen = idx->chr_len[b.chr]; const unsigned qlen = (unsigned)q.seq.size();
-		fprintf(fp, "a score=%d\n", b.bdup ? 1 : b.score);
-		if (b.bdir) {
-			fprintf(fp, "s ref.%s %d %d + %d %s\n", rname.c_str(), b.gpos - 1, b.aln_len - count_gaps(t1, 0, b.aln_len), clen, t1.c_str());
-			fprintf(fp, "s qry.%s %d %d + %d %s\n\n", qname.c_str(), r.frags[b.frag_off].qpos, b.aln_len - count_gaps(t2, 0, b.aln_len), qlen, t2.c_str());
-		} else {
-			const int64_t rpos = last.rpos + last.rlen - 1;
-			self_complement(t1, b.aln_len); self_complement(t2, b.aln_len);
-			int d, c, g; idx->coordinate(rpos, &d, &c, &g);
-			fprintf(fp, "s ref.%s %d %d + %d %s\n", rname.c_str(), g - 1, b.aln_len - count_gaps(t1, 0, b.aln_len), clen, t1.c_str());
-			fprintf(fp, "s qry.%s %d %d - %d %s\n\n", qname.c_str(), qlen - (last.qpos + last.qlen), b.aln_len - count_gaps(t2, 0, b.aln_len), qlen, t2.c_str());
-		}
-	}
+	maf_text(first, q, r, [&](OutBuf &&o) { if (o.n) fwrite(o.p, 1, o.n, fp); }, [](size_t c) { return OutBuf(c); });
 }
 
 void Emitter::aln(FILE *fp, const QueryContig &q, ContigResult &r) const
@@ -187,82 +364,167 @@ bool Emitter::dotplot(const std::string &gp_path, const std::string &out_prefix,
 	return true;
 }
 
-void Emitter::variants(int query_idx, const QueryContig &q, const ContigResult &r)
+// VariantIdentification for the records [kb, ke) of one block (SeqVariant.cpp:27-117): a record's variants depend on that record only
+static void variants_of(const HostIndex *idx, int query_idx, const QueryContig &q, const ContigResult &r, const gsa_block &b, size_t kb, size_t ke, std::vector<Variant> &vars, int cnt[3])
 {
 	const std::string &ref = idx->ref;
-	for (size_t bi = 0; bi < r.blocks.size(); bi++) {
-		const gsa_block &b = r.blocks[bi];
-		if (b.bdup) continue;
-		Variant v; v.chr_idx = b.chr; v.query_idx = query_idx;
-		int d, c, g;
-		for (int k = 0; k < b.n_frag; k++) {
-			const gsa_frag &f = r.frags[b.frag_off + k];
-			if (f.bseed) continue;
-			if (f.qlen == 0 && f.rlen == 0) continue;
-			if (f.qlen == 0) {                                        // pure deletion (:36-45)
-				n_del++;
-				v.type = 2; idx->coordinate(f.rpos - 1, &d, &c, &g); v.pos = g;
-				v.ref_frag = ref.substr(f.rpos - 1, f.rlen + 1); v.alt_frag.assign(1, q.seq[f.qpos - 1]);
+	Variant v; v.chr_idx = b.chr; v.query_idx = query_idx;
+	int d, c, g;
+	for (size_t k = kb; k < ke; k++) {
+		const gsa_frag &f = r.frags[b.frag_off + k];
+		if (f.bseed) continue;
+		if (f.qlen == 0 && f.rlen == 0) continue;
+		if (f.qlen == 0) {                                        // pure deletion (:36-45)
+			cnt[2]++;
+			v.type = 2; idx->coordinate(f.rpos - 1, &d, &c, &g); v.pos = g;
+			v.ref_frag = ref.substr(f.rpos - 1, f.rlen + 1); v.alt_frag.assign(1, q.seq[f.qpos - 1]);
+			vars.push_back(v);
+		} else if (f.rlen == 0) {                                 // pure insertion (:46-55)
+			cnt[1]++;
+			v.type = 1; idx->coordinate(f.rpos - 1, &d, &c, &g); v.pos = g;
+			v.ref_frag.assign(1, ref[f.rpos - 1]); v.alt_frag = q.seq.substr(f.qpos - 1, f.qlen + 1);
+			vars.push_back(v);
+		} else if (f.qlen == 1 && f.rlen == 1) {                  // 1x1 (:56-67)
+			const char a1 = r.aln1[f.aln_off], a2 = r.aln2[f.aln_off];
+			if (nt4(a1) != nt4(a2) && nt4(a2) != 4) {
+				cnt[0]++;
+				v.type = 0; idx->coordinate(f.rpos, &d, &c, &g); v.pos = g;
+				v.ref_frag.assign(1, a1); v.alt_frag.assign(1, a2);
 				vars.push_back(v);
-			} else if (f.rlen == 0) {                                 // pure insertion (:46-55)
-				n_ins++;
-				v.type = 1; idx->coordinate(f.rpos - 1, &d, &c, &g); v.pos = g;
-				v.ref_frag.assign(1, ref[f.rpos - 1]); v.alt_frag = q.seq.substr(f.qpos - 1, f.qlen + 1);
-				vars.push_back(v);
-			} else if (f.qlen == 1 && f.rlen == 1) {                  // 1x1 (:56-67)
-				const char a1 = r.aln1[f.aln_off], a2 = r.aln2[f.aln_off];
-				if (nt4(a1) != nt4(a2) && nt4(a2) != 4) {
-					n_snv++;
-					v.type = 0; idx->coordinate(f.rpos, &d, &c, &g); v.pos = g;
-					v.ref_frag.assign(1, a1); v.alt_frag.assign(1, a2);
+			}
+		} else {                                                  // walk the aligned columns (:68-115)
+			const char *x1 = r.aln1.data() + f.aln_off, *x2 = r.aln2.data() + f.aln_off;
+			const int L = f.aln_len; int64_t rp = f.rpos; int qp = f.qpos;
+			for (int i = 0; i < L; i++) {
+				if (x1[i] == '-') {
+					cnt[1]++;
+					int n = 1; while (i + n < L && x1[i + n] == '-') n++;
+					const std::string fr = q.seq.substr(qp - 1, n + 1);
+					v.type = 1; idx->coordinate(rp - 1, &d, &c, &g); v.pos = g;
+					v.ref_frag.assign(1, fr[0]); v.alt_frag = fr;           // REF anchor comes from the QUERY (App. B #15)
 					vars.push_back(v);
-				}
-			} else {                                                  // walk the aligned columns (:68-115)
-				const char *x1 = r.aln1.data() + f.aln_off, *x2 = r.aln2.data() + f.aln_off;
-				const int L = f.aln_len; int64_t rp = f.rpos; int qp = f.qpos;
-				for (int i = 0; i < L; i++) {
-					if (x1[i] == '-') {
-						n_ins++;
-						int n = 1; while (i + n < L && x1[i + n] == '-') n++;
-						const std::string fr = q.seq.substr(qp - 1, n + 1);
-						v.type = 1; idx->coordinate(rp - 1, &d, &c, &g); v.pos = g;
-						v.ref_frag.assign(1, fr[0]); v.alt_frag = fr;           // REF anchor comes from the QUERY (App. B #15)
+					qp += n; i += n - 1;
+				} else if (x2[i] == '-') {
+					cnt[2]++;
+					int n = 1; while (i + n < L && x2[i + n] == '-') n++;
+					const std::string fr = ref.substr(rp - 1, n + 1);
+					v.type = 2; idx->coordinate(rp - 1, &d, &c, &g); v.pos = g;
+					v.ref_frag = fr; v.alt_frag.assign(1, fr[0]);
+					vars.push_back(v);
+					rp += n; i += n - 1;
+				} else if (nt4(x1[i]) != nt4(x2[i])) {
+					if (nt4(x2[i]) != 4) {
+						cnt[0]++;
+						v.type = 0; idx->coordinate(rp, &d, &c, &g); v.pos = g;
+						v.ref_frag.assign(1, x1[i]); v.alt_frag.assign(1, x2[i]);
 						vars.push_back(v);
-						qp += n; i += n - 1;
-					} else if (x2[i] == '-') {
-						n_del++;
-						int n = 1; while (i + n < L && x2[i + n] == '-') n++;
-						const std::string fr = ref.substr(rp - 1, n + 1);
-						v.type = 2; idx->coordinate(rp - 1, &d, &c, &g); v.pos = g;
-						v.ref_frag = fr; v.alt_frag.assign(1, fr[0]);
-						vars.push_back(v);
-						rp += n; i += n - 1;
-					} else if (nt4(x1[i]) != nt4(x2[i])) {
-						if (nt4(x2[i]) != 4) {
-							n_snv++;
-							v.type = 0; idx->coordinate(rp, &d, &c, &g); v.pos = g;
-							v.ref_frag.assign(1, x1[i]); v.alt_frag.assign(1, x2[i]);
-							vars.push_back(v);
-						}
-						rp++; qp++;
-					} else { rp++; qp++; }
-				}
+					}
+					rp++; qp++;
+				} else { rp++; qp++; }
 			}
 		}
 	}
 }
 
-void Emitter::vcf(FILE *fp, const std::string &reference_label)
+// VarVec grows block after block, record after record (SeqVariant.cpp:12-119); here a long block's records are dealt to the pool in ranges
+// and the ranges' lists are kept IN THAT ORDER (var_chunks): the sequence the final sort sees is the serial one.
+void Emitter::variants(int query_idx, const QueryContig &q, ContigResult &r)
+{
+	r.expand();
+	for (size_t bi = 0; bi < r.blocks.size(); bi++) {
+		const gsa_block &b = r.blocks[bi];
+		if (b.bdup) continue;
+		const size_t nf = (size_t)b.n_frag;
+		if (nf * 16 < par_min_bytes()) {
+			if (var_chunks.empty() || var_chunks.back().size() > ((size_t)1 << 20)) var_chunks.emplace_back();
+			int cnt[3] = { 0, 0, 0 };
+			variants_of(idx, query_idx, q, r, b, 0, nf, var_chunks.back(), cnt);
+			n_snv += cnt[0]; n_ins += cnt[1]; n_del += cnt[2];
+			continue;
+		}
+		const size_t parts = std::min<size_t>((size_t)HostPool::global().threads() * 4, nf / 4096 + 1);
+		const size_t at = var_chunks.size();
+		var_chunks.resize(at + parts);
+		std::vector<std::array<int, 3> > cnts(parts, std::array<int, 3>{ { 0, 0, 0 } });
+		HostPool::global().run(parts, [&](size_t k) {
+			variants_of(idx, query_idx, q, r, b, nf * k / parts, nf * (k + 1) / parts, var_chunks[at + k], cnts[k].data());
+		});
+		for (size_t k = 0; k < parts; k++) { n_snv += cnts[k][0]; n_ins += cnts[k][1]; n_del += cnts[k][2]; }
+	}
+}
+
+namespace {
+inline char *put_int(char *p, long long v)
+{
+	char tmp[24]; int n = 0; bool neg = v < 0; unsigned long long u = neg ? 0ull - (unsigned long long)v : (unsigned long long)v;
+	do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+	if (neg) *p++ = '-';
+	while (n) *p++ = tmp[--n];
+	return p;
+}
+}
+
+// OutputSequenceVariants (SeqVariant.cpp:121-143).  The reference std::sorts VarVec on (chr_idx, pos) -- an incomplete key: the order of
+// variants that share a position is whatever libstdc++'s introsort leaves (App. B #17).  What introsort does depends on the comparator's
+// answers only, never on what else an element carries, so sorting 16-byte keys {chr, pos, where the variant lies} with the same comparator
+// on the same initial sequence makes the same comparisons and the same moves: the permutation is the reference's, without dragging two
+// std::strings per element through every swap.  The lines are then formatted by the pool in ranges and written in order.
+void Emitter::vcf_text(const std::string &reference_label, const std::function<void(OutBuf &&)> &sink)
 {
 	static const char *MutType[3] = { "SUBSTITUTE", "INSERT", "DELETE" };
-	struct ByPos { bool operator()(const Variant &a, const Variant &b) const { return a.chr_idx == b.chr_idx ? a.pos < b.pos : a.chr_idx < b.chr_idx; } };
-	std::sort(vars.begin(), vars.end(), ByPos());                    // same std::sort, same incomplete key (App. B #17)
-	fprintf(fp, "##fileformat=VCFv4.1\n");
-	fprintf(fp, "##reference=%s\n", reference_label.c_str());
-	fprintf(fp, "##source=GSAlign %s\n", "1.0.22");
-	fprintf(fp, "##INFO=<ID=TYPE,Number=1,Type=String,Description=\"The type of allele, either SUBSTITUTE, INSERT, or DELETE.\">\n");
-	for (size_t i = 0; i < idx->chr_name.size(); i++) fprintf(fp, "##contig=<ID=%s,length=%d>\n", idx->chr_name[i].c_str(), idx->chr_len[i]);
-	fprintf(fp, "#CHROM	POS	ID	REF	ALT	QUAL	FILTER	INFO\n");
-	for (size_t i = 0; i < vars.size(); i++)
-		fprintf(fp, "%s\t%d\t.\t%s\t%s\t100\t*\tTYPE=%s\n", idx->chr_name[vars[i].chr_idx].c_str(), vars[i].pos, vars[i].ref_frag.c_str(), vars[i].alt_frag.c_str(), MutType[vars[i].type]);
+	struct Key { int32_t chr, pos; uint32_t chunk, at; };
+	struct ByPos { bool operator()(const Key &a, const Key &b) const { return a.chr == b.chr ? a.pos < b.pos : a.chr < b.chr; } };
+	if (!vars.empty()) { var_chunks.insert(var_chunks.begin(), std::vector<Variant>()); var_chunks.front().swap(vars); }      // (variants pushed into `vars` directly come first)
+	std::vector<size_t> base(var_chunks.size() + 1, 0);
+	for (size_t c = 0; c < var_chunks.size(); c++) base[c + 1] = base[c] + var_chunks[c].size();
+	const size_t n = base.back();
+	std::vector<Key> keys(n);
+	HostPool::global().run(var_chunks.size(), [&](size_t c) {
+		const std::vector<Variant> &vc = var_chunks[c]; Key *k = keys.data() + base[c];
+		for (size_t i = 0; i < vc.size(); i++) { k[i].chr = vc[i].chr_idx; k[i].pos = vc[i].pos; k[i].chunk = (uint32_t)c; k[i].at = (uint32_t)i; }
+	});
+	std::sort(keys.begin(), keys.end(), ByPos());                    // same std::sort, same incomplete key, same initial order
+	{
+		OutBuf h;
+		h.append("##fileformat=VCFv4.1\n"); h.append("##reference=" + reference_label + "\n"); h.append("##source=GSAlign 1.0.22\n");
+		h.append("##INFO=<ID=TYPE,Number=1,Type=String,Description=\"The type of allele, either SUBSTITUTE, INSERT, or DELETE.\">\n");
+		for (size_t i = 0; i < idx->chr_name.size(); i++) h.append("##contig=<ID=" + idx->chr_name[i] + ",length=" + std::to_string(idx->chr_len[i]) + ">\n");
+		h.append("#CHROM	POS	ID	REF	ALT	QUAL	FILTER	INFO\n");
+		sink(std::move(h));
+	}
+	const size_t per = (size_t)1 << 16, parts = (n + per - 1) / per;
+	// (ranges are formatted a batch at a time so that the writer gets them in order while the next batch is formatted)
+	const size_t batch = (size_t)HostPool::global().threads() * 2;
+	for (size_t p0 = 0; p0 < parts; p0 += batch) {
+		const size_t pn = std::min(batch, parts - p0);
+		std::vector<OutBuf> outs(pn);
+		auto one = [&](size_t j) {
+			const size_t b = (p0 + j) * per, e = std::min(n, b + per);
+			OutBuf &o = outs[j]; o.reserve((e - b) * 48);
+			for (size_t i = b; i < e; i++) {
+				const Variant &v = var_chunks[keys[i].chunk][keys[i].at];
+				const std::string &cn = idx->chr_name[(size_t)v.chr_idx];
+				const char *mt = MutType[v.type]; const size_t ml = strlen(mt);
+				// "%s" of a std::string's c_str(): up to its first NUL (a fragment never holds one, kept for the letter)
+				const size_t rl = strnlen(v.ref_frag.c_str(), v.ref_frag.size()), al = strnlen(v.alt_frag.c_str(), v.alt_frag.size());
+				const size_t need = cn.size() + rl + al + ml + 48;
+				if (o.n + need > o.cap) o.reserve((o.n + need) * 2);
+				char *w = o.p + o.n;
+				memcpy(w, cn.data(), cn.size()); w += cn.size(); *w++ = '\t';
+				w = put_int(w, v.pos); memcpy(w, "\t.\t", 3); w += 3;
+				memcpy(w, v.ref_frag.data(), rl); w += rl; *w++ = '\t';
+				memcpy(w, v.alt_frag.data(), al); w += al;
+				memcpy(w, "\t100\t*\tTYPE=", 12); w += 12;
+				memcpy(w, mt, ml); w += ml; *w++ = '\n';
+				o.n = (size_t)(w - o.p);
+			}
+		};
+		if (n * 48 < par_min_bytes()) for (size_t j = 0; j < pn; j++) one(j); else HostPool::global().run(pn, one);
+		for (size_t j = 0; j < pn; j++) sink(std::move(outs[j]));
+	}
+}
+
+void Emitter::vcf(FILE *fp, const std::string &reference_label)
+{
+	vcf_text(reference_label, [&](OutBuf &&o) { if (o.n) fwrite(o.p, 1, o.n, fp); });
 }

@@ -7,6 +7,7 @@
 #define GSA_HOST_H
 #include <stdint.h>
 #include <stdio.h>
+#include <functional>
 #include <string>
 #include <vector>
 #include "gsa_hip.h"
@@ -40,30 +41,41 @@ bool gsah_load_query(const std::string &path, std::vector<QueryContig> &out, std
 // one finished contig, as delivered by gsa_align_contig
 struct ContigResult {
 	std::vector<gsa_block> blocks;
-	std::vector<gsa_frag> frags;
+	std::vector<gsa_rec> recs;             // the 16-byte records as they arrived (assign_raw), until expand() turns them into ...
+	std::vector<gsa_frag> frags;           // ... the FragPair_t-shaped records the emitters read
 	std::string aln1, aln2;
-	void assign(const gsa_result &r);
+	void assign_raw(const gsa_result &r);  // the copies only: what a GPU worker thread does inside the result callback
+	void expand();                         // recs -> frags (on the pool); a no-op the second time
+	void assign(const gsa_result &r);      // both
 };
 
 struct Variant { int pos, chr_idx, query_idx, type; std::string ref_frag, alt_frag; };   // structure.h:124-132
 
+struct OutBuf;                             // par.h
+
 struct Emitter {
 	const HostIndex *idx = nullptr;
 	bool allow_dup = true;                 // !-unique
-	std::vector<Variant> vars;             // VarVec
+	std::vector<Variant> vars;             // VarVec ...
+	std::vector<std::vector<Variant> > var_chunks;   // ... kept as the lists the pool's threads filled, in the serial order (vars first)
 	int n_snv = 0, n_ins = 0, n_del = 0;
 	// OutputMAF (tools.cpp:149-220).  first = (QueryChrIdx == 0).  May shorten the last record of a block (iExtension).
 	void maf(FILE *fp, bool first, const QueryContig &q, ContigResult &r) const;
+	// the same bytes handed to `sink` buffer after buffer, in order; a block's two text lines are filled by the pool's threads (par.h);
+	// `take(n)` supplies the large buffers (OrderedWriter::take recycles them)
+	void maf_text(bool first, const QueryContig &q, ContigResult &r, const std::function<void(OutBuf &&)> &sink, const std::function<OutBuf(size_t)> &take) const;
+	void maf_block(const QueryContig &q, ContigResult &r, gsa_block &b, OutBuf &small, const std::function<void(OutBuf &&)> &sink, const std::function<OutBuf(size_t)> &take) const;
 	// OutputAlignment (tools.cpp:222-286)
 	void aln(FILE *fp, const QueryContig &q, ContigResult &r) const;
 	// OutputDotplot (DotPloting.cpp:10-71): gnuplot script `gp_path` + one data file per plotted reference sequence
 	// (`<prefix>.<query>vs<chr>`); returns false when there is nothing to plot.  Running gnuplot on the script and removing
 	// the data files afterwards (DotPloting.cpp:69-70) is the caller's business: `data_files` receives their names.
 	bool dotplot(const std::string &gp_path, const std::string &out_prefix, const QueryContig &q, const ContigResult &r, std::vector<std::string> *data_files = nullptr) const;
-	// VariantIdentification (SeqVariant.cpp:12-119)
-	void variants(int query_idx, const QueryContig &q, const ContigResult &r);
+	// VariantIdentification (SeqVariant.cpp:12-119); long blocks are dealt to the pool in record ranges
+	void variants(int query_idx, const QueryContig &q, ContigResult &r);
 	// OutputSequenceVariants (SeqVariant.cpp:121-143)
 	void vcf(FILE *fp, const std::string &reference_label);
+	void vcf_text(const std::string &reference_label, const std::function<void(OutBuf &&)> &sink);
 };
 
 #endif

@@ -6,6 +6,20 @@
 
 extern "C" {
 
+// LoadQueryFile through the C API (tests): the contigs stay in a static list until the next call
+static std::vector<QueryContig> g_query;
+int gsah_c_load_query(const char *path, char *err)
+{
+	g_query.clear(); std::string e;
+	if (gsah_load_query(path, g_query, e)) return (int)g_query.size();
+	if (err) { strncpy(err, e.c_str(), 255); err[255] = 0; }
+	g_query.clear();
+	return -1;
+}
+const char *gsah_c_query_name(int i) { return g_query[(size_t)i].name.c_str(); }
+long long gsah_c_query_len(int i) { return (long long)g_query[(size_t)i].seq.size(); }
+const char *gsah_c_query_seq(int i) { return g_query[(size_t)i].seq.data(); }
+
 // returns 0 on success; err (>= 256 bytes) receives the message otherwise
 int gsah_c_build_index(const char *fasta, const char *prefix, char *err)
 {

@@ -3,23 +3,33 @@
 // (the CODE's defaults: -clr 200, -alen 200), same output files, with the per-contig
 // hot path handed to libgsa_hip.so (gsa_align_contig) instead of GenomeComparison's
 // pthread stages.  Extra flags: -gpu LIST (device ordinals, comma separated: the query contigs shard over them with the
-// index replicated) and -ctx N (contexts per GPU: gsa_clone, contigs overlap on one device).
-// The contigs go through gsa_align_many (the per-contig loop of GSAlign.cpp:483-548); MAF / VCF are written afterwards in
-// contig order, so the output bytes do not depend on how many GPUs or contexts worked.
+// index replicated), -ctx N (contexts per GPU: gsa_clone, contigs overlap on one device) and -timing
+// (one JSON line on stderr: where the wall time of the run went).
+// The contigs go through gsa_align_many (the per-contig loop of GSAlign.cpp:483-548).  Round 5: a GPU worker thread only COPIES a finished
+// contig out of the library's memory; ONE formatter thread takes the contigs in contig order (OutputMAF appends per contig, VarVec grows in
+// contig order: GSAlign.cpp:543-546) and formats each with the host pool's threads (par.h: the text lines of a block, the variants of a
+// block's records), a writer thread writes the buffers in order -- so the output bytes depend neither on GPUs / contexts nor on -t.
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <fcntl.h>
+#include <unistd.h>
 #include "gsa_host.h"
+#include "par.h"
 
 static void usage(const char *prog, int t, const gsa_params &p, int fmt)
 {
 	fprintf(stderr, "\nGenAlign v%s\n", "1.0.22");
 	fprintf(stderr, "Usage: %s [-i IndexFile Prefix / -r Reference file] -q QueryFile[Fasta]\n\n", prog);
-	fprintf(stderr, "Options: -t     INT     number of threads [%d] (accepted for compatibility; the hot path runs on the GPU)\n", t);
+	fprintf(stderr, "Options: -t     INT     number of threads [%d] (host side: FASTA / index loading, MAF / VCF formatting; the hot path runs on the GPU)\n", t);
 	fprintf(stderr, "         -o     STR     Set the prefix of the output files [output]\n");
 	fprintf(stderr, "         -fmt   INT     Set the output format 1:maf, 2:aln [%d]\n", fmt);
 	fprintf(stderr, "         -idy   INT     Set the minimal sequence identity (0-100) of a local alignment [%d]\n", p.min_identity);
@@ -29,10 +39,13 @@ static void usage(const char *prog, int t, const gsa_params &p, int fmt)
 	fprintf(stderr, "         -clr   INT     Set the minimal cluster size [%d]\n", p.min_block_score);
 	fprintf(stderr, "         -unique        Output unique alignment only [false]\n");
 	fprintf(stderr, "         -sen           Sensitive mode [False]\n");
+	fprintf(stderr, "         -dp            Output Dot-plots\n");
 	fprintf(stderr, "         -one           set one on one aligment mode[false]\n");
+	fprintf(stderr, "         -gp    STR     Specify the path of gnuplot\n");
 	fprintf(stderr, "         -no_vcf        do not write the VCF file\n");
 	fprintf(stderr, "         -gpu   LIST    GPU ordinals, comma separated [0]\n");
-	fprintf(stderr, "         -ctx   INT     contexts per GPU working on different query sequences [2]\n\n");
+	fprintf(stderr, "         -ctx   INT     contexts per GPU working on different query sequences [2]\n");
+	fprintf(stderr, "         -timing        print where the wall time went (one JSON line on stderr)\n\n");
 }
 
 static bool check_prefix(const char *p)                     // CheckOutputPrefix (main.cpp:116-138)
@@ -52,13 +65,16 @@ static bool first_char_is_header(const char *path)          // CheckInputFile (m
 	return c == '>';
 }
 
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int main(int argc, char *argv[])
 {
-	setenv("GPU_MAX_HW_QUEUES", "8", 0);        // (-ctx contexts x 4 streams each: the runtime's default is 4 hardware queues per process)
+	// -ctx contexts x 5 streams each; the runtime's default is 4 hardware queues per process.  bench.py uses the same value (--hwq); see INTEGRATION.md
+	setenv("GPU_MAX_HW_QUEUES", "16", 0);
 	gsa_params prm; gsa_default_params(&prm);
-	int threads = 8, fmt = 1, n_ctx_per_gpu = 2; bool vcf = true, allow_dup = true, dotplot = false;
+	int threads = HostPool::default_threads(), fmt = 1, n_ctx_per_gpu = 2; bool vcf = true, allow_dup = true, dotplot = false, timing = getenv("GSA_TIMING") != NULL;
 	std::vector<int> gpus;
-	const char *index_prefix = NULL, *ref_fa = NULL, *query_fa = NULL, *out_prefix = NULL;
+	const char *index_prefix = NULL, *ref_fa = NULL, *query_fa = NULL, *out_prefix = NULL, *gnuplot_arg = NULL;
 	if (argc == 1 || strcmp(argv[1], "-h") == 0) { usage(argv[0], threads, prm, fmt); return 0; }
 	if (strcmp(argv[1], "index") == 0) {
 		if (argc == 4) { std::string e; if (!gsah_build_index(argv[2], argv[3], e)) { fprintf(stderr, "%s\n", e.c_str()); return 1; } }
@@ -84,31 +100,40 @@ int main(int argc, char *argv[])
 		else if (a == "-o") out_prefix = argv[++i];
 		else if (a == "-gpu" && i + 1 < argc) { for (const char *p = argv[++i]; *p;) { gpus.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; } }
 		else if (a == "-ctx" && i + 1 < argc) { n_ctx_per_gpu = atoi(argv[++i]); if (n_ctx_per_gpu < 1) n_ctx_per_gpu = 1; }
+		else if (a == "-timing") timing = true;
 		else if (a == "-dp") dotplot = true;
+		else if (a == "-gp" && i + 1 < argc) gnuplot_arg = argv[++i];      // main.cpp:285: the path of gnuplot, used as given
 		else if (a == "-d" || a == "-debug") { /* debug printers: not reproduced */ }
-		else if ((a == "-gp" || a == "-obr") && i + 1 < argc) ++i;
+		else if (a == "-obr" && i + 1 < argc) ++i;
 		else fprintf(stderr, "Warning! Unknow parameter: %s\n", argv[i]);
 	}
 	if ((index_prefix == NULL && ref_fa == NULL) || query_fa == NULL) { usage(argv[0], threads, prm, fmt); return 0; }
 	if (out_prefix == NULL) out_prefix = "output"; else if (!check_prefix(out_prefix)) return 0;
+	HostPool::global().resize(threads < 1 ? 1 : (threads > 256 ? 256 : threads));
 
 	const time_t t0 = time(NULL);
+	const double T0 = now_s();
+	double t_query = 0, t_index = 0, t_create = 0, t_align = 0, t_drain = 0, t_vcf = 0, t_maf_fmt = 0, t_var = 0, t_copy = 0, t_expand = 0, t_build = 0;
 	fprintf(stderr, "Step1. Load the two genome sequences...\n");
-	std::string err; std::vector<QueryContig> qs;
-	if (!first_char_is_header(query_fa) || !gsah_load_query(query_fa, qs, err)) { fprintf(stderr, "Please check the query file: %s\n", query_fa); return 0; }
-	fprintf(stderr, "\tLoad the query sequences (%d %s)\n", (int)qs.size(), qs.size() > 1 ? "chromosomes" : "chromosome");
+	std::string err, qerr; std::vector<QueryContig> qs; bool q_ok = false;
+	if (!first_char_is_header(query_fa)) { fprintf(stderr, "Please check the query file: %s\n", query_fa); return 0; }
+	// the query FASTA is read beside the index (both use the pool: their parallel sections take turns) and beside gsa_create, which is GPU work
+	std::thread q_loader([&] { const double t = now_s(); q_ok = gsah_load_query(query_fa, qs, qerr); t_query = now_s() - t; });
+	struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } q_join{ q_loader };
 	HostIndex idx; std::string prefix;
 	if (index_prefix != NULL && gsah_index_files_exist(index_prefix)) prefix = index_prefix;
 	else if (ref_fa != NULL && first_char_is_header(ref_fa)) {
 		prefix = ref_fa; size_t p = prefix.find_last_of('.'); if (p != std::string::npos && p > 0) prefix.resize(p);
+		const double t = now_s();
 		if (!gsah_build_index(ref_fa, prefix, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
-	} else { fprintf(stderr, "Please specify a valid reference genome\n"); return 0; }
-	if (!gsah_load_index(prefix, idx, err)) { fprintf(stderr, "\n\nError! Please check your input! (%s)\n", err.c_str()); return 1; }
-	fprintf(stderr, "\tLoad the reference sequences (%d %s)\n", (int)idx.chr_len.size(), idx.chr_len.size() > 1 ? "chromosomes" : "chromosome");
+		t_build = now_s() - t;
+	} else { q_loader.join(); if (!q_ok) fprintf(stderr, "Please check the query file: %s\n", query_fa); else fprintf(stderr, "Please specify a valid reference genome\n"); return 0; }
+	{ const double t = now_s(); const bool ok = gsah_load_index(prefix, idx, err); t_index = now_s() - t; if (!ok) { fprintf(stderr, "\n\nError! Please check your input! (%s)\n", err.c_str()); return 1; } }
 
-	// FindGnuPlotPath (main.cpp:169-191): -dp needs a gnuplot binary; without one the reference plots nothing either
-	std::string gnuplot;
-	if (dotplot) {
+	// FindGnuPlotPath (main.cpp:169-191): -dp needs a gnuplot binary -- the one -gp names, else the first one on PATH; without one the
+	// reference plots nothing either
+	std::string gnuplot = gnuplot_arg ? gnuplot_arg : "";
+	if (dotplot && gnuplot.empty()) {
 		const char *path = getenv("PATH");
 		for (std::string p = path ? path : ""; !p.empty();) {
 			const size_t k = p.find(':'); const std::string dir = p.substr(0, k);
@@ -121,54 +146,78 @@ int main(int argc, char *argv[])
 	gsa_index_view view; idx.fill_view(&view);
 	if (gpus.empty()) gpus.push_back(0);
 	if (getenv("GSA_BIND")) (void)gsa_bind_host_thread(gpus[0]);      // (opt-in: small contigs gain from a near-socket thread, chromosome-sized ones lose 5 %)
-	// one context per GPU owns that device's copy of the index; the others borrow it (gsa_clone)
+	// one context per GPU owns that device's copy of the index; the others borrow it (gsa_clone).  The number of contexts wanted depends on
+	// the number of query sequences: the owners are created first (GPU work, beside the FASTA loader), the clones once the count is known
 	std::vector<gsa_ctx *> ctxs;
-	// (at least one context per listed GPU: with fewer query sequences than GPUs gsa_align_many seeds a long sequence on several of them)
-	const size_t want_ctx = std::min(std::max(qs.size(), gpus.size()), gpus.size() * (size_t)n_ctx_per_gpu);
-	for (size_t g = 0; g < gpus.size() && ctxs.size() < std::max<size_t>(want_ctx, 1); g++) {
-		gsa_ctx *owner = NULL;
-		// (the HOST PROGRAM honours a few environment variables and hands them to the library as options -- the library itself reads none:
-		//  GSA_FORCE_WIDE=1: the >= 2^32-row device layout on any index; GSA_SPLIT_MIN / GSA_BUNDLE_CONTIG / GSA_BUNDLE_CAP: gsa_align_many's policy)
-		const char *fw = getenv("GSA_FORCE_WIDE");
-		if (gsa_create_opts(gpus[g], &view, &prm, (fw && *fw && *fw != '0') ? GSA_CREATE_WIDE : 0u, &owner) != GSA_OK) { fprintf(stderr, "GPU initialisation failed (device %d): %s\n", gpus[g], gsa_last_error(NULL)); return 2; }
-		for (const char *nm : { "split_min", "bundle_contig", "bundle_cap" }) {
-			std::string ev = std::string("GSA_") + nm; for (char &ch : ev) ch = (char)toupper((unsigned char)ch);
-			if (const char *v = getenv(ev.c_str())) (void)gsa_set_option(owner, nm, atoll(v));
+	{
+		const double t = now_s();
+		for (size_t g = 0; g < gpus.size(); g++) {
+			gsa_ctx *owner = NULL;
+			// (the HOST PROGRAM honours a few environment variables and hands them to the library as options -- the library itself reads none:
+			//  GSA_FORCE_WIDE=1: the >= 2^32-row device layout on any index; GSA_SPLIT_MIN / GSA_BUNDLE_CONTIG / GSA_BUNDLE_CAP: gsa_align_many's policy)
+			const char *fw = getenv("GSA_FORCE_WIDE");
+			if (gsa_create_opts(gpus[g], &view, &prm, (fw && *fw && *fw != '0') ? GSA_CREATE_WIDE : 0u, &owner) != GSA_OK) { fprintf(stderr, "GPU initialisation failed (device %d): %s\n", gpus[g], gsa_last_error(NULL)); return 2; }
+			for (const char *nm : { "split_min", "bundle_contig", "bundle_cap" }) {
+				std::string ev = std::string("GSA_") + nm; for (char &ch : ev) ch = (char)toupper((unsigned char)ch);
+				if (const char *v = getenv(ev.c_str())) (void)gsa_set_option(owner, nm, atoll(v));
+			}
+			ctxs.push_back(owner);
 		}
-		ctxs.push_back(owner);
+		t_create = now_s() - t;
 	}
-	for (int k = 1; k < n_ctx_per_gpu; k++)
-		for (size_t g = 0; g < gpus.size() && ctxs.size() < want_ctx; g++) {
-			gsa_ctx *cl = NULL;
-			if (g >= ctxs.size() || gsa_clone(ctxs[g], &cl) != GSA_OK) { fprintf(stderr, "GPU initialisation failed (device %d): %s\n", gpus[g], gsa_last_error(NULL)); return 2; }
-			ctxs.push_back(cl);
-		}
+	q_loader.join();
+	if (!q_ok) { fprintf(stderr, "Please check the query file: %s\n", query_fa); return 0; }
+	fprintf(stderr, "\tLoad the query sequences (%d %s)\n", (int)qs.size(), qs.size() > 1 ? "chromosomes" : "chromosome");
+	fprintf(stderr, "\tLoad the reference sequences (%d %s)\n", (int)idx.chr_len.size(), idx.chr_len.size() > 1 ? "chromosomes" : "chromosome");
+	{
+		// (at least one context per listed GPU: with fewer query sequences than GPUs gsa_align_many seeds a long sequence on several of them)
+		const size_t want_ctx = std::min(std::max(qs.size(), gpus.size()), gpus.size() * (size_t)n_ctx_per_gpu);
+		const double t = now_s();
+		for (int k = 1; k < n_ctx_per_gpu; k++)
+			for (size_t g = 0; g < gpus.size() && ctxs.size() < want_ctx; g++) {
+				gsa_ctx *cl = NULL;
+				if (gsa_clone(ctxs[g], &cl) != GSA_OK) { fprintf(stderr, "GPU initialisation failed (device %d): %s\n", gpus[g], gsa_last_error(NULL)); return 2; }
+				ctxs.push_back(cl);
+			}
+		t_create += now_s() - t;
+	}
 
 	const std::string maf = std::string(out_prefix) + ".maf", aln = std::string(out_prefix) + ".aln", vcfn = std::string(out_prefix) + ".vcf";
 	Emitter em; em.idx = &idx; em.allow_dup = allow_dup;
 	long long n_aln = 0, tot_len = 0, tot_match = 0, n_dup = 0;
 	fprintf(stderr, "Step2. Sequence analysis for all query chromosomes\n");
-	// the hot path: every contig through gsa_align_contig on whichever context is free; the finished blocks are copied out
-	// of the context by the worker that produced them.  Output is written in contig order AS THE CONTIGS FINISH (OutputMAF
-	// appends per contig, VarVec grows in contig order: GSAlign.cpp:543-546): a result waits only for the contigs in front
-	// of it, is freed once written, and a GPU error keeps what was written before it.  One writer at a time, outside the lock.
 	std::vector<const char *> qptr(qs.size()); std::vector<int32_t> qlen(qs.size());
 	for (size_t ci = 0; ci < qs.size(); ci++) { qptr[ci] = qs[ci].seq.data(); qlen[ci] = (int32_t)qs[ci].seq.size(); }
+	// finished contigs: copied by the GPU worker that produced them (on_result), taken in contig order by the formatter thread
 	struct Sink {
-		std::mutex mu; std::vector<ContigResult> res; std::vector<char> ready; size_t next = 0; bool writing = false;
-		std::function<void(size_t, ContigResult &)> write;
+		std::mutex mu; std::condition_variable cv; std::vector<ContigResult> res; std::vector<char> ready; bool abort = false; double copy_s = 0;
 	} sink;
 	sink.res.resize(qs.size()); sink.ready.assign(qs.size(), 0);
-	sink.write = [&](size_t ci, ContigResult &cr) {
+	// the MAF file: created by the first contig that has alignments ("w" for contig 0, "a" afterwards: tools.cpp:158-163 -- a run whose
+	// first contig aligns nowhere appends to whatever the file held, as the reference does)
+	int maf_fd = -1; std::unique_ptr<OrderedWriter> maf_w;
+	size_t written = 0;
+	auto write_contig = [&](size_t ci, ContigResult &cr) {
 		fprintf(stderr, "\tProcess query chromsomoe: %s...\n", qs[ci].name.c_str());
 		if (cr.blocks.empty()) return;
+		{ const double t = now_s(); cr.expand(); t_expand += now_s() - t; }
 		long long len = 0, score = 0;
 		for (size_t b = 0; b < cr.blocks.size(); b++) { len += cr.blocks[b].aln_len; score += cr.blocks[b].score; if (cr.blocks[b].bdup) n_dup++; }
 		n_aln += (long long)cr.blocks.size(); tot_len += len; tot_match += score;
 		fprintf(stderr, "\t\tProduce %d local alignments (length = %lld), ANI=%.2f%%\n", (int)cr.blocks.size(), len, 100 * (1.0 * score / len));
-		if (fmt == 1) { FILE *fp = fopen(maf.c_str(), ci == 0 ? "w" : "a"); if (fp) { em.maf(fp, ci == 0, qs[ci], cr); fclose(fp); } }
+		if (fmt == 1) {
+			const double t = now_s();
+			if (maf_fd < 0 || ci == 0) {
+				if (maf_w) { maf_w->close(); maf_w.reset(); }
+				if (maf_fd >= 0) close(maf_fd);
+				maf_fd = open(maf.c_str(), O_WRONLY | O_CREAT | (ci == 0 ? O_TRUNC : O_APPEND), 0644);
+				if (maf_fd >= 0) maf_w.reset(new OrderedWriter(maf_fd));
+			}
+			if (maf_w) em.maf_text(ci == 0, qs[ci], cr, [&](OutBuf &&o) { maf_w->push(std::move(o)); }, [&](size_t c) { return maf_w->take(c); });
+			t_maf_fmt += now_s() - t;
+		}
 		if (fmt == 2) { FILE *fp = fopen(aln.c_str(), ci == 0 ? "w" : "a"); if (fp) { em.aln(fp, qs[ci], cr); fclose(fp); } }
-		if (vcf) em.variants((int)ci, qs[ci], cr);
+		if (vcf) { const double t = now_s(); em.variants((int)ci, qs[ci], cr); t_var += now_s() - t; }
 		if (dotplot && !gnuplot.empty()) {                               // GSAlign.cpp:546: only when gnuplot was found (main.cpp:324)
 			const std::string gp = std::string(out_prefix) + ".gp";
 			std::vector<std::string> data_files;
@@ -181,36 +230,65 @@ int main(int argc, char *argv[])
 			}
 		}
 	};
+	std::thread formatter([&] {
+		for (size_t k = 0; k < qs.size(); k++) {
+			{ std::unique_lock<std::mutex> lk(sink.mu); sink.cv.wait(lk, [&] { return sink.abort || sink.ready[k]; }); if (!sink.ready[k]) return; }
+			write_contig(k, sink.res[k]);
+			ContigResult().blocks.swap(sink.res[k].blocks); std::vector<gsa_frag>().swap(sink.res[k].frags); std::vector<gsa_rec>().swap(sink.res[k].recs);
+			std::string().swap(sink.res[k].aln1); std::string().swap(sink.res[k].aln2);
+			written = k + 1;
+		}
+	});
 	auto on_result = [](void *user, int32_t ci, const gsa_result *res) -> int {
 		Sink &sk = *(Sink *)user;
-		sk.res[(size_t)ci].assign(*res);
-		std::unique_lock<std::mutex> lk(sk.mu);
-		sk.ready[(size_t)ci] = 1;
-		if (sk.writing) return 0;                                       // the current writer picks it up when its turn comes
-		sk.writing = true;
-		while (sk.next < sk.ready.size() && sk.ready[sk.next]) {
-			const size_t k = sk.next++;
-			lk.unlock();
-			sk.write(k, sk.res[k]);
-			ContigResult().blocks.swap(sk.res[k].blocks); std::vector<gsa_frag>().swap(sk.res[k].frags); std::string().swap(sk.res[k].aln1); std::string().swap(sk.res[k].aln2);
-			lk.lock();
-		}
-		sk.writing = false;
+		const double t = now_s();
+		sk.res[(size_t)ci].assign_raw(*res);
+		const double dt = now_s() - t;
+		{ std::lock_guard<std::mutex> lk(sk.mu); sk.ready[(size_t)ci] = 1; sk.copy_s += dt; }
+		sk.cv.notify_all();
 		return 0;
 	};
+	const double ta = now_s();
 	const int rc_many = gsa_align_many(ctxs.data(), (int32_t)ctxs.size(), qptr.data(), qlen.data(), (int32_t)qs.size(), 0, on_result, &sink);
+	t_align = now_s() - ta;
+	{ std::lock_guard<std::mutex> lk(sink.mu); if (rc_many != GSA_OK) sink.abort = true; }
+	sink.cv.notify_all();
+	const double td = now_s();
+	formatter.join();
+	double maf_write_s = 0; unsigned long long maf_bytes = 0;
+	if (maf_w) { maf_w->close(); maf_write_s = maf_w->write_seconds(); maf_bytes = maf_w->bytes(); maf_w.reset(); }
+	if (maf_fd >= 0) close(maf_fd);
+	t_drain = now_s() - td; t_copy = sink.copy_s;
 	if (rc_many != GSA_OK) {
 		for (gsa_ctx *c : ctxs) if (*gsa_last_error(c)) fprintf(stderr, "GPU error: %s\n", gsa_last_error(c));
-		fprintf(stderr, "\t%d of %d query sequences were written before the error\n", (int)sink.next, (int)qs.size());
+		fprintf(stderr, "\t%d of %d query sequences were written before the error\n", (int)written, (int)qs.size());
 		return 2;
 	}
 	if (n_aln > 0) fprintf(stderr, "\tAlignment#=%d (total alignment length=%lld) ANI=%.2f%%, unique alignment#=%d\n", (int)n_aln, tot_len, 100 * (1.0 * tot_match / tot_len), (int)(n_aln - n_dup));
 	fprintf(stderr, "\tIt took %lld seconds for genome sequence alignment.\n", (long long)(time(NULL) - t0));
+	unsigned long long vcf_bytes = 0; double vcf_write_s = 0;
 	if (vcf) {
+		const double t = now_s();
 		fprintf(stderr, "\nGSAlign identifies %d SNVs, %d insertions, and %d deletions [%s].\n\n", em.n_snv, em.n_ins, em.n_del, vcfn.c_str());
-		FILE *fp = fopen(vcfn.c_str(), "w");
-		if (fp) { em.vcf(fp, index_prefix != NULL ? index_prefix : ref_fa); fclose(fp); }
+		const int fd = open(vcfn.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+		if (fd >= 0) {
+			OrderedWriter w(fd);
+			em.vcf_text(index_prefix != NULL ? index_prefix : ref_fa, [&](OutBuf &&o) { w.push(std::move(o)); });
+			w.close(); vcf_bytes = w.bytes(); vcf_write_s = w.write_seconds(); close(fd);
+		}
+		t_vcf = now_s() - t;
 	}
+	const double t_destroy0 = now_s();
 	for (size_t k = ctxs.size(); k-- > 0;) gsa_destroy(ctxs[k]);      // clones before the owners of their index
+	const double t_destroy = now_s() - t_destroy0;
+	if (timing) {
+		long long qbp = 0; for (const QueryContig &q : qs) qbp += (long long)q.seq.size();
+		const double total = now_s() - T0;
+		fprintf(stderr, "GSA_TIMING {\"total_s\": %.3f, \"index_build_s\": %.3f, \"index_load_s\": %.3f, \"gsa_create_s\": %.3f, \"query_load_s\": %.3f, \"align_many_s\": %.3f, "
+		        "\"result_copy_s_sum\": %.3f, \"expand_s\": %.3f, \"maf_format_s\": %.3f, \"variants_s\": %.3f, \"output_drain_after_align_s\": %.3f, \"maf_write_s\": %.3f, \"maf_bytes\": %llu, "
+		        "\"vcf_s\": %.3f, \"vcf_write_s\": %.3f, \"vcf_bytes\": %llu, \"destroy_s\": %.3f, \"host_threads\": %d, \"contexts\": %d, \"query_bp\": %lld, \"contigs\": %d, \"gbp_per_s_excl_index_build\": %.4f}\n",
+		        total, t_build, t_index, t_create, t_query, t_align, t_copy, t_expand, t_maf_fmt, t_var, t_drain, maf_write_s, maf_bytes, t_vcf, vcf_write_s, vcf_bytes, t_destroy,
+		        HostPool::global().threads(), (int)ctxs.size(), qbp, (int)qs.size(), (double)qbp / (total - t_build) / 1e9);
+	}
 	return 0;
 }

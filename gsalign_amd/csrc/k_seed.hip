@@ -1552,7 +1552,12 @@ static int prepare_pd_bitmap(gsa_ctx *c, i64 n_hits)
 	if (c->pd_path) {
 		const size_t cap0 = c->d_pdbm.cap;
 		const size_t ccap0 = c->d_pdcb.cap;
-		if (!dev_ensure<u32>(c, c->d_pdbm, (size_t)pd_words + 66) || !dev_ensure<u32>(c, c->d_pdcb, (size_t)(pd_words >> 10) + 4)) return GSA_ERR_NOMEM;
+		if (!dev_ensure<u32>(c, c->d_pdbm, (size_t)pd_words + 66) || !dev_ensure<u32>(c, c->d_pdcb, (size_t)(pd_words >> 10) + 4)) {
+			// no room for the bitmap (up to 2 GB per context): this contig's groups come from the PosDiff sort instead (seed_view_sort), as
+			// for MaxIndelSize > 31 -- slower, same result
+			(void)hipGetLastError(); c->err.clear(); c->pd_path = false; c->pdbm_dirty = true;
+			return GSA_OK;
+		}
 		if (c->d_pdbm.cap != cap0 || c->pdbm_dirty) GSA_CHECK(c, hipMemsetAsync(c->d_pdbm.p, 0, c->d_pdbm.cap, c->stream));
 		if (c->d_pdcb.cap != ccap0 || c->pdbm_dirty) GSA_CHECK(c, hipMemsetAsync(c->d_pdcb.p, 0, c->d_pdcb.cap, c->stream));
 		c->pdbm_dirty = true; c->pd_words = (i64)pd_words;

@@ -154,7 +154,8 @@ class ResultStage:
         import ctypes
         import torch
         sizes = [int(n) for _, n in pieces]
-        assert len(sizes) == 4
+        if len(sizes) != 4:
+            raise ValueError("ResultStage.put: pieces = (blocks, records, string pool 1, string pool 2)")
         pad = [(n + 7) & ~7 for n in sizes]
         t = torch.empty(self.HDR + sum(pad), dtype=torch.uint8, device=self.dev)
         hdr = np.array([contig] + sizes, np.int64)
@@ -191,10 +192,12 @@ def parse_staged(buf: np.ndarray, block_dt, rec_dt) -> tuple:
 
 
 def gather_staged(staged, max_items: int, device=None, dst: int = 0, host_pool=None):
-    """One step's staged contigs of every rank -> rank `dst`, as host byte arrays (one per contig, in contig order).  One all_gather
-    of the per-contig byte counts (max_items slots per rank), then batched point-to-point sends / receives of exact sizes
-    (device to device: RCCL over xGMI), then -- on `dst` -- one D2H copy per contig into `host_pool` (a pinned uint8 tensor that
-    grows as needed; pass the returned pool back in).  Other ranks return ([], host_pool)."""
+    """One step's staged contigs of every rank OTHER THAN `dst` -> rank `dst`, as host byte arrays: one per contig, sorted by the contig
+    id in each header (parse_staged).  `dst`'s own contigs are NOT in the list -- they never leave the memory its aligner returned them
+    in; a writer on `dst` merges the two by contig id.  One all_gather of the per-contig byte counts (max_items slots per rank), then
+    batched point-to-point sends / receives of exact sizes (device to device: RCCL over xGMI), then -- on `dst` -- one D2H copy per
+    contig into `host_pool` (a pinned uint8 tensor that grows as needed; pass the returned pool back in).  Other ranks return
+    ([], host_pool)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -231,8 +234,11 @@ def gather_staged(staged, max_items: int, device=None, dst: int = 0, host_pool=N
         for t in recv:
             h = host_pool[off:off + t.numel()]; h.copy_(t, non_blocking=True); out.append(h); off += t.numel()
         torch.cuda.current_stream(dev).synchronize()
-        return [h.numpy() for h in out], host_pool
-    return [t.numpy() for t in recv], host_pool
+        got = [h.numpy() for h in out]
+    else:
+        got = [t.numpy() for t in recv]
+    got.sort(key=lambda b: int(b[:8].view(np.int64)[0]))        # contig order, whatever rank a contig came from
+    return got, host_pool
 
 
 def gather_block_records(records: np.ndarray, contig_ids: np.ndarray, device=None):

@@ -153,7 +153,10 @@ int  gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *pr
  *   "walk_coop"      1 = the pointer-doubling rounds of the window walk (chaining, contigs above 100 000 seeds) as ONE cooperative launch instead of a
  *                    launch per round (default 0: measured slower)
  *   "dp_safe", "dp_fake_timeout"   test hooks: one striped DP job per launch; the next n contigs report a stripe hand-off time-out once
- * Unknown names: GSA_ERR_ARG. */
+ * Unknown names and values outside an option's range (negative sizes, seed_budget 0, ...): GSA_ERR_ARG, nothing changed.
+ * Until round 4 some of these were environment variables read by the library (GSA_SPLIT_MIN, GSA_BUNDLE_CONTIG, GSA_BUNDLE_CAP, GSA_SEED_BUDGET,
+ * GSA_DP_LANE, GSA_SEED_MODE, GSA_NO_PDBITMAP, GSA_FORCE_WIDE, GSA_KMER_K, GSA_DP_SAFE, GSA_DP_FAKE_TIMEOUT, GSA_NO_BIND): the library ignores
+ * them now -- a C host sets the option (or the gsa_create_opts flag) itself; INTEGRATION.md lists the mapping. */
 int  gsa_set_option(gsa_ctx *ctx, const char *name, int64_t value);
 /* A further context on the same GPU that borrows `parent`'s device-resident index (read-only) and owns everything else.
  * The reference runs -t N threads inside one contig (GSAlign.cpp:477-526); contigs are independent (all per-contig state
@@ -164,7 +167,7 @@ int  gsa_set_option(gsa_ctx *ctx, const char *name, int64_t value);
 int  gsa_clone(gsa_ctx *parent, gsa_ctx **out);
 void gsa_destroy(gsa_ctx *ctx);
 /* Puts the CALLING host thread on the CPUs of the socket `device` hangs off (sysfs local_cpulist of its PCI function; a no-op
- * without that information or with GSA_NO_BIND set).  The reference's worker threads (GSAlign.cpp:479, pthread_create) run
+ * without that information).  The reference's worker threads (GSAlign.cpp:479, pthread_create) run
  * wherever the OS puts them, which costs nothing there; a thread that drives a GPU through ~60 short operations per 5 Mb
  * contig pays the inter-socket hop on every one (0.86 -> 0.65-0.75 ms per 5 Mb contig); chromosome-sized contigs ran 5 %
  * slower with bound threads, so nothing in the library calls this by itself: threads started by gsa_align_many inherit the
@@ -217,7 +220,7 @@ typedef int (*gsa_result_fn)(void *user, int32_t contig, const gsa_result *res);
 #define GSA_MANY_NO_BUNDLE 8u  /* never align several short contigs in one pass (see gsa_align_bundle) */
 #define GSA_MANY_NO_PREFETCH 16u /* upload every contig when its turn comes (default: a context uploads its next contig while it aligns the current one) */
 /* With FEWER contigs than contexts (one chromosome, two GPUs: BASELINE configs[3]) the contexts are dealt out in groups, one
- * group per contig, sized by contig length, and a contig of at least 20 Mb (GSA_SPLIT_MIN) is seeded by chunk range on all
+ * group per contig, sized by contig length, and a contig of at least 20 Mb (gsa_set_option "split_min") is seeded by chunk range on all
  * contexts of its group -- gsa_seed_chunks ... gsa_finish_contig below, driven from the library's own threads, hits moved
  * device to device (peer to peer between GPUs).  Results do not depend on the grouping. */
 int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query, const int32_t *qlen, int32_t n,
@@ -229,7 +232,7 @@ int gsa_align_many(gsa_ctx *const *ctx, int32_t n_ctx, const char *const *query,
  * through all stages together; seed groups never span contigs, AlnBlockVec is kept per contig.  out[k] is EXACTLY what
  * gsa_align_contig(query[k]) returns -- positions, record and string offsets relative to contig k -- and stays valid until the
  * next call on ctx.  n <= 4096, total length < 2^31.  flags: GSA_MANY_DEVICE (query[] are device pointers on ctx's GPU).
- * gsa_align_many bundles contigs of at most 16 Mb by itself (GSA_BUNDLE_CONTIG; bundles of about GSA_BUNDLE_CAP = 64 Mb at most). */
+ * gsa_align_many bundles contigs of at most 16 Mb by itself (gsa_set_option "bundle_contig"; bundles of about "bundle_cap" = 64 Mb at most). */
 int gsa_align_bundle(gsa_ctx *ctx, const char *const *query, const int32_t *qlen, int32_t n, uint32_t flags, gsa_result *out);
 
 /* ---- one long contig on several GPUs ---------------------------------------

@@ -234,7 +234,8 @@ def _main_refdump(argv):
         ref.set_query(seq, name)
         for k, v in ref.dump_stages(upto).items():
             out[f"c{ci}_{k}"] = v
-    np.savez_compressed(out_npz, **out)
+    # (chromosome-sized contigs: hundreds of MB of dumps -- zlib would cost more than the stages themselves)
+    (np.savez if sum(v.nbytes for v in out.values()) > (64 << 20) else np.savez_compressed)(out_npz, **out)
 
 
 if __name__ == "__main__":

@@ -1,8 +1,14 @@
 #!/usr/bin/env python3
-"""BASELINE configs[4] on ONE GPU: a 24-contig reference with GRCh38 chromosome lengths (3.08 Gbp, 6.2 G BWT rows: the wide
-device layout and the 64-bit suffix sorter on their real input), query = 1 %-diverged copy of every chromosome (one of them
-reverse-complemented), -alen 5000, all contigs through gsa_align_many on two contexts.  Result invariants on three contigs,
-throughput of the whole set.  GPU box only (host: ~120 GB, HBM: ~110 GB).   usage: human_scale_probe.py [scale=1.0]"""
+"""BASELINE configs[4] on ONE GPU (run by tests/test_gpu_parity.py::test_config5_full_human_all_contigs in a process of its own): a
+24-contig reference with GRCh38 chromosome lengths (3.08 Gbp, 6.2 G BWT rows: the >= 2^32-row device layout and the 64-bit suffix sorter
+on their real input), query = 1 %-diverged copy of every chromosome (one of them reverse-complemented), -alen 5000.
+  1. all contigs through gsa_align_many on two contexts: throughput, then EVERY contig through the result invariants;
+  2. ORACLE PARITY ON THE NATIVE >= 2^32-ROW INDEX (round 5): whole contigs and pieces -- forward strand, reverse strand, reference positions
+     above 2^32 -- against the real reference (oracle/_ref/libgsref.so loads the same index files; the CPU restatement when it is absent),
+     every stage dump S1..S8 incl. both gapped-string pools, bit for bit;
+  3. a bundle of short contigs against the human-sized index == the same contigs one by one.
+Test infrastructure (it loads oracle/): lives under tests/.  GPU box only (host: ~120 GB, HBM: ~110 GB).
+usage: human_scale_check.py [scale=1.0]"""
 import os, sys, time, tempfile, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -35,7 +41,7 @@ try:
         print(f"pass {rep}, contigs resident in HBM: {total} bp in {dt * 1e3:.0f} ms = {total / dt / 1e9:.2f} Gbp/s (D2H included, 2 contexts)", flush=True)
     from test_gpu_parity import _check_result_invariants
     # every contig: result invariants (records tile their blocks, seeds are exact matches, the gapped strings spell both fragments,
-    # lengths and scores are what the strings say) -- there is no oracle at this size
+    # lengths and scores are what the strings say); the oracle comparison follows below
     tot_cov = 0
     for ci in range(len(qs)):
         t = time.time(); g0.align_contig(pinned[ci]); dt = time.time() - t
@@ -47,9 +53,43 @@ try:
         #  the same shape against the oracle)
         assert cov > (0.45 if ci == 20 else 0.9) * qs[ci].size
     print(f"all {len(qs)} contigs checked, total coverage {tot_cov / total:.3f}")
+    # ---- oracle parity on the native >= 2^32-row index (reference loader: bwt_index.cpp:147-264; loop body: GSAlign.cpp:483-540) ----
+    from oracle import oracle_py as op
+    from conftest import assert_stage_equal
+    PRM = dict(alen=5000)
+    cases = [("contig20_whole_revcomp", qs[20]),                                             # 46 Mb, reverse strand
+             ("contig18_whole_forward", qs[18]),                                             # 58 Mb, forward strand
+             ("contig0_piece_revcomp", synth.revcomp(np.ascontiguousarray(qs[0][30000000:50000000]))),   # reverse strand of chr1: reference positions ~ 2G - 50 Mb > 2^32
+             ("contig7_piece", np.ascontiguousarray(qs[7][5000000:6500000])),
+             ("contig22_head", np.ascontiguousarray(qs[22][0:3000001])),
+             ("contig20_piece", np.ascontiguousarray(qs[20][300000:1299999])),
+             ("contig12_one_chunk", np.ascontiguousarray(qs[12][40000000:40010000]))]
+    if scale < 1.0:
+        cases = [(n, q[:max(10000, int(q.size * scale))]) for n, q in cases]
+    t = time.time()
+    if op.have_ref():
+        qfa, npz = os.path.join(tmp, "parity_q.fa"), os.path.join(tmp, "parity.npz")
+        synth.write_fasta(qfa, cases)
+        op.ref_dump_subprocess(os.path.join(tmp, "r"), qfa, npz, PRM, upto=8)      # the real reference, one thread, a process of its own
+        want_all = np.load(npz); kind = "real reference (libgsref)"
+        want = lambda ci: {k[len(f"c{ci}_"):]: want_all[k] for k in want_all.files if k.startswith(f"c{ci}_")}
+    else:
+        ora = op.Oracle(idx, PRM); kind = "CPU restatement (oracle/gsa_oracle.cpp)"
+        def want(ci):
+            ora.set_query(cases[ci][1]); return ora.dump_stages(8)
+    print(f"oracle side: {kind}, {sum(q.size for _, q in cases)} bp in {time.time() - t:.0f} s", flush=True)
+    hi = rev = 0
+    for ci, (name, q) in enumerate(cases):
+        w = want(ci)
+        g0.set_query(q)
+        assert_stage_equal(g0.dump_stages(8), w)
+        hi += int((w["s8_f_rpos"] >= 2 ** 32).sum()); rev += int((w["s8_b_bdir"] == 0).sum())
+        assert w["s8_b_score"].size > 0 or q.size <= 10000, name
+        print(f"  {name}: {q.size} bp, {w['s1_qpos'].size} seeds, {w['s8_b_score'].size} blocks, {w['s8_f_qpos'].size} records, {w['s8_aln1'].size} string bytes: all stage dumps identical", flush=True)
+    assert scale < 1.0 or (hi > 0 and rev > 0), (hi, rev)
+    print(f"ORACLE PARITY OK on the native wide index: {len(cases)} contigs vs the {kind}; {hi} records at reference positions >= 2^32, {rev} reverse-strand blocks")
     # short contigs against the human-sized index, bundled (the PosDiff stride of a bundle is ~ 2G = 6.2 G here: the seed key's width
     # and the PosDiff-sort path at their real size): pieces of five query chromosomes, one reverse-complemented, in one pass == one by one
-    import numpy as np
     pieces = [np.ascontiguousarray(qs[ci][o:o + ln]) for ci, o, ln in ((0, 1000000, 2000000), (7, 5000000, 1500000), (20, 300000, 999999), (22, 0, 3000001), (12, 40000000, 10000))]
     bun = g0.align_bundle(pieces)
     for k, pc in enumerate(pieces):

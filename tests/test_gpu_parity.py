@@ -625,8 +625,10 @@ def _check_result_invariants(idx, qry, r):
 @pytest.mark.parametrize("total,ncontig,div,seed,repeats", [(24000000, 2, 0.015, 31, False), (250000000, 1, 0.01, 32, True), (250000000, 1, 0.01, 33, "adversarial")])
 def test_full_size_result_invariants(tmp_path, total, ncontig, div, seed, repeats):
     """BASELINE-sized pairs (configs[3]: one 250 Mb chromosome at 1 %, with the repeat-stress injection, and once with the
-    adversarial one: copy-number spectrum up to 10^5, microsatellites, Mb-long N runs, soft-masked blocks): no oracle at this
-    size, so the result is checked against itself and the inputs."""
+    adversarial one: copy-number spectrum up to 10^5, microsatellites, Mb-long N runs, soft-masked blocks).  The 250 Mb repeat-stress
+    contig is ALSO compared with the oracle at every stage (round 5: the real reference at one thread needs about a minute for it); the
+    24 Mb two-strand pair and the adversarial contig (whose repeats cost the reference's walk O(L^2) Occ steps per copy: hours) are checked
+    against themselves and the inputs."""
     from gsalign_amd import hostlib
     if repeats == "adversarial":
         refs, qrys = synth.make_adversarial_pair(total, ncontig, div, seed=seed)
@@ -638,6 +640,20 @@ def test_full_size_result_invariants(tmp_path, total, ncontig, div, seed, repeat
     synth.write_fasta(rf, refs); hostlib.build_index(rf, px)
     idx = indexio.load_index(px)
     g = capi.Aligner(idx)
+    if total == 250000000 and repeats is True:
+        # BASELINE configs[3] against the oracle (round 5): the whole 250 Mb contig through the real reference at one thread (libgsref,
+        # ~60 s; the CPU restatement where oracle/_ref is absent), every stage dump S1..S8 incl. both gapped-string pools, bit for bit
+        from oracle import oracle_py as op
+        if op.have_ref():
+            qfa, npz = str(tmp_path / "q.fa"), str(tmp_path / "ref.npz")
+            synth.write_fasta(qfa, qrys); op.ref_dump_subprocess(px, qfa, npz, {}, upto=8)
+            z = np.load(npz); want = {k[3:]: z[k] for k in z.files if k.startswith("c0_")}
+        else:
+            op.build(ref=False); o = op.Oracle(idx); o.set_query(qrys[0][1]); want = o.dump_stages(8); o.close()
+        g.set_query(qrys[0][1])
+        assert_stage_equal(g.dump_stages(8), want)
+        assert want["s8_b_score"].size > 0 and want["s1_qpos"].size > 1000000
+        print(f"250 Mb contig vs the {'real reference' if op.have_ref() else 'oracle restatement'}: {want['s1_qpos'].size} seeds, {want['s8_b_score'].size} blocks, {want['s8_f_qpos'].size} records, {want['s8_aln1'].size} string bytes per side -- identical at every stage")
     for name, seq in qrys:
         g.align_contig(seq)
         r = g.blocks()
@@ -653,8 +669,10 @@ def test_config5_full_human_all_contigs():
     """BASELINE configs[4] on one GPU (the whole job of the 8-GPU configuration; the index is replicated per GPU there): a 24-contig
     reference with GRCh38 chromosome lengths, 3.08 Gbp / 6.2 G BWT rows -- the >= 2^32-row device layout and the 64-bit suffix sorter
     on their real input (the index builds in ~80 s on the host's cores since round 3) -- vs a 1 %-diverged query, -alen 5000, through
-    gsa_align_many on two contexts, then EVERY contig through the result invariants (no oracle at this size).  tools/human_scale_probe.py;
-    needs a host with >= 256 GB of memory (skipped elsewhere)."""
+    gsa_align_many on two contexts, then EVERY contig through the result invariants, and -- round 5 -- ORACLE PARITY at this scale: two whole
+    contigs (46 Mb reverse strand, 58 Mb forward), a 20 Mb reverse-strand piece of chr1 (reference positions above 2^32) and four short
+    pieces against the real reference (libgsref loads the same index files: bwt_index.cpp:147-264), every stage dump S1..S8 with both string
+    pools, bit for bit.  tests/human_scale_check.py; needs a host with >= 256 GB of memory (skipped elsewhere)."""
     import subprocess
     import sys
     from conftest import ROOT
@@ -664,8 +682,8 @@ def test_config5_full_human_all_contigs():
             mem_gb = int(ln.split()[1]) / 1e6
     if mem_gb < 256:
         pytest.skip(f"host has {mem_gb:.0f} GB of memory")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "human_scale_probe.py")], capture_output=True, text=True, timeout=1000)
-    assert r.returncode == 0 and "HUMAN SCALE PROBE OK" in r.stdout and "all 24 contigs checked" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "human_scale_check.py")], capture_output=True, text=True, timeout=1100)
+    assert r.returncode == 0 and "HUMAN SCALE PROBE OK" in r.stdout and "all 24 contigs checked" in r.stdout and "ORACLE PARITY OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     print(r.stdout)
 
 

@@ -74,8 +74,13 @@ def test_index_builder_parallel_vs_reference_builder_on_repeats(oracle_built, tm
     ("cx", dict(unique=1), "cx_unique.maf", "cx_unique.vcf"), ("cx", dict(fmt=2), "cx_fmt2.aln", "cx_fmt2.vcf"), ("cx", dict(one=1), "cx_one.maf", "cx_one.vcf"),
     ("cx", dict(idy=95), "cx_idy95.maf", "cx_idy95.vcf"), ("cx", dict(one=1, ind=40, clr=300, alen=1000, unique=1), "cx_combo.maf", "cx_combo.vcf"),
     ("cx", dict(sen=1, clr=50, fmt=2), "cx_sen_fmt2.aln", None)])
-def test_emitters_byte_identical(oracle_built, golden_dir, tmp_path, name, params, maf, vcf):
+@pytest.mark.parametrize("par_min", [None, "1"])
+def test_emitters_byte_identical(oracle_built, golden_dir, tmp_path, name, params, maf, vcf, par_min, monkeypatch):
+    """par_min = "1" (GSA_HOST_PAR_MIN): every block's text lines, every block's variants, the VCF lines and the FASTA / index loaders go
+    through their PARALLEL forms (host pool, csrc/host/par.h) although the goldens are small -- same bytes either way."""
     from gsalign_amd import indexio
+    if par_min:
+        monkeypatch.setenv("GSA_HOST_PAR_MIN", par_min)
     px = os.path.join(golden_dir, name)
     params = dict(params); unique = params.pop("unique", 0); fmt = params.pop("fmt", 1)
     o = oracle_built.Oracle(indexio.load_index(px), params)
@@ -137,3 +142,72 @@ def test_index_builder_gives_up_on_deep_repeats(oracle_built, tmp_path, monkeypa
         hostlib.build_index(fa, str(tmp_path / tag))
         for ext in ("pac", "ann", "amb", "bwt", "sa"):
             assert filecmp.cmp(str(tmp_path / f"{tag}.{ext}"), str(tmp_path / f"ref.{ext}"), shallow=False), (tag, ext)
+
+
+def _reference_loader(path):
+    """LoadQueryFile / TrimChromosomeName / CheckQuerySeq (reference src/main.cpp:35-114), restated line by line."""
+    out = []
+    data = open(path, "rb").read()
+    lines = data.split(b"\n")
+    if data.endswith(b"\n"):
+        lines = lines[:-1]
+    for ln in lines:
+        if ln == b"":
+            continue
+        if ln[:1] == b">":
+            name = bytearray(ln[1:]); i = 0
+            while i < len(name):
+                if name[i:i + 1] == b"|":
+                    name[i:i + 1] = b"-"
+                elif name[i:i + 1] in (b" ", b"#", b":", b"=", b"\t"):
+                    break
+                i += 1
+            out.append([bytes(name[:i]), bytearray()])
+        else:
+            if ln.endswith(b"\r"):
+                ln = ln[:-1]
+            if not all((65 <= c <= 90) or (97 <= c <= 122) for c in ln):
+                return None
+            out[-1][1] += ln
+    return [(n, bytes(q)) for n, q in out]
+
+
+@pytest.mark.parametrize("par_min", [None, "1", "37"])
+def test_query_loader_matches_the_reference_loop(tmp_path, par_min, monkeypatch):
+    """gsah_load_query reads the file in slices, cuts it into segments at line starts and fills the sequences from all of them at once (round 5);
+    the reference reads line by line.  Awkward files -- CRLF, empty lines, no final newline, headers with cut characters, a '>' inside a header,
+    a header directly behind a header, one-base lines, lines of every length around the segment cuts -- through both."""
+    import ctypes as C
+    if par_min:
+        monkeypatch.setenv("GSA_HOST_PAR_MIN", par_min)
+    lib = hostlib.load()
+    lib.gsah_c_query_name.restype = C.c_char_p; lib.gsah_c_query_len.restype = C.c_longlong; lib.gsah_c_query_seq.restype = C.POINTER(C.c_char)
+    rng = np.random.default_rng(5)
+
+    def seq(n):
+        return bytes(rng.choice(np.frombuffer(b"ACGTacgtNnRY", np.uint8), size=n))
+    files = {
+        "plain": b">c1\n" + seq(70) + b"\n" + seq(70) + b"\n" + seq(13) + b"\n>c2 description here\n" + seq(5) + b"\n",
+        "crlf": b">c1 x\r\n" + seq(60) + b"\r\n" + seq(9) + b"\r\n>c|2#y\r\n" + seq(11) + b"\r\n",
+        "no_final_newline": b">a\n" + seq(30) + b"\n>b\n" + seq(7),
+        "empty_lines_and_empty_contigs": b">a\n\n" + seq(10) + b"\n\n\n>empty\n>b=3\n" + seq(3) + b"\n\n",
+        "header_with_gt": b">a > b\n" + seq(40) + b"\n>x:y\tz\n" + seq(1) + b"\n" + seq(1) + b"\n",
+        "many": b"".join(b">s%d|v\n" % i + b"".join(seq(int(rng.integers(1, 90))) + (b"\r\n" if i % 3 == 0 else b"\n") for _ in range(int(rng.integers(0, 40)))) for i in range(60)),
+        "lone_cr_line": b">a\n" + seq(10) + b"\n\r\n" + seq(4) + b"\n",
+    }
+    bad = {"digit": b">a\nACGT\nAC1T\n", "space": b">a\nAC GT\n", "cr_inside": b">a\nAC\rGT\n", "gt_in_sequence": b">a\nACGT\nAC>GT\n"}
+    for name, data in files.items():
+        fn = str(tmp_path / (name + ".fa")); open(fn, "wb").write(data)
+        want = _reference_loader(fn)
+        err = C.create_string_buffer(256)
+        n = lib.gsah_c_load_query(fn.encode(), err)
+        assert n == len(want), (name, n, err.value)
+        for i, (nm, sq) in enumerate(want):
+            assert lib.gsah_c_query_name(i) == nm, (name, i)
+            ln = lib.gsah_c_query_len(i)
+            assert ln == len(sq) and C.string_at(lib.gsah_c_query_seq(i), ln) == sq, (name, i)
+    for name, data in bad.items():
+        fn = str(tmp_path / (name + ".fa")); open(fn, "wb").write(data)
+        assert _reference_loader(fn) is None
+        err = C.create_string_buffer(256)
+        assert lib.gsah_c_load_query(fn.encode(), err) == -1 and b"non-alphabet" in err.value, name

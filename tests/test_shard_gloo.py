@@ -93,6 +93,8 @@ for ci in assign[rank]:
         stage.put(7, ci, [(B.ctypes.data, B.nbytes), (R.ctypes.data, R.nbytes), (a1.ctypes.data, a1.nbytes), (a2.ctypes.data, a2.nbytes)])
 got, _ = shard.gather_staged(stage.take(7), max(len(x) for x in assign), device=torch.device("cpu"))
 if rank == 0:
+    ids = [shard.parse_staged(b, capi.BLOCK_DT, capi.REC_DT)[0] for b in got]
+    assert ids == sorted(ids), ids                      # (the documented contract: the other ranks' contigs in contig order)
     seen = dict(shard.parse_staged(b, capi.BLOCK_DT, capi.REC_DT) for b in got)
     assert sorted(seen) == sorted(ci for r in range(1, world) for ci in assign[r])
     for ci, r in seen.items():
