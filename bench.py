@@ -66,6 +66,10 @@ WORKLOADS = {
     # to 10^5 copies at 1-15 % divergence over 25 % of the sequence, microsatellites, two Mb-long N runs, soft-masked blocks
     "adversarial": dict(lengths=[250_000_000], div=0.01, repeats="adversarial", params={}, n_query=2, inflight=4, steps=32,
                         label="adversarial repeats (not a BASELINE config): 250 Mb reference, 25 % in eight repeat families up to 10^5 copies at 1-15 % divergence, microsatellites, N runs, soft-masked blocks, vs 1 %-diverged query"),
+    # not a BASELINE config either: the interspersed-repeat spectrum of a primate genome over ~45 % of the sequence (Alu-like family in three age classes,
+    # truncated L1-like copies, LTR-like families, ancient repeats, segmental duplications, microsatellites) -- the headline workload's realistic sibling
+    "human_like": dict(lengths=[250_000_000], div=0.01, repeats="human_like", params={}, n_query=2, inflight=4, steps=32,
+                       label="human-like repeats (not a BASELINE config): 250 Mb reference with a primate-like interspersed-repeat spectrum over ~45 % of the sequence (Alu-, L1-, LTR-like families by age class, ancient repeats, segmental duplications, microsatellites, N runs, soft-masked blocks), vs 1 %-diverged query"),
 }
 
 
@@ -94,6 +98,8 @@ def build_reference(tmp, name, wl, rank, world, args):
             r = synth.fast_genome(int(ln), 11000 + i)
             if wl["repeats"] == "adversarial":
                 synth.inject_adversarial(r, 11000 + i)
+            elif wl["repeats"] == "human_like":
+                synth.inject_human_like(r, 11000 + i)
             elif wl["repeats"]:
                 synth.inject_repeats(r, 11000 + i)
             refs.append((f"chr{i + 1}", r))
@@ -463,6 +469,47 @@ def cpu_baseline(px, qry, tmp, budget_bp, params=None, parity_gpu=None):
                       f"host has {cores} logical cores"}
 
 
+def end_to_end(px, genome, params, inflight, tmp, tag):
+    """The PRODUCT end to end on this workload ("End-to-end wall time is reported beside it"; the reference prints its own at
+    GSAlign.cpp:550): `GSAlign_hip -i <index> -q <query genome 0 as FASTA> -o <prefix> -ctx N -timing` in a process of its own -- index files
+    from disk, FASTA parse, gsa_create, the hot path, MAF and VCF written to disk -- and where its wall time went (the CLI's own clock)."""
+    from gsalign_amd import hostlib, synth
+    qfa = os.path.join(tmp, f"e2e_{tag}_q.fa"); outp = os.path.join(tmp, f"e2e_{tag}_out")
+    synth.write_fasta(qfa, [(f"q{i + 1}", c) for i, c in enumerate(genome)])
+    cmd = [hostlib.CLI_PATH, "-i", px, "-q", qfa, "-o", outp, "-ctx", str(inflight), "-timing"]
+    for k, v in (params or {}).items():
+        if k == "sen":
+            if v:
+                cmd.append("-sen")
+        elif k == "one":
+            if v:
+                cmd.append("-one")
+        elif k == "clr" and (params or {}).get("sen"):
+            continue                     # (-sen sets -clr 50 itself)
+        else:
+            cmd += ["-" + k, str(v)]
+    t = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+    wall = time.time() - t
+    line = [ln for ln in r.stderr.splitlines() if ln.startswith("GSA_TIMING ")]
+    out = {"command": " ".join(["GSAlign_hip"] + cmd[1:]), "rc": r.returncode, "wall_s": wall}
+    if r.returncode == 0 and line:
+        d = json.loads(line[-1][len("GSA_TIMING "):])
+        out.update(d)
+        out["note"] = ("wall time of the whole program incl. process start; index_load = .bwt/.sa/.pac from disk (page cache) + unpacking, gsa_create = index upload + device-side tables, "
+                       "query_load runs beside both; align_many = the hot path with the contigs read from pageable host memory; MAF / variants are formatted while later contigs align, "
+                       "output_drain_after_align = what of that was left when the last contig was aligned; vcf = sort + format + write; gbp_per_s_excl_index_build = query bases / total")
+    else:
+        out["stderr_tail"] = r.stderr[-600:]
+    for ext in (".maf", ".vcf", ".aln"):
+        try:
+            os.remove(outp + ext)
+        except OSError:
+            pass
+    os.remove(qfa)
+    return out
+
+
 def dry_main(args):
     """--dry: the launcher, the rank plumbing, the LPT contig shard and the staged result gather of the multi-GPU path on CPU (gloo) with a
     stub in place of the aligner -- what tests/test_bench_launcher.py runs at world size 2.  Prints the same JSON shape; no performance claim."""
@@ -535,7 +582,7 @@ def main():
     ap.add_argument("--genome", type=int, default=0, help="override the reference length of a one-contig workload")
     ap.add_argument("--divergence", type=float, default=-1.0)
     ap.add_argument("--inflight", type=int, default=0, help="contexts (host threads) per GPU working on different contigs (0 = the workload's own)")
-    ap.add_argument("--extra", default="human,ecoli,yeast,adversarial", help="further workloads measured in the same run (a process each, loops of their own); '' = none")
+    ap.add_argument("--extra", default="human,ecoli,yeast,adversarial,human_like", help="further workloads measured in the same run (a process each, loops of their own); '' = none")
     ap.add_argument("--hwq", type=int, default=16, help="GPU_MAX_HW_QUEUES for this process (0 = leave the runtime's default of 4; the contexts in flight have 5 streams each)")
     ap.add_argument("--split", action="store_true", help="N > 1 only: ONE contig per step, its seed search sharded by chunk range over the ranks (BASELINE configs[3])")
     ap.add_argument("--no-torch", action="store_true", help="experiment (N = 1): keep torch out of the process, so that the library runs on the system's HIP runtime")
@@ -543,6 +590,7 @@ def main():
     ap.add_argument("--same-gpu", action="store_true", help="plumbing check on a one-GPU box: every rank uses GPU 0 (with --backend gloo)")
     ap.add_argument("--dry", action="store_true", help="no GPU: stub aligner + gloo, checks the launcher and the rank plumbing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the `end_to_end` leg (the GSAlign_hip program on query genome 0 of this workload: FASTA + index from disk -> MAF + VCF)")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the `resident` / `no_prefetch` / `bundled` legs (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="bases of one query contig the CPU baseline is timed on")
     ap.add_argument("--fasta-ref", default="", help="real genomes on this host: reference FASTA (the index is built next to the bench's scratch files) ...")
@@ -650,18 +698,23 @@ def main():
         extras = []
         for xn in [x for x in args.extra.split(",") if x and x != name and world == 1 and not args.fasta_ref]:
             st = WORKLOADS[xn]["steps"]
-            cmd = [sys.executable, os.path.abspath(__file__), "--workload", xn, "--extra", "", "--no-cpu-baseline", "--hwq", str(args.hwq)]
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", xn, "--extra", "", "--no-cpu-baseline", "--hwq", str(args.hwq)] + ([] if xn == "human" and not args.no_e2e else ["--no-e2e"])
             if args.no_torch:
                 cmd.append("--no-torch")
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GSA_BENCH_TMP=tmp, GSA_BENCH_KEEP="1"))
                 d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
                 e = {"workload": xn, "steps": st, "unit": "Gbp/s"}
-                e.update({k: d[k] for k in ("value", "ms_per_step", "resident", "h2d_inclusive_over_resident", "no_prefetch", "bundled", "one_contig_latency", "config", "roofline", "kernels", "stage_ms_one_context_alone", "counters_per_step") if k in d})
+                e.update({k: d[k] for k in ("value", "ms_per_step", "resident", "h2d_inclusive_over_resident", "no_prefetch", "bundled", "one_contig_latency", "config", "roofline", "kernels", "stage_ms_one_context_alone", "counters_per_step", "end_to_end") if k in d})
                 extras.append(e)
             except Exception as ex:      # noqa: BLE001
                 extras.append({"workload": xn, "value": None, "error": repr(ex)[:300]})
         out["extra_workloads"] = extras
+        if world == 1 and not args.no_e2e and not args.fasta_ref and name in ("human_full", "human", "yeast", "ecoli"):
+            try:
+                out["end_to_end"] = end_to_end(m["px"], m["genomes"][0], wl["params"], m["inflight"], tmp, name)
+            except Exception as e:      # noqa: BLE001
+                out["end_to_end"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:
             try:
                 q0 = max(m["genomes"][0], key=lambda c: c.size)

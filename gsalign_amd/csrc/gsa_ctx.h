@@ -80,7 +80,7 @@ struct Options {
 	int pd_bitmap = 1;                 // 0: groups by the PosDiff sort although MaxIndelSize <= 31 would allow the bitmap scan
 	int sweep_shape = -1;              // k_dense_sweep's launch shape: -1 by the number of dense chunks, 0 = four chunks per two-wave workgroup / 160-start segments, 1 = one chunk per four-wave workgroup / 40-start segments
 	int dp_side = 0;                   // 1: the striped DP's lower size class on a stream of its own, beside the upper class (0: behind it)
-	int walk_coop = 0;                 // 1: the window walk's pointer-doubling rounds as one cooperative launch (measured slower, alone and under load); 0: a launch per round
+	int64_t walk_chain_min = 100000;   // contigs with more seeds than this walk their window chain in slices (k_walk_chain) instead of one workgroup's LDS (k_walk_windows); tests: 0
 	int kmer_k = 0;                    // gsa_create_opts (GSA_CREATE_KMER_K): length of the jump table's k-mers (0: by text length and free memory)
 };
 
@@ -161,8 +161,7 @@ struct gsa_ctx {
 	DevBuf d_flag, d_scan;                         // generic i32 flag / scan arrays (n+1)
 	i32 n_groups = 0;
 	bool pd_path = false, seed_view_ready = false, pdbm_dirty = true; i64 pd_words = 0;      // groups from the PosDiff bitmap (no PosDiff sort on the hot path)
-	DevBuf d_wbar; u32 wbar_cnt = 0, wbar_gen = 0;  // k_walkg_ladder's barrier words (arrivals, generation: never reset) and what the host knows they hold
-	DevBuf w_j0, w_j1, w_on;                      // window chain of large contigs: leave(), its double, orbit flags
+	DevBuf w_j0; u32 walk_ticket = 0, walk_epoch = 0;   // window chain of large contigs (k_walk_chain): ticket counter + one entry word per slice, never reset -- the host passes the counter's value and the launch epoch
 	DevBuf d_pdcb;                                 // coarse bitmap: one bit per block of 32 words of d_pdbm (the blocks that hold a hit)
 	DevBuf d_pdbm, d_gpre, d_key_c, d_val_c;      // bitmap of occupied PosDiff values, group starts below each word, (group, qPos, rank) keys
 	DevBuf g_beg;                                  // group start indices (n_groups+1)

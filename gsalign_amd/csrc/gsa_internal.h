@@ -4,6 +4,8 @@
 #define GSA_INTERNAL_H
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include "../../include/gsa_hip.h"
@@ -89,6 +91,13 @@ int gsa_fail(gsa_ctx *ctx, int code, const std::string &msg);
 int gsa_sort_pairs_u64_u32(gsa_ctx *, const u64 *kin, u64 *kout, const u32 *vin, u32 *vout, size_t n, int begin_bit, int end_bit);      // gsa_sort.hip: stable LSD radix sort, kin / vin untouched
 
 static inline int ceil_log2_u64(u64 v) { int b = 0; while ((1ull << b) < v && b < 63) b++; return b; }
-static inline unsigned grid_for(size_t n, unsigned block) { size_t g = (n + block - 1) / block; return (unsigned)(g ? g : 1); }
+// workgroups for n work-items.  A launch holds fewer than 2^32 work-items (the dispatch packet's grid size is a 32-bit count of work-items; the
+// runtime takes a larger one modulo 2^32 without a word -- round 5's presence-table bug): a caller with more elements than that strides.
+static inline unsigned grid_for(size_t n, unsigned block)
+{
+	size_t g = (n + block - 1) / block;
+	if (g * block >= ((size_t)1 << 32)) { fprintf(stderr, "libgsa_hip: internal error: launch of %zu work-items (>= 2^32)\n", g * block); abort(); }
+	return (unsigned)(g ? g : 1);
+}
 
 #endif

@@ -16,6 +16,7 @@
 #include <unistd.h>
 #include "gsa_host.h"
 #include "par.h"
+#include "exact_sort.h"
 
 namespace {
 
@@ -56,7 +57,7 @@ void block_text(const QueryContig &q, const ContigResult &r, const gsa_block &b,
 {
 	t1.clear(); t2.clear();
 	for (int k = 0; k < b.n_frag; k++) {
-		const gsa_frag &f = r.frags[b.frag_off + k];
+		const gsa_frag f = r.frag(b.frag_off + k);
 		if (f.bseed) { t1.append(q.seq, f.qpos, f.qlen); t2.append(q.seq, f.qpos, f.qlen); }     // seeds print the QUERY text on both lines (App. B #4)
 		else { t1.append(r.aln1, f.aln_off, f.aln_len); t2.append(r.aln2, f.aln_off, f.aln_len); }
 	}
@@ -73,28 +74,21 @@ int extension(const HostIndex &ix, const gsa_block &b, const gsa_frag &last)
 } // namespace
 
 // what a GPU worker thread does inside gsa_align_many's callback: the result is valid during the call only, so its bytes are copied -- and
-// nothing else; the FragPair_t-shaped view is made later, off that thread (expand)
-void ContigResult::assign_raw(const gsa_result &r)
+// nothing else.  The records stay in their 16-byte form: the emitters expand the one they look at (frag()), 70 M records of a human genome
+// are never materialised as 40-byte FragPair_t copies
+void ContigResult::assign(const gsa_result &r)
 {
 	blocks.assign(r.blocks, r.blocks + r.n_blocks);
-	recs.assign(r.recs, r.recs + r.n_frags); frags.clear();
+	recs.assign(r.recs, r.recs + r.n_frags);
 	aln1.assign(r.aln1, (size_t)r.n_aln); aln2.assign(r.aln2, (size_t)r.n_aln);
 }
 
-void ContigResult::expand()
+// iExtension's trim of a block's last record (tools.cpp:192-202): a seed's one length, or a gap's two
+void ContigResult::trim(int64_t i, int ext)
 {
-	if (!frags.empty() || recs.empty()) return;
-	frags.resize(recs.size());
-	// a gap record takes its position from the seed record in front of it (gsa_expand_frags): ranges may start anywhere, the expander
-	// only looks one record back
-	gsa_frag *F = frags.data(); const gsa_rec *R = recs.data();
-	par_ranges(recs.size(), (size_t)1 << 16, [&](size_t b, size_t e) {
-		for (size_t i = b; i < e; i++) gsa_rec_expand(R, (int64_t)i, F + i);      // (a gap record reads the seed record in front of it: any range start is fine)
-	});
-	std::vector<gsa_rec>().swap(recs);
+	gsa_rec &x = recs[(size_t)i];
+	if (x.seed.qpos >= 0) x.seed.len -= ext; else { x.gap.rlen -= ext; x.gap.nqlen += ext; }
 }
-
-void ContigResult::assign(const gsa_result &r) { assign_raw(r); expand(); }
 
 // LoadQueryFile (main.cpp:82-114) line by line -- getline on '\n', empty lines skipped, a line that starts with '>' opens a sequence
 // (TrimChromosomeName), every other line loses ONE trailing '\r', must be all isalpha (CheckQuerySeq) and is appended -- but on the whole
@@ -211,14 +205,16 @@ bool gsah_load_query(const std::string &path, std::vector<QueryContig> &out, std
 // independent) and the NUL quirk (an unknown byte maps to '\0' and "%s" stops there) are the serial code's.
 void Emitter::maf_block(const QueryContig &q, ContigResult &r, gsa_block &b, OutBuf &small, const std::function<void(OutBuf &&)> &sink, const std::function<OutBuf(size_t)> &take) const
 {
-	gsa_frag *F = r.frags.data() + b.frag_off;
+	const int64_t f0 = b.frag_off;
 	const size_t nf = (size_t)b.n_frag;
 	std::vector<size_t> off(nf + 1); off[0] = 0;
-	for (size_t k = 0; k < nf; k++) off[k + 1] = off[k] + (size_t)(F[k].bseed ? F[k].qlen : F[k].aln_len);
+	auto piece = [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; k++) { const gsa_frag f = r.frag(f0 + (int64_t)k); off[k + 1] = (size_t)(f.bseed ? f.qlen : f.aln_len); } };
+	if (nf * 16 >= par_min_bytes()) par_ranges(nf, (size_t)1 << 16, piece); else piece(0, nf);
+	for (size_t k = 0; k < nf; k++) off[k + 1] += off[k];
 	const size_t total = off[nf];
-	gsa_frag &last = F[nf - 1];
+	gsa_frag last = r.frag(f0 + (int64_t)nf - 1);
 	const int ext = extension(*idx, b, last);
-	if (ext > 0) { b.aln_len -= ext; b.score -= ext; last.rlen -= ext; last.qlen -= ext; }
+	if (ext > 0) { b.aln_len -= ext; b.score -= ext; last.rlen -= ext; last.qlen -= ext; r.trim(f0 + (int64_t)nf - 1, ext); }
 	const size_t L = (size_t)(b.aln_len > 0 ? b.aln_len : 0);
 	const bool big = 2 * L >= par_min_bytes();
 	OutBuf t1 = big ? take(L + 1) : OutBuf(L + 1), t2 = big ? take(L + 1) : OutBuf(L + 1);
@@ -227,8 +223,10 @@ void Emitter::maf_block(const QueryContig &q, ContigResult &r, gsa_block &b, Out
 		size_t k = (size_t)(std::upper_bound(off.begin(), off.end(), pb) - off.begin()) - 1;
 		for (size_t p = pb; p < pe; k++) {
 			const size_t o = p - off[k], n = std::min(off[k + 1], pe) - p;
-			if (F[k].bseed) { memcpy(t1.p + p, q.seq.data() + F[k].qpos + o, n); memcpy(t2.p + p, q.seq.data() + F[k].qpos + o, n); }
-			else { memcpy(t1.p + p, r.aln1.data() + F[k].aln_off + o, n); memcpy(t2.p + p, r.aln2.data() + F[k].aln_off + o, n); }
+			if (n == 0) continue;
+			const gsa_frag f = r.frag(f0 + (int64_t)k);
+			if (f.bseed) { memcpy(t1.p + p, q.seq.data() + f.qpos + o, n); memcpy(t2.p + p, q.seq.data() + f.qpos + o, n); }
+			else { memcpy(t1.p + p, r.aln1.data() + f.aln_off + o, n); memcpy(t2.p + p, r.aln2.data() + f.aln_off + o, n); }
 			p += n;
 		}
 	};
@@ -260,7 +258,7 @@ void Emitter::maf_block(const QueryContig &q, ContigResult &r, gsa_block &b, Out
 	int l1, l2;
 	if (b.bdir) {
 		l1 = snprintf(h1.data(), h1.size(), "a score=%d\ns ref.%s %d %d + %d ", b.bdup ? 1 : b.score, rname.c_str(), b.gpos - 1, b.aln_len - (int)g1.load(), clen);
-		l2 = snprintf(h2.data(), h2.size(), "\ns qry.%s %d %d + %d ", qname.c_str(), F[0].qpos, b.aln_len - (int)g2.load(), qlen);
+		l2 = snprintf(h2.data(), h2.size(), "\ns qry.%s %d %d + %d ", qname.c_str(), r.frag(f0).qpos, b.aln_len - (int)g2.load(), qlen);
 	} else {
 		const int64_t rpos = last.rpos + last.rlen - 1;
 		int d, c, g; idx->coordinate(rpos, &d, &c, &g);
@@ -283,7 +281,6 @@ void Emitter::maf_block(const QueryContig &q, ContigResult &r, gsa_block &b, Out
 
 void Emitter::maf_text(bool first, const QueryContig &q, ContigResult &r, const std::function<void(OutBuf &&)> &sink, const std::function<OutBuf(size_t)> &take) const
 {
-	r.expand();
 	OutBuf small;
 	if (first) small.append("##maf version=1\n", 16);
 	for (size_t bi = 0; bi < r.blocks.size(); bi++) {
@@ -307,13 +304,13 @@ void Emitter::aln(FILE *fp, const QueryContig &q, ContigResult &r) const
 		if (!allow_dup && b.bdup) continue;
 		block_text(q, r, b, t1, t2);
 		const unsigned full = (unsigned)t1.size();
-		gsa_frag &last = r.frags[b.frag_off + b.n_frag - 1];
+		const gsa_frag last = r.frag(b.frag_off + b.n_frag - 1);
 		const int ext = extension(*idx, b, last);
-		if (ext > 0) { b.aln_len -= ext; b.score -= ext; last.rlen -= ext; last.qlen -= ext; t1[b.aln_len] = t2[b.aln_len] = '\0'; }
+		if (ext > 0) { b.aln_len -= ext; b.score -= ext; r.trim(b.frag_off + b.n_frag - 1, ext); t1[b.aln_len] = t2[b.aln_len] = '\0'; }
 		std::string rname = idx->chr_name[b.chr], qname = q.name;
 		if (qname.size() > rname.size()) rname.append(qname.size() - rname.size(), ' '); else qname.append(rname.size() - qname.size(), ' ');
 		fprintf(fp, "#Identity = %d / %d (%.2f%%) Orientation = %s\n\n", b.score, b.aln_len, (int)(1000 * (1.0 * b.score / b.aln_len)) / 10.0, b.bdir ? "Forward" : "Reverse");
-		unsigned pos = 0; int qp = r.frags[b.frag_off].qpos + 1; long long rp = b.gpos;
+		unsigned pos = 0; int qp = r.frag(b.frag_off).qpos + 1; long long rp = b.gpos;
 		while (pos < full) {                                         // the reference loops over the UNtrimmed length (tools.cpp:275)
 			const unsigned stop = pos + 80 > full ? full : pos + 80;
 			const int p = 80 - count_gaps(t1, pos, stop), qn = 80 - count_gaps(t2, pos, stop);
@@ -354,7 +351,7 @@ bool Emitter::dotplot(const std::string &gp_path, const std::string &out_prefix,
 	}
 	for (const gsa_block &b : r.blocks) {
 		if (b.score <= 0 || !fh[(size_t)b.chr]) continue;
-		const gsa_frag &first = r.frags[b.frag_off], &last = r.frags[b.frag_off + b.n_frag - 1];
+		const gsa_frag first = r.frag(b.frag_off), last = r.frag(b.frag_off + b.n_frag - 1);
 		int d, c, g0, g1;
 		idx->coordinate(first.rpos, &d, &c, &g0); idx->coordinate(last.rpos + last.rlen - 1, &d, &c, &g1);
 		fprintf(fh[(size_t)b.chr], "%d %d\n%d %d\n\n", first.qpos + 1, g0, last.qpos + last.qlen, g1);
@@ -367,29 +364,32 @@ bool Emitter::dotplot(const std::string &gp_path, const std::string &out_prefix,
 // VariantIdentification for the records [kb, ke) of one block (SeqVariant.cpp:27-117): a record's variants depend on that record only
 static void variants_of(const HostIndex *idx, int query_idx, const QueryContig &q, const ContigResult &r, const gsa_block &b, size_t kb, size_t ke, std::vector<Variant> &vars, int cnt[3])
 {
-	const std::string &ref = idx->ref;
+	// Every allele the reference copies into a Variant (SeqVariant.cpp: ref_frag / alt_frag) is a piece of RefSequence or of the query sequence --
+	// also the single columns it takes from the gapped strings, which hold exactly those bytes -- so a Variant points there instead of owning
+	// two std::strings: 30 M variants of a human genome are 40 bytes each, written once.
+	const char *ref = idx->ref.data(), *qs = q.seq.data();
 	Variant v; v.chr_idx = b.chr; v.query_idx = query_idx;
 	int d, c, g;
 	for (size_t k = kb; k < ke; k++) {
-		const gsa_frag &f = r.frags[b.frag_off + k];
+		const gsa_frag f = r.frag(b.frag_off + (int64_t)k);
 		if (f.bseed) continue;
 		if (f.qlen == 0 && f.rlen == 0) continue;
 		if (f.qlen == 0) {                                        // pure deletion (:36-45)
 			cnt[2]++;
 			v.type = 2; idx->coordinate(f.rpos - 1, &d, &c, &g); v.pos = g;
-			v.ref_frag = ref.substr(f.rpos - 1, f.rlen + 1); v.alt_frag.assign(1, q.seq[f.qpos - 1]);
+			v.ref_p = ref + f.rpos - 1; v.ref_n = (uint32_t)f.rlen + 1; v.alt_p = qs + f.qpos - 1; v.alt_n = 1;
 			vars.push_back(v);
 		} else if (f.rlen == 0) {                                 // pure insertion (:46-55)
 			cnt[1]++;
 			v.type = 1; idx->coordinate(f.rpos - 1, &d, &c, &g); v.pos = g;
-			v.ref_frag.assign(1, ref[f.rpos - 1]); v.alt_frag = q.seq.substr(f.qpos - 1, f.qlen + 1);
+			v.ref_p = ref + f.rpos - 1; v.ref_n = 1; v.alt_p = qs + f.qpos - 1; v.alt_n = (uint32_t)f.qlen + 1;
 			vars.push_back(v);
 		} else if (f.qlen == 1 && f.rlen == 1) {                  // 1x1 (:56-67)
 			const char a1 = r.aln1[f.aln_off], a2 = r.aln2[f.aln_off];
 			if (nt4(a1) != nt4(a2) && nt4(a2) != 4) {
 				cnt[0]++;
 				v.type = 0; idx->coordinate(f.rpos, &d, &c, &g); v.pos = g;
-				v.ref_frag.assign(1, a1); v.alt_frag.assign(1, a2);
+				v.ref_p = ref + f.rpos; v.ref_n = 1; v.alt_p = qs + f.qpos; v.alt_n = 1;      // (the column a1 / a2 = these two bytes)
 				vars.push_back(v);
 			}
 		} else {                                                  // walk the aligned columns (:68-115)
@@ -399,24 +399,22 @@ static void variants_of(const HostIndex *idx, int query_idx, const QueryContig &
 				if (x1[i] == '-') {
 					cnt[1]++;
 					int n = 1; while (i + n < L && x1[i + n] == '-') n++;
-					const std::string fr = q.seq.substr(qp - 1, n + 1);
 					v.type = 1; idx->coordinate(rp - 1, &d, &c, &g); v.pos = g;
-					v.ref_frag.assign(1, fr[0]); v.alt_frag = fr;           // REF anchor comes from the QUERY (App. B #15)
+					v.ref_p = qs + qp - 1; v.ref_n = 1; v.alt_p = qs + qp - 1; v.alt_n = (uint32_t)n + 1;           // REF anchor comes from the QUERY (App. B #15)
 					vars.push_back(v);
 					qp += n; i += n - 1;
 				} else if (x2[i] == '-') {
 					cnt[2]++;
 					int n = 1; while (i + n < L && x2[i + n] == '-') n++;
-					const std::string fr = ref.substr(rp - 1, n + 1);
 					v.type = 2; idx->coordinate(rp - 1, &d, &c, &g); v.pos = g;
-					v.ref_frag = fr; v.alt_frag.assign(1, fr[0]);
+					v.ref_p = ref + rp - 1; v.ref_n = (uint32_t)n + 1; v.alt_p = ref + rp - 1; v.alt_n = 1;
 					vars.push_back(v);
 					rp += n; i += n - 1;
 				} else if (nt4(x1[i]) != nt4(x2[i])) {
 					if (nt4(x2[i]) != 4) {
 						cnt[0]++;
 						v.type = 0; idx->coordinate(rp, &d, &c, &g); v.pos = g;
-						v.ref_frag.assign(1, x1[i]); v.alt_frag.assign(1, x2[i]);
+						v.ref_p = ref + rp; v.ref_n = 1; v.alt_p = qs + qp; v.alt_n = 1;      // (the literal column characters = these two bytes)
 						vars.push_back(v);
 					}
 					rp++; qp++;
@@ -430,7 +428,6 @@ static void variants_of(const HostIndex *idx, int query_idx, const QueryContig &
 // and the ranges' lists are kept IN THAT ORDER (var_chunks): the sequence the final sort sees is the serial one.
 void Emitter::variants(int query_idx, const QueryContig &q, ContigResult &r)
 {
-	r.expand();
 	for (size_t bi = 0; bi < r.blocks.size(); bi++) {
 		const gsa_block &b = r.blocks[bi];
 		if (b.bdup) continue;
@@ -468,7 +465,9 @@ inline char *put_int(char *p, long long v)
 // variants that share a position is whatever libstdc++'s introsort leaves (App. B #17).  What introsort does depends on the comparator's
 // answers only, never on what else an element carries, so sorting 16-byte keys {chr, pos, where the variant lies} with the same comparator
 // on the same initial sequence makes the same comparisons and the same moves: the permutation is the reference's, without dragging two
-// std::strings per element through every swap.  The lines are then formatted by the pool in ranges and written in order.
+// std::strings per element through every swap; and introsort's partition steps split the array into parts that never meet again, so they run
+// on the pool's threads (exact_sort.h: std::sort's permutation, element for element).  The lines are then formatted by the pool in ranges and
+// written in order.
 void Emitter::vcf_text(const std::string &reference_label, const std::function<void(OutBuf &&)> &sink)
 {
 	static const char *MutType[3] = { "SUBSTITUTE", "INSERT", "DELETE" };
@@ -483,7 +482,7 @@ void Emitter::vcf_text(const std::string &reference_label, const std::function<v
 		const std::vector<Variant> &vc = var_chunks[c]; Key *k = keys.data() + base[c];
 		for (size_t i = 0; i < vc.size(); i++) { k[i].chr = vc[i].chr_idx; k[i].pos = vc[i].pos; k[i].chunk = (uint32_t)c; k[i].at = (uint32_t)i; }
 	});
-	std::sort(keys.begin(), keys.end(), ByPos());                    // same std::sort, same incomplete key, same initial order
+	exact_sort(keys.data(), keys.data() + keys.size(), ByPos());      // std::sort's permutation (same incomplete key, same initial order), on the pool: exact_sort.h
 	{
 		OutBuf h;
 		h.append("##fileformat=VCFv4.1\n"); h.append("##reference=" + reference_label + "\n"); h.append("##source=GSAlign 1.0.22\n");
@@ -505,15 +504,14 @@ void Emitter::vcf_text(const std::string &reference_label, const std::function<v
 				const Variant &v = var_chunks[keys[i].chunk][keys[i].at];
 				const std::string &cn = idx->chr_name[(size_t)v.chr_idx];
 				const char *mt = MutType[v.type]; const size_t ml = strlen(mt);
-				// "%s" of a std::string's c_str(): up to its first NUL (a fragment never holds one, kept for the letter)
-				const size_t rl = strnlen(v.ref_frag.c_str(), v.ref_frag.size()), al = strnlen(v.alt_frag.c_str(), v.alt_frag.size());
+				const size_t rl = v.ref_n, al = v.alt_n;      // (RefSequence and a validated query hold no NUL: "%s" prints the whole fragment)
 				const size_t need = cn.size() + rl + al + ml + 48;
 				if (o.n + need > o.cap) o.reserve((o.n + need) * 2);
 				char *w = o.p + o.n;
 				memcpy(w, cn.data(), cn.size()); w += cn.size(); *w++ = '\t';
 				w = put_int(w, v.pos); memcpy(w, "\t.\t", 3); w += 3;
-				memcpy(w, v.ref_frag.data(), rl); w += rl; *w++ = '\t';
-				memcpy(w, v.alt_frag.data(), al); w += al;
+				memcpy(w, v.ref_p, rl); w += rl; *w++ = '\t';
+				memcpy(w, v.alt_p, al); w += al;
 				memcpy(w, "\t100\t*\tTYPE=", 12); w += 12;
 				memcpy(w, mt, ml); w += ml; *w++ = '\n';
 				o.n = (size_t)(w - o.p);

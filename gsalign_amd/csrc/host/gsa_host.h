@@ -7,21 +7,35 @@
 #define GSA_HOST_H
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <functional>
 #include <string>
 #include <vector>
 #include "gsa_hip.h"
 
+// A buffer that is NOT zero-filled when it is sized: the index arrays of a 3.08 Gbp reference are 11 GB that the loader overwrites anyway
+// (std::vector / std::string would first clear them on one thread, ~1 s; the loader's threads then fault the pages in themselves).
+template <class T> struct RawBuf {
+	T *p = nullptr; size_t n = 0;
+	RawBuf() {}
+	RawBuf(const RawBuf &) = delete; RawBuf &operator=(const RawBuf &) = delete;
+	~RawBuf() { free(p); }
+	void resize(size_t m) { free(p); p = m ? (T *)malloc(m * sizeof(T)) : nullptr; n = p ? m : 0; }
+	T *data() { return p; } const T *data() const { return p; }
+	size_t size() const { return n; }
+	T &operator[](size_t i) { return p[i]; } const T &operator[](size_t i) const { return p[i]; }
+};
+
 struct HostIndex {
 	uint64_t primary = 0, L2[5] = {0, 0, 0, 0, 0};
-	std::vector<uint32_t> bwt;
-	std::vector<uint64_t> sa;
+	RawBuf<uint32_t> bwt;
+	RawBuf<uint64_t> sa;
 	int64_t G = 0;
 	std::vector<std::string> chr_name;
 	std::vector<int32_t> chr_len;
 	std::vector<int64_t> chr_fwd, chr_rev;        // FowardLocation / ReverseLocation (bwt_index.cpp:247-248)
 	std::vector<int64_t> end_key; std::vector<int32_t> end_chr;   // ChrLocMap as sorted arrays
-	std::string ref;                              // RefSequence: 2G ASCII
+	RawBuf<char> ref;                             // RefSequence: 2G ASCII
 
 	void fill_view(gsa_index_view *v) const;
 	// GenCoordinateInfo (tools.cpp:120-140)
@@ -41,15 +55,16 @@ bool gsah_load_query(const std::string &path, std::vector<QueryContig> &out, std
 // one finished contig, as delivered by gsa_align_contig
 struct ContigResult {
 	std::vector<gsa_block> blocks;
-	std::vector<gsa_rec> recs;             // the 16-byte records as they arrived (assign_raw), until expand() turns them into ...
-	std::vector<gsa_frag> frags;           // ... the FragPair_t-shaped records the emitters read
+	std::vector<gsa_rec> recs;             // the 16-byte records as they arrived; frag(i) is record i as a FragPair_t
 	std::string aln1, aln2;
-	void assign_raw(const gsa_result &r);  // the copies only: what a GPU worker thread does inside the result callback
-	void expand();                         // recs -> frags (on the pool); a no-op the second time
-	void assign(const gsa_result &r);      // both
+	void assign(const gsa_result &r);      // the copies only: what a GPU worker thread does inside the result callback
+	gsa_frag frag(int64_t i) const { gsa_frag f; gsa_rec_expand(recs.data(), i, &f); return f; }
+	void trim(int64_t i, int ext);         // iExtension (tools.cpp:192-202): record i loses its last `ext` bases
 };
 
-struct Variant { int pos, chr_idx, query_idx, type; std::string ref_frag, alt_frag; };   // structure.h:124-132
+// Variant_t (structure.h:124-132); the two alleles are pieces of RefSequence / of the query sequence and are pointed at, not copied:
+// both outlive the Emitter's list (the index and the query contigs are loaded once per run)
+struct Variant { int pos, chr_idx, query_idx, type; const char *ref_p, *alt_p; uint32_t ref_n, alt_n; };
 
 struct OutBuf;                             // par.h
 

@@ -1,8 +1,10 @@
 // gsalign_amd/csrc/host/host_api.cpp -- C entry points of libgsa_host.so, so that
 // the CPU test-suite can drive the host-side components (index builder, loader,
 // emitters) without a GPU.  The CLI uses the C++ interface directly.
+#include <algorithm>
 #include <cstring>
 #include "gsa_host.h"
+#include "exact_sort.h"
 
 extern "C" {
 
@@ -19,6 +21,40 @@ int gsah_c_load_query(const char *path, char *err)
 const char *gsah_c_query_name(int i) { return g_query[(size_t)i].name.c_str(); }
 long long gsah_c_query_len(int i) { return (long long)g_query[(size_t)i].seq.size(); }
 const char *gsah_c_query_seq(int i) { return g_query[(size_t)i].seq.data(); }
+
+// exact_sort (exact_sort.h) against std::sort itself on n keys {a, b, original index} compared on (a, b) only -- the VCF sort's shape.
+// pattern 0: random with `distinct` values per field (ties), 1: ascending, 2: descending, 3: all equal, 4: organ pipe, 5: a few long runs, 6: the
+// median-of-three killer (quicksort's depth budget runs out: the heapsort fallback).  Returns 0 when every element sits where std::sort put it.
+int gsah_c_exact_sort_check(long long n, int distinct, unsigned seed, int pattern, long long grain)
+{
+	struct Key { int32_t a, b; uint32_t idx, pad; };
+	struct ByAB { bool operator()(const Key &x, const Key &y) const { return x.a == y.a ? x.b < y.b : x.a < y.a; } };
+	std::vector<Key> v((size_t)n);
+	unsigned long long st = seed * 2654435761ull + 88172645463325252ull;
+	auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+	for (long long i = 0; i < n; i++) {
+		Key k; k.idx = (uint32_t)i; k.pad = 0;
+		switch (pattern) {
+		case 1: k.a = 0; k.b = (int32_t)(i / 3); break;
+		case 2: k.a = 0; k.b = (int32_t)((n - i) / 3); break;
+		case 3: k.a = 7; k.b = 7; break;
+		case 4: k.a = 0; k.b = (int32_t)(i < n / 2 ? i : n - i); break;
+		case 5: k.a = (int32_t)(i * 5 / (n > 0 ? n : 1)); k.b = (int32_t)(rnd() % 3); break;
+		default: k.a = (int32_t)(rnd() % (unsigned)(distinct < 1 ? 1 : distinct)) / 97; k.b = (int32_t)(rnd() % (unsigned)(distinct < 1 ? 1 : distinct)); break;
+		}
+		v[(size_t)i] = k;
+	}
+	if (pattern == 6 && n >= 4) {      // Musser's median-of-three killer on b
+		const long long k2 = n / 2;
+		for (long long i = 0; i < k2; i++) { v[(size_t)i].a = 0; v[(size_t)i].b = (i % 2 == 0) ? (int32_t)(i + 1) : (int32_t)(k2 + i + (k2 % 2 ? 0 : 1)); }
+		for (long long i = k2; i < n; i++) { v[(size_t)i].a = 0; v[(size_t)i].b = (int32_t)((i - k2 + 1) * 2); }
+	}
+	std::vector<Key> w(v);
+	std::sort(v.begin(), v.end(), ByAB());
+	exact_sort(w.data(), w.data() + w.size(), ByAB(), grain > 0 ? (size_t)grain : (size_t)1 << 16);
+	for (size_t i = 0; i < v.size(); i++) if (v[i].idx != w[i].idx) return 1;
+	return 0;
+}
 
 // returns 0 on success; err (>= 256 bytes) receives the message otherwise
 int gsah_c_build_index(const char *fasta, const char *prefix, char *err)

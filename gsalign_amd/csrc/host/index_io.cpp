@@ -341,9 +341,10 @@ bool gsah_load_index(const std::string &prefix, HostIndex &idx, std::string &err
 	}
 	// RestoreReferenceInfo (bwt_index.cpp:229-264): forward strand, then its reverse complement
 	idx.ref.resize((size_t)(2 * idx.G));
+	if (!idx.bwt.data() || !idx.sa.data() || !idx.ref.data()) { err = "out of memory"; return false; }
 	const int64_t G2 = 2 * idx.G;
 	{
-		char *ref = &idx.ref[0]; const uint8_t *pac = raw.data();
+		char *ref = idx.ref.data(); const uint8_t *pac = raw.data();
 		par_ranges((size_t)((idx.G + 3) / 4), (size_t)1 << 20, [&](size_t b4, size_t e4) {
 			const int64_t fe = std::min<int64_t>((int64_t)e4 * 4, idx.G);
 			for (int64_t f = (int64_t)b4 * 4; f < fe; f++) {

@@ -150,6 +150,75 @@ int64_t gsah_c_synth_adversarial(char *seq, int64_t n, uint64_t seed, double fra
 	return total;
 }
 
+// Human-like injection, in place ("a realistic sibling" of the i.i.d. headline workload): the interspersed-repeat spectrum of a
+// primate genome, ~45 % of the sequence, instead of the adversarial spectrum's few very young families:
+//   * an Alu-like family (300 bp), 10 % of the sequence, three age classes sharing one consensus: 15 % of the copies 3 % diverged from it, 50 % 8 %, 35 % 14 %;
+//   * an L1-like family (6 kb consensus), 17 %: copies are 5'-truncated (length 6 kb x u^2, at least 100 bp, taken from the 3' end), 3 - 20 % diverged;
+//   * two LTR/ERV-like families (5 kb and 7 kb; four copies in five are solo LTRs: the first 500 bp), 8 %, 5 - 15 %;
+//   * three ancient families (MIR / L2 / DNA-transposon-like, 200-bp pieces, 25 - 30 % diverged: unique at seed level), 5 %;
+//   * segmental duplications: 20-kb blocks copied from elsewhere in the sequence at 1 - 3 % divergence, 3 %;
+//   * microsatellites (unit 1 - 6 bp, 20 - 300 bp), 2 %; soft-masked blocks and two N runs as in the adversarial injection.
+// Copy numbers follow from the fractions and the sequence length (a 250 Mb sequence: 83 000 Alu-like copies, 3 Gbp: a million).  Returns the number of copies written.
+int64_t gsah_c_synth_human_like(char *seq, int64_t n, uint64_t seed, double scale, int64_t n_run)
+{
+	if (n < 200000) return 0;
+	int64_t total = 0;
+	struct Fam { int len; double frac; int trunc; int solo; double d_lo, d_hi; };      // trunc: 5'-truncated copies; solo: length of the solo-LTR form
+	static const Fam fams[7] = {
+		{ 300, 0.10, 0, 0, 0.03, 0.14 }, { 6000, 0.17, 1, 0, 0.03, 0.20 }, { 5000, 0.04, 0, 500, 0.05, 0.15 }, { 7000, 0.04, 0, 500, 0.05, 0.15 },
+		{ 200, 0.02, 0, 0, 0.25, 0.30 }, { 200, 0.02, 0, 0, 0.25, 0.30 }, { 200, 0.01, 0, 0, 0.25, 0.30 } };
+	for (int f = 0; f < 7; f++) {
+		const Fam &F = fams[f];
+		std::vector<char> fam((size_t)F.len), cp((size_t)F.len * 12 + 64);
+		gsah_c_synth_genome(F.len, seed ^ (0x48554D41ull + 7919ull * (uint64_t)f), fam.data());
+		const int64_t want = (int64_t)(F.frac * scale * (double)n);
+		int64_t have = 0;
+		for (int64_t c = 0; have < want; c++) {
+			const uint64_t r = rnd(seed, 400 + (uint64_t)f, (uint64_t)c);
+			int len = F.len, off = 0;
+			if (F.trunc) { const double u = (double)((r >> 8) & 0xffffff) / 16777216.0; len = (int)(F.len * u * u); if (len < 100) len = 100; off = F.len - len; }
+			else if (F.solo && (r & 7) < 6 && (r & 7) > 0) len = F.solo;
+			double d;
+			if (f == 0) { const unsigned a = (unsigned)((r >> 40) % 100); d = a < 15 ? 0.03 : (a < 65 ? 0.08 : 0.14); }
+			else d = F.d_lo + (F.d_hi - F.d_lo) * (double)((r >> 40) & 0xffff) / 65536.0;
+			int64_t got = mutate_into(fam.data() + off, len, d, seed + 131 * (uint64_t)f, 5000 + 2 * (uint64_t)c, cp.data(), (int64_t)cp.size());
+			if (got < 0) got = 0;
+			if (got > len) got = len;
+			for (; got < len; got++) cp[(size_t)got] = ACGT[rnd(seed, 17 + (uint64_t)f, (uint64_t)c * 8192 + (uint64_t)got) & 3];
+			const int64_t pos = (int64_t)(rnd(seed, 500 + (uint64_t)f, (uint64_t)c) % (uint64_t)(n - len));
+			memcpy(seq + pos, cp.data(), (size_t)len);
+			have += len; total++;
+		}
+	}
+	{                                                                        // segmental duplications: 20-kb blocks, 1 - 3 % diverged from their source
+		const int L = 20000; std::vector<char> cp((size_t)L * 2 + 64);
+		for (int64_t c = 0; c < (int64_t)(0.03 * scale * (double)n / L); c++) {
+			const uint64_t r = rnd(seed, 61, (uint64_t)c);
+			const int64_t src = (int64_t)(r % (uint64_t)(n - L)), dst = (int64_t)(rnd(seed, 62, (uint64_t)c) % (uint64_t)(n - L));
+			if (src < dst + L && dst < src + L) continue;
+			int64_t got = mutate_into(seq + src, L, 0.01 + 0.02 * (double)((r >> 44) & 0xffff) / 65536.0, seed, 9000 + 2 * (uint64_t)c, cp.data(), (int64_t)cp.size());
+			if (got < 0) continue;
+			if (got > L) got = L;
+			memcpy(seq + dst, cp.data(), (size_t)got); total++;
+		}
+	}
+	for (int64_t k = 0; k < (int64_t)(0.02 * scale * (double)n / 160); k++) {    // microsatellites: mean length 160
+		const uint64_t r = rnd(seed, 51, (uint64_t)k);
+		const int unit = 1 + (int)(r % 6), len = 20 + (int)((r >> 8) % 281);
+		const int64_t pos = (int64_t)((r >> 20) % (uint64_t)(n - len));
+		char u[6]; for (int t = 0; t < unit; t++) u[t] = ACGT[(r >> (40 + 2 * t)) & 3];
+		for (int t = 0; t < len; t++) seq[pos + t] = u[t % unit];
+	}
+	for (int64_t k = 0; k < n / 60000; k++) {                              // soft-masked blocks
+		const uint64_t r = rnd(seed, 52, (uint64_t)k);
+		const int len = 200 + (int)(r % 4801);
+		const int64_t pos = (int64_t)((r >> 16) % (uint64_t)(n - len));
+		for (int t = 0; t < len; t++) { const char c = seq[pos + t]; if (c >= 'A' && c <= 'Z' && c != 'N') seq[pos + t] = (char)(c | 0x20); }
+	}
+	if (n_run > 0 && 8 * n_run < n) for (int g = 1; g <= 2; g++) memset(seq + g * (n / 3) - n_run / 2, 'N', (size_t)n_run);
+	return total;
+}
+
 // query = mutated copy of ref; returns the length written (<= cap), or -1 if cap is too small
 int64_t gsah_c_synth_mutate(const char *ref, int64_t n, double d, uint64_t seed, char *out, int64_t cap)
 {

@@ -646,7 +646,7 @@ int launch_early_dp(gsa_ctx *c)
 	                        c->e_ops.as<uint8_t>(), c->e_opsoff.as<i64>(), c->e_nops.as<i32>(), c->e_rev.as<uint8_t>(), M_DPERR3);
 	if (rc) return rc;
 	GSA_CHECK(c, hipEventRecord(c->ev[14], sa));
-	c->n_early = ne; c->early_in_flight = true;
+	c->n_early = ne; c->early_in_flight = true; c->dbg[6] = (u64)ne;      // (gsa_get_seed_stats[6]: large gaps launched early, [7]: large jobs of the late launch)
 	return GSA_OK;
 }
 
@@ -654,78 +654,100 @@ int launch_early_dp(gsa_ctx *c)
 #define ENS(T, buf, n) do { if (!dev_ensure<T>(c, c->buf, (size_t)(n))) return GSA_ERR_NOMEM; } while (0)
 #define RC(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
-// The same segmentation for contigs whose chain does not fit one workgroup's LDS: the three steps of k_walk_windows as
-// grid-wide kernels over global memory (leave() per tile, the orbit of candidate 0 by pointer doubling -- a chase would
-// pay a global round trip per tile --, marks).  All in candidate space: nextk[k] = rank of the next start after k.
-#define WALKG_TS 256
-__global__ void k_walkg_leave(i64 na, i32 nt, const i32 *__restrict__ candEx, const i32 *__restrict__ nextk, i32 *J, i32 *on)
+// The same segmentation for contigs whose chain does not fit one workgroup's LDS (round 5: ONE launch; until then leave() per tile, 13-14
+// pointer-doubling launches for the orbit of candidate 0 and a marking launch -- each of the doubling launches a few microseconds of work that,
+// with four contexts in flight, waited ~80 us for its turn: 3.8 % of all kernel time, profiles/r04_kernels_human_full.txt).
+// All in candidate space: nextk[k] = rank of the next window start after candidate k (nC: none).  The candidates are cut into SLICES of 16 384; a
+// workgroup takes a slice (by ticket: the slices in front of it belong to workgroups that already run), keeps its hops in LDS as 16-bit offsets and
+// computes, for EVERY candidate k of the slice, the last element of the walk from k that still lies in k's sub-tile (64 candidates: E1, one lane
+// per sub-tile, back to front), in k's mid-tile (1 024: E2, a wavefront per mid-tile, sub-tile by sub-tile from the back -- a sub-tile's 64 values
+// only need values of later sub-tiles) and in the slice (E3, mid-tile by mid-tile from the back, 1 024 lanes at once).  All of that needs no entry
+// point and runs in every slice at the same time.  What is sequential is one look-up per slice: the slice's entry e arrives in a self-validating
+// word {launch epoch, rank}, its exit is nextk[E3[e]], which is published as the entry of the slice it lands in (~2 us per slice: 60 slices for
+// the 1 M candidates of a 250 Mb contig).  The marks then go level by level: one lane walks the mid-tile entries (h(E2)), 16 lanes the sub-tile
+// entries (h(E1)), 256 lanes the starts inside their sub-tile, all lanes scatter ws[].  Exactly the orbit of candidate 0 under next().
+#define WC_SL 16384
+#define WC_T 1024
+__global__ void __launch_bounds__(WC_T) k_walk_chain(i64 na, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, const i32 *__restrict__ nextk, i32 *ws,
+                                                     u32 *ticket, u32 ticket0, unsigned long long *entry_w, u32 epoch, i32 *err)
 {
-	const i32 t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= nt) return;
+	__shared__ uint16_t h[WC_SL], E1[WC_SL], E2[WC_SL], E3[WC_SL];
+	__shared__ u32 on[WC_SL / 32];
+	__shared__ uint16_t mid_e[WC_SL / 1024], sub_e[WC_SL / 64];
+	__shared__ u32 s_slice; __shared__ i32 s_entry;
+	const int tid = threadIdx.x;
 	const i32 nC = candEx[na];
-	const i64 pe = (i64)(t + 1) * WALKG_TS < na ? (i64)(t + 1) * WALKG_TS : na;
-	const i32 kb = candEx[(i64)t * WALKG_TS], ke = candEx[pe];
-	for (i32 k = ke - 1; k >= kb; k--) {
-		const i32 nx = nextk[k];
-		J[k] = nx >= ke ? (nx < nC ? nx : nC) : J[nx];      // (J[nx] was written by this thread a moment ago)
-		on[k] = k == 0 ? 1 : 0;
+	if (tid == 0) s_slice = atomicAdd(ticket, 1u) - ticket0;
+	__syncthreads();
+	const i32 sl = (i32)s_slice, base = sl * WC_SL;
+	const i32 nsl = (nC + WC_SL - 1) / WC_SL;
+	if (sl >= nsl) return;
+	const i32 cnt = nC - base < WC_SL ? nC - base : WC_SL;
+	for (int k = tid; k < WC_SL; k += WC_T) {
+		u32 v = 0xffffu;
+		if (k < cnt) { const i32 nx = nextk[base + k] - base; if (nx < cnt) v = (u32)nx; }      // (next() only moves forward: nx > k)
+		h[k] = (uint16_t)v;
 	}
-}
-__global__ void k_walkg_double(i64 na, const i32 *__restrict__ candEx, const i32 *__restrict__ Jin, i32 *Jout, i32 *on)
-{
-	const i32 nC = candEx[na];
-	const i32 k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= nC) return;
-	const i32 j = Jin[k];
-	if (j < nC) { if (on[k]) on[j] = 1; Jout[k] = Jin[j]; } else Jout[k] = nC;
-}
-// The doubling rounds as ONE launch (round 4; one kernel per round until then: 13-14 launches per 250 Mb contig, and with four contexts in flight
-// every one of those tiny launches waited ~80 us for its turn: profiles/r04_kernels_human_full.txt).  A grid of WALKG_COOP workgroups per CU -- all
-// resident: no LDS, 256 threads -- strides over the candidates, and a counter barrier separates the rounds.  What one round writes and the next one reads
-// goes through agent-scope atomic accesses (coherent across the XCDs' L2s by themselves, like the look-back words), and every wave's stores are
-// complete (vmcnt) before its workgroup arrives at the barrier, so no fence is needed.  The barrier words are never reset: the host passes the arrival
-// count and the generation they have at launch.  MEASURED SLOWER than the launches it replaces, alone (chaining of a 250 Mb contig 1.58 -> 1.73-1.82 ms:
-// a round is a barrier plus dependent agent-scope loads on 65-130 k threads instead of one thread per candidate) and with four contexts (full human 26.9 ->
-// 25.8 Gbp/s, 250 Mb contigs 33.7 -> 32.8): a kernel boundary is the cheapest grid barrier this part has.  Off by default (gsa_set_option "walk_coop").
-#define WALKG_COOP 2
-__device__ __forceinline__ i32 wg_ald(const i32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void wg_ast(i32 *p, i32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__global__ void __launch_bounds__(256) k_walkg_ladder(i64 na, const i32 *__restrict__ candEx, i32 *J0, i32 *J1, i32 *on, int rounds, u32 *bar, u32 cnt0, u32 gen0, i32 *err)
-{
-	const i32 nC = candEx[na];
-	const i32 G = (i32)(gridDim.x * 256), gtid = (i32)(blockIdx.x * 256 + threadIdx.x);
-	for (int r = 0; r < rounds; r++) {
-		const i32 *Jin = (r & 1) ? J1 : J0; i32 *Jout = (r & 1) ? J0 : J1;
-		for (i32 k = gtid; k < nC; k += G) {
-			const i32 j = wg_ald(&Jin[k]);
-			if (j < nC) { if (wg_ald(&on[k])) wg_ast(&on[j], 1); wg_ast(&Jout[k], wg_ald(&Jin[j])); } else wg_ast(&Jout[k], nC);
+	for (int w = tid; w < WC_SL / 32; w += WC_T) on[w] = 0;
+	if (tid < WC_SL / 1024) mid_e[tid] = 0xffff;
+	if (tid < WC_SL / 64) sub_e[tid] = 0xffff;
+	__syncthreads();
+	if (tid < WC_SL / 64) {
+		const int b = tid * 64;
+		for (int k = b + 63; k >= b; k--) { const u32 nx = h[k]; E1[k] = (uint16_t)((nx != 0xffffu && (nx >> 6) == (u32)tid) ? E1[nx] : (u32)k); }
+	}
+	__syncthreads();
+	{
+		const u32 w = (u32)tid >> 6, l = (u32)tid & 63u;      // (16 wavefronts, 16 mid-tiles)
+		for (int j = 15; j >= 0; j--) {
+			const u32 k = w * 1024u + (u32)j * 64u + l;
+			const u32 e1 = E1[k], nx = h[e1];
+			E2[k] = (uint16_t)((nx != 0xffffu && (nx >> 10) == w) ? E2[nx] : e1);
+			__syncthreads();
 		}
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+	for (int j = WC_SL / 1024 - 1; j >= 0; j--) {
+		const u32 k = (u32)j * 1024u + (u32)tid;
+		const u32 e2 = E2[k], nx = h[e2];
+		E3[k] = (uint16_t)(nx != 0xffffu ? E3[nx] : e2);
 		__syncthreads();
-		if (threadIdx.x == 0) {
-			const u32 t = __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (t == cnt0 + gridDim.x * (u32)(r + 1) - 1u) __hip_atomic_store(&bar[1], gen0 + (u32)r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			else {
-				u32 spins = 0;
-				while ((i32)(__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (gen0 + (u32)r + 1u)) < 0) {
-					if (++spins > (1u << 24)) { *err = 1; break; }
-					__builtin_amdgcn_s_sleep(2);
-				}
+	}
+	if (tid == 0) {
+		i32 e = -2;
+		if (sl == 0) e = 0;
+		else {
+			u32 spins = 0;
+			for (;;) {
+				const unsigned long long wv = __hip_atomic_load(&entry_w[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((u32)(wv >> 32) == epoch) { e = (i32)(u32)wv - 2; break; }
+				if (++spins > (1u << 23)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+				__builtin_amdgcn_s_sleep(1);
 			}
 		}
-		__syncthreads();
+		s_entry = e;
+		if (e >= 0) {
+			const i32 x = nextk[base + (i32)E3[e - base]];      // where the walk leaves the slice: a later slice's entry, or nC
+			const i32 t = x < nC ? x / WC_SL : nsl;
+			if (t < nsl) __hip_atomic_store(&entry_w[t], ((unsigned long long)epoch << 32) | (u32)(x + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			for (i32 s2 = sl + 1; s2 < t; s2++) __hip_atomic_store(&entry_w[s2], (unsigned long long)epoch << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (slices the walk jumps over: no entry)
+		}
 	}
-}
-__global__ void k_walkg_mark(i64 na, i32 nt, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, const i32 *__restrict__ nextk, const i32 *__restrict__ on, i32 *ws)
-{
-	const i32 t = blockIdx.x * blockDim.x + threadIdx.x;
-	if (t >= nt) return;
-	const i64 pe = (i64)(t + 1) * WALKG_TS < na ? (i64)(t + 1) * WALKG_TS : na;
-	const i32 kb = candEx[(i64)t * WALKG_TS], ke = candEx[pe];
-	i32 e = -1;
-	for (i32 k = kb; k < ke; k++) if (on[k]) { e = k; break; }      // (the orbit enters a tile at most once)
+	__syncthreads();
+	const i32 e = s_entry;
 	if (e < 0) return;
-	for (i32 k = e; k < ke; k = nextk[k]) ws[clist[k]] = 1;
+	if (tid == 0) { u32 x = (u32)(e - base); for (;;) { mid_e[x >> 10] = (uint16_t)x; const u32 nx = h[E2[x]]; if (nx == 0xffffu) break; x = nx; } }
+	__syncthreads();
+	if (tid < WC_SL / 1024 && mid_e[tid] != 0xffff) { u32 x = mid_e[tid]; for (;;) { sub_e[x >> 6] = (uint16_t)x; const u32 nx = h[E1[x]]; if (nx == 0xffffu || (nx >> 10) != (u32)tid) break; x = nx; } }
+	__syncthreads();
+	if (tid < WC_SL / 64 && sub_e[tid] != 0xffff) { u32 x = sub_e[tid]; for (;;) { atomicOr(&on[x >> 5], 1u << (x & 31)); const u32 nx = h[x]; if (nx == 0xffffu || (nx >> 6) != (u32)tid) break; x = nx; } }
+	__syncthreads();
+	for (int k0 = tid; k0 < cnt; k0 += 8 * WC_T) {
+		i32 p[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++) { const int k = k0 + u * WC_T; p[u] = (k < cnt && ((on[k >> 5] >> (k & 31)) & 1u)) ? clist[base + k] : -1; }
+#pragma unroll
+		for (int u = 0; u < 8; u++) if (p[u] >= 0) ws[p[u]] = 1;
+	}
 }
 
 int stage2_chain(gsa_ctx *c)
@@ -778,26 +800,18 @@ int stage2_chain(gsa_ctx *c)
 	i32 *candf = c->d_flag.as<i32>(), *candEx = c->d_scan.as<i32>(), *clist = c->a_runinfo.as<i32>();
 	{ OpCand op = { na, c->a_gb.as<i32>(), c->a_ge.as<i32>(), cuEx, brk, candf, candEx, clist, ws }; RC((lb_launch<1>(c, na, op))); }
 	LAUNCH(k_next_window, na, na, c->a_q.as<i32>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, cuEx, brk, brkEx, blist, candf, candEx, clist, next, c->d_flag2.as<i32>());
-	if (na <= 100000) hipLaunchKernelGGL(k_walk_windows, dim3(1), dim3(WALK_T), 0, st, na, candEx, clist, next, c->d_flag2.as<i32>(), ws);
+	if (na <= c->opt.walk_chain_min) hipLaunchKernelGGL(k_walk_windows, dim3(1), dim3(WALK_T), 0, st, na, candEx, clist, next, c->d_flag2.as<i32>(), ws);
 	else {
-		// (large contigs: grid-wide kernels, see k_walkg_leave; candidates <= seeds, so seed-sized scratch)
-		const i32 nt = (i32)((na + WALKG_TS - 1) / WALKG_TS);
-		ENS(i32, w_j0, na + 2); ENS(i32, w_j1, na + 2); ENS(i32, w_on, na + 2);
-		i32 *J0 = c->w_j0.as<i32>(), *J1 = c->w_j1.as<i32>(), *on = c->w_on.as<i32>();
-		const i32 *nextk = c->d_flag2.as<i32>();
-		LAUNCH(k_walkg_leave, nt, na, nt, candEx, nextk, J0, on);
-		if (!c->opt.walk_coop) { for (i32 span = 1; span < nt; span <<= 1) { LAUNCH(k_walkg_double, na, na, candEx, J0, J1, on); std::swap(J0, J1); } }
-		else {
-			int rounds = 0; for (i32 span = 1; span < nt; span <<= 1) rounds++;
-			if (!c->d_wbar.p) { ENS(u32, d_wbar, 4); GSA_CHECK(c, hipMemsetAsync(c->d_wbar.p, 0, 16, st)); c->wbar_cnt = c->wbar_gen = 0; }
-			if (c->n_cus <= 0) { hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device)); c->n_cus = pr.multiProcessorCount; }
-			const unsigned grid = (unsigned)c->n_cus * WALKG_COOP;
-			if (rounds > 0) {
-				hipLaunchKernelGGL(k_walkg_ladder, dim3(grid), dim3(256), 0, st, na, candEx, J0, J1, on, rounds, c->d_wbar.as<u32>(), c->wbar_cnt, c->wbar_gen, c->d_mail.as<i32>() + M_LBERR);
-				c->wbar_cnt += grid * (u32)rounds; c->wbar_gen += (u32)rounds;
-			}
-		}
-		LAUNCH(k_walkg_mark, nt, na, nt, candEx, clist, nextk, on, ws);
+		// (large contigs: slices of the candidate list, one launch -- k_walk_chain; candidates <= seeds bounds the grid, the ticket counter and the
+		//  entry words are never reset: the host passes the counter's value and the launch's epoch)
+		const u32 grid = (u32)((na + WC_SL - 1) / WC_SL);
+		const size_t cap0 = c->w_j0.cap;
+		ENS(unsigned long long, w_j0, (size_t)grid + 8);
+		if (c->w_j0.cap != cap0) { GSA_CHECK(c, hipMemsetAsync(c->w_j0.p, 0, c->w_j0.cap, st)); c->walk_ticket = 0; c->walk_epoch = 0; }
+		unsigned long long *words = c->w_j0.as<unsigned long long>();
+		c->walk_epoch++;
+		hipLaunchKernelGGL(k_walk_chain, dim3(grid), dim3(WC_T), 0, st, na, candEx, clist, (const i32 *)c->d_flag2.as<i32>(), ws, (u32 *)words, c->walk_ticket, words + 4, c->walk_epoch, mail + M_LBERR);
+		c->walk_ticket += grid;
 	}
 	// C. outliers
 	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);

@@ -442,7 +442,7 @@ int stage78_extend(gsa_ctx *c)
 		hipLaunchKernelGGL(k_bundle_rebase, dim3(grid_for((size_t)nfu, TPB)), dim3(TPB), 0, sc, nfu, mail + M_NF, nfb, d_fragbase, c->d_bblk.as<i32>(), c->d_bblk.as<i32>() + nfb,
 		                   c->bnd.off, c->d_alnoff.as<i64>(), c->f_rec16.as<gsa_rec>(), c->p_ba0.as<i64>());
 	const i32 *hm = c->p_dp.as<i32>();      // (the mailbox as run_ksw2_jobs read it: the record count is final since stage 7)
-	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN]; c->n_large = kl.nlarge;
+	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN]; c->n_large = kl.nlarge; c->dbg[7] = (u64)kl.nlarge;
 	GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec16.p, (size_t)c->n_frags * sizeof(gsa_rec), hipMemcpyDeviceToHost, sc));
 	// everything that can only leave at the very end sits in ONE buffer: final mailbox | patch list of the large DP jobs |
 	// string pool 1 | string pool 2 -- a single copy behind the last kernel instead of a chain of four

@@ -1369,10 +1369,13 @@ __global__ void __launch_bounds__(256) k_pack_ref(const uint8_t *__restrict__ re
 }
 
 // (layout of the grouped presence table: comment at pres4_line, top of this file)
+// (grid-stride: a launch holds at most 2^32 - 1 work-items -- the dispatch packet's grid size is 32 bits wide -- and a human index has 6.2 G text
+//  positions.  Until round 5 this kernel was launched with one work-item per position: the runtime took the count modulo 2^32, only the first 1.86 G
+//  positions of a 3.08 Gbp index were entered, and a 15-mer whose occurrences all lie behind them -- one in five -- was reported ABSENT: the search from
+//  such a start ended without a seed.  Found by the first oracle comparison on the native index, tests/human_scale_check.py.)
 __global__ void __launch_bounds__(256) k_build_pres(const u32 *__restrict__ ref2, u64 seq_len, int k, u32 *bm)
 {
-	const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (p + (u64)k > seq_len) return;
+	for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p + (u64)k <= seq_len; p += (u64)gridDim.x * blockDim.x) {
 	const u64 w = p >> 4;
 	const u64 X = funnel64(ref2[w], ref2[w + 1], ref2[w + 2], (int)(p & 15) << 1) & ((1ull << (2 * k)) - 1);      // the k-mer at p, base t at bits 2t
 #pragma unroll
@@ -1382,6 +1385,7 @@ __global__ void __launch_bounds__(256) k_build_pres(const u32 *__restrict__ ref2
 		const u32 head = (u32)X & ((1u << (2 * (3 - i))) - 1), tail = (u32)(X >> (2 * (k - i))) & ((1u << (2 * i)) - 1);
 		const u32 bit = (u32)i * 64u + (head | (tail << (2 * (3 - i))));
 		atomicOr(&bm[(size_t)line * 8 + (bit >> 5)], 1u << (bit & 31));
+	}
 	}
 }
 
@@ -1412,7 +1416,7 @@ int build_presence(gsa_ctx *c)
 	const size_t words = ((size_t)1 << (2 * (k - 3))) * 8;      // 4^(k-3) lines of 32 bytes
 	if (!dev_ensure<u32>(c, c->d_pres, words)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemsetAsync(c->d_pres.p, 0, words * 4, c->stream));
-	hipLaunchKernelGGL(k_build_pres, dim3(grid_for(c->di.seq_len, 256)), dim3(256), 0, c->stream, c->di.ref2, c->di.seq_len, k, c->d_pres.as<u32>());
+	hipLaunchKernelGGL(k_build_pres, dim3(grid_for(std::min<u64>(c->di.seq_len, 1ull << 30), 256)), dim3(256), 0, c->stream, c->di.ref2, c->di.seq_len, k, c->d_pres.as<u32>());
 	GSA_CHECK(c, hipGetLastError());
 	GSA_CHECK(c, hipStreamSynchronize(c->stream));
 	c->di.pres = c->d_pres.as<u32>(); c->di.pres_k = k;

@@ -83,6 +83,8 @@ def _hostlib():
     lib.gsah_c_synth_mutate.restype = C.c_int64
     lib.gsah_c_synth_adversarial.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int, C.c_int64, C.c_int64]
     lib.gsah_c_synth_adversarial.restype = C.c_int64
+    lib.gsah_c_synth_human_like.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_double, C.c_int64]
+    lib.gsah_c_synth_human_like.restype = C.c_int64
     return lib
 
 
@@ -105,6 +107,27 @@ def inject_adversarial(seq: np.ndarray, seed: int = 11, frac: float = 0.25, n_fa
     two runs of n_run N's (capped at 1/8 of the sequence) and soft-masked blocks -- csrc/host/synth.cpp.  Returns the copy count."""
     assert seq.flags.c_contiguous and seq.dtype == np.uint8
     return int(_hostlib().gsah_c_synth_adversarial(seq.ctypes.data, seq.size, seed, frac, n_fam, max_copies, min(n_run, seq.size // 9)))
+
+
+def inject_human_like(seq: np.ndarray, seed: int = 11, scale: float = 1.0, n_run: int = 1_000_000) -> int:
+    """In place: the interspersed-repeat spectrum of a primate genome over ~45 % of the sequence (x `scale`) -- an Alu-like family in three age
+    classes, 5'-truncated L1-like copies, LTR-like families with solo LTRs, ancient repeats, segmental duplications, microsatellites, soft-masked
+    blocks and two N runs -- csrc/host/synth.cpp.  Returns the copy count."""
+    assert seq.flags.c_contiguous and seq.dtype == np.uint8
+    return int(_hostlib().gsah_c_synth_human_like(seq.ctypes.data, seq.size, seed, scale, min(n_run, seq.size // 9)))
+
+
+def make_human_like_pair(total_len: int, n_contigs: int, d: float, seed: int = 11, **kw):
+    """(ref_contigs, qry_contigs) like make_pair_fast, every reference contig with the human-like repeat spectrum."""
+    base = total_len // n_contigs
+    refs, qrys = [], []
+    for i in range(n_contigs):
+        ln = base if i + 1 < n_contigs else total_len - base * (n_contigs - 1)
+        r = fast_genome(int(ln), seed * 1000 + i)
+        inject_human_like(r, seed * 1000 + i, **kw)
+        refs.append((f"chr{i + 1}", r))
+        qrys.append((f"qry{i + 1}", fast_mutate(r, d, seed * 1000 + 500 + i)))
+    return refs, qrys
 
 
 def make_adversarial_pair(total_len: int, n_contigs: int, d: float, seed: int = 11, **kw):

@@ -150,8 +150,8 @@ int  gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *pr
  *                    workgroup and 160-start segments (many chunks), 1 = one chunk per workgroup and 40-start segments (few).  Results do not depend on it
  *   "dp_side"        1 = the striped DP launches its lower size class on a stream of its own, beside the upper class, instead of behind it (measured: the DP
  *                    span of a 250 Mb contig 4.9 -> 1.9 ms, but the refinement passes beside it starve: contig latency 13.7 -> 14.3 ms, throughput -4 % / +4 %); default 0
- *   "walk_coop"      1 = the pointer-doubling rounds of the window walk (chaining, contigs above 100 000 seeds) as ONE cooperative launch instead of a
- *                    launch per round (default 0: measured slower)
+ *   "walk_chain_min" seeds; a contig with more seeds than this walks its window chain (chaining, GSAlign.cpp:326-338) in slices of the candidate list,
+ *                    one launch (default 100 000; below that one workgroup holds the chain in LDS).  Results do not depend on it (tests: 0)
  *   "dp_safe", "dp_fake_timeout"   test hooks: one striped DP job per launch; the next n contigs report a stripe hand-off time-out once
  * Unknown names and values outside an option's range (negative sizes, seed_budget 0, ...): GSA_ERR_ARG, nothing changed.
  * Until round 4 some of these were environment variables read by the library (GSA_SPLIT_MIN, GSA_BUNDLE_CONTIG, GSA_BUNDLE_CAP, GSA_SEED_BUDGET,

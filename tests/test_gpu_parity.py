@@ -280,6 +280,21 @@ def test_adversarial_repeats_vs_oracle(oracle_built, tmp_path, total, ncontig, d
     o.close(); g.close()
 
 
+@pytest.mark.parametrize("total,ncontig,div,seed,params", [(10000000, 2, 0.01, 81, {}), (3000000, 1, 0.02, 82, dict(wide=True))])
+def test_human_like_repeats_vs_oracle(oracle_built, tmp_path, total, ncontig, div, seed, params):
+    """Round 5: the interspersed-repeat spectrum of a primate genome over ~45 % of the sequence -- an Alu-like family in
+    three age classes, 5'-truncated L1-like copies, LTR-like families with solo LTRs, ancient repeats, 20-kb segmental duplications at 1-3 %,
+    microsatellites, N runs, soft-masked blocks (csrc/host/synth.cpp: gsah_c_synth_human_like; bench.py --workload human_like) -- every block,
+    record and gapped string vs the oracle (pinned on such input against the live reference: test_oracle_vs_reference.py::test_human_like_repeats_live)."""
+    params = dict(params); wide = params.pop("wide", False)
+    refs, qrys = synth.make_human_like_pair(total, ncontig, div, seed=seed, n_run=200000)
+    qrys[-1] = (qrys[-1][0], synth.revcomp(qrys[-1][1]))
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx, params); g = capi.Aligner(idx, wide=wide, **params)
+    _same_as_oracle(o, g, qrys)
+    o.close(); g.close()
+
+
 @pytest.mark.parametrize("shape,params", [(0, {}), (1, {}), (0, dict(sen=1, clr=50)), (1, dict(sen=1, clr=50, wide=True))])
 def test_sweep_launch_shapes_vs_oracle(oracle_built, tmp_path, shape, params):
     """k_dense_sweep's two launch shapes (round 4: four chunks per workgroup with the 160-start segments drawn by the lanes from an LDS counter;

@@ -211,3 +211,18 @@ def test_query_loader_matches_the_reference_loop(tmp_path, par_min, monkeypatch)
         assert _reference_loader(fn) is None
         err = C.create_string_buffer(256)
         assert lib.gsah_c_load_query(fn.encode(), err) == -1 and b"non-alphabet" in err.value, name
+
+
+def test_exact_sort_is_std_sort():
+    """csrc/host/exact_sort.h (the VCF sort on many threads) against std::sort itself, element for element: random keys full of ties at
+    several sizes and grains (so that the level-by-level partition phase, the per-range phase and the <= 16-element leaves all run), sorted /
+    reversed / constant / organ-pipe / few-runs inputs, and the median-of-three killer that drives introsort into its heapsort fallback."""
+    lib = hostlib.load()
+    import ctypes as C
+    lib.gsah_c_exact_sort_check.argtypes = [C.c_longlong, C.c_int, C.c_uint, C.c_int, C.c_longlong]
+    for n in (0, 1, 2, 15, 16, 17, 33, 1000, 65537, 300000, 2000003):
+        for distinct, grain in ((3, 64), (50, 1000), (100000, 1 << 16), (7, 5000)):
+            assert lib.gsah_c_exact_sort_check(n, distinct, n + distinct, 0, grain) == 0, (n, distinct, grain)
+    for pattern in (1, 2, 3, 4, 5, 6):
+        for n in (17, 1000, 100000, 1500000):
+            assert lib.gsah_c_exact_sort_check(n, 10, 1, pattern, 2000) == 0, (pattern, n)

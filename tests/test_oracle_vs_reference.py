@@ -72,6 +72,24 @@ def test_adversarial_repeats_live(op, tmp_path):
     o.close()
 
 
+def test_human_like_repeats_live(op, tmp_path):
+    """Round 5: the human-like repeat spectrum (csrc/host/synth.cpp: gsah_c_synth_human_like -- Alu-, L1-, LTR-like families by age class, ancient
+    repeats, segmental duplications, microsatellites, N runs, soft-masked blocks over ~45 % of the sequence).  The restatement against the real
+    reference objects after all 8 stages, forward and reverse strand."""
+    refs, qrys = synth.make_human_like_pair(2_000_000, 2, 0.015, seed=93, n_run=60_000)
+    qrys[1] = (qrys[1][0], synth.revcomp(qrys[1][1]))
+    rf, qf, px = str(tmp_path / "r.fa"), str(tmp_path / "q.fa"), str(tmp_path / "r")
+    synth.write_fasta(rf, refs); synth.write_fasta(qf, qrys)
+    op.ref_build_index(rf, px)
+    op.ref_dump_subprocess(px, qf, str(tmp_path / "ref.npz"), {})
+    want = np.load(str(tmp_path / "ref.npz"))
+    o = op.Oracle(indexio.load_index(px))
+    for ci, (name, seq) in enumerate(qrys):
+        o.set_query(seq)
+        assert_stage_equal(o.dump_stages(8), want, prefix=f"c{ci}_")
+    o.close()
+
+
 def test_ksw2_edge_shapes_live(op):
     """The pairs the striped GPU kernel is checked on (tools/dp_fuzz.py: query lengths around multiples of 64 / 128, one-row and
     1500-row reference sides, N bases, long pairs up to 5000 x 5000), here the restatement against the reference's own

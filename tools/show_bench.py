@@ -14,3 +14,5 @@ for e in d.get("extra_workloads", []):
     if e.get("value") is None: print("==", e["workload"], e.get("error"))
     else: show(e, e["workload"])
 if "cpu_baseline" in d: print(d["cpu_baseline"])
+for e in [d] + d.get("extra_workloads", []):
+    if "end_to_end" in e: print("== end_to_end", e.get("workload", "main"), json.dumps(e["end_to_end"]))
