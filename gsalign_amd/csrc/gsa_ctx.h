@@ -81,6 +81,7 @@ struct Options {
 	int sweep_shape = -1;              // k_dense_sweep's launch shape: -1 by the number of dense chunks, 0 = four chunks per two-wave workgroup / 160-start segments, 1 = one chunk per four-wave workgroup / 40-start segments
 	int dp_side = 0;                   // 1: the striped DP's lower size class on a stream of its own, beside the upper class (0: behind it)
 	int64_t walk_chain_min = 100000;   // contigs with more seeds than this walk their window chain in slices (k_walk_chain) instead of one workgroup's LDS (k_walk_windows); tests: 0
+	int pres_from_kmer = 1;            // the presence table is derived from the k-mer jump table when both hold k-mers of one length (0: always from a scan of the text; a test compares the two)
 	int kmer_k = 0;                    // gsa_create_opts (GSA_CREATE_KMER_K): length of the jump table's k-mers (0: by text length and free memory)
 };
 

@@ -1389,6 +1389,25 @@ __global__ void __launch_bounds__(256) k_build_pres(const u32 *__restrict__ ref2
 	}
 }
 
+// The same table from the k-mer jump table, when that holds k-mers of exactly this length (the default: -slen 15 against a text of more than 4^13
+// rows): a k-mer occurs iff its entry's interval is not empty, so 4^k entries are read in order instead of 2G text positions (a human index: 1.07 G
+// entries against 6.2 G positions; the scan's four atomics per position were 0.9 s of gsa_create there).
+__global__ void __launch_bounds__(256) k_pres_from_kmer(const u64 *__restrict__ tab, int e16, int k, u32 *bm)
+{
+	const u64 n = 1ull << (2 * k);
+	for (u64 X = (u64)blockIdx.x * blockDim.x + threadIdx.x; X < n; X += (u64)gridDim.x * blockDim.x) {
+		const bool occurs = e16 ? ((const uint4 *)tab)[X].z != 0u : tab[(X << 2) + 2] != 0ull;
+		if (!occurs) continue;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const u32 line = (u32)((X >> (2 * (3 - i))) & ((1ull << (2 * (k - 3))) - 1));
+			const u32 head = (u32)X & ((1u << (2 * (3 - i))) - 1), tail = (u32)(X >> (2 * (k - i))) & ((1u << (2 * i)) - 1);
+			const u32 bit = (u32)i * 64u + (head | (tail << (2 * (3 - i))));
+			atomicOr(&bm[(size_t)line * 8 + (bit >> 5)], 1u << (bit & 31));
+		}
+	}
+}
+
 // the short companion of the k-mer table (DevIndex::kmer_lo): MinSeedLength bases, when that is less than kmer_k
 static int build_kmer_lo(gsa_ctx *c)
 {
@@ -1416,7 +1435,10 @@ int build_presence(gsa_ctx *c)
 	const size_t words = ((size_t)1 << (2 * (k - 3))) * 8;      // 4^(k-3) lines of 32 bytes
 	if (!dev_ensure<u32>(c, c->d_pres, words)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemsetAsync(c->d_pres.p, 0, words * 4, c->stream));
-	hipLaunchKernelGGL(k_build_pres, dim3(grid_for(std::min<u64>(c->di.seq_len, 1ull << 30), 256)), dim3(256), 0, c->stream, c->di.ref2, c->di.seq_len, k, c->d_pres.as<u32>());
+	if (c->di.kmer && c->di.kmer_k == k && c->opt.pres_from_kmer)
+		hipLaunchKernelGGL(k_pres_from_kmer, dim3(grid_for(std::min<u64>(1ull << (2 * k), 1ull << 28), 256)), dim3(256), 0, c->stream, c->di.kmer, c->di.kmer_e16, k, c->d_pres.as<u32>());
+	else
+		hipLaunchKernelGGL(k_build_pres, dim3(grid_for(std::min<u64>(c->di.seq_len, 1ull << 30), 256)), dim3(256), 0, c->stream, c->di.ref2, c->di.seq_len, k, c->d_pres.as<u32>());
 	GSA_CHECK(c, hipGetLastError());
 	GSA_CHECK(c, hipStreamSynchronize(c->stream));
 	c->di.pres = c->d_pres.as<u32>(); c->di.pres_k = k;

@@ -325,6 +325,10 @@ def test_long_kmer_table(oracle_built, tmp_path, monkeypatch, k, wide):
     idx = _build(tmp_path, refs)
     o = oracle_built.Oracle(idx); g = capi.Aligner(idx, wide=wide)
     _same_as_oracle(o, g, qrys)
+    # round 5: with k = MinSeedLength the presence table is derived from the k-mer table (what a human index gets); the same table from the
+    # scan of the text (the other build path: option pres_from_kmer 0, rebuilt by a parameter change and back) gives the same result
+    g.set_option("pres_from_kmer", 0); g.set_params(slen=14); g.set_params()
+    _same_as_oracle(o, g, qrys)
     o.close(); g.close()
 
 
