@@ -325,6 +325,18 @@ void *gsa_host_alloc(size_t bytes)
 	return p;
 }
 void gsa_host_free(void *p) { if (p) (void)hipHostFree(p); }
+int gsa_host_register(void *p, size_t bytes)
+{
+	if (!p || !bytes) return GSA_ERR_ARG;
+	if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return GSA_ERR_HIP; }
+	return GSA_OK;
+}
+int gsa_host_unregister(void *p)
+{
+	if (!p) return GSA_ERR_ARG;
+	if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return GSA_ERR_HIP; }
+	return GSA_OK;
+}
 
 int gsa_set_option(gsa_ctx *c, const char *name, int64_t value)
 {

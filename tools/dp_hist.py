@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Histogram of the gap-closing DP jobs of one contig (GPU box): which (m, n) classes hold the cells and the jobs.
-usage: dp_hist.py [workload: human|ecoli|yeast] [genome_len]"""
+usage: dp_hist.py [workload of bench.py: human|human_like|adversarial|ecoli|yeast] [genome_len]"""
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,8 +12,10 @@ name = sys.argv[1] if len(sys.argv) > 1 else "human"
 wl = dict(bench.WORKLOADS[name])
 if len(sys.argv) > 2: wl["lengths"] = [int(sys.argv[2])]
 tmp = tempfile.mkdtemp(prefix="dphist_")
-px, idx, refs = bench.build_reference(tmp, name, wl, 0, 1)
-q = bench.make_queries(wl, refs, 0)[0][0]
+import argparse
+args = argparse.Namespace(fasta_ref="", fasta_query="")
+px, idx, refs = bench.build_reference(tmp, name, wl, 0, 1, args)
+q = bench.make_queries(wl, refs, args)[0][0]
 g = capi.Aligner(idx, **wl["params"])
 r = g.align_contig(q)
 F = r["frags"]; B = r["blocks"]

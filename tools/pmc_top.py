@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/pmc_<workload>/*.csv (tools/pmc_top.sh) -> profiles/r04_pmc_<workload>.json: HBM traffic per step of the
+"""gpurun_out/pmc_<workload>/*.csv (tools/pmc_top.sh) -> profiles/r05_pmc_<workload>.json: HBM traffic per step of the
 top kernels and of the whole step, from separate rocprofv3 --pmc passes.  Reads: from the request counters
 (TCC_EA0_RDREQ: requests that are not 32-byte ones are 128 bytes wide on gfx950 -- the same correction as
 "FETCH_SIZE x 2" in MI355X_MICROARCH.md, HBM section); writes: WRITE_SIZE (KB) as is (uncalibrated there)."""
@@ -16,6 +16,10 @@ GROUPS = {      # key in the json -> predicate on the (mangled) kernel name
     "k_seed_select": lambda k: "k_seed_select" in k,
     "k_materialize": lambda k: "k_materialize" in k,
     "copies": lambda k: "copyBuffer" in k or "fillBuffer" in k,
+    # chain + refine (S2-S5): everything between the located hits and the leaf table -- the fused look-back passes of those stages, the sort, the
+    # PosDiff-bitmap kernels, the window walk and histogram kernels, the gap-similarity kernel (the passes of stages 6-7 belong to `extend`)
+    "chain_refine": lambda k: (("k_lb_pass" in k and not any(o in k for o in ("OpDpJobs", "OpSlots", "OpClassify"))) or any(n in k for n in ("k_pd_", "k_rs_", "k_walk", "k_window", "k_outlier", "k_multihit", "k_next_window", "k_gapsim", "k_leaf_emit", "k_group_keys", "k_gather_active"))),
+    "extend_passes": lambda k: any(o in k for o in ("OpDpJobs", "OpSlots", "OpClassify", "k_gap_class")),
 }
 
 
@@ -59,12 +63,12 @@ def main():
     # runs with the production seed kernel = launches of k_seed_wg<false,*>
     sel = sum(v for k, v in launches.items() if "k_seed_select" in k)
     prod = sum(v for k, v in launches.items() if "k_seed_wg" in k and "Lb1ELb0" not in k and "<true" not in k) or sum(v for k, v in launches.items() if "k_dense_resolve" in k)
-    contigs_per_step = {"human": 1, "ecoli": 1, "yeast": 16, "human_full": 24, "adversarial": 1}[W]
+    contigs_per_step = {"human": 1, "ecoli": 1, "yeast": 16, "human_full": 24, "adversarial": 1, "human_like": 1}[W]
     def bytes_of(d):
         rd, rd32 = d.get("TCC_EA0_RDREQ_sum", 0.0), d.get("TCC_EA0_RDREQ_32B_sum", 0.0)
         rb = (rd - rd32) * 128.0 + rd32 * 32.0 if rd else d.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
         return rb, d.get("WRITE_SIZE", 0.0) * 1024.0
-    out = {"_what": f"HBM traffic per step of bench.py --workload {W} from rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only beside it), inflight 1",
+    out = {"_what": f"HBM traffic per step of bench.py --workload {W} from rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only beside it), the workload's own --inflight (4 contexts)",
            "_method": "reads = (TCC_EA0_RDREQ - RDREQ_32B) x 128 B + RDREQ_32B x 32 B (gfx950: FETCH_SIZE tallies 128-byte requests at 64 B, MI355X_MICROARCH.md HBM section; CALIBRATED in round 4 -- profiles/r04_pmc_calibration.txt: a random read of 16, 32, 64 or 128 bytes costs exactly one RDREQ, none of the 32-byte kind, and FETCH_SIZE counts it as 64 B: every L2 miss fetches one 128-byte line); writes = WRITE_SIZE KB x 1024 (uncalibrated); "
                       "Infinity-Cache hits are counted, so this is L2-miss traffic, an upper bound of HBM bytes; per step = total over the run / hot-path runs x contigs per step "
                       "(seed kernels: / runs with the production seed kernel)",
@@ -86,7 +90,7 @@ def main():
                                     "traffic_bytes_per_step": (rb + wb) / runs * contigs_per_step}
     if sel:
         out["traffic_bytes_per_step"] = (tot_r + tot_w) / sel * contigs_per_step
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"r04_pmc_{W}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"r05_pmc_{W}.json"), "w"), indent=1)
     print(json.dumps(out, indent=1)[:3000])
 
 

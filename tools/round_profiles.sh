@@ -5,14 +5,14 @@ cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 export GSA_BENCH_TMP=/tmp/gsa_round GSA_BENCH_KEEP=1; mkdir -p $GSA_BENCH_TMP gpurun_out
 timeout 900 python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
 tail -c 400 gpurun_out/bench_default.json; echo
-for w in ${KW:-human_full human ecoli yeast adversarial}; do
-  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$w -o p -- python bench.py --workload $w --extra "" --no-cpu-baseline --no-side-legs > gpurun_out/prof_$w.log 2>&1
+for w in ${KW:-human_full human human_like ecoli yeast adversarial}; do
+  timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$w -o p -- python bench.py --workload $w --extra "" --no-cpu-baseline --no-side-legs --no-e2e > gpurun_out/prof_$w.log 2>&1
   python tools/rocprof_summary.py gpurun_out/prof_$w/p_results.db > gpurun_out/kernels_$w.txt
   rm -rf gpurun_out/prof_$w
 done
-WL="human ecoli yeast adversarial" STEPS=8 bash tools/tl1.sh
+WL="human human_like ecoli yeast adversarial" STEPS=8 bash tools/sweeps/tl1.sh
 STEPS=1 bash tools/pmc_top.sh human_full > gpurun_out/pmc_top_full.log 2>&1
 bash tools/pmc_top.sh human > gpurun_out/pmc_top.log 2>&1
 bash tools/pmc_sq.sh human > gpurun_out/pmc_sq.log 2>&1
-bash tools/r4_adv_pmc.sh > gpurun_out/pmc_adv.log 2>&1
-# then, back in the container: python tools/pmc_top.py human_full; python tools/pmc_top.py human ; python tools/pmc_sq.py human > profiles/r04_sq_human.txt ; python tools/pmc_adv.py > profiles/r04_pmc_adversarial.txt
+STEPS=1 bash tools/pmc_sq.sh human_full > gpurun_out/pmc_sq_full.log 2>&1
+# then, back in the container: python tools/pmc_top.py human_full; python tools/pmc_top.py human ; python tools/pmc_sq.py human > profiles/r05_sq_human.txt ; python tools/pmc_sq.py human_full > profiles/r05_sq_human_full.txt
