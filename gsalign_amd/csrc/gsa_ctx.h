@@ -24,7 +24,7 @@ struct Leaf {
 
 // Device "mailbox" (i32[MAIL_N]) of the counts the stages produce; the host reads the whole
 // box in ONE pinned copy where it needs them instead of one read-back per count.
-enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_NTINY = 40, M_TICKET = 48, M_NBRAW = 49, M_NR2 = 50, M_NF = 51, M_NJOB = 52, M_OPSTOT = 53, M_NALN = 54, M_DPERR = 64, M_NLARGE = 65, M_DPERR2 = 66, M_CELLS = 68 /* two u64: sum m*n, sum m+n */ /* 64..71: cleared together, one aligned 32-byte fill */, M_DPERR3 = 41, M_LBDONE = 42, M_LFSTEPS = 44 /* u64, accounting build */, M_NEARLY = 62, M_EOPS = 63, MAIL_N = 72 };
+enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_NTINY = 40, M_TICKET = 48, M_NBRAW = 49, M_NR2 = 50, M_NF = 51, M_NJOB = 52, M_OPSTOT = 53, M_NALN = 54, M_DPERR = 64, M_NLARGE = 65, M_DPERR2 = 66, M_CELLS = 68 /* two u64: sum m*n, sum m+n */ /* 64..71: cleared together, one aligned 32-byte fill */, M_DPERR3 = 41, M_LBDONE = 42, M_LFSTEPS = 44 /* u64, accounting build */, M_NEARLY = 62, M_EOPS = 63, M_NTOUCH = 46 /* touched PosDiff-bitmap blocks (OpPdTouched) */, MAIL_N = 72 };
 #define LEAF_CHUNK 1024      // leaves copied together with the mailbox (more -> a second copy)
 
 struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf range
@@ -81,6 +81,7 @@ struct Options {
 	int sweep_shape = -1;              // k_dense_sweep's launch shape: -1 by the number of dense chunks, 0 = four chunks per two-wave workgroup / 160-start segments, 1 = one chunk per four-wave workgroup / 40-start segments
 	int dp_side = 0;                   // 1: the striped DP's lower size class on a stream of its own, beside the upper class (0: behind it)
 	int64_t walk_chain_min = 100000;   // contigs with more seeds than this walk their window chain in slices (k_walk_chain) instead of one workgroup's LDS (k_walk_windows); tests: 0
+	int64_t pd_two_level_min = 2000000;   // PosDiff bitmaps of more blocks than this (a reference above ~1 Gbp) are scanned in two passes: list the touched blocks, count those (tests: 0)
 	int pres_from_kmer = 1;            // the presence table is derived from the k-mer jump table when both hold k-mers of one length (0: always from a scan of the text; a test compares the two)
 	int kmer_k = 0;                    // gsa_create_opts (GSA_CREATE_KMER_K): length of the jump table's k-mers (0: by text length and free memory)
 };

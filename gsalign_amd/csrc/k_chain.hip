@@ -96,6 +96,39 @@ struct OpPdScan {      // over the BLOCKS (32 bitmap words each); a block withou
 	__device__ void emit(i64 blk, const i32 *v, const i32 *ex) const { if (v[0] || ((cb[blk >> 5] >> (blk & 31)) & 1u)) gpre[blk] = ex[0]; }
 	__device__ void done(const i32 *t) const { mail[M_NG] = t[0]; }
 };
+// Round 5: the same numbers in two passes that only look at what is occupied.  Against a human reference the bitmap has 6 M blocks per contig of which
+// a few hundred thousand hold a hit; the pass over ALL blocks was 6 000 tiles of look-back machinery for coarse bits that are zero.  (1) a pass over the
+// coarse WORDS (32 blocks each: 190 000 elements) lists the touched blocks in block order (value = popcount, emit = the set bits' block numbers); (2) a pass
+// over that list counts the group starts of each touched block (one 128-byte line each, all independent) and leaves gpre[block].
+struct OpPdTouched {
+	const u32 *cb; i64 nblk; i32 *tlist, *mail;
+	__device__ i32 value(i64 w, int) const { u32 x = cb[w]; const i64 left = nblk - (w << 5); if (left < 32) x &= left <= 0 ? 0u : ((1u << left) - 1u); return __popc(x); }
+	__device__ void emit(i64 w, const i32 *v, const i32 *ex) const
+	{
+		if (!v[0]) return;
+		u32 x = cb[w]; const i64 left = nblk - (w << 5); if (left < 32) x &= left <= 0 ? 0u : ((1u << left) - 1u);
+		i32 at = ex[0];
+		while (x) { const int b = __ffs((int)x) - 1; x &= x - 1; tlist[at++] = (i32)((w << 5) + b); }
+	}
+	__device__ void done(const i32 *t) const { mail[M_NTOUCH] = t[0]; }
+};
+struct OpPdScanList {
+	const u32 *bm; const i32 *tlist; int max_indel; i32 *gpre, *mail;
+	struct Item { i32 blk, n; };
+	__device__ Item load(i64 j) const
+	{
+		Item it; it.blk = -1; it.n = 0;
+		if (j >= mail[M_NTOUCH]) return it;
+		it.blk = tlist[j];
+		u32 w[33]; pd_block_load(bm, it.blk, w);
+#pragma unroll
+		for (int k = 0; k < 32; k++) it.n += __popc(pd_starts_pair(w[k + 1], w[k], max_indel));
+		return it;
+	}
+	__device__ i32 value(const Item &it, i64, int) const { return it.n; }
+	__device__ void emit(const Item &it, i64, const i32 *, const i32 *ex) const { if (it.blk >= 0) gpre[it.blk] = ex[0]; }
+	__device__ void done(const i32 *t) const { mail[M_NG] = t[0]; }
+};
 // key = (group, qPos, rank among the hits of the same start); val = index of the hit
 __global__ void k_pd_keys(i64 n, const u64 *__restrict__ hkey, const u32 *__restrict__ hval, const u32 *__restrict__ bm, const i32 *__restrict__ gpre, int max_indel, int qbits,
                           u64 *key, u32 *val)
@@ -771,6 +804,12 @@ int stage2_chain(gsa_ctx *c)
 		const i64 nblk = (nw + 31) >> 5;      // blocks of 32 bitmap words (one coarse bit each)
 		ENS(i32, d_gpre, ((nw + 31) >> 5) + 2); ENS(u64, d_key_c, n); ENS(u32, d_val_c, n); ENS(u64, d_key_b, n); ENS(u32, d_val_b, n); ENS(i32, g_beg, n + 2);
 		i32 *mail_ = c->d_mail.as<i32>();
+		if (nblk > c->opt.pd_two_level_min) {
+			// (a large bitmap -- a human reference: 6 M blocks per contig --: the touched blocks are listed first, then only those are counted)
+			const i64 nw2 = (nblk + 31) >> 5;
+			{ OpPdTouched op = { c->d_pdcb.as<u32>(), nblk, c->d_flag.as<i32>(), mail_ }; RC((lb_launch<1, 4>(c, nw2, op))); }
+			{ OpPdScanList op = { c->d_pdbm.as<u32>(), c->d_flag.as<i32>(), c->prm.MaxIndelSize, c->d_gpre.as<i32>(), mail_ }; RC((lb_launch<1, 4>(c, n < nblk ? n : nblk, op, nullptr, 8))); }
+		} else
 		{ OpPdScan op = { c->d_pdbm.as<u32>(), c->d_pdcb.as<u32>(), c->prm.MaxIndelSize, c->d_gpre.as<i32>(), mail_, nw };
 		  if (nblk <= (1 << 20)) RC((lb_launch<1, 1>(c, nblk, op, nullptr, 8))); else RC((lb_launch<1, 4>(c, nblk, op, nullptr, 8))); }      // (a small bitmap: a block per thread -- four in a row are four times two dependent looks)
 		{}      // (eight workgroups per CU: a block costs two dependent looks and nothing else)      // (16 bitmap words per thread: a popcount each -- the pass is the 94 MB read of a 250 Mb contig's bitmap, not 23 000 tiles of look-back)

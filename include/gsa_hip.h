@@ -152,6 +152,8 @@ int  gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *pr
  *                    span of a 250 Mb contig 4.9 -> 1.9 ms, but the refinement passes beside it starve: contig latency 13.7 -> 14.3 ms, throughput -4 % / +4 %); default 0
  *   "walk_chain_min" seeds; a contig with more seeds than this walks its window chain (chaining, GSAlign.cpp:326-338) in slices of the candidate list,
  *                    one launch (default 100 000; below that one workgroup holds the chain in LDS).  Results do not depend on it (tests: 0)
+ *   "pd_two_level_min" blocks; PosDiff bitmaps larger than this are scanned in two passes (touched blocks listed, then counted); default 2 000 000
+ *                    (references above ~1 Gbp).  "pres_from_kmer" 0 = the presence table always from a scan of the text.  Results do not depend on either
  *   "dp_safe", "dp_fake_timeout"   test hooks: one striped DP job per launch; the next n contigs report a stripe hand-off time-out once
  * Unknown names and values outside an option's range (negative sizes, seed_budget 0, ...): GSA_ERR_ARG, nothing changed.
  * Until round 4 some of these were environment variables read by the library (GSA_SPLIT_MIN, GSA_BUNDLE_CONTIG, GSA_BUNDLE_CAP, GSA_SEED_BUDGET,

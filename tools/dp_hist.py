@@ -41,4 +41,7 @@ for i in range(len(edges) - 1):
         if t.any():
             steps = (((nn[t] + 63) // 64) * (mm[t] + 63) * 64).sum()
             print(f"    n ({edges[i]},{edges[i+1]}] m ({edges[j]},{edges[j+1]}]: {int(t.sum()):8d} jobs {cells[t].sum()/1e6:10.1f} Mcells {steps/1e6:10.1f} Msteps")
+o = np.argsort(-cells)[:24]
+print('  largest jobs (m x n):', ' '.join(f'{int(mm[i])}x{int(nn[i])}' for i in o))
+print('  jobs with m > 3968 (one wave per workgroup, hand-off through HBM):', int((mm > 3968).sum()), ' with m in (768, 3968]:', int(((mm > 768) & (mm <= 3968)).sum()), ' cells there:', int(cells[(mm > 768) & (mm <= 3968)].sum()))
 g.close()
