@@ -24,7 +24,7 @@ struct Leaf {
 
 // Device "mailbox" (i32[MAIL_N]) of the counts the stages produce; the host reads the whole
 // box in ONE pinned copy where it needs them instead of one read-back per count.
-enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_NTINY = 40, M_TICKET = 48, M_NBRAW = 49, M_NR2 = 50, M_NF = 51, M_NJOB = 52, M_OPSTOT = 53, M_NALN = 54, M_DPERR = 64, M_NLARGE = 65, M_DPERR2 = 66, M_CELLS = 68 /* two u64: sum m*n, sum m+n */ /* 64..71: cleared together, one aligned 32-byte fill */, M_DPERR3 = 41, M_LBDONE = 42, M_LFSTEPS = 44 /* u64, accounting build */, M_NEARLY = 62, M_EOPS = 63, M_NTOUCH = 46 /* touched PosDiff-bitmap blocks (OpPdTouched) */, MAIL_N = 72 };
+enum { M_NB = 0, M_NC = 1, M_NBLK = 2, M_NG = 3, M_NR = 4, M_NJ = 5, M_NL = 6, M_LBERR = 7, M_ANY = 8, M_NTINY = 40, M_TICKET = 48, M_NBRAW = 49, M_NR2 = 50, M_NF = 51, M_NJOB = 52, M_OPSTOT = 53, M_NALN = 54, M_DPERR = 64, M_NLARGE = 65, M_DPERR2 = 66, M_CELLS = 68 /* two u64: sum m*n, sum m+n */ /* 64..71: cleared together, one aligned 32-byte fill */, M_DPERR3 = 41, M_LBDONE = 42, M_LFSTEPS = 44 /* u64, accounting build */, M_NEARLY = 62, M_EOPS = 63, M_NTOUCH = 46 /* touched PosDiff-bitmap blocks (OpPdTouched) */, M_MAXBLK = 56 /* u64 {score, number} of the best-scoring stage-2 block */, MAIL_N = 72 };
 #define LEAF_CHUNK 1024      // leaves copied together with the mailbox (more -> a second copy)
 
 struct HostBlock {       // one entry of the reference's AlnBlockVec, as leaf range

@@ -545,7 +545,7 @@ struct OpNoise {
 		const i32 p = ex[0];
 		c_q[p] = it.q; c_len[p] = it.len; c_r[p] = it.r; c_g[p] = it.g;
 	}
-	__device__ void done(const i32 *t) const { mail[M_NC] = t[0]; }
+	__device__ void done(const i32 *t) const { mail[M_NC] = t[0]; mail[M_MAXBLK] = 0; mail[M_MAXBLK + 1] = 0; }      // (+ the slot OpBlockFilter's atomicMax fills)
 };
 
 // block heads (GSAlign.cpp:364-374): group head, query gap > MaxSeedGap, or diagonal jump > 100
@@ -588,6 +588,8 @@ struct OpBlockFilter {
 		bkeep[b] = v[0]; bkeepEx[b] = ex[0];
 		if (!v[0]) return;
 		blk_beg[ex[0]] = it.s; blk_end[ex[0]] = it.e; blk_score[ex[0]] = it.score;
+		// the best-scoring kept block {score, its number}: OpEarlyGaps launches no early DP for small blocks inside its query span (see there)
+		atomicMax((unsigned long long *)(mail + M_MAXBLK), ((unsigned long long)(u32)it.score << 32) | (u32)ex[0]);
 	}
 	__device__ void done(const i32 *t) const { mail[M_NBLK] = t[0]; }
 };
@@ -606,13 +608,32 @@ struct OpEarlyGaps {
 	// stages behind (was a kernel of its own in front of this pass)
 	__device__ i32 bid_of(i64 i) const { const i32 b = headEx[i] + head[i] - 1; return bkeep[b] ? bkeepEx[b] : -1; }
 	i32 *e_id, *e_list; i64 *off1, *off2, *opsoff; i32 *mail;
+	// Round 5: WHICH blocks get their large gaps aligned early.  A stage-2 block still has to pass the redundancy filter (RemoveRedundantAlnBlocks,
+	// GSAlign.cpp:415-471: a block covered to 90 % by an overlapping better one goes), and the reference only aligns the gaps of the blocks that do
+	// (FillAlnBlockGaps comes behind it, :510-513).  On repeat-rich input most stage-2 blocks are copy-against-copy alignments of interspersed repeats
+	// inside the span of the contig's main block -- sparse seeds, kilobase gaps -- and every one of them is removed there: the human-like workload
+	// launched 12 900 workgroups of the upper size class early for 304 jobs of that class in the final result (12.5 of a contig's 30 ms).  So a block
+	// whose query span lies inside the best-scoring block's and that scores under a quarter of it -- or under a sixteenth of it wherever it lies (a
+	// contig cut into several main blocks by N runs: the copy-against-copy blocks inside the second and third are as redundant) -- is left to the late
+	// launch (which aligns whatever survives and was not aligned early: nothing is assumed).  Only WHEN a gap is aligned changes, never what is aligned.
+	const i32 *blk_beg, *blk_end, *blk_score;
+	__device__ bool early_block(i32 b) const
+	{
+		const unsigned long long mx = *(const unsigned long long *)(mail + M_MAXBLK);
+		const i32 bm = (i32)(u32)mx; const i64 sm = (i64)(mx >> 32);
+		if (b == bm || (i64)blk_score[b] * 4 >= sm) return true;
+		if ((i64)blk_score[b] * 16 < sm) return false;
+		const i32 qs = q[blk_beg[b]], qe = q[blk_end[b] - 1] + len[blk_end[b] - 1];
+		const i32 ms = q[blk_beg[bm]], me = q[blk_end[bm] - 1] + len[blk_end[bm] - 1];
+		return !(qs >= ms && qe <= me);
+	}
 	i32 *e_rec;      // record of an early job, -1 until stage 7 finds it (k_gap_class)
 	__device__ bool gap(i64 s, i32 &qp, i64 &rp, i32 &qg, i32 &rg) const
 	{
 		// same block, and one that AddAlnBlock keeps: the raw blocks it drops are pairs of stray seeds kilobases apart -- listing
 		// their gaps (measured: right behind the block heads, 12 us earlier) costs 0.45 ms of wasted striped DP on a 50 Mb contig
 		if (s + 1 >= mail[M_NC]) return false;
-		{ const i32 b0 = bid_of(s); if (b0 < 0 || bid_of(s + 1) != b0) return false; }
+		{ const i32 b0 = bid_of(s); if (b0 < 0 || bid_of(s + 1) != b0 || !early_block(b0)) return false; }
 		qp = q[s] + len[s]; rp = r[s] + len[s];
 		qg = q[s + 1] - qp; if (qg < 0) qg = 0;
 		const i64 rg64 = r[s + 1] - rp; rg = rg64 < 0 ? 0 : (i32)rg64;
@@ -890,7 +911,8 @@ int stage2_chain(gsa_ctx *c)
 	ENS(i32, e_id, na + 2); ENS(i32, e_rec, na + 2); ENS(i32, e_list, 3 * (na + 1)); ENS(i64, e_off1, na + 1); ENS(i64, e_off2, na + 1); ENS(i64, e_opsoff, na + 2);
 	if (!pin_ensure<i32>(c, c->p_early, 4 + 3 * (size_t)EARLY_CHUNK)) return GSA_ERR_NOMEM;
 	{ OpEarlyGaps op = { c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), bhead, bheadEx, bkeep, bkeepEx, c->c_bid.as<i32>(), c->q_dev, c->di.ref,
-	                     c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail, c->e_rec.as<i32>(),
+	                     c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail,
+	                     c->blk_beg.as<i32>(), c->blk_end.as<i32>(), c->blk_score.as<i32>(), c->e_rec.as<i32>(),
 	                     c->p_early.as<i32>(), (i32)std::min<i64>(na, EARLY_CHUNK) }; RC((lb_launch<2>(c, na, op))); }
 	GSA_CHECK(c, hipEventRecord(c->ev[16], st));
 	c->early_listed = true;
