@@ -393,6 +393,7 @@ struct StripeJob { i32 job, m, n, P; i64 diroff, bndoff; i32 ctr, first_block; }
 #define DP_LOOK 21
 #define DP_WAIT_TICKS 200000000ull   // bound of a hand-off wait: 2 s of the 100 MHz wall clock
 #define DP_CLASS_M 768          // size classes of a long job list: reference fragments above / up to this (see launch_stripes)
+#define DP_CLASS_TOP 1536       // ... and, round 5, the upper class cut once more: fragments above this keep the 64 KB layout, (768, 1536] run with 26 KB
 #define DP_CLASS_MIN_JOBS 4096
 #define DP_LDS_M 3968         // longest reference fragment for which four waves share a workgroup (selectors + 3 boundary columns in 64 KB of LDS)
 
@@ -825,13 +826,17 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 	// contig: 700 jobs) stay one launch -- there the second kernel would only wait for the longest job of the first.
 	// (in front of both: the few fragments above DP_LDS_M, whose boundary columns do not fit LDS -- one wave per workgroup, hand-off
 	//  through HBM; they used to drag the whole upper class down to that layout)
-	size_t n_xl = 0, n_hi = large.size();
+	// Round 5: the upper class is cut once more at DP_CLASS_TOP.  Its workgroups hold 16 bytes of LDS per reference row of the class's LONGEST fragment
+	// (53 - 64 KB: two or three workgroups per CU), while nine in ten of its jobs are shorter than 1 536 rows (26 KB: six per CU) -- the class ran
+	// four rounds of ~0.5 ms on a 250 Mb contig although its longest job needs one.
+	size_t n_xl = 0, n_top = large.size(), n_hi = large.size();
 	{
 		auto it0 = std::stable_partition(large.begin(), large.end(), [](const LgJob &g) { return g.m > DP_LDS_M; });
 		n_xl = (size_t)(it0 - large.begin());
 		if (large.size() >= DP_CLASS_MIN_JOBS) {
-			auto it = std::stable_partition(it0, large.end(), [](const LgJob &g) { return g.m > DP_CLASS_M; });
-			n_hi = (size_t)(it - large.begin());
+			auto it1 = std::stable_partition(it0, large.end(), [](const LgJob &g) { return g.m > DP_CLASS_TOP; });
+			auto it = std::stable_partition(it1, large.end(), [](const LgJob &g) { return g.m > DP_CLASS_M; });
+			n_top = (size_t)(it1 - large.begin()); n_hi = (size_t)(it - large.begin());
 		}
 	}
 	for (const LgJob &g : large) if ((((g.m + 63) & ~63) + DP_C1_PAD) * 4 > 150 * 1024) return gsa_fail(c, GSA_ERR_LIMIT, "DP reference-side fragment longer than 38000 bases");
@@ -844,9 +849,10 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		else { size_t l = first; i64 db = 128; while (l < large.size()) { const i64 cells = (((i64)large[l].n + 63) / 64) * (i64)DP_STRIPE_BYTES(large[l].m); if (l > first && db + cells > budget) break; db += cells + 128; l++; } cnt = l - first; }
 		// (the early launch and a late one may be in flight together: each has its own table)
 		DevBuf &psj = err_slot == M_DPERR3 ? c->p_sj_early : c->p_sj;
-		// the segments of this batch: [first, s0) above DP_LDS_M, [s0, s1) above the class limit, [s1, first + cnt) below
-		const size_t s0 = std::min(std::max(n_xl, first), first + cnt), s1 = std::min(std::max(n_hi, first), first + cnt);
-		struct Seg { size_t b, e; int mmax, wpb, mpad, lds_rows; size_t dyn_lds; i32 *b2j; i32 nblocks; } seg[3] = { { first, s0 }, { s0, s1 }, { s1, first + cnt } };
+		// the segments of this batch: [first, s0) above DP_LDS_M, [s0, st) above DP_CLASS_TOP, [st, s1) above DP_CLASS_M, [s1, first + cnt) below
+		const size_t s0 = std::min(std::max(n_xl, first), first + cnt), stp = std::min(std::max(n_top, first), first + cnt), s1 = std::min(std::max(n_hi, first), first + cnt);
+		constexpr int NSEG = 4;
+		struct Seg { size_t b, e; int mmax, wpb, mpad, lds_rows; size_t dyn_lds; i32 *b2j; i32 nblocks; } seg[NSEG] = { { first, s0 }, { s0, stp }, { stp, s1 }, { s1, first + cnt } };
 		size_t nb_ub = 0;
 		for (Seg &sg : seg) {
 			sg.mmax = 1;
@@ -861,7 +867,7 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		if (!pin_ensure<char>(c, psj, (cnt + 1) * sizeof(StripeJob) + (nb_ub + 2) * 4)) return GSA_ERR_NOMEM;
 		StripeJob *sj = psj.as<StripeJob>();
 		i32 *b2j_all = (i32 *)(sj + cnt + 1);
-		i64 dbytes = 128, bwords = 0; i32 nctr = 3; size_t b2j_used = 0;      // (ctr[0 .. 2]: launch tickets of the size classes)
+		i64 dbytes = 128, bwords = 0; i32 nctr = NSEG; size_t b2j_used = 0;      // (ctr[0 .. NSEG-1]: launch tickets of the size classes)
 		for (Seg &sg : seg) {
 			sg.b2j = b2j_all + b2j_used; sg.nblocks = 0;
 			for (size_t k = sg.b; k < sg.e; k++) {
@@ -892,13 +898,13 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 		//  was measured at 250 Mb: same step time, the refinement passes beside them starve instead: the chip is busy either way)
 		// (option dp_side: the lower class on a stream of its own -- it then starts with the upper one instead of behind it; the classes share
 		//  nothing but the error word: tickets per class, direction / boundary bytes per job)
-		const bool side = c->opt.dp_side && c->stream_aux[3] && seg[2].nblocks > 0 && (seg[0].nblocks > 0 || seg[1].nblocks > 0);
+		const bool side = c->opt.dp_side && c->stream_aux[3] && seg[NSEG - 1].nblocks > 0 && (seg[0].nblocks > 0 || seg[1].nblocks > 0 || seg[2].nblocks > 0);
 		if (side) { GSA_CHECK(c, hipEventRecord(c->ev[24], st)); GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[3], c->ev[24], 0)); }
 		hipStream_t st_main = st;
-		for (int si = 0; si < 3; si++) {
+		for (int si = 0; si < NSEG; si++) {
 			const Seg &sg = seg[si];
 			if (sg.nblocks == 0) continue;
-			hipStream_t st = (side && si == 2) ? c->stream_aux[3] : st_main;
+			hipStream_t st = (side && si == NSEG - 1) ? c->stream_aux[3] : st_main;
 			if (sg.wpb == 4) hipLaunchKernelGGL(k_dp_stripe<4>, dim3((unsigned)sg.nblocks), dim3(256), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
 			else hipLaunchKernelGGL(k_dp_stripe<1>, dim3((unsigned)sg.nblocks), dim3(64), sg.dyn_lds, st, (const i32 *)sg.b2j, (const StripeJob *)sj, pool1, off1, pool2, off2, dir + 256, bnd, ctr, rev, ops, ops_off, ops_len, c->dp_epoch, (i32)(sg.mpad * 4), (i32)sg.lds_rows, (u32 *)(mail + err_slot), si);
 		}

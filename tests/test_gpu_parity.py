@@ -332,6 +332,24 @@ def test_long_kmer_table(oracle_built, tmp_path, monkeypatch, k, wide):
     o.close(); g.close()
 
 
+def test_host_register_in_place(oracle_built, tmp_path):
+    """gsa_host_register (round 5): a sequence page-locked where the loader put it aligns to the same result as from pageable memory and as the
+    oracle says; registering twice / unregistering something else reports GSA_ERR_HIP instead of failing later."""
+    import ctypes as C
+    refs, qrys = synth.make_pair_fast(1200000, 1, 0.02, seed=64)
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx); g = capi.Aligner(idx)
+    q = np.ascontiguousarray(qrys[0][1])
+    lib = g.lib
+    lib.gsa_host_register.argtypes = [C.c_void_p, C.c_size_t]; lib.gsa_host_unregister.argtypes = [C.c_void_p]
+    assert lib.gsa_host_register(C.c_void_p(q.ctypes.data), q.size) == 0
+    _same_as_oracle(o, g, [("q", q)])
+    assert lib.gsa_host_unregister(C.c_void_p(q.ctypes.data)) == 0
+    _same_as_oracle(o, g, [("q", q)])
+    assert lib.gsa_host_register(None, 10) != 0 and lib.gsa_host_unregister(C.c_void_p(q.ctypes.data)) != 0
+    o.close(); g.close()
+
+
 def test_striped_dp_fallback_path(oracle_built, tmp_path, monkeypatch):
     """The safety net behind the striped DP's bounded hand-off wait: one job per launch (GSA_DP_SAFE=1 forces it)."""
     monkeypatch.setenv("GSA_DP_SAFE", "1")
