@@ -353,6 +353,7 @@ int gsa_set_option(gsa_ctx *c, const char *name, int64_t value)
 	else if (k == "pd_bitmap") c->opt.pd_bitmap = value != 0;
 	else if (k == "dp_side") c->opt.dp_side = value != 0;
 	else if (k == "pd_two_level_min") { if (!in(0, BIG)) return gsa_fail(c, GSA_ERR_ARG, "pd_two_level_min: >= 0 blocks"); c->opt.pd_two_level_min = value; }
+	else if (k == "dp_occupancy") { if (!in(0, 16)) return gsa_fail(c, GSA_ERR_ARG, "dp_occupancy: 0 (off) .. 16 workgroups per CU"); c->opt.dp_occupancy = (int)value; }
 	else if (k == "pres_from_kmer") c->opt.pres_from_kmer = value != 0;      // (takes effect at the next gsa_set_params that rebuilds the table)
 	else if (k == "walk_chain_min") { if (!in(0, BIG)) return gsa_fail(c, GSA_ERR_ARG, "walk_chain_min: >= 0 seeds"); c->opt.walk_chain_min = value; }
 	else if (k == "sweep_shape") { if (value < -1 || value > 1) return gsa_fail(c, GSA_ERR_ARG, "sweep_shape: -1, 0 or 1"); c->opt.sweep_shape = (int)value; }

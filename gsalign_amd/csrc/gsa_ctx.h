@@ -82,6 +82,7 @@ struct Options {
 	int dp_side = 0;                   // 1: the striped DP's lower size class on a stream of its own, beside the upper class (0: behind it)
 	int64_t walk_chain_min = 100000;   // contigs with more seeds than this walk their window chain in slices (k_walk_chain) instead of one workgroup's LDS (k_walk_windows); tests: 0
 	int64_t pd_two_level_min = 2000000;   // PosDiff bitmaps of more blocks than this (a reference above ~1 Gbp) are scanned in two passes: list the touched blocks, count those (tests: 0)
+	int dp_occupancy = 0;              // > 0: at most this many striped-DP workgroups per CU (LDS padding): leaves wave slots for the passes beside it (experiment; 0 = off)
 	int pres_from_kmer = 1;            // the presence table is derived from the k-mer jump table when both hold k-mers of one length (0: always from a scan of the text; a test compares the two)
 	int kmer_k = 0;                    // gsa_create_opts (GSA_CREATE_KMER_K): length of the jump table's k-mers (0: by text length and free memory)
 };

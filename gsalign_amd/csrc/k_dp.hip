@@ -862,6 +862,9 @@ int launch_stripes(gsa_ctx *c, hipStream_t st, std::vector<LgJob> &large, const 
 			sg.lds_rows = (sg.mmax + 15) & ~15;
 			sg.dyn_lds = (size_t)sg.mpad * 4 + (sg.wpb > 1 ? (size_t)(sg.wpb - 1) * sg.lds_rows * 4 : 0);      // (one selector dword per row)
 			if (sg.dyn_lds < (size_t)DP_TILE_ROWS * 32) sg.dyn_lds = (size_t)DP_TILE_ROWS * 32;      // (the traceback tile -- nibbles -- lives in the same bytes)
+			// option dp_occupancy (experiment): a four-wave workgroup of the lower classes asks for 1/occ of a CU's LDS, so that at most `occ` of them sit on a
+			// CU and one or two workgroup slots stay free for the fused passes that run beside the striped kernel (they wait for wave slots otherwise)
+			if (c->opt.dp_occupancy > 0 && sg.wpb == 4) { const size_t want = (size_t)(160 * 1024) / (size_t)c->opt.dp_occupancy - 1024; if (sg.dyn_lds < want && want <= 64 * 1024) sg.dyn_lds = want; }
 			for (size_t k = sg.b; k < sg.e; k++) nb_ub += (size_t)((((large[k].n + 63) / 64 + 1) / 2 + sg.wpb - 1) / sg.wpb);      // (a wave takes two stripes)
 		}
 		if (!pin_ensure<char>(c, psj, (cnt + 1) * sizeof(StripeJob) + (nb_ub + 2) * 4)) return GSA_ERR_NOMEM;
