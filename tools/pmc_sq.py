@@ -13,7 +13,7 @@ for fn in sorted(os.listdir(D)):
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[k][r["Counter_Name"]] += int(r["Launches"]) if "Launches" in r else 1
 cols = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
         "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
-print(f"# rocprofv3 --pmc SQ counters, bench.py --workload {W} --inflight 1, per launch (mean); two passes of 8 counters")
+print(f"# rocprofv3 --pmc SQ counters, bench.py --workload {W} the workload's own --inflight (4 contexts; counter collection serialises the dispatches), per launch (mean); two passes of 8 counters")
 print(f"{'kernel':44s} {'launches':>8s} " + " ".join(f"{c[3:][:13]:>13s}" for c in cols))
 rows = sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0))
 for k, d in rows[:32]:

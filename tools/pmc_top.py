@@ -25,6 +25,8 @@ GROUPS = {      # key in the json -> predicate on the (mangled) kernel name
 
 def commit():
     """The commit the counters belong to: the tree gpurun shipped = HEAD (+ '-dirty' when the work tree differs)."""
+    if os.environ.get("GSA_PMC_COMMIT"):          # (the counters were taken on a gpurun snapshot of an earlier commit than the tree this script runs in)
+        return os.environ["GSA_PMC_COMMIT"]
     try:
         h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
         dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True).stdout.strip()
