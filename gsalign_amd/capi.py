@@ -256,7 +256,8 @@ class Aligner:
         # kmer_k (or GSA_KMER_K): GSA_CREATE_KMER_K
         wide = wide or os.environ.get("GSA_FORCE_WIDE", "0") not in ("", "0")
         kmer_k = kmer_k or int(os.environ.get("GSA_KMER_K", "0") or 0)
-        flags = (1 if wide else 0) | ((kmer_k & 15) << 8)
+        prio = int(os.environ.get("GSA_PRIO", "0") or 0)          # GSA_CREATE_PRIO (experiments / bench: stream priorities)
+        flags = (1 if wide else 0) | ((kmer_k & 15) << 8) | ((prio & 3) << 16)
         rc = self.lib.gsa_create_opts(device, C.byref(v), C.byref(p), flags, C.byref(self.ctx))
         if rc != 0:
             raise GsaError(f"gsa_create -> {rc}: {self.lib.gsa_last_error(None).decode()}")

@@ -111,7 +111,18 @@ static int ctx_private_init(gsa_ctx *c, gsa_ctx *share = nullptr)
 		for (int i = 0; i < 4; i++) GSA_CHECK(c, hipStreamCreateWithPriority(&c->stream_aux[i], hipStreamDefault, (i == 0 || i == 3 || (prio > 1 && i == 1)) ? lo : hi));
 	} else
 #endif
-	{
+	if (c->prio_mode > 0) {
+		// GSA_CREATE_PRIO(mode): the MAIN stream -- the ~45 short passes of chaining / refinement / the extend stage's bookkeeping: little work, but every one of
+		// them is a dispatch that has to find wave slots between the long kernels of the other contexts (measured with four contexts on the human index:
+		// those phases take 6x their time alone, 11 of a contig's 19 ms: profiles/r05_contig_phases_human_full.txt) -- at the greatest priority; the seed-search
+		// kernels move to a stream of their own (mode 1, 3: normal; mode 2: least) so that they do not inherit it; the striped DP's stream normal (mode 3: least)
+		int lo = 0, hi = 0; GSA_CHECK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));      // (lo = least, hi = greatest priority: numerically lo >= hi)
+		const int mid = (lo + hi) / 2;
+		GSA_CHECK(c, hipStreamCreateWithPriority(&c->stream, hipStreamDefault, hi));
+		GSA_CHECK(c, hipStreamCreateWithPriority(&c->stream_seed, hipStreamDefault, c->prio_mode == 2 ? lo : mid));
+		GSA_CHECK(c, hipEventCreateWithFlags(&c->ev_seed_fork, hipEventDisableTiming));
+		for (int i = 0; i < 4; i++) GSA_CHECK(c, hipStreamCreateWithPriority(&c->stream_aux[i], hipStreamDefault, (c->prio_mode == 3 && (i == 0 || i == 3)) ? lo : mid));
+	} else {
 	GSA_CHECK(c, hipStreamCreate(&c->stream));
 	for (int i = 0; i < 4; i++) GSA_CHECK(c, hipStreamCreate(&c->stream_aux[i]));
 	}
@@ -177,10 +188,10 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gsa_fail(nullptr, GSA_ERR_HIP, "no HIP device available (libgsa_hip.so has no CPU path)");
 	if (device < 0 || device >= ndev) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create: bad device ordinal");
-	if (flags & ~(uint32_t)(GSA_CREATE_WIDE | GSA_CREATE_KMER_K(15))) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create_opts: unknown flag");
+	if (flags & ~(uint32_t)(GSA_CREATE_WIDE | GSA_CREATE_KMER_K(15) | GSA_CREATE_PRIO(3))) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create_opts: unknown flag");
 	{ const uint32_t kk = (flags >> 8) & 15u; if (kk == 1) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create_opts: GSA_CREATE_KMER_K takes 2 .. 15 (0: chosen by text length and free memory)"); }
 	gsa_ctx *c = new gsa_ctx();
-	c->device = device; c->force_wide = (flags & GSA_CREATE_WIDE) != 0; c->opt.kmer_k = (int)((flags >> 8) & 15u);
+	c->device = device; c->force_wide = (flags & GSA_CREATE_WIDE) != 0; c->opt.kmer_k = (int)((flags >> 8) & 15u); c->prio_mode = (int)((flags >> 16) & 3u);
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
 #define CK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gsa_fail(nullptr, GSA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); gsa_destroy(c); return GSA_ERR_HIP; } } while (0)
 	CK(hipSetDevice(device));
@@ -271,7 +282,7 @@ int gsa_clone(gsa_ctx *parent, gsa_ctx **out)
 	if (!parent || !out) return GSA_ERR_ARG;
 	if (hipSetDevice(parent->device) != hipSuccess) return gsa_fail(nullptr, GSA_ERR_HIP, "hipSetDevice");
 	gsa_ctx *c = new gsa_ctx();
-	c->device = parent->device; c->force_wide = parent->force_wide;
+	c->device = parent->device; c->force_wide = parent->force_wide; c->prio_mode = parent->prio_mode;
 	c->index_owner = parent->index_owner ? parent->index_owner : parent; c->seed_budget = parent->seed_budget; c->opt = parent->opt;
 	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
 	if (int rc = ctx_private_init(c, c->index_owner)) { g_create_error = c->err; gsa_destroy(c); return rc; }

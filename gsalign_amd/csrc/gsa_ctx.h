@@ -103,6 +103,7 @@ struct gsa_ctx {
 	gsa_ctx *index_owner = nullptr;                // gsa_clone: the context whose device index this one borrows (nullptr = own)
 	gsa_ctx *lender = nullptr;                     // gsa_clone: the context `di` was copied from -- its presence bitmap / short k-mer table are read through that copy
 	std::atomic<int> n_borrowers{0};               // live clones made FROM this context (gsa_set_params must not rebuild the tables they read)
+	int prio_mode = 0;                             // GSA_CREATE_PRIO: stream priorities (0: none; see ctx_private_init)
 	bool force_wide = false;                       // GSA_CREATE_WIDE: 64-bit dense SA + 32-byte k-mer entries whatever the text length (the >= 2^32-row layout)
 	bool profiling = false;
 	bool prof_seed = false;                        // time the seed kernel only (two events instead of ten per contig)

@@ -219,8 +219,11 @@ struct OpCand {
 // candidate behind it (the head of the next big group) or to na
 __global__ void k_next_window(i64 na, const i32 *__restrict__ a_q, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge,
                               const i32 *__restrict__ uniq, const i32 *__restrict__ cuEx, const i32 *__restrict__ brk, const i32 *__restrict__ brkEx,
-                              const i32 *__restrict__ blist, const i32 *__restrict__ candf, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, i32 *next, i32 *nextk)
+                              const i32 *__restrict__ blist, const i32 *__restrict__ candf, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, i32 *next, i32 *nextk,
+                              uint4 *tab_clear, i64 tab_cap)
 {
+	// (the outlier filter's hash table -- empty = all bits set -- is cleared here, two stages ahead of its use, instead of by a fill operation of its own)
+	for (i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x; j < tab_cap; j += (i64)gridDim.x * blockDim.x) tab_clear[j] = make_uint4(~0u, ~0u, ~0u, ~0u);
 	GID(na);
 	if (!candf[i]) { next[i] = -1; return; }
 	const i32 gb = a_gb[i], ge = a_ge[i];
@@ -457,58 +460,69 @@ __global__ void k_window_avg(i64 na, const i32 *__restrict__ slot_of, const Buck
 	if (i < na && vn > 0 && (lane == 63 || nw != w)) { atomicAdd(&wsum[w], vs); atomicAdd(&wn[w], vn); }
 }
 
-__global__ void k_outlier_kill(i64 na, const i32 *__restrict__ slot_of, const Bucket *__restrict__ tab, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r,
-                               const unsigned long long *__restrict__ wbest, const unsigned long long *__restrict__ wsum, const i32 *__restrict__ wn,
-                               i64 G, i32 max_indel, i32 *alive, Bundle bnd)
-{
-	GID(na);
-	const i32 sl = slot_of[i];
-	if (sl < 0) return;
-	const unsigned long long k = tab[sl].key; const u32 w = (u32)(k >> 32);
-	const i64 kk = (i64)(u32)k, mode = (i64)(0xFFFFFFFFu - (u32)wbest[w]);
-	const i32 cnt = d_llabs(kk - mode) < 3 ? (i32)(tab[sl].cnt + 1u) : 0;       // counts are read after zeroing (App. B #23)
-	const i64 avg = wn[w] > 0 ? (i64)wsum[w] / wn[w] : G;                      // C division: truncation toward zero
-	const i64 pd = a_r[i] - a_q[i] + bundle_off(bnd, a_q[i]);
-	if (d_llabs(avg - pd) > max_indel && cnt < 3) alive[i] = 0;               // GSAlign.cpp:290, Min_PD_Freq = 3
-}
-
 // ---- D. multi-hit query positions (GSAlign.cpp:178-225,341-350) -------------------
-struct OpAliveUnique {      // ranks of the alive unique seeds
-	i64 na; const i32 *uniq, *alive; i32 *auEx, *aulist;
-	__device__ i32 value(i64 i, int) const { return (uniq[i] && alive[i]) ? 1 : 0; }
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const { auEx[i] = ex[0]; if (v[0]) aulist[ex[0]] = (i32)i; }
+// Round 5: RemoveOutlierSeeds' verdict (GSAlign.cpp:260-296; a kernel of its own until now, k_outlier_kill) is taken where the alive unique seeds are ranked:
+// load() decides "outlier" from the window's modal bucket, mean and this seed's bucket count, emit() writes alive[] and the rank.
+struct OpAliveUnique {      // outlier verdict + ranks of the alive unique seeds
+	i64 na; const i32 *uniq; i32 *alive, *auEx, *aulist;
+	const i32 *slot_of; const Bucket *tab; const i32 *a_q; const i64 *a_r; const unsigned long long *wbest, *wsum; const i32 *wn; i64 G; i32 max_indel; Bundle bnd;
+	struct Item { i32 alive, uniq; };
+	__device__ Item load(i64 i) const
+	{
+		Item it; it.uniq = uniq[i]; it.alive = 1;                                    // (every seed is alive in front of this pass: OpUniqBrk)
+		const i32 sl = slot_of[i];
+		if (sl < 0) return it;
+		const unsigned long long k = tab[sl].key; const u32 w = (u32)(k >> 32);
+		const i64 kk = (i64)(u32)k, mode = (i64)(0xFFFFFFFFu - (u32)wbest[w]);
+		const i32 cnt = d_llabs(kk - mode) < 3 ? (i32)(tab[sl].cnt + 1u) : 0;       // counts are read after zeroing (App. B #23)
+		const i64 avg = wn[w] > 0 ? (i64)wsum[w] / wn[w] : G;                      // C division: truncation toward zero
+		const i32 q = a_q[i];
+		const i64 pd = a_r[i] - q + bundle_off(bnd, q);
+		if (d_llabs(avg - pd) > max_indel && cnt < 3) it.alive = 0;               // GSAlign.cpp:290, Min_PD_Freq = 3
+		return it;
+	}
+	__device__ i32 value(const Item &it, i64, int) const { return (it.uniq && it.alive) ? 1 : 0; }
+	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const { alive[i] = it.alive; auEx[i] = ex[0]; if (v[0]) aulist[ex[0]] = (i32)i; }
 	__device__ void done(const i32 *t) const { auEx[na] = t[0]; }
 };
 
-__global__ void k_multihit(i64 na, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, const i32 *__restrict__ a_gb, const i32 *__restrict__ a_ge,
-                           const i32 *__restrict__ auEx, const i32 *__restrict__ aulist, i64 G, i32 max_indel, i32 *alive, Bundle bnd)
+// FindNeighboringPosDiffAvg / RemoveRedundantSeeds for the multi-hit run that holds seed i (GSAlign.cpp:178-225,341-350): the member of the run that stays
+// (-1: none).  Every member of a run computes the same answer from the ranked alive unique seeds around the run (a kernel of its own per run HEAD until round
+// 5, k_multihit; now part of the compaction pass: a run is a handful of seeds, a hundred at most).
+__device__ __forceinline__ i32 multihit_keep(i64 i, const i32 *__restrict__ a_q, const i64 *__restrict__ a_r, i32 gb, i32 ge, const i32 *__restrict__ auEx, const i32 *__restrict__ aulist,
+                                             i64 G, i32 max_indel, const Bundle &bnd)
 {
-	GID(na);
-	const i32 gb = a_gb[i], ge = a_ge[i], q = a_q[i];
-	if (!(i + 1 < ge && a_q[i + 1] == q) || (i > gb && a_q[i - 1] == q)) return;   // not the head of a multi-hit run
+	const i32 q = a_q[i];
+	i32 h = (i32)i; while (h > gb && a_q[h - 1] == q) h--;
 	i32 j = (i32)i + 1; while (j < ge && a_q[j] == q) j++;
 	i64 s1 = 0, s2 = 0; i32 n1 = 0, n2 = 0;
-	for (i32 k = auEx[i] - 1; k >= auEx[gb] && n1 < 5; k--) { const i32 s = aulist[k]; s1 += a_r[s] - a_q[s]; n1++; }
+	for (i32 k = auEx[h] - 1; k >= auEx[gb] && n1 < 5; k--) { const i32 s = aulist[k]; s1 += a_r[s] - a_q[s]; n1++; }
 	for (i32 k = auEx[j]; k < auEx[ge] && n2 < 5; k++) { const i32 s = aulist[k]; s2 += a_r[s] - a_q[s]; n2++; }
 	// (a bundle: a group lies in one contig; the mean is taken over TRUE PosDiff values -- C division truncates toward zero)
 	const i64 o = bundle_off(bnd, q);
-	const i64 avg = (n1 > 0 || n2 > 0) ? (s1 + s2 + o * (n1 + n2)) / (n1 + n2) : (a_r[i] - q + o);
+	const i64 avg = (n1 > 0 || n2 > 0) ? (s1 + s2 + o * (n1 + n2)) / (n1 + n2) : (a_r[h] - q + o);
 	i32 idx = -1; i64 md = G;
-	for (i32 k = (i32)i; k < j; k++) { const i64 d = d_llabs((a_r[k] - q + o) - avg); if (d < max_indel && d < md) { md = d; idx = k; } }
-	for (i32 k = (i32)i; k < j; k++) if (k != idx) alive[k] = 0;
+	for (i32 k = h; k < j; k++) { const i64 d = d_llabs((a_r[k] - q + o) - avg); if (d < max_indel && d < md) { md = d; idx = k; } }
+	return idx;
 }
 
 // ---- E. compaction, noise stencil, block cuts -----------------------------------
 // After the first compaction only "is my neighbour in my group" is ever asked, so the seeds
 // carry a group id (the group's old begin index) instead of group bounds.
 struct OpCompactAlive {
-	const i32 *alive, *a_q, *a_len; const i64 *a_r; const i32 *a_gb;
+	const i32 *alive, *a_q, *a_len; const i64 *a_r; const i32 *a_gb, *a_ge, *auEx, *aulist; i64 G; i32 max_indel; Bundle bnd;
 	i32 *b_q, *b_len; i64 *b_r; i32 *b_g, *mail;
 	struct Item { i32 alive, q, len, g; i64 r; };
 	__device__ Item load(i64 i) const
 	{
 		Item it; it.alive = alive[i] ? 1 : 0; it.q = it.len = it.g = 0; it.r = 0;
-		if (it.alive) { it.q = a_q[i]; it.len = a_len[i]; it.r = a_r[i]; it.g = a_gb[i]; }
+		if (!it.alive) return it;
+		it.q = a_q[i]; it.g = a_gb[i];
+		const i32 ge = a_ge[i];
+		if ((i + 1 < ge && a_q[i + 1] == it.q) || (i > it.g && a_q[i - 1] == it.q)) {      // a multi-hit query position: one member of the run stays at most
+			if (multihit_keep(i, a_q, a_r, it.g, ge, auEx, aulist, G, max_indel, bnd) != (i32)i) { it.alive = 0; return it; }
+		}
+		it.len = a_len[i]; it.r = a_r[i];
 		return it;
 	}
 	__device__ i32 value(const Item &it, i64, int) const { return it.alive; }
@@ -859,7 +873,11 @@ int stage2_chain(gsa_ctx *c)
 	{ OpUniqBrk op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, brk, alive, cuEx, brkEx, blist }; RC((lb_launch<2>(c, na, op))); }
 	i32 *candf = c->d_flag.as<i32>(), *candEx = c->d_scan.as<i32>(), *clist = c->a_runinfo.as<i32>();
 	{ OpCand op = { na, c->a_gb.as<i32>(), c->a_ge.as<i32>(), cuEx, brk, candf, candEx, clist, ws }; RC((lb_launch<1>(c, na, op))); }
-	LAUNCH(k_next_window, na, na, c->a_q.as<i32>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, cuEx, brk, brkEx, blist, candf, candEx, clist, next, c->d_flag2.as<i32>());
+	int capbits = 10; while ((1ull << capbits) < 2 * (u64)na) capbits++;      // the outlier filter's (window, bucket) table: load factor <= 1/2
+	const i64 cap = 1ll << capbits;
+	ENS(Bucket, d_btab, cap);
+	static_assert(sizeof(Bucket) == 16, "the table is cleared as uint4s");
+	LAUNCH(k_next_window, na, na, c->a_q.as<i32>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, cuEx, brk, brkEx, blist, candf, candEx, clist, next, c->d_flag2.as<i32>(), c->d_btab.as<uint4>(), cap);
 	if (na <= c->opt.walk_chain_min) hipLaunchKernelGGL(k_walk_windows, dim3(1), dim3(WALK_T), 0, st, na, candEx, clist, next, c->d_flag2.as<i32>(), ws);
 	else {
 		// (large contigs: slices of the candidate list, one launch -- k_walk_chain; candidates <= seeds bounds the grid, the ticket counter and the
@@ -876,25 +894,19 @@ int stage2_chain(gsa_ctx *c)
 	// C. outliers
 	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);
 	const i64 bmin = ((-(i64)c->qlen) >> 4) - 1;
-	int capbits = 10; while ((1ull << capbits) < 2 * (u64)na) capbits++;      // load factor <= 1/2
-	const i64 cap = 1ll << capbits;
-	ENS(Bucket, d_btab, cap);
-	GSA_CHECK(c, hipMemsetAsync(c->d_btab.p, 0xff, (size_t)cap * sizeof(Bucket), st));
 	i32 *slot_of = c->a_runinfo.as<i32>();
 	{ OpWindowBuckets op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, bmin, capbits, wsEx, slot_of, c->d_btab.as<Bucket>(),
 	                         c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>() }; RC((lb_launch<1, 4>(c, na, op))); }
 	LAUNCH(k_window_mode, cap, cap, c->d_btab.as<Bucket>(), c->w_best.as<unsigned long long>());
 	LAUNCH(k_window_avg, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(), c->w_best.as<unsigned long long>(), ws, wsEx,
 	       c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->bnd);
-	LAUNCH(k_outlier_kill, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(),
-	       c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->G, c->prm.MaxIndelSize, alive, c->bnd);
-	// D. multi-hit positions
+	// D. outlier verdict + ranks of the alive unique seeds (one pass); the multi-hit positions are settled inside the compaction pass
 	i32 *auEx = c->a_aurank.as<i32>(), *aulist = c->a_aulist.as<i32>();
-	{ OpAliveUnique op = { na, uniq, alive, auEx, aulist }; RC((lb_launch<1>(c, na, op))); }
-	LAUNCH(k_multihit, na, na, c->a_q.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), auEx, aulist, c->G, c->prm.MaxIndelSize, alive, c->bnd);
+	{ OpAliveUnique op = { na, uniq, alive, auEx, aulist, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(),
+	                       c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>(), c->G, c->prm.MaxIndelSize, c->bnd }; RC((lb_launch<1>(c, na, op))); }
 	// E. compaction #1, noise stencil + compaction #2 (counts stay in the mailbox)
 	ENS(i32, b_q, na); ENS(i32, b_len, na); ENS(i64, b_r, na); ENS(i32, b_gb, na);
-	{ OpCompactAlive op = { alive, c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(),
+	{ OpCompactAlive op = { alive, c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), auEx, aulist, c->G, c->prm.MaxIndelSize, c->bnd,
 	                        c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(), mail }; RC((lb_launch<1>(c, na, op))); }
 	ENS(i32, c_q, na); ENS(i32, c_len, na + 1); ENS(i64, c_r, na); ENS(i32, c_gb, na); ENS(i32, c_bid, na);
 	{ OpNoise op = { c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(),

@@ -136,6 +136,10 @@ int  gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gs
 /* GSA_CREATE_KMER_K(k), 2 <= k <= 15: the jump table that replaces the first k steps of BWT_Search (bwt_search.cpp:152-165) is built for
  * k-mers of this length if it fits (default: by text length and free device memory; tests: a long table on a short text). */
 #define GSA_CREATE_KMER_K(k) (((uint32_t)(k) & 15u) << 8)
+/* GSA_CREATE_PRIO(mode), mode 1..3: stream priorities for a host that drives SEVERAL contexts on one GPU (clones inherit it).  The short bookkeeping passes of
+ * chaining / refinement / extension run on a stream of the greatest priority, the seed-search kernels on a stream of their own (1, 3: normal priority, 2: least),
+ * the striped DP normal (3: least).  Results do not depend on it.  0 (default): every stream at the default priority. */
+#define GSA_CREATE_PRIO(mode) (((uint32_t)(mode) & 3u) << 16)
 int  gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm, uint32_t flags, gsa_ctx **out);
 /* Tunables that are not aligner parameters (the library reads no environment variable).  A clone starts with its parent's values;
  * gsa_align_many takes its policy from ctx[0].

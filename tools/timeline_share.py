@@ -2,15 +2,16 @@
 """Whose time is a multi-context step?  From a rocpd kernel trace (rocprofv3 --kernel-trace of bench.py with several contexts in flight): over a
 steady-state window, how long k kernels were in flight at once, and every kernel's SHARE of the window -- each instant is split evenly among the
 kernels running at it, so the shares add up to the busy time: a kernel that runs alone for 1 ms owns 1 ms, four that overlap for 1 ms own 0.25 ms each.
-    python tools/timeline_share.py results.db [skip_frac=0.4]"""
+    python tools/timeline_share.py results.db [contigs_in_window=100]"""
 import collections, sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
 kd = [t for t in tabs if "kernel_dispatch" in t][0]; ks = [t for t in tabs if "kernel_symbol" in t][0]
 ops = [(r[0], r[1], r[2].split("(")[0].replace(".kd", "")) for r in cur.execute(f"select d.start, d.end, s.kernel_name from {kd} d join {ks} s on d.kernel_id=s.id order by d.start")]
-skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.4
-t0, t1 = ops[0][0], max(o[1] for o in ops)
-w0 = t0 + int((t1 - t0) * skip); w1 = t1 - int((t1 - t0) * 0.05)
+# the window: the last K contigs of the trace (K k_seed_select launches from the end, the very last few left out): the timed steps of bench.py
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+sel = [o for o in ops if "k_seed_select" in o[2]]
+w0 = sel[max(0, len(sel) - K)][0]; w1 = sel[max(0, len(sel) - 1 - max(4, K // 20))][0]
 ev = []
 for i, (s, e, n) in enumerate(ops):
     s, e = max(s, w0), min(e, w1)
