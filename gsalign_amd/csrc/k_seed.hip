@@ -1141,13 +1141,20 @@ __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ c
 // hits of its start by position: the tie-break of the (group, qPos) order, which the reference gets from a stable sort
 // of the PosDiff order (the f rows of one start are re-read by f lanes: L1/L2 hits on the dense SA).
 #define SEL_HASH 256
+#ifndef SEL_TRIES
+#define SEL_TRIES 4      // probes of the workgroup's LDS table of occupied PosDiff words before a hit goes to its word in HBM
+#endif
 // the coarse bitmap beside the PosDiff bitmap: bit (w >> 5) for bitmap word w (k_chain.hip, OpPdScan)
 __device__ __forceinline__ void pd_coarse_set(u32 *pdcb, unsigned long long w)
 {
 	const unsigned long long blk = w >> 5; const u32 bit = 1u << (blk & 31);
 	// (looked at first: the main diagonal of a whole contig sits in one block, and an unconditional atomic per workgroup queues on that word
 	//  -- locate + order of a 250 Mb contig 0.31 -> 0.67 ms when tried; a kernel of its own with a thread per hit: 1.4 ms, the looks queue too)
+#ifdef SEL_COARSE_PLAIN      // (experiment: a plain cached look instead of the agent-scope one)
+	if (!(pdcb[blk >> 5] & bit)) atomicOr(&pdcb[blk >> 5], bit);
+#else
 	if (!(__hip_atomic_load(&pdcb[blk >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(&pdcb[blk >> 5], bit);
+#endif
 }
 __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, const u32 *__restrict__ cand_cnt, const i32 *__restrict__ cand_s, const i32 *__restrict__ cand_len,
                                                       const u64 *__restrict__ cand_x0, const i32 *__restrict__ cand_freq, const u32 *__restrict__ onpath,
@@ -1255,11 +1262,11 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 		if (pdbm) {
 			const unsigned long long w = (unsigned long long)(pd >> 5); const u32 bit = 1u << (pd & 31);
 			int hh = (int)((w * 0x9E3779B1ull) >> 7) & (SEL_HASH - 1), tries = 0;
-			for (; tries < 4; tries++, hh = (hh + 1) & (SEL_HASH - 1)) {
+			for (; tries < SEL_TRIES; tries++, hh = (hh + 1) & (SEL_HASH - 1)) {
 				const unsigned long long prev = atomicCAS(&s_w[hh], ~0ull, w);
 				if (prev == ~0ull || prev == w) { atomicOr(&s_b[hh], bit); break; }
 			}
-			if (tries == 4) { atomicOr(&pdbm[w], bit); pd_coarse_set(pdcb, w); }
+			if (tries == SEL_TRIES) { atomicOr(&pdbm[w], bit); pd_coarse_set(pdcb, w); }
 		}
 		}
 		__syncthreads();
