@@ -56,7 +56,7 @@ WORKLOADS = {
                   label="human-chr1-sized pair (BASELINE configs[3] on one GPU): 250 Mb reference with repeat injection (300-bp family over 10 %, 150-copy tandem) vs 1 %-diverged query, defaults"),
     "ecoli": dict(lengths=[5_000_000], div=0.02, repeats=False, params={}, n_query=4, inflight=2, steps=200,
                   label="E. coli-sized pair (BASELINE configs[1] stand-in): 5 Mb reference vs 2 %-diverged query, default -slen 15 -ind 25"),
-    "yeast": dict(lengths=[1000 * k for k in YEAST_KB], div=0.02, repeats=False, params=dict(sen=1, clr=50), n_query=2, inflight=3, steps=12,
+    "yeast": dict(lengths=[1000 * k for k in YEAST_KB], div=0.02, repeats=False, params=dict(sen=1, clr=50), n_query=2, inflight=3, steps=60,
                   label="S. cerevisiae-sized pair (BASELINE configs[2]): 16 contigs / 12 Mb vs 2 %-diverged copy, -sen"),
     # BASELINE configs[4]: the whole job of the 8-GPU configuration (the index is replicated per GPU there, so one GPU
     # holds exactly this index).  6.2 G BWT rows: the >= 2^32-row device layout and the 64-bit suffix sorter on their real input.

@@ -250,7 +250,7 @@ void gsa_destroy(gsa_ctx *c)
 	if (c->lender) c->lender->n_borrowers.fetch_sub(1);      // (`parent` outlives its clones: gsa_hip.h)
 	DevBuf *bufs[] = { &c->d_bwt, &c->d_bwt_ref, &c->d_occ_base, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->qs[0].d_query, &c->qs[1].d_query, &c->qs[0].d_bndtab, &c->qs[1].d_bndtab, &c->tmp, &c->d_cnt, &c->d_mail, &c->d_lb_status[0], &c->d_lb_status[1],
 		&c->d_sa_dense, &c->d_kmer, &c->d_kmer_lo, &c->d_pres, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_heavy, &c->dn_lf, &c->dn_x0, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
-		&c->d_flag, &c->d_scan, &c->g_beg, &c->w_j0, &c->d_pdbm, &c->d_pdcb, &c->d_gpre, &c->d_key_c, &c->d_val_c, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
+		&c->d_flag, &c->d_scan, &c->g_beg, &c->w_j0, &c->d_pdbm, &c->d_pdby, &c->d_pdcb, &c->d_gpre, &c->d_key_c, &c->d_val_c, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
 		&c->a_next, &c->a_brk, &c->a_aurank, &c->a_aulist, &c->a_runinfo, &c->w_best, &c->w_sum, &c->w_n, &c->d_btab, &c->d_flag2, &c->d_scan2, &c->d_i64a,
 		&c->b_q, &c->b_len, &c->b_r, &c->b_gb, &c->b_ge, &c->c_q, &c->c_len, &c->c_r, &c->c_gb, &c->c_ge, &c->c_bid, &c->blk_beg, &c->blk_end, &c->blk_score,
 		&c->r_q, &c->r_len, &c->r_r, &c->r_bid, &c->r_tmp_q, &c->r_tmp_len, &c->r_tmp_r, &c->r_tmp_bid, &c->r_cut4, &c->r_cut5, &c->r_simjob, &c->r_simres, &c->d_leaf,
@@ -365,6 +365,7 @@ int gsa_set_option(gsa_ctx *c, const char *name, int64_t value)
 	else if (k == "dp_side") c->opt.dp_side = value != 0;
 	else if (k == "pd_two_level_min") { if (!in(0, BIG)) return gsa_fail(c, GSA_ERR_ARG, "pd_two_level_min: >= 0 blocks"); c->opt.pd_two_level_min = value; }
 	else if (k == "dp_occupancy") { if (!in(0, 16)) return gsa_fail(c, GSA_ERR_ARG, "dp_occupancy: 0 (off) .. 16 workgroups per CU"); c->opt.dp_occupancy = (int)value; }
+	else if (k == "pd_bytes") { if (!in(0, 2)) return gsa_fail(c, GSA_ERR_ARG, "pd_bytes: 0 never, 1 by the hit count, 2 always"); c->opt.pd_bytes = (int)value; }
 	else if (k == "pres_from_kmer") c->opt.pres_from_kmer = value != 0;      // (takes effect at the next gsa_set_params that rebuilds the table)
 	else if (k == "walk_chain_min") { if (!in(0, BIG)) return gsa_fail(c, GSA_ERR_ARG, "walk_chain_min: >= 0 seeds"); c->opt.walk_chain_min = value; }
 	else if (k == "sweep_shape") { if (value < -1 || value > 1) return gsa_fail(c, GSA_ERR_ARG, "sweep_shape: -1, 0 or 1"); c->opt.sweep_shape = (int)value; }

@@ -83,6 +83,8 @@ struct Options {
 	int64_t walk_chain_min = 100000;   // contigs with more seeds than this walk their window chain in slices (k_walk_chain) instead of one workgroup's LDS (k_walk_windows); tests: 0
 	int64_t pd_two_level_min = 2000000;   // PosDiff bitmaps of more blocks than this (a reference above ~1 Gbp) are scanned in two passes: list the touched blocks, count those (tests: 0)
 	int dp_occupancy = 0;              // > 0: at most this many striped-DP workgroups per CU (LDS padding): leaves wave slots for the passes beside it (experiment; 0 = off)
+	int pd_bytes = 1;                  // the PosDiff bitmap of a contig (bundle) whose hits scatter (-sen: thousands of chance hits per chunk) is filled through a byte per value, plain stores, and packed
+	                                   // afterwards -- no device-scope atomics (k_pd_pack, k_seed.hip); 1 = when the hit count says so, 0 = never, 2 = always (tests)
 	int pres_from_kmer = 1;            // the presence table is derived from the k-mer jump table when both hold k-mers of one length (0: always from a scan of the text; a test compares the two)
 	int kmer_k = 0;                    // gsa_create_opts (GSA_CREATE_KMER_K): length of the jump table's k-mers (0: by text length and free memory)
 };
@@ -166,6 +168,7 @@ struct gsa_ctx {
 	i32 n_groups = 0;
 	bool pd_path = false, seed_view_ready = false, pdbm_dirty = true; i64 pd_words = 0;      // groups from the PosDiff bitmap (no PosDiff sort on the hot path)
 	DevBuf w_j0; u32 walk_ticket = 0, walk_epoch = 0;   // window chain of large contigs (k_walk_chain): ticket counter + one entry word per slice, never reset -- the host passes the counter's value and the launch epoch
+	DevBuf d_pdby; bool pd_bytes = false;          // a byte per PosDiff value (all zero between contigs), see Options::pd_bytes
 	DevBuf d_pdcb;                                 // coarse bitmap: one bit per block of 32 words of d_pdbm (the blocks that hold a hit)
 	DevBuf d_pdbm, d_gpre, d_key_c, d_val_c;      // bitmap of occupied PosDiff values, group starts below each word, (group, qPos, rank) keys
 	DevBuf g_beg;                                  // group start indices (n_groups+1)

@@ -1158,7 +1158,7 @@ __device__ __forceinline__ void pd_coarse_set(u32 *pdcb, unsigned long long w)
 }
 __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, const u32 *__restrict__ cand_cnt, const i32 *__restrict__ cand_s, const i32 *__restrict__ cand_len,
                                                       const u64 *__restrict__ cand_x0, const i32 *__restrict__ cand_freq, const u32 *__restrict__ onpath,
-                                                      const i32 *__restrict__ hit_base, Bundle bnd, i32 s_off, int qbits, u64 *key, u32 *val, u32 *pdbm, u32 *pdcb, u32 lds_cand)
+                                                      const i32 *__restrict__ hit_base, Bundle bnd, i32 s_off, int qbits, u64 *key, u32 *val, u32 *pdbm, u32 *pdcb, u32 lds_cand, uint8_t *pdby)
 {
 	// (bnd.lmax = length of the whole contig, s_off = contig position of the first chunk searched: not 0 when only a chunk range
 	//  of the contig was seeded on this GPU, gsa_seed_chunks.  A bundle of contigs: the key's PosDiff is the true one of the
@@ -1259,7 +1259,10 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 		// global OR per touched word at the end: a chunk's hits sit in two or three words and the whole contig's main
 		// diagonal in one cache line -- an atomic (or even a look) per hit queues 75 k operations on that line.  Hits of
 		// repeats scatter over the genome: after a few probes they go straight to their own (uncontended) word.
-		if (pdbm) {
+		// (round 5) where the hits scatter -- -sen: a chunk holds thousands of chance hits on as many words, and a device-scope atomic each is what `locate` then
+		// costs (9.7 M of them in a 60 Mb bundle, 2.8 ms) -- a byte per PosDiff value takes a plain store; k_pd_pack makes the bitmap of it
+		if (pdby) pdby[pd] = 1;
+		else if (pdbm) {
 			const unsigned long long w = (unsigned long long)(pd >> 5); const u32 bit = 1u << (pd & 31);
 			int hh = (int)((w * 0x9E3779B1ull) >> 7) & (SEL_HASH - 1), tries = 0;
 			for (; tries < SEL_TRIES; tries++, hh = (hh + 1) & (SEL_HASH - 1)) {
@@ -1271,9 +1274,48 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 		}
 		__syncthreads();
 	}
-	if (pdbm) {
+	if (pdbm && !pdby) {
 		__syncthreads();
 		for (int t = j; t < SEL_HASH; t += 256) if (s_w[t] != ~0ull) { atomicOr(&pdbm[s_w[t]], s_b[t]); pd_coarse_set(pdcb, s_w[t]); }
+	}
+}
+
+// The byte map of occupied PosDiff values -> the bitmap and its coarse bitmap, and the bytes back to zero.  A workgroup per 1 024 bitmap words (32 KB of
+// bytes, one coarse word): a thread reads the 32 bytes of a word, gathers their low bits (the bytes are 0 or 1: one multiplication per four), stores the
+// word if it holds a hit and clears its bytes; the coarse bits are the waves' ballots.  The bitmap is all zero when the pass starts (the invariant of
+// stage 2: k_pd_gather clears what a contig set), so plain stores do.
+__device__ __forceinline__ u32 pd_nib(u32 x) { return ((x * 0x01020408u) >> 24) & 15u; }      // bytes b0..b3 in {0, 1} -> b0 | b1 << 1 | b2 << 2 | b3 << 3 (no two partial products share a bit)
+__global__ void __launch_bounds__(256) k_pd_pack(uint8_t *pdby, i64 nw, u32 *pdbm, u32 *pdcb)
+{
+	__shared__ u32 s_c[4];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const i64 n_tiles = (nw + 1023) >> 10;
+	for (i64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+		u32 cb = 0;
+		uint4 a[4], b[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const i64 w = (tile << 10) + k * 256 + tid;
+			a[k] = make_uint4(0, 0, 0, 0); b[k] = a[k];
+			if (w < nw) { a[k] = ((const uint4 *)pdby)[2 * w]; b[k] = ((const uint4 *)pdby)[2 * w + 1]; }
+		}
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const i64 w = (tile << 10) + k * 256 + tid;
+			const bool any = (a[k].x | a[k].y | a[k].z | a[k].w | b[k].x | b[k].y | b[k].z | b[k].w) != 0;
+			if (any) {
+				const u32 word = pd_nib(a[k].x) | (pd_nib(a[k].y) << 4) | (pd_nib(a[k].z) << 8) | (pd_nib(a[k].w) << 12) | (pd_nib(b[k].x) << 16) | (pd_nib(b[k].y) << 20) | (pd_nib(b[k].z) << 24) | (pd_nib(b[k].w) << 28);
+				pdbm[w] = word;
+				((uint4 *)pdby)[2 * w] = make_uint4(0, 0, 0, 0); ((uint4 *)pdby)[2 * w + 1] = make_uint4(0, 0, 0, 0);
+			}
+			const unsigned long long m = __ballot(any);      // 64 words = two blocks of 32
+			cb |= ((m & 0xffffffffull) ? 1u : 0u) << (k * 8 + wv * 2);
+			cb |= ((m >> 32) ? 1u : 0u) << (k * 8 + wv * 2 + 1);
+		}
+		if (lane == 0) s_c[wv] = cb;
+		__syncthreads();
+		if (tid == 0) { const u32 v = s_c[0] | s_c[1] | s_c[2] | s_c[3]; if (v) pdcb[tile] = v; }
+		__syncthreads();
 	}
 }
 
@@ -1574,7 +1616,7 @@ template <class T> static T *dev_grow_keep(gsa_ctx *c, DevBuf &b, size_t n, size
 }
 
 // Groups without the PosDiff sort: decide whether the bitmap of occupied PosDiff values is kept for this contig and clear it
-static int prepare_pd_bitmap(gsa_ctx *c, i64 n_hits)
+static int prepare_pd_bitmap(gsa_ctx *c, i64 n_hits, i64 n_chunks = 0)
 {
 	const u64 pd_words = ((u64)c->pd_span >> 5) + 2;
 	// (a chunk range: the hit count of the whole contig is not known here; the bitmap is kept whenever MaxIndelSize allows it)
@@ -1594,6 +1636,15 @@ static int prepare_pd_bitmap(gsa_ctx *c, i64 n_hits)
 		if (c->d_pdbm.cap != cap0 || c->pdbm_dirty) GSA_CHECK(c, hipMemsetAsync(c->d_pdbm.p, 0, c->d_pdbm.cap, c->stream));
 		if (c->d_pdcb.cap != ccap0 || c->pdbm_dirty) GSA_CHECK(c, hipMemsetAsync(c->d_pdcb.p, 0, c->d_pdcb.cap, c->stream));
 		c->pdbm_dirty = true; c->pd_words = (i64)pd_words;
+		// the byte map (Options::pd_bytes): where a chunk's hits overflow the workgroup's table of words (256) and the pass over the bytes costs less than their atomics would
+		c->pd_bytes = false;
+		if (!c->split && n_chunks > 0 && (c->opt.pd_bytes == 2 || (c->opt.pd_bytes == 1 && n_hits >= 512 * n_chunks && pd_words * 32 <= 256ull * (u64)n_hits))) {
+			const size_t bcap0 = c->d_pdby.cap;
+			if (dev_ensure<uint8_t>(c, c->d_pdby, ((size_t)pd_words + 66) * 32)) {
+				if (c->d_pdby.cap != bcap0) GSA_CHECK(c, hipMemsetAsync(c->d_pdby.p, 0, c->d_pdby.cap, c->stream));
+				c->pd_bytes = true;
+			} else { (void)hipGetLastError(); c->err.clear(); }      // (no room: the atomics do it)
+		}
 	}
 	return GSA_OK;
 }
@@ -1770,14 +1821,18 @@ int stage1_seed(gsa_ctx *c)
 	// Groups: a new group starts where the sorted PosDiff values jump by more than MaxIndelSize.  With a bitmap of the
 	// occupied PosDiff values that needs no sort: group id = number of group starts at or below a hit's PosDiff (a scan
 	// over the bitmap, stage 2).  The PosDiff-sorted view of the seeds (stage-1 view of the C ABI) is then built on demand.
-	if (int rcp = prepare_pd_bitmap(c, n_hits)) return rcp;
+	if (int rcp = prepare_pd_bitmap(c, n_hits, n_chunks)) return rcp;
 	if (n_hits > 0) {
 		if (!dev_ensure<u64>(c, c->d_key_a, hcap) || !dev_ensure<u32>(c, c->d_val_a, hcap)) return GSA_ERR_NOMEM;
 		// (LDS by the contig's own maximum: the segments' capacity only grows -- one contig with a crowded chunk, or the counting pass of the
 		//  bench, and every later launch would run one workgroup per CU)
 		const size_t sel_cand = contig_maxcand < ccap ? (((size_t)contig_maxcand + 64) & ~(size_t)63) : ccap;
 		hipLaunchKernelGGL(k_seed_select, dim3((unsigned)n_chunks), dim3(256), 2 * (sel_cand + 2) * sizeof(u32), st, c->di, (u32)ccap, c->d_cand_cnt.as<u32>(), c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(),
-		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), c->bnd, s_off, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr, c->d_pdcb.as<u32>(), (u32)sel_cand);
+		                   c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), c->d_onpath.as<u32>(), c->d_chunk_base.as<i32>(), c->bnd, s_off, c->qbits, c->d_key_a.as<u64>(), c->d_val_a.as<u32>(), c->pd_path ? c->d_pdbm.as<u32>() : (u32 *)nullptr, c->d_pdcb.as<u32>(), (u32)sel_cand, (c->pd_path && c->pd_bytes) ? c->d_pdby.as<uint8_t>() : (uint8_t *)nullptr);
+		if (c->pd_path && c->pd_bytes) {
+			const i64 tiles = (c->pd_words + 1023) >> 10;
+			hipLaunchKernelGGL(k_pd_pack, dim3((unsigned)(tiles < 4096 ? tiles : 4096)), dim3(256), 0, st, c->d_pdby.as<uint8_t>(), c->pd_words, c->d_pdbm.as<u32>(), c->d_pdcb.as<u32>());
+		}
 	}
 	if (c->profiling) hipEventRecord(c->ev[2], st);
 	u64 lf_steps = 0;

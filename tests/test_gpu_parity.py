@@ -332,6 +332,40 @@ def test_long_kmer_table(oracle_built, tmp_path, monkeypatch, k, wide):
     o.close(); g.close()
 
 
+@pytest.mark.parametrize("mode,params", [(2, dict(sen=1, clr=50)), (2, {}), (2, dict(sen=1, clr=50, wide=True)), (0, dict(sen=1, clr=50))])
+def test_pd_byte_map_vs_oracle(oracle_built, tmp_path, mode, params):
+    """Round 5: under -sen a chunk holds thousands of chance hits, each on a PosDiff-bitmap word of its own, and k_seed_select's device-scope atomics on
+    those words were what `locate` cost (GSAlign.cpp:88 start += 5, :80-86 one seed per located hit).  Such contigs now mark a BYTE per PosDiff value
+    with plain stores and k_pd_pack makes the bitmap of it (option pd_bytes: 1 = by the hit count, the default; here 2 = every contig, 0 = never).
+    Every block, record and gapped string vs the oracle, contig after contig on one context (the byte map must be left clean), then the same contigs
+    as bundles through gsa_align_many on two contexts."""
+    params = dict(params); wide = params.pop("wide", False)
+    refs, qrys = synth.make_pair_fast(2400000, 5, 0.02, seed=66, repeats=True)
+    qrys[2] = (qrys[2][0], synth.revcomp(qrys[2][1]))
+    idx = _build(tmp_path, refs)
+    o = oracle_built.Oracle(idx, params); g = capi.Aligner(idx, wide=wide, **params)
+    g.set_option("pd_bytes", mode)
+    _same_as_oracle(o, g, qrys)
+    _same_as_oracle(o, g, qrys[:2])
+    want = []
+    for name, seq in qrys:
+        o.set_query(seq); o.run_to(8); want.append(o.blocks(with_aln=False))
+    g2 = g.clone(); g2.set_params(**params); g2.set_option("pd_bytes", mode)
+    got = {}
+
+    def on_result(ci, res):
+        B = np.ctypeslib.as_array(capi.C.cast(res.blocks, capi.C.POINTER(capi.C.c_uint8)), shape=(res.n_blocks * 40,)).view(capi.BLOCK_DT).copy()
+        got[ci] = (B["score"].copy(), B["aln_len"].copy(), int(res.n_frags))
+        return 0
+
+    capi.align_many([g, g2], [q for _, q in qrys] * 3, on_result)
+    assert sorted(got) == list(range(3 * len(qrys)))
+    for ci, (sc, al, nf) in got.items():
+        w = want[ci % len(qrys)]
+        assert np.array_equal(sc, w["b_score"]) and np.array_equal(al, w["b_aln_len"]) and nf == int(w["b_nfrag"].sum()), ci
+    g2.close(); o.close(); g.close()
+
+
 def test_host_register_in_place(oracle_built, tmp_path):
     """gsa_host_register (round 5): a sequence page-locked where the loader put it aligns to the same result as from pageable memory and as the
     oracle says; registering twice / unregistering something else reports GSA_ERR_HIP instead of failing later."""
