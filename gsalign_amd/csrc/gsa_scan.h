@@ -15,7 +15,9 @@
 #include <algorithm>
 #include "gsa_ctx.h"
 
+#ifndef LB_TPB
 #define LB_TPB 256
+#endif
 #ifndef LB_GRID_PER_CU
 #define LB_GRID_PER_CU 2    // workgroups per CU of a fused pass (persistent: tiles are drawn from the ticket counter)
 #endif
@@ -71,7 +73,10 @@ __device__ __forceinline__ void lb_tile_prefix(const LbArgs &lb, int tile, const
 		i32 excl[NV]; bool fin[NV];                                   // (fin: wave-uniform)
 #pragma unroll
 		for (int c = 0; c < NV; c++) { excl[c] = 0; fin[c] = false; }
-		for (int base = tile - 1;; base -= 64) {
+#ifndef LB_WIN
+#define LB_WIN 64      // (experiment: predecessors looked at per round trip)
+#endif
+		for (int base = tile - 1;; base -= LB_WIN) {
 			const int idx = base - lane;
 			unsigned long long w[NV];
 			int first[NV];
@@ -83,7 +88,8 @@ __device__ __forceinline__ void lb_tile_prefix(const LbArgs &lb, int tile, const
 					w[c] = lb_pack(ep, 2, 0);                            // tiles before tile 0: prefix 0
 					first[c] = 0;
 					if (fin[c]) continue;
-					if (idx >= 0) w[c] = __hip_atomic_load(&lb.status[c][idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (LB_WIN < 64 && lane >= LB_WIN) w[c] = lb_pack(ep, 1, 0);      // (not looked at: a total of nothing)
+					else if (idx >= 0) w[c] = __hip_atomic_load(&lb.status[c][idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
 #pragma unroll
 				for (int c = 0; c < NV; c++) {
@@ -144,6 +150,8 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 	for (bool first = true;; first = false) {
 	if (!first && (i32)gridDim.x >= lb.n_tiles) break;      // (a launch with a workgroup per tile: one draw each, no failing second one -- a round trip per pass on small contigs)
 	__syncthreads();
+	// (tiles by workgroup number instead of the ticket -- round 5 experiment -- hang as soon as other kernels share the chip: a workgroup waits for a tile whose
+	//  workgroup has not been dispatched yet; profiles/r05_lb_pass_experiments.txt)
 	if (tid == 0) s_tile = (i32)(atomicAdd(lb.ticket, 1u) - lb.base);
 	__syncthreads();
 	const int tile = s_tile;
