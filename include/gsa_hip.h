@@ -160,7 +160,7 @@ int  gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *pr
  *                    (references above ~1 Gbp).  "pres_from_kmer" 0 = the presence table always from a scan of the text.  Results do not depend on either
  *   "pd_bytes"       how k_seed_select marks the occupied PosDiff values of a contig whose hits scatter over the genome (-sen: thousands of chance hits per
  *                    10 000-bp chunk): 1 (default) = through a byte per value, plain stores, packed into the bitmap by a pass of its own, when there are at least
- *                    512 hits per chunk and at most 256 values per hit (2 GB per context for a 64 Mb bundle against a 12 Mb reference); 0 = always with atomics
+ *                    512 hits per chunk, at most 256 values per hit and at most 2^32 values (2 GB per context for a 64 Mb bundle against a 12 Mb reference); 0 = always with atomics
  *                    on the bitmap; 2 = always through the bytes (tests).  Results do not depend on it
  *   "dp_safe", "dp_fake_timeout"   test hooks: one striped DP job per launch; the next n contigs report a stripe hand-off time-out once
  * Unknown names and values outside an option's range (negative sizes, seed_budget 0, ...): GSA_ERR_ARG, nothing changed.
