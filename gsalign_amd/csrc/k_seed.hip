@@ -1638,7 +1638,7 @@ static int prepare_pd_bitmap(gsa_ctx *c, i64 n_hits, i64 n_chunks = 0)
 		c->pdbm_dirty = true; c->pd_words = (i64)pd_words;
 		// the byte map (Options::pd_bytes): where a chunk's hits overflow the workgroup's table of words (256) and the pass over the bytes costs less than their atomics would
 		c->pd_bytes = false;
-		if (!c->split && n_chunks > 0 && (c->opt.pd_bytes == 2 || (c->opt.pd_bytes == 1 && n_hits >= 512 * n_chunks && pd_words * 32 <= 256ull * (u64)n_hits && pd_words <= (128ull << 20))))      // (at most 4 GB of bytes per context) {
+		if (!c->split && n_chunks > 0 && (c->opt.pd_bytes == 2 || (c->opt.pd_bytes == 1 && n_hits >= 512 * n_chunks && pd_words * 32 <= 256ull * (u64)n_hits && pd_words <= (128ull << 20)))) {      // (at most 4 GB of bytes per context)
 			const size_t bcap0 = c->d_pdby.cap;
 			if (dev_ensure<uint8_t>(c, c->d_pdby, ((size_t)pd_words + 66) * 32)) {
 				if (c->d_pdby.cap != bcap0) GSA_CHECK(c, hipMemsetAsync(c->d_pdby.p, 0, c->d_pdby.cap, c->stream));
