@@ -443,7 +443,12 @@ int stage78_extend(gsa_ctx *c)
 		                   c->bnd.off, c->d_alnoff.as<i64>(), c->f_rec16.as<gsa_rec>(), c->p_ba0.as<i64>());
 	const i32 *hm = c->p_dp.as<i32>();      // (the mailbox as run_ksw2_jobs read it: the record count is final since stage 7)
 	c->n_frags = hm[M_NF]; c->n_aln = hm[M_NALN]; c->n_large = kl.nlarge; c->dbg[7] = (u64)kl.nlarge;
-	GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec16.p, (size_t)c->n_frags * sizeof(gsa_rec), hipMemcpyDeviceToHost, sc));
+#ifdef GSA_EXPERIMENTS      // (what the results' way home costs: GSA_SKIP_D2H=1 leaves the string pools on the device, 2 the records too -- results are garbage, timing only)
+	static const int skip_d2h = [] { const char *e = getenv("GSA_SKIP_D2H"); return e ? atoi(e) : 0; }();
+#else
+	const int skip_d2h = 0;
+#endif
+	GSA_CHECK(c, hipMemcpyAsync(c->p_frags.p, c->f_rec16.p, skip_d2h >= 2 ? 16 : (size_t)c->n_frags * sizeof(gsa_rec), hipMemcpyDeviceToHost, sc));
 	// everything that can only leave at the very end sits in ONE buffer: final mailbox | patch list of the large DP jobs |
 	// string pool 1 | string pool 2 -- a single copy behind the last kernel instead of a chain of four
 	const size_t npatch = (size_t)kl.nlarge + (size_t)c->n_early;
@@ -478,7 +483,7 @@ int stage78_extend(gsa_ctx *c)
 	GSA_CHECK(c, hipEventRecord(c->ev[17], sx));      // the strings of everything but the large jobs are written
 	if (pools_early) {
 		GSA_CHECK(c, hipStreamWaitEvent(sc, c->ev[17], 0));
-		GSA_CHECK(c, hipMemcpyAsync((char *)c->p_tail.p + t_aln1, d_aln1, t_total - t_aln1, hipMemcpyDeviceToHost, sc));
+		GSA_CHECK(c, hipMemcpyAsync((char *)c->p_tail.p + t_aln1, d_aln1, skip_d2h ? 256 : t_total - t_aln1, hipMemcpyDeviceToHost, sc));
 		GSA_CHECK(c, hipEventRecord(c->ev[23], sc));
 	}
 	// (per-block sums: left by k_materialize itself; the large jobs' records count as zero there, the host adds them from the patch list)
@@ -510,7 +515,7 @@ int stage78_extend(gsa_ctx *c)
 	} else {
 		// no large job: the mailbox goes home by itself, the pools (if any) behind it
 		GSA_CHECK(c, hipMemcpyAsync(c->p_tail.p, mail, MAIL_N * sizeof(i32), hipMemcpyDeviceToHost, st));
-		if (c->n_aln) GSA_CHECK(c, hipMemcpyAsync((char *)c->p_tail.p + t_aln1, d_aln1, t_total - t_aln1, hipMemcpyDeviceToHost, st));
+		if (c->n_aln) GSA_CHECK(c, hipMemcpyAsync((char *)c->p_tail.p + t_aln1, d_aln1, skip_d2h ? 256 : t_total - t_aln1, hipMemcpyDeviceToHost, st));
 	}
 	if (c->profiling) hipEventRecord(c->ev[9], st);
 	GSA_CHECK(c, hipGetLastError());
