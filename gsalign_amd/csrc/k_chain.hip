@@ -369,11 +369,13 @@ __global__ void __launch_bounds__(WALK_T) k_walk_windows(i64 na, const i32 *__re
 // seed, no sort): the same pass that numbers the windows inserts the seeds.
 struct Bucket { unsigned long long key; u32 cnt; u32 pad; };      // cleared to 0xff: key = empty, count = cnt + 1
 #define BKT_EMPTY (~0ull)
-__device__ __forceinline__ u32 bkt_hash(unsigned long long k, int capbits) { return (u32)((k * 0x9E3779B97F4A7C15ull) >> (64 - capbits)); }
+// (round 5: any capacity, not a power of two -- a table of 2^k >= 2 na entries was 3 na on average, cleared and scanned once per contig: 4.6 GB per human genome;
+//  the slot is the high half of hash x capacity)
+__device__ __forceinline__ u32 bkt_hash(unsigned long long k, u32 cap) { return (u32)((((k * 0x9E3779B97F4A7C15ull) >> 32) * (unsigned long long)cap) >> 32); }
 
 // window id per seed = (number of starts up to and including it) - 1
 struct OpWindowBuckets {
-	i64 na; const i32 *a_q; const i64 *a_r; const i32 *uniq, *ws; i64 bmin; int capbits;
+	i64 na; const i32 *a_q; const i64 *a_r; const i32 *uniq, *ws; i64 bmin; u32 cap;
 	i32 *wsEx, *slot_of; Bucket *tab; unsigned long long *wbest, *wsum; i32 *wn;
 	struct Item { i32 ws, uniq; i64 pd; };
 	__device__ Item load(i64 i) const { Item it; it.ws = ws[i]; it.uniq = uniq[i]; it.pd = a_r[i] - a_q[i]; return it; }
@@ -381,7 +383,7 @@ struct OpWindowBuckets {
 	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const
 	{
 		wsEx[i] = ex[0];
-		wbest[i] = 0; wsum[i] = 0; wn[i] = 0;
+		if (it.ws) { wbest[ex[0]] = 0; wsum[ex[0]] = 0; wn[ex[0]] = 0; }      // (the sums of window ex[0], which this seed opens; round 5: not 20 bytes per SEED -- windows are few)
 		// One table operation per DISTINCT (window, bucket) of the wavefront: its 64 lanes hold 64 consecutive seeds, which mostly share both (the main
 		// diagonal: two or three keys per wavefront), so the lanes with the first pending lane's key step aside together -- that lane inserts the key and adds
 		// their number; twice, then the lanes that are left (a repeat's scattered hits) go for themselves, all at once.  Measured per 250 Mb contig: every seed for
@@ -399,12 +401,11 @@ struct OpWindowBuckets {
 			const unsigned long long grp = __ballot(mine);
 			u32 h = 0;
 			if ((int)(threadIdx.x & 63) == lead) {
-				const u32 mask = (1u << capbits) - 1;
-				h = bkt_hash(key, capbits);
+				h = bkt_hash(key, cap);
 				for (;;) {
 					const unsigned long long old = atomicCAS(&tab[h].key, BKT_EMPTY, key);
 					if (old == BKT_EMPTY || old == key) break;
-					h = (h + 1) & mask;
+					h = h + 1 == cap ? 0u : h + 1;
 				}
 				atomicAdd(&tab[h].cnt, (u32)__popcll(grp));
 			}
@@ -412,12 +413,11 @@ struct OpWindowBuckets {
 			if (mine) { slot = (i32)h; pend = false; }
 		}
 		if (pend) {      // (a wavefront of scattered seeds -- a repeat's hits: every lane for itself, all at once)
-			const u32 mask = (1u << capbits) - 1;
-			u32 h = bkt_hash(key, capbits);
+			u32 h = bkt_hash(key, cap);
 			for (;;) {
 				const unsigned long long old = atomicCAS(&tab[h].key, BKT_EMPTY, key);
 				if (old == BKT_EMPTY || old == key) break;
-				h = (h + 1) & mask;
+				h = h + 1 == cap ? 0u : h + 1;
 			}
 			atomicAdd(&tab[h].cnt, 1u);
 			slot = (i32)h;
@@ -873,8 +873,7 @@ int stage2_chain(gsa_ctx *c)
 	{ OpUniqBrk op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, brk, alive, cuEx, brkEx, blist }; RC((lb_launch<2>(c, na, op))); }
 	i32 *candf = c->d_flag.as<i32>(), *candEx = c->d_scan.as<i32>(), *clist = c->a_runinfo.as<i32>();
 	{ OpCand op = { na, c->a_gb.as<i32>(), c->a_ge.as<i32>(), cuEx, brk, candf, candEx, clist, ws }; RC((lb_launch<1>(c, na, op))); }
-	int capbits = 10; while ((1ull << capbits) < 2 * (u64)na) capbits++;      // the outlier filter's (window, bucket) table: load factor <= 1/2
-	const i64 cap = 1ll << capbits;
+	const i64 cap = na + na / 4 + 1024;      // the outlier filter's (window, bucket) table: one key per unique seed at most -- load factor <= 0.8 if every seed is unique and alone in its bucket, a few per cent on real input
 	ENS(Bucket, d_btab, cap);
 	static_assert(sizeof(Bucket) == 16, "the table is cleared as uint4s");
 	LAUNCH(k_next_window, na, na, c->a_q.as<i32>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), uniq, cuEx, brk, brkEx, blist, candf, candEx, clist, next, c->d_flag2.as<i32>(), c->d_btab.as<uint4>(), cap);
@@ -895,7 +894,7 @@ int stage2_chain(gsa_ctx *c)
 	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);
 	const i64 bmin = ((-(i64)c->qlen) >> 4) - 1;
 	i32 *slot_of = c->a_runinfo.as<i32>();
-	{ OpWindowBuckets op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, bmin, capbits, wsEx, slot_of, c->d_btab.as<Bucket>(),
+	{ OpWindowBuckets op = { na, c->a_q.as<i32>(), c->a_r.as<i64>(), uniq, ws, bmin, (u32)cap, wsEx, slot_of, c->d_btab.as<Bucket>(),
 	                         c->w_best.as<unsigned long long>(), c->w_sum.as<unsigned long long>(), c->w_n.as<i32>() }; RC((lb_launch<1, 4>(c, na, op))); }
 	LAUNCH(k_window_mode, cap, cap, c->d_btab.as<Bucket>(), c->w_best.as<unsigned long long>());
 	LAUNCH(k_window_avg, na, na, slot_of, c->d_btab.as<Bucket>(), c->a_q.as<i32>(), c->a_r.as<i64>(), c->w_best.as<unsigned long long>(), ws, wsEx,
