@@ -27,6 +27,12 @@
                             // 21 passes of a 250 Mb contig (16 spills); the hash-table pass stays at 4, the record pass takes 12
 #endif
 
+#ifdef LB_TIMING      // (experiment build, one translation unit: where a tile's time goes -- sums of 100 MHz ticks over all tiles of all passes; gsa_debug_lb_prof reads them)
+static __device__ unsigned long long g_lb_prof[8];
+#define LB_T(K) { if (tid == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_lb_prof[K], t_ - t_last); t_last = t_; } }
+#else
+#define LB_T(K)
+#endif
 struct LbArgs {
 	unsigned long long *status[2];   // tile status words, one array per scanned component
 	u32 *ticket;                     // never reset: tile = ticket - base
@@ -147,6 +153,9 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 	// of 64 aggregates -- a dependent agent-scope load each -- before it met one (58 us mean tile lifetime in OpDpJobs: r03_sq_human.txt,
 	// 2.2 x 10^9 wave-cycles per contig, more than the striped DP).  With a few hundred tiles in flight, all of them consecutive, the
 	// predecessors of a tile are mostly through and the first window answers.
+#ifdef LB_TIMING
+	unsigned long long t_last = wall_clock64();
+#endif
 	for (bool first = true;; first = false) {
 	if (!first && (i32)gridDim.x >= lb.n_tiles) break;      // (a launch with a workgroup per tile: one draw each, no failing second one -- a round trip per pass on small contigs)
 	__syncthreads();
@@ -155,6 +164,7 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 	if (tid == 0) s_tile = (i32)(atomicAdd(lb.ticket, 1u) - lb.base);
 	__syncthreads();
 	const int tile = s_tile;
+	LB_T(0)      // ticket (+ the barriers around it)
 	if (tile >= lb.n_tiles) break;
 	// STRIPED since round 4: item k of thread t is element tile * LB_TILE + k * LB_TPB + t, so the 64 lanes of a wave read 64 consecutive
 	// elements of every array an Op touches (with consecutive items per thread a wave's load touched 64 lines at 16 items per thread and ran
@@ -201,7 +211,12 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 		agg[c] = run;
 	}
 	i32 pre[NV];
+	LB_T(1)      // loads + values + the tile's own scan
 	lb_tile_prefix<NV>(lb, tile, agg, pre, s_bcast);
+	LB_T(2)      // look-back
+#ifdef LB_TIMING
+	if (tid == 0) atomicAdd(&g_lb_prof[4], 1ull);
+#endif
 	i32 vv[NV], ee[NV];
 #pragma unroll
 	for (int k = 0; k < ITEMS; k++) {
@@ -215,6 +230,10 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 		}
 	}
 	if (n == 0 && tile == 0 && tid == 0) { i32 tt[NV]; for (int c = 0; c < NV; c++) tt[c] = 0; op.done(tt); }
+#ifdef LB_TIMING
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+	LB_T(3)      // emit (stores drained)
 	}
 	// Ops with a finish(tid) hook: the workgroup that is through LAST runs it (all 256 threads) -- everything every tile
 	// emitted is visible to it.  Used to put counts and list heads into pinned memory for the host without another launch.

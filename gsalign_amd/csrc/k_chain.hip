@@ -947,3 +947,13 @@ int stage2_fetch_host(gsa_ctx *c)
 	c->s2_host = true;
 	return GSA_OK;
 }
+
+#ifdef LB_TIMING
+// experiment build: tick sums of the fused passes of THIS translation unit (chaining): [0] ticket, [1] loads + scan, [2] look-back, [3] emit, [4] tiles; reset = 1 clears them
+extern "C" int gsa_debug_lb_prof(unsigned long long *out, int reset)
+{
+	if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lb_prof), sizeof(g_lb_prof)) != hipSuccess) return -1;
+	if (reset) { unsigned long long z[8] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lb_prof), z, sizeof(z)) != hipSuccess) return -1; }
+	return 0;
+}
+#endif
