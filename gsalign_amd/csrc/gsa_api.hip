@@ -128,6 +128,7 @@ static int ctx_private_init(gsa_ctx *c, gsa_ctx *share = nullptr)
 	}
 	if (share) { c->up = share->up; c->own_up = false; } else if (int rc = uploader_start(c)) return rc;      // (Uploader, gsa_ctx.h)
 	for (int i = 0; i < 28; i++) GSA_CHECK(c, hipEventCreate(&c->ev[i]));
+	GSA_CHECK(c, hipMalloc(&c->d_zero.p, 256)); c->d_zero.cap = 256; GSA_CHECK(c, hipMemset(c->d_zero.p, 0, 256));      // (the bundle tables of a context that holds no bundle: bundle_off_flat)
 	GSA_CHECK(c, hipMalloc(&c->d_cnt.p, 32 * sizeof(u64))); c->d_cnt.cap = 32 * sizeof(u64); GSA_CHECK(c, hipMemset(c->d_cnt.p, 0, 32 * sizeof(u64)));      // (16 counters + the seed kernel's ticket counter)
 	GSA_CHECK(c, hipHostMalloc((void **)&c->h_cnt, 16 * sizeof(u64)));
 	GSA_CHECK(c, hipMalloc(&c->d_mail.p, MAIL_N * sizeof(i32))); c->d_mail.cap = MAIL_N * sizeof(i32);
@@ -248,7 +249,7 @@ void gsa_destroy(gsa_ctx *c)
 	for (int i = 0; i < 2; i++) slot_wait(c->qs[i]);
 	uploader_stop(c);
 	if (c->lender) c->lender->n_borrowers.fetch_sub(1);      // (`parent` outlives its clones: gsa_hip.h)
-	DevBuf *bufs[] = { &c->d_bwt, &c->d_bwt_ref, &c->d_occ_base, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->qs[0].d_query, &c->qs[1].d_query, &c->qs[0].d_bndtab, &c->qs[1].d_bndtab, &c->tmp, &c->d_cnt, &c->d_mail, &c->d_lb_status[0], &c->d_lb_status[1],
+	DevBuf *bufs[] = { &c->d_bwt, &c->d_bwt_ref, &c->d_occ_base, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->qs[0].d_query, &c->qs[1].d_query, &c->qs[0].d_bndtab, &c->qs[1].d_bndtab, &c->tmp, &c->d_cnt, &c->d_zero, &c->d_mail, &c->d_lb_status[0], &c->d_lb_status[1],
 		&c->d_sa_dense, &c->d_kmer, &c->d_kmer_lo, &c->d_pres, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_heavy, &c->dn_lf, &c->dn_x0, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
 		&c->d_flag, &c->d_scan, &c->g_beg, &c->w_j0, &c->d_pdbm, &c->d_pdby, &c->d_pdcb, &c->d_gpre, &c->d_key_c, &c->d_val_c, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
 		&c->a_next, &c->a_brk, &c->a_aurank, &c->a_aulist, &c->a_runinfo, &c->w_best, &c->w_sum, &c->w_n, &c->d_btab, &c->d_flag2, &c->d_scan2, &c->d_i64a,
@@ -388,7 +389,7 @@ int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->a
 static int query_geometry(gsa_ctx *c, int32_t qlen)
 {
 	c->qlen = qlen;
-	c->bnd.n = 0; c->bnd.lmax = qlen; c->bnd.pds = 0; c->bnd.off = nullptr; c->bnd.chunk_contig = nullptr;
+	c->bnd.n = 0; c->bnd.lmax = qlen; c->bnd.pds = 0; c->bnd.off = (const i32 *)c->d_zero.p; c->bnd.chunk_contig = (const uint16_t *)c->d_zero.p;      // (contig 0 at offset 0: readable without asking bnd.n)
 	c->qbits = ceil_log2_u64((u64)qlen + 1); if (c->qbits < 1) c->qbits = 1;
 	c->pd_span = 2 * c->G + (i64)qlen + 2;
 	c->pdbits = ceil_log2_u64((u64)c->pd_span);

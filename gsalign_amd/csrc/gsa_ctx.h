@@ -168,6 +168,7 @@ struct gsa_ctx {
 	i32 n_groups = 0;
 	bool pd_path = false, seed_view_ready = false, pdbm_dirty = true; i64 pd_words = 0;      // groups from the PosDiff bitmap (no PosDiff sort on the hot path)
 	DevBuf w_j0; u32 walk_ticket = 0, walk_epoch = 0;   // window chain of large contigs (k_walk_chain): ticket counter + one entry word per slice, never reset -- the host passes the counter's value and the launch epoch
+	DevBuf d_zero;                                 // 256 zero bytes: Bundle::off / chunk_contig of a context without a bundle
 	DevBuf d_pdby; bool pd_bytes = false;          // a byte per PosDiff value (all zero between contigs), see Options::pd_bytes
 	DevBuf d_pdcb;                                 // coarse bitmap: one bit per block of 32 words of d_pdbm (the blocks that hold a hit)
 	DevBuf d_pdbm, d_gpre, d_key_c, d_val_c;      // bitmap of occupied PosDiff values, group starts below each word, (group, qPos, rank) keys

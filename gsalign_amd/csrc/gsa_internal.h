@@ -70,6 +70,8 @@ struct Bundle {
 #if defined(__HIPCC__)
 __device__ __forceinline__ i32 bundle_contig(const Bundle &b, i32 q) { return b.n ? (i32)b.chunk_contig[q / GSA_CHUNK] : 0; }
 __device__ __forceinline__ i32 bundle_off(const Bundle &b, i32 q) { return b.n ? b.off[b.chunk_contig[q / GSA_CHUNK]] : 0; }
+// the same without a branch around the loads (the fused passes' load(): a context without a bundle points both tables at zeros)
+__device__ __forceinline__ i32 bundle_off_flat(const Bundle &b, i32 q) { return b.off[b.chunk_contig[b.n ? q / GSA_CHUNK : 0]]; }
 #endif
 
 struct DevBuf {

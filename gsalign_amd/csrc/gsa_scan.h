@@ -50,6 +50,27 @@ template <class T> struct lb_has_finish<T, std::void_t<decltype(&T::finish)>> : 
 // wave-cycles waiting -- profiles/r04_sq_human.txt).
 template <class T, class = void> struct lb_has_item : std::false_type {};
 template <class T> struct lb_has_item<T, std::void_t<typename T::Item>> : std::true_type {};
+// Ops that declare `static constexpr bool clamped = true` promise that load(i) / value(i, c) may be called for ANY i in [0, n) without a guard and contain no
+// branch around a load (neighbours are read at clamped indices and selected afterwards).  The pass then calls them unconditionally -- for the elements past the end
+// at index n - 1, result ignored -- so that the ITEMS elements of a thread are one basic block and their loads go out level by level, all elements together.
+// (Round 5: with a guard per element, and `a && b[i - 1]` inside the Ops, every load was waited for on its own -- ~100 loads and ~100 s_waitcnt vmcnt per pass,
+// the elements one after the other: half of a tile's 42 us, profiles/r05_lb_pass_experiments.txt.)
+template <class T, class = void> struct lb_is_clamped : std::false_type {};
+template <class T> struct lb_is_clamped<T, std::void_t<decltype(T::clamped)>> : std::true_type {};
+// optional `void prep(Item &it, i64 i)`: run for every element after ALL loads of the thread are issued -- the place for branches, divisions and rare slow paths
+template <class T, class = void> struct lb_has_prep : std::false_type {};
+template <class T> struct lb_has_prep<T, std::void_t<decltype(&T::prep)>> : std::true_type {};
+// every 32-bit word of a loaded Item is "used" right behind the loads: without that the compiler sinks a load into the conditional block that needs its value
+// (`b = u && ... r - q != ...`: the two a_r loads moved behind a branch on u, one branch per element, and the elements were serial again)
+template <class T> __device__ __forceinline__ void lb_pin(T &x)
+{
+	static_assert(sizeof(T) % 4 == 0, "Items are made of 32- and 64-bit fields");
+	u32 w[sizeof(T) / 4];
+	__builtin_memcpy(w, &x, sizeof(T));
+#pragma unroll
+	for (unsigned k = 0; k < sizeof(T) / 4; k++) asm volatile("" : "+v"(w[k]));
+	__builtin_memcpy(&x, w, sizeof(T));
+}
 template <class T, bool = lb_has_item<T>::value> struct lb_item_of { struct type {}; };
 template <class T> struct lb_item_of<T, true> { using type = typename T::Item; };
 
@@ -174,8 +195,21 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 	i32 v[NV][ITEMS], inc[NV][ITEMS];
 	typename lb_item_of<Op>::type item[ITEMS];
 	if constexpr (lb_has_item<Op>::value) {
+		if constexpr (lb_is_clamped<Op>::value) {
+			if (n > 0) {
 #pragma unroll
-		for (int k = 0; k < ITEMS; k++) { const i64 i = i0 + (i64)k * LB_TPB; if (i < n) item[k] = op.load(i); }
+				for (int k = 0; k < ITEMS; k++) { const i64 i = i0 + (i64)k * LB_TPB; item[k] = op.load(i < n ? i : n - 1); }
+#pragma unroll
+				for (int k = 0; k < ITEMS; k++) lb_pin(item[k]);
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < ITEMS; k++) { const i64 i = i0 + (i64)k * LB_TPB; if (i < n) item[k] = op.load(i); }
+		}
+		if constexpr (lb_has_prep<Op>::value) {
+#pragma unroll
+			for (int k = 0; k < ITEMS; k++) { const i64 i = i0 + (i64)k * LB_TPB; if (i < n) op.prep(item[k], i); }
+		}
 	}
 #pragma unroll
 	for (int k = 0; k < ITEMS; k++) {

@@ -175,16 +175,23 @@ __global__ void k_pd_gather(i64 n, const u64 *__restrict__ key, const u32 *__res
 // brk : unique and PosDiff differs from the previous seed (the only places where
 //       an outlier window may close, :328-331)
 struct OpUniqBrk {
+	static constexpr bool clamped = true;
 	i64 na; const i32 *a_q; const i64 *a_r; const i32 *a_gb, *a_ge;
 	i32 *uniq, *brk, *alive, *cuEx, *brkEx, *blist;
-	__device__ i32 value(i64 i, int c) const
+	struct Item { i32 gb, ge, q, qm, qp, u, b; i64 r, rm; };
+	__device__ Item load(i64 i) const      // (loads only, neighbours at clamped indices: see lb_is_clamped; the flags are prep()'s)
 	{
-		const i32 gb = a_gb[i], ge = a_ge[i], q = a_q[i];
-		const bool u = !(i > gb && a_q[i - 1] == q) && !(i + 1 < ge && a_q[i + 1] == q);
-		if (c == 0) return u ? 1 : 0;
-		return (u && i > gb && (a_r[i] - q) != (a_r[i - 1] - a_q[i - 1])) ? 1 : 0;
+		const i64 im = i > 0 ? i - 1 : 0, ip = i + 1 < na ? i + 1 : i;
+		Item it; it.gb = a_gb[i]; it.ge = a_ge[i]; it.q = a_q[i]; it.qm = a_q[im]; it.qp = a_q[ip]; it.r = a_r[i]; it.rm = a_r[im]; it.u = it.b = 0;
+		return it;
 	}
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const
+	__device__ void prep(Item &it, i64 i) const
+	{
+		const bool u = !(i > it.gb && it.qm == it.q) && !(i + 1 < it.ge && it.qp == it.q);
+		it.u = u ? 1 : 0; it.b = (u && i > it.gb && (it.r - it.q) != (it.rm - it.qm)) ? 1 : 0;
+	}
+	__device__ i32 value(const Item &it, i64, int c) const { return c == 0 ? it.u : it.b; }
+	__device__ void emit(const Item &, i64 i, const i32 *v, const i32 *ex) const
 	{
 		uniq[i] = v[0]; brk[i] = v[1]; alive[i] = 1; cuEx[i] = ex[0]; brkEx[i] = ex[1];
 		if (v[1]) blist[ex[1]] = (i32)i;
@@ -196,16 +203,16 @@ struct OpUniqBrk {
 // GSA_WIN_SEEDS unique seeds (a window needs that many to close, GSAlign.cpp:326-338).  Candidates =
 // heads and break positions of those "big" groups; ws[] starts out as the head flags.
 struct OpCand {
+	static constexpr bool clamped = true;
 	i64 na; const i32 *a_gb, *a_ge, *cuEx, *brk;
 	i32 *candf, *candEx, *clist, *ws;
-	struct Item { i32 cand, head; };
+	struct Item { i32 cand, head, gb, b, ce, cb; };
 	__device__ Item load(i64 i) const
 	{
-		const i32 gb = a_gb[i], ge = a_ge[i];
-		Item it; it.head = i == gb ? 1 : 0;
-		it.cand = (cuEx[ge] - cuEx[gb] >= GSA_WIN_SEEDS && (i == gb || brk[i])) ? 1 : 0;
+		Item it; it.gb = a_gb[i]; it.b = brk[i]; it.ce = cuEx[a_ge[i]]; it.cb = cuEx[it.gb]; it.cand = it.head = 0;
 		return it;
 	}
+	__device__ void prep(Item &it, i64 i) const { it.head = i == it.gb ? 1 : 0; it.cand = (it.ce - it.cb >= GSA_WIN_SEEDS && (i == it.gb || it.b)) ? 1 : 0; }
 	__device__ i32 value(const Item &it, i64, int) const { return it.cand; }
 	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const
 	{
@@ -375,6 +382,7 @@ __device__ __forceinline__ u32 bkt_hash(unsigned long long k, u32 cap) { return 
 
 // window id per seed = (number of starts up to and including it) - 1
 struct OpWindowBuckets {
+	static constexpr bool clamped = true;
 	i64 na; const i32 *a_q; const i64 *a_r; const i32 *uniq, *ws; i64 bmin; u32 cap;
 	i32 *wsEx, *slot_of; Bucket *tab; unsigned long long *wbest, *wsum; i32 *wn;
 	struct Item { i32 ws, uniq; i64 pd; };
@@ -464,22 +472,30 @@ __global__ void k_window_avg(i64 na, const i32 *__restrict__ slot_of, const Buck
 // Round 5: RemoveOutlierSeeds' verdict (GSAlign.cpp:260-296; a kernel of its own until now, k_outlier_kill) is taken where the alive unique seeds are ranked:
 // load() decides "outlier" from the window's modal bucket, mean and this seed's bucket count, emit() writes alive[] and the rank.
 struct OpAliveUnique {      // outlier verdict + ranks of the alive unique seeds
+	static constexpr bool clamped = true;
 	i64 na; const i32 *uniq; i32 *alive, *auEx, *aulist;
 	const i32 *slot_of; const Bucket *tab; const i32 *a_q; const i64 *a_r; const unsigned long long *wbest, *wsum; const i32 *wn; i64 G; i32 max_indel; Bundle bnd;
-	struct Item { i32 alive, uniq; };
+	struct Item { i32 alive, uniq, sl, q, wn, boff; u32 cnt; unsigned long long key, wbest, wsum; i64 r; };
+	// load(): the gathers, three levels deep (slot -> table entry -> window sums), at indices that are valid whatever the slot says; prep(): the verdict
 	__device__ Item load(i64 i) const
 	{
 		Item it; it.uniq = uniq[i]; it.alive = 1;                                    // (every seed is alive in front of this pass: OpUniqBrk)
-		const i32 sl = slot_of[i];
-		if (sl < 0) return it;
-		const unsigned long long k = tab[sl].key; const u32 w = (u32)(k >> 32);
-		const i64 kk = (i64)(u32)k, mode = (i64)(0xFFFFFFFFu - (u32)wbest[w]);
-		const i32 cnt = d_llabs(kk - mode) < 3 ? (i32)(tab[sl].cnt + 1u) : 0;       // counts are read after zeroing (App. B #23)
-		const i64 avg = wn[w] > 0 ? (i64)wsum[w] / wn[w] : G;                      // C division: truncation toward zero
-		const i32 q = a_q[i];
-		const i64 pd = a_r[i] - q + bundle_off(bnd, q);
-		if (d_llabs(avg - pd) > max_indel && cnt < 3) it.alive = 0;               // GSAlign.cpp:290, Min_PD_Freq = 3
+		it.sl = slot_of[i]; it.q = a_q[i]; it.r = a_r[i];
+		const uint4 e = *(const uint4 *)&tab[it.sl < 0 ? 0 : it.sl];                  // {key lo, key hi, cnt, pad}
+		it.key = ((unsigned long long)e.y << 32) | e.x; it.cnt = e.z;
+		const u32 w = it.sl < 0 ? 0u : e.y;                                         // (slot < 0: no entry -- window 0's sums are read and not used)
+		it.wbest = wbest[w]; it.wsum = wsum[w]; it.wn = wn[w];
+		it.boff = bundle_off_flat(bnd, it.q);
 		return it;
+	}
+	__device__ void prep(Item &it, i64) const
+	{
+		if (it.sl < 0) return;
+		const i64 kk = (i64)(u32)it.key, mode = (i64)(0xFFFFFFFFu - (u32)it.wbest);
+		const i32 cnt = d_llabs(kk - mode) < 3 ? (i32)(it.cnt + 1u) : 0;            // counts are read after zeroing (App. B #23)
+		const i64 avg = it.wn > 0 ? (i64)it.wsum / it.wn : G;                        // C division: truncation toward zero
+		const i64 pd = it.r - it.q + it.boff;
+		if (d_llabs(avg - pd) > max_indel && cnt < 3) it.alive = 0;                 // GSAlign.cpp:290, Min_PD_Freq = 3
 	}
 	__device__ i32 value(const Item &it, i64, int) const { return (it.uniq && it.alive) ? 1 : 0; }
 	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const { alive[i] = it.alive; auEx[i] = ex[0]; if (v[0]) aulist[ex[0]] = (i32)i; }
@@ -510,20 +526,21 @@ __device__ __forceinline__ i32 multihit_keep(i64 i, const i32 *__restrict__ a_q,
 // After the first compaction only "is my neighbour in my group" is ever asked, so the seeds
 // carry a group id (the group's old begin index) instead of group bounds.
 struct OpCompactAlive {
+	static constexpr bool clamped = true;
 	const i32 *alive, *a_q, *a_len; const i64 *a_r; const i32 *a_gb, *a_ge, *auEx, *aulist; i64 G; i32 max_indel; Bundle bnd;
-	i32 *b_q, *b_len; i64 *b_r; i32 *b_g, *mail;
-	struct Item { i32 alive, q, len, g; i64 r; };
+	i32 *b_q, *b_len; i64 *b_r; i32 *b_g, *mail; i64 na;
+	struct Item { i32 alive, q, len, g, ge, qm, qp; i64 r; };
 	__device__ Item load(i64 i) const
 	{
-		Item it; it.alive = alive[i] ? 1 : 0; it.q = it.len = it.g = 0; it.r = 0;
-		if (!it.alive) return it;
-		it.q = a_q[i]; it.g = a_gb[i];
-		const i32 ge = a_ge[i];
-		if ((i + 1 < ge && a_q[i + 1] == it.q) || (i > it.g && a_q[i - 1] == it.q)) {      // a multi-hit query position: one member of the run stays at most
-			if (multihit_keep(i, a_q, a_r, it.g, ge, auEx, aulist, G, max_indel, bnd) != (i32)i) { it.alive = 0; return it; }
-		}
-		it.len = a_len[i]; it.r = a_r[i];
+		const i64 im = i > 0 ? i - 1 : 0, ip = i + 1 < na ? i + 1 : i;
+		Item it; it.alive = alive[i]; it.q = a_q[i]; it.g = a_gb[i]; it.ge = a_ge[i]; it.len = a_len[i]; it.r = a_r[i]; it.qm = a_q[im]; it.qp = a_q[ip];
 		return it;
+	}
+	__device__ void prep(Item &it, i64 i) const      // (the multi-hit case is rare and slow: behind everybody's loads)
+	{
+		it.alive = it.alive ? 1 : 0;
+		const bool multi = it.alive && ((i + 1 < it.ge && it.qp == it.q) || (i > it.g && it.qm == it.q));      // a multi-hit query position: one member of the run stays at most
+		if (multi && multihit_keep(i, a_q, a_r, it.g, it.ge, auEx, aulist, G, max_indel, bnd) != (i32)i) it.alive = 0;
 	}
 	__device__ i32 value(const Item &it, i64, int) const { return it.alive; }
 	__device__ void emit(const Item &it, i64, const i32 *v, const i32 *ex) const
@@ -537,20 +554,25 @@ struct OpCompactAlive {
 
 // 3-point noise filter (GSAlign.cpp:355-362): pure stencil on PosDiff, then compaction #2
 struct OpNoise {
+	static constexpr bool clamped = true;
 	const i32 *b_q, *b_len; const i64 *b_r; const i32 *b_g;
-	i32 *c_q, *c_len; i64 *c_r; i32 *c_g, *mail;
-	struct Item { i32 keep, q, len, g; i64 r; };
+	i32 *c_q, *c_len; i64 *c_r; i32 *c_g, *mail; i64 na;
+	struct Item { i32 keep, q, len, g, gm, gp, qm, qp, nb; i64 r, rm, rp; };
 	__device__ Item load(i64 i) const
 	{
-		Item it; it.keep = 0; it.q = it.len = it.g = 0; it.r = 0;
-		const i64 nb = mail[M_NB];
-		if (i >= nb) return it;
-		it.keep = 1; it.q = b_q[i]; it.len = b_len[i]; it.r = b_r[i]; it.g = b_g[i];
-		if (i > 0 && i + 1 < nb && b_g[i - 1] == it.g && b_g[i + 1] == it.g) {
-			const i64 pd = it.r - it.q, p0 = b_r[i - 1] - b_q[i - 1], p1 = b_r[i + 1] - b_q[i + 1];
+		// (what lies beyond the nb compacted seeds is stale but allocated: read, not used)
+		const i64 im = i > 0 ? i - 1 : 0, ip = i + 1 < na ? i + 1 : i;
+		Item it; it.nb = mail[M_NB]; it.q = b_q[i]; it.len = b_len[i]; it.r = b_r[i]; it.g = b_g[i];
+		it.gm = b_g[im]; it.gp = b_g[ip]; it.qm = b_q[im]; it.qp = b_q[ip]; it.rm = b_r[im]; it.rp = b_r[ip]; it.keep = 0;
+		return it;
+	}
+	__device__ void prep(Item &it, i64 i) const
+	{
+		it.keep = i < it.nb ? 1 : 0;
+		if (i > 0 && i + 1 < it.nb && it.gm == it.g && it.gp == it.g) {
+			const i64 pd = it.r - it.q, p0 = it.rm - it.qm, p1 = it.rp - it.qp;
 			if (d_llabs(pd - p0) > 5 && d_llabs(pd - p1) > 5) it.keep = 0;
 		}
-		return it;
 	}
 	__device__ i32 value(const Item &it, i64, int) const { return it.keep; }
 	__device__ void emit(const Item &it, i64, const i32 *v, const i32 *ex) const
@@ -565,35 +587,45 @@ struct OpNoise {
 // block heads (GSAlign.cpp:364-374): group head, query gap > MaxSeedGap, or diagonal jump > 100
 // (second component: prefix sums of the seed lengths, 32-bit wrapping -- only differences over a block are used)
 struct OpBlockHeads {
+	static constexpr bool clamped = true;
 	i64 na; const i32 *c_q, *c_len; const i64 *c_r; const i32 *c_g;
 	i32 *bhead, *bheadEx, *bstart; u32 *ps; i32 *mail;
-	__device__ i32 value(i64 i, int c) const
+	struct Item { i32 h, len, nc, q, qm, lenm, g, gm; i64 r, rm; };
+	__device__ Item load(i64 i) const
 	{
-		if (i >= mail[M_NC]) return 0;
-		if (c == 1) return c_len[i];
-		if (i == 0 || c_g[i - 1] != c_g[i]) return 1;
-		const i64 pd = c_r[i] - c_q[i], p0 = c_r[i - 1] - c_q[i - 1];
-		return (c_q[i] - c_q[i - 1] - c_len[i - 1] > GSA_MAX_SEED_GAP || d_llabs(p0 - pd) > 100) ? 1 : 0;
+		const i64 im = i > 0 ? i - 1 : 0;
+		Item it; it.nc = mail[M_NC]; it.q = c_q[i]; it.qm = c_q[im]; it.len = c_len[i]; it.lenm = c_len[im]; it.g = c_g[i]; it.gm = c_g[im]; it.r = c_r[i]; it.rm = c_r[im]; it.h = 0;
+		return it;
 	}
-	__device__ void emit(i64 i, const i32 *v, const i32 *ex) const { bhead[i] = v[0]; bheadEx[i] = ex[0]; ps[i] = (u32)ex[1]; if (v[0]) bstart[ex[0]] = (i32)i; }
+	__device__ void prep(Item &it, i64 i) const
+	{
+		const i64 pd = it.r - it.q, p0 = it.rm - it.qm;
+		const bool head = i == 0 || it.gm != it.g || it.q - it.qm - it.lenm > GSA_MAX_SEED_GAP || d_llabs(p0 - pd) > 100;
+		it.h = (i < it.nc && head) ? 1 : 0; if (i >= it.nc) it.len = 0;
+	}
+	__device__ i32 value(const Item &it, i64, int c) const { return c == 1 ? it.len : it.h; }
+	__device__ void emit(const Item &, i64 i, const i32 *v, const i32 *ex) const { bhead[i] = v[0]; bheadEx[i] = ex[0]; ps[i] = (u32)ex[1]; if (v[0]) bstart[ex[0]] = (i32)i; }
 	__device__ void done(const i32 *t) const { bheadEx[na] = t[0]; bhead[na] = 0; ps[na] = (u32)t[1]; mail[M_NBRAW] = t[0]; }
 };
 
 // AddAlnBlock filter (GSAlign.cpp:29-49) over the raw blocks + the table of the kept ones
 struct OpBlockFilter {
+	static constexpr bool clamped = true;
 	i64 na; const i32 *bstart, *c_q, *c_len; const u32 *ps; Params prm;
 	i32 *bkeep, *bkeepEx, *blk_beg, *blk_end, *blk_score, *mail;
 	__device__ void span(i64 b, i32 &s, i32 &e) const { const i32 nAll = mail[M_NBRAW]; s = bstart[b]; e = (b + 1 < nAll) ? bstart[b + 1] : mail[M_NC]; }
 	struct Item { i32 keep, s, e, score; };
 	__device__ Item load(i64 b) const
 	{
-		Item it; it.keep = 0; it.s = it.e = it.score = 0;
-		if (b >= mail[M_NBRAW]) return it;
-		span(b, it.s, it.e);
-		it.score = (i32)(ps[it.e] - ps[it.s]);
-		const i32 region = c_q[it.e - 1] + c_len[it.e - 1] - c_q[it.s];
+		// (a raw block that does not exist reads stale starts: clamped into the arrays, its result not used)
+		const i32 nAll = mail[M_NBRAW], nc = mail[M_NC];
+		const i32 s0 = bstart[b], sn = bstart[b + 1];
+		Item it; it.s = s0; it.e = (b + 1 < nAll) ? sn : nc;
+		const i64 sc = it.s < 0 ? 0 : (it.s < na ? it.s : na - 1), ec = it.e < 1 ? 1 : (it.e <= na ? it.e : na);
+		it.score = (i32)(ps[ec] - ps[sc]);
+		const i32 region = c_q[ec - 1] + c_len[ec - 1] - c_q[sc];
 		const bool drop = it.score < prm.MinAlnBlockScore || region < prm.MinAlnLength || (it.score < 1000 && (double)it.score < region * 0.05);
-		it.keep = drop ? 0 : 1;
+		it.keep = (b < nAll && !drop) ? 1 : 0;
 		return it;
 	}
 	__device__ i32 value(const Item &it, i64, int) const { return it.keep; }
@@ -906,10 +938,10 @@ int stage2_chain(gsa_ctx *c)
 	// E. compaction #1, noise stencil + compaction #2 (counts stay in the mailbox)
 	ENS(i32, b_q, na); ENS(i32, b_len, na); ENS(i64, b_r, na); ENS(i32, b_gb, na);
 	{ OpCompactAlive op = { alive, c->a_q.as<i32>(), c->a_len.as<i32>(), c->a_r.as<i64>(), c->a_gb.as<i32>(), c->a_ge.as<i32>(), auEx, aulist, c->G, c->prm.MaxIndelSize, c->bnd,
-	                        c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(), mail }; RC((lb_launch<1>(c, na, op))); }
+	                        c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(), mail, na }; RC((lb_launch<1>(c, na, op))); }
 	ENS(i32, c_q, na); ENS(i32, c_len, na + 1); ENS(i64, c_r, na); ENS(i32, c_gb, na); ENS(i32, c_bid, na);
 	{ OpNoise op = { c->b_q.as<i32>(), c->b_len.as<i32>(), c->b_r.as<i64>(), c->b_gb.as<i32>(),
-	                 c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), mail }; RC((lb_launch<1>(c, na, op))); }
+	                 c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), mail, na }; RC((lb_launch<1>(c, na, op))); }
 	// block cuts + AddAlnBlock
 	i32 *bhead = c->a_uniq.as<i32>(), *bheadEx = c->a_cu.as<i32>(), *bstart = c->a_brk.as<i32>();
 	{ OpBlockHeads op = { na, c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), c->c_gb.as<i32>(), bhead, bheadEx, bstart, c->d_flag2.as<u32>(), mail }; RC((lb_launch<2>(c, na, op))); }
