@@ -21,6 +21,9 @@
 #ifndef LB_GRID_PER_CU
 #define LB_GRID_PER_CU 2    // workgroups per CU of a fused pass (persistent: tiles are drawn from the ticket counter)
 #endif
+#ifndef LB_BATCH
+#define LB_BATCH 4         // elements of a thread whose loads are in flight together (clamped Ops)
+#endif
 #ifndef LB_ITEMS
 #define LB_ITEMS 8          // elements per thread (default).  Round 4 (late): 4 -> 8 once the passes read an element's inputs in front of the scan (Item): a tile's fixed
                             // cost -- ticket, barriers, look-back -- is what a pass pays; 2 / 4 / 8 / 12 / 16 per thread: 3.06 / 2.29 / 1.86 / 1.81 / 3.49 ms for the
@@ -56,7 +59,7 @@ template <class T> struct lb_has_item<T, std::void_t<typename T::Item>> : std::t
 // (Round 5: with a guard per element, and `a && b[i - 1]` inside the Ops, every load was waited for on its own -- ~100 loads and ~100 s_waitcnt vmcnt per pass,
 // the elements one after the other: half of a tile's 42 us, profiles/r05_lb_pass_experiments.txt.)
 template <class T, class = void> struct lb_is_clamped : std::false_type {};
-template <class T> struct lb_is_clamped<T, std::void_t<decltype(T::clamped)>> : std::true_type {};
+template <class T> struct lb_is_clamped<T, std::void_t<decltype(T::clamped)>> : std::integral_constant<bool, T::clamped> {};
 // optional `void prep(Item &it, i64 i)`: run for every element after ALL loads of the thread are issued -- the place for branches, divisions and rare slow paths
 template <class T, class = void> struct lb_has_prep : std::false_type {};
 template <class T> struct lb_has_prep<T, std::void_t<decltype(&T::prep)>> : std::true_type {};
@@ -196,19 +199,28 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 	typename lb_item_of<Op>::type item[ITEMS];
 	if constexpr (lb_has_item<Op>::value) {
 		if constexpr (lb_is_clamped<Op>::value) {
+			// LB_BATCH elements at a time: their loads together, pinned, then their prep() -- the raw values of a batch are dead before the next one is loaded
+			// (all ITEMS = 8 at once: 180 - 250 VGPRs, most of them the 64-bit addresses of ~56 loads in flight)
 			if (n > 0) {
 #pragma unroll
-				for (int k = 0; k < ITEMS; k++) { const i64 i = i0 + (i64)k * LB_TPB; item[k] = op.load(i < n ? i : n - 1); }
+				for (int k0 = 0; k0 < ITEMS; k0 += LB_BATCH) {
 #pragma unroll
-				for (int k = 0; k < ITEMS; k++) lb_pin(item[k]);
+					for (int k = k0; k < k0 + LB_BATCH && k < ITEMS; k++) { const i64 i = i0 + (i64)k * LB_TPB; item[k] = op.load(i < n ? i : n - 1); }
+#pragma unroll
+					for (int k = k0; k < k0 + LB_BATCH && k < ITEMS; k++) lb_pin(item[k]);
+					if constexpr (lb_has_prep<Op>::value) {
+#pragma unroll
+						for (int k = k0; k < k0 + LB_BATCH && k < ITEMS; k++) { const i64 i = i0 + (i64)k * LB_TPB; if (i < n) op.prep(item[k], i); }
+					}
+				}
 			}
 		} else {
 #pragma unroll
 			for (int k = 0; k < ITEMS; k++) { const i64 i = i0 + (i64)k * LB_TPB; if (i < n) item[k] = op.load(i); }
-		}
-		if constexpr (lb_has_prep<Op>::value) {
+			if constexpr (lb_has_prep<Op>::value) {
 #pragma unroll
-			for (int k = 0; k < ITEMS; k++) { const i64 i = i0 + (i64)k * LB_TPB; if (i < n) op.prep(item[k], i); }
+				for (int k = 0; k < ITEMS; k++) { const i64 i = i0 + (i64)k * LB_TPB; if (i < n) op.prep(item[k], i); }
+			}
 		}
 	}
 #pragma unroll

@@ -687,15 +687,49 @@ struct OpEarlyGaps {
 		i32 mism;
 		return classify_gap(query, ref, qp, rp, qg, rg, mism) == FT_DP;
 	}
-	// (everything a seed's verdict needs is read once, in front of the scan: Item)
-	struct Item { i32 in, bid, g, qp, qg, rg; i64 rp; };      // in: s < the live seed count; g: a large DP gap follows s; qg / rg: its two lengths as the job list takes them
+	// (everything a seed's verdict needs is read once, in front of the scan: Item.  Round 5, late: load() only loads -- this seed and the next, their raw blocks'
+	//  keep flags and numbers, the block's score, all at clamped indices -- and prep() decides; the sequence comparison of a large gap (rare) and the span test of a
+	//  middling block are prep()'s too, behind everybody's loads.  Same decisions as gap() / bid_of() / early_block() above, which the tests of stage 2 still call.)
+	static constexpr bool clamped = true;
+	struct Item { i32 in, bid, g, qp, qg, rg; i64 rp;      // in: s < the live seed count; g: a large DP gap follows s; qg / rg: its two lengths as the job list takes them
+	              i32 q0, len0, q1, k0, x0, k1, x1, sc0; i64 r0, r1; };      // raw: this seed, the next one's start, keep flag / kept number of their raw blocks, score of this one's block
 	__device__ Item load(i64 s) const
 	{
+		const i64 sp = s + 1 < na ? s + 1 : s;
 		Item it; it.in = 0; it.bid = -1; it.g = 0; it.qp = it.qg = it.rg = 0; it.rp = 0;
-		if (s < mail[M_NC]) { it.in = 1; it.bid = bid_of(s); }
-		i32 qp, qg, rg; i64 rp;
-		if (gap(s, qp, rp, qg, rg)) { it.g = 1; it.qp = qp; it.rp = rp; it.qg = q[s + 1] - qp; it.rg = (i32)(r[s + 1] - rp); }
+		it.q0 = q[s]; it.len0 = len[s]; it.r0 = r[s]; it.q1 = q[sp]; it.r1 = r[sp];
+		i64 b0 = (i64)headEx[s] + head[s] - 1, b1 = (i64)headEx[sp] + head[sp] - 1;
+		b0 = b0 < 0 ? 0 : (b0 < na ? b0 : na - 1); b1 = b1 < 0 ? 0 : (b1 < na ? b1 : na - 1);
+		it.k0 = bkeep[b0]; it.x0 = bkeepEx[b0]; it.k1 = bkeep[b1]; it.x1 = bkeepEx[b1];
+		const i64 kb = it.x0 < 0 ? 0 : (it.x0 <= na ? it.x0 : na);
+		it.sc0 = blk_score[kb];
 		return it;
+	}
+	__device__ void prep(Item &it, i64 s) const
+	{
+		const i32 nc = mail[M_NC];
+		if (s >= nc) return;
+		it.in = 1; it.bid = it.k0 ? it.x0 : -1;
+		if (s + 1 >= nc) return;
+		const i32 b0 = it.bid, b1 = it.k1 ? it.x1 : -1;
+		if (b0 < 0 || b1 != b0) return;
+		{	// early_block(b0) with the score at hand
+			const unsigned long long mx = *(const unsigned long long *)(mail + M_MAXBLK);
+			const i32 bm = (i32)(u32)mx; const i64 sm = (i64)(mx >> 32);
+			if (!(b0 == bm || (i64)it.sc0 * 4 >= sm)) {
+				if ((i64)it.sc0 * 16 < sm) return;
+				const i32 qs = q[blk_beg[b0]], qe = q[blk_end[b0] - 1] + len[blk_end[b0] - 1];
+				const i32 ms = q[blk_beg[bm]], me = q[blk_end[bm] - 1] + len[blk_end[bm] - 1];
+				if (qs >= ms && qe <= me) return;
+			}
+		}
+		const i32 qp = it.q0 + it.len0; const i64 rp = it.r0 + it.len0;
+		i32 qg = it.q1 - qp; if (qg < 0) qg = 0;
+		const i64 rg64 = it.r1 - rp; const i32 rg = rg64 < 0 ? 0 : (i32)rg64;
+		if (qg > GSA_MAX_SEED_GAP || rg64 > GSA_MAX_SEED_GAP || !dp_is_large(rg, qg)) return;      // (cheap tests first)
+		i32 mism;
+		if (classify_gap(query, ref, qp, rp, qg, rg, mism) != FT_DP) return;
+		it.g = 1; it.qp = qp; it.rp = rp; it.qg = it.q1 - qp; it.rg = (i32)(it.r1 - rp);
 	}
 	__device__ i32 value(const Item &it, i64, int c) const { return c == 1 ? (it.g ? it.qg + it.rg : 0) : it.g; }
 	__device__ void emit(const Item &it, i64 s, const i32 *v, const i32 *ex) const
@@ -710,6 +744,7 @@ struct OpEarlyGaps {
 	__device__ void done(const i32 *t) const { lb_pub(&mail[M_NEARLY], t[0]); lb_pub(&mail[M_EOPS], t[1]); lb_pub(&mail[M_DPERR3], 0); }
 	// the last tile puts the two counts and the head of the list into pinned memory: the host launches from there
 	i32 *h_early; i32 h_cap;
+	i64 na;      // (elements of the launch: the arrays' length; set behind the aggregate)
 	__device__ void finish(int tid) const
 	{
 		const i32 ne = __hip_atomic_load(&mail[M_NEARLY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -956,7 +991,7 @@ int stage2_chain(gsa_ctx *c)
 	{ OpEarlyGaps op = { c->c_q.as<i32>(), c->c_len.as<i32>(), c->c_r.as<i64>(), bhead, bheadEx, bkeep, bkeepEx, c->c_bid.as<i32>(), c->q_dev, c->di.ref,
 	                     c->e_id.as<i32>(), c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(), c->e_opsoff.as<i64>(), mail,
 	                     c->blk_beg.as<i32>(), c->blk_end.as<i32>(), c->blk_score.as<i32>(), c->e_rec.as<i32>(),
-	                     c->p_early.as<i32>(), (i32)std::min<i64>(na, EARLY_CHUNK) }; RC((lb_launch<2>(c, na, op))); }
+	                     c->p_early.as<i32>(), (i32)std::min<i64>(na, EARLY_CHUNK) }; op.na = na; RC((lb_launch<2>(c, na, op))); }
 	GSA_CHECK(c, hipEventRecord(c->ev[16], st));
 	c->early_listed = true;
 	return GSA_OK;      // counts stay in the mailbox; stage 3 reads them with its own first read-back

@@ -757,8 +757,10 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 // as (job, m, n) triples and packs the others into the small kernel's order array.
 struct OpClassify {
 	const i32 *len1, *len2; i32 *order, *order_tiny, *lg, *jlarge, *mail;
+	static constexpr bool clamped = true;      // (gsa_scan.h: every element's loads unconditional and together; beyond the job count the lengths are stale, not used)
 	struct Item { i32 in, m, n; };
-	__device__ Item load(i64 j) const { Item it; it.in = j < mail[M_NJOB] ? 1 : 0; it.m = it.in ? len1[j] : 0; it.n = it.in ? len2[j] : 0; return it; }
+	__device__ Item load(i64 j) const { Item it; it.in = 0; it.m = len1[j]; it.n = len2[j]; return it; }
+	__device__ void prep(Item &it, i64 j) const { it.in = j < mail[M_NJOB] ? 1 : 0; if (!it.in) it.m = it.n = 0; }
 	__device__ i32 value(const Item &it, i64, int c) const
 	{
 		if (!it.in) return 0;

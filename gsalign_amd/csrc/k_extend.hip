@@ -28,7 +28,11 @@ __device__ __forceinline__ i32 find_block(const i32 *__restrict__ base, i32 nfb,
 // (each struct below is one fused pass: value -> exclusive scan -> emit, see gsa_scan.h)
 // per seed slot: the seed record and, if a gap follows (IdentifyNormalPairs :241-265), the gap record,
 // classified (GenerateFragAlignment :311-342)
-struct OpSlots {
+// STEPS > 0 (round 5): fewer than 2^STEPS blocks -- the slot's block is found by exactly STEPS probes without a branch and every load of load() is unconditional, so
+// the loads of a thread's elements go out together (gsa_scan.h, clamped Ops); STEPS = 0: any number of blocks, the loop form.
+template <int STEPS>
+struct OpSlotsT {
+	static constexpr bool clamped = STEPS > 0;
 	i32 nfb; const i32 *seedbase, *sbeg, *q, *len; const i64 *r; const i32 *e_id, *r_orig;
 	gsa_frag *frag; i32 *ftype, *fmism, *fragbase, *fearly, *mail;
 	__device__ void slot(i64 i, i32 &k, i32 &s, i32 &n) const
@@ -41,15 +45,35 @@ struct OpSlots {
 			if (qg > 0 || rg > 0) n = 2;
 		}
 	}
-	struct Item { i32 k, first, n, q, len, qn, early; i64 r, rn; };      // first: the slot opens block k; n = 2: a gap record follows; qn / rn: the next seed's start; early: its early DP job
+	struct Item { i32 k, first, n, q, len, qn, early; i64 r, rn; i32 last; };      // first: the slot opens block k; n = 2: a gap record follows; qn / rn: the next seed's start; early: its early DP job
 	__device__ Item load(i64 i) const
 	{
 		Item it; i32 s;
-		slot(i, it.k, s, it.n);
-		it.first = i == seedbase[it.k] ? 1 : 0;
-		it.q = q[s]; it.len = len[s]; it.r = r[s]; it.qn = 0; it.rn = 0; it.early = -1;
-		if (it.n == 2) { it.qn = q[s + 1]; it.rn = r[s + 1]; it.early = e_id[r_orig[s]]; }
+		if constexpr (STEPS > 0) {
+			i32 lo = 0, hi = nfb;                      // last k with seedbase[k] <= i
+#pragma unroll
+			for (int st = 0; st < STEPS; st++) { const i32 m = (lo + hi) >> 1; const bool act = hi - lo > 1, le = seedbase[m] <= i; lo = (act && le) ? m : lo; hi = (act && !le) ? m : hi; }
+			it.k = lo;
+			const i32 sb = seedbase[lo], sb1 = seedbase[lo + 1];
+			s = sbeg[lo] + (i32)(i - sb);
+			it.first = i == sb ? 1 : 0; it.last = i + 1 == sb1 ? 1 : 0;
+			const i32 sp = it.last ? s : s + 1;      // (the block's last seed has no successor in the block: its own values are read and not used)
+			it.q = q[s]; it.len = len[s]; it.r = r[s]; it.qn = q[sp]; it.rn = r[sp]; it.early = e_id[r_orig[s]]; it.n = 1;
+		} else {
+			slot(i, it.k, s, it.n);
+			it.first = i == seedbase[it.k] ? 1 : 0; it.last = 0;
+			it.q = q[s]; it.len = len[s]; it.r = r[s]; it.qn = 0; it.rn = 0; it.early = -1;
+			if (it.n == 2) { it.qn = q[s + 1]; it.rn = r[s + 1]; it.early = e_id[r_orig[s]]; }
+		}
 		return it;
+	}
+	__device__ void prep(Item &it, i64) const
+	{
+		if constexpr (STEPS > 0) {
+			it.n = 1;
+			if (!it.last) { const i32 qg = it.qn - (it.q + it.len); const i64 rg = it.rn - (it.r + it.len); if (qg > 0 || rg > 0) it.n = 2; }
+			if (it.n != 2) { it.qn = 0; it.rn = 0; it.early = -1; }
+		}
 	}
 	__device__ i32 value(const Item &it, i64, int) const { return it.n; }
 	__device__ void emit(const Item &it, i64, const i32 *v, const i32 *ex) const
@@ -94,6 +118,7 @@ __global__ void k_gap_class(i64 ub, const i32 *__restrict__ mail, const gsa_frag
 struct OpDpJobs {
 	const i32 *ftype, *fearly; gsa_frag *frag; gsa_rec *rec16;
 	i32 *jfrag; i64 *off1; i32 *len1; i64 *off2; i32 *len2; i64 *opsoff; i32 *fjob, *alen; i64 *aoff; i32 *mail;
+	// (not a clamped Op: twelve 48-byte Items per thread are 156 VGPRs as it is; with the loads of four elements pinned together the kernel needs 324)
 	struct Item { gsa_frag f; i32 t, early; };      // t = -1: behind the last record
 	__device__ Item load(i64 i) const
 	{
@@ -394,9 +419,11 @@ int stage7_fill(gsa_ctx *c)
 	ENS(gsa_frag, f_rec, nfu + 1); ENS(i32, f_type, nfu + 1); ENS(i32, f_mism, nfu + 1); ENS(i32, f_score, nfu + 1); ENS(i32, f_job, nfu + 1); ENS(i32, f_alnlen, nfu + 1);
 	ENS(i32, f_early, nfu + 2);
 	// (e_rec[] of the early jobs is -1 since the pass that listed them, OpEarlyGaps)
-	OpSlots op = { nfb, c->fb_seedbase.as<i32>(), d_sbeg, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->e_id.as<i32>(), c->r_orig.as<i32>(),
-	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), d_fragbase, c->f_early.as<i32>(), c->d_mail.as<i32>() };
-	RC((lb_launch<1>(c, ns, op)));
+#define GSA_SLOTS_ARGS { nfb, c->fb_seedbase.as<i32>(), d_sbeg, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->e_id.as<i32>(), c->r_orig.as<i32>(), \
+	               c->f_rec.as<gsa_frag>(), c->f_type.as<i32>(), c->f_mism.as<i32>(), d_fragbase, c->f_early.as<i32>(), c->d_mail.as<i32>() }
+	if (nfb < 256) { OpSlotsT<8> op = GSA_SLOTS_ARGS; RC((lb_launch<1>(c, ns, op))); }
+	else { OpSlotsT<0> op = GSA_SLOTS_ARGS; RC((lb_launch<1>(c, ns, op))); }
+#undef GSA_SLOTS_ARGS
 	LAUNCH(k_gap_class, nfu, nfu, c->d_mail.as<i32>(), c->f_rec.as<gsa_frag>(), c->q_dev, c->di.ref, c->e_list.as<i32>(), c->e_off1.as<i64>(), c->e_off2.as<i64>(),
 	       c->f_type.as<i32>(), c->f_mism.as<i32>(), c->f_early.as<i32>(), c->e_rec.as<i32>());
 	c->n_frags = -1;

@@ -27,13 +27,10 @@
 struct OpTakeInBlock {      // seeds that belong to a kept S2 block
 	const i32 *c_q, *c_len; const i64 *c_r; const i32 *c_bid;
 	i32 *r_q, *r_len; i64 *r_r; i32 *r_bid, *r_orig, *mail;      // r_orig: index in the stage-2 seed arrays (links stage-2's early DP launches to the final gaps)
+	static constexpr bool clamped = true;      // (gsa_scan.h: loads of every element unconditional; what lies beyond the live count is stale but allocated)
 	struct Item { i32 q, len, bid; i64 r; };      // (bid < 0: not taken)
-	__device__ Item load(i64 i) const
-	{
-		Item it; it.bid = -1; it.q = it.len = 0; it.r = 0;
-		if (i < mail[M_NC]) { it.bid = c_bid[i]; it.q = c_q[i]; it.len = c_len[i]; it.r = c_r[i]; }
-		return it;
-	}
+	__device__ Item load(i64 i) const { Item it; it.bid = c_bid[i]; it.q = c_q[i]; it.len = c_len[i]; it.r = c_r[i]; return it; }
+	__device__ void prep(Item &it, i64 i) const { if (i >= mail[M_NC]) it.bid = -1; }
 	__device__ i32 value(const Item &it, i64, int) const { return it.bid >= 0 ? 1 : 0; }
 	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const
 	{
@@ -49,27 +46,33 @@ struct OpTakeInBlock {      // seeds that belong to a kept S2 block
 struct OpOverlapPass {
 	const i32 *q, *len; const i64 *r; const i32 *bid, *orig;
 	i32 *oq, *olen; i64 *orr; i32 *obid, *oorig, *mail; int nin, nout, anyslot;
-	struct Item { i32 in, keep, l, q, bid, orig; i64 r; };      // in: i < the live count; keep / l: the pass's verdict and the trimmed length
+	static constexpr bool clamped = true;
+	i64 ub;      // (elements of the launch = length of the arrays; set behind the aggregate)
+	struct Item { i32 in, keep, l, q, bid, orig; i64 r;      // in: i < the live count; keep / l: the pass's verdict and the trimmed length
+	              i32 qj, bj; i64 rj; };                        // raw: the next seed
 	__device__ Item load(i64 i) const
 	{
-		Item it; it.in = 0; it.keep = 0; it.l = it.q = it.bid = it.orig = 0; it.r = 0;
+		const i64 ip = i + 1 < ub ? i + 1 : i;
+		Item it; it.in = 0; it.keep = 0;
+		it.l = len[i]; it.r = r[i]; it.q = q[i]; it.bid = bid[i]; it.orig = orig[i];
+		it.bj = bid[ip]; it.rj = r[ip]; it.qj = q[ip];
+		return it;
+	}
+	__device__ void prep(Item &it, i64 i) const
+	{
 		const i64 n = mail[nin];
-		if (i >= n) return it;
+		if (i >= n) return;
 		it.in = 1; it.keep = 1;
-		i32 l = len[i];
-		const i64 ri = r[i]; const i32 qi = q[i], bi = bid[i];
-		it.q = qi; it.r = ri; it.bid = bi; it.orig = orig[i];
-		if (i + 1 < n && bid[i + 1] == bi) {
-			const i64 rj = r[i + 1]; const i32 qj = q[i + 1];
-			if (rj <= ri) it.keep = 0;
+		i32 l = it.l;
+		if (i + 1 < n && it.bj == it.bid) {
+			if (it.rj <= it.r) it.keep = 0;
 			else {
-				i32 ov = (i32)(ri + l - rj);
+				i32 ov = (i32)(it.r + l - it.rj);
 				if (ov > 0) { l -= ov; if (l <= 0) it.keep = 0; }
-				if (it.keep) { ov = qi + l - qj; if (ov > 0) { l -= ov; if (l <= 0) it.keep = 0; } }
+				if (it.keep) { ov = it.q + l - it.qj; if (ov > 0) { l -= ov; if (l <= 0) it.keep = 0; } }
 			}
 		}
 		it.l = l;
-		return it;
 	}
 	__device__ i32 value(const Item &it, i64, int) const { return it.in ? it.keep : 0; }
 	__device__ void emit(const Item &it, i64, const i32 *v, const i32 *ex) const
@@ -87,20 +90,25 @@ struct OpOverlapPass {
 struct OpGapCuts {
 	int nin; const i32 *q, *len; const i64 *r; const i32 *bid;
 	i32 *cut4, *jq1, *jq2; i64 *jr1, *jr2; i32 *jseed, *mail;
-	struct Item { i32 cut, jb, q1, q2; i64 r1, r2; };
+	static constexpr bool clamped = true;
+	struct Item { i32 cut, jb, q1, q2; i64 r1, r2; i32 b0, b1, l0; };
 	__device__ Item load(i64 i) const
 	{
-		Item it; it.cut = 0; it.jb = 0; it.q1 = it.q2 = 0; it.r1 = it.r2 = 0;
-		if (i < mail[nin] && i > 0 && bid[i - 1] == bid[i]) {
-			const i32 l0 = len[i - 1];
-			it.q1 = q[i - 1] + l0; it.q2 = q[i]; it.r1 = r[i - 1] + l0; it.r2 = r[i];
+		const i64 im = i > 0 ? i - 1 : 0;
+		Item it; it.cut = 0; it.jb = 0;
+		it.b0 = bid[im]; it.b1 = bid[i]; it.l0 = len[im]; it.q1 = q[im]; it.q2 = q[i]; it.r1 = r[im]; it.r2 = r[i];
+		return it;
+	}
+	__device__ void prep(Item &it, i64 i) const
+	{
+		if (i < mail[nin] && i > 0 && it.b0 == it.b1) {
+			it.q1 += it.l0; it.r1 += it.l0;
 			const i32 qGap = it.q2 - it.q1;
 			const i32 rGap = (i32)(it.r2 - it.r1);
 			if (qGap > GSA_GAP_CHECK || rGap > GSA_GAP_CHECK) {
 				if (qGap > GSA_MAX_SEED_GAP || rGap > GSA_MAX_SEED_GAP) it.cut = 1; else it.jb = 1;
 			}
-		}
-		return it;
+		} else { it.q1 = it.q2 = 0; it.r1 = it.r2 = 0; }
 	}
 	__device__ i32 value(const Item &it, i64, int) const { return it.jb; }
 	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const
@@ -117,7 +125,12 @@ struct OpGapCuts {
 // rPos is strictly increasing after S3, so "first seed past the end of the copy
 // holding the piece's first seed" == "copy index changes".  Second component: prefix sums of the
 // trimmed lengths, 32-bit wrapping -- only differences over a leaf are ever used.
-struct OpChrCuts {
+// STEPS > 0 (round 5): the reference has fewer than 2^STEPS sequence ends, and both lower bounds of EVERY element are found by exactly STEPS probes without a branch --
+// the probes of a thread's elements go out together (gsa_scan.h, clamped Ops).  The loop form (STEPS = 0: any number of ends) ran its two searches of ~6 dependent
+// loads each for one element after the other: ~100 dependent loads per thread and tile.
+template <int STEPS>
+struct OpChrCutsT {
+	static constexpr bool clamped = STEPS > 0;
 	i64 ub; const i32 *d_n; DevIndex di; const i64 *r; const i32 *bid, *cut4, *len;
 	i32 *cut5, *lstart, *head; u32 *ps; i32 *mail;
 	__device__ void cuts(i64 i, i32 &c5, i32 &h) const
@@ -133,13 +146,42 @@ struct OpChrCuts {
 			}
 		}
 	}
-	struct Item { i32 in, c5, h, len; };
+	__device__ int lower_fixed(i64 a) const
+	{
+		int lo = 0, hi = di.n_ends;
+#pragma unroll
+		for (int s = 0; s < STEPS; s++) {
+			const int m = (lo + hi) >> 1;
+			const i64 v = di.chr_end[m < di.n_ends ? m : di.n_ends - 1];
+			const bool act = lo < hi, less = v < a;
+			lo = (act && less) ? m + 1 : lo; hi = (act && !less) ? m : hi;
+		}
+		return lo;
+	}
+	struct Item { i32 in, c5, h, len, b0, b1, c4, lo0, lo1; };
 	__device__ Item load(i64 i) const
 	{
 		Item it; it.in = 0; it.c5 = 0; it.h = 0; it.len = 0;
-		if (i >= *d_n) return it;
-		it.in = 1; it.len = len[i]; cuts(i, it.c5, it.h);
+		if constexpr (STEPS > 0) {
+			const i64 im = i > 0 ? i - 1 : 0;
+			it.len = len[i]; it.b0 = bid[im]; it.b1 = bid[i]; it.c4 = cut4[i];
+			it.lo0 = lower_fixed(r[im]); it.lo1 = lower_fixed(r[i]);
+		} else {
+			if (i >= *d_n) return it;
+			it.in = 1; it.len = len[i]; cuts(i, it.c5, it.h);
+		}
 		return it;
+	}
+	__device__ void prep(Item &it, i64 i) const
+	{
+		if constexpr (STEPS > 0) {
+			if (i >= *d_n) { it.len = 0; return; }
+			it.in = 1; it.c5 = 0; it.h = 1;
+			if (i > 0 && it.b0 == it.b1) {
+				it.h = it.c4;
+				if (!it.c4 && it.lo0 != it.lo1) { it.c5 = 1; it.h = 1; }
+			}
+		}
 	}
 	__device__ i32 value(const Item &it, i64, int c) const { return c == 1 ? it.len : it.h; }
 	__device__ void emit(const Item &it, i64 i, const i32 *v, const i32 *ex) const
@@ -202,7 +244,7 @@ int stage345_refine(gsa_ctx *c)
 	for (;;) {
 		for (int k = 0; k < 2; k++, round++) {
 			OpOverlapPass op = { c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), c->r_orig.as<i32>(),
-			                     c->r_tmp_q.as<i32>(), c->r_tmp_len.as<i32>(), c->r_tmp_r.as<i64>(), c->r_tmp_bid.as<i32>(), c->r_tmp_orig.as<i32>(), mail, cur, oth, M_ANY + (round & 31) };
+			                     c->r_tmp_q.as<i32>(), c->r_tmp_len.as<i32>(), c->r_tmp_r.as<i64>(), c->r_tmp_bid.as<i32>(), c->r_tmp_orig.as<i32>(), mail, cur, oth, M_ANY + (round & 31) }; op.ub = ub;
 			RC((lb_launch<1>(c, ub, op)));
 			std::swap(c->r_q, c->r_tmp_q); std::swap(c->r_len, c->r_tmp_len); std::swap(c->r_r, c->r_tmp_r); std::swap(c->r_bid, c->r_tmp_bid); std::swap(c->r_orig, c->r_tmp_orig);
 			std::swap(cur, oth);
@@ -211,7 +253,8 @@ int stage345_refine(gsa_ctx *c)
 		{ OpGapCuts op = { cur, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, jq1, jq2, jr1, jr2, jseed, mail }; RC((lb_launch<1>(c, ub, op))); }
 		RC(run_gapsim_jobs(c, (i32)ub, mail + M_NJ, jq1, jq2, jr1, jr2, c->r_simres.as<i32>(), jseed, cut4));      // (sets cut4 of the dissimilar gaps)
 		// S5 cuts + leaf table + large DP gaps of the leaves
-		{ OpChrCuts op = { ub, mail + cur, c->di, c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, c->r_len.as<i32>(), cut5, lstart, c->r_head.as<i32>(), ps, mail }; RC((lb_launch<2>(c, ub, op))); }
+		if (c->di.n_ends > 0 && c->di.n_ends < 256) { OpChrCutsT<8> op = { ub, mail + cur, c->di, c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, c->r_len.as<i32>(), cut5, lstart, c->r_head.as<i32>(), ps, mail }; RC((lb_launch<2>(c, ub, op))); }
+		else { OpChrCutsT<0> op = { ub, mail + cur, c->di, c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, c->r_len.as<i32>(), cut5, lstart, c->r_head.as<i32>(), ps, mail }; RC((lb_launch<2>(c, ub, op))); }
 		LAUNCH(k_leaf_emit, ub, ub, mail + cur, mail, lstart, c->r_q.as<i32>(), c->r_len.as<i32>(), c->r_r.as<i64>(), c->r_bid.as<i32>(), cut4, cut5, ps,
 		       c->blk_score.as<i32>(), c->d_leaf.as<Leaf>(), c->h_mail, c->p_leaf.as<Leaf>(), (i32)first);
 		// (the mailbox and the first LEAF_CHUNK leaves are in pinned memory when this kernel is done)
