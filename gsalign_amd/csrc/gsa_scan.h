@@ -163,6 +163,19 @@ __device__ __forceinline__ void lb_tile_prefix(const LbArgs &lb, int tile, const
 // a store that the finish() hook of a pass (run by whichever workgroup is through last, possibly on another XCD) will read
 __device__ __forceinline__ void lb_pub(i32 *p, i32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// for finish() hooks: n words that other workgroups published with lb_pub() -> pinned host memory, by the whole workgroup.  Eight agent-scope loads in flight per
+// thread before the first store (one load, one store, one load ... was a round trip past the L2 per 256 words: 48 of them for the first 4 096 large gaps of a contig)
+__device__ __forceinline__ void lb_copy_out(i32 *dst, const i32 *src, i32 n, int tid)
+{
+	for (i32 t0 = 0; t0 < n; t0 += 8 * LB_TPB) {
+		i32 v[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++) { const i32 t = t0 + u * LB_TPB + tid; v[u] = t < n ? __hip_atomic_load(&src[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; }
+#pragma unroll
+		for (int u = 0; u < 8; u++) { const i32 t = t0 + u * LB_TPB + tid; if (t < n) dst[t] = v[u]; }
+	}
+}
+
 // Generic fused pass over i in [0, n):  v = op.value(i, k)  (NV components, k < NV),
 // ex = exclusive prefix sums, then op.emit(i, v, ex);  op.done(totals) once, by the thread
 // that owns the last element (or thread 0 of tile 0 when n == 0).

@@ -690,7 +690,10 @@ struct OpEarlyGaps {
 	// (everything a seed's verdict needs is read once, in front of the scan: Item.  Round 5, late: load() only loads -- this seed and the next, their raw blocks'
 	//  keep flags and numbers, the block's score, all at clamped indices -- and prep() decides; the sequence comparison of a large gap (rare) and the span test of a
 	//  middling block are prep()'s too, behind everybody's loads.  Same decisions as gap() / bid_of() / early_block() above, which the tests of stage 2 still call.)
-	static constexpr bool clamped = true;
+#ifndef EG_CLAMPED
+#define EG_CLAMPED false      // (measured: 236 us per 250 Mb contig with the elements one after the other, 276 with their loads together -- the verdict needs 14 values per seed, and 154 - 176 VGPRs)
+#endif
+	static constexpr bool clamped = EG_CLAMPED;
 	struct Item { i32 in, bid, g, qp, qg, rg; i64 rp;      // in: s < the live seed count; g: a large DP gap follows s; qg / rg: its two lengths as the job list takes them
 	              i32 q0, len0, q1, k0, x0, k1, x1, sc0; i64 r0, r1; };      // raw: this seed, the next one's start, keep flag / kept number of their raw blocks, score of this one's block
 	__device__ Item load(i64 s) const
@@ -750,7 +753,7 @@ struct OpEarlyGaps {
 		const i32 ne = __hip_atomic_load(&mail[M_NEARLY], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (tid == 0) { h_early[0] = ne; h_early[1] = __hip_atomic_load(&mail[M_EOPS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 		const i32 w = 3 * (ne < h_cap ? ne : h_cap);
-		for (i32 t = tid; t < w; t += LB_TPB) h_early[4 + t] = __hip_atomic_load(&e_list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		lb_copy_out(h_early + 4, e_list, w, tid);
 	}
 };
 #define EARLY_CHUNK 4096      // large gaps copied with the first look (more -> a second copy)

@@ -787,7 +787,7 @@ struct OpClassify {
 	{
 		if (tid < MAIL_N) h_out[tid] = __hip_atomic_load(&mail[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		i32 nl = __hip_atomic_load(&mail[M_NLARGE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (nl > h_cap) nl = h_cap;
-		for (i32 t = tid; t < 3 * nl; t += LB_TPB) h_out[MAIL_N + t] = __hip_atomic_load(&lg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		lb_copy_out(h_out + MAIL_N, lg, 3 * nl, tid);
 	}
 };
 
