@@ -74,6 +74,9 @@ template <class T> __device__ __forceinline__ void lb_pin(T &x)
 	for (unsigned k = 0; k < sizeof(T) / 4; k++) asm volatile("" : "+v"(w[k]));
 	__builtin_memcpy(&x, w, sizeof(T));
 }
+// optional `emit_all(items, i0, in[], v[], ex[])` instead of emit(): all ITEMS rows of the thread at once (row k is element i0 + k * LB_TPB, in[k]: it exists)
+template <class T, class = void> struct lb_has_emit_all : std::false_type {};
+template <class T> struct lb_has_emit_all<T, std::void_t<decltype(T::has_emit_all)>> : std::true_type {};
 template <class T, bool = lb_has_item<T>::value> struct lb_item_of { struct type {}; };
 template <class T> struct lb_item_of<T, true> { using type = typename T::Item; };
 
@@ -277,6 +280,16 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 	if (tid == 0) atomicAdd(&g_lb_prof[4], 1ull);
 #endif
 	i32 vv[NV], ee[NV];
+	if constexpr (lb_has_emit_all<Op>::value) {
+		// (single-component Ops whose emit() has round trips of its own -- atomics with a result: the rows of a thread go through them together)
+		static_assert(NV == 1, "emit_all: one component");
+		i32 ex0[ITEMS]; bool in[ITEMS];
+#pragma unroll
+		for (int k = 0; k < ITEMS; k++) { ex0[k] = pre[0] + inc[0][k]; in[k] = i0 + (i64)k * LB_TPB < n; }
+		op.emit_all(item, i0, in, v[0], ex0);
+#pragma unroll
+		for (int k = 0; k < ITEMS; k++) if (i0 + (i64)k * LB_TPB == n - 1) { i32 tt[1] = { ex0[k] + v[0][k] }; op.done(tt); }
+	} else {
 #pragma unroll
 	for (int k = 0; k < ITEMS; k++) {
 		const i64 i = i0 + (i64)k * LB_TPB;
@@ -287,6 +300,7 @@ __global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
 			else op.emit(i, vv, ee);
 			if (i == n - 1) { i32 tt[NV]; for (int c = 0; c < NV; c++) tt[c] = ee[c] + vv[c]; op.done(tt); }
 		}
+	}
 	}
 	if (n == 0 && tile == 0 && tid == 0) { i32 tt[NV]; for (int c = 0; c < NV; c++) tt[c] = 0; op.done(tt); }
 #ifdef LB_TIMING

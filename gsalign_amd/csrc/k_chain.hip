@@ -432,6 +432,68 @@ struct OpWindowBuckets {
 		}
 		slot_of[i] = slot;
 	}
+	// Round 5, late: the rows of a thread go through the table TOGETHER.  emit() above costs a row up to three round trips to the memory-side atomic unit (the
+	// compare-and-swap of its first key's leader, of its second key's leader, of the lanes that are left), and the four rows of a thread took them one after the
+	// other: 12 round trips per tile, the longest pass of the chain (223 us per 250 Mb contig).  Here every round issues the compare-and-swaps of all rows, then
+	// looks at the answers.  Same table operations, same counts; which slot a key lands in does not matter to anybody (k_window_mode takes maxima).
+	static constexpr bool has_emit_all = true;
+	template <int ITEMS>
+	__device__ void emit_all(const Item (&it)[ITEMS], i64 i0, const bool (&in)[ITEMS], const i32 (&v)[ITEMS], const i32 (&ex)[ITEMS]) const
+	{
+		const int lane = (int)(threadIdx.x & 63);
+		unsigned long long key[ITEMS]; bool pend[ITEMS]; i32 slot[ITEMS];
+#pragma unroll
+		for (int k = 0; k < ITEMS; k++) {
+			const i64 i = i0 + (i64)k * LB_TPB;
+			slot[k] = -1; pend[k] = false; key[k] = 0;
+			if (in[k]) {
+				wsEx[i] = ex[k];
+				if (it[k].ws) { wbest[ex[k]] = 0; wsum[ex[k]] = 0; wn[ex[k]] = 0; }
+				const u32 w = (u32)(ex[k] + v[k] - 1);
+				const u32 b = (u32)((it[k].pd >> 4) - bmin);
+				key[k] = ((unsigned long long)w << 32) | b;
+				pend[k] = it[k].uniq != 0;
+			}
+		}
+		for (int round = 0; round < 2; round++) {
+			int lead[ITEMS]; unsigned long long k0[ITEMS], old[ITEMS]; u32 h[ITEMS]; unsigned long long grp[ITEMS]; bool act[ITEMS], mine[ITEMS];
+#pragma unroll
+			for (int k = 0; k < ITEMS; k++) {
+				const unsigned long long live = __ballot(pend[k]);
+				act[k] = live != 0;
+				lead[k] = act[k] ? __ffsll((long long)live) - 1 : 0;
+				k0[k] = __shfl(key[k], lead[k]);
+				mine[k] = pend[k] && key[k] == k0[k];
+				grp[k] = __ballot(mine[k]);
+				h[k] = bkt_hash(k0[k], cap);
+				old[k] = k0[k];
+			}
+#pragma unroll
+			for (int k = 0; k < ITEMS; k++) if (act[k] && lane == lead[k]) old[k] = atomicCAS(&tab[h[k]].key, BKT_EMPTY, k0[k]);      // (all rows' first probes in flight together)
+#pragma unroll
+			for (int k = 0; k < ITEMS; k++) {
+				if (act[k] && lane == lead[k]) {
+					while (old[k] != BKT_EMPTY && old[k] != k0[k]) { h[k] = h[k] + 1 == cap ? 0u : h[k] + 1; old[k] = atomicCAS(&tab[h[k]].key, BKT_EMPTY, k0[k]); }
+					atomicAdd(&tab[h[k]].cnt, (u32)__popcll(grp[k]));
+				}
+				const u32 hs = __shfl(h[k], lead[k]);
+				if (mine[k]) { slot[k] = (i32)hs; pend[k] = false; }
+			}
+		}
+		{	// (what is left: scattered seeds -- a repeat's hits --, every lane for itself, all rows at once)
+			u32 h[ITEMS]; unsigned long long old[ITEMS];
+#pragma unroll
+			for (int k = 0; k < ITEMS; k++) { h[k] = bkt_hash(key[k], cap); old[k] = key[k]; if (pend[k]) old[k] = atomicCAS(&tab[h[k]].key, BKT_EMPTY, key[k]); }
+#pragma unroll
+			for (int k = 0; k < ITEMS; k++) if (pend[k]) {
+				while (old[k] != BKT_EMPTY && old[k] != key[k]) { h[k] = h[k] + 1 == cap ? 0u : h[k] + 1; old[k] = atomicCAS(&tab[h[k]].key, BKT_EMPTY, key[k]); }
+				atomicAdd(&tab[h[k]].cnt, 1u);
+				slot[k] = (i32)h[k];
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < ITEMS; k++) if (in[k]) slot_of[i0 + (i64)k * LB_TPB] = slot[k];
+	}
 	__device__ void done(const i32 *t) const { wsEx[na] = t[0]; wbest[na] = 0; wsum[na] = 0; wn[na] = 0; }
 };
 
