@@ -20,8 +20,12 @@ __global__ void __launch_bounds__(256) k_rs_hist(i64 n, const u64 *__restrict__ 
 	h[tid] = 0;
 	__syncthreads();
 	const i64 base = (i64)tile * RS_TILE + (tid >> 6) * (RS_TILE / 4) + (tid & 63);
+	// (all sixteen keys of the thread first -- at clamped indices, so that no load sits behind a branch and they go out together; round 5: one waited load per key before)
+	u64 kk[RS_ITEMS];
 #pragma unroll
-	for (int k = 0; k < RS_ITEMS; k++) { const i64 i = base + (i64)k * 64; if (i < n) atomicAdd(&h[(u32)(key[i] >> shift) & dmask], 1u); }
+	for (int k = 0; k < RS_ITEMS; k++) { const i64 i = base + (i64)k * 64; kk[k] = key[i < n ? i : n - 1]; }
+#pragma unroll
+	for (int k = 0; k < RS_ITEMS; k++) { const i64 i = base + (i64)k * 64; if (i < n) atomicAdd(&h[(u32)(kk[k] >> shift) & dmask], 1u); }
 	__syncthreads();
 	hist[(size_t)tid * n_tiles + tile] = h[tid];
 }
@@ -42,13 +46,16 @@ __global__ void __launch_bounds__(256) k_rs_scatter(i64 n, const u64 *__restrict
 	for (int w = 0; w < 4; w++) cnt[w][tid] = 0;
 	__syncthreads();
 	const i64 base = (i64)tile * RS_TILE + wv * (RS_TILE / 4) + lane;
-	u64 kk[RS_ITEMS]; u32 rk[RS_ITEMS];
+	u64 kk[RS_ITEMS]; u32 rk[RS_ITEMS], vv[RS_ITEMS];
 	const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+	// (keys and values of the thread's sixteen rows first, at clamped indices: all loads in flight together)
+#pragma unroll
+	for (int k = 0; k < RS_ITEMS; k++) { const i64 i = base + (i64)k * 64, ic = i < n ? i : n - 1; kk[k] = kin[ic]; vv[k] = vin[ic]; }
 #pragma unroll
 	for (int k = 0; k < RS_ITEMS; k++) {
 		const i64 i = base + (i64)k * 64;
 		const bool valid = i < n;
-		kk[k] = valid ? kin[i] : 0;
+		if (!valid) kk[k] = 0;
 		const u32 d = (u32)(kk[k] >> shift) & dmask;
 		// the lanes of this row that hold my digit
 		unsigned long long m = __ballot(valid);
@@ -72,7 +79,7 @@ __global__ void __launch_bounds__(256) k_rs_scatter(i64 n, const u64 *__restrict
 #pragma unroll
 	for (int k = 0; k < RS_ITEMS; k++) {
 		const i64 i = base + (i64)k * 64;
-		if (i < n) { const u32 pos = cnt[wv][rk[k] >> 16] + (rk[k] & 0xffffu); kout[pos] = kk[k]; vout[pos] = vin[i]; }
+		if (i < n) { const u32 pos = cnt[wv][rk[k] >> 16] + (rk[k] & 0xffffu); kout[pos] = kk[k]; vout[pos] = vv[k]; }
 	}
 }
 
