@@ -1141,6 +1141,9 @@ __global__ void __launch_bounds__(256) k_dense_resolve(const u32 *__restrict__ c
 // hits of its start by position: the tie-break of the (group, qPos) order, which the reference gets from a stable sort
 // of the PosDiff order (the f rows of one start are re-read by f lanes: L1/L2 hits on the dense SA).
 #define SEL_HASH 256
+#ifndef SEL_BATCH
+#define SEL_BATCH 1     // (experiment: > 1 = that many windows of 256 hits per round of k_seed_select's hit loop)
+#endif
 #ifndef SEL_TRIES
 #define SEL_TRIES 4      // probes of the workgroup's LDS table of occupied PosDiff words before a hit goes to its word in HBM
 #endif
@@ -1227,6 +1230,55 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 	const u64 base = (u64)hit_base[chunk];
 	i64 pd_base = bnd.lmax;                              // key = rPos - qPos + pd_base
 	if (bnd.n) { const i32 ci = bnd.chunk_contig[chunk]; pd_base += (i64)bnd.off[ci] + (i64)ci * bnd.pds; }
+#if SEL_BATCH > 1      // (experiment, round 5: SEL_BATCH windows of 256 hits per round -- their gathers and dense-SA reads in flight together, two barriers per round instead of per window)
+	__shared__ unsigned long long s_rb[SEL_BATCH][256];
+	for (u32 t0 = 0; t0 < total; t0 += 256 * SEL_BATCH) {
+		u32 i_[SEL_BATCH], h_[SEL_BATCH], f_[SEL_BATCH], len_[SEL_BATCH]; i32 s_[SEL_BATCH]; u64 x0_[SEL_BATCH], r_[SEL_BATCH]; bool in_[SEL_BATCH];
+#pragma unroll
+		for (int u = 0; u < SEL_BATCH; u++) {
+			const u32 t = t0 + (u32)u * 256 + j; in_[u] = t < total;
+			const u32 tc = in_[u] ? t : total - 1;
+			u32 lo = 0, hi = n_on;
+			while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (s_offs[mid] <= tc) lo = mid; else hi = mid; }
+			i_[u] = s_ord[lo]; h_[u] = tc - s_offs[lo];
+		}
+#pragma unroll
+		for (int u = 0; u < SEL_BATCH; u++) { s_[u] = cand_s[cbase + i_[u]] + s_off; f_[u] = (u32)cand_freq[cbase + i_[u]]; len_[u] = (u32)cand_len[cbase + i_[u]]; x0_[u] = cand_x0[cbase + i_[u]]; }
+#pragma unroll
+		for (int u = 0; u < SEL_BATCH; u++) { const bool known = (x0_[u] >> 63) != 0; const u64 loc = fm_locate(di, known ? 0ull : x0_[u] + h_[u]); r_[u] = known ? (x0_[u] & ~(1ull << 63)) : loc; }
+#pragma unroll
+		for (int u = 0; u < SEL_BATCH; u++) s_rb[u][j] = r_[u];
+		__syncthreads();
+#pragma unroll
+		for (int u = 0; u < SEL_BATCH; u++) if (in_[u]) {
+			const u32 t = t0 + (u32)u * 256 + j, h = h_[u], f = f_[u]; const u64 r = r_[u], x0 = x0_[u]; const i32 s = s_[u];
+			const i64 pd = (i64)r - s + pd_base;
+			u32 rank = 0;
+			if (f > 1) {
+				const u32 first = t - h;
+				for (u32 h2 = 0; h2 < f; h2++) {
+					const u32 ts = first + h2;
+					const u64 r2 = (ts >= t0 && ts < t0 + 256 * SEL_BATCH) ? s_rb[(ts - t0) >> 8][(ts - t0) & 255] : fm_locate(di, x0 + h2);
+					rank += r2 < r ? 1u : 0u;
+				}
+			}
+			const u64 at = base + (t - h) + rank;
+			key[at] = ((u64)pd << qbits) | (u32)s;
+			val[at] = len_[u] | (rank << 16);
+			if (pdby) pdby[pd] = 1;
+			else if (pdbm) {
+				const unsigned long long w = (unsigned long long)(pd >> 5); const u32 bit = 1u << (pd & 31);
+				int hh = (int)((w * 0x9E3779B1ull) >> 7) & (SEL_HASH - 1), tries = 0;
+				for (; tries < SEL_TRIES; tries++, hh = (hh + 1) & (SEL_HASH - 1)) {
+					const unsigned long long prev = atomicCAS(&s_w[hh], ~0ull, w);
+					if (prev == ~0ull || prev == w) { atomicOr(&s_b[hh], bit); break; }
+				}
+				if (tries == SEL_TRIES) { atomicOr(&pdbm[w], bit); pd_coarse_set(pdcb, w); }
+			}
+		}
+		__syncthreads();
+	}
+#else
 	__shared__ unsigned long long s_r[256];                  // located positions of the 256 hits in flight: a hit ranks itself among its siblings from here
 	for (u32 t0 = 0; t0 < total; t0 += 256) {
 		const u32 t = t0 + j;
@@ -1274,6 +1326,7 @@ __global__ void __launch_bounds__(256) k_seed_select(DevIndex di, u32 cand_cap, 
 		}
 		__syncthreads();
 	}
+#endif
 	if (pdbm && !pdby) {
 		__syncthreads();
 		for (int t = j; t < SEL_HASH; t += 256) if (s_w[t] != ~0ull) { atomicOr(&pdbm[s_w[t]], s_b[t]); pd_coarse_set(pdcb, s_w[t]); }
