@@ -498,7 +498,7 @@ def end_to_end(px, genome, params, inflight, tmp, tag):
         out.update(d)
         out["note"] = ("wall time of the whole program incl. process start; index_load = .bwt/.sa/.pac from disk (page cache) + unpacking, gsa_create = index upload + device-side tables, "
                        "query_load runs beside both; align_many = the hot path with the contigs read from pageable host memory; MAF / variants are formatted while later contigs align, "
-                       "output_drain_after_align = what of that was left when the last contig was aligned; vcf = sort + format + write; gbp_per_s_excl_index_build = query bases / total")
+                       "output_drain_after_align = from the last contig's alignment to both output files closed (what was left of MAF formatting / writing, the VCF beside the MAF writer's tail, the contexts' teardown beside both); vcf = sort + format + write (inside output_drain); gbp_per_s_excl_index_build = query bases / total")
     else:
         out["stderr_tail"] = r.stderr[-600:]
     for ext in (".maf", ".vcf", ".aln"):

@@ -256,12 +256,19 @@ int main(int argc, char *argv[])
 	{ std::lock_guard<std::mutex> lk(sink.mu); if (rc_many != GSA_OK) sink.abort = true; }
 	sink.cv.notify_all();
 	const double td = now_s();
+	// (the contexts are done with -- every result was copied by on_result: their teardown, 0.2 s of hipFree at human scale, runs beside the output's tail)
+	double t_destroy = 0;
+	std::thread destroyer([&] { if (rc_many != GSA_OK) return; const double t = now_s(); for (size_t k = ctxs.size(); k-- > 0;) gsa_destroy(ctxs[k]); t_destroy = now_s() - t; });      // clones before the owners of their index (after an error the contexts stay: their messages are printed below)
 	formatter.join();
 	double maf_write_s = 0; unsigned long long maf_bytes = 0;
-	if (maf_w) { maf_w->close(); maf_write_s = maf_w->write_seconds(); maf_bytes = maf_w->bytes(); maf_w.reset(); }
-	if (maf_fd >= 0) close(maf_fd);
-	t_drain = now_s() - td; t_copy = sink.copy_s;
+	// (the MAF writer still has its queue to write -- ~1 s at human scale: the VCF is sorted, formatted and written beside it, the MAF file is closed behind)
+	auto close_maf = [&] {
+		if (maf_w) { maf_w->close(); maf_write_s = maf_w->write_seconds(); maf_bytes = maf_w->bytes(); maf_w.reset(); }
+		if (maf_fd >= 0) { close(maf_fd); maf_fd = -1; }
+	};
+	t_copy = sink.copy_s;
 	if (rc_many != GSA_OK) {
+		close_maf(); destroyer.join();
 		for (gsa_ctx *c : ctxs) if (*gsa_last_error(c)) fprintf(stderr, "GPU error: %s\n", gsa_last_error(c));
 		fprintf(stderr, "\t%d of %d query sequences were written before the error\n", (int)written, (int)qs.size());
 		return 2;
@@ -280,9 +287,9 @@ int main(int argc, char *argv[])
 		}
 		t_vcf = now_s() - t;
 	}
-	const double t_destroy0 = now_s();
-	for (size_t k = ctxs.size(); k-- > 0;) gsa_destroy(ctxs[k]);      // clones before the owners of their index
-	const double t_destroy = now_s() - t_destroy0;
+	close_maf();
+	t_drain = now_s() - td;      // (from the last contig's alignment to both files closed; the VCF's time lies inside it now)
+	destroyer.join();
 	if (timing) {
 		long long qbp = 0; for (const QueryContig &q : qs) qbp += (long long)q.seq.size();
 		const double total = now_s() - T0;
