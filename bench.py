@@ -510,6 +510,95 @@ def end_to_end(px, genome, params, inflight, tmp, tag):
     return out
 
 
+COMPACT_LIMIT = 4096         # bytes: the LAST stdout line must stay well inside what the driver keeps of stdout (round 5: a 32 KB line was cut, parsed = null)
+DETAIL_FILE = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+
+
+def _clean(x):
+    """NaN / Infinity are not JSON: -> null, recursively."""
+    if isinstance(x, float):
+        return x if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _clean(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_clean(v) for v in x]
+    if isinstance(x, (np.floating, np.integer)):
+        return _clean(x.item())
+    return x
+
+
+def _r(x, nd=4):
+    return round(float(x), nd) if isinstance(x, (int, float)) and not isinstance(x, bool) and x == x and abs(x) != float("inf") else None
+
+
+def compact_line(out):
+    """The driver-facing object: the contract's keys + roofline + cpu_baseline + end_to_end and one number per further workload, short
+    strings only.  Everything else (terms, kernels[], stage times, counters, notes, the extras' full objects) is the detail file."""
+    cfg = out.get("config", {}); rf = out.get("roofline") or {}; cb = out.get("cpu_baseline"); ee = out.get("end_to_end")
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    c["value"] = _r(c["value"], 4); c["ms_per_step"] = _r(c["ms_per_step"], 4)
+    c["data"] = str(c["data"])[:80]
+    c["config"] = {"workload": str(cfg.get("workload", ""))[:120]}
+    for k in ("query_bp_per_step", "contigs_per_step", "inflight_contexts_per_gpu", "world_size", "backend", "contigs_on_rank0_after_gather"):
+        if k in cfg:
+            c["config"][k] = cfg[k]
+    if "parallelism" in cfg:
+        c["config"]["parallelism"] = str(cfg["parallelism"])[:60]
+    if "aligner_params" in cfg:
+        c["config"]["aligner_params"] = cfg["aligner_params"]
+    if "fallback" in cfg:
+        c["config"]["fallback"] = str(cfg["fallback"])[:100]
+    if rf:
+        c["roofline"] = {"bound": rf.get("bound", "hbm"), "kernel": str(rf.get("kernel", ""))[:60], "achieved": _r(rf.get("achieved"), 2), "peak": _r(rf.get("peak"), 1), "unit": rf.get("unit", "GB/s"),
+                         "frac": _r(rf.get("frac"), 4), "traffic": _r(rf.get("traffic"), 0), "physical_frac": _r(rf.get("physical_frac"), 4),
+                         "algorithmic_bytes_per_step": _r(rf.get("algorithmic_bytes_per_step"), 0), "avg_launch_ms": _r(rf.get("avg_launch_ms"), 4), "launches_per_step": rf.get("launches_per_step")}
+    if cb:
+        c["cpu_baseline"] = {"value": _r(cb.get("value"), 6), "unit": cb.get("unit", "Gbp/s"), "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:160],
+                             "parity_sample": cb.get("parity_sample")}
+    if ee:
+        c["end_to_end"] = {k: _r(ee.get(k), 3) for k in ("total_s", "align_many_s", "gsa_create_s", "index_load_s") if k in ee}
+        if "error" in ee or "stderr_tail" in ee:
+            c["end_to_end"]["error"] = str(ee.get("error", ee.get("stderr_tail")))[:80]
+    if "resident" in out and out["resident"]:
+        c["resident_value"] = _r(out["resident"].get("value"), 4)
+    st = out.get("stage_ms_one_context_alone")
+    if st:
+        c["stage_ms_alone"] = {k: _r(v, 2) for k, v in st.items()}
+    xs = []
+    for e in out.get("extra_workloads", []):
+        x = {"workload": e.get("workload"), "value": _r(e.get("value"), 3), "ms_per_step": _r(e.get("ms_per_step"), 3)}
+        if e.get("roofline"):
+            x["frac"] = _r(e["roofline"].get("frac"), 4)
+        if e.get("error"):
+            x["error"] = str(e["error"])[:60]
+        xs.append(x)
+    if xs:
+        c["extra_workloads"] = xs
+    c["detail"] = "gpurun_out/bench_detail.json"
+    c = _clean(c)
+    line = json.dumps(c, allow_nan=False)
+    for drop in ("stage_ms_alone", "extra_workloads", "resident_value", "end_to_end"):     # (never needed at today's sizes: a guard, so that the line cannot outgrow the limit again)
+        if len(line) < COMPACT_LIMIT:
+            break
+        c.pop(drop, None); line = json.dumps(c, allow_nan=False)
+    assert len(line) < COMPACT_LIMIT, len(line)
+    return line
+
+
+def emit(out):
+    """Detail -> gpurun_out/bench_detail.json (the whole object, merged back by gpurun); compact object -> the LAST line of stdout."""
+    full = _clean(out)
+    try:
+        os.makedirs(os.path.dirname(DETAIL_FILE), exist_ok=True)
+        name = DETAIL_FILE if os.environ.get("GSA_BENCH_DETAIL") is None else os.environ["GSA_BENCH_DETAIL"]
+        with open(name, "w") as f:
+            json.dump(full, f)
+    except OSError as e:
+        print(f"bench.py: could not write the detail file: {e}", file=sys.stderr)
+    sys.stdout.flush()
+    print(compact_line(full), flush=True)
+
+
 def dry_main(args):
     """--dry: the launcher, the rank plumbing, the LPT contig shard and the staged result gather of the multi-GPU path on CPU (gloo) with a
     stub in place of the aligner -- what tests/test_bench_launcher.py runs at world size 2.  Prints the same JSON shape; no performance claim."""
@@ -566,7 +655,7 @@ def dry_main(args):
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({"metric": "aligned query Gbp/s (whole node)", "value": float(sum(c.size for c in contigs) * args.steps) / float(tt.item()) / 1e9, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps,
+        print(compact_line({"metric": "aligned query Gbp/s (whole node)", "value": float(sum(c.size for c in contigs) * args.steps) / float(tt.item()) / 1e9, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": 1000.0 * float(tt.item()) / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
                           "data": "dry run: stub aligner on CPU, gloo (launcher / plumbing check only)", "config": {"workload": "dry", "contigs_on_rank0_after_gather": seen, "world_size": world}}))
     if world > 1:
@@ -673,10 +762,10 @@ def main():
         m = measure_split(name, wl, args, tmp, rank, world, local_rank, sync, args.steps, args.warmup, dev)
         t_max, total_bp = whole_job(m)
         if rank == 0:
-            print(json.dumps({"metric": "aligned query Gbp/s (whole node)", "value": total_bp / t_max / 1e9, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            emit({"metric": "aligned query Gbp/s (whole node)", "value": total_bp / t_max / 1e9, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": 1000.0 * t_max / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
                               "config": {"workload": wl["label"] + "; ONE contig per step, S1 sharded by chunk range over the ranks, hits to the (rotating) owner over RCCL, S2-S7 on the owner",
-                                         "query_bp_per_step": int(m["bp_per_step"]), "parallelism": f"chunk-range shard x{world} of one contig, index replicated", "world_size": world}}))
+                                         "query_bp_per_step": int(m["bp_per_step"]), "parallelism": f"chunk-range shard x{world} of one contig, index replicated", "world_size": world}})
         dist.barrier(); dist.destroy_process_group()
         return
     m = measure(name, wl, args, tmp, rank, world, local_rank, sync, args.steps, args.warmup, dev, dist)
@@ -702,8 +791,11 @@ def main():
             if args.no_torch:
                 cmd.append("--no-torch")
             try:
-                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GSA_BENCH_TMP=tmp, GSA_BENCH_KEEP="1"))
-                d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                dfile = os.path.join(tmp, f"detail_{xn}.json")
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GSA_BENCH_TMP=tmp, GSA_BENCH_KEEP="1", GSA_BENCH_DETAIL=dfile))
+                json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])            # (the child's own compact line must parse too)
+                with open(dfile) as f:
+                    d = json.load(f)
                 e = {"workload": xn, "steps": st, "unit": "Gbp/s"}
                 e.update({k: d[k] for k in ("value", "ms_per_step", "resident", "h2d_inclusive_over_resident", "no_prefetch", "bundled", "one_contig_latency", "config", "roofline", "kernels", "stage_ms_one_context_alone", "counters_per_step", "end_to_end") if k in d})
                 extras.append(e)
@@ -721,7 +813,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(m["px"], q0, tmp, args.cpu_sample, params=wl["params"], parity_gpu=m["parity_gpu"])
             except Exception as e:   # never lose the GPU line to a baseline hiccup      # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "unit": "Gbp/s", "cores": 0, "kind": "reference", "sample": f"failed: {e}"}
-        print(json.dumps(out), flush=True)
+        emit(out)
         if out.get("cpu_baseline", {}).get("parity_sample") == "DIFFERENT":      # a fast result that differs from the reference's is not a result
             print("bench.py: the GPU's result for the CPU baseline's sample differs from the reference's: " + out["cpu_baseline"]["parity_detail"], file=sys.stderr)
             if world > 1:
