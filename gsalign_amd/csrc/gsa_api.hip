@@ -237,6 +237,7 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	gsa_params dp; gsa_default_params(&dp);
 	int rc = gsa_set_params(c, prm ? prm : &dp);
 	if (rc) { g_create_error = c->err; gsa_destroy(c); return rc; }
+	if (const unsigned long long ov = gsa_take_grid_overflow()) { gsa_fail(nullptr, GSA_ERR_LIMIT, "gsa_create: a table build needed a launch of " + std::to_string(ov) + " work-items (>= 2^32)"); gsa_destroy(c); return GSA_ERR_LIMIT; }
 	*out = c;
 	return GSA_OK;
 }
@@ -626,6 +627,7 @@ int gsa_run_to(gsa_ctx *c, int stage)
 		{ const auto t_now = std::chrono::steady_clock::now(); c->wall_ms[next] += std::chrono::duration<double, std::milli>(t_now - t_prev).count(); t_prev = t_now; }
 	}
 	if (stage == 8) c->wall_n++;
+	if (const unsigned long long ov = gsa_take_grid_overflow()) rc = gsa_fail(c, GSA_ERR_LIMIT, "a kernel launch of " + std::to_string(ov) + " work-items (>= 2^32) was needed: contig too large for this build");
 	// stages 1-2 leave work in flight (no count read-backs); the call returns with the stream idle
 	if (rc == GSA_OK) { GSA_CHECK(c, hipStreamSynchronize(c->stream)); collect_events(c); }
 	if (c->early_in_flight && (rc != GSA_OK || !c->early_consumed)) GSA_CHECK(c, hipStreamSynchronize(c->stream_aux[0]));      // a stage view (or an error) must not leave the early DP launch running

@@ -2,6 +2,7 @@
 // libgsa_hip.so.  Device-side index view, the context, small helpers.
 #ifndef GSA_INTERNAL_H
 #define GSA_INTERNAL_H
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -95,11 +96,15 @@ int gsa_sort_pairs_u64_u32(gsa_ctx *, const u64 *kin, u64 *kout, const u32 *vin,
 static inline int ceil_log2_u64(u64 v) { int b = 0; while ((1ull << b) < v && b < 63) b++; return b; }
 // workgroups for n work-items.  A launch holds fewer than 2^32 work-items (the dispatch packet's grid size is a 32-bit count of work-items; the
 // runtime takes a larger one modulo 2^32 without a word -- round 5's presence-table bug): a caller with more elements than that strides.
+// A launch that would need more is NOT made to fit silently and does not kill the host process either: the grid is clamped (so the launch itself is legal),
+// the overflow is latched, and the entry point that issued it returns GSA_ERR_LIMIT (gsa_take_grid_overflow in gsa_run_to / gsa_create_opts).
+inline std::atomic<unsigned long long> gsa_grid_overflow{0};
 static inline unsigned grid_for(size_t n, unsigned block)
 {
 	size_t g = (n + block - 1) / block;
-	if (g * block >= ((size_t)1 << 32)) { fprintf(stderr, "libgsa_hip: internal error: launch of %zu work-items (>= 2^32)\n", g * block); abort(); }
+	if (g * block >= ((size_t)1 << 32)) { gsa_grid_overflow.store((unsigned long long)(g * block)); g = (((size_t)1 << 32) - 1) / block; }
 	return (unsigned)(g ? g : 1);
 }
+static inline unsigned long long gsa_take_grid_overflow() { return gsa_grid_overflow.exchange(0); }
 
 #endif

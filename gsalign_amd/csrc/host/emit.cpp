@@ -87,7 +87,11 @@ void ContigResult::assign(const gsa_result &r)
 void ContigResult::trim(int64_t i, int ext)
 {
 	gsa_rec &x = recs[(size_t)i];
-	if (x.seed.qpos >= 0) x.seed.len -= ext; else { x.gap.rlen -= ext; x.gap.nqlen += ext; }
+	// A block's records are seed [gap] seed ... seed (gsa_hip.h): the last one is a seed, whose tag is its qpos -- its length may go to
+	// zero or below exactly as the reference's qLen / rLen do.  A gap's tag is the SIGN of nqlen (= -1 - qLen): it never crosses zero here,
+	// so a record can not change its kind under a later gsa_rec_expand.
+	if (x.seed.qpos >= 0) x.seed.len -= ext;
+	else { x.gap.rlen -= ext; x.gap.nqlen = (int64_t)x.gap.nqlen + ext > -1 ? -1 : x.gap.nqlen + ext; }
 }
 
 // LoadQueryFile (main.cpp:82-114) line by line -- getline on '\n', empty lines skipped, a line that starts with '>' opens a sequence

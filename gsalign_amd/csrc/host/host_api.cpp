@@ -1,6 +1,7 @@
 // gsalign_amd/csrc/host/host_api.cpp -- C entry points of libgsa_host.so, so that
 // the CPU test-suite can drive the host-side components (index builder, loader,
 // emitters) without a GPU.  The CLI uses the C++ interface directly.
+#include <atomic>
 #include <algorithm>
 #include <cstring>
 #include "gsa_host.h"
@@ -57,6 +58,24 @@ int gsah_c_exact_sort_check(long long n, int distinct, unsigned seed, int patter
 }
 
 // returns 0 on success; err (>= 256 bytes) receives the message otherwise
+// HostPool::run back to back with short jobs of changing size (the shape maf_block produces): every index of every run exactly once.
+// Returns 0, or the 1-based run in which an index ran twice or not at all.  (Round-5 advisor finding: a worker that woke late could carry an
+// index of the previous job into the next one.)
+int gsah_c_pool_stress(int threads, int runs, unsigned seed)
+{
+	HostPool pool(threads);
+	std::vector<std::atomic<int>> hit(4096);
+	unsigned x = seed * 2654435761u + 1u;
+	for (int r = 0; r < runs; r++) {
+		x = x * 1664525u + 1013904223u;
+		const size_t n = 2 + (x >> 20) % 4094;
+		for (size_t i = 0; i < n; i++) hit[i].store(0, std::memory_order_relaxed);
+		pool.run(n, [&](size_t i) { hit[i].fetch_add(1, std::memory_order_relaxed); });
+		for (size_t i = 0; i < n; i++) if (hit[i].load(std::memory_order_relaxed) != 1) return r + 1;
+	}
+	return 0;
+}
+
 int gsah_c_build_index(const char *fasta, const char *prefix, char *err)
 {
 	std::string e;

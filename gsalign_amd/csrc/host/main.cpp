@@ -9,6 +9,7 @@
 // contig out of the library's memory; ONE formatter thread takes the contigs in contig order (OutputMAF appends per contig, VarVec grows in
 // contig order: GSAlign.cpp:543-546) and formats each with the host pool's threads (par.h: the text lines of a block, the variants of a
 // block's records), a writer thread writes the buffers in order -- so the output bytes depend neither on GPUs / contexts nor on -t.
+#include <errno.h>
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -199,6 +200,7 @@ int main(int argc, char *argv[])
 	// the MAF file: created by the first contig that has alignments ("w" for contig 0, "a" afterwards: tools.cpp:158-163 -- a run whose
 	// first contig aligns nowhere appends to whatever the file held, as the reference does)
 	int maf_fd = -1; std::unique_ptr<OrderedWriter> maf_w;
+	bool out_failed = false;          // an output file that could not be opened or written: reported, exit status 1 (a full disk must not look like success)
 	size_t written = 0;
 	auto write_contig = [&](size_t ci, ContigResult &cr) {
 		fprintf(stderr, "\tProcess query chromsomoe: %s...\n", qs[ci].name.c_str());
@@ -210,15 +212,20 @@ int main(int argc, char *argv[])
 		if (fmt == 1) {
 			const double t = now_s();
 			if (maf_fd < 0 || ci == 0) {
-				if (maf_w) { maf_w->close(); maf_w.reset(); }
+				if (maf_w) { if (!maf_w->close()) out_failed = true; maf_w.reset(); }
 				if (maf_fd >= 0) close(maf_fd);
 				maf_fd = open(maf.c_str(), O_WRONLY | O_CREAT | (ci == 0 ? O_TRUNC : O_APPEND), 0644);
 				if (maf_fd >= 0) maf_w.reset(new OrderedWriter(maf_fd));
+				else if (!out_failed) { out_failed = true; fprintf(stderr, "Error! cannot open [%s] for writing: %s\n", maf.c_str(), strerror(errno)); }
 			}
 			if (maf_w) em.maf_text(ci == 0, qs[ci], cr, [&](OutBuf &&o) { maf_w->push(std::move(o)); }, [&](size_t c) { return maf_w->take(c); });
 			t_maf_fmt += now_s() - t;
 		}
-		if (fmt == 2) { FILE *fp = fopen(aln.c_str(), ci == 0 ? "w" : "a"); if (fp) { em.aln(fp, qs[ci], cr); fclose(fp); } }
+		if (fmt == 2) {
+			FILE *fp = fopen(aln.c_str(), ci == 0 ? "w" : "a");
+			if (fp) { em.aln(fp, qs[ci], cr); if (ferror(fp) | fclose(fp)) out_failed = true; }
+			else if (!out_failed) { out_failed = true; fprintf(stderr, "Error! cannot open [%s] for writing: %s\n", aln.c_str(), strerror(errno)); }
+		}
 		if (vcf) { const double t = now_s(); em.variants((int)ci, qs[ci], cr); t_var += now_s() - t; }
 		if (dotplot && !gnuplot.empty()) {                               // GSAlign.cpp:546: only when gnuplot was found (main.cpp:324)
 			const std::string gp = std::string(out_prefix) + ".gp";
@@ -263,8 +270,8 @@ int main(int argc, char *argv[])
 	double maf_write_s = 0; unsigned long long maf_bytes = 0;
 	// (the MAF writer still has its queue to write -- ~1 s at human scale: the VCF is sorted, formatted and written beside it, the MAF file is closed behind)
 	auto close_maf = [&] {
-		if (maf_w) { maf_w->close(); maf_write_s = maf_w->write_seconds(); maf_bytes = maf_w->bytes(); maf_w.reset(); }
-		if (maf_fd >= 0) { close(maf_fd); maf_fd = -1; }
+		if (maf_w) { if (!maf_w->close()) out_failed = true; maf_write_s = maf_w->write_seconds(); maf_bytes = maf_w->bytes(); maf_w.reset(); }
+		if (maf_fd >= 0) { if (close(maf_fd) != 0) out_failed = true; maf_fd = -1; }
 	};
 	t_copy = sink.copy_s;
 	if (rc_many != GSA_OK) {
@@ -283,8 +290,10 @@ int main(int argc, char *argv[])
 		if (fd >= 0) {
 			OrderedWriter w(fd);
 			em.vcf_text(index_prefix != NULL ? index_prefix : ref_fa, [&](OutBuf &&o) { w.push(std::move(o)); });
-			w.close(); vcf_bytes = w.bytes(); vcf_write_s = w.write_seconds(); close(fd);
-		}
+			if (!w.close()) out_failed = true;
+			vcf_bytes = w.bytes(); vcf_write_s = w.write_seconds();
+			if (close(fd) != 0) out_failed = true;
+		} else { out_failed = true; fprintf(stderr, "Error! cannot open [%s] for writing: %s\n", vcfn.c_str(), strerror(errno)); }
 		t_vcf = now_s() - t;
 	}
 	close_maf();
@@ -301,6 +310,7 @@ int main(int argc, char *argv[])
 	}
 	// (everything is on disk and the GPU is released: the process ends here -- unwinding 20 GB of host buffers and the HIP runtime's own
 	//  teardown cost a second or two of wall time at human scale and produce nothing)
+	if (out_failed) fprintf(stderr, "Error! an output file could not be written completely (disk full?)\n");
 	fflush(stdout); fflush(stderr);
-	_exit(0);
+	_exit(out_failed ? 1 : 0);
 }

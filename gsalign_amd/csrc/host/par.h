@@ -36,15 +36,13 @@ public:
 		if (n == 0) return;
 		if (n == 1 || th.empty()) { for (size_t i = 0; i < n; i++) fn(i); return; }
 		std::lock_guard<std::mutex> one(gate);
-		{
-			std::lock_guard<std::mutex> g(mu);
-			job = &fn; job_n = n; next.store(0); left.store(n); epoch++;
-		}
+		Job j; j.fn = &fn; j.n = n; j.left.store(n);
+		{ std::lock_guard<std::mutex> g(mu); cur = &j; epoch++; }
 		cv.notify_all();
-		drain();
+		drain(j);
 		std::unique_lock<std::mutex> g(mu);
-		done.wait(g, [&] { return left.load() == 0 && busy == 0; });
-		job = nullptr;
+		done.wait(g, [&] { return j.left.load() == 0 && j.busy == 0; });
+		cur = nullptr;             // (under mu: a worker that wakes late for this epoch finds no job and goes back to sleep)
 	}
 	// the process-wide pool: GSA_HOST_THREADS, or -t of the CLI (set_threads), default min(hardware threads, 32)
 	static HostPool &global()
@@ -60,27 +58,38 @@ public:
 	}
 
 private:
-	void drain()
+	// One run()'s state, on run()'s stack.  A worker takes the pointer under `mu` (and counts itself in `busy` there), so it can never
+	// pair an index drawn from one job with the size or function of the next: run() does not return -- and the object does not die --
+	// while a worker is counted in.
+	struct Job {
+		const std::function<void(size_t)> *fn = nullptr; size_t n = 0;
+		std::atomic<size_t> next{0}, left{0};
+		int busy = 0;              // (guarded by mu)
+	};
+	static void drain(Job &j)
 	{
 		for (;;) {
-			const size_t i = next.fetch_add(1);
-			if (i >= job_n) return;
-			(*job)(i);
-			left.fetch_sub(1);
+			const size_t i = j.next.fetch_add(1);
+			if (i >= j.n) return;
+			(*j.fn)(i);
+			j.left.fetch_sub(1);
 		}
 	}
 	void work()
 	{
 		unsigned long long seen = 0;
 		for (;;) {
+			Job *j;
 			{
 				std::unique_lock<std::mutex> g(mu);
 				cv.wait(g, [&] { return quit || epoch != seen; });
 				if (quit) return;
-				seen = epoch; busy++;
+				seen = epoch; j = cur;
+				if (!j) continue;      // that run() has already finished without us
+				j->busy++;
 			}
-			drain();
-			{ std::lock_guard<std::mutex> g(mu); busy--; }
+			drain(*j);
+			{ std::lock_guard<std::mutex> g(mu); j->busy--; }
 			done.notify_all();
 		}
 	}
@@ -93,9 +102,8 @@ private:
 	}
 	std::vector<std::thread> th;
 	std::mutex gate, mu; std::condition_variable cv, done;
-	const std::function<void(size_t)> *job = nullptr; size_t job_n = 0;
-	std::atomic<size_t> next{0}, left{0};
-	unsigned long long epoch = 0; int busy = 0; bool quit = false;
+	Job *cur = nullptr;            // (guarded by mu)
+	unsigned long long epoch = 0; bool quit = false;
 };
 
 // [0, n) cut into at most `parts` contiguous ranges of at least `grain` items; fn(begin, end) per range on the global pool

@@ -867,6 +867,9 @@ int launch_early_dp(gsa_ctx *c)
 // the 1 M candidates of a 250 Mb contig).  The marks then go level by level: one lane walks the mid-tile entries (h(E2)), 16 lanes the sub-tile
 // entries (h(E1)), 256 lanes the starts inside their sub-tile, all lanes scatter ws[].  Exactly the orbit of candidate 0 under next().
 #define WC_SL 16384
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_walk_chain keeps 4 x 32 KB of slice tables in LDS: gfx950 (160 KB of LDS per CU) only"
+#endif
 #define WC_T 1024
 __global__ void __launch_bounds__(WC_T) k_walk_chain(i64 na, const i32 *__restrict__ candEx, const i32 *__restrict__ clist, const i32 *__restrict__ nextk, i32 *ws,
                                                      u32 *ticket, u32 ticket0, unsigned long long *entry_w, u32 epoch, i32 *err)
@@ -1018,9 +1021,10 @@ int stage2_chain(gsa_ctx *c)
 		ENS(unsigned long long, w_j0, (size_t)grid + 8);
 		if (c->w_j0.cap != cap0) { GSA_CHECK(c, hipMemsetAsync(c->w_j0.p, 0, c->w_j0.cap, st)); c->walk_ticket = 0; c->walk_epoch = 0; }
 		unsigned long long *words = c->w_j0.as<unsigned long long>();
-		c->walk_epoch++;
-		hipLaunchKernelGGL(k_walk_chain, dim3(grid), dim3(WC_T), 0, st, na, candEx, clist, (const i32 *)c->d_flag2.as<i32>(), ws, (u32 *)words, c->walk_ticket, words + 4, c->walk_epoch, mail + M_LBERR);
-		c->walk_ticket += grid;
+		hipLaunchKernelGGL(k_walk_chain, dim3(grid), dim3(WC_T), 0, st, na, candEx, clist, (const i32 *)c->d_flag2.as<i32>(), ws, (u32 *)words, c->walk_ticket, words + 4, c->walk_epoch + 1, mail + M_LBERR);
+		// (the slice numbering of every later launch depends on these two: they advance only for a launch that was accepted)
+		GSA_CHECK(c, hipGetLastError());
+		c->walk_epoch++; c->walk_ticket += grid;
 	}
 	// C. outliers
 	ENS(unsigned long long, w_best, na + 1); ENS(unsigned long long, w_sum, na + 1); ENS(i32, w_n, na + 1);

@@ -1,6 +1,7 @@
 """CPU tests of the host-side components (rows (f) of SURVEY.md section 8):
 index builder -> byte-identical files; MAF/VCF emitters -> byte-identical text,
 fed with the ORACLE's finished blocks (the GPU is not needed for this)."""
+import ctypes as C
 import filecmp
 import os
 
@@ -226,3 +227,14 @@ def test_exact_sort_is_std_sort():
     for pattern in (1, 2, 3, 4, 5, 6):
         for n in (17, 1000, 100000, 1500000):
             assert lib.gsah_c_exact_sort_check(n, 10, 1, pattern, 2000) == 0, (pattern, n)
+
+
+def test_host_pool_back_to_back_runs():
+    """HostPool::run with short jobs back to back on more threads than cores (late wake-ups are routine then): every index of every
+    run executes exactly once (csrc/host/par.h: a run's state is its own object, taken by a worker under the pool's mutex)."""
+    from gsalign_amd import hostlib
+    lib = hostlib.load()
+    lib.gsah_c_pool_stress.restype = C.c_int
+    lib.gsah_c_pool_stress.argtypes = [C.c_int, C.c_int, C.c_uint]
+    for threads, runs in ((32, 20000), (3, 20000)):
+        assert lib.gsah_c_pool_stress(threads, runs, 7) == 0
