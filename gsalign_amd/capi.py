@@ -16,11 +16,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgsa_hip.so")
 
 EXPORTS = [
-    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many", "gsa_align_bundle",
+    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_clone_to_device", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many", "gsa_align_bundle",
     "gsa_align_contig_device", "gsa_set_query_device", "gsa_device_alloc", "gsa_device_free", "gsa_device_upload", "gsa_get_seed_stats", "gsa_hit_buffers", "gsa_seed_chunks", "gsa_hit_count", "gsa_export_hits", "gsa_import_hits", "gsa_finish_contig",
     "gsa_set_query", "gsa_rewind", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
     "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling", "gsa_bind_host_thread",
-    "gsa_prefetch_contig", "gsa_prefetch_bundle", "gsa_cancel_prefetch", "gsa_get_wall_sums", "gsa_set_option", "gsa_host_register", "gsa_host_unregister",
+    "gsa_prefetch_contig", "gsa_prefetch_bundle", "gsa_cancel_prefetch", "gsa_get_wall_sums", "gsa_get_alloc_stats", "gsa_set_option", "gsa_host_register", "gsa_host_unregister",
 ]
 
 
@@ -107,6 +107,7 @@ def load_library() -> C.CDLL:
     lib.gsa_create.argtypes = [C.c_int, C.POINTER(IndexView), C.POINTER(Params), C.POINTER(C.c_void_p)]
     lib.gsa_create_opts.argtypes = [C.c_int, C.POINTER(IndexView), C.POINTER(Params), C.c_uint32, C.POINTER(C.c_void_p)]
     lib.gsa_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.gsa_clone_to_device.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
     lib.gsa_host_alloc.restype = C.c_void_p
     lib.gsa_host_alloc.argtypes = [C.c_size_t]
     lib.gsa_host_free.argtypes = [C.c_void_p]
@@ -227,11 +228,18 @@ class Aligner:
     def set_option(self, name: str, value) -> None:
         self._ck(self.lib.gsa_set_option(self.ctx, name.encode(), C.c_int64(int(value))))
 
-    def __init__(self, idx, device: int = 0, wide: bool = False, kmer_k: int = 0, _clone_of=None, **params):
+    def __init__(self, idx, device: int = 0, wide: bool = False, kmer_k: int = 0, _clone_of=None, _copy_to=None, **params):
         self.lib = load_library()
         self.idx = idx
         self._pinned = []
         self._devbufs = []
+        if _clone_of is not None and _copy_to is not None:
+            self.ctx = C.c_void_p()
+            rc = self.lib.gsa_clone_to_device(_clone_of.ctx, int(_copy_to), C.byref(self.ctx))
+            if rc != 0:
+                raise GsaError(f"gsa_clone_to_device -> {rc}: {self.lib.gsa_last_error(None).decode()}")
+            self._options_from_env()          # (independent of its parent: owns its copy of the index)
+            return
         if _clone_of is not None:
             self.ctx = C.c_void_p()
             rc = self.lib.gsa_clone(_clone_of.ctx, C.byref(self.ctx))
@@ -266,6 +274,10 @@ class Aligner:
     def clone(self) -> "Aligner":
         """A further context on the same GPU sharing this one's device index (gsa_clone)."""
         return Aligner(self.idx, _clone_of=self)
+
+    def clone_to_device(self, device: int) -> "Aligner":
+        """A context on GPU `device` whose device index is a device-to-device COPY of this one's (gsa_clone_to_device): no upload, no table builds."""
+        return Aligner(self.idx, _clone_of=self, _copy_to=device)
 
     def pinned_copy(self, seq: np.ndarray) -> np.ndarray:
         """seq copied into pinned host memory from gsa_host_alloc (what a FASTA loader of an integrated host reads into)."""

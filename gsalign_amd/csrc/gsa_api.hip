@@ -220,6 +220,7 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 		std::sort(ends.begin(), ends.end());
 		for (size_t i = 0; i < ends.size(); i++) { c->h_chr_end.push_back(ends[i].first); c->h_chr_of_end.push_back(ends[i].second); }
 	}
+	c->d_chr_end.cap = c->h_chr_end.size() * 8; c->d_chr_of_end.cap = c->h_chr_of_end.size() * 4;
 	CK(hipMalloc(&c->d_chr_end.p, c->h_chr_end.size() * 8)); CK(hipMemcpy(c->d_chr_end.p, c->h_chr_end.data(), c->h_chr_end.size() * 8, hipMemcpyHostToDevice));
 	CK(hipMalloc(&c->d_chr_of_end.p, c->h_chr_of_end.size() * 4)); CK(hipMemcpy(c->d_chr_of_end.p, c->h_chr_of_end.data(), c->h_chr_of_end.size() * 4, hipMemcpyHostToDevice));
 #undef CK
@@ -292,6 +293,65 @@ int gsa_clone(gsa_ctx *parent, gsa_ctx **out)
 	c->lender = parent; parent->n_borrowers.fetch_add(1);
 	c->h_chr_end = parent->h_chr_end; c->h_chr_fwd = parent->h_chr_fwd; c->h_chr_of_end = parent->h_chr_of_end; c->h_chr_len = parent->h_chr_len;
 	c->prm = parent->prm;
+	*out = c;
+	return GSA_OK;
+}
+
+// A context on ANOTHER GPU (or the same one) with a device index of its own that is COPIED from `parent`'s, device to device, instead of uploaded
+// and rebuilt: the Occ blocks, both suffix arrays, the k-mer tables, the presence table and both text forms are plain position-independent arrays, so a
+// second GPU needs none of gsa_create's work -- the 10.7 GB over PCIe, the regrouping, the dense-SA walk, the table scans (1.3 - 2.7 s for the
+// human index) -- only the bytes, over xGMI.  The host-side state being replicated is bwt_index.cpp:147-264's (RefIdx, RefSequence, ChrLocMap).
+int gsa_clone_to_device(gsa_ctx *parent, int device, gsa_ctx **out)
+{
+	if (!parent || !out) return GSA_ERR_ARG;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { (void)hipGetLastError(); return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_clone_to_device: bad device ordinal"); }
+	gsa_ctx *own = parent->index_owner ? parent->index_owner : parent;
+	if (hipSetDevice(parent->device) != hipSuccess) return gsa_fail(nullptr, GSA_ERR_HIP, "hipSetDevice");
+	if (hipStreamSynchronize(parent->stream) != hipSuccess || hipStreamSynchronize(own->stream) != hipSuccess) return gsa_fail(nullptr, GSA_ERR_HIP, "gsa_clone_to_device: the parent's stream");      // (tables a gsa_set_params has just queued)
+	if (hipSetDevice(device) != hipSuccess) return gsa_fail(nullptr, GSA_ERR_HIP, "hipSetDevice");
+	(void)hipSetDeviceFlags(hipDeviceScheduleSpin); (void)hipGetLastError();
+	gsa_ctx *c = new gsa_ctx();
+	c->device = device; c->force_wide = parent->force_wide; c->prio_mode = parent->prio_mode; c->seed_budget = parent->seed_budget; c->opt = parent->opt;
+	memset(c->kernel_ms, 0, sizeof(c->kernel_ms)); memset(c->counters, 0, sizeof(c->counters));
+	if (int rc = ctx_private_init(c)) { g_create_error = c->err; gsa_destroy(c); return rc; }
+	// every index table of the owner (and the tables a clone built for parameters of its own: presence bitmap, short k-mer table)
+	struct Pair { const DevBuf *src; DevBuf *dst; };
+	std::vector<Pair> tab = { { &own->d_bwt, &c->d_bwt }, { &own->d_occ_base, &c->d_occ_base }, { &own->d_sa, &c->d_sa }, { &own->d_ref, &c->d_ref }, { &own->d_chr_end, &c->d_chr_end },
+		{ &own->d_chr_of_end, &c->d_chr_of_end }, { &own->d_sa_dense, &c->d_sa_dense }, { &own->d_kmer, &c->d_kmer }, { &own->d_ref2, &c->d_ref2 } };
+	for (gsa_ctx *src = parent; src; src = src->lender) {      // (a clone reads these two through the context it was cloned from, unless it built its own)
+		if (!c->d_pres.cap && src->d_pres.p && (const void *)parent->di.pres == src->d_pres.p) { tab.push_back({ &src->d_pres, &c->d_pres }); c->d_pres.cap = 1; }
+		if (!c->d_kmer_lo.cap && src->d_kmer_lo.p && (const void *)parent->di.kmer_lo == src->d_kmer_lo.p) { tab.push_back({ &src->d_kmer_lo, &c->d_kmer_lo }); c->d_kmer_lo.cap = 1; }
+	}
+	c->d_pres.cap = c->d_kmer_lo.cap = 0;
+	auto fail = [&](int code, const std::string &m) { gsa_fail(nullptr, code, m); gsa_destroy(c); return code; };
+	for (const Pair &t : tab) {
+		if (!t.src->p) continue;
+		const size_t bytes = t.src->len ? t.src->len : t.src->cap;
+		if (bytes == 0) return fail(GSA_ERR_STATE, "gsa_clone_to_device: an index table of unknown size");
+		if (hipMalloc(&t.dst->p, bytes + 256) != hipSuccess) { (void)hipGetLastError(); return fail(GSA_ERR_NOMEM, "gsa_clone_to_device: hipMalloc of an index table"); }
+		t.dst->cap = bytes + 256; t.dst->len = bytes;
+		const hipError_t e = (device == own->device) ? hipMemcpyAsync(t.dst->p, t.src->p, bytes, hipMemcpyDeviceToDevice, c->stream)
+		                                             : hipMemcpyPeerAsync(t.dst->p, device, t.src->p, own->device, bytes, c->stream);
+		if (e != hipSuccess) return fail(GSA_ERR_HIP, std::string("gsa_clone_to_device: device-to-device copy: ") + hipGetErrorString(e));
+	}
+	// `di` with every pointer moved to the copy it points into
+	c->di = parent->di;
+	auto move_ptr = [&](const void *p) -> const void * {
+		if (!p) return nullptr;
+		for (const Pair &t : tab) if (t.src->p && (const char *)p >= (const char *)t.src->p && (const char *)p < (const char *)t.src->p + (t.src->len ? t.src->len : t.src->cap)) return (const char *)t.dst->p + ((const char *)p - (const char *)t.src->p);
+		return (const void *)~(uintptr_t)0;
+	};
+	bool lost = false;
+#define MOVE(field, T) do { const void *q_ = move_ptr((const void *)c->di.field); if (q_ == (const void *)~(uintptr_t)0) lost = true; c->di.field = (T)q_; } while (0)
+	MOVE(bwt, const uint4 *); MOVE(occ_base, const u64 *); MOVE(sa, const u64 *); MOVE(sa32, const u32 *); MOVE(sa64, const u64 *); MOVE(ref, const uint8_t *); MOVE(ref2, const u32 *);
+	MOVE(chr_end, const i64 *); MOVE(chr_of_end, const i32 *); MOVE(kmer, const u64 *); MOVE(kmer_lo, const u64 *); MOVE(pres, const u32 *);
+#undef MOVE
+	if (lost) return fail(GSA_ERR_STATE, "gsa_clone_to_device: an index pointer outside the tables of its owner");
+	c->G = parent->G;
+	c->h_chr_end = parent->h_chr_end; c->h_chr_fwd = parent->h_chr_fwd; c->h_chr_of_end = parent->h_chr_of_end; c->h_chr_len = parent->h_chr_len;
+	c->prm = parent->prm;
+	if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(GSA_ERR_HIP, "gsa_clone_to_device: waiting for the copies");
 	*out = c;
 	return GSA_OK;
 }
@@ -385,6 +445,12 @@ int gsa_get_wall_sums(gsa_ctx *c, double ms[10], int64_t *n)
 	return GSA_OK;
 }
 
+int gsa_get_alloc_stats(gsa_ctx *c, double *ms, int64_t *n, int64_t *bytes)
+{
+	if (!c) return GSA_ERR_ARG;
+	if (ms) *ms = c->alloc_ms; if (n) *n = c->alloc_n; if (bytes) *bytes = c->alloc_bytes;
+	return GSA_OK;
+}
 int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->acc_seed_ms = 0.0; memset(c->wall_ms, 0, sizeof(c->wall_ms)); c->wall_n = 0; if (c->up && c->own_up) { std::lock_guard<std::mutex> g(c->up->mu); c->up->copy_ms = c->up->wait_ms = c->up->bytes = 0; c->up->jobs = 0; } c->profiling = (enable & 1) != 0; c->count_blocks = (enable & 2) != 0; c->prof_seed = (enable & 4) != 0; return GSA_OK; }
 
 static int query_geometry(gsa_ctx *c, int32_t qlen)

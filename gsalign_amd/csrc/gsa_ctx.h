@@ -230,6 +230,8 @@ struct gsa_ctx {
 	int frags_stage = 0;                           // stage for which h_frags/h_blocks were built
 	// stage-8 results land in pinned host memory (one async D2H each, no pageable staging)
 	DevBuf p_frags, p_blk; bool result_pinned = false;
+	// what growing buffers cost this context (dev_ensure / pin_ensure: hipMalloc, hipHostMalloc, the frees and the quiesce in front of them) -- gsa_get_alloc_stats
+	double alloc_ms = 0; long long alloc_n = 0, alloc_bytes = 0;
 };
 
 // A buffer is about to be freed: nothing of this context may still use it -- not only the main stream: the early striped DP launch runs on
@@ -245,11 +247,14 @@ static inline void ctx_quiesce(gsa_ctx *c)
 template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 {
 	size_t bytes = (n ? n : 1) * sizeof(T);
+	b.len = bytes;
 	if (bytes <= b.cap) return (T *)b.p;
+	const auto t0_ = std::chrono::steady_clock::now();
 	if (b.p) { ctx_quiesce(c); hipFree(b.p); b.p = nullptr; b.cap = 0; }
 	size_t want = bytes + bytes / 2 + 256;      // (half again: a context that meets a somewhat larger contig or bundle than it has seen does not stop to reallocate)
 	if (hipMalloc(&b.p, want) != hipSuccess) { gsa_fail(c, GSA_ERR_NOMEM, "hipMalloc"); return nullptr; }
 	b.cap = want;
+	c->alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(); c->alloc_n++; c->alloc_bytes += (long long)want;
 	return (T *)b.p;
 }
 
@@ -257,10 +262,12 @@ template <class T> static inline T *pin_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 {
 	size_t bytes = (n ? n : 1) * sizeof(T);
 	if (bytes <= b.cap) return (T *)b.p;
+	const auto t0_ = std::chrono::steady_clock::now();
 	if (b.p) { ctx_quiesce(c); hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
 	size_t want = bytes + bytes / 4 + 4096;
 	if (hipHostMalloc(&b.p, want) != hipSuccess) { gsa_fail(c, GSA_ERR_NOMEM, "hipHostMalloc"); return nullptr; }
 	b.cap = want;
+	c->alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(); c->alloc_n++; c->alloc_bytes += (long long)want;
 	return (T *)b.p;
 }
 

@@ -77,6 +77,7 @@ __device__ __forceinline__ i32 bundle_off_flat(const Bundle &b, i32 q) { return 
 
 struct DevBuf {
 	void *p = nullptr; size_t cap = 0;
+	size_t len = 0;            // bytes last asked for (dev_ensure); the index tables are asked for once, so this is their true size (gsa_clone_to_device copies that much)
 	template <class T> T *as() const { return (T *)p; }
 };
 

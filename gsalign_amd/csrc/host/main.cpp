@@ -157,7 +157,10 @@ int main(int argc, char *argv[])
 			// (the HOST PROGRAM honours a few environment variables and hands them to the library as options -- the library itself reads none:
 			//  GSA_FORCE_WIDE=1: the >= 2^32-row device layout on any index; GSA_SPLIT_MIN / GSA_BUNDLE_CONTIG / GSA_BUNDLE_CAP: gsa_align_many's policy)
 			const char *fw = getenv("GSA_FORCE_WIDE");
-			if (gsa_create_opts(gpus[g], &view, &prm, (fw && *fw && *fw != '0') ? GSA_CREATE_WIDE : 0u, &owner) != GSA_OK) { fprintf(stderr, "GPU initialisation failed (device %d): %s\n", gpus[g], gsa_last_error(NULL)); return 2; }
+			// (the first GPU gets the index from the host -- upload + table builds; every further GPU gets a device-to-device copy of the finished tables:
+			//  gsa_clone_to_device, no second pass over PCIe, nothing rebuilt)
+			const int rc_c = g == 0 ? gsa_create_opts(gpus[g], &view, &prm, (fw && *fw && *fw != '0') ? GSA_CREATE_WIDE : 0u, &owner) : gsa_clone_to_device(ctxs[0], gpus[g], &owner);
+			if (rc_c != GSA_OK) { fprintf(stderr, "GPU initialisation failed (device %d): %s\n", gpus[g], gsa_last_error(NULL)); return 2; }
 			for (const char *nm : { "split_min", "bundle_contig", "bundle_cap" }) {
 				std::string ev = std::string("GSA_") + nm; for (char &ch : ev) ch = (char)toupper((unsigned char)ch);
 				if (const char *v = getenv(ev.c_str())) (void)gsa_set_option(owner, nm, atoll(v));
@@ -260,6 +263,12 @@ int main(int argc, char *argv[])
 	const double ta = now_s();
 	const int rc_many = gsa_align_many(ctxs.data(), (int32_t)ctxs.size(), qptr.data(), qlen.data(), (int32_t)qs.size(), 0, on_result, &sink);
 	t_align = now_s() - ta;
+	// where the contexts' host threads spent that time (gsa_get_wall_sums: [0] query set-up / wait for the upload, [s] stage s) and what growing buffers cost them
+	double wall_sum[10] = { 0 }; double alloc_ms = 0; long long alloc_n = 0, alloc_bytes = 0;
+	for (gsa_ctx *c : ctxs) {
+		double w[10]; int64_t wn = 0; if (gsa_get_wall_sums(c, w, &wn) == GSA_OK) for (int k = 0; k < 9; k++) wall_sum[k] += w[k];
+		double am = 0; int64_t an = 0, ab = 0; if (gsa_get_alloc_stats(c, &am, &an, &ab) == GSA_OK) { alloc_ms += am; alloc_n += an; alloc_bytes += ab; }
+	}
 	{ std::lock_guard<std::mutex> lk(sink.mu); if (rc_many != GSA_OK) sink.abort = true; }
 	sink.cv.notify_all();
 	const double td = now_s();
@@ -304,9 +313,11 @@ int main(int argc, char *argv[])
 		const double total = now_s() - T0;
 		fprintf(stderr, "GSA_TIMING {\"total_s\": %.3f, \"index_build_s\": %.3f, \"index_load_s\": %.3f, \"gsa_create_s\": %.3f, \"query_load_s\": %.3f, \"query_pin_s\": %.3f, \"align_many_s\": %.3f, "
 		        "\"result_copy_s_sum\": %.3f, \"maf_format_s\": %.3f, \"variants_s\": %.3f, \"output_drain_after_align_s\": %.3f, \"maf_write_s\": %.3f, \"maf_bytes\": %llu, "
-		        "\"vcf_s\": %.3f, \"vcf_write_s\": %.3f, \"vcf_bytes\": %llu, \"destroy_s\": %.3f, \"host_threads\": %d, \"contexts\": %d, \"query_bp\": %lld, \"contigs\": %d, \"gbp_per_s_excl_index_build\": %.4f}\n",
+		        "\"vcf_s\": %.3f, \"vcf_write_s\": %.3f, \"vcf_bytes\": %llu, \"destroy_s\": %.3f, \"host_threads\": %d, \"contexts\": %d, \"query_bp\": %lld, \"contigs\": %d, \"gbp_per_s_excl_index_build\": %.4f, "
+		        "\"ctx_wall_ms_sum\": [%.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f], \"alloc_ms_sum\": %.1f, \"alloc_n\": %lld, \"alloc_gb\": %.2f}\n",
 		        total, t_build, t_index, t_create, t_query, t_pin, t_align, t_copy, t_maf_fmt, t_var, t_drain, maf_write_s, maf_bytes, t_vcf, vcf_write_s, vcf_bytes, t_destroy,
-		        HostPool::global().threads(), (int)ctxs.size(), qbp, (int)qs.size(), (double)qbp / (total - t_build) / 1e9);
+		        HostPool::global().threads(), (int)ctxs.size(), qbp, (int)qs.size(), (double)qbp / (total - t_build) / 1e9,
+		        wall_sum[0], wall_sum[1], wall_sum[2], wall_sum[3], wall_sum[4], wall_sum[5], wall_sum[6], wall_sum[7], wall_sum[8], alloc_ms, alloc_n, (double)alloc_bytes / 1e9);
 	}
 	// (everything is on disk and the GPU is released: the process ends here -- unwinding 20 GB of host buffers and the HIP runtime's own
 	//  teardown cost a second or two of wall time at human scale and produce nothing)

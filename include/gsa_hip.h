@@ -175,6 +175,13 @@ int  gsa_set_option(gsa_ctx *ctx, const char *name, int64_t value);
  * gsa_set_params on THAT context may not change min_seed_len / sensitive (GSA_ERR_STATE: the clones read its presence bitmap
  * and short k-mer table); a clone may change its own parameters freely -- it then builds tables of its own. */
 int  gsa_clone(gsa_ctx *parent, gsa_ctx **out);
+/* A context on GPU `device` with a device index of ITS OWN, copied from `parent`'s device to device (over xGMI between GPUs) instead of
+ * uploaded and rebuilt.  The reference loads its index once per process and every thread reads it (RefIdx / RefSequence / ChrLocMap,
+ * bwt_index.cpp:147-264; the workers of GSAlign.cpp:477-526 share it); N GPUs need N copies, and gsa_create per GPU pays the PCIe upload
+ * (10.7 GB for a human index) and the device-side table builds every time.  This pays one device-to-device copy of the finished tables.
+ * The new context is independent of `parent` afterwards (it may outlive it), starts with parent's parameters and options, and may itself
+ * be gsa_clone'd.  `device` may be parent's own GPU (a second, independent copy: what the tests on a one-GPU box exercise). */
+int  gsa_clone_to_device(gsa_ctx *parent, int device, gsa_ctx **out);
 void gsa_destroy(gsa_ctx *ctx);
 /* Puts the CALLING host thread on the CPUs of the socket `device` hangs off (sysfs local_cpulist of its PCI function; a no-op
  * without that information).  The reference's worker threads (GSAlign.cpp:479, pthread_create) run
@@ -333,6 +340,10 @@ int gsa_get_timings(gsa_ctx *ctx, float kernel_ms[8]);
  * *n = contigs; on the context that owns the index, ms[9] / *n = mean duration of one query upload (the Uploader's copies, one at a time).
  * Always on (nine clock reads per contig). */
 int gsa_get_wall_sums(gsa_ctx *ctx, double ms[10], int64_t *n);
+/* What growing its buffers has cost this context since it was created: host wall time inside hipMalloc / hipHostMalloc / the frees (and the wait for
+ * the context's streams in front of a free), number of allocations, bytes allocated.  A context allocates when it meets a larger contig than it has
+ * seen (the reference's vectors grow the same way inside GenomeComparison, GSAlign.cpp:473-552): a steady-state loop shows no growth here. */
+int gsa_get_alloc_stats(gsa_ctx *ctx, double *ms, int64_t *n, int64_t *bytes);
 /* flags: bit 0 = per-stage hipEvent timing; bit 1 = run the ACCOUNTING build of the seed kernel,
  * which also records, per search, how many Occ blocks the reference's walk reads, so that counters[0]
  * is exact (same seeds either way; the default build leaves counters[0] = 0); bit 2 = time the seed

@@ -615,6 +615,36 @@ def test_two_contexts_share_one_index(oracle_built, tmp_path):
     g0.close()
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_clone_to_device_copies_the_built_index(oracle_built, tmp_path, wide):
+    """gsa_clone_to_device: a context whose device index is a device-to-device copy of the parent's finished tables (SURVEY 8(e)'s "build once,
+    copy over xGMI"; the state being replicated is bwt_index.cpp:147-264's).  On a one-GPU box the target is the parent's own device: the copy is still a
+    second, independent index -- it answers like the oracle AFTER the parent (and the clone it was taken from, which had built -sen tables of its
+    own) are destroyed, and it can be gsa_clone'd itself."""
+    refs, qrys = synth.make_pair_fast(1500000, 3, 0.02, seed=91)
+    idx = _build(tmp_path, refs)
+    want = {}
+    for sen in (0, 1):
+        o = oracle_built.Oracle(idx, dict(sen=sen, clr=50) if sen else {})
+        want[sen] = []
+        for name, seq in qrys:
+            o.set_query(seq); o.run_to(8); want[sen].append(o.blocks(with_aln=True))
+        o.close()
+    parent = capi.Aligner(idx, wide=wide)
+    child = parent.clone(); child.set_params(sen=1, clr=50)             # builds a presence table and a short k-mer table of its own
+    copy_default = parent.clone_to_device(0)
+    copy_sen = child.clone_to_device(0)                                  # must carry the CHILD's tables, not the index owner's
+    child.close(); parent.close()                                        # the copies own everything they read
+    grand = copy_default.clone()
+    for g, sen in ((copy_default, 0), (copy_sen, 1), (grand, 0)):
+        for ci, (name, seq) in enumerate(qrys):
+            g.align_contig(seq)
+            got = g.blocks_as_dump(with_aln=True)
+            for key, v in want[sen][ci].items():
+                assert np.array_equal(got[key], v), (sen, ci, key)
+    grand.close(); copy_default.close(); copy_sen.close()
+
+
 def test_degenerate_queries(gpu, ora, golden_dir):
     """Edge cases against the committed index: empty-ish, ambiguous, unrelated, exact-copy and chunk-edge queries."""
     refs = synth.read_fasta(os.path.join(golden_dir, "cx.ref.fa"))
