@@ -491,6 +491,9 @@ def end_to_end(px, genome, params, inflight, tmp, tag):
     t = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     wall = time.time() - t
+    if os.environ.get("GSA_DUMP_BUFFERS"):      # (diagnosis: the CLI lists its contexts' device buffers on stderr)
+        with open(os.path.join(ROOT, "gpurun_out", f"e2e_{tag}_stderr.txt"), "w") as f:
+            f.write(r.stderr)
     line = [ln for ln in r.stderr.splitlines() if ln.startswith("GSA_TIMING ")]
     out = {"command": " ".join(["GSAlign_hip"] + cmd[1:]), "rc": r.returncode, "wall_s": wall}
     if r.returncode == 0 and line:

@@ -20,7 +20,7 @@ EXPORTS = [
     "gsa_align_contig_device", "gsa_set_query_device", "gsa_device_alloc", "gsa_device_free", "gsa_device_upload", "gsa_get_seed_stats", "gsa_hit_buffers", "gsa_seed_chunks", "gsa_hit_count", "gsa_export_hits", "gsa_import_hits", "gsa_finish_contig",
     "gsa_set_query", "gsa_rewind", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
     "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling", "gsa_bind_host_thread",
-    "gsa_prefetch_contig", "gsa_prefetch_bundle", "gsa_cancel_prefetch", "gsa_get_wall_sums", "gsa_get_alloc_stats", "gsa_set_option", "gsa_host_register", "gsa_host_unregister",
+    "gsa_prefetch_contig", "gsa_prefetch_bundle", "gsa_cancel_prefetch", "gsa_get_wall_sums", "gsa_get_alloc_stats", "gsa_debug_buffers", "gsa_set_option", "gsa_host_register", "gsa_host_unregister",
 ]
 
 

@@ -243,6 +243,8 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	return GSA_OK;
 }
 
+// every device buffer a context can own (gsa_destroy frees them; gsa_debug_buffers lists them)
+#define GSA_DEVBUFS(X) X(d_bwt) X(d_bwt_ref) X(d_occ_base) X(d_sa) X(d_ref) X(d_chr_end) X(d_chr_of_end) X(qs[0].d_query) X(qs[1].d_query) X(qs[0].d_bndtab) X(qs[1].d_bndtab) X(tmp) X(d_cnt) X(d_zero) X(d_mail) X(d_lb_status[0]) X(d_lb_status[1]) X(d_sa_dense) X(d_kmer) X(d_kmer_lo) X(d_pres) X(d_ref2) X(d_cand_s) X(d_cand_len) X(d_cand_x0) X(d_cand_freq) X(d_onpath) X(d_cand_cnt) X(d_heavy) X(dn_lf) X(dn_x0) X(d_chunk_hits) X(d_chunk_base) X(d_key_a) X(d_key_b) X(d_val_a) X(d_val_b) X(s_q) X(s_len) X(s_r) X(s_gid) X(d_flag) X(d_scan) X(g_beg) X(w_j0) X(d_pdbm) X(d_pdby) X(d_pdcb) X(d_gpre) X(d_key_c) X(d_val_c) X(a_q) X(a_len) X(a_r) X(a_gb) X(a_ge) X(a_uniq) X(a_cu) X(a_alive) X(a_ws) X(a_wid) X(a_next) X(a_brk) X(a_aurank) X(a_aulist) X(a_runinfo) X(w_best) X(w_sum) X(w_n) X(d_btab) X(d_flag2) X(d_scan2) X(d_i64a) X(b_q) X(b_len) X(b_r) X(b_gb) X(b_ge) X(c_q) X(c_len) X(c_r) X(c_gb) X(c_ge) X(c_bid) X(blk_beg) X(blk_end) X(blk_score) X(r_q) X(r_len) X(r_r) X(r_bid) X(r_tmp_q) X(r_tmp_len) X(r_tmp_r) X(r_tmp_bid) X(r_cut4) X(r_cut5) X(r_simjob) X(r_simres) X(d_leaf) X(fb_seedbase) X(fb_sbeg) X(fb_fragbase) X(f_rec) X(f_rec16) X(f_type) X(f_mism) X(f_alnlen) X(f_job) X(f_score) X(d_dp_tiny) X(d_dp_bnd) X(d_dp_ctr) X(d_dp_jobs) X(d_dp_large) X(d_tail) X(e_id) X(e_rec) X(e_list) X(e_off1) X(e_off2) X(e_opsoff) X(e_nops) X(e_ops) X(e_rev) X(r_head) X(f_early) X(r_orig) X(r_tmp_orig) X(j_frag) X(j_opsoff) X(j_nops) X(d_ops) X(j_cells) X(d_alnoff) X(bl_alnlen) X(bl_score) X(d_bblk) X(d_dp_arena) X(leaf[0]) X(leaf[1]) X(leaf[2]) X(leaf[3]) X(leaf[4]) X(leaf[5]) X(leaf[6]) X(leaf[7]) X(leaf[8])
 void gsa_destroy(gsa_ctx *c)
 {
 	if (!c) return;
@@ -251,17 +253,9 @@ void gsa_destroy(gsa_ctx *c)
 	for (int i = 0; i < 2; i++) slot_wait(c->qs[i]);
 	uploader_stop(c);
 	if (c->lender) c->lender->n_borrowers.fetch_sub(1);      // (`parent` outlives its clones: gsa_hip.h)
-	DevBuf *bufs[] = { &c->d_bwt, &c->d_bwt_ref, &c->d_occ_base, &c->d_sa, &c->d_ref, &c->d_chr_end, &c->d_chr_of_end, &c->qs[0].d_query, &c->qs[1].d_query, &c->qs[0].d_bndtab, &c->qs[1].d_bndtab, &c->tmp, &c->d_cnt, &c->d_zero, &c->d_mail, &c->d_lb_status[0], &c->d_lb_status[1],
-		&c->d_sa_dense, &c->d_kmer, &c->d_kmer_lo, &c->d_pres, &c->d_ref2, &c->d_cand_s, &c->d_cand_len, &c->d_cand_x0, &c->d_cand_freq, &c->d_onpath, &c->d_cand_cnt, &c->d_heavy, &c->dn_lf, &c->dn_x0, &c->d_chunk_hits, &c->d_chunk_base, &c->d_key_a, &c->d_key_b, &c->d_val_a, &c->d_val_b, &c->s_q, &c->s_len, &c->s_r, &c->s_gid,
-		&c->d_flag, &c->d_scan, &c->g_beg, &c->w_j0, &c->d_pdbm, &c->d_pdby, &c->d_pdcb, &c->d_gpre, &c->d_key_c, &c->d_val_c, &c->a_q, &c->a_len, &c->a_r, &c->a_gb, &c->a_ge, &c->a_uniq, &c->a_cu, &c->a_alive, &c->a_ws, &c->a_wid,
-		&c->a_next, &c->a_brk, &c->a_aurank, &c->a_aulist, &c->a_runinfo, &c->w_best, &c->w_sum, &c->w_n, &c->d_btab, &c->d_flag2, &c->d_scan2, &c->d_i64a,
-		&c->b_q, &c->b_len, &c->b_r, &c->b_gb, &c->b_ge, &c->c_q, &c->c_len, &c->c_r, &c->c_gb, &c->c_ge, &c->c_bid, &c->blk_beg, &c->blk_end, &c->blk_score,
-		&c->r_q, &c->r_len, &c->r_r, &c->r_bid, &c->r_tmp_q, &c->r_tmp_len, &c->r_tmp_r, &c->r_tmp_bid, &c->r_cut4, &c->r_cut5, &c->r_simjob, &c->r_simres, &c->d_leaf,
-		&c->fb_seedbase, &c->fb_sbeg, &c->fb_fragbase, &c->f_rec, &c->f_rec16, &c->f_type, &c->f_mism, &c->f_alnlen, &c->f_job, &c->f_score,
-		&c->d_dp_tiny, &c->d_dp_bnd, &c->d_dp_ctr, &c->d_dp_jobs, &c->d_dp_large, &c->d_tail,
-		&c->e_id, &c->e_rec, &c->e_list, &c->e_off1, &c->e_off2, &c->e_opsoff, &c->e_nops, &c->e_ops, &c->e_rev, &c->r_head, &c->f_early, &c->r_orig, &c->r_tmp_orig, &c->j_frag, &c->j_opsoff, &c->j_nops, &c->d_ops, &c->j_cells, &c->d_alnoff, &c->bl_alnlen, &c->bl_score,
-		&c->d_bblk, &c->d_dp_arena,
-		&c->leaf[0], &c->leaf[1], &c->leaf[2], &c->leaf[3], &c->leaf[4], &c->leaf[5], &c->leaf[6], &c->leaf[7], &c->leaf[8] };
+#define X(n) &c->n,
+	DevBuf *bufs[] = { GSA_DEVBUFS(X) };
+#undef X
 	// (a gsa_clone context borrows the index through `di` only: its index DevBufs are empty, a presence bitmap it built after
 	//  a parameter change is its own)
 	for (DevBuf *b : bufs) if (b->p) hipFree(b->p);
@@ -449,6 +443,21 @@ int gsa_get_alloc_stats(gsa_ctx *c, double *ms, int64_t *n, int64_t *bytes)
 {
 	if (!c) return GSA_ERR_ARG;
 	if (ms) *ms = c->alloc_ms; if (n) *n = c->alloc_n; if (bytes) *bytes = c->alloc_bytes;
+	return GSA_OK;
+}
+// The device buffers of a context, largest first, to stderr: name, bytes held, bytes last asked for (diagnosis: what a context's share of HBM is made of).
+int gsa_debug_buffers(gsa_ctx *c, int top)
+{
+	if (!c) return GSA_ERR_ARG;
+	struct E { const char *name; size_t cap, len; };
+	std::vector<E> v;
+#define X(n) if (c->n.p) v.push_back({ #n, c->n.cap, c->n.len });
+	GSA_DEVBUFS(X)
+#undef X
+	std::sort(v.begin(), v.end(), [](const E &a, const E &b) { return a.cap > b.cap; });
+	size_t tot = 0; for (const E &e : v) tot += e.cap;
+	fprintf(stderr, "[gsa_debug_buffers] %zu device buffers, %.2f GB held\n", v.size(), (double)tot / 1e9);
+	for (size_t k = 0; k < v.size() && (int)k < top; k++) fprintf(stderr, "  %-16s %10.1f MB held  %10.1f MB asked\n", v[k].name, (double)v[k].cap / 1e6, (double)v[k].len / 1e6);
 	return GSA_OK;
 }
 int gsa_set_profiling(gsa_ctx *c, int enable) { if (!c) return GSA_ERR_ARG; c->acc_seed_ms = 0.0; memset(c->wall_ms, 0, sizeof(c->wall_ms)); c->wall_n = 0; if (c->up && c->own_up) { std::lock_guard<std::mutex> g(c->up->mu); c->up->copy_ms = c->up->wait_ms = c->up->bytes = 0; c->up->jobs = 0; } c->profiling = (enable & 1) != 0; c->count_blocks = (enable & 2) != 0; c->prof_seed = (enable & 4) != 0; return GSA_OK; }

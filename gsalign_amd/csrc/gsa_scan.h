@@ -183,7 +183,10 @@ __device__ __forceinline__ void lb_copy_out(i32 *dst, const i32 *src, i32 n, int
 // ex = exclusive prefix sums, then op.emit(i, v, ex);  op.done(totals) once, by the thread
 // that owns the last element (or thread 0 of tile 0 when n == 0).
 template <int NV, class Op, int ITEMS>
-__global__ void __launch_bounds__(LB_TPB) k_lb_pass(i64 n, Op op, LbArgs lb)
+#ifndef LB_MIN_WAVES
+#define LB_MIN_WAVES 1      // (experiment: waves per SIMD the register allocation of a fused pass must allow -- 8: at most 64 VGPRs, 10: 48)
+#endif
+__global__ void __launch_bounds__(LB_TPB, LB_MIN_WAVES) k_lb_pass(i64 n, Op op, LbArgs lb)
 {
 	constexpr int LB_TILE = LB_TPB * ITEMS;
 	__shared__ i32 s_tile, s_bcast[2], s_wsum[NV][ITEMS][LB_TPB / 64];

@@ -59,7 +59,7 @@ void block_text(const QueryContig &q, const ContigResult &r, const gsa_block &b,
 	for (int k = 0; k < b.n_frag; k++) {
 		const gsa_frag f = r.frag(b.frag_off + k);
 		if (f.bseed) { t1.append(q.seq, f.qpos, f.qlen); t2.append(q.seq, f.qpos, f.qlen); }     // seeds print the QUERY text on both lines (App. B #4)
-		else { t1.append(r.aln1, f.aln_off, f.aln_len); t2.append(r.aln2, f.aln_off, f.aln_len); }
+		else { t1.append(r.aln1.data() + f.aln_off, (size_t)f.aln_len); t2.append(r.aln2.data() + f.aln_off, (size_t)f.aln_len); }
 	}
 }
 
@@ -76,10 +76,24 @@ int extension(const HostIndex &ix, const gsa_block &b, const gsa_frag &last)
 // what a GPU worker thread does inside gsa_align_many's callback: the result is valid during the call only, so its bytes are copied -- and
 // nothing else.  The records stay in their 16-byte form: the emitters expand the one they look at (frag()), 70 M records of a human genome
 // are never materialised as 40-byte FragPair_t copies
+
+template <class T> void RawArr<T>::assign(const T *src, size_t count)
+{
+	reset();
+	if (count == 0) return;
+	p = (T *)malloc(count * sizeof(T)); if (!p) abort();
+	n = count;
+	const size_t bytes = count * sizeof(T);
+	char *d = (char *)p; const char *sp = (const char *)src;
+	if (bytes < ((size_t)8 << 20)) { memcpy(d, sp, bytes); return; }
+	par_ranges(bytes, (size_t)2 << 20, [&](size_t b, size_t e) { memcpy(d + b, sp + b, e - b); });
+}
+template struct RawArr<gsa_rec>;
+template struct RawArr<char>;
 void ContigResult::assign(const gsa_result &r)
 {
 	blocks.assign(r.blocks, r.blocks + r.n_blocks);
-	recs.assign(r.recs, r.recs + r.n_frags);
+	recs.assign(r.recs, (size_t)r.n_frags);
 	aln1.assign(r.aln1, (size_t)r.n_aln); aln2.assign(r.aln2, (size_t)r.n_aln);
 }
 

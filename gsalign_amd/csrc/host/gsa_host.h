@@ -52,11 +52,27 @@ bool gsah_build_index(const std::string &fasta, const std::string &prefix, std::
 // LoadQueryFile / TrimChromosomeName / CheckQuerySeq (reference src/main.cpp:35-114)
 bool gsah_load_query(const std::string &path, std::vector<QueryContig> &out, std::string &err);
 
+// A plain array that is allocated WITHOUT being touched (std::vector / std::string write every byte once before the copy does, or fault their pages on one
+// thread): a 250 Mb contig's records and gapped strings are ~150 MB, and a GPU worker thread is inside the result callback while they are copied.
+template <class T> struct RawArr {
+	T *p = nullptr; size_t n = 0;
+	RawArr() {}
+	RawArr(const RawArr &) = delete; RawArr &operator=(const RawArr &) = delete;
+	RawArr(RawArr &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+	RawArr &operator=(RawArr &&o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+	~RawArr() { free(p); }
+	void reset() { free(p); p = nullptr; n = 0; }
+	void assign(const T *src, size_t count);            // emit.cpp: large arrays are copied by the pool's threads (first touch spread over them)
+	T *data() { return p; } const T *data() const { return p; }
+	size_t size() const { return n; }
+	T &operator[](size_t i) { return p[i]; } const T &operator[](size_t i) const { return p[i]; }
+};
+
 // one finished contig, as delivered by gsa_align_contig
 struct ContigResult {
 	std::vector<gsa_block> blocks;
-	std::vector<gsa_rec> recs;             // the 16-byte records as they arrived; frag(i) is record i as a FragPair_t
-	std::string aln1, aln2;
+	RawArr<gsa_rec> recs;                  // the 16-byte records as they arrived; frag(i) is record i as a FragPair_t
+	RawArr<char> aln1, aln2;
 	void assign(const gsa_result &r);      // the copies only: what a GPU worker thread does inside the result callback
 	gsa_frag frag(int64_t i) const { gsa_frag f; gsa_rec_expand(recs.data(), i, &f); return f; }
 	void trim(int64_t i, int ext);         // iExtension (tools.cpp:192-202): record i loses its last `ext` bases

@@ -246,8 +246,8 @@ int main(int argc, char *argv[])
 		for (size_t k = 0; k < qs.size(); k++) {
 			{ std::unique_lock<std::mutex> lk(sink.mu); sink.cv.wait(lk, [&] { return sink.abort || sink.ready[k]; }); if (!sink.ready[k]) return; }
 			write_contig(k, sink.res[k]);
-			ContigResult().blocks.swap(sink.res[k].blocks); std::vector<gsa_rec>().swap(sink.res[k].recs);
-			std::string().swap(sink.res[k].aln1); std::string().swap(sink.res[k].aln2);
+			ContigResult().blocks.swap(sink.res[k].blocks); sink.res[k].recs.reset();
+			sink.res[k].aln1.reset(); sink.res[k].aln2.reset();
 			written = k + 1;
 		}
 	});
@@ -264,6 +264,7 @@ int main(int argc, char *argv[])
 	const int rc_many = gsa_align_many(ctxs.data(), (int32_t)ctxs.size(), qptr.data(), qlen.data(), (int32_t)qs.size(), 0, on_result, &sink);
 	t_align = now_s() - ta;
 	// where the contexts' host threads spent that time (gsa_get_wall_sums: [0] query set-up / wait for the upload, [s] stage s) and what growing buffers cost them
+	if (timing && getenv("GSA_DUMP_BUFFERS")) for (gsa_ctx *c : ctxs) (void)gsa_debug_buffers(c, 24);
 	double wall_sum[10] = { 0 }; double alloc_ms = 0; long long alloc_n = 0, alloc_bytes = 0;
 	for (gsa_ctx *c : ctxs) {
 		double w[10]; int64_t wn = 0; if (gsa_get_wall_sums(c, w, &wn) == GSA_OK) for (int k = 0; k < 9; k++) wall_sum[k] += w[k];

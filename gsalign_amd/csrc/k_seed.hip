@@ -134,6 +134,27 @@ __device__ __forceinline__ void wg_exscan_hits(const i32 *hits, i32 *base, int n
 	}
 }
 
+// The same by ONE WAVE of a workgroup whose other waves are busy with chunks of their own (k_seed_wg with SEED_WPW > 1): no LDS, no workgroup barrier.
+__device__ __forceinline__ void wave_exscan_hits(const i32 *hits, i32 *base, int n1)
+{
+	constexpr int V = 16;
+	const int lane = threadIdx.x & 63;
+	i32 run = 0;
+	for (int b0 = 0; b0 < n1; b0 += 64 * V) {
+		i32 v[V], tsum = 0;
+#pragma unroll
+		for (int k = 0; k < V; k++) { const int idx = b0 + lane * V + k; v[k] = idx < n1 ? __hip_atomic_load(&hits[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0; }
+#pragma unroll
+		for (int k = 0; k < V; k++) tsum += v[k];
+		i32 inc = tsum;
+		for (int o = 1; o < 64; o <<= 1) { const i32 t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+		i32 e = run + inc - tsum;
+#pragma unroll
+		for (int k = 0; k < V; k++) { const int idx = b0 + lane * V + k; if (idx < n1) base[idx] = e; e += v[k]; }
+		run += __shfl(inc, 63);
+	}
+}
+
 // next(s) - s per position of a chunk, 0 = unknown, as NIBBLES (round 3; bytes in round 2, u16 before): hops of 15 and more --
 // every accepted match, a few hundred per chunk counting the speculative walks -- keep their value in a hash table beside the
 // nibbles.  LDS per workgroup is what limits how many chunks a CU works on at once (and with them the random reads in flight):
@@ -221,27 +242,58 @@ __device__ __forceinline__ void stage32(const uint8_t *src, int p0, int clen, u3
 // walk each), not instruction issue, so what counts is requests in flight = waves x active lanes, and half the waves with 1.4x the lanes
 // is fewer.  PRODUCTION STAYS AT NCH = 1 (SEED_NCH); the pair form is kept for the day the LDS per chunk halves (then ten PAIRS fit a CU).
 // The accounting build (COUNT) keeps one chunk per wave in any case (its per-start Occ-block array is 20 KB per chunk).
-template <bool COUNT, bool E16, int NCH>
+// Everything a wave keeps in LDS for its chunk(s).  One object per WAVE: a workgroup of k_seed_wg is SEED_WPW independent waves (round 6), each with
+// its own chunk, queue, memo and resolver state; nothing in seed_chunk synchronises across waves.
+template <bool COUNT, int NCH>
+struct SeedLds {
+	static constexpr int NV = NCH * NSUB;
+	u32 s_ncand[NCH], s_queue, s_hits[NCH];
+	int changed, s_abort;
+	u32 qp[NCH][QP_WORDS], qn[NCH][QN_WORDS];
+	// next(s) - s per position as 2-bit codes + a hash table for the long hops (memo_get / memo_set above); a full table (never
+	// seen) sends the chunk to the dense kernels like an exhausted budget does.
+	u32 memo[NCH][MEMO_WORDS];
+	u32 lhop[NCH][LHOP_N];            // (s + 1) << 16 | hop, 0 = free
+	uint16_t mblk[COUNT ? GSA_CHUNK : 1];   // Occ blocks the search from s read (accounting build only: NCH = 1)
+	u32 bits[NCH][PATH_WORDS];
+	uint16_t entry_of[NV], exit_of[NV];
+	uint16_t pend_it[SEED_WG];                          // items to walk for real in this pass
+	uint16_t jmp[2][NV], walked_from[NV];               // pointer-jumping buffers; entry of the last real walk of a re-walked sub-range
+	u32 rewalked[(NV + 31) / 32], onchain[(NV + 31) / 32], s_npend;
+	int s_last;
+};
+// A wave's own synchronisation point.  One wave per workgroup: __syncthreads() as ever (the barrier itself is elided for a one-wave workgroup, the fences
+// stay).  Several: the waves are independent, and LDS operations of ONE wave are performed in the order they were issued, so all that is needed is that
+// the compiler keeps that order.
+#define SEED_SYNC() do { if (WPW == 1) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } } while (0)
+#define s_ncand sl_.s_ncand
+#define s_queue sl_.s_queue
+#define s_hits sl_.s_hits
+#define changed sl_.changed
+#define s_abort sl_.s_abort
+#define qp sl_.qp
+#define qn sl_.qn
+#define memo sl_.memo
+#define lhop sl_.lhop
+#define mblk sl_.mblk
+#define bits sl_.bits
+#define entry_of sl_.entry_of
+#define exit_of sl_.exit_of
+#define pend_it sl_.pend_it
+#define jmp sl_.jmp
+#define walked_from sl_.walked_from
+#define rewalked sl_.rewalked
+#define onchain sl_.onchain
+#define s_npend sl_.s_npend
+#define s_last sl_.s_last
+template <bool COUNT, bool E16, int NCH, int WPW>
 __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__restrict__ q, i32 qlen, const Params &prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
-                                                      u32 budget, u32 *heavy_list, i32 *chunk_base, const int chunk0, const u32 n_chunks)
+                                                      u32 budget, u32 *heavy_list, i32 *chunk_base, const int chunk0, const u32 n_chunks, SeedLds<COUNT, NCH> &sl_)
 {
 	constexpr int NV = NCH * NSUB;                     // virtual items
-	__shared__ u32 s_ncand[NCH], s_queue, s_hits[NCH];
-	__shared__ int changed, s_abort;
-	__shared__ u32 qp[NCH][QP_WORDS], qn[NCH][QN_WORDS];
-	// next(s) - s per position as nibbles + a hash table for the long hops (memo_get / memo_set above); a full table (never
-	// seen) sends the chunk to the dense kernels like an exhausted budget does.
-	__shared__ u32 memo[NCH][MEMO_WORDS];
-	__shared__ u32 lhop[NCH][LHOP_N];         // (s + 1) << 16 | hop, 0 = free
-	__shared__ uint16_t mblk[COUNT ? GSA_CHUNK : 1];   // Occ blocks the search from s read (accounting build only: NCH = 1)
-	__shared__ u32 bits[NCH][PATH_WORDS];
-	__shared__ uint16_t entry_of[NV], exit_of[NV];
-	__shared__ uint16_t pend_it[SEED_WG];                       // items to walk for real in this pass
-	__shared__ uint16_t jmp[2][NV], walked_from[NV];            // pointer-jumping buffers; entry of the last real walk of a re-walked sub-range
-	__shared__ u32 rewalked[(NV + 31) / 32], onchain[(NV + 31) / 32], s_npend;
 	static_assert(!COUNT || NCH == 1, "the accounting build walks one chunk per wave");
-	const int j = threadIdx.x;
+	const int j = threadIdx.x & 63;      // (lane: a workgroup is SEED_WPW independent waves)
 	const int nch = (u32)chunk0 + NCH <= n_chunks ? NCH : (int)(n_chunks - (u32)chunk0);      // chunks of this pair that exist (the last pair of an odd contig: one)
 	i64 c0[NCH]; int clen[NCH], S[NCH], nitems[NCH]; size_t cbase[NCH];
 #pragma unroll
@@ -280,7 +332,7 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 	unsigned long long t_begin = wall_clock64(), t_round0 = 0, t_resolve = 0;
 	u32 dirty = 0;                                      // rounds >= 2: this lane has one item (fb_item) to walk for real
 	int fb_item = 0;
-	__syncthreads();
+	SEED_SYNC();
 	for (;;) {
 		// One flat loop per wave.  Every iteration each lane has exactly ONE memory request pending
 		// (two Occ blocks / 12 bytes of packed reference text / a k-mer table entry / an SA entry); all
@@ -489,7 +541,7 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 		}
 #undef PRES4_TEST
 		rounds++;
-		__syncthreads();
+		SEED_SYNC();
 		if (s_abort) break;
 		if (rounds == 1) t_round0 = wall_clock64() - t_begin;
 		const unsigned long long t_r0 = wall_clock64();
@@ -509,9 +561,9 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 		}
 		if (j < (NV + 31) / 32) onchain[j] = 0;
 		if (j == 0) s_npend = 0;
-		__syncthreads();
+		SEED_SYNC();
 		if (j == 0) { onchain[0] = 1u; if (NCH > 1 && nitems[NCH - 1] > 0) atomicOr(&onchain[NSUB >> 5], 1u << (NSUB & 31)); }
-		__syncthreads();
+		SEED_SYNC();
 		int cur = 0;
 		const int nmax = NCH == 1 ? nitems[0] : (nitems[0] > nitems[NCH - 1] ? nitems[0] : nitems[NCH - 1]);
 		for (int span = 1; span < nmax; span <<= 1) {
@@ -522,14 +574,14 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 					jmp[cur ^ 1][v] = jmp[cur][t];
 				} else jmp[cur ^ 1][v] = 0xffff;
 			}
-			__syncthreads();
+			SEED_SYNC();
 			cur ^= 1;
 		}
 		for (int v = j; v < NV; v += SEED_WG) if (V_LIVE(v)) { const int ch = v >= NSUB ? NCH - 1 : 0; entry_of[v] = (uint16_t)((v - ch * NSUB) ? CH_SEL(clen, ch) : 0); }      // off-chain: nothing to mark
-		__syncthreads();
+		SEED_SYNC();
 		for (int v = j; v < NV; v += SEED_WG) if (V_LIVE(v))
 			if ((onchain[v >> 5] >> (v & 31)) & 1u) { const int ch = v >= NSUB ? NCH - 1 : 0; const int X = exit_of[v]; if (X < CH_SEL(clen, ch)) entry_of[ch * NSUB + X / CH_SEL(S, ch)] = (uint16_t)X; }
-		__syncthreads();
+		SEED_SYNC();
 		for (int v = j; v < NV; v += SEED_WG) if (V_LIVE(v)) {
 			if (!((onchain[v >> 5] >> (v & 31)) & 1u)) continue;
 			const int ch = v >= NSUB ? NCH - 1 : 0;
@@ -540,13 +592,13 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 				if (idx < SEED_WG) { pend_it[idx] = (uint16_t)v; walked_from[v] = (uint16_t)e; atomicOr(&rewalked[v >> 5], 1u << (v & 31)); }
 			}
 		}
-		__syncthreads();
+		SEED_SYNC();
 		if (j == 0) { if (s_npend > SEED_WG) s_npend = SEED_WG; changed = s_npend > 0 ? 1 : 0; }
-		__syncthreads();
+		SEED_SYNC();
 		t_resolve += wall_clock64() - t_r0;
 		const int again = changed;
 		if (again && j < (int)s_npend) { fb_item = pend_it[j]; dirty = 1; }
-		__syncthreads();
+		SEED_SYNC();
 		if (!again) break;
 	}
 	const bool heavy = s_abort != 0;
@@ -556,7 +608,7 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 			heavy_list[hslot] = (u32)(chunk0 + ch);
 			s_ncand[ch] = 0; cand_cnt[chunk0 + ch] = 0; lb_pub(&chunk_hits[chunk0 + ch], 0); if (chunk0 + ch == 0) lb_pub(&chunk_hits[n_chunks], 0);
 		}
-		__syncthreads();
+		SEED_SYNC();
 	}
 	// mark the true path and count the Occ blocks the reference's walk reads
 	u32 alg_blocks = 0;
@@ -580,7 +632,7 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 	if (false)
 #endif
 	if (j == 0) { atomicMax((unsigned long long *)&cnt[11], (unsigned long long)rounds); atomicMax((unsigned long long *)&cnt[14], t_round0); atomicMax((unsigned long long *)&cnt[15], t_resolve); atomicMax((unsigned long long *)&cnt[7], wall_clock64() - t_begin); }
-	__syncthreads();
+	SEED_SYNC();
 	// per chunk: the on-path bits, and how many located hits it will contribute (so that the select kernel needs no global atomic)
 	if (!heavy) {
 #pragma unroll
@@ -592,7 +644,7 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 			for (int o = 32; o; o >>= 1) h += __shfl_down(h, o);
 			if ((j & 63) == 0 && h) atomicAdd(&s_hits[ch], h);
 		}
-		__syncthreads();
+		SEED_SYNC();
 		if (j == 0) for (int ch = 0; ch < nch; ch++) {
 			const u32 nc = s_ncand[ch] < cand_cap ? s_ncand[ch] : cand_cap;
 			cand_cnt[chunk0 + ch] = nc; lb_pub(&chunk_hits[chunk0 + ch], (i32)s_hits[ch]); if (chunk0 + ch == 0) lb_pub(&chunk_hits[n_chunks], 0); atomicMax((unsigned long long *)&cnt[CNT_CAND], (unsigned long long)s_ncand[ch]);
@@ -602,20 +654,40 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 #undef CH_SEL
 	// the workgroup that is through last puts the counters into pinned memory (the host waits for this kernel, nothing
 	// else) and leaves them at zero for the next contig
-	__shared__ int s_last;
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (every wave: its counter atomics are done before the workgroup counts itself)
-	__syncthreads();
+	SEED_SYNC();
 	if (j == 0) {
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (counters are device atomics; an agent-scope fence is an L2 write-back per workgroup here)
 		s_last = atomicAdd((unsigned long long *)&cnt[CNT_DONE], (unsigned long long)nch) == (unsigned long long)n_chunks - (unsigned long long)nch ? 1 : 0;
 	}
-	__syncthreads();
+	SEED_SYNC();
 	if (s_last && j < 16) {
 		hcnt[j] = j == CNT_DONE ? 0 : __hip_atomic_load(&cnt[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		cnt[j] = 0;
 	}
-	if (s_last) wg_exscan_hits<SEED_WG>(chunk_hits, chunk_base, (int)n_chunks + 1);
+	if (s_last) { if (WPW == 1) wg_exscan_hits<SEED_WG>(chunk_hits, chunk_base, (int)n_chunks + 1); else wave_exscan_hits(chunk_hits, chunk_base, (int)n_chunks + 1); }
 }
+#undef s_ncand
+#undef s_queue
+#undef s_hits
+#undef changed
+#undef s_abort
+#undef qp
+#undef qn
+#undef memo
+#undef lhop
+#undef mblk
+#undef bits
+#undef entry_of
+#undef exit_of
+#undef pend_it
+#undef jmp
+#undef walked_from
+#undef rewalked
+#undef onchain
+#undef s_npend
+#undef s_last
+#undef SEED_SYNC
 
 
 // The kernel: workgroups DRAW their chunk pairs from a ticket counter (cnt[SEED_TICKET], never reset: the host passes the value it has
@@ -629,20 +701,33 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 #ifndef SEED_NCH
 #define SEED_NCH 1              // chunks per wave of the production kernel (2: measured slower, see seed_chunk; the accounting build: always 1)
 #endif
+// Round 6: a workgroup is SEED_WPW INDEPENDENT waves -- each draws its own tickets and owns its own SeedLds -- and the LDS a workgroup asks for is more than half a
+// CU's (SEED_WG_LDS > 80 KB), so exactly ONE workgroup fits a CU: a launch of n_cus workgroups lands on every CU (the dispatcher fills a CU before it moves on:
+// with one-wave workgroups a short grid meant FEWER CUs, not thinner ones) with SEED_WPW chunks in flight per CU, and what is left of the CU's LDS (160 KB -
+// SEED_WG_LDS) stays free for the other contexts' kernels -- the striped DP above all, which could not share a CU with twelve one-wave seed workgroups.
+#ifndef SEED_WPW
+#define SEED_WPW 1              // waves (= chunks in flight) per workgroup.  1 = twelve one-wave workgroups per CU (SEED_PERSIST), the production shape; > 1: ONE workgroup of that many independent waves per CU (measured: profiles/r06_seed_wpw.txt)
+#endif
+#define SEED_WG_LDS_MIN (82 * 1024)      // more than half of the 160 KB: two such workgroups never share a CU
 template <bool COUNT, bool E16>
-__global__ void __launch_bounds__(SEED_WG, COUNT ? 1 : SEED_MIN_WAVES) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
+__global__ void __launch_bounds__(SEED_WG * (COUNT ? 1 : SEED_WPW), (COUNT || SEED_WPW > 1) ? 1 : SEED_MIN_WAVES) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
                                                       u32 budget, u32 *heavy_list, i32 *chunk_base, u64 tk_base, u32 n_chunks)
 {
 	constexpr int NCH = COUNT ? 1 : SEED_NCH;
-	__shared__ u32 s_tk;
+	constexpr int WPW = COUNT ? 1 : SEED_WPW;
+	typedef SeedLds<COUNT, NCH> Lds;
+	constexpr size_t need = sizeof(Lds) * WPW, pad = (WPW > 1 && need < SEED_WG_LDS_MIN) ? SEED_WG_LDS_MIN - need : 0;
+	__shared__ Lds lds[WPW];
+	__shared__ u32 s_pad[pad / 4 + 1];
+	if (pad && threadIdx.x == 0 && n_chunks == 0xffffffffu) s_pad[cnt[0] & 1] = 1;      // (keeps the padding allocated: never true)
+	Lds &L = lds[WPW == 1 ? 0 : (threadIdx.x >> 6)];
 	for (;;) {
-		__syncthreads();
-		if (threadIdx.x == 0) s_tk = (u32)(atomicAdd((unsigned long long *)&cnt[SEED_TICKET], 1ull) - tk_base);
-		__syncthreads();
-		const u32 unit = s_tk;
+		u32 unit = 0;
+		if ((threadIdx.x & 63) == 0) unit = (u32)(atomicAdd((unsigned long long *)&cnt[SEED_TICKET], 1ull) - tk_base);
+		unit = (u32)__builtin_amdgcn_readfirstlane((int)unit);
 		if ((u64)unit * NCH >= n_chunks) return;
-		seed_chunk<COUNT, E16, NCH>(di, q, qlen, prm, cnt, cand_s, cand_len, cand_x0, cand_freq, cand_cap, cand_cnt, onpath, chunk_hits, hcnt, budget, heavy_list, chunk_base, (int)(unit * NCH), n_chunks);
+		seed_chunk<COUNT, E16, NCH, WPW>(di, q, qlen, prm, cnt, cand_s, cand_len, cand_x0, cand_freq, cand_cap, cand_cnt, onpath, chunk_hits, hcnt, budget, heavy_list, chunk_base, (int)(unit * NCH), n_chunks, L);
 	}
 }
 
@@ -1793,18 +1878,20 @@ int stage1_seed(gsa_ctx *c)
 			//  0 = one workgroup per chunk.  Measured on a 250 Mb contig: the kernel alone 3.40 -> 3.20 ms at 10 or 16 per CU, 3.6 / 4.2 / 4.8 / 5.7 /
 			//  7.1 / 9.9 ms at 8 / 6 / 5 / 4 / 3 / 2 (the dispatcher fills CUs one after the other, so fewer workgroups mean fewer CUs, not thinner
 			//  ones); four contexts' throughput within +- 2 % of each other from 4 per CU upwards: tools/persist.sh)
-#ifdef GSA_EXPERIMENTS
-			static const int persist = [] { const char *e = getenv("GSA_SEED_PERSIST"); return e ? atoi(e) : SEED_PERSIST / SEED_NCH; }();
-#else
-			const int persist = SEED_PERSIST / SEED_NCH;      // (what the LDS admits)
-#endif
+			// (persistent launch, round 6: ONE workgroup of SEED_WPW independent waves per CU -- its LDS is more than half a CU's, so the dispatcher cannot stack two --
+			//  every wave draws chunk after chunk from the ticket counter.  A short contig: as many workgroups as its chunks fill)
 			const i64 n_units = c->count_blocks ? n_chunks : (n_chunks + SEED_NCH - 1) / SEED_NCH;      // (a wave of the production kernel owns SEED_NCH chunks)
-			unsigned grid = (unsigned)n_units;
-			if (persist > 0 && !c->count_blocks) { if (c->n_cus <= 0) { hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device)); c->n_cus = pr.multiProcessorCount; } const i64 cap = (i64)persist * c->n_cus; if (cap < n_units) grid = (unsigned)cap; }
-			const u64 tk_base = c->seed_ticket; c->seed_ticket += (u64)n_units + grid;
+			const int wpw = c->count_blocks ? 1 : SEED_WPW;
+			unsigned grid = (unsigned)((n_units + wpw - 1) / wpw);
+			if (!c->count_blocks) {
+				if (c->n_cus <= 0) { hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device)); c->n_cus = pr.multiProcessorCount; }
+				const i64 cap = (i64)c->n_cus * (SEED_WPW > 1 ? 1 : SEED_PERSIST);      // (SEED_WPW = 1: round 5's twelve one-wave workgroups per CU, kept for A/B builds)
+				if (cap < (i64)grid) grid = (unsigned)cap;
+			}
+			const u64 tk_base = c->seed_ticket; c->seed_ticket += (u64)n_units + (u64)grid * (u64)wpw;      // (every wave's last draw is the one that fails)
 			if (c->count_blocks) hipLaunchKernelGGL((k_seed_wg<true, false>), dim3(grid), dim3(SEED_WG), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
-			else if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3(grid), dim3(SEED_WG), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
-			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3(grid), dim3(SEED_WG), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
+			else if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3(grid), dim3(SEED_WG * SEED_WPW), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
+			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3(grid), dim3(SEED_WG * SEED_WPW), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
 #undef GSA_SEED_ARGS
 			if (c->profiling || c->prof_seed) hipEventRecord(c->ev[1], st);
 			// (the counters are in pinned memory when the seed kernel is done; the host waits for that, not for the scan of the

@@ -344,6 +344,8 @@ int gsa_get_wall_sums(gsa_ctx *ctx, double ms[10], int64_t *n);
  * the context's streams in front of a free), number of allocations, bytes allocated.  A context allocates when it meets a larger contig than it has
  * seen (the reference's vectors grow the same way inside GenomeComparison, GSAlign.cpp:473-552): a steady-state loop shows no growth here. */
 int gsa_get_alloc_stats(gsa_ctx *ctx, double *ms, int64_t *n, int64_t *bytes);
+/* diagnosis: the `top` largest device buffers of the context to stderr (name, bytes held, bytes last asked for) */
+int gsa_debug_buffers(gsa_ctx *ctx, int top);
 /* flags: bit 0 = per-stage hipEvent timing; bit 1 = run the ACCOUNTING build of the seed kernel,
  * which also records, per search, how many Occ blocks the reference's walk reads, so that counters[0]
  * is exact (same seeds either way; the default build leaves counters[0] = 0); bit 2 = time the seed

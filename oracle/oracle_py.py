@@ -216,24 +216,39 @@ def ref_run_cli(prefix: str, query_fa: str, out_prefix: str, extra: list | None 
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
-def ref_dump_subprocess(prefix: str, query_fa: str, out_npz: str, params: dict | None = None, upto: int = 8) -> None:
-    """Stage dumps of the real reference for every contig of query_fa, in a fresh process."""
+def ref_dump_subprocess(prefix: str, query_fa: str, out_npz: str, params: dict | None = None, upto: int = 8, stages=None, wait: bool = True):
+    """Stage dumps of the real reference for every contig of query_fa, in a fresh process.  stages: keep only these stages' dumps;
+    wait=False: returns the running Popen (several reference processes side by side: one index each, one thread each)."""
     p = dict(DEFAULT_PARAMS); p.update(params or {})
     args = [sys.executable, os.path.abspath(__file__), "refdump", prefix, query_fa, out_npz, str(upto)] + [f"{k}={v}" for k, v in p.items()]
+    if stages is not None:
+        args.append("stages=" + ",".join(str(int(x)) for x in stages))
+    if not wait:
+        return subprocess.Popen(args)
     subprocess.run(args, check=True)
+    return None
 
 
 def _main_refdump(argv):
     sys.path.insert(0, ROOT)
     from gsalign_amd.synth import read_fasta
     prefix, query_fa, out_npz, upto = argv[0], argv[1], argv[2], int(argv[3])
-    params = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in argv[4:]}
+    # (stages=1,8: keep only these stages' dumps -- whole genomes: the intermediate block lists are the bulk of the bytes)
+    keep = None
+    rest = []
+    for kv in argv[4:]:
+        if kv.startswith("stages="):
+            keep = {int(x) for x in kv.split("=")[1].split(",")}
+        else:
+            rest.append(kv)
+    params = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in rest}
     ref = RefLib(prefix, params)
     out = {}
     for ci, (name, seq) in enumerate(read_fasta(query_fa)):
         ref.set_query(seq, name)
         for k, v in ref.dump_stages(upto).items():
-            out[f"c{ci}_{k}"] = v
+            if keep is None or int(k[1:k.index("_")]) in keep:
+                out[f"c{ci}_{k}"] = v
     # (chromosome-sized contigs: hundreds of MB of dumps -- zlib would cost more than the stages themselves)
     (np.savez if sum(v.nbytes for v in out.values()) > (64 << 20) else np.savez_compressed)(out_npz, **out)
 

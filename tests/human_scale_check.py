@@ -32,6 +32,28 @@ try:
     qs[20] = synth.revcomp(qs[20])
     pinned = [g0.pinned_copy(q) for q in qs]
     total = sum(q.size for q in qs)
+    # ---- round 6: EVERY contig of the genome against the real reference (GenomeComparison's loop, GSAlign.cpp:473-552, on the index files its own loader
+    # reads, bwt_index.cpp:147-264): P reference processes side by side, one thread and one copy of the index (~11 GB) each, started now and collected
+    # after the GPU passes below -- the seeds (stage 1) and the final result with both gapped-string pools (stage 8) of all 24 contigs
+    from oracle import oracle_py as op
+    PRM = dict(alen=5000)
+    ref_jobs = []
+    if op.have_ref():
+        avail = 0.0
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable"):
+                avail = int(ln.split()[1]) / 1e6
+        P = int(max(1, min(16, (avail - 80.0) // 16, (os.cpu_count() or 8) // 4, len(qs))))
+        from gsalign_amd import shard
+        deal = shard.assign_contigs([q.size for q in qs], P)
+        for k, own in enumerate(deal):
+            if not own:
+                continue
+            qfa, npz = os.path.join(tmp, f"all_q{k}.fa"), os.path.join(tmp, f"all_{k}.npz")
+            synth.write_fasta(qfa, [(f"q{ci}", qs[ci]) for ci in own])
+            ref_jobs.append((own, npz, op.ref_dump_subprocess(os.path.join(tmp, "r"), qfa, npz, PRM, upto=8, stages=(1, 8), wait=False)))
+        t_ref0 = time.time()
+        print(f"reference side of the whole-genome comparison: {len(ref_jobs)} processes started ({avail:.0f} GB of host memory available)", flush=True)
     devq = [g0.device_copy(q) for q in qs]
     for rep in range(2):
         t = time.time(); capi.align_many([g0, g1], pinned); dt = time.time() - t
@@ -54,9 +76,7 @@ try:
         assert cov > (0.45 if ci == 20 else 0.9) * qs[ci].size
     print(f"all {len(qs)} contigs checked, total coverage {tot_cov / total:.3f}")
     # ---- oracle parity on the native >= 2^32-row index (reference loader: bwt_index.cpp:147-264; loop body: GSAlign.cpp:483-540) ----
-    from oracle import oracle_py as op
     from conftest import assert_stage_equal
-    PRM = dict(alen=5000)
     cases = [("contig20_whole_revcomp", qs[20]),                                             # 46 Mb, reverse strand
              ("contig18_whole_forward", qs[18]),                                             # 58 Mb, forward strand
              ("contig0_piece_revcomp", synth.revcomp(np.ascontiguousarray(qs[0][30000000:50000000]))),   # reverse strand of chr1: reference positions ~ 2G - 50 Mb > 2^32
@@ -88,6 +108,21 @@ try:
         print(f"  {name}: {q.size} bp, {w['s1_qpos'].size} seeds, {w['s8_b_score'].size} blocks, {w['s8_f_qpos'].size} records, {w['s8_aln1'].size} string bytes: all stage dumps identical", flush=True)
     assert scale < 1.0 or (hi > 0 and rev > 0), (hi, rev)
     print(f"ORACLE PARITY OK on the native wide index: {len(cases)} contigs vs the {kind}; {hi} records at reference positions >= 2^32, {rev} reverse-strand blocks")
+    # ---- all 24 contigs against the real reference: stage 1 (seeds, groups) and stage 8 (blocks, records, both gapped-string pools), bit for bit ----
+    if ref_jobs:
+        n_seeds = n_blocks = n_bytes = 0
+        for own, npz, proc in ref_jobs:
+            rc = proc.wait(timeout=900)
+            assert rc == 0, f"reference process for contigs {own} failed ({rc})"
+            with np.load(npz) as z:
+                for k, ci in enumerate(own):
+                    w = {key[len(f"c{k}_"):]: z[key] for key in z.files if key.startswith(f"c{k}_")}
+                    g0.set_query(pinned[ci])
+                    assert_stage_equal(g0.dump_stages(8), w, stages=(1, 8))
+                    n_seeds += int(w["s1_qpos"].size); n_blocks += int(w["s8_b_score"].size); n_bytes += int(w["s8_aln1"].size)
+            os.remove(npz)
+        print(f"WHOLE GENOME == real reference: all {len(qs)} contigs ({total} bp) at stages 1 and 8: {n_seeds} seeds, {n_blocks} blocks, {n_bytes} gapped-string bytes per side identical "
+              f"({len(ref_jobs)} reference processes, {time.time() - t_ref0:.0f} s after their start)", flush=True)
     # short contigs against the human-sized index, bundled (the PosDiff stride of a bundle is ~ 2G = 6.2 G here: the seed key's width
     # and the PosDiff-sort path at their real size): pieces of five query chromosomes, one reverse-complemented, in one pass == one by one
     pieces = [np.ascontiguousarray(qs[ci][o:o + ln]) for ci, o, ln in ((0, 1000000, 2000000), (7, 5000000, 1500000), (20, 300000, 999999), (22, 0, 3000001), (12, 40000000, 10000))]

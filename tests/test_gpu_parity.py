@@ -173,6 +173,7 @@ def test_midsize_pair_2pct(oracle_built, tmp_path):
     (800000, 2, 0.08, 14, dict(slen=12, idy=60)),     # high divergence, short seeds
     (12000000, 1, 0.02, 21, {}),                      # 12 Mb contig: window chain in global memory, > 2048 striped DP jobs, multi-tile scans
     (50000000, 1, 0.02, 22, {}),                      # 50 Mb contig: two size classes of striped jobs, grid-wide window chain, > 4096 early gaps
+    (50000000, 1, 0.02, 23, dict(sen=1, clr=50)),     # round 6: -sen at 50 Mb (BASELINE configs[2]'s mode at 4x its size): 5 000 chunks through the sweep, ~13 M seeds, the PosDiff byte map
     (3000000, 2, 0.05, 15, {}),                       # 5 %: short seeds, dense gaps, many small DP jobs
     (1000000, 1, 0.02, 16, dict(ind=40)),             # MaxIndelSize > 31: grouping by the PosDiff sort instead of the bitmap
     (1500000, 1, 0.003, 17, dict(sen=1, clr=50)),     # -sen at low divergence: long seeds cut every 5 bases, multi-kb gaps
@@ -723,7 +724,7 @@ def _check_result_invariants(idx, qry, r):
     assert np.array_equal(cs[fe] - cs[fb], B["score"].astype(np.int64))
 
 
-@pytest.mark.parametrize("total,ncontig,div,seed,repeats", [(24000000, 2, 0.015, 31, False), (250000000, 1, 0.01, 32, True), (250000000, 1, 0.01, 33, "adversarial")])
+@pytest.mark.parametrize("total,ncontig,div,seed,repeats", [(24000000, 2, 0.015, 31, False), (250000000, 1, 0.01, 32, True), (250000000, 1, 0.01, 33, "adversarial"), (250000000, 1, 0.01, 34, "human_like")])
 def test_full_size_result_invariants(tmp_path, total, ncontig, div, seed, repeats):
     """BASELINE-sized pairs (configs[3]: one 250 Mb chromosome at 1 %, with the repeat-stress injection, and once with the
     adversarial one: copy-number spectrum up to 10^5, microsatellites, Mb-long N runs, soft-masked blocks).  The 250 Mb repeat-stress
@@ -733,6 +734,8 @@ def test_full_size_result_invariants(tmp_path, total, ncontig, div, seed, repeat
     from gsalign_amd import hostlib
     if repeats == "adversarial":
         refs, qrys = synth.make_adversarial_pair(total, ncontig, div, seed=seed)
+    elif repeats == "human_like":
+        refs, qrys = synth.make_human_like_pair(total, ncontig, div, seed=seed)
     else:
         refs, qrys = synth.make_pair_fast(total, ncontig, div, seed=seed, repeats=repeats)
     if ncontig > 1:
@@ -741,6 +744,27 @@ def test_full_size_result_invariants(tmp_path, total, ncontig, div, seed, repeat
     synth.write_fasta(rf, refs); hostlib.build_index(rf, px)
     idx = indexio.load_index(px)
     g = capi.Aligner(idx)
+    if total == 250000000 and repeats == "human_like":
+        # round 6: the primate-like repeat spectrum (the bench's `human_like` workload) at the size the bench runs it, against the REAL reference at every
+        # stage.  The reference's walk pays for repeats (bwt_search.cpp:177-182): it gets ten minutes; if it has not finished, the contig's first 60 Mb are compared instead
+        from oracle import oracle_py as op
+        if op.have_ref():
+            import subprocess
+            qfa, npz = str(tmp_path / "q.fa"), str(tmp_path / "ref.npz")
+            synth.write_fasta(qfa, qrys)
+            proc = op.ref_dump_subprocess(px, qfa, npz, {}, upto=8, wait=False)
+            q_cmp = qrys[0][1]
+            try:
+                assert proc.wait(timeout=600) == 0
+            except subprocess.TimeoutExpired:
+                proc.kill(); proc.wait()
+                q_cmp = np.ascontiguousarray(qrys[0][1][:60000000])
+                synth.write_fasta(qfa, [("q60", q_cmp)]); op.ref_dump_subprocess(px, qfa, npz, {}, upto=8)
+            z = np.load(npz); want = {k[3:]: z[k] for k in z.files if k.startswith("c0_")}
+            g.set_query(q_cmp)
+            assert_stage_equal(g.dump_stages(8), want)
+            assert want["s8_b_score"].size > 0 and want["s1_qpos"].size > 200000
+            print(f"human-like {q_cmp.size} bp vs the real reference: {want['s1_qpos'].size} seeds, {want['s8_b_score'].size} blocks, {want['s8_f_qpos'].size} records, {want['s8_aln1'].size} string bytes per side -- identical at every stage")
     if total == 250000000 and repeats is True:
         # BASELINE configs[3] against the oracle (round 5): the whole 250 Mb contig through the real reference at one thread (libgsref,
         # ~60 s; the CPU restatement where oracle/_ref is absent), every stage dump S1..S8 incl. both gapped-string pools, bit for bit
@@ -760,7 +784,7 @@ def test_full_size_result_invariants(tmp_path, total, ncontig, div, seed, repeat
         r = g.blocks()
         _check_result_invariants(idx, seq, r)
         cov = int(r["blocks"]["aln_len"].sum())
-        assert cov > (0.8 if repeats == "adversarial" else 0.9) * seq.size, (name, cov)
+        assert cov > (0.8 if repeats in ("adversarial", "human_like") else 0.9) * seq.size, (name, cov)
         if repeats == "adversarial":
             print(f"adversarial 250 Mb: {int(g.seed_stats()[1])} of {(seq.size + 9999) // 10000} chunks took the dense search, {r['blocks'].size} blocks, coverage {cov / seq.size:.3f}")
     g.close()
@@ -773,7 +797,7 @@ def test_config5_full_human_all_contigs():
     gsa_align_many on two contexts, then EVERY contig through the result invariants, and -- round 5 -- ORACLE PARITY at this scale: two whole
     contigs (46 Mb reverse strand, 58 Mb forward), a 20 Mb reverse-strand piece of chr1 (reference positions above 2^32) and four short
     pieces against the real reference (libgsref loads the same index files: bwt_index.cpp:147-264), every stage dump S1..S8 with both string
-    pools, bit for bit.  tests/human_scale_check.py; needs a host with >= 256 GB of memory (skipped elsewhere)."""
+    pools, bit for bit; round 6 -- ALL 24 contigs against the real reference at stages 1 and 8 (seeds, groups, blocks, records, both string pools).  tests/human_scale_check.py; needs a host with >= 256 GB of memory (skipped elsewhere)."""
     import subprocess
     import sys
     from conftest import ROOT
@@ -785,6 +809,9 @@ def test_config5_full_human_all_contigs():
         pytest.skip(f"host has {mem_gb:.0f} GB of memory")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "human_scale_check.py")], capture_output=True, text=True, timeout=1100)
     assert r.returncode == 0 and "HUMAN SCALE PROBE OK" in r.stdout and "all 24 contigs checked" in r.stdout and "ORACLE PARITY OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    from oracle import oracle_py as op
+    if op.have_ref():      # round 6: every contig of the genome against the real reference (stages 1 and 8), reference processes side by side on the host's cores
+        assert "WHOLE GENOME == real reference: all 24 contigs" in r.stdout, r.stdout[-3000:]
     print(r.stdout)
 
 
