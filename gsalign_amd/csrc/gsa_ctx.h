@@ -244,14 +244,15 @@ static inline void ctx_quiesce(gsa_ctx *c)
 	for (int i = 0; i < 4; i++) if (c->stream_aux[i]) hipStreamSynchronize(c->stream_aux[i]);
 }
 
-template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n)
+// exact = true: the index tables -- asked for once, never grown: no slack (the dense SA of a human index is 49 GB: half again was 25 GB of HBM and 0.1 s of gsa_create)
+template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n, bool exact = false)
 {
 	size_t bytes = (n ? n : 1) * sizeof(T);
 	b.len = bytes;
 	if (bytes <= b.cap) return (T *)b.p;
 	const auto t0_ = std::chrono::steady_clock::now();
 	if (b.p) { ctx_quiesce(c); hipFree(b.p); b.p = nullptr; b.cap = 0; }
-	size_t want = bytes + bytes / 2 + 256;      // (half again: a context that meets a somewhat larger contig or bundle than it has seen does not stop to reallocate)
+	size_t want = exact ? bytes + 256 : bytes + bytes / 2 + 256;      // (half again: a context that meets a somewhat larger contig or bundle than it has seen does not stop to reallocate)
 	if (hipMalloc(&b.p, want) != hipSuccess) { gsa_fail(c, GSA_ERR_NOMEM, "hipMalloc"); return nullptr; }
 	b.cap = want;
 	c->alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(); c->alloc_n++; c->alloc_bytes += (long long)want;

@@ -10,6 +10,7 @@
 // contig order: GSAlign.cpp:543-546) and formats each with the host pool's threads (par.h: the text lines of a block, the variants of a
 // block's records), a writer thread writes the buffers in order -- so the output bytes depend neither on GPUs / contexts nor on -t.
 #include <errno.h>
+#include <malloc.h>
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -72,6 +73,9 @@ int main(int argc, char *argv[])
 {
 	// -ctx contexts x 5 streams each; the runtime's default is 4 hardware queues per process.  bench.py uses the same value (--hwq); see INTEGRATION.md
 	setenv("GPU_MAX_HW_QUEUES", "16", 0);
+	// (finished contigs are copied into fresh ~100 MB blocks and freed after they are written: keep that memory in the heap instead of handing it back to the
+	//  kernel and faulting it in again for the next contig)
+	mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_TOP_PAD, 256 << 20);
 	gsa_params prm; gsa_default_params(&prm);
 	int threads = HostPool::default_threads(), fmt = 1, n_ctx_per_gpu = 2; bool vcf = true, allow_dup = true, dotplot = false, timing = getenv("GSA_TIMING") != NULL;
 	std::vector<int> gpus;

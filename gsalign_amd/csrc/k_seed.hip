@@ -1603,7 +1603,7 @@ static int build_kmer_lo(gsa_ctx *c)
 	c->di.kmer_lo = nullptr; c->di.kmer_lo_k = 0;
 	if (!c->di.kmer || k < 8 || k >= c->di.kmer_k || k > 13) return GSA_OK;
 	const size_t n = (size_t)1 << (2 * k);
-	if (!dev_ensure<u64>(c, c->d_kmer_lo, c->di.kmer_e16 ? n * 2 : n * 4)) return GSA_ERR_NOMEM;
+	if (!dev_ensure<u64>(c, c->d_kmer_lo, c->di.kmer_e16 ? n * 2 : n * 4, true)) return GSA_ERR_NOMEM;
 	hipLaunchKernelGGL(k_build_kmer, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->di, k, c->d_kmer_lo.as<u64>(), c->di.kmer_e16);
 	GSA_CHECK(c, hipGetLastError());
 	GSA_CHECK(c, hipStreamSynchronize(c->stream));
@@ -1620,7 +1620,7 @@ int build_presence(gsa_ctx *c)
 	c->di.pres = nullptr; c->di.pres_k = 0;
 	if (k < 8) return GSA_OK;                             // short seeds: nearly every k-mer present, nothing to gain
 	const size_t words = ((size_t)1 << (2 * (k - 3))) * 8;      // 4^(k-3) lines of 32 bytes
-	if (!dev_ensure<u32>(c, c->d_pres, words)) return GSA_ERR_NOMEM;
+	if (!dev_ensure<u32>(c, c->d_pres, words, true)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemsetAsync(c->d_pres.p, 0, words * 4, c->stream));
 	if (c->di.kmer && c->di.kmer_k == k && c->opt.pres_from_kmer)
 		hipLaunchKernelGGL(k_pres_from_kmer, dim3(grid_for(std::min<u64>(1ull << (2 * k), 1ull << 28), 256)), dim3(256), 0, c->stream, c->di.kmer, c->di.kmer_e16, k, c->d_pres.as<u32>());
@@ -1673,12 +1673,12 @@ int build_occ(gsa_ctx *c, const void *ref_layout, u64 n_blocks128)
 	// super-blocks of 2^31 rows where the counts need them; the forced-wide layout of the test-suite uses 2^16 rows so that small
 	// texts have several super-blocks and their relative counts really are relative
 	const int shift = c->di.seq_len >= 0xFFFFFF00ull ? 25 : 10;
-	if (!dev_ensure<uint4>(c, c->d_bwt, 2 * n_blocks + 4)) return GSA_ERR_NOMEM;
+	if (!dev_ensure<uint4>(c, c->d_bwt, 2 * n_blocks + 4, true)) return GSA_ERR_NOMEM;
 	GSA_CHECK(c, hipMemsetAsync(c->d_bwt.p, 0, (2 * n_blocks + 4) * sizeof(uint4), c->stream));
 	u64 *base = nullptr;
 	if (wide) {
 		const u64 n_super = (n_blocks >> shift) + 1;
-		if (!dev_ensure<u64>(c, c->d_occ_base, 4 * n_super)) return GSA_ERR_NOMEM;
+		if (!dev_ensure<u64>(c, c->d_occ_base, 4 * n_super, true)) return GSA_ERR_NOMEM;
 		base = c->d_occ_base.as<u64>();
 		hipLaunchKernelGGL(k_occ_base, dim3(grid_for(n_super, 256)), dim3(256), 0, c->stream, (const uint4 *)ref_layout, n_super, shift, base);
 		GSA_CHECK(c, hipGetLastError());
@@ -1694,15 +1694,15 @@ int build_dense_sa(gsa_ctx *c, u64 n_sa)
 {
 	{
 		const u64 words = c->di.seq_len / 16 + 8;      // (the 64-base text window reads five words from any base)
-		if (!dev_ensure<u32>(c, c->d_ref2, words)) return GSA_ERR_NOMEM;
+		if (!dev_ensure<u32>(c, c->d_ref2, words, true)) return GSA_ERR_NOMEM;
 		hipLaunchKernelGGL(k_pack_ref, dim3(grid_for(words, 256)), dim3(256), 0, c->stream, c->di.ref, c->di.seq_len, c->d_ref2.as<u32>(), words);
 		GSA_CHECK(c, hipGetLastError());
 		c->di.ref2 = c->d_ref2.as<u32>();
 	}
 	const u64 rows = c->di.seq_len + 1;
 	const bool use32 = c->di.seq_len < 0xFFFFFFF0ull && !c->force_wide;
-	if (use32) { if (!dev_ensure<u32>(c, c->d_sa_dense, rows + 32)) return GSA_ERR_NOMEM; c->di.sa32 = c->d_sa_dense.as<u32>(); c->di.sa64 = nullptr; }
-	else { if (!dev_ensure<u64>(c, c->d_sa_dense, rows + 32)) return GSA_ERR_NOMEM; c->di.sa64 = c->d_sa_dense.as<u64>(); c->di.sa32 = nullptr; }
+	if (use32) { if (!dev_ensure<u32>(c, c->d_sa_dense, rows + 32, true)) return GSA_ERR_NOMEM; c->di.sa32 = c->d_sa_dense.as<u32>(); c->di.sa64 = nullptr; }
+	else { if (!dev_ensure<u64>(c, c->d_sa_dense, rows + 32, true)) return GSA_ERR_NOMEM; c->di.sa64 = c->d_sa_dense.as<u64>(); c->di.sa32 = nullptr; }
 	hipLaunchKernelGGL(k_densify_sa, dim3(grid_for(n_sa, 256)), dim3(256), 0, c->stream, c->di, n_sa, (u32 *)c->di.sa32, (u64 *)c->di.sa64);
 	GSA_CHECK(c, hipGetLastError());
 	GSA_CHECK(c, hipStreamSynchronize(c->stream));
