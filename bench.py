@@ -371,7 +371,12 @@ def summarise(name, wl, m, t_max, total_bp, world, args):
                      "achieved": achieved, "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": achieved / (HBM_PEAK_GBS * world), "traffic": traffic, "traffic_source": traffic_source,
                      "physical_frac": (traffic / (ms_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world)) if traffic is not None else None,
                      "physical_frac_note": "PMC traffic per step / measured step time / peak: what HBM actually moves; `frac` divides the SURVEY 8(d) formula's bytes (the reference's Occ and LF walks, most of which this path does not perform) by the same time",
-                     "algorithmic_bytes_per_step": alg_total, "terms": m["alg"], "bytes_per_query_base": alg_total / m["bp_per_step"]},
+                     "algorithmic_bytes_per_step": alg_total, "terms": m["alg"], "bytes_per_query_base": alg_total / m["bp_per_step"],
+                     # the DOMINANT KERNEL by itself (k_seed_wg + the dense kernels of a contig = one "launch"): its algorithmic bytes per launch / its average duration, measured
+                     # LIVE in the timed region (two hipEvents per contig on the library's stream, beside the other contexts' kernels -- so this is occupancy time, the lower bound of its rate)
+                     "dominant_kernel": "k_seed_wg (+ dense kernels), seed search S1", "launches_per_step": m["contigs_per_step"] if world == 1 else None,
+                     "avg_launch_ms": (m["seed_live_ms"] / m["contigs_per_step"]) if (m["seed_live_ms"] > 0 and world == 1) else None,
+                     "dominant_kernel_frac": (seed_alg / (m["seed_live_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if (m["seed_live_ms"] > 0 and world == 1) else None},
         "kernels": kern,
         "stage_ms_one_context_alone": {"seed_search": float(tm[0]), "locate": float(tm[1]), "sort_group": float(tm[2]), "chain": float(tm[3]), "refine": float(tm[4]),
                                        "extend": float(tm[5]), "host_lists": float(tm[7])},
@@ -554,7 +559,8 @@ def compact_line(out):
     if rf:
         c["roofline"] = {"bound": rf.get("bound", "hbm"), "kernel": str(rf.get("kernel", ""))[:60], "achieved": _r(rf.get("achieved"), 2), "peak": _r(rf.get("peak"), 1), "unit": rf.get("unit", "GB/s"),
                          "frac": _r(rf.get("frac"), 4), "traffic": _r(rf.get("traffic"), 0), "physical_frac": _r(rf.get("physical_frac"), 4),
-                         "algorithmic_bytes_per_step": _r(rf.get("algorithmic_bytes_per_step"), 0), "avg_launch_ms": _r(rf.get("avg_launch_ms"), 4), "launches_per_step": rf.get("launches_per_step")}
+                         "algorithmic_bytes_per_step": _r(rf.get("algorithmic_bytes_per_step"), 0), "dominant_kernel": str(rf.get("dominant_kernel", ""))[:40], "avg_launch_ms": _r(rf.get("avg_launch_ms"), 4),
+                         "launches_per_step": rf.get("launches_per_step"), "dominant_kernel_frac": _r(rf.get("dominant_kernel_frac"), 4)}
     if cb:
         c["cpu_baseline"] = {"value": _r(cb.get("value"), 6), "unit": cb.get("unit", "Gbp/s"), "cores": cb.get("cores"), "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:160],
                              "parity_sample": cb.get("parity_sample")}

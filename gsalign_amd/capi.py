@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libgsa_hip.so")
 
 EXPORTS = [
-    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_clone", "gsa_clone_to_device", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many", "gsa_align_bundle",
+    "gsa_default_params", "gsa_create", "gsa_create_opts", "gsa_reserve_index", "gsa_release_reserved", "gsa_clone", "gsa_clone_to_device", "gsa_host_alloc", "gsa_host_free", "gsa_destroy", "gsa_set_params", "gsa_last_error", "gsa_align_contig", "gsa_align_many", "gsa_align_bundle",
     "gsa_align_contig_device", "gsa_set_query_device", "gsa_device_alloc", "gsa_device_free", "gsa_device_upload", "gsa_get_seed_stats", "gsa_hit_buffers", "gsa_seed_chunks", "gsa_hit_count", "gsa_export_hits", "gsa_import_hits", "gsa_finish_contig",
     "gsa_set_query", "gsa_rewind", "gsa_run_to", "gsa_seed_count", "gsa_get_seeds", "gsa_group_count", "gsa_get_groups", "gsa_get_blocks",
     "gsa_bwt_search_batch", "gsa_ksw2_batch", "gsa_gap_similarity_batch", "gsa_get_counters", "gsa_get_timings", "gsa_set_profiling", "gsa_bind_host_thread",
@@ -228,7 +228,7 @@ class Aligner:
     def set_option(self, name: str, value) -> None:
         self._ck(self.lib.gsa_set_option(self.ctx, name.encode(), C.c_int64(int(value))))
 
-    def __init__(self, idx, device: int = 0, wide: bool = False, kmer_k: int = 0, _clone_of=None, _copy_to=None, **params):
+    def __init__(self, idx, device: int = 0, wide: bool = False, kmer_k: int = 0, pac=None, _clone_of=None, _copy_to=None, **params):
         self.lib = load_library()
         self.idx = idx
         self._pinned = []
@@ -257,6 +257,10 @@ class Aligner:
         v.bwt = _p(idx.bwt, C.c_uint32); v.bwt_words = idx.bwt.size
         v.sa = _p(idx.sa, C.c_uint64); v.n_sa = idx.sa.size
         v.ref = self._ref.ctypes.data_as(C.c_char_p); v.G = idx.G
+        if pac is not None:      # GSA_CREATE_REF_PAC: the bytes of the .pac file instead of RefSequence -- the device unpacks the text itself
+            self._pac = np.ascontiguousarray(pac, dtype=np.uint8)
+            assert self._pac.size >= (idx.G + 3) // 4
+            v.ref = self._pac.ctypes.data_as(C.c_char_p)
         v.chr_len = _p(idx.chr_len, C.c_int32); v.n_chr = len(idx.chr_len)
         self.ctx = C.c_void_p()
         p = self._params(**params)
@@ -265,7 +269,7 @@ class Aligner:
         wide = wide or os.environ.get("GSA_FORCE_WIDE", "0") not in ("", "0")
         kmer_k = kmer_k or int(os.environ.get("GSA_KMER_K", "0") or 0)
         prio = int(os.environ.get("GSA_PRIO", "0") or 0)          # GSA_CREATE_PRIO (experiments / bench: stream priorities)
-        flags = (1 if wide else 0) | ((kmer_k & 15) << 8) | ((prio & 3) << 16)
+        flags = (1 if wide else 0) | ((kmer_k & 15) << 8) | ((prio & 3) << 16) | (4 if pac is not None else 0)
         rc = self.lib.gsa_create_opts(device, C.byref(v), C.byref(p), flags, C.byref(self.ctx))
         if rc != 0:
             raise GsaError(f"gsa_create -> {rc}: {self.lib.gsa_last_error(None).decode()}")

@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <pthread.h>
 #include <sched.h>
@@ -137,6 +138,31 @@ static int ctx_private_init(gsa_ctx *c, gsa_ctx *share = nullptr)
 	return GSA_OK;
 }
 
+// One large index array, host to device.  Pageable memory goes through the runtime's staging buffers at ~12 GB/s; page-locked in place first (hipHostRegister:
+// ~10 ms per GB) the copy is one DMA transfer at link speed -- 5.4 GB of a human index: 0.45 s -> 0.17 s.  A buffer that cannot be registered (already registered
+// by the host, file-backed, too large for the limit) is copied as it is.
+static hipError_t h2d_big(void *dst, const void *src, size_t bytes)
+{
+	if (bytes >= ((size_t)64 << 20) && hipHostRegister(const_cast<void *>(src), bytes, hipHostRegisterDefault) == hipSuccess) {
+		const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+		(void)hipHostUnregister(const_cast<void *>(src));
+		return e;
+	}
+	(void)hipGetLastError();
+	return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+}
+
+// Device memory set aside for the two largest index tables before the index files are even read (gsa_reserve_index): their sizes follow from the text length
+// alone.  One slot per device; gsa_create on that device adopts what fits (dev_take_reserved), gsa_release_reserved frees what was not used.
+struct ReservedBuf { void *p = nullptr; size_t bytes = 0; };
+static std::mutex g_res_mu; static ReservedBuf g_res[64][2];
+void *dev_take_reserved(int device, size_t bytes, size_t *got)
+{
+	std::lock_guard<std::mutex> g(g_res_mu);
+	for (int k = 0; k < 2; k++) { ReservedBuf &r = g_res[device & 63][k]; if (r.p && r.bytes >= bytes && r.bytes <= bytes + bytes / 8 + 4096) { void *p = r.p; *got = r.bytes; r.p = nullptr; r.bytes = 0; return p; } }
+	return nullptr;
+}
+
 extern "C" {
 
 void gsa_default_params(gsa_params *p)
@@ -189,7 +215,7 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return gsa_fail(nullptr, GSA_ERR_HIP, "no HIP device available (libgsa_hip.so has no CPU path)");
 	if (device < 0 || device >= ndev) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create: bad device ordinal");
-	if (flags & ~(uint32_t)(GSA_CREATE_WIDE | GSA_CREATE_KMER_K(15) | GSA_CREATE_PRIO(3))) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create_opts: unknown flag");
+	if (flags & ~(uint32_t)(GSA_CREATE_WIDE | GSA_CREATE_KMER_K(15) | GSA_CREATE_PRIO(3) | GSA_CREATE_REF_PAC)) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create_opts: unknown flag");
 	{ const uint32_t kk = (flags >> 8) & 15u; if (kk == 1) return gsa_fail(nullptr, GSA_ERR_ARG, "gsa_create_opts: GSA_CREATE_KMER_K takes 2 .. 15 (0: chosen by text length and free memory)"); }
 	gsa_ctx *c = new gsa_ctx();
 	c->device = device; c->force_wide = (flags & GSA_CREATE_WIDE) != 0; c->opt.kmer_k = (int)((flags >> 8) & 15u); c->prio_mode = (int)((flags >> 16) & 3u);
@@ -202,11 +228,22 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	const size_t bwt_bytes = ((idx->bwt_words + 15) / 16) * 64;          // whole 64-byte blocks of the reference's layout (regrouped below: build_occ)
 	CK(hipMalloc(&c->d_bwt_ref.p, bwt_bytes + 64)); c->d_bwt_ref.cap = bwt_bytes + 64;      // (freed once regrouped)
 	CK(hipMemset(c->d_bwt_ref.p, 0, bwt_bytes + 64));
-	CK(hipMemcpy(c->d_bwt_ref.p, idx->bwt, idx->bwt_words * 4, hipMemcpyHostToDevice));
+	CK(h2d_big(c->d_bwt_ref.p, idx->bwt, idx->bwt_words * 4));
 	CK(hipMalloc(&c->d_sa.p, idx->n_sa * 8)); c->d_sa.cap = idx->n_sa * 8;
-	CK(hipMemcpy(c->d_sa.p, idx->sa, idx->n_sa * 8, hipMemcpyHostToDevice));
+	CK(h2d_big(c->d_sa.p, idx->sa, idx->n_sa * 8));
 	CK(hipMalloc(&c->d_ref.p, (size_t)2 * idx->G + 64)); c->d_ref.cap = (size_t)2 * idx->G + 64;
-	CK(hipMemcpy(c->d_ref.p, idx->ref, (size_t)2 * idx->G, hipMemcpyHostToDevice));
+	if (flags & GSA_CREATE_REF_PAC) {
+		// idx->ref = the .pac bytes (four bases per byte, first base in the top bits: bntseq.c's _get_pac): RestoreReferenceInfo's loop (bwt_index.cpp:229-264) runs
+		// on the device -- G / 4 bytes cross PCIe instead of 2G, and the host need not have unpacked anything before the table builds start
+		const size_t pac_bytes = ((size_t)idx->G + 3) / 4;
+		void *d_pac = nullptr;
+		CK(hipMalloc(&d_pac, pac_bytes + 64));
+		if (h2d_big(d_pac, idx->ref, pac_bytes) != hipSuccess) { hipFree(d_pac); gsa_fail(nullptr, GSA_ERR_HIP, "hipMemcpy (.pac)"); gsa_destroy(c); return GSA_ERR_HIP; }
+		const int rcu = unpack_pac(c, (const uint8_t *)d_pac, idx->G, (uint8_t *)c->d_ref.p);
+		(void)hipStreamSynchronize(c->stream); hipFree(d_pac);
+		if (rcu) { g_create_error = c->err; gsa_destroy(c); return rcu; }
+	} else
+	CK(h2d_big(c->d_ref.p, idx->ref, (size_t)2 * idx->G));
 	// ChrLocMap (bwt_index.cpp:240-253) as a sorted table of last coordinates
 	c->G = idx->G;
 	{
@@ -238,6 +275,7 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 	gsa_params dp; gsa_default_params(&dp);
 	int rc = gsa_set_params(c, prm ? prm : &dp);
 	if (rc) { g_create_error = c->err; gsa_destroy(c); return rc; }
+	gsa_release_reserved(device);      // (a reservation that did not fit this index)
 	if (const unsigned long long ov = gsa_take_grid_overflow()) { gsa_fail(nullptr, GSA_ERR_LIMIT, "gsa_create: a table build needed a launch of " + std::to_string(ov) + " work-items (>= 2^32)"); gsa_destroy(c); return GSA_ERR_LIMIT; }
 	*out = c;
 	return GSA_OK;
@@ -375,6 +413,40 @@ static bool device_local_cpus(int device, cpu_set_t *set)
 	}
 	return n > 0;
 }
+int gsa_reserve_index(int device, uint64_t seq_len, uint32_t flags)
+{
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev || seq_len == 0) { (void)hipGetLastError(); return GSA_ERR_ARG; }
+	if (hipSetDevice(device) != hipSuccess) return GSA_ERR_HIP;
+	const bool wide = (flags & GSA_CREATE_WIDE) != 0 || seq_len >= 0xFFFFFFF0ull;
+	size_t want[2];
+	want[0] = ((size_t)seq_len + 1 + 32) * (wide ? 8 : 4) + 256;                 // dense SA (build_dense_sa: rows + 32 entries, exact)
+	{	// k-mer table: build_dense_sa's choice of k (text length, a quarter of the free memory, GSA_CREATE_KMER_K)
+		int k = 0; while ((1ull << (2 * k)) < seq_len) k++;
+		k += 2; if (k > 15) k = 15;
+		size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); fr = 8ull << 30; }
+		const size_t esz = wide ? 32 : 16;
+		while (k > 2 && ((size_t)esz << (2 * k)) > fr / 4) k--;
+		const int kk = (int)((flags >> 8) & 15u); if (kk >= 2 && kk <= 15 && ((size_t)esz << (2 * kk)) <= fr / 2) k = kk;
+		want[1] = k >= 2 ? ((size_t)esz << (2 * k)) : 0;
+	}
+	gsa_release_reserved(device);
+	for (int k = 0; k < 2; k++) {
+		if (!want[k]) continue;
+		void *p = nullptr;
+		if (hipMalloc(&p, want[k]) != hipSuccess) { (void)hipGetLastError(); continue; }      // (no reservation: gsa_create allocates as ever)
+		std::lock_guard<std::mutex> g(g_res_mu);
+		g_res[device & 63][k].p = p; g_res[device & 63][k].bytes = want[k];
+	}
+	return GSA_OK;
+}
+void gsa_release_reserved(int device)
+{
+	void *f[2] = { nullptr, nullptr };
+	{ std::lock_guard<std::mutex> g(g_res_mu); for (int k = 0; k < 2; k++) { f[k] = g_res[device & 63][k].p; g_res[device & 63][k].p = nullptr; g_res[device & 63][k].bytes = 0; } }
+	if (f[0] || f[1]) { (void)hipSetDevice(device); for (int k = 0; k < 2; k++) if (f[k]) hipFree(f[k]); }
+}
+
 int gsa_bind_host_thread(int device)
 {
 	cpu_set_t set;

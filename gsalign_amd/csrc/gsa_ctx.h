@@ -244,6 +244,7 @@ static inline void ctx_quiesce(gsa_ctx *c)
 	for (int i = 0; i < 4; i++) if (c->stream_aux[i]) hipStreamSynchronize(c->stream_aux[i]);
 }
 
+void *dev_take_reserved(int device, size_t bytes, size_t *got);   // gsa_api.hip  (gsa_reserve_index: memory set aside for the dense SA / the k-mer table)
 // exact = true: the index tables -- asked for once, never grown: no slack (the dense SA of a human index is 49 GB: half again was 25 GB of HBM and 0.1 s of gsa_create)
 template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n, bool exact = false)
 {
@@ -253,6 +254,7 @@ template <class T> static inline T *dev_ensure(gsa_ctx *c, DevBuf &b, size_t n, 
 	const auto t0_ = std::chrono::steady_clock::now();
 	if (b.p) { ctx_quiesce(c); hipFree(b.p); b.p = nullptr; b.cap = 0; }
 	size_t want = exact ? bytes + 256 : bytes + bytes / 2 + 256;      // (half again: a context that meets a somewhat larger contig or bundle than it has seen does not stop to reallocate)
+	if (exact && bytes >= ((size_t)1 << 30)) { size_t got = 0; if (void *r = dev_take_reserved(c->device, want, &got)) { b.p = r; b.cap = got; return (T *)b.p; } }
 	if (hipMalloc(&b.p, want) != hipSuccess) { gsa_fail(c, GSA_ERR_NOMEM, "hipMalloc"); return nullptr; }
 	b.cap = want;
 	c->alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count(); c->alloc_n++; c->alloc_bytes += (long long)want;
@@ -274,6 +276,7 @@ template <class T> static inline T *pin_ensure(gsa_ctx *c, DevBuf &b, size_t n)
 
 // stage drivers (one per translation unit)
 int build_dense_sa(gsa_ctx *c, u64 n_sa);   // k_seed.hip
+int unpack_pac(gsa_ctx *c, const uint8_t *d_pac, i64 G, uint8_t *d_ref);   // k_seed.hip  (GSA_CREATE_REF_PAC: RefSequence from the .pac bytes, on the device)
 int build_occ(gsa_ctx *c, const void *ref_layout, u64 n_blocks128);   // k_seed.hip: the device's Occ blocks from the reference's layout
 int build_presence(gsa_ctx *c);             // k_seed.hip  (after MinSeedLength changed)
 int stage1_seed(gsa_ctx *c);          // k_seed.hip

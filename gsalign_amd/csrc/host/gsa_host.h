@@ -36,6 +36,7 @@ struct HostIndex {
 	std::vector<int64_t> chr_fwd, chr_rev;        // FowardLocation / ReverseLocation (bwt_index.cpp:247-248)
 	std::vector<int64_t> end_key; std::vector<int32_t> end_chr;   // ChrLocMap as sorted arrays
 	RawBuf<char> ref;                             // RefSequence: 2G ASCII
+	RawBuf<uint8_t> pac;                          // the .pac bytes (between gsah_load_index_files and gsah_unpack_ref)
 
 	void fill_view(gsa_index_view *v) const;
 	// GenCoordinateInfo (tools.cpp:120-140)
@@ -47,6 +48,10 @@ struct QueryContig { std::string name, seq; };
 // index files (reference src/bwt_index.cpp:25-264, src/GetData.cpp:8-24)
 bool gsah_index_files_exist(const std::string &prefix);
 bool gsah_load_index(const std::string &prefix, HostIndex &idx, std::string &err);
+// the same in two steps: the files as they are (idx.pac = the raw .pac bytes, idx.ref still empty), then RestoreReferenceInfo's unpacking (bwt_index.cpp:229-264) --
+// a host hands idx.pac to gsa_create_opts(GSA_CREATE_REF_PAC) after the first step and unpacks its own RefSequence while the device builds its tables
+bool gsah_load_index_files(const std::string &prefix, HostIndex &idx, std::string &err);
+bool gsah_unpack_ref(HostIndex &idx, std::string &err, bool keep_pac = false);
 // bwa_idx_build (reference src/BWT_Index/bwtindex.c:77-149): byte-identical .bwt .sa .pac .ann .amb
 bool gsah_build_index(const std::string &fasta, const std::string &prefix, std::string &err);
 // LoadQueryFile / TrimChromosomeName / CheckQuerySeq (reference src/main.cpp:35-114)

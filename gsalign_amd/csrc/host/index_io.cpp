@@ -297,7 +297,9 @@ static bool pread_all(const std::string &path, size_t off, void *dst, size_t n)
 }
 static int64_t file_size(const std::string &path) { struct stat st; return stat(path.c_str(), &st) == 0 ? (int64_t)st.st_size : -1; }
 
-bool gsah_load_index(const std::string &prefix, HostIndex &idx, std::string &err)
+// The index files as they lie on disk: .bwt, .sa, .ann and the RAW .pac bytes (idx.pac) -- everything gsa_create needs (with GSA_CREATE_REF_PAC the device unpacks the
+// text itself), so a host program can start the device-side table builds and unpack RefSequence for its own emitters (gsah_unpack_ref) beside them.
+bool gsah_load_index_files(const std::string &prefix, HostIndex &idx, std::string &err)
 {
 	// (round 5: every file goes straight into the vector that keeps it -- the first version read it into a scratch buffer and copied -- in
 	//  slices read by the pool's threads, and RestoreReferenceInfo's unpacking loop runs on the pool as well: 12 s -> ~2 s for a 3.08 Gbp index)
@@ -332,27 +334,14 @@ bool gsah_load_index(const std::string &prefix, HostIndex &idx, std::string &err
 	}
 	fclose(fp);
 	if (seq_len != (uint64_t)(2 * idx.G)) { err = "index is not forward+reverse"; return false; }
-	std::vector<uint8_t> raw;
 	{
 		const int64_t pac_sz = file_size(prefix + ".pac");
 		if (pac_sz < idx.G / 4 + (idx.G % 4 ? 1 : 0)) { err = "cannot read " + prefix + ".pac"; return false; }
-		raw.resize((size_t)pac_sz);
-		if (!pread_all(prefix + ".pac", 0, raw.data(), raw.size())) { err = "cannot read " + prefix + ".pac"; return false; }
+		idx.pac.resize((size_t)pac_sz);
+		if (!idx.pac.data() || !pread_all(prefix + ".pac", 0, idx.pac.data(), idx.pac.size())) { err = "cannot read " + prefix + ".pac"; return false; }
 	}
-	// RestoreReferenceInfo (bwt_index.cpp:229-264): forward strand, then its reverse complement
-	idx.ref.resize((size_t)(2 * idx.G));
-	if (!idx.bwt.data() || !idx.sa.data() || !idx.ref.data()) { err = "out of memory"; return false; }
+	if (!idx.bwt.data() || !idx.sa.data()) { err = "out of memory"; return false; }
 	const int64_t G2 = 2 * idx.G;
-	{
-		char *ref = idx.ref.data(); const uint8_t *pac = raw.data();
-		par_ranges((size_t)((idx.G + 3) / 4), (size_t)1 << 20, [&](size_t b4, size_t e4) {
-			const int64_t fe = std::min<int64_t>((int64_t)e4 * 4, idx.G);
-			for (int64_t f = (int64_t)b4 * 4; f < fe; f++) {
-				const int b = pac[f >> 2] >> ((~f & 3) << 1) & 3;
-				ref[f] = "ACGT"[b]; ref[G2 - 1 - f] = "TGCA"[b];
-			}
-		});
-	}
 	idx.chr_fwd.clear(); idx.chr_rev.clear(); idx.end_key.clear(); idx.end_chr.clear();
 	int64_t tot = 0; std::vector<std::pair<int64_t, int32_t> > ends;
 	for (int i = 0; i < n_seqs; i++) {
@@ -363,6 +352,32 @@ bool gsah_load_index(const std::string &prefix, HostIndex &idx, std::string &err
 	for (size_t i = 0; i < ends.size(); i++) { idx.end_key.push_back(ends[i].first); idx.end_chr.push_back(ends[i].second); }
 	return true;
 }
+
+// RestoreReferenceInfo (bwt_index.cpp:229-264): forward strand, then its reverse complement, from idx.pac; idx.pac is released afterwards unless keep_pac
+bool gsah_unpack_ref(HostIndex &idx, std::string &err, bool keep_pac)
+{
+	idx.ref.resize((size_t)(2 * idx.G));
+	if (!idx.ref.data() || !idx.pac.data()) { err = "out of memory"; return false; }
+	const int64_t G2 = 2 * idx.G;
+	{
+		char *ref = idx.ref.data(); const uint8_t *pac = idx.pac.data();
+		par_ranges((size_t)((idx.G + 3) / 4), (size_t)1 << 20, [&](size_t b4, size_t e4) {
+			const int64_t fe = std::min<int64_t>((int64_t)e4 * 4, idx.G);
+			for (int64_t f = (int64_t)b4 * 4; f < fe; f++) {
+				const int b = pac[f >> 2] >> ((~f & 3) << 1) & 3;
+				ref[f] = "ACGT"[b]; ref[G2 - 1 - f] = "TGCA"[b];
+			}
+		});
+	}
+	if (!keep_pac) idx.pac.resize(0);
+	return true;
+}
+
+bool gsah_load_index(const std::string &prefix, HostIndex &idx, std::string &err)
+{
+	return gsah_load_index_files(prefix, idx, err) && gsah_unpack_ref(idx, err, false);
+}
+
 
 bool gsah_build_index(const std::string &fasta, const std::string &prefix, std::string &err)
 {

@@ -133,7 +133,20 @@ int main(int argc, char *argv[])
 		if (!gsah_build_index(ref_fa, prefix, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
 		t_build = now_s() - t;
 	} else { q_loader.join(); if (!q_ok) fprintf(stderr, "Please check the query file: %s\n", query_fa); else fprintf(stderr, "Please specify a valid reference genome\n"); return 0; }
-	{ const double t = now_s(); const bool ok = gsah_load_index(prefix, idx, err); t_index = now_s() - t; if (!ok) { fprintf(stderr, "\n\nError! Please check your input! (%s)\n", err.c_str()); return 1; } }
+	// while the files are read: the HIP runtime comes up and the device memory of the two largest tables (their sizes follow from the text length in the .bwt header)
+	// is set aside -- ~0.4 s of hipMalloc for a human index that gsa_create would otherwise spend AFTER the files are in
+	if (gpus.empty()) gpus.push_back(0);
+	std::thread reserver([&] {
+		uint64_t hdr[5] = { 0, 0, 0, 0, 0 };
+		FILE *fb = fopen((prefix + ".bwt").c_str(), "rb");
+		const bool ok = fb && fread(hdr, 8, 5, fb) == 5; if (fb) fclose(fb);
+		const char *fw = getenv("GSA_FORCE_WIDE");
+		if (ok && hdr[4] > 0) (void)gsa_reserve_index(gpus[0], hdr[4], (fw && *fw && *fw != '0') ? GSA_CREATE_WIDE : 0u);
+	});
+	struct Joiner3 { std::thread &t; ~Joiner3() { if (t.joinable()) t.join(); } } reserve_join{ reserver };
+	// the index files as they lie on disk first (.bwt, .sa, .ann, the raw .pac bytes); RefSequence -- which only the emitters of THIS program read -- is unpacked further
+	// down, beside gsa_create: the device gets the .pac bytes and unpacks its own copy (GSA_CREATE_REF_PAC)
+	{ const double t = now_s(); const bool ok = gsah_load_index_files(prefix, idx, err); t_index = now_s() - t; if (!ok) { fprintf(stderr, "\n\nError! Please check your input! (%s)\n", err.c_str()); return 1; } }
 
 	// FindGnuPlotPath (main.cpp:169-191): -dp needs a gnuplot binary -- the one -gp names, else the first one on PATH; without one the
 	// reference plots nothing either
@@ -149,11 +162,16 @@ int main(int argc, char *argv[])
 		}
 	}
 	gsa_index_view view; idx.fill_view(&view);
+	view.ref = (const char *)idx.pac.data();      // (GSA_CREATE_REF_PAC below)
 	if (gpus.empty()) gpus.push_back(0);
+	double t_unpack = 0; bool unpack_ok = false; std::string unpack_err;
+	std::thread unpacker([&] { const double t = now_s(); unpack_ok = gsah_unpack_ref(idx, unpack_err, true); t_unpack = now_s() - t; });      // (RestoreReferenceInfo for the emitters, beside gsa_create)
+	struct Joiner2 { std::thread &t; ~Joiner2() { if (t.joinable()) t.join(); } } unpack_join{ unpacker };
 	if (getenv("GSA_BIND")) (void)gsa_bind_host_thread(gpus[0]);      // (opt-in: small contigs gain from a near-socket thread, chromosome-sized ones lose 5 %)
 	// one context per GPU owns that device's copy of the index; the others borrow it (gsa_clone).  The number of contexts wanted depends on
 	// the number of query sequences: the owners are created first (GPU work, beside the FASTA loader), the clones once the count is known
 	std::vector<gsa_ctx *> ctxs;
+	reserver.join();
 	{
 		const double t = now_s();
 		for (size_t g = 0; g < gpus.size(); g++) {
@@ -163,7 +181,7 @@ int main(int argc, char *argv[])
 			const char *fw = getenv("GSA_FORCE_WIDE");
 			// (the first GPU gets the index from the host -- upload + table builds; every further GPU gets a device-to-device copy of the finished tables:
 			//  gsa_clone_to_device, no second pass over PCIe, nothing rebuilt)
-			const int rc_c = g == 0 ? gsa_create_opts(gpus[g], &view, &prm, (fw && *fw && *fw != '0') ? GSA_CREATE_WIDE : 0u, &owner) : gsa_clone_to_device(ctxs[0], gpus[g], &owner);
+			const int rc_c = g == 0 ? gsa_create_opts(gpus[g], &view, &prm, ((fw && *fw && *fw != '0') ? GSA_CREATE_WIDE : 0u) | GSA_CREATE_REF_PAC, &owner) : gsa_clone_to_device(ctxs[0], gpus[g], &owner);
 			if (rc_c != GSA_OK) { fprintf(stderr, "GPU initialisation failed (device %d): %s\n", gpus[g], gsa_last_error(NULL)); return 2; }
 			for (const char *nm : { "split_min", "bundle_contig", "bundle_cap" }) {
 				std::string ev = std::string("GSA_") + nm; for (char &ch : ev) ch = (char)toupper((unsigned char)ch);
@@ -173,6 +191,9 @@ int main(int argc, char *argv[])
 		}
 		t_create = now_s() - t;
 	}
+	unpacker.join();
+	if (!unpack_ok) { fprintf(stderr, "\n\nError! Please check your input! (%s)\n", unpack_err.c_str()); return 1; }
+	idx.pac.resize(0);
 	q_loader.join();
 	if (!q_ok) { fprintf(stderr, "Please check the query file: %s\n", query_fa); return 0; }
 	fprintf(stderr, "\tLoad the query sequences (%d %s)\n", (int)qs.size(), qs.size() > 1 ? "chromosomes" : "chromosome");
@@ -319,10 +340,10 @@ int main(int argc, char *argv[])
 		fprintf(stderr, "GSA_TIMING {\"total_s\": %.3f, \"index_build_s\": %.3f, \"index_load_s\": %.3f, \"gsa_create_s\": %.3f, \"query_load_s\": %.3f, \"query_pin_s\": %.3f, \"align_many_s\": %.3f, "
 		        "\"result_copy_s_sum\": %.3f, \"maf_format_s\": %.3f, \"variants_s\": %.3f, \"output_drain_after_align_s\": %.3f, \"maf_write_s\": %.3f, \"maf_bytes\": %llu, "
 		        "\"vcf_s\": %.3f, \"vcf_write_s\": %.3f, \"vcf_bytes\": %llu, \"destroy_s\": %.3f, \"host_threads\": %d, \"contexts\": %d, \"query_bp\": %lld, \"contigs\": %d, \"gbp_per_s_excl_index_build\": %.4f, "
-		        "\"ctx_wall_ms_sum\": [%.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f], \"alloc_ms_sum\": %.1f, \"alloc_n\": %lld, \"alloc_gb\": %.2f}\n",
+		        "\"ref_unpack_s\": %.3f, \"ctx_wall_ms_sum\": [%.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f], \"alloc_ms_sum\": %.1f, \"alloc_n\": %lld, \"alloc_gb\": %.2f}\n",
 		        total, t_build, t_index, t_create, t_query, t_pin, t_align, t_copy, t_maf_fmt, t_var, t_drain, maf_write_s, maf_bytes, t_vcf, vcf_write_s, vcf_bytes, t_destroy,
 		        HostPool::global().threads(), (int)ctxs.size(), qbp, (int)qs.size(), (double)qbp / (total - t_build) / 1e9,
-		        wall_sum[0], wall_sum[1], wall_sum[2], wall_sum[3], wall_sum[4], wall_sum[5], wall_sum[6], wall_sum[7], wall_sum[8], alloc_ms, alloc_n, (double)alloc_bytes / 1e9);
+		        t_unpack, wall_sum[0], wall_sum[1], wall_sum[2], wall_sum[3], wall_sum[4], wall_sum[5], wall_sum[6], wall_sum[7], wall_sum[8], alloc_ms, alloc_n, (double)alloc_bytes / 1e9);
 	}
 	// (everything is on disk and the GPU is released: the process ends here -- unwinding 20 GB of host buffers and the HIP runtime's own
 	//  teardown cost a second or two of wall time at human scale and produce nothing)

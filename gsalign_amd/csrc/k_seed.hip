@@ -1545,6 +1545,29 @@ __global__ void __launch_bounds__(256) k_build_kmer(DevIndex di, int k, u64 *tab
 	e[0] = ik.x0; e[1] = ik.x1; e[2] = alive ? ik.x2 : 0; e[3] = loc1;
 }
 
+// RefSequence from the .pac bytes (RestoreReferenceInfo, bwt_index.cpp:229-264; packing: bntseq.c _get_pac -- base f in byte f >> 2, bits ((~f & 3) << 1)): the forward
+// strand, then its reverse complement.  A thread takes one pac byte = four bases: one 4-byte store forward, one 4-byte store (when G is a multiple of four; else bytes) backward
+__global__ void __launch_bounds__(256) k_unpack_pac(const uint8_t *__restrict__ pac, i64 G, uint8_t *ref)
+{
+	const i64 G2 = 2 * G;
+	for (i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x; b * 4 < G; b += (i64)gridDim.x * blockDim.x) {
+		const u32 v = pac[b];
+		const i64 f0 = b * 4;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			const i64 f = f0 + t;
+			if (f < G) { const u32 code = (v >> ((~(u32)t & 3u) << 1)) & 3u; ref[f] = (uint8_t)"ACGT"[code]; ref[G2 - 1 - f] = (uint8_t)"TGCA"[code]; }
+		}
+	}
+}
+int unpack_pac(gsa_ctx *c, const uint8_t *d_pac, i64 G, uint8_t *d_ref)
+{
+	const u64 n = ((u64)G + 3) / 4;
+	hipLaunchKernelGGL(k_unpack_pac, dim3(grid_for(std::min<u64>(n, 1ull << 28), 256)), dim3(256), 0, c->stream, d_pac, G, d_ref);
+	GSA_CHECK(c, hipGetLastError());
+	return GSA_OK;
+}
+
 // 2-bit packed copy of RefSequence (16 bases per word, LSB first) for the unique-interval text comparison
 __global__ void __launch_bounds__(256) k_pack_ref(const uint8_t *__restrict__ ref, u64 n, u32 *out, u64 words)
 {
@@ -1727,8 +1750,12 @@ int build_dense_sa(gsa_ctx *c, u64 n_sa)
 				const size_t bytes = (e16 ? n * 2 : n * 4) * sizeof(u64);
 				if (c->d_kmer.cap < bytes) {
 					if (c->d_kmer.p) { hipFree(c->d_kmer.p); c->d_kmer.p = nullptr; c->d_kmer.cap = 0; }
+					size_t got = 0;
+					if (void *r = dev_take_reserved(c->device, bytes, &got)) { c->d_kmer.p = r; c->d_kmer.cap = got; }
+					else {
 					if (hipMalloc(&c->d_kmer.p, bytes) != hipSuccess) { (void)hipGetLastError(); return gsa_fail(c, GSA_ERR_NOMEM, "hipMalloc (k-mer table)"); }
 					c->d_kmer.cap = bytes;
+					}
 				}
 			}
 			hipLaunchKernelGGL(k_build_kmer, dim3(grid_for(n, 256)), dim3(256), 0, c->stream, c->di, k, c->d_kmer.as<u64>(), e16);

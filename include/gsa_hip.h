@@ -140,7 +140,17 @@ int  gsa_create(int device, const gsa_index_view *idx, const gsa_params *prm, gs
  * chaining / refinement / extension run on a stream of the greatest priority, the seed-search kernels on a stream of their own (1, 3: normal priority, 2: least),
  * the striped DP normal (3: least).  Results do not depend on it.  0 (default): every stream at the default priority. */
 #define GSA_CREATE_PRIO(mode) (((uint32_t)(mode) & 3u) << 16)
+/* GSA_CREATE_REF_PAC: idx->ref points at the bytes of the .pac file (G bases, four per byte, as bns_fasta2bntseq wrote them: bntseq.c:110-211) instead of at RefSequence.
+ * The reference unpacks .pac into 2G ASCII bytes on the host (RestoreReferenceInfo, bwt_index.cpp:229-264) before anything else can start; with this flag the device does
+ * that loop itself -- G / 4 bytes cross PCIe instead of 2G, and a host program can unpack its own copy (for its emitters) WHILE gsa_create builds the device tables. */
+#define GSA_CREATE_REF_PAC 4u
 int  gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm, uint32_t flags, gsa_ctx **out);
+/* Optional, before gsa_create: sets device memory aside for the two largest device tables of an index whose text has `seq_len` BWT rows (bwt_t::seq_len, the fifth
+ * word of the .bwt header: structure.h:28-38) -- the dense suffix array and the k-mer table, 84 GB for a human index, ~0.4 s of hipMalloc -- so that a host can do that
+ * while it is still READING the index files (the reference's bwa_idx_load reads first and allocates as it goes, bwt_index.cpp:147-227).  `flags` as for gsa_create_opts.
+ * The next gsa_create[_opts] on `device` adopts what fits and frees the rest; gsa_release_reserved frees a reservation nobody adopted.  Thread-safe. */
+int  gsa_reserve_index(int device, uint64_t seq_len, uint32_t flags);
+void gsa_release_reserved(int device);
 /* Tunables that are not aligner parameters (the library reads no environment variable).  A clone starts with its parent's values;
  * gsa_align_many takes its policy from ctx[0].
  *   "split_min"      bases; gsa_align_many seeds a contig of at least this length on several contexts when contexts would idle (20 000 000)

@@ -28,6 +28,9 @@ try:
     t = time.time(); hostlib.build_index(os.path.join(tmp, "r.fa"), os.path.join(tmp, "r")); print(f"index built in {time.time() - t:.0f} s", flush=True)
     t = time.time(); idx = indexio.load_index(os.path.join(tmp, "r")); print(f"index loaded in {time.time() - t:.0f} s, seq_len {idx.seq_len}", flush=True)
     t = time.time(); g0 = capi.Aligner(idx, alen=5000); g1 = g0.clone(); print(f"gsa_create {time.time() - t:.0f} s", flush=True)
+    # (round 6) a second, independent copy of the finished device index, device to device: what every further GPU of a node costs instead of gsa_create
+    t = time.time(); g_copy = g0.clone_to_device(0); dt_copy = time.time() - t
+    print(f"gsa_clone_to_device (same device, {idx.G / 1e9:.2f} Gbp index): {dt_copy:.2f} s", flush=True)
     qs = [synth.fast_mutate(r, 0.01, 51000 + i) for i, (_, r) in enumerate(refs)]
     qs[20] = synth.revcomp(qs[20])
     pinned = [g0.pinned_copy(q) for q in qs]
@@ -55,6 +58,13 @@ try:
         t_ref0 = time.time()
         print(f"reference side of the whole-genome comparison: {len(ref_jobs)} processes started ({avail:.0f} GB of host memory available)", flush=True)
     devq = [g0.device_copy(q) for q in qs]
+    # ... and it answers like the original: one contig through the copy == through the owner, byte for byte
+    ra = g0.align_contig(pinned[21]); da = capi.result_as_dump(ra, with_aln=True)
+    rb = g_copy.align_contig(pinned[21]); db = capi.result_as_dump(rb, with_aln=True)
+    for key in da:
+        assert np.array_equal(da[key], db[key]), ("clone_to_device", key)
+    g_copy.close()
+    print("the copied index answers like the original (contig 21, every block, record and string byte)", flush=True)
     for rep in range(2):
         t = time.time(); capi.align_many([g0, g1], pinned); dt = time.time() - t
         print(f"pass {rep}: {len(qs)} contigs, {total} bp in {dt * 1e3:.0f} ms = {total / dt / 1e9:.2f} Gbp/s (H2D and D2H included, 2 contexts)", flush=True)

@@ -646,6 +646,41 @@ def test_clone_to_device_copies_the_built_index(oracle_built, tmp_path, wide):
     grand.close(); copy_default.close(); copy_sen.close()
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_create_from_pac_bytes(golden_dir, cx_index, cx_queries, ora, wide):
+    """GSA_CREATE_REF_PAC: gsa_create given the bytes of the .pac file instead of RefSequence -- RestoreReferenceInfo's unpacking (bwt_index.cpp:229-264: forward
+    strand + reverse complement) runs on the device -- answers exactly like a context created from the unpacked text (and so like the oracle)."""
+    pac = np.fromfile(os.path.join(golden_dir, "cx.pac"), dtype=np.uint8)
+    g = capi.Aligner(cx_index, wide=wide, pac=pac)
+    for name, seq in cx_queries:
+        ora.set_query(seq); ora.run_to(8); want = ora.blocks(with_aln=True)
+        g.align_contig(seq); got = g.blocks_as_dump(with_aln=True)
+        for k, v in want.items():
+            assert np.array_equal(got[k], v), (name, k)
+    g.close()
+
+
+def test_reserved_index_memory_is_adopted_or_released(cx_index, cx_queries, ora):
+    """gsa_reserve_index: device memory for the dense SA and the k-mer table set aside before the index files are read (sizes from the text length alone:
+    bwt_t::seq_len, structure.h:28-38); the following gsa_create adopts what fits and frees the rest -- results are what they are without a reservation, and a
+    reservation nobody adopts is freed by gsa_release_reserved."""
+    import ctypes as C
+    lib = capi.load_library()
+    lib.gsa_reserve_index.argtypes = [C.c_int, C.c_uint64, C.c_uint32]
+    lib.gsa_release_reserved.argtypes = [C.c_int]; lib.gsa_release_reserved.restype = None
+    assert lib.gsa_reserve_index(0, int(cx_index.seq_len), 0) == 0
+    g = capi.Aligner(cx_index)
+    name, seq = cx_queries[0]
+    ora.set_query(seq); ora.run_to(8); want = ora.blocks(with_aln=True)
+    g.align_contig(seq); got = g.blocks_as_dump(with_aln=True)
+    for k, v in want.items():
+        assert np.array_equal(got[k], v), k
+    g.close()
+    assert lib.gsa_reserve_index(0, int(cx_index.seq_len), 1) == 0      # (wide layout sizes; never adopted)
+    lib.gsa_release_reserved(0)
+    assert lib.gsa_reserve_index(99, 1000, 0) != 0                        # bad device
+
+
 def test_degenerate_queries(gpu, ora, golden_dir):
     """Edge cases against the committed index: empty-ish, ambiguous, unrelated, exact-copy and chunk-edge queries."""
     refs = synth.read_fasta(os.path.join(golden_dir, "cx.ref.fa"))
