@@ -300,12 +300,12 @@ def measure_split(name, wl, args, tmp, rank, world, local_rank, sync, steps, war
     return dict(t_total=t_total, bp=bp_per_step * steps, bp_per_step=bp_per_step, steps=steps)
 
 
-PMC_FILE = "profiles/r05_pmc_{name}.json"
+PMC_FILE = "profiles/r06_pmc_{name}.json"
 
 
 def pmc_traffic(name):
     """PMC traffic per step of the top kernels.  NOT measured in this run: rocprofv3 --pmc needs passes of its own (one counter
-    set per pass, tools/pmc_top.sh -> tools/pmc_top.py -> profiles/r05_pmc_<workload>.json, which names the commit it was taken
+    set per pass, tools/pmc_top.sh -> tools/pmc_top.py -> profiles/r06_pmc_<workload>.json, which names the commit it was taken
     at); the JSON line says where the number comes from (`traffic_source`)."""
     try:
         return json.load(open(os.path.join(ROOT, PMC_FILE.format(name=name))))
@@ -708,7 +708,7 @@ def main():
     no_torch = args.no_torch and world == 1
     if no_torch:
         # experiment: N = 1 without torch in the process -- libgsa_hip.so then runs on the system's HIP runtime (its D2H copies go through the
-        # SDMA engines; under the runtime bundled with torch they are shader blits, profiles/r04_blit_probe.txt).  Every library call the
+        # SDMA engines; under the runtime bundled with torch they are shader blits, profiles/archive/r04_blit_probe.txt).  Every library call the
         # timed region makes is synchronous, so the clock needs no device-wide synchronisation of its own
         torch = dist = dev = None
     else:

@@ -50,7 +50,7 @@ template <class T> struct lb_has_finish<T, std::void_t<decltype(&T::finish)>> : 
 // thread's ITEMS elements are independent and go out together -- and `value(item, i, c)` / `emit(item, i, v, ex)` work from the registers.
 // Without it emit() re-reads its inputs behind the look-back (atomics: nothing loaded earlier may be kept) and, its pointers being plain,
 // behind each of its own stores: ~10 dependent L2 round trips per element, ITEMS times in a row (OpDpJobs: 64 us per tile, 98 % of its
-// wave-cycles waiting -- profiles/r04_sq_human.txt).
+// wave-cycles waiting -- profiles/archive/r04_sq_human.txt).
 template <class T, class = void> struct lb_has_item : std::false_type {};
 template <class T> struct lb_has_item<T, std::void_t<typename T::Item>> : std::true_type {};
 // Ops that declare `static constexpr bool clamped = true` promise that load(i) / value(i, c) may be called for ANY i in [0, n) without a guard and contain no

@@ -136,12 +136,15 @@ int main(int argc, char *argv[])
 	// while the files are read: the HIP runtime comes up and the device memory of the two largest tables (their sizes follow from the text length in the .bwt header)
 	// is set aside -- ~0.4 s of hipMalloc for a human index that gsa_create would otherwise spend AFTER the files are in
 	if (gpus.empty()) gpus.push_back(0);
+	double t_reserve = 0, t_reserve_wait = 0, t_unpack_wait = 0, t_at_align = 0;
 	std::thread reserver([&] {
+		const double t = now_s();
 		uint64_t hdr[5] = { 0, 0, 0, 0, 0 };
 		FILE *fb = fopen((prefix + ".bwt").c_str(), "rb");
 		const bool ok = fb && fread(hdr, 8, 5, fb) == 5; if (fb) fclose(fb);
 		const char *fw = getenv("GSA_FORCE_WIDE");
 		if (ok && hdr[4] > 0) (void)gsa_reserve_index(gpus[0], hdr[4], (fw && *fw && *fw != '0') ? GSA_CREATE_WIDE : 0u);
+		t_reserve = now_s() - t;
 	});
 	struct Joiner3 { std::thread &t; ~Joiner3() { if (t.joinable()) t.join(); } } reserve_join{ reserver };
 	// the index files as they lie on disk first (.bwt, .sa, .ann, the raw .pac bytes); RefSequence -- which only the emitters of THIS program read -- is unpacked further
@@ -171,7 +174,7 @@ int main(int argc, char *argv[])
 	// one context per GPU owns that device's copy of the index; the others borrow it (gsa_clone).  The number of contexts wanted depends on
 	// the number of query sequences: the owners are created first (GPU work, beside the FASTA loader), the clones once the count is known
 	std::vector<gsa_ctx *> ctxs;
-	reserver.join();
+	{ const double t = now_s(); reserver.join(); t_reserve_wait = now_s() - t; }
 	{
 		const double t = now_s();
 		for (size_t g = 0; g < gpus.size(); g++) {
@@ -191,7 +194,7 @@ int main(int argc, char *argv[])
 		}
 		t_create = now_s() - t;
 	}
-	unpacker.join();
+	{ const double t = now_s(); unpacker.join(); t_unpack_wait = now_s() - t; }
 	if (!unpack_ok) { fprintf(stderr, "\n\nError! Please check your input! (%s)\n", unpack_err.c_str()); return 1; }
 	idx.pac.resize(0);
 	q_loader.join();
@@ -285,7 +288,7 @@ int main(int argc, char *argv[])
 		sk.cv.notify_all();
 		return 0;
 	};
-	const double ta = now_s();
+	const double ta = now_s(); t_at_align = ta - T0;
 	const int rc_many = gsa_align_many(ctxs.data(), (int32_t)ctxs.size(), qptr.data(), qlen.data(), (int32_t)qs.size(), 0, on_result, &sink);
 	t_align = now_s() - ta;
 	// where the contexts' host threads spent that time (gsa_get_wall_sums: [0] query set-up / wait for the upload, [s] stage s) and what growing buffers cost them
@@ -340,10 +343,10 @@ int main(int argc, char *argv[])
 		fprintf(stderr, "GSA_TIMING {\"total_s\": %.3f, \"index_build_s\": %.3f, \"index_load_s\": %.3f, \"gsa_create_s\": %.3f, \"query_load_s\": %.3f, \"query_pin_s\": %.3f, \"align_many_s\": %.3f, "
 		        "\"result_copy_s_sum\": %.3f, \"maf_format_s\": %.3f, \"variants_s\": %.3f, \"output_drain_after_align_s\": %.3f, \"maf_write_s\": %.3f, \"maf_bytes\": %llu, "
 		        "\"vcf_s\": %.3f, \"vcf_write_s\": %.3f, \"vcf_bytes\": %llu, \"destroy_s\": %.3f, \"host_threads\": %d, \"contexts\": %d, \"query_bp\": %lld, \"contigs\": %d, \"gbp_per_s_excl_index_build\": %.4f, "
-		        "\"ref_unpack_s\": %.3f, \"ctx_wall_ms_sum\": [%.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f], \"alloc_ms_sum\": %.1f, \"alloc_n\": %lld, \"alloc_gb\": %.2f}\n",
+		        "\"ref_unpack_s\": %.3f, \"reserve_s\": %.3f, \"reserve_wait_s\": %.3f, \"unpack_wait_s\": %.3f, \"align_starts_at_s\": %.3f, \"ctx_wall_ms_sum\": [%.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f, %.1f], \"alloc_ms_sum\": %.1f, \"alloc_n\": %lld, \"alloc_gb\": %.2f}\n",
 		        total, t_build, t_index, t_create, t_query, t_pin, t_align, t_copy, t_maf_fmt, t_var, t_drain, maf_write_s, maf_bytes, t_vcf, vcf_write_s, vcf_bytes, t_destroy,
 		        HostPool::global().threads(), (int)ctxs.size(), qbp, (int)qs.size(), (double)qbp / (total - t_build) / 1e9,
-		        t_unpack, wall_sum[0], wall_sum[1], wall_sum[2], wall_sum[3], wall_sum[4], wall_sum[5], wall_sum[6], wall_sum[7], wall_sum[8], alloc_ms, alloc_n, (double)alloc_bytes / 1e9);
+		        t_unpack, t_reserve, t_reserve_wait, t_unpack_wait, t_at_align, wall_sum[0], wall_sum[1], wall_sum[2], wall_sum[3], wall_sum[4], wall_sum[5], wall_sum[6], wall_sum[7], wall_sum[8], alloc_ms, alloc_n, (double)alloc_bytes / 1e9);
 	}
 	// (everything is on disk and the GPU is released: the process ends here -- unwinding 20 GB of host buffers and the HIP runtime's own
 	//  teardown cost a second or two of wall time at human scale and produce nothing)

@@ -856,7 +856,7 @@ int launch_early_dp(gsa_ctx *c)
 
 // The same segmentation for contigs whose chain does not fit one workgroup's LDS (round 5: ONE launch; until then leave() per tile, 13-14
 // pointer-doubling launches for the orbit of candidate 0 and a marking launch -- each of the doubling launches a few microseconds of work that,
-// with four contexts in flight, waited ~80 us for its turn: 3.8 % of all kernel time, profiles/r04_kernels_human_full.txt).
+// with four contexts in flight, waited ~80 us for its turn: 3.8 % of all kernel time, profiles/archive/r04_kernels_human_full.txt).
 // All in candidate space: nextk[k] = rank of the next window start after candidate k (nC: none).  The candidates are cut into SLICES of 16 384; a
 // workgroup takes a slice (by ticket: the slices in front of it belong to workgroups that already run), keeps its hops in LDS as 16-bit offsets and
 // computes, for EVERY candidate k of the slice, the last element of the walk from k that still lies in k's sub-tile (64 candidates: E1, one lane

@@ -949,7 +949,7 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 	if (!mail_clean) GSA_CHECK(c, hipMemsetAsync(mail + M_DPERR, 0, 8 * sizeof(i32), st));                    // M_DPERR, M_NLARGE, M_DPERR2, -, M_CELLS (2 x u64): one aligned fill (28 bytes at an odd offset were three)
 	i32 *h = c->p_dp.as<i32>();
 	const size_t first_lg = (size_t)std::min<i64>(n_ub, LG_CHUNK);
-	// Size classes below the striped kernel: alignments of at most GSA_DP_LANE cells (default 512; swept 256 .. 8192: profiles/r03_dp_lane_sweep.txt) go one per LANE (k_dp_lane: every lane busy
+	// Size classes below the striped kernel: alignments of at most GSA_DP_LANE cells (default 512; swept 256 .. 8192: profiles/archive/r03_dp_lane_sweep.txt) go one per LANE (k_dp_lane: every lane busy
 	// on every instruction; a lane walks its cells one after the other, so the largest job of a launch is its latency floor --
 	// 35 instructions per cell), the larger ones one per wavefront (k_dp_small).  GSA_DP_LANE=0: round 2's tiny / small split.
 	const int dp_lane = c->opt.dp_lane;

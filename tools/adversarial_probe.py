@@ -2,7 +2,7 @@
 """VERDICT r2 item 7 at size: a 250 Mb reference with the adversarial injection (csrc/host/synth.cpp: repeat families with a copy-number
 spectrum up to 10^5, microsatellites, two Mb-long N runs, soft-masked blocks) vs a 1 %-diverged query -- how many chunks the speculative
 seed kernel hands to the dense search, stage times of one context alone, and the throughput of two contexts.  GPU box.
-    python tools/adversarial_probe.py [genome_len] > profiles/r03_adversarial_probe.txt"""
+    python tools/adversarial_probe.py [genome_len] > profiles/archive/r03_adversarial_probe.txt"""
 import os, sys, time, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

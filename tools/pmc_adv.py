@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Counters of the adversarial workload's dense seed kernels per launch (gpurun_out/pmc_adversarial/*.csv and pmc_sq_adversarial/*.csv,
-written by tools/r4_adv_pmc.sh): python tools/pmc_adv.py > profiles/r04_pmc_adversarial.txt"""
+written by tools/r4_adv_pmc.sh): python tools/pmc_adv.py > profiles/archive/r04_pmc_adversarial.txt"""
 import csv
 import glob
 

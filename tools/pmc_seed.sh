@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the dominant kernel (k_seed_wg) from rocprofv3 PMC passes on the default bench workload.
 # Separate passes (TCC slots), --pmc only together with --kernel-trace.  Output: gpurun_out/pmc/*.csv,
-# then tools/pmc_seed.py turns them into profiles/r01_pmc_seed.json.
+# then tools/pmc_seed.py turns them into profiles/archive/r01_pmc_seed.json.
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/pmc
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum"; do

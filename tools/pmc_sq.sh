@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ / LDS counters of the top kernels (GPU box): issue utilisation, wait states, LDS bank conflicts.
-#   tools/pmc_sq.sh human -> gpurun_out/pmc_sq_human/*.csv ; tools/pmc_sq.py human -> profiles/r05_sq_human.txt
+#   tools/pmc_sq.sh human -> gpurun_out/pmc_sq_human/*.csv ; tools/pmc_sq.py human -> profiles/r06_sq_human.txt
 W=${1:-human}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/pmc_sq_$W

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/pmc_<workload>/*.csv (tools/pmc_top.sh) -> profiles/r05_pmc_<workload>.json: HBM traffic per step of the
+"""gpurun_out/pmc_<workload>/*.csv (tools/pmc_top.sh) -> profiles/r06_pmc_<workload>.json: HBM traffic per step of the
 top kernels and of the whole step, from separate rocprofv3 --pmc passes.  Reads: from the request counters
 (TCC_EA0_RDREQ: requests that are not 32-byte ones are 128 bytes wide on gfx950 -- the same correction as
 "FETCH_SIZE x 2" in MI355X_MICROARCH.md, HBM section); writes: WRITE_SIZE (KB) as is (uncalibrated there)."""
@@ -71,14 +71,14 @@ def main():
         rb = (rd - rd32) * 128.0 + rd32 * 32.0 if rd else d.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
         return rb, d.get("WRITE_SIZE", 0.0) * 1024.0
     out = {"_what": f"HBM traffic per step of bench.py --workload {W} from rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only beside it), the workload's own --inflight (4 contexts)",
-           "_method": "reads = (TCC_EA0_RDREQ - RDREQ_32B) x 128 B + RDREQ_32B x 32 B (gfx950: FETCH_SIZE tallies 128-byte requests at 64 B, MI355X_MICROARCH.md HBM section; CALIBRATED in round 4 -- profiles/r04_pmc_calibration.txt: a random read of 16, 32, 64 or 128 bytes costs exactly one RDREQ, none of the 32-byte kind, and FETCH_SIZE counts it as 64 B: every L2 miss fetches one 128-byte line); writes = WRITE_SIZE KB x 1024 (uncalibrated); "
+           "_method": "reads = (TCC_EA0_RDREQ - RDREQ_32B) x 128 B + RDREQ_32B x 32 B (gfx950: FETCH_SIZE tallies 128-byte requests at 64 B, MI355X_MICROARCH.md HBM section; CALIBRATED in round 4 -- profiles/archive/r04_pmc_calibration.txt: a random read of 16, 32, 64 or 128 bytes costs exactly one RDREQ, none of the 32-byte kind, and FETCH_SIZE counts it as 64 B: every L2 miss fetches one 128-byte line); writes = WRITE_SIZE KB x 1024 (uncalibrated); "
                       "Infinity-Cache hits are counted, so this is L2-miss traffic, an upper bound of HBM bytes; per step = total over the run / hot-path runs x contigs per step "
                       "(seed kernels: / runs with the production seed kernel)",
            "commit": commit(), "workload": W, "hot_path_runs": sel, "production_seed_runs": prod, "kernels": {}}
     tot_r = tot_w = 0.0
     for k, d in acc.items():
         rb, wb = bytes_of(d)
-        if "Lb1ELb0" in k or "k_seed_wg<true" in k or "k_count_lf" in k or "k_build" in k or "k_densify" in k or "k_pack_ref" in k:
+        if "Lb1ELb0" in k or "k_seed_wg<true" in k or "k_count_lf" in k or "k_build" in k or "k_densify" in k or "k_pack_ref" in k or "k_pres_from" in k or "k_unpack_pac" in k or "k_occ_" in k:
             continue      # accounting build / index upload: not part of a step
         tot_r += rb; tot_w += wb
     for name, pred in GROUPS.items():
@@ -92,7 +92,7 @@ def main():
                                     "traffic_bytes_per_step": (rb + wb) / runs * contigs_per_step}
     if sel:
         out["traffic_bytes_per_step"] = (tot_r + tot_w) / sel * contigs_per_step
-    json.dump(out, open(os.path.join(ROOT, "profiles", f"r05_pmc_{W}.json"), "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"r06_pmc_{W}.json"), "w"), indent=1)
     print(json.dumps(out, indent=1)[:3000])
 
 

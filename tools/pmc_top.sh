@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the top kernels of one bench.py workload from rocprofv3 PMC passes (GPU box).
 # Separate passes (FETCH_SIZE costs 3 of the 4 TCC slots, WRITE_SIZE 2), --pmc only together with --kernel-trace.
-#   tools/pmc_top.sh human   ->  gpurun_out/pmc_human/*.csv ; then tools/pmc_top.py human -> profiles/r05_pmc_human.json
+#   tools/pmc_top.sh human   ->  gpurun_out/pmc_human/*.csv ; then tools/pmc_top.py human -> profiles/r06_pmc_human.json
 W=${1:-human}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/pmc_$W

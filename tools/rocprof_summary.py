@@ -2,7 +2,7 @@
 """Turn a rocprofv3 (rocpd sqlite) kernel trace into the per-kernel summary text we
 commit under profiles/ (the .db itself is scratch under gpurun_out/).
 
-    python tools/rocprof_summary.py gpurun_out/prof1/r1_results.db > profiles/r01_xxx.txt
+    python tools/rocprof_summary.py gpurun_out/prof1/r1_results.db > profiles/archive/r01_xxx.txt
 """
 import sqlite3
 import sys

@@ -15,4 +15,4 @@ STEPS=1 bash tools/pmc_top.sh human_full > gpurun_out/pmc_top_full.log 2>&1
 bash tools/pmc_top.sh human > gpurun_out/pmc_top.log 2>&1
 bash tools/pmc_sq.sh human > gpurun_out/pmc_sq.log 2>&1
 STEPS=1 bash tools/pmc_sq.sh human_full > gpurun_out/pmc_sq_full.log 2>&1
-# then, back in the container: python tools/pmc_top.py human_full; python tools/pmc_top.py human ; python tools/pmc_sq.py human > profiles/r05_sq_human.txt ; python tools/pmc_sq.py human_full > profiles/r05_sq_human_full.txt
+# then, back in the container: python tools/pmc_top.py human_full; python tools/pmc_top.py human ; python tools/pmc_sq.py human > profiles/r06_sq_human.txt ; python tools/pmc_sq.py human_full > profiles/r06_sq_human_full.txt
