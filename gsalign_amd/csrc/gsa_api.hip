@@ -282,7 +282,7 @@ int gsa_create_opts(int device, const gsa_index_view *idx, const gsa_params *prm
 }
 
 // every device buffer a context can own (gsa_destroy frees them; gsa_debug_buffers lists them)
-#define GSA_DEVBUFS(X) X(d_bwt) X(d_bwt_ref) X(d_occ_base) X(d_sa) X(d_ref) X(d_chr_end) X(d_chr_of_end) X(qs[0].d_query) X(qs[1].d_query) X(qs[0].d_bndtab) X(qs[1].d_bndtab) X(tmp) X(d_cnt) X(d_zero) X(d_mail) X(d_lb_status[0]) X(d_lb_status[1]) X(d_sa_dense) X(d_kmer) X(d_kmer_lo) X(d_pres) X(d_ref2) X(d_cand_s) X(d_cand_len) X(d_cand_x0) X(d_cand_freq) X(d_onpath) X(d_cand_cnt) X(d_heavy) X(d_preheavy) X(dn_lf) X(dn_x0) X(d_chunk_hits) X(d_chunk_base) X(d_key_a) X(d_key_b) X(d_val_a) X(d_val_b) X(s_q) X(s_len) X(s_r) X(s_gid) X(d_flag) X(d_scan) X(g_beg) X(w_j0) X(d_pdbm) X(d_pdby) X(d_pdcb) X(d_gpre) X(d_key_c) X(d_val_c) X(a_q) X(a_len) X(a_r) X(a_gb) X(a_ge) X(a_uniq) X(a_cu) X(a_alive) X(a_ws) X(a_wid) X(a_next) X(a_brk) X(a_aurank) X(a_aulist) X(a_runinfo) X(w_best) X(w_sum) X(w_n) X(d_btab) X(d_flag2) X(d_scan2) X(d_i64a) X(b_q) X(b_len) X(b_r) X(b_gb) X(b_ge) X(c_q) X(c_len) X(c_r) X(c_gb) X(c_ge) X(c_bid) X(blk_beg) X(blk_end) X(blk_score) X(r_q) X(r_len) X(r_r) X(r_bid) X(r_tmp_q) X(r_tmp_len) X(r_tmp_r) X(r_tmp_bid) X(r_cut4) X(r_cut5) X(r_simjob) X(r_simres) X(d_leaf) X(fb_seedbase) X(fb_sbeg) X(fb_fragbase) X(f_rec) X(f_rec16) X(f_type) X(f_mism) X(f_alnlen) X(f_job) X(f_score) X(d_dp_tiny) X(d_dp_bnd) X(d_dp_ctr) X(d_dp_jobs) X(d_dp_large) X(d_tail) X(e_id) X(e_rec) X(e_list) X(e_off1) X(e_off2) X(e_opsoff) X(e_nops) X(e_ops) X(e_rev) X(r_head) X(f_early) X(r_orig) X(r_tmp_orig) X(j_frag) X(j_opsoff) X(j_nops) X(d_ops) X(j_cells) X(d_alnoff) X(bl_alnlen) X(bl_score) X(d_bblk) X(d_dp_arena) X(leaf[0]) X(leaf[1]) X(leaf[2]) X(leaf[3]) X(leaf[4]) X(leaf[5]) X(leaf[6]) X(leaf[7]) X(leaf[8])
+#define GSA_DEVBUFS(X) X(d_bwt) X(d_bwt_ref) X(d_occ_base) X(d_sa) X(d_ref) X(d_chr_end) X(d_chr_of_end) X(qs[0].d_query) X(qs[1].d_query) X(qs[0].d_bndtab) X(qs[1].d_bndtab) X(tmp) X(d_cnt) X(d_zero) X(d_mail) X(d_lb_status[0]) X(d_lb_status[1]) X(d_sa_dense) X(d_kmer) X(d_kmer_lo) X(d_pres) X(d_ref2) X(d_cand_s) X(d_cand_len) X(d_cand_x0) X(d_cand_freq) X(d_onpath) X(d_cand_cnt) X(d_heavy) X(dn_lf) X(dn_x0) X(d_chunk_hits) X(d_chunk_base) X(d_key_a) X(d_key_b) X(d_val_a) X(d_val_b) X(s_q) X(s_len) X(s_r) X(s_gid) X(d_flag) X(d_scan) X(g_beg) X(w_j0) X(d_pdbm) X(d_pdby) X(d_pdcb) X(d_gpre) X(d_key_c) X(d_val_c) X(a_q) X(a_len) X(a_r) X(a_gb) X(a_ge) X(a_uniq) X(a_cu) X(a_alive) X(a_ws) X(a_wid) X(a_next) X(a_brk) X(a_aurank) X(a_aulist) X(a_runinfo) X(w_best) X(w_sum) X(w_n) X(d_btab) X(d_flag2) X(d_scan2) X(d_i64a) X(b_q) X(b_len) X(b_r) X(b_gb) X(b_ge) X(c_q) X(c_len) X(c_r) X(c_gb) X(c_ge) X(c_bid) X(blk_beg) X(blk_end) X(blk_score) X(r_q) X(r_len) X(r_r) X(r_bid) X(r_tmp_q) X(r_tmp_len) X(r_tmp_r) X(r_tmp_bid) X(r_cut4) X(r_cut5) X(r_simjob) X(r_simres) X(d_leaf) X(fb_seedbase) X(fb_sbeg) X(fb_fragbase) X(f_rec) X(f_rec16) X(f_type) X(f_mism) X(f_alnlen) X(f_job) X(f_score) X(d_dp_tiny) X(d_dp_bnd) X(d_dp_ctr) X(d_dp_jobs) X(d_dp_large) X(d_tail) X(e_id) X(e_rec) X(e_list) X(e_off1) X(e_off2) X(e_opsoff) X(e_nops) X(e_ops) X(e_rev) X(r_head) X(f_early) X(r_orig) X(r_tmp_orig) X(j_frag) X(j_opsoff) X(j_nops) X(d_ops) X(j_cells) X(d_alnoff) X(bl_alnlen) X(bl_score) X(d_bblk) X(d_dp_arena) X(leaf[0]) X(leaf[1]) X(leaf[2]) X(leaf[3]) X(leaf[4]) X(leaf[5]) X(leaf[6]) X(leaf[7]) X(leaf[8])
 void gsa_destroy(gsa_ctx *c)
 {
 	if (!c) return;
@@ -496,8 +496,6 @@ int gsa_set_option(gsa_ctx *c, const char *name, int64_t value)
 	else if (k == "pd_bytes") { if (!in(0, 2)) return gsa_fail(c, GSA_ERR_ARG, "pd_bytes: 0 never, 1 by the hit count, 2 always"); c->opt.pd_bytes = (int)value; }
 	else if (k == "pres_from_kmer") c->opt.pres_from_kmer = value != 0;      // (takes effect at the next gsa_set_params that rebuilds the table)
 	else if (k == "walk_chain_min") { if (!in(0, BIG)) return gsa_fail(c, GSA_ERR_ARG, "walk_chain_min: >= 0 seeds"); c->opt.walk_chain_min = value; }
-	else if (k == "seed_preclass") { if (!in(0, 2)) return gsa_fail(c, GSA_ERR_ARG, "seed_preclass: 0 never, 1 by the previous contig, 2 always"); c->opt.seed_preclass = (int)value; }
-	else if (k == "seed_preclass_min") { if (!in(1, 192)) return gsa_fail(c, GSA_ERR_ARG, "seed_preclass_min: 1 .. 192 sampled starts"); c->opt.seed_preclass_min = (int)value; }
 	else if (k == "sweep_shape") { if (value < -1 || value > 1) return gsa_fail(c, GSA_ERR_ARG, "sweep_shape: -1, 0 or 1"); c->opt.sweep_shape = (int)value; }
 	else if (k == "dp_safe") c->dp_safe = value != 0;                    // (test hook)
 	else if (k == "dp_fake_timeout") { if (!in(0, 1 << 20)) return gsa_fail(c, GSA_ERR_ARG, "dp_fake_timeout: >= 0"); c->dp_fake_timeout = (int)value; }    // (test hook)

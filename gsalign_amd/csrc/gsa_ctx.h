@@ -86,8 +86,6 @@ struct Options {
 	int pd_bytes = 1;                  // the PosDiff bitmap of a contig (bundle) whose hits scatter (-sen: thousands of chance hits per chunk) is filled through a byte per value, plain stores, and packed
 	                                   // afterwards -- no device-scope atomics (k_pd_pack, k_seed.hip); 1 = when the hit count says so, 0 = never, 2 = always (tests)
 	int pres_from_kmer = 1;            // the presence table is derived from the k-mer jump table when both hold k-mers of one length (0: always from a scan of the text; a test compares the two)
-	int seed_preclass = 1;             // repeat-heavy chunks flagged in front of the speculative seed kernel (k_chunk_preclass): 0 never, 1 when the contig before handed over > 2 % of its chunks, 2 always (tests)
-	int seed_preclass_min = 2;         // ... a chunk is flagged when at least this many of its 192 sampled start positions open with a k-mer of more than MaxSeedFreq occurrences
 	int kmer_k = 0;                    // gsa_create_opts (GSA_CREATE_KMER_K): length of the jump table's k-mers (0: by text length and free memory)
 };
 
@@ -159,7 +157,6 @@ struct gsa_ctx {
 	DevBuf d_sa_dense;                             // one SA entry per BWT row (built at gsa_create)
 	DevBuf d_cand_s, d_cand_len, d_cand_x0, d_cand_freq, d_onpath, d_cand_cnt;
 	size_t cand_cap_per_chunk = 1536;
-	DevBuf d_preheavy; bool seed_pre_next = false;   // k_chunk_preclass: one flag per chunk (repeat-heavy: straight to the dense kernels); switched on by the contig before (stage1_seed)
 	DevBuf d_heavy, dn_lf, dn_x0;               // chunks the speculative seed kernel gave up on; next(s) / accepted match per start of the dense chunks
 	bool seed_sweep_next = false, seed_sweep_probe = false; int seed_sweep_run = 0, seed_sweep_period = 8;   // the previous contig handed most chunks to the sweep: the next one starts there (k_seed.hip, stage1_seed)
 	u32 seed_budget = 256;                         // wave-iterations a chunk may take in the speculative kernel before it goes to the dense path (GSA_SEED_BUDGET)

@@ -289,7 +289,7 @@ struct SeedLds {
 template <bool COUNT, bool E16, int NCH, int WPW>
 __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__restrict__ q, i32 qlen, const Params &prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
-                                                      u32 budget, u32 *heavy_list, i32 *chunk_base, const int chunk0, const u32 n_chunks, SeedLds<COUNT, NCH> &sl_, const uint8_t *__restrict__ pre)
+                                                      u32 budget, u32 *heavy_list, i32 *chunk_base, const int chunk0, const u32 n_chunks, SeedLds<COUNT, NCH> &sl_)
 {
 	constexpr int NV = NCH * NSUB;                     // virtual items
 	static_assert(!COUNT || NCH == 1, "the accounting build walks one chunk per wave");
@@ -306,13 +306,10 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 	}
 	const int nitems_all = NCH == 1 ? nitems[0] : nitems[0] + nitems[NCH - 1];
 #define CH_SEL(ARR, CH) (NCH == 1 ? ARR[0] : ((CH) ? ARR[NCH - 1] : ARR[0]))
-	// (round 6) a chunk the pre-classifier (k_chunk_preclass) calls repeat-heavy is handed to the dense kernels at once: it would have burnt the whole budget
-	// first -- 256 wave-iterations against the ~75 an ordinary chunk takes -- and on repeat-rich sequence a third of the chunks do
-	const bool skip = !COUNT && pre != nullptr && pre[chunk0] != 0 && (NCH == 1 || nch < 2 || pre[chunk0 + 1] != 0);
 	// stage the chunks: 32 bases per lane per pass -> two code words + one N word (16-byte global loads)
 #pragma unroll
 	for (int ch = 0; ch < NCH; ch++) {
-		for (int g = j; g < QN_WORDS && !skip; g += SEED_WG) {
+		for (int g = j; g < QN_WORDS; g += SEED_WG) {
 			u32 w0 = 0, w1 = 0, wn = 0;
 			const int p0 = g << 5;
 			if (p0 < clen[ch]) stage32(q + c0[ch] + p0, p0, clen[ch], w0, w1, wn);
@@ -326,7 +323,7 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 		for (int it = j; it < nitems[ch]; it += SEED_WG) entry_of[ch * NSUB + it] = (uint16_t)(it * S[ch]);
 		if (j == 0) { s_ncand[ch] = 0; s_hits[ch] = 0; }
 	}
-	if (j == 0) { s_queue = 0; s_npend = 0; s_abort = skip ? 1 : 0; }
+	if (j == 0) { s_queue = 0; s_npend = 0; s_abort = 0; }
 	if (j < (NV + 31) / 32) rewalked[j] = 0;
 	u32 all_blocks = 0, rounds = 0, iters = 0;
 #ifdef SEED_STATS
@@ -704,35 +701,6 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 #ifndef SEED_NCH
 #define SEED_NCH 1              // chunks per wave of the production kernel (2: measured slower, see seed_chunk; the accounting build: always 1)
 #endif
-// Pre-classifier of repeat-heavy chunks (round 6).  A search is only ever REJECTED for its frequency (bwt_search.cpp:177-182: freq > MaxSeedFreq, next start + 1 --
-// the regime that makes the speculative walk of a chunk take thousands of dependent searches) when the first kmer_k bases of its match already occur more than
-// MaxSeedFreq times: the k-mer jump table holds exactly that count (x2 of the entry).  One wave per chunk looks 192 evenly spaced start positions up (three
-// random reads per lane) and flags the chunk when at least `thresh` of them are over the limit; k_seed_wg hands a flagged chunk straight to the dense kernels.
-// The flag only chooses between two EXACT algorithms for the chunk, so results do not depend on it; it is switched on by the contig in front (stage1_seed).
-#define PRE_SAMPLES 192
-__global__ void __launch_bounds__(256) k_chunk_preclass(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, u32 n_chunks, int thresh, uint8_t *__restrict__ flag)
-{
-	const u32 chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63;
-	if (chunk >= n_chunks) return;
-	const i64 c0 = (i64)chunk * GSA_CHUNK;
-	const int clen = (int)((i64)qlen - c0 < GSA_CHUNK ? (i64)qlen - c0 : GSA_CHUNK);
-	const int k = di.kmer_k, step = GSA_CHUNK / PRE_SAMPLES;
-	int over = 0;
-#pragma unroll
-	for (int rnd = 0; rnd < PRE_SAMPLES / 64; rnd++) {
-		const int p = (rnd * 64 + lane) * step;
-		bool ok = p + k <= clen;
-		u32 kid = 0;
-		if (ok) for (int t = 0; t < k; t++) { const int code = gsa_nt4(q[c0 + p + t]); ok = ok && code < 4; kid |= (u32)(code & 3) << (2 * t); }
-		u64 x2 = 0;
-		if (ok) x2 = di.kmer_e16 ? (u64)((const uint4 *)di.kmer)[kid].z : di.kmer[((size_t)kid << 2) + 2];
-		over += (ok && x2 > (u64)GSA_MAX_SEED_FREQ) ? 1 : 0;
-	}
-	for (int o = 32; o; o >>= 1) over += __shfl_down(over, o);
-	if (lane == 0) flag[chunk] = over >= thresh ? 1 : 0;
-}
-
 // Round 6: a workgroup is SEED_WPW INDEPENDENT waves -- each draws its own tickets and owns its own SeedLds -- and the LDS a workgroup asks for is more than half a
 // CU's (SEED_WG_LDS > 80 KB), so exactly ONE workgroup fits a CU: a launch of n_cus workgroups lands on every CU (the dispatcher fills a CU before it moves on:
 // with one-wave workgroups a short grid meant FEWER CUs, not thinner ones) with SEED_WPW chunks in flight per CU, and what is left of the CU's LDS (160 KB -
@@ -744,7 +712,7 @@ __global__ void __launch_bounds__(256) k_chunk_preclass(DevIndex di, const uint8
 template <bool COUNT, bool E16>
 __global__ void __launch_bounds__(SEED_WG * (COUNT ? 1 : SEED_WPW), (COUNT || SEED_WPW > 1) ? 1 : SEED_MIN_WAVES) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
-                                                      u32 budget, u32 *heavy_list, i32 *chunk_base, u64 tk_base, u32 n_chunks, const uint8_t *__restrict__ pre)
+                                                      u32 budget, u32 *heavy_list, i32 *chunk_base, u64 tk_base, u32 n_chunks)
 {
 	constexpr int NCH = COUNT ? 1 : SEED_NCH;
 	constexpr int WPW = COUNT ? 1 : SEED_WPW;
@@ -759,7 +727,7 @@ __global__ void __launch_bounds__(SEED_WG * (COUNT ? 1 : SEED_WPW), (COUNT || SE
 		if ((threadIdx.x & 63) == 0) unit = (u32)(atomicAdd((unsigned long long *)&cnt[SEED_TICKET], 1ull) - tk_base);
 		unit = (u32)__builtin_amdgcn_readfirstlane((int)unit);
 		if ((u64)unit * NCH >= n_chunks) return;
-		seed_chunk<COUNT, E16, NCH, WPW>(di, q, qlen, prm, cnt, cand_s, cand_len, cand_x0, cand_freq, cand_cap, cand_cnt, onpath, chunk_hits, hcnt, budget, heavy_list, chunk_base, (int)(unit * NCH), n_chunks, L, pre);
+		seed_chunk<COUNT, E16, NCH, WPW>(di, q, qlen, prm, cnt, cand_s, cand_len, cand_x0, cand_freq, cand_cap, cand_cnt, onpath, chunk_hits, hcnt, budget, heavy_list, chunk_base, (int)(unit * NCH), n_chunks, L);
 	}
 }
 
@@ -1948,17 +1916,9 @@ int stage1_seed(gsa_ctx *c)
 				if (cap < (i64)grid) grid = (unsigned)cap;
 			}
 			const u64 tk_base = c->seed_ticket; c->seed_ticket += (u64)n_units + (u64)grid * (u64)wpw;      // (every wave's last draw is the one that fails)
-			// repeat-heavy chunks flagged in front of the speculative kernel (k_chunk_preclass) when the contig before this one handed more than 2 % of its chunks over
-			// (option seed_preclass: 0 never, 1 by the previous contig, 2 always); the accounting build takes no shortcut
-			const uint8_t *pre = nullptr;
-			if (!c->count_blocks && c->di.kmer && c->di.kmer_k >= 8 && (c->opt.seed_preclass == 2 || (c->opt.seed_preclass == 1 && c->seed_pre_next))) {
-				if (!dev_ensure<uint8_t>(c, c->d_preheavy, (size_t)n_chunks + 8)) return GSA_ERR_NOMEM;
-				hipLaunchKernelGGL(k_chunk_preclass, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, st, c->di, d_q, qlen, (u32)n_chunks, c->opt.seed_preclass_min, c->d_preheavy.as<uint8_t>());
-				pre = c->d_preheavy.as<uint8_t>();
-			}
-			if (c->count_blocks) hipLaunchKernelGGL((k_seed_wg<true, false>), dim3(grid), dim3(SEED_WG), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks, pre);
-			else if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3(grid), dim3(SEED_WG * SEED_WPW), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks, pre);
-			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3(grid), dim3(SEED_WG * SEED_WPW), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks, pre);
+			if (c->count_blocks) hipLaunchKernelGGL((k_seed_wg<true, false>), dim3(grid), dim3(SEED_WG), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
+			else if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3(grid), dim3(SEED_WG * SEED_WPW), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
+			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3(grid), dim3(SEED_WG * SEED_WPW), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
 #undef GSA_SEED_ARGS
 			if (c->profiling || c->prof_seed) hipEventRecord(c->ev[1], st);
 			// (the counters are in pinned memory when the seed kernel is done; the host waits for that, not for the scan of the
@@ -1968,13 +1928,10 @@ int stage1_seed(gsa_ctx *c)
 			hits = c->h_cnt[CNT_HITS]; maxcand = c->h_cnt[CNT_CAND]; n_heavy = c->h_cnt[CNT_HEAVY]; occ_all = c->h_cnt[CNT_OCCBLK_ALL];
 			c->dbg[0] = c->h_cnt[11]; c->dbg[1] = n_heavy; c->dbg[2] = c->h_cnt[13]; c->dbg[3] = c->h_cnt[14]; c->dbg[4] = c->h_cnt[15]; c->dbg[5] = c->h_cnt[7];
 			c->counters[0] = c->h_cnt[CNT_OCCBLK];
-			c->seed_pre_next = n_heavy * 50 > (u64)n_chunks;      // (more than 2 % of the chunks handed over: the next contig is classified first)
 			if (seed_mode == 1) {
 				// re-decided by every contig that goes through the speculative kernel.  A look that only confirms the sweep doubles the distance to
 				// the next one (8, 16, 32, 64 contigs: the speculative attempt costs a repeat-rich 250 Mb contig 4.9 ms on top of its 12)
-				// (with the pre-classifier on, the attempt no longer pays for the chunks it hands over: it stays worth making for whatever is left -- the speculative
-				//  kernel is four times the sweep's speed on ordinary chunks -- until nearly every chunk is flagged)
-				c->seed_sweep_next = pre ? n_heavy * 10 > (u64)n_chunks * 9 : n_heavy * 5 > (u64)n_chunks * 2;
+				c->seed_sweep_next = n_heavy * 5 > (u64)n_chunks * 2;
 				c->seed_sweep_period = (c->seed_sweep_next && c->seed_sweep_probe) ? (c->seed_sweep_period < 64 ? c->seed_sweep_period * 2 : 64) : 8;
 				c->seed_sweep_probe = false;
 			}

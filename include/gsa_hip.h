@@ -172,10 +172,6 @@ void gsa_release_reserved(int device);
  *                    10 000-bp chunk): 1 (default) = through a byte per value, plain stores, packed into the bitmap by a pass of its own, when there are at least
  *                    512 hits per chunk, at most 256 values per hit and at most 2^32 values (2 GB per context for a 64 Mb bundle against a 12 Mb reference); 0 = always with atomics
  *                    on the bitmap; 2 = always through the bytes (tests).  Results do not depend on it
- *   "seed_preclass"  repeat-heavy chunks are flagged IN FRONT of the speculative seed kernel (192 sampled start positions per chunk looked up in the k-mer table: a search can
- *                    only be rejected for its frequency, bwt_search.cpp:177-182, when its first k bases already occur more than MaxSeedFreq times) and go straight to the
- *                    dense kernels instead of burning the speculative budget first: 0 never, 1 (default) when the contig before handed over more than 2 % of its chunks,
- *                    2 always (tests).  "seed_preclass_min": sampled starts over the limit that flag a chunk (2).  Results do not depend on either
  *   "dp_safe", "dp_fake_timeout"   test hooks: one striped DP job per launch; the next n contigs report a stripe hand-off time-out once
  * Unknown names and values outside an option's range (negative sizes, seed_budget 0, ...): GSA_ERR_ARG, nothing changed.
  * Until round 4 some of these were environment variables read by the library (GSA_SPLIT_MIN, GSA_BUNDLE_CONTIG, GSA_BUNDLE_CAP, GSA_SEED_BUDGET,
