@@ -215,7 +215,7 @@ class Aligner:
 
     # gsa_set_option names a test / tool may also give through the environment (GSA_<NAME>): the LIBRARY reads no environment variable,
     # this Python layer does and passes the values on
-    ENV_OPTIONS = ("split_min", "bundle_contig", "bundle_cap", "seed_budget", "dp_lane", "seed_mode", "pd_bitmap", "walk_chain_min", "pd_two_level_min", "pres_from_kmer", "pd_bytes", "dp_occupancy", "sweep_shape", "dp_side", "dp_safe", "dp_fake_timeout")
+    ENV_OPTIONS = ("split_min", "bundle_contig", "bundle_cap", "seed_budget", "dp_lane", "seed_mode", "pd_bitmap", "walk_chain_min", "pd_two_level_min", "pres_from_kmer", "pd_bytes", "dp_occupancy", "sweep_shape", "dp_side", "dp_small_side", "dp_safe", "dp_fake_timeout")
 
     def _options_from_env(self):
         for name in self.ENV_OPTIONS:

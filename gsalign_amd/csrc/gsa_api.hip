@@ -491,6 +491,7 @@ int gsa_set_option(gsa_ctx *c, const char *name, int64_t value)
 	else if (k == "seed_mode") { if (value < 0 || value > 2) return gsa_fail(c, GSA_ERR_ARG, "seed_mode: 0 sweep, 1 speculative, 2 search"); c->opt.seed_mode = (int)value; }
 	else if (k == "pd_bitmap") c->opt.pd_bitmap = value != 0;
 	else if (k == "dp_side") c->opt.dp_side = value != 0;
+	else if (k == "dp_small_side") c->opt.dp_small_side = value != 0;
 	else if (k == "pd_two_level_min") { if (!in(0, BIG)) return gsa_fail(c, GSA_ERR_ARG, "pd_two_level_min: >= 0 blocks"); c->opt.pd_two_level_min = value; }
 	else if (k == "dp_occupancy") { if (!in(0, 16)) return gsa_fail(c, GSA_ERR_ARG, "dp_occupancy: 0 (off) .. 16 workgroups per CU"); c->opt.dp_occupancy = (int)value; }
 	else if (k == "pd_bytes") { if (!in(0, 2)) return gsa_fail(c, GSA_ERR_ARG, "pd_bytes: 0 never, 1 by the hit count, 2 always"); c->opt.pd_bytes = (int)value; }

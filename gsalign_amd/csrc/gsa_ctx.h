@@ -79,6 +79,7 @@ struct Options {
 	int seed_mode = 1;                 // 0 sweep: every chunk through k_dense_sweep; 1: the speculative kernel + dense kernels for what it gives up on; 2: round 2's k_dense_search in place of the sweep
 	int pd_bitmap = 1;                 // 0: groups by the PosDiff sort although MaxIndelSize <= 31 would allow the bitmap scan
 	int sweep_shape = -1;              // k_dense_sweep's launch shape: -1 by the number of dense chunks, 0 = four chunks per two-wave workgroup / 160-start segments, 1 = one chunk per four-wave workgroup / 40-start segments
+	int dp_small_side = 0;             // 1: k_dp_small on a stream of its own (stream_aux[3]) so that the late striped launch starts beside it instead of behind it on the caller's stream (experiment; results do not depend on it)
 	int dp_side = 0;                   // 1: the striped DP's lower size class on a stream of its own, beside the upper class (0: behind it)
 	int64_t walk_chain_min = 100000;   // contigs with more seeds than this walk their window chain in slices (k_walk_chain) instead of one workgroup's LDS (k_walk_windows); tests: 0
 	int64_t pd_two_level_min = 2000000;   // PosDiff bitmaps of more blocks than this (a reference above ~1 Gbp) are scanned in two passes: list the touched blocks, count those (tests: 0)

@@ -994,7 +994,11 @@ int run_ksw2_jobs(gsa_ctx *c, i32 n_ub, const uint8_t *pool1, const i64 *off1, c
 			hipLaunchKernelGGL(k_dp_lane, dim3(nwg), dim3(256), 0, c->stream_aux[1], ntiny, d_order_tiny, 0, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag, arena, kstride);
 		}
 		if (nsmall > 0) {
-			hipStream_t s2 = ntiny > 0 ? st : c->stream_aux[1];
+			// (option dp_small_side: the one-per-wavefront kernel on a stream of its own instead of the caller's -- the late striped launch below then starts beside it
+			//  instead of behind it; with 16 hardware queues a fifth stream per context no longer shares one)
+			const bool own = c->opt.dp_small_side && c->stream_aux[3] && ntiny > 0;
+			hipStream_t s2 = own ? c->stream_aux[3] : (ntiny > 0 ? st : c->stream_aux[1]);
+			if (own) GSA_CHECK(c, hipStreamWaitEvent(s2, ev_fork, 0));
 			const unsigned nb = (unsigned)((nsmall + SMALL_WAVES - 1) / SMALL_WAVES);
 			hipLaunchKernelGGL(k_dp_small, dim3(nb), dim3(64 * SMALL_WAVES), 0, s2, nsmall, d_order, pool1, off1, len1, pool2, off2, len2, ops, ops_off, ops_len, jfrag, frag);
 			if (ntiny > 0) { GSA_CHECK(c, hipEventRecord(c->ev[18], s2)); GSA_CHECK(c, hipStreamWaitEvent(c->stream_aux[1], c->ev[18], 0)); }
