@@ -185,7 +185,9 @@ __global__ void __launch_bounds__(64 * TINY_WAVES) k_dp_tiny(i32 n_jobs, const i
 #define LANE_TILE 512
 #define LANE_BINS 128
 #define LANE_KMAX 576           // direction dwords of one job at most: m * ceil(n / 8) with n <= 64, m + n - 1 <= 128 (n = 57, m = 72)
+#ifndef LANE_WGS
 #define LANE_WGS 1024           // persistent workgroups (four per CU: 38 KB of LDS each)
+#endif
 #define LANE_LDS_WAVE 8448      // 64 columns x 64 lanes x 2 bytes (forward)  |  (128 + 2) op bytes x 64 lanes (traceback)
 __device__ __forceinline__ u32 lane_bin(u32 cells)      // floor(8 log2 cells): 1 <= cells < 8192 -> 0 .. 103
 {

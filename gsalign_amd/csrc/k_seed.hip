@@ -161,9 +161,8 @@ __device__ __forceinline__ void wave_exscan_hits(const i32 *hits, i32 *base, int
 // 18.7 KB -> 15.7 KB = ten workgroups per CU instead of eight.  Lanes set different nibbles of one word at the same time
 // (atomic OR); a position is only ever given ONE value (next(s) is a function of s), so setting it twice is harmless.
 #ifndef SEED_MIN_WAVES
-#define SEED_MIN_WAVES 3        // waves per SIMD the register allocation must allow: the LDS admits ten one-wave workgroups per CU (2.5 per SIMD), the loop wants
-                                // ~120 VGPRs.  (Two waves per chunk: 4; 5 needed 96 VGPRs -- 16 dwords of scratch in the loop, 4.87 against 4.32 ms.  The
-                                // kernel's time does not depend on its occupancy between 5 and 10 chunks per CU: profiles/archive/r03_seed_shape_sweep.txt)
+#define SEED_MIN_WAVES 5        // waves per SIMD the register allocation must allow: 5 = 96 VGPRs (37 of them spilled into 152 bytes of scratch; the loop wants ~150).  Round 6: what the
+                                // kernel leaves FREE on a CU is worth more than what the spills cost it -- see k_seed_wg.  (3 until round 6: 149 VGPRs, no scratch.)
 #endif
 #ifndef LHOP_N
 #define LHOP_N 1024
@@ -701,26 +700,37 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 #ifndef SEED_NCH
 #define SEED_NCH 1              // chunks per wave of the production kernel (2: measured slower, see seed_chunk; the accounting build: always 1)
 #endif
-// Round 6: a workgroup is SEED_WPW INDEPENDENT waves -- each draws its own tickets and owns its own SeedLds -- and the LDS a workgroup asks for is more than half a
-// CU's (SEED_WG_LDS > 80 KB), so exactly ONE workgroup fits a CU: a launch of n_cus workgroups lands on every CU (the dispatcher fills a CU before it moves on:
-// with one-wave workgroups a short grid meant FEWER CUs, not thinner ones) with SEED_WPW chunks in flight per CU, and what is left of the CU's LDS (160 KB -
-// SEED_WG_LDS) stays free for the other contexts' kernels -- the striped DP above all, which could not share a CU with twelve one-wave seed workgroups.
+// Round 6 -- THE KERNEL'S FOOTPRINT ON A CU.  Until round 5 twelve one-wave workgroups sat on every CU the kernel held: 154 KB of its 160 KB of LDS and 89 % of its
+// vector registers (3 waves per SIMD x 152), for a kernel that issues VALU in 20 % of its cycles and waits for memory in 54 %.  Nothing else fitted beside it -- not a
+// striped-DP workgroup (13 - 55 KB of LDS, 48 VGPRs), not a fused pass (four waves of ~100 VGPRs) -- so with four contexts in flight the CUs were handed back and forth
+// between kernels that each use a fraction of them, and the step was the SUM of the stages (52 + 46 ms of the 98).  Now:
+//  * a workgroup is SEED_WPW = 8 INDEPENDENT waves, each with its own SeedLds and its own tickets, and asks for more than half a CU's LDS (102 KB), so exactly ONE
+//    workgroup fits a CU and a launch of n_cus workgroups lands on EVERY CU (the dispatcher fills a CU before it moves on: a short grid of one-wave workgroups meant
+//    fewer CUs, not thinner ones);
+//  * the register budget is 96 VGPRs per wave (SEED_MIN_WAVES = 5; the LDS is a launch parameter because with static LDS the compiler knows that the LDS holds the kernel
+//    at three waves per SIMD and spends the registers that leaves, whatever the launch bound says: 149).
+// A CU that runs the seed kernel keeps 58 KB of LDS and ~320 VGPRs per SIMD lane free: a top-class DP workgroup, or four low-class ones, or the fused passes of the other
+// contexts run BESIDE it and issue while its waves wait.  Measured (profiles/r06_seed_footprint.txt, four contexts, human index): the seed stage ALONE 52 -> 60 ms (eight
+// chunks per CU instead of twelve, spills), the STEP 98.7 -> 93.1 ms; 250 Mb contigs 35.7 -> 38.2 Gbp/s.  Either half alone does nothing: 8 waves at 155 VGPRs 98.7 ms,
+// 12 one-wave workgroups at 96 VGPRs 97.9 ms.
 #ifndef SEED_WPW
-#define SEED_WPW 1              // waves (= chunks in flight) per workgroup.  1 = twelve one-wave workgroups per CU (SEED_PERSIST), the production shape; > 1: ONE workgroup of that many independent waves per CU (measured: profiles/r06_seed_wpw.txt)
+#define SEED_WPW 8              // waves (= chunks in flight) per workgroup = per CU (7 / 9 / 10: 96.9 / 95.2 / 94.7 ms; 1 = round 5's twelve one-wave workgroups per CU, an A/B build)
 #endif
-#define SEED_WG_LDS_MIN (82 * 1024)      // more than half of the 160 KB: two such workgroups never share a CU
+#ifndef SEED_WGS_PER_CU
+#define SEED_WGS_PER_CU 1       // fat workgroups per CU (the LDS a workgroup asks for is more than 160 KB / (SEED_WGS_PER_CU + 1): one more never fits)
+#endif
+#define SEED_WG_LDS_MIN ((160 * 1024) / (SEED_WGS_PER_CU + 1) + 2048)
+#define SEED_LB_WAVES(COUNT_) ((COUNT_) ? 1 : SEED_MIN_WAVES)
 template <bool COUNT, bool E16>
-__global__ void __launch_bounds__(SEED_WG * (COUNT ? 1 : SEED_WPW), (COUNT || SEED_WPW > 1) ? 1 : SEED_MIN_WAVES) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
+__global__ void __launch_bounds__(SEED_WG * (COUNT ? 1 : SEED_WPW), SEED_LB_WAVES(COUNT)) k_seed_wg(DevIndex di, const uint8_t *__restrict__ q, i32 qlen, Params prm, u64 *cnt,
                                                       i32 *cand_s, i32 *cand_len, u64 *cand_x0, i32 *cand_freq, u32 cand_cap, u32 *cand_cnt, u32 *onpath, i32 *chunk_hits, u64 *hcnt,
                                                       u32 budget, u32 *heavy_list, i32 *chunk_base, u64 tk_base, u32 n_chunks)
 {
 	constexpr int NCH = COUNT ? 1 : SEED_NCH;
 	constexpr int WPW = COUNT ? 1 : SEED_WPW;
 	typedef SeedLds<COUNT, NCH> Lds;
-	constexpr size_t need = sizeof(Lds) * WPW, pad = (WPW > 1 && need < SEED_WG_LDS_MIN) ? SEED_WG_LDS_MIN - need : 0;
-	__shared__ Lds lds[WPW];
-	__shared__ u32 s_pad[pad / 4 + 1];
-	if (pad && threadIdx.x == 0 && n_chunks == 0xffffffffu) s_pad[cnt[0] & 1] = 1;      // (keeps the padding allocated: never true)
+	extern __shared__ __attribute__((aligned(16))) unsigned char seed_dyn_lds[];      // (a launch parameter: see the kernel's header)
+	Lds *lds = (Lds *)seed_dyn_lds;
 	Lds &L = lds[WPW == 1 ? 0 : (threadIdx.x >> 6)];
 	for (;;) {
 		u32 unit = 0;
@@ -1912,13 +1922,15 @@ int stage1_seed(gsa_ctx *c)
 			unsigned grid = (unsigned)((n_units + wpw - 1) / wpw);
 			if (!c->count_blocks) {
 				if (c->n_cus <= 0) { hipDeviceProp_t pr; GSA_CHECK(c, hipGetDeviceProperties(&pr, c->device)); c->n_cus = pr.multiProcessorCount; }
-				const i64 cap = (i64)c->n_cus * (SEED_WPW > 1 ? 1 : SEED_PERSIST);      // (SEED_WPW = 1: round 5's twelve one-wave workgroups per CU, kept for A/B builds)
+				const i64 cap = (i64)c->n_cus * (SEED_WPW > 1 ? SEED_WGS_PER_CU : SEED_PERSIST);      // (SEED_WPW = 1: round 5's twelve one-wave workgroups per CU, kept for A/B builds)
 				if (cap < (i64)grid) grid = (unsigned)cap;
 			}
 			const u64 tk_base = c->seed_ticket; c->seed_ticket += (u64)n_units + (u64)grid * (u64)wpw;      // (every wave's last draw is the one that fails)
-			if (c->count_blocks) hipLaunchKernelGGL((k_seed_wg<true, false>), dim3(grid), dim3(SEED_WG), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
-			else if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3(grid), dim3(SEED_WG * SEED_WPW), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
-			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3(grid), dim3(SEED_WG * SEED_WPW), 0, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
+			const size_t dl_count = sizeof(SeedLds<true, 1>);
+			size_t dl = sizeof(SeedLds<false, SEED_NCH>) * SEED_WPW; if (SEED_WPW > 1 && dl < SEED_WG_LDS_MIN) dl = SEED_WG_LDS_MIN;      // (more than half a CU's LDS: two fat workgroups never share a CU)
+			if (c->count_blocks) hipLaunchKernelGGL((k_seed_wg<true, false>), dim3(grid), dim3(SEED_WG), dl_count, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
+			else if (c->di.kmer_e16) hipLaunchKernelGGL((k_seed_wg<false, true>), dim3(grid), dim3(SEED_WG * SEED_WPW), dl, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
+			else hipLaunchKernelGGL((k_seed_wg<false, false>), dim3(grid), dim3(SEED_WG * SEED_WPW), dl, st, GSA_SEED_ARGS, tk_base, (u32)n_chunks);
 #undef GSA_SEED_ARGS
 			if (c->profiling || c->prof_seed) hipEventRecord(c->ev[1], st);
 			// (the counters are in pinned memory when the seed kernel is done; the host waits for that, not for the scan of the
