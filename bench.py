@@ -51,16 +51,17 @@ YEAST_KB = [230, 813, 317, 1532, 577, 270, 1091, 563, 440, 746, 667, 1078, 924, 
 GRCH38_MB = [248, 242, 198, 190, 181, 170, 159, 145, 138, 133, 135, 133, 114, 107, 101, 90, 83, 80, 58, 64, 46, 50, 156, 57]      # chr1..22, X, Y
 
 WORKLOADS = {
-    # name: genome length(s), divergence, repeat injection, aligner parameters, distinct query genomes
-    "human": dict(lengths=[250_000_000], div=0.01, repeats=True, params={}, n_query=4, inflight=4, steps=160,
+    # name: genome length(s), divergence, repeat injection, aligner parameters, distinct query genomes, contexts in flight per GPU (round 6: since the seed kernel leaves room on the CUs it
+    # holds, eight contexts beat four on the unique-text workloads -- 92.4 against 94.5 ms per human genome, 39.8 against 37.8 Gbp/s on 250 Mb contigs -- and lose on the repeat-rich ones)
+    "human": dict(lengths=[250_000_000], div=0.01, repeats=True, params={}, n_query=4, inflight=8, steps=160,
                   label="human-chr1-sized pair (BASELINE configs[3] on one GPU): 250 Mb reference with repeat injection (300-bp family over 10 %, 150-copy tandem) vs 1 %-diverged query, defaults"),
     "ecoli": dict(lengths=[5_000_000], div=0.02, repeats=False, params={}, n_query=4, inflight=2, steps=200,
                   label="E. coli-sized pair (BASELINE configs[1] stand-in): 5 Mb reference vs 2 %-diverged query, default -slen 15 -ind 25"),
-    "yeast": dict(lengths=[1000 * k for k in YEAST_KB], div=0.02, repeats=False, params=dict(sen=1, clr=50), n_query=2, inflight=3, steps=60,
+    "yeast": dict(lengths=[1000 * k for k in YEAST_KB], div=0.02, repeats=False, params=dict(sen=1, clr=50), n_query=2, inflight=6, steps=60,
                   label="S. cerevisiae-sized pair (BASELINE configs[2]): 16 contigs / 12 Mb vs 2 %-diverged copy, -sen"),
     # BASELINE configs[4]: the whole job of the 8-GPU configuration (the index is replicated per GPU there, so one GPU
     # holds exactly this index).  6.2 G BWT rows: the >= 2^32-row device layout and the 64-bit suffix sorter on their real input.
-    "human_full": dict(lengths=[1_000_000 * m for m in GRCH38_MB], div=0.01, repeats=True, params=dict(alen=5000), n_query=2, inflight=4, steps=10,
+    "human_full": dict(lengths=[1_000_000 * m for m in GRCH38_MB], div=0.01, repeats=True, params=dict(alen=5000), n_query=2, inflight=8, steps=10,
                        label="full-human-sized pair (BASELINE configs[4]): 24 contigs with GRCh38 chromosome lengths, 3.08 Gbp, repeat injection, vs 1 %-diverged copy, -alen 5000"),
     # not a BASELINE config: the repeat regime of real (T2T) sequence -- csrc/host/synth.cpp: eight families with a copy-number spectrum up
     # to 10^5 copies at 1-15 % divergence over 25 % of the sequence, microsatellites, two Mb-long N runs, soft-masked blocks

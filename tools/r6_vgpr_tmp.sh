@@ -13,7 +13,19 @@ except Exception as e:
     print("run $1 FAILED", e); print(open("gpurun_out/r6v_$1.err").read()[-800:])
 P
 }
-F="--steps 10 --warmup 2"
-for v in - lw512 lw768 -; do run full_$v human_full $v GSA_X=0 "$F"; done
-( time timeout 1200 python bench.py ) > gpurun_out/r6v_bench_default.txt 2> gpurun_out/r6v_bench_default.err; tail -c 1500 gpurun_out/r6v_bench_default.txt; cp gpurun_out/bench_detail.json gpurun_out/r6v_bench_default_detail.json
-( time timeout 1700 python -m pytest tests -m gpu -x -q --durations=5 ) > gpurun_out/r6v_gputest_full.txt 2>&1; tail -14 gpurun_out/r6v_gputest_full.txt
+F="--steps 20 --warmup 4"
+run warm human_full - GSA_X=0 "$F"
+for rep in 1 2; do
+  run full_ctx4_$rep human_full - GSA_X=0 "$F"
+  run full_ctx6_$rep human_full - GSA_X=0 "$F --inflight 6"
+  run full_ctx8_$rep human_full - GSA_X=0 "$F --inflight 8"
+  run full_ctx7_$rep human_full - GSA_X=0 "$F --inflight 7"
+done
+run hum_ctx4 human - GSA_X=0 ""
+run hum_ctx6 human - GSA_X=0 "--inflight 6"
+run hum_ctx8 human - GSA_X=0 "--inflight 8"
+run hl_ctx4 human_like - GSA_X=0 ""
+run hl_ctx6 human_like - GSA_X=0 "--inflight 6"
+run adv_ctx6 adversarial - GSA_X=0 "--inflight 6"
+run yeast_ctx3 yeast - GSA_X=0 ""
+run yeast_ctx6 yeast - GSA_X=0 "--inflight 6"
