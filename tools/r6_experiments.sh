@@ -8,6 +8,8 @@
 #   budget     the speculative seed kernel's give-up budget 256 .. 48 on the repeat workloads; SEED_NCH=2 (variant nch2) on the human index
 #   dplane     per-lane DP class boundary 512 .. 8192 cells
 #   dpsmall    k_dp_small on a stream of its own (option dp_small_side), with and without dp_side
+#   footprint  the seed kernel's footprint on a CU: waves per CU x register bound (variants built with -DSEED_WPW=<n> -DSEED_MIN_WAVES=<b> [-DLHOP_N=512]; "r5" = -DSEED_WPW=1 -DSEED_MIN_WAVES=3)
+#   contexts   3 .. 8 contexts in flight behind the adopted footprint
 ulimit -c 0      # (a faulting experiment must not fill the box's disk with a core dump: the third call of the round did)
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 export GSA_BENCH_KEEP=1 GSA_BENCH_TMP=/tmp/gb; mkdir -p $GSA_BENCH_TMP
@@ -36,5 +38,8 @@ case "${1:-}" in
            for v in 512 2048 8192; do run hum_lane$v human - GSA_DP_LANE=$v ""; done ;;
   dpsmall) run full_base human_full - GSA_X=0 "$F"; run full_ss human_full - GSA_DP_SMALL_SIDE=1 "$F"; run full_ss_ds human_full - "GSA_DP_SMALL_SIDE=1 GSA_DP_SIDE=1" "$F"
            run hum_base human - GSA_X=0 ""; run hum_ss human - GSA_DP_SMALL_SIDE=1 ""; run hum_ss_ds human - "GSA_DP_SMALL_SIDE=1 GSA_DP_SIDE=1" "" ;;
-  *) echo "usage: r6_experiments.sh wpw|passes|hwq|budget|dplane|dpsmall" ;;
+  footprint) for v in r5 - w8b4 w10b5 w9b5 w7b5 w6b5 w8b5lh; do run full_$v human_full $v GSA_X=0 "$F"; done; for v in r5 -; do run hum_$v human $v GSA_X=0 ""; done ;;
+  contexts) for n in 3 4 5 6 7 8; do run full_ctx$n human_full - GSA_X=0 "--steps 20 --warmup 4 --inflight $n"; done
+           for n in 4 6 8; do run hum_ctx$n human - GSA_X=0 "--inflight $n"; done; run hl_ctx6 human_like - GSA_X=0 "--inflight 6"; run yeast_ctx6 yeast - GSA_X=0 "--inflight 6" ;;
+  *) echo "usage: r6_experiments.sh wpw|passes|hwq|budget|dplane|dpsmall|footprint|contexts" ;;
 esac
