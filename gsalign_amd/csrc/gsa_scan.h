@@ -106,6 +106,9 @@ __device__ __forceinline__ void lb_tile_prefix(const LbArgs &lb, int tile, const
 		i32 excl[NV]; bool fin[NV];                                   // (fin: wave-uniform)
 #pragma unroll
 		for (int c = 0; c < NV; c++) { excl[c] = 0; fin[c] = false; }
+#ifndef LB_WAIT_TICKS
+#define LB_WAIT_TICKS 500000000ull      // 5 s of the 100 MHz wall clock: the bound of a look-back wait (a bug, not a state, when it trips)
+#endif
 #ifndef LB_WIN
 #define LB_WIN 64      // (experiment: predecessors looked at per round trip)
 #endif
@@ -113,7 +116,7 @@ __device__ __forceinline__ void lb_tile_prefix(const LbArgs &lb, int tile, const
 			const int idx = base - lane;
 			unsigned long long w[NV];
 			int first[NV];
-			u32 spins = 0;
+			u32 spins = 0; unsigned long long t_spin0 = 0;
 			for (;;) {
 				bool settled = true;
 #pragma unroll
@@ -134,7 +137,9 @@ __device__ __forceinline__ void lb_tile_prefix(const LbArgs &lb, int tile, const
 					if (nr & need) settled = false;
 				}
 				if (settled) break;
-				if (++spins > (1u << 22)) {
+				// (the bound is wall-clock time -- LB_WAIT_TICKS of the 100 MHz clock = 5 s -- not a number of looks: a predecessor is always a tile that RUNS, but since round 6 kernels of
+				//  up to eight contexts share a CU and a running wave can be kept from issuing for a long time; a count of 2^22 looks was ~0.8 s and tripped once in ~60 runs of ten contexts)
+				if ((++spins & 1023u) == 0 && (t_spin0 == 0 ? (t_spin0 = wall_clock64(), false) : wall_clock64() - t_spin0 > LB_WAIT_TICKS)) {
 					if (lane == 0) *lb.err = 1;
 #pragma unroll
 					for (int c = 0; c < NV; c++) { w[c] = lb_pack(ep, 2, 0); first[c] = 0; }

@@ -919,11 +919,11 @@ __global__ void __launch_bounds__(WC_T) k_walk_chain(i64 na, const i32 *__restri
 		i32 e = -2;
 		if (sl == 0) e = 0;
 		else {
-			u32 spins = 0;
+			u32 spins = 0; unsigned long long t_spin0 = 0;
 			for (;;) {
 				const unsigned long long wv = __hip_atomic_load(&entry_w[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				if ((u32)(wv >> 32) == epoch) { e = (i32)(u32)wv - 2; break; }
-				if (++spins > (1u << 23)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+				if ((++spins & 1023u) == 0 && (t_spin0 == 0 ? (t_spin0 = wall_clock64(), false) : wall_clock64() - t_spin0 > LB_WAIT_TICKS)) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // (5 s of wall clock: gsa_scan.h)
 				__builtin_amdgcn_s_sleep(1);
 			}
 		}
