@@ -448,7 +448,10 @@ __global__ void __launch_bounds__(64 * WPB) k_dp_stripe(const i32 *__restrict__ 
 	}
 	__syncthreads();
 	const u32 bid = s_bid;
-	if (bid < 96) __builtin_amdgcn_s_setprio(3);
+#ifndef DP_PRIO_BLOCKS
+#define DP_PRIO_BLOCKS 96      // the first workgroups of a launch (its largest jobs: the list is sorted by cells) issue at raised priority
+#endif
+	if (bid < DP_PRIO_BLOCKS) __builtin_amdgcn_s_setprio(3);
 	// which job / pair of stripes am I (uniform).  Both tables are read where the host wrote them (pinned memory): two
 	// dependent reads across the link cost less than a copy operation in front of the launch
 	const StripeJob sj = sjobs[blk2job[bid]];

@@ -695,7 +695,7 @@ __device__ __forceinline__ void seed_chunk(const DevIndex &di, const uint8_t *__
 // workgroups' worth of LDS and wave slots whatever the contig's size (what it leaves free the kernels of other contexts can take).
 #define SEED_TICKET 16
 #ifndef SEED_PERSIST
-#define SEED_PERSIST 12        // workgroups per CU of the persistent launch: what the LDS admits (12.8 KB per chunk since the memo is two bits per position)
+#define SEED_PERSIST 12        // (A/B builds with SEED_WPW = 1 only: one-wave workgroups per CU of round 5's launch shape -- what the LDS admits at 12.8 KB per chunk)
 #endif
 #ifndef SEED_NCH
 #define SEED_NCH 1              // chunks per wave of the production kernel (2: measured slower, see seed_chunk; the accounting build: always 1)
@@ -1911,12 +1911,9 @@ int stage1_seed(gsa_ctx *c)
 		if (!dense_all) {
 #define GSA_SEED_ARGS c->di, d_q, qlen, c->prm, cnt, c->d_cand_s.as<i32>(), c->d_cand_len.as<i32>(), c->d_cand_x0.as<u64>(), c->d_cand_freq.as<i32>(), (u32)ccap, \
 			c->d_cand_cnt.as<u32>(), c->d_onpath.as<u32>(), c->d_chunk_hits.as<i32>(), c->h_cnt, budget, c->d_heavy.as<u32>(), c->d_chunk_base.as<i32>()
-			// (persistent launch: GSA_SEED_PERSIST workgroups per CU -- default 10, what the LDS admits -- draw the chunks from the ticket counter;
-			//  0 = one workgroup per chunk.  Measured on a 250 Mb contig: the kernel alone 3.40 -> 3.20 ms at 10 or 16 per CU, 3.6 / 4.2 / 4.8 / 5.7 /
-			//  7.1 / 9.9 ms at 8 / 6 / 5 / 4 / 3 / 2 (the dispatcher fills CUs one after the other, so fewer workgroups mean fewer CUs, not thinner
-			//  ones); four contexts' throughput within +- 2 % of each other from 4 per CU upwards: tools/persist.sh)
-			// (persistent launch, round 6: ONE workgroup of SEED_WPW independent waves per CU -- its LDS is more than half a CU's, so the dispatcher cannot stack two --
-			//  every wave draws chunk after chunk from the ticket counter.  A short contig: as many workgroups as its chunks fill)
+			// (persistent launch: ONE workgroup of SEED_WPW independent waves per CU -- its LDS is more than half a CU's, so the dispatcher cannot stack two -- every wave
+			//  draws chunk after chunk from the ticket counter.  A short contig: as many workgroups as its chunks fill.  Until round 5: twelve one-wave workgroups per CU;
+			//  the dispatcher fills a CU before it moves on, so a shorter grid of those meant FEWER CUs, not thinner ones: 3.6 / 4.8 / 7.1 ms at 8 / 5 / 3 per CU against 3.2 at 12)
 			const i64 n_units = c->count_blocks ? n_chunks : (n_chunks + SEED_NCH - 1) / SEED_NCH;      // (a wave of the production kernel owns SEED_NCH chunks)
 			const int wpw = c->count_blocks ? 1 : SEED_WPW;
 			unsigned grid = (unsigned)((n_units + wpw - 1) / wpw);
