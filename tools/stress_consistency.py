@@ -19,7 +19,8 @@ import types
 args = types.SimpleNamespace(fasta_ref="", fasta_query="")
 px, idx, refs = bench.build_reference(tmp, name, wl, 0, 1, args)
 contigs = [c for gq in bench.make_queries(wl, refs, args) for c in gq]
-g0 = capi.Aligner(idx, **wl["params"]); ctxs = [g0, g0.clone(), g0.clone(), g0.clone()]
+nctx = int(os.environ.get("STRESS_CTX", "4"))      # (round 6: eight, as bench.py runs the unique-text workloads)
+g0 = capi.Aligner(idx, **wl["params"]); ctxs = [g0] + [g0.clone() for _ in range(nctx - 1)]
 pinned = [g0.pinned_copy(c) for c in contigs]
 sums = {}; lock = threading.Lock(); bad = []
 
@@ -36,6 +37,6 @@ def on_result(ci, res):
     return 0
 
 capi.align_many(ctxs, pinned * rounds, on_result)
-print(f"{name}: {len(contigs)} contigs x {rounds} rounds on 4 contexts: {len(bad)} differences", sums if len(sums) < 6 else len(sums))
+print(f"{name}: {len(contigs)} contigs x {rounds} rounds on {len(ctxs)} contexts: {len(bad)} differences", sums if len(sums) < 6 else len(sums))
 for b in bad[:5]: print("  DIFF", b)
 sys.exit(1 if bad else 0)
