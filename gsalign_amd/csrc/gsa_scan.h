@@ -187,11 +187,18 @@ __device__ __forceinline__ void lb_copy_out(i32 *dst, const i32 *src, i32 n, int
 // Generic fused pass over i in [0, n):  v = op.value(i, k)  (NV components, k < NV),
 // ex = exclusive prefix sums, then op.emit(i, v, ex);  op.done(totals) once, by the thread
 // that owns the last element (or thread 0 of tile 0 when n == 0).
-template <int NV, class Op, int ITEMS>
 #ifndef LB_MIN_WAVES
 #define LB_MIN_WAVES 1      // (experiment: waves per SIMD the register allocation of a fused pass must allow -- 8: at most 64 VGPRs, 10: 48)
 #endif
-__global__ void __launch_bounds__(LB_TPB, LB_MIN_WAVES) k_lb_pass(i64 n, Op op, LbArgs lb)
+#ifdef LB_BISECT      // (diagnosis build: the register bound on ONE Op -- the one whose lb_id is LB_BISECT -- to find which pass miscomputes under it)
+template <class T, class = void> struct lb_id_of { static constexpr int value = -1; };
+template <class T> struct lb_id_of<T, std::void_t<decltype(T::lb_id)>> { static constexpr int value = T::lb_id; };
+#define LB_BOUND_OF(Op_) (lb_id_of<Op_>::value == (LB_BISECT) ? 4 : 1)
+#else
+#define LB_BOUND_OF(Op_) LB_MIN_WAVES
+#endif
+template <int NV, class Op, int ITEMS>
+__global__ void __launch_bounds__(LB_TPB, LB_BOUND_OF(Op)) k_lb_pass(i64 n, Op op, LbArgs lb)
 {
 	constexpr int LB_TILE = LB_TPB * ITEMS;
 	__shared__ i32 s_tile, s_bcast[2], s_wsum[NV][ITEMS][LB_TPB / 64];
@@ -366,6 +373,9 @@ static inline int lb_launch(gsa_ctx *c, i64 n, const Op &op, hipStream_t stream 
 	const size_t grid = std::min<size_t>(tiles, (size_t)grid_per_cu * (size_t)c->n_cus);
 	hipLaunchKernelGGL((k_lb_pass<NV, Op, ITEMS>), dim3((unsigned)grid), dim3(LB_TPB), 0, stream, n, op, lb);
 	GSA_CHECK(c, hipGetLastError());
+#ifdef LB_SYNC_DEBUG      // (diagnosis build: every fused pass is waited for, the first one that faults names itself)
+	{ const hipError_t e_ = hipStreamSynchronize(stream); if (e_ != hipSuccess) { fprintf(stderr, "[LB_SYNC_DEBUG] %s: n = %lld, tiles = %zu, grid = %zu: %s\n", __PRETTY_FUNCTION__, (long long)n, tiles, grid, hipGetErrorString(e_)); return gsa_fail(c, GSA_ERR_HIP, "fused pass failed (LB_SYNC_DEBUG)"); } }
+#endif
 	c->lb_base += (u32)(tiles + (grid < tiles ? grid : 0));      // (persistent: every workgroup's last draw is the one that fails)
 	return GSA_OK;
 }

@@ -82,7 +82,10 @@ __device__ __forceinline__ void pd_block_load(const u32 *__restrict__ bm, i64 bl
 #pragma unroll
 	for (int k = 0; k < 8; k++) { const uint4 q = p[k]; w[1 + 4 * k] = q.x; w[2 + 4 * k] = q.y; w[3 + 4 * k] = q.z; w[4 + 4 * k] = q.w; }
 }
-struct OpPdScan {      // over the BLOCKS (32 bitmap words each); a block without a hit costs a look at its coarse bit
+struct OpPdScan {
+#ifdef LB_BISECT
+	static constexpr int lb_id = 0;
+#endif      // over the BLOCKS (32 bitmap words each); a block without a hit costs a look at its coarse bit
 	const u32 *bm, *cb; int max_indel; i32 *gpre, *mail; i64 nw;
 	__device__ i32 value(i64 blk, int) const
 	{
@@ -101,6 +104,9 @@ struct OpPdScan {      // over the BLOCKS (32 bitmap words each); a block withou
 // coarse WORDS (32 blocks each: 190 000 elements) lists the touched blocks in block order (value = popcount, emit = the set bits' block numbers); (2) a pass
 // over that list counts the group starts of each touched block (one 128-byte line each, all independent) and leaves gpre[block].
 struct OpPdTouched {
+#ifdef LB_BISECT
+	static constexpr int lb_id = 1;
+#endif
 	const u32 *cb; i64 nblk; i32 *tlist, *mail;
 	__device__ i32 value(i64 w, int) const { u32 x = cb[w]; const i64 left = nblk - (w << 5); if (left < 32) x &= left <= 0 ? 0u : ((1u << left) - 1u); return __popc(x); }
 	__device__ void emit(i64 w, const i32 *v, const i32 *ex) const
@@ -113,6 +119,9 @@ struct OpPdTouched {
 	__device__ void done(const i32 *t) const { mail[M_NTOUCH] = t[0]; }
 };
 struct OpPdScanList {
+#ifdef LB_BISECT
+	static constexpr int lb_id = 2;
+#endif
 	const u32 *bm; const i32 *tlist; int max_indel; i32 *gpre, *mail;
 	struct Item { i32 blk, n; };
 	__device__ Item load(i64 j) const
@@ -175,6 +184,9 @@ __global__ void k_pd_gather(i64 n, const u64 *__restrict__ key, const u32 *__res
 // brk : unique and PosDiff differs from the previous seed (the only places where
 //       an outlier window may close, :328-331)
 struct OpUniqBrk {
+#ifdef LB_BISECT
+	static constexpr int lb_id = 3;
+#endif
 	static constexpr bool clamped = true;
 	i64 na; const i32 *a_q; const i64 *a_r; const i32 *a_gb, *a_ge;
 	i32 *uniq, *brk, *alive, *cuEx, *brkEx, *blist;
@@ -203,6 +215,9 @@ struct OpUniqBrk {
 // GSA_WIN_SEEDS unique seeds (a window needs that many to close, GSAlign.cpp:326-338).  Candidates =
 // heads and break positions of those "big" groups; ws[] starts out as the head flags.
 struct OpCand {
+#ifdef LB_BISECT
+	static constexpr int lb_id = 4;
+#endif
 	static constexpr bool clamped = true;
 	i64 na; const i32 *a_gb, *a_ge, *cuEx, *brk;
 	i32 *candf, *candEx, *clist, *ws;
@@ -382,6 +397,9 @@ __device__ __forceinline__ u32 bkt_hash(unsigned long long k, u32 cap) { return 
 
 // window id per seed = (number of starts up to and including it) - 1
 struct OpWindowBuckets {
+#ifdef LB_BISECT
+	static constexpr int lb_id = 5;
+#endif
 	static constexpr bool clamped = true;
 	i64 na; const i32 *a_q; const i64 *a_r; const i32 *uniq, *ws; i64 bmin; u32 cap;
 	i32 *wsEx, *slot_of; Bucket *tab; unsigned long long *wbest, *wsum; i32 *wn;
@@ -533,7 +551,10 @@ __global__ void k_window_avg(i64 na, const i32 *__restrict__ slot_of, const Buck
 // ---- D. multi-hit query positions (GSAlign.cpp:178-225,341-350) -------------------
 // Round 5: RemoveOutlierSeeds' verdict (GSAlign.cpp:260-296; a kernel of its own until now, k_outlier_kill) is taken where the alive unique seeds are ranked:
 // load() decides "outlier" from the window's modal bucket, mean and this seed's bucket count, emit() writes alive[] and the rank.
-struct OpAliveUnique {      // outlier verdict + ranks of the alive unique seeds
+struct OpAliveUnique {
+#ifdef LB_BISECT
+	static constexpr int lb_id = 6;
+#endif      // outlier verdict + ranks of the alive unique seeds
 	static constexpr bool clamped = true;
 	i64 na; const i32 *uniq; i32 *alive, *auEx, *aulist;
 	const i32 *slot_of; const Bucket *tab; const i32 *a_q; const i64 *a_r; const unsigned long long *wbest, *wsum; const i32 *wn; i64 G; i32 max_indel; Bundle bnd;
@@ -588,6 +609,9 @@ __device__ __forceinline__ i32 multihit_keep(i64 i, const i32 *__restrict__ a_q,
 // After the first compaction only "is my neighbour in my group" is ever asked, so the seeds
 // carry a group id (the group's old begin index) instead of group bounds.
 struct OpCompactAlive {
+#ifdef LB_BISECT
+	static constexpr int lb_id = 7;
+#endif
 	static constexpr bool clamped = true;
 	const i32 *alive, *a_q, *a_len; const i64 *a_r; const i32 *a_gb, *a_ge, *auEx, *aulist; i64 G; i32 max_indel; Bundle bnd;
 	i32 *b_q, *b_len; i64 *b_r; i32 *b_g, *mail; i64 na;
@@ -616,6 +640,9 @@ struct OpCompactAlive {
 
 // 3-point noise filter (GSAlign.cpp:355-362): pure stencil on PosDiff, then compaction #2
 struct OpNoise {
+#ifdef LB_BISECT
+	static constexpr int lb_id = 8;
+#endif
 	static constexpr bool clamped = true;
 	const i32 *b_q, *b_len; const i64 *b_r; const i32 *b_g;
 	i32 *c_q, *c_len; i64 *c_r; i32 *c_g, *mail; i64 na;
@@ -649,6 +676,9 @@ struct OpNoise {
 // block heads (GSAlign.cpp:364-374): group head, query gap > MaxSeedGap, or diagonal jump > 100
 // (second component: prefix sums of the seed lengths, 32-bit wrapping -- only differences over a block are used)
 struct OpBlockHeads {
+#ifdef LB_BISECT
+	static constexpr int lb_id = 9;
+#endif
 	static constexpr bool clamped = true;
 	i64 na; const i32 *c_q, *c_len; const i64 *c_r; const i32 *c_g;
 	i32 *bhead, *bheadEx, *bstart; u32 *ps; i32 *mail;
@@ -672,6 +702,9 @@ struct OpBlockHeads {
 
 // AddAlnBlock filter (GSAlign.cpp:29-49) over the raw blocks + the table of the kept ones
 struct OpBlockFilter {
+#ifdef LB_BISECT
+	static constexpr int lb_id = 10;
+#endif
 	static constexpr bool clamped = true;
 	i64 na; const i32 *bstart, *c_q, *c_len; const u32 *ps; Params prm;
 	i32 *bkeep, *bkeepEx, *blk_beg, *blk_end, *blk_score, *mail;
@@ -711,6 +744,9 @@ struct OpBlockFilter {
 // always cut by S4 and are not listed; what S4's similarity test or the list logic drops was computed
 // in vain.
 struct OpEarlyGaps {
+#ifdef LB_BISECT
+	static constexpr int lb_id = 11;
+#endif
 	const i32 *q, *len; const i64 *r; const i32 *head, *headEx, *bkeep, *bkeepEx; i32 *bid; const uint8_t *query, *ref;
 	// the kept block a seed belongs to (-1: its raw block was dropped by AddAlnBlock); written to bid[] by emit() for the
 	// stages behind (was a kernel of its own in front of this pass)
