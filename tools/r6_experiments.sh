@@ -10,6 +10,8 @@
 #   dpsmall    k_dp_small on a stream of its own (option dp_small_side), with and without dp_side
 #   footprint  the seed kernel's footprint on a CU: waves per CU x register bound (variants built with -DSEED_WPW=<n> -DSEED_MIN_WAVES=<b> [-DLHOP_N=512]; "r5" = -DSEED_WPW=1 -DSEED_MIN_WAVES=3)
 #   contexts   3 .. 8 contexts in flight behind the adopted footprint
+#   soak10     ten contexts six times over (30 steps each): does the look-back wait bound (5 s of wall clock) ever trip?
+#   late       the fused passes at four elements per thread (variant lbi4: -DLB_ITEMS=4, 67 - 122 VGPRs instead of 111 - 213) and ten contexts, on the final tree
 ulimit -c 0      # (a faulting experiment must not fill the box's disk with a core dump: the third call of the round did)
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 export GSA_BENCH_KEEP=1 GSA_BENCH_TMP=/tmp/gb; mkdir -p $GSA_BENCH_TMP
@@ -41,5 +43,7 @@ case "${1:-}" in
   footprint) for v in r5 - w8b4 w10b5 w9b5 w7b5 w6b5 w8b5lh; do run full_$v human_full $v GSA_X=0 "$F"; done; for v in r5 -; do run hum_$v human $v GSA_X=0 ""; done ;;
   contexts) for n in 3 4 5 6 7 8; do run full_ctx$n human_full - GSA_X=0 "--steps 20 --warmup 4 --inflight $n"; done
            for n in 4 6 8; do run hum_ctx$n human - GSA_X=0 "--inflight $n"; done; run hl_ctx6 human_like - GSA_X=0 "--inflight 6"; run yeast_ctx6 yeast - GSA_X=0 "--inflight 6" ;;
-  *) echo "usage: r6_experiments.sh wpw|passes|hwq|budget|dplane|dpsmall|footprint|contexts" ;;
+  late)    run late_base human_full - GSA_X=0 "$F"; run late_lbi4 human_full lbi4 GSA_X=0 "$F"; run late_ctx10 human_full - GSA_X=0 "$F --inflight 10"; run late_lbi4_hum human lbi4 GSA_X=0 "" ;;
+  soak10)  for i in 1 2 3 4 5 6; do run soak10_$i human_full - GSA_X=0 "--steps 30 --warmup 4 --inflight 10"; grep -il "timed out\|error" gpurun_out/r6x_soak10_$i.err; done ;;
+  *) echo "usage: r6_experiments.sh wpw|passes|hwq|budget|dplane|dpsmall|footprint|contexts|late|soak10" ;;
 esac
