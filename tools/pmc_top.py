@@ -70,7 +70,7 @@ def main():
         rd, rd32 = d.get("TCC_EA0_RDREQ_sum", 0.0), d.get("TCC_EA0_RDREQ_32B_sum", 0.0)
         rb = (rd - rd32) * 128.0 + rd32 * 32.0 if rd else d.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0
         return rb, d.get("WRITE_SIZE", 0.0) * 1024.0
-    out = {"_what": f"HBM traffic per step of bench.py --workload {W} from rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only beside it), the workload's own --inflight (4 contexts)",
+    out = {"_what": f"HBM traffic per step of bench.py --workload {W} from rocprofv3 --pmc passes (one counter set per pass, --kernel-trace only beside it), the workload's own --inflight (bench.py WORKLOADS: eight contexts on human / human_full since round 6)",
            "_method": "reads = (TCC_EA0_RDREQ - RDREQ_32B) x 128 B + RDREQ_32B x 32 B (gfx950: FETCH_SIZE tallies 128-byte requests at 64 B, MI355X_MICROARCH.md HBM section; CALIBRATED in round 4 -- profiles/archive/r04_pmc_calibration.txt: a random read of 16, 32, 64 or 128 bytes costs exactly one RDREQ, none of the 32-byte kind, and FETCH_SIZE counts it as 64 B: every L2 miss fetches one 128-byte line); writes = WRITE_SIZE KB x 1024 (uncalibrated); "
                       "Infinity-Cache hits are counted, so this is L2-miss traffic, an upper bound of HBM bytes; per step = total over the run / hot-path runs x contigs per step "
                       "(seed kernels: / runs with the production seed kernel)",
