@@ -22,9 +22,10 @@ def build() -> None:
 
 
 def load() -> C.CDLL:
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build()")
-    return C.CDLL(LIB_PATH)
+    path = os.environ.get("GSA_HOST_LIB_PATH") or LIB_PATH      # (an instrumented build of the same sources: tools/host_tsan.sh)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run __graft_entry__.build()")
+    return C.CDLL(path)
 
 
 def build_index(fasta: str, prefix: str) -> None:
