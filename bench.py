@@ -523,7 +523,8 @@ def end_to_end(px, genome, params, inflight, tmp, tag):
             os.remove(outp + ext)
         except OSError:
             pass
-    os.remove(qfa)
+    if not os.environ.get("GSA_BENCH_KEEP"):      # (tools/e2e_threads.sh runs the CLI again on the same files)
+        os.remove(qfa)
     return out
 
 
